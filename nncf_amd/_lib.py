@@ -1,0 +1,82 @@
+"""ctypes loader for libnncf_hip.so (the C ABI declared in include/nncf_hip.h).
+
+The product has no CPU fallback: if the shared library is missing, or a device entry
+point is called without a HIP device, this raises instead of degrading.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnncf_hip.so")
+
+_lib = None
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class NncfError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    vp, i32, i64, u64, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
+    lib.nncf_last_error.restype = ctypes.c_char_p
+    lib.nncf_version.restype = ctypes.c_char_p
+    lib.nncf_device_count.restype = i32
+    lib.nncf_lcg_jump.restype = u64
+    lib.nncf_lcg_jump.argtypes = [u64, u64]
+    sig = {
+        "nncf_sampler_create": [c_f64p, i64, f64, u64, i32, ctypes.POINTER(vp)],
+        "nncf_sampler_destroy": [vp],
+        "nncf_sampler_build_bounds": [c_f64p, i64, f64, c_i32p],
+        "nncf_sampler_bounds": [vp, c_i32p],
+        "nncf_sampler_sample_dev": [vp, i64, vp, vp],
+        "nncf_sampler_sample_slice_dev": [vp, i64, i64, vp, vp],
+        "nncf_sampler_skip": [vp, i64],
+        "nncf_sampler_sample_batch": [vp, i64, c_i32p, vp],
+        "nncf_sampler_get_state": [vp, c_u64p],
+        "nncf_sampler_set_state": [vp, u64],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    lib.nncf_sampler_size.restype = i64
+    lib.nncf_sampler_size.argtypes = [vp]
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NncfError(
+                "libnncf_hip.so is not built (%s). Run `make -C nncf_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+_EXC = {-1: ValueError, -2: MemoryError, -3: NncfError, -4: NncfError}
+
+
+def check(rc):
+    """Translate an nncf_status into the exception the reference's Cython shim would raise
+    (sampler.pyx:13 `except +`: bad_alloc -> MemoryError, others -> RuntimeError; buffer
+    validation -> ValueError)."""
+    if rc != 0:
+        msg = lib().nncf_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, NncfError)(msg)
+
+
+def stream_ptr(stream=None):
+    """hipStream_t of `stream` (a torch.cuda.Stream) or of torch's current stream."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream)

@@ -1,0 +1,56 @@
+// Shared host-side helpers for libnncf_hip.so (error state, HIP call checking).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nncf_hip.h"
+
+namespace nncf {
+
+// Thread-local message behind nncf_last_error().
+void set_error(const char* fmt, ...);
+int fail(int status, const char* fmt, ...);
+
+#define NNCF_HIP_CHECK(expr)                                                                    \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return ::nncf::fail(NNCF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                          __FILE__, __LINE__);                                                  \
+  } while (0)
+
+#define NNCF_REQUIRE(cond, ...)                                      \
+  do {                                                               \
+    if (!(cond)) return ::nncf::fail(NNCF_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// Affine map x -> a*x + c over Z/2^64 (one or many LCG steps composed).
+struct Affine {
+  uint64_t a, c;
+};
+__host__ __device__ inline Affine compose(Affine f, Affine g) {  // g after f
+  return Affine{g.a * f.a, g.a * f.c + g.c};
+}
+__host__ __device__ inline uint64_t apply(Affine f, uint64_t x) { return f.a * x + f.c; }
+
+constexpr uint64_t kLcgA = 25214903917ULL;  // nodesampler.cpp:24
+constexpr uint64_t kLcgC = 11ULL;
+constexpr int64_t kTableSize = 100000000LL;  // nodesampler.cpp:14
+
+// f^n for the LCG step f (O(log n)).
+inline Affine lcg_power(uint64_t n) {
+  Affine result{1, 0}, base{kLcgA, kLcgC};
+  while (n) {
+    if (n & 1) result = compose(result, base);
+    base = compose(base, base);
+    n >>= 1;
+  }
+  return result;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace nncf

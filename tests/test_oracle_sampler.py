@@ -1,0 +1,118 @@
+"""CPU: pins the oracle (oracle/nodesampler_oracle.c) to golden vectors produced by the
+compiled, unmodified reference (tools/gen_golden_sampler.py), and checks the product's host
+logic (boundary builder, LCG jump-ahead) against both.  SURVEY.md section 8(c)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import sampler_oracle as so
+from nncf_amd import sampler as ns
+
+
+def _power(tag):
+    return 1.0 if tag.endswith("_p1") else 0.75
+
+
+def test_lcg_known_answers():
+    # state0 = 42 (compiled reference + independent big-int arithmetic)
+    kat = [16159453, 28765935, 26410514, 53133836, 51638694, 96321661]
+    assert so.lcg_draws_py(42, 6) == kat
+    assert so.lcg_draws(42, 6).tolist() == kat
+    # high-bit state: 64-bit wrap-around, not a 48-bit java.util.Random
+    s0 = 2**63 + 5
+    assert so.lcg_draws(s0, 64).tolist() == so.lcg_draws_py(s0, 64)
+
+
+def test_table_known_answers(sampler_golden):
+    g = sampler_golden
+    # dist = [5,3,0,2]: per-id table counts
+    assert np.diff(np.concatenate([[0], g["toy_p1_bounds"]])).tolist() == [50000000, 30000000, 0, 20000000]
+    assert np.diff(np.concatenate([[0], g["toy_p0_75_bounds"]])).tolist() == [45772771, 31204745, 0, 23022484]
+    assert g["toy_p1_s42_first"][:10].tolist() == [0, 0, 0, 1, 1, 3, 3, 1, 0, 3]
+    assert g["mod13_p1_s12345_first"][:8].tolist() == [8455, 9552, 8549, 15325, 1973, 14580, 9007, 2885]
+
+
+@pytest.mark.parametrize("tag", ["toy_p1", "toy_p0_75", "zipf17000_p0_75", "zeros_edges5000_p1", "single_p1"])
+def test_oracle_matches_reference_golden(sampler_golden, tag):
+    g = sampler_golden
+    o = so.OracleSampler(g[tag + "_dist"], _power(tag), 1)
+    assert o.filled == 100000000
+    assert np.array_equal(o.bounds(), g[tag + "_bounds"])
+    for s0 in g["states"].tolist():
+        o.state = s0
+        assert np.array_equal(o.sample_batch(4096), g["%s_s%d_first" % (tag, s0)])
+        assert o.state == int(g["%s_s%d_state_after" % (tag, s0)][0])
+        singles = np.array([o.sample() for _ in range(16)], dtype=np.int32)
+        assert np.array_equal(singles, g["%s_s%d_single" % (tag, s0)])
+    o.close()
+
+
+def test_oracle_long_stream_checksum(sampler_golden):
+    g = sampler_golden
+    o = so.OracleSampler(g["zipf17000_p1_dist"], 1.0, 12345)
+    h = hashlib.sha256()
+    for _ in range(10):
+        h.update(o.sample_batch(1000000).tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), g["zipf17000_p1_s12345_sha256_1e7"])
+    o.close()
+
+
+@pytest.mark.skipif(not so.ref_available(), reason="oracle/_ref not built here")
+def test_oracle_matches_compiled_reference_live():
+    rs = np.random.RandomState(7)
+    dist = np.floor(rs.pareto(1.2, size=3000) * 3).astype(np.float64)  # many zeros, heavy tail
+    dist[17] = 0.
+    for power in (1.0, 0.75, 0.5):
+        r = so.RefSampler(dist, power, 99)
+        o = so.OracleSampler(dist, power, 99)
+        assert np.array_equal(r.bounds(), o.bounds())
+        assert np.array_equal(r.sample_batch(20000), o.sample_batch(20000))
+        assert r.state == o.state
+        assert np.array_equal(ns.build_bounds(dist, power), r.bounds())
+        r.close()
+        o.close()
+
+
+def test_product_bounds_bit_exact(sampler_golden):
+    g = sampler_golden
+    for tag in g["tags"].tolist():
+        b = ns.build_bounds(np.ascontiguousarray(g[tag + "_dist"]), _power(tag))
+        assert np.array_equal(b, g[tag + "_bounds"]), tag
+
+
+def test_product_bounds_random_vs_oracle():
+    rs = np.random.RandomState(3)
+    for trial in range(3):
+        v = int(rs.randint(2, 4000))
+        dist = rs.randint(0, 50, size=v).astype(np.float64)
+        dist[rs.randint(v)] = 1.0
+        power = [1.0, 0.75, 0.3][trial]
+        o = so.OracleSampler(dist, power, 1)
+        assert np.array_equal(ns.build_bounds(dist, power), o.bounds())
+        o.close()
+
+
+def test_lcg_jump_matches_sequential():
+    for s0 in (1, 42, 12345, 2**63 + 5, 2**64 - 1):
+        s = s0
+        for n in range(0, 300):
+            assert ns.lcg_jump(s0, n) == s
+            s = (s * 25214903917 + 11) & (2**64 - 1)
+    assert ns.lcg_jump(ns.lcg_jump(7, 1000003), 999) == ns.lcg_jump(7, 1000003 + 999)
+
+
+def test_sampler_argument_errors():
+    # mirrors the Cython buffer validation of sampler.pyx:25
+    with pytest.raises(TypeError):
+        ns.build_bounds(None)
+    with pytest.raises(ValueError):
+        ns.build_bounds(np.ones(4, dtype=np.float32))
+    with pytest.raises(ValueError):
+        ns.build_bounds(np.ones((2, 2)))
+    with pytest.raises(ValueError):
+        ns.build_bounds(np.ones(8)[::2])
+    with pytest.raises(ValueError):
+        ns.build_bounds(np.zeros(5))  # nothing to sample (reference: undefined behaviour)
+    with pytest.raises(ValueError):
+        ns.build_bounds(np.array([1., -2.]))
