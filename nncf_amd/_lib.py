@@ -56,6 +56,10 @@ def lib():
             raise NncfError(
                 "libnncf_hip.so is not built (%s). Run `make -C nncf_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+        # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Importing torch first
+        # makes the loader bind our NEEDED entry to that copy; loading ours first would put two
+        # HIP runtimes in one process, and the second one to initialise sees no GPU.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         _declare(l)
         _lib = l

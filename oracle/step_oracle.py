@@ -1,0 +1,405 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement (oracle) of the reference's per-batch
+scoring path: embedding gather -> (L2 normalise) -> dot / U.V^T interaction -> loss ->
+analytic gradient -> sparse SGD scatter update.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; nncf_amd never does.
+
+Follows (all paths under /root/reference):
+  models/model_framework.py:36-176   graph wiring: gathers, tf.unique, slicing, heads
+  utils/objectives.py:15-220         the four loss families x {skip-gram, mse, log-loss, max-margin}
+  modules/interaction/interaction_dot.py:82-109   'mul' (row-wise dot) and 'matmul' (U.V^T)
+  utils/utilities.py:74-83,122-135   K.diag via gather_nd; L1L2Act activity regulariser
+  models/train_{original,neg_shared,group_neg_shared}.py   batch assembly conventions
+
+Parity status: UNPINNED by the reference.  The Keras-1.2.2 / TF-1.0 half of the reference can
+neither be imported nor installed here and ships no tests or golden
+vectors, so this restatement is pinned only against (a) torch-CPU autograd of the same
+formulas (tests/test_oracle_step.py) and (b) hand-computed toy cases.  Items taken from
+memory of the absent packages are marked [K-mem]:
+  * tf.nn.l2_normalize(x, dim=-1) = x * rsqrt(max(sum(x^2), 1e-12))            [K-mem]
+  * a custom-objective Keras model's train_on_batch returns mean(loss_tensor) + sum of
+    activity-regulariser terms of the layers on the model's own graph             [K-mem]
+  * K.relu gradient at 0 is 0                                                      [K-mem]
+The optimiser is the north-star's sparse SGD (BASELINE.json), not the reference's dense
+Adam (configs/basic_embedding_conf.py:59-60): table[row] -= lr * sum_of_row_gradients.
+-log(sigmoid(x)) is evaluated as softplus(-x) (identical wherever the reference's
+K.log(K.sigmoid(x)) is finite).
+"""
+import numpy as np
+
+LOSSES = ("skip-gram", "mse", "log-loss", "max-margin")
+
+
+class OracleConf(object):
+    """Subset of configs/basic_embedding_conf.py:10-56 consumed on the path."""
+
+    def __init__(self, batch_size_p=512, num_negatives=10, loss="skip-gram", loss_gamma=None,
+                 neg_loss_weight=None, u_reg=1e-6, learn_rate=0.01, emb_normalization=None,
+                 model_choice="mf"):
+        self.batch_size_p = int(batch_size_p)
+        self.num_negatives = int(num_negatives)
+        assert loss in LOSSES, "[ERROR!] loss %s not specified." % loss
+        self.loss = loss
+        # basic_embedding_conf.py:22-24 defaults
+        self.loss_gamma = (0.1 if loss == "max-margin" else 10.) if loss_gamma is None else float(loss_gamma)
+        self.neg_loss_weight = (8. if loss == "mse" else 128.) if neg_loss_weight is None else float(neg_loss_weight)
+        self.u_reg = float(u_reg)
+        self.learn_rate = float(learn_rate)
+        if emb_normalization is None:  # basic_embedding_conf.py:52-56
+            emb_normalization = loss in ("max-margin", "log-loss")
+        self.emb_normalization = bool(emb_normalization)
+        self.model_choice = model_choice
+        # model_framework.py:62-63 normalises U for every model; :109-111 normalises the item
+        # side only inside the content-model branch (not for 'mf', :85-88).
+        self.normalize_user = self.emb_normalization
+        self.normalize_item = self.emb_normalization and model_choice != "mf"
+
+
+# ----------------------------------------------------------------------------------------
+# elementary pieces
+# ----------------------------------------------------------------------------------------
+def _softplus(x):
+    return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+
+def _sigmoid(x):
+    # numerically stable logistic, same dtype as x
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1 / (1 + e), e / (1 + e)).astype(x.dtype)
+
+
+def l2_normalize(x):
+    """tf.nn.l2_normalize(x, dim=-1) (model_framework.py:63,110-111) [K-mem]."""
+    ss = np.sum(x * x, axis=-1, keepdims=True)
+    inv = (1.0 / np.sqrt(np.maximum(ss, x.dtype.type(1e-12)))).astype(x.dtype)
+    return x * inv, inv
+
+
+def l2_normalize_backward(xhat, inv, g):
+    """d/dx of xhat = x*inv:  (g - xhat (xhat.g)) * inv   (valid where sum(x^2) > 1e-12)."""
+    return (g - xhat * np.sum(xhat * g, axis=-1, keepdims=True)) * inv
+
+
+def tf_unique(x):
+    """tf.unique (model_framework.py:45-48): unique values in FIRST-OCCURRENCE order and the
+    index of each element into them."""
+    x = np.asarray(x)
+    _, first, inv = np.unique(x, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")          # sorted-unique slot -> first-occurrence rank
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    return x[np.sort(first)], rank[inv].astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------
+# losses: value and d(loss)/d(score)
+# ----------------------------------------------------------------------------------------
+def original_loss(s, y, conf):
+    """get_original_loss (objectives.py:35-75).  s, y: (b(1+k),) ; first b rows positive,
+    negative row j (0-based among negatives) belongs to positive j // k (K.repeat, :51-57)."""
+    b, k = conf.batch_size_p, conf.num_negatives
+    dt = s.dtype
+    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    g = np.zeros_like(s)
+    if conf.loss in ("max-margin", "log-loss"):
+        pos, neg = s[:b], s[b:]
+        diff = np.repeat(pos, k) - neg
+        m = dt.type(b * k)
+        if conf.loss == "max-margin":
+            loss = np.sum(np.maximum(gamma - diff, 0)) / m           # K.mean(K.relu(margin - diff))
+            gd = np.where(gamma - diff > 0, dt.type(-1), dt.type(0)) / m
+        else:
+            loss = np.sum(_softplus(-gamma * diff)) / m              # K.mean(-log sigmoid(g*diff))
+            gd = -gamma * _sigmoid(-gamma * diff) / m
+        g[b:] = -gd
+        g[:b] = gd.reshape(b, k).sum(axis=1)
+    elif conf.loss == "skip-gram":
+        wv = lam / dt.type(k)
+        w = 1 + (1 - y) / 2 * (wv - 1)                               # objectives.py:60-62
+        loss = np.sum(w * _softplus(-y * s)) / dt.type(b)
+        g = -w * y * _sigmoid(-y * s) / dt.type(b)
+    else:  # mse
+        wv = lam / dt.type(k)
+        w = 1 + (1 - y) * (wv - 1)                                   # objectives.py:66-68
+        loss = np.sum(w * (y - s) ** 2) / dt.type(b)
+        g = 2 * w * (s - y) / dt.type(b)
+    return dt.type(loss), g.astype(dt)
+
+
+def neg_shared_loss(S, conf):
+    """get_neg_shared_loss (objectives.py:78-117).  S: (b,b), diagonal = positives.
+    Pairwise orientation follows the CODE: K.diag(y_pred) - y_pred is (b,) - (b,b), i.e.
+    diff[i,j] = S[j,j] - S[i,j]  (objectives.py:92,97; utilities.py:74-83)."""
+    b = S.shape[0]
+    dt = S.dtype
+    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    eye = np.eye(b, dtype=bool)
+    if conf.loss in ("max-margin", "log-loss"):
+        diff = np.diag(S)[None, :] - S
+        m = dt.type(b * b)
+        if conf.loss == "max-margin":
+            margin = np.where(eye, dt.type(0), gamma)                 # objectives.py:93
+            act = margin - diff
+            loss = np.sum(np.maximum(act, 0)) / m
+            gd = np.where(act > 0, dt.type(-1), dt.type(0)) / m       # d loss / d diff
+        else:
+            loss = np.sum(_softplus(-gamma * diff)) / m
+            gd = -gamma * _sigmoid(-gamma * diff) / m
+        G = -gd                                                       # through -S[i,j]
+        G[np.arange(b), np.arange(b)] += gd.sum(axis=0)               # through S[j,j] (column j)
+    else:
+        wv = lam / dt.type(b - 1)
+        w = np.where(eye, dt.type(1), wv)                             # objectives.py:100-102
+        if conf.loss == "skip-gram":
+            label = np.where(eye, dt.type(1), dt.type(-1))            # :103
+            loss = np.sum(w * _softplus(-label * S)) / dt.type(b)
+            G = -w * label * _sigmoid(-label * S) / dt.type(b)
+        else:
+            label = np.where(eye, dt.type(1), dt.type(0))             # :110
+            loss = np.sum(w * (S - label) ** 2) / dt.type(b)
+            G = 2 * w * (S - label) / dt.type(b)
+    return dt.type(loss), G.astype(dt)
+
+
+def group_neg_shared_loss(S, pos_col, conf):
+    """get_group_neg_shared_loss (objectives.py:163-220).  S: (b, n_u); pos_col[i] = cid_x[i].
+    diff[i,j] = S[i,pos_i] - S[i,j]  (row-anchored, :175,196,200); num_negatives = n_u - 1 (:177)."""
+    b, nu = S.shape
+    dt = S.dtype
+    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    rows = np.arange(b)
+    posmask = np.zeros((b, nu), dtype=bool)
+    posmask[rows, pos_col] = True
+    if conf.loss in ("max-margin", "log-loss"):
+        diff = S[rows, pos_col][:, None] - S
+        m = dt.type(b * nu)
+        if conf.loss == "max-margin":
+            act = gamma - diff                                        # :195-197 (no diag exemption)
+            loss = np.sum(np.maximum(act, 0)) / m
+            gd = np.where(act > 0, dt.type(-1), dt.type(0)) / m
+        else:
+            loss = np.sum(_softplus(-gamma * diff)) / m
+            gd = -gamma * _sigmoid(-gamma * diff) / m
+        G = -gd
+        G[rows, pos_col] += gd.sum(axis=1)
+    else:
+        wv = lam / dt.type(nu - 1) if nu > 1 else dt.type(0)          # :203,211 (nu == 1: reference NaNs)
+        w = np.where(posmask, dt.type(1), wv)
+        if conf.loss == "skip-gram":
+            label = np.where(posmask, dt.type(1), dt.type(-1))
+            loss = np.sum(w * _softplus(-label * S)) / dt.type(b)
+            G = -w * label * _sigmoid(-label * S) / dt.type(b)
+        else:
+            label = np.where(posmask, dt.type(1), dt.type(0))
+            loss = np.sum(w * (S - label) ** 2) / dt.type(b)
+            G = 2 * w * (S - label) / dt.type(b)
+    return dt.type(loss), G.astype(dt)
+
+
+def sampled_neg_shared_loss(S, conf):
+    """get_sampled_neg_shared_loss (objectives.py:120-161).  S: (b, 1+k); column 0 positive."""
+    b, k1 = S.shape
+    k = k1 - 1
+    dt = S.dtype
+    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    if conf.loss in ("max-margin", "log-loss"):
+        diff = S[:, :1] - S[:, 1:]
+        m = dt.type(b * k)
+        if conf.loss == "max-margin":
+            loss = np.sum(np.maximum(gamma - diff, 0)) / m
+            gd = np.where(gamma - diff > 0, dt.type(-1), dt.type(0)) / m
+        else:
+            loss = np.sum(_softplus(-gamma * diff)) / m
+            gd = -gamma * _sigmoid(-gamma * diff) / m
+        G = np.concatenate([gd.sum(axis=1, keepdims=True), -gd], axis=1)
+    else:
+        wv = lam / dt.type(k)
+        w = np.ones((b, k1), dtype=dt)
+        w[:, 1:] = wv
+        label = np.ones((b, k1), dtype=dt)
+        if conf.loss == "skip-gram":
+            label[:, 1:] = -1
+            loss = np.sum(w * _softplus(-label * S)) / dt.type(b)
+            G = -w * label * _sigmoid(-label * S) / dt.type(b)
+        else:
+            label[:, 1:] = 0
+            loss = np.sum(w * (S - label) ** 2) / dt.type(b)
+            G = 2 * w * (S - label) / dt.type(b)
+    return dt.type(loss), G.astype(dt)
+
+
+# ----------------------------------------------------------------------------------------
+# the model: id-table towers ('mf', model_framework.py:59-63,85-88) + sparse SGD
+# ----------------------------------------------------------------------------------------
+class StepOracle(object):
+    """Holds copies of the user / item tables and applies one reference step at a time.
+
+    U: (user_count, d), V: (item_count, d) float arrays (copied, cast to `dtype`)."""
+
+    def __init__(self, U, V, conf, dtype=np.float32):
+        self.dt = np.dtype(dtype)
+        self.U = np.array(U, dtype=self.dt, copy=True)
+        self.V = np.array(V, dtype=self.dt, copy=True)
+        self.conf = conf
+
+    # -- shared pieces -------------------------------------------------------------------
+    def _user_side(self, uid):
+        """Emb_U gather (+ activity_l2(u_reg) on the raw output, model_framework.py:59-61;
+        utilities.py:122-135: u_reg * sum_d mean_n(E[n,d]^2)) then optional l2_normalize (:62-63)."""
+        raw = self.U[uid]
+        reg = self.dt.type(self.conf.u_reg) * np.sum(np.mean(raw * raw, axis=0))
+        if self.conf.normalize_user:
+            hat, inv = l2_normalize(raw)
+        else:
+            hat, inv = raw, None
+        return raw, hat, inv, self.dt.type(reg)
+
+    def _item_side(self, cid):
+        raw = self.V[cid]
+        if self.conf.normalize_item:
+            hat, inv = l2_normalize(raw)
+        else:
+            hat, inv = raw, None
+        return raw, hat, inv
+
+    def _apply(self, uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g_uhat, g_vhat):
+        """Back through the normalisation, add the regulariser gradient, scatter-SGD."""
+        lr = self.dt.type(self.conf.learn_rate)
+        n = self.dt.type(len(uid))
+        g_u = l2_normalize_backward(hat_u, inv_u, g_uhat) if inv_u is not None else g_uhat
+        g_u = g_u + 2 * self.dt.type(self.conf.u_reg) * raw_u / n
+        g_v = l2_normalize_backward(hat_v, inv_v, g_vhat) if inv_v is not None else g_vhat
+        dU = np.zeros_like(self.U)
+        dV = np.zeros_like(self.V)
+        np.add.at(dU, uid, g_u.astype(self.dt))
+        np.add.at(dV, cid, g_v.astype(self.dt))
+        tu, tv = np.unique(uid), np.unique(cid)
+        self.U[tu] -= lr * dU[tu]
+        self.V[tv] -= lr * dV[tv]
+        self.last = dict(g_u=g_u, g_v=g_v, dU=dU, dV=dV)
+
+    # -- train_scheme = original (train_original.py:49-58; model 'model', :123,147-149) ---
+    def step_original(self, uid, cid, y, update=True):
+        uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        y = np.asarray(y).astype(self.dt).reshape(-1)
+        raw_u, hat_u, inv_u, reg = self._user_side(uid)
+        raw_v, hat_v, inv_v = self._item_side(cid)
+        s = np.sum(hat_u * hat_v, axis=1)                              # interaction_dot.py:92-95
+        loss, g = original_loss(s, y, self.conf)
+        self.scores = s
+        if update:
+            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g[:, None] * hat_v, g[:, None] * hat_u)
+        return float(loss + reg)
+
+    # -- train_scheme = neg_shared (train_neg_shared.py:46-51; :128-129,153-155) ----------
+    def step_neg_shared(self, uid, cid, update=True):
+        uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        raw_u, hat_u, inv_u, reg = self._user_side(uid)
+        raw_v, hat_v, inv_v = self._item_side(cid)
+        S = hat_u @ hat_v.T                                            # interaction_dot.py:100-103
+        loss, G = neg_shared_loss(S, self.conf)
+        self.scores = S
+        if update:
+            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+        return float(loss + reg)
+
+    # -- train_scheme = group_neg_shared (train_group_neg_shared.py:53-61; :131-136,158-161)
+    def step_group_neg_shared(self, uid, cid, update=True):
+        uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        assert len(uid) == self.conf.batch_size_p                      # row_cidx_prefx, :38-39,133-134
+        cid_u, cid_x = tf_unique(cid)                                  # :45-48
+        raw_u, hat_u, inv_u, reg = self._user_side(uid)
+        raw_v, hat_v, inv_v = self._item_side(cid_u)                   # compact item block
+        S = hat_u @ hat_v.T                                            # (b, n_u)
+        loss, G = group_neg_shared_loss(S, cid_x, self.conf)
+        self.scores, self.cid_u, self.cid_x = S, cid_u, cid_x
+        if update:
+            self._apply(uid, cid_u, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+        return float(loss + reg)
+
+    # -- train_scheme = sampled_neg_shared (train_sampled_neg_shared.py:46-52; :138-143,166-170)
+    def step_sampled_neg_shared(self, uid, cid, update=True):
+        b = self.conf.batch_size_p
+        uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        # the head uses U_emb_front = Emb_U(uid[:b]) WITHOUT normalisation (:64-65) and C_emb
+        # sliced front/back (:114-117); the regulariser node is the front call.
+        ufront = uid[:b]
+        raw_u = self.U[ufront]
+        reg = self.dt.type(self.conf.u_reg) * np.sum(np.mean(raw_u * raw_u, axis=0))
+        raw_v, hat_v, inv_v = self._item_side(cid)
+        pos = np.sum(raw_u * hat_v[:b], axis=1, keepdims=True)
+        neg = raw_u @ hat_v[b:].T
+        S = np.concatenate([pos, neg], axis=1)
+        loss, G = sampled_neg_shared_loss(S, self.conf)
+        self.scores = S
+        if update:
+            g_u = G[:, :1] * hat_v[:b] + G[:, 1:] @ hat_v[b:]
+            g_v = np.concatenate([G[:, :1] * raw_u, G[:, 1:].T @ raw_u], axis=0)
+            self._apply(ufront, cid, raw_u, raw_u, None, hat_v, inv_v, g_u, g_v)
+        return float(loss + reg)
+
+    # -- inference heads (model_framework.py:153,173-176) --------------------------------
+    def predict_neg_shared(self, uid, cid):
+        _, hat_u, _, _ = self._user_side(np.asarray(uid, dtype=np.int64))
+        _, hat_v, _ = self._item_side(np.asarray(cid, dtype=np.int64))
+        return hat_u @ hat_v.T
+
+
+# ----------------------------------------------------------------------------------------
+# batch assembly as the trainers do it
+# ----------------------------------------------------------------------------------------
+def assemble_original(batch_p, negatives, loss):
+    """train_original.py:49-56: positives, then each positive repeated k times consecutively
+    with the item replaced by a sampled negative; label -1 (skip-gram) or 0 (:13-14)."""
+    batch_p = np.asarray(batch_p)
+    b = batch_p.shape[0]
+    k = len(negatives) // b
+    neg_sign = -1 if loss == "skip-gram" else 0
+    batch_n = batch_p.repeat(k, axis=0)
+    batch_n[:, 1] = negatives
+    batch_n[:, 2] = neg_sign
+    tb = np.vstack((batch_p, batch_n))
+    return tb[:, 0], tb[:, 1], tb[:, 2]
+
+
+# ----------------------------------------------------------------------------------------
+# evaluation: whole@k  (objectives.py:296-370,395-421; metrics_ranking.py:6-35)
+# ----------------------------------------------------------------------------------------
+def eval_multiple(true_scores, pred_scores, topk, noise=None):
+    """metrics_ranking.py:6-35 with the tie-break noise passed in (default: none => ties are
+    broken by the true label, then arbitrarily -- use tie-free scores in tests)."""
+    pred_scores = np.asarray(pred_scores)
+    true_scores = np.asarray(true_scores)
+    idx = np.argpartition(-pred_scores, topk)[:topk]
+    if noise is None:
+        noise = np.zeros(topk)
+    rec = sorted(zip(pred_scores[idx], noise, true_scores[idx]), reverse=True)
+    nhits_topk, sumap, nh = 0., 0., 0.
+    k = topk
+    for i in range(len(rec)):
+        if rec[i][-1] != 0.:
+            nh += 1.0
+            if i < k:
+                nhits_topk += 1
+                sumap += nh / (i + 1.0)
+    nhits = np.sum(true_scores)
+    if nhits != 0:
+        return sumap / min(nhits, k), nhits_topk / nhits, nhits_topk / k
+    return 0., 0., 0.
+
+
+def evaluate_whole(U_hat, V_hat, links, candidate_items, topk):
+    """Evaluator whole@k for one candidate set (objectives.py:395-421,296-321,333-370):
+    truth[user, slot(item)] = 1 for every link whose item is a candidate; users with no
+    truth are skipped; returns mean (map, recall, precision)."""
+    cand = np.asarray(sorted(set(candidate_items)))
+    slot = {it: i for i, it in enumerate(cand)}
+    nu = U_hat.shape[0]
+    truth = np.zeros((nu, len(cand)), dtype=np.int32)
+    for u, i in links:
+        if i in slot:
+            truth[u, slot[i]] = 1
+    pred = U_hat @ V_hat[cand].T
+    keep = truth.sum(axis=1) > 0
+    res = [eval_multiple(truth[u], pred[u], topk) for u in np.nonzero(keep)[0]]
+    res = np.asarray(res, dtype=np.float64)
+    return dict(map=res[:, 0].mean(), recall=res[:, 1].mean(), precision=res[:, 2].mean(), users=int(keep.sum()))

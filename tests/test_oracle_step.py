@@ -1,0 +1,222 @@
+"""CPU: pins oracle/step_oracle.py.  The Keras/TF half of the reference cannot run here
+(SURVEY.md 8(c)), so the restatement is checked against torch-CPU autograd of the loss
+formulas written the way the reference writes them (utils/objectives.py), plus hand-computed
+toy values.  "parity unpinned" by the reference itself -- see the oracle's header."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import step_oracle as so
+
+LOSSES = ["skip-gram", "mse", "log-loss", "max-margin"]
+
+
+def _tables(nu=40, ni=50, d=12, seed=0):
+    rs = np.random.RandomState(seed)
+    return rs.uniform(-0.5, 0.5, (nu, d)), rs.uniform(-0.5, 0.5, (ni, d))
+
+
+def _t_normalize(x):
+    return x * torch.rsqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))
+
+
+def _torch_original(U, V, uid, cid, y, conf):
+    b, k = conf.batch_size_p, conf.num_negatives
+    e = U[uid]
+    reg = conf.u_reg * (e * e).mean(0).sum()
+    u = _t_normalize(e) if conf.normalize_user else e
+    v = V[cid]
+    v = _t_normalize(v) if conf.normalize_item else v
+    pred = (u * v).sum(1, keepdim=True)
+    y = y.reshape(-1, 1)
+    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    pos, neg = pred[:b], pred[b:]
+    if conf.loss == "max-margin":
+        diff = pos.repeat(1, k).reshape(-1, 1) - neg
+        task = torch.relu(gamma - diff).mean()
+    elif conf.loss == "log-loss":
+        diff = pos.repeat(1, k).reshape(-1, 1) - neg
+        task = (-torch.log(torch.sigmoid(gamma * diff))).mean()
+    elif conf.loss == "skip-gram":
+        w = 1 + (1 - y) / 2.0 * (lam / k - 1)
+        task = (-w * torch.log(torch.sigmoid(y * pred))).sum() / b
+    else:
+        w = 1 + (1 - y) * (lam / k - 1)
+        task = (w * (y - pred) ** 2).sum() / b
+    return task + reg
+
+
+def _torch_neg_shared(U, V, uid, cid, conf):
+    b = conf.batch_size_p
+    e = U[uid]
+    reg = conf.u_reg * (e * e).mean(0).sum()
+    u = _t_normalize(e) if conf.normalize_user else e
+    v = V[cid]
+    v = _t_normalize(v) if conf.normalize_item else v
+    pred = u @ v.t()
+    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    eye = torch.eye(b, dtype=pred.dtype)
+    if conf.loss == "max-margin":
+        diff = torch.diagonal(pred) - pred  # (b,) - (b,b): broadcasts over rows
+        margin = torch.diag(torch.full((b,), -gamma, dtype=pred.dtype)) + gamma
+        task = torch.relu(margin - diff).mean()
+    elif conf.loss == "log-loss":
+        diff = torch.diagonal(pred) - pred
+        task = (-torch.log(torch.sigmoid(gamma * diff))).mean()
+    elif conf.loss == "skip-gram":
+        wv = lam / (b - 1)
+        w = eye * (1 - wv) + wv
+        label = 2 * eye - 1
+        task = (-w * torch.log(torch.sigmoid(label * pred))).sum() / b
+    else:
+        wv = lam / (b - 1)
+        w = eye * (1 - wv) + wv
+        task = (w * (pred - eye) ** 2).sum() / b
+    return task + reg
+
+
+def _torch_group(U, V, uid, cid_u, cid_x, conf):
+    b = conf.batch_size_p
+    e = U[uid]
+    reg = conf.u_reg * (e * e).mean(0).sum()
+    u = _t_normalize(e) if conf.normalize_user else e
+    v = V[cid_u]
+    v = _t_normalize(v) if conf.normalize_item else v
+    pred = u @ v.t()
+    nu = pred.shape[1]
+    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    rows = torch.arange(b)
+    pred_pos = pred[rows, cid_x].reshape(-1, 1)
+    mask = torch.zeros_like(pred)
+    mask[rows, cid_x] = 1
+    if conf.loss == "max-margin":
+        task = torch.relu(gamma - (pred_pos - pred)).mean()
+    elif conf.loss == "log-loss":
+        task = (-torch.log(torch.sigmoid(gamma * (pred_pos - pred)))).mean()
+    elif conf.loss == "skip-gram":
+        wv = lam / (nu - 1)
+        label = mask * 2 - 1
+        w = mask * (1 - wv) + wv
+        task = (-w * torch.log(torch.sigmoid(label * pred))).sum() / b
+    else:
+        wv = lam / (nu - 1)
+        w = mask * (1 - wv) + wv
+        task = (w * (pred - mask) ** 2).sum() / b
+    return task + reg
+
+
+def _conf(loss, b, k, model="mf", norm=None, lr=0.05):
+    gamma = {"max-margin": 0.1, "log-loss": 10.}.get(loss)
+    return so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=1e-3,
+                         learn_rate=lr, emb_normalization=norm, model_choice=model)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_original_vs_autograd(loss, model):
+    b, k = 8, 3
+    conf = _conf(loss, b, k, model)
+    Un, Vn = _tables()
+    rs = np.random.RandomState(1)
+    pu, pi = rs.randint(0, 40, b), rs.randint(0, 50, b)
+    pu[1] = pu[0]  # duplicate user across positives
+    negs = rs.randint(0, 50, b * k)
+    negs[0] = pi[2]  # a negative colliding with a positive item
+    uid, cid, y = so.assemble_original(np.stack([pu, pi, np.ones(b, dtype=int)], 1), negs, loss)
+    o = so.StepOracle(Un, Vn, conf, dtype=np.float64)
+    l_o = o.step_original(uid, cid, y)
+    U = torch.tensor(Un, requires_grad=True)
+    V = torch.tensor(Vn, requires_grad=True)
+    l_t = _torch_original(U, V, torch.tensor(uid), torch.tensor(cid), torch.tensor(y, dtype=torch.float64), conf)
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    np.testing.assert_allclose(o.last["dU"], U.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(o.last["dV"], V.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(o.U, Un - conf.learn_rate * U.grad.numpy(), atol=1e-12)
+    np.testing.assert_allclose(o.V, Vn - conf.learn_rate * V.grad.numpy(), atol=1e-12)
+    # fp32 mode agrees with fp64 to fp32 precision (the tolerance GPU parity is held to)
+    o32 = so.StepOracle(Un, Vn, conf, dtype=np.float32)
+    l32 = o32.step_original(uid, cid, y)
+    assert abs(l32 - l_o) < 1e-5 * max(1, abs(l_o))
+    np.testing.assert_allclose(o32.U, o.U, atol=2e-6)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_neg_shared_vs_autograd(loss, model):
+    b = 8
+    conf = _conf(loss, b, 0, model)
+    Un, Vn = _tables(seed=2)
+    rs = np.random.RandomState(3)
+    uid, cid = rs.randint(0, 40, b), rs.randint(0, 50, b)
+    uid[3] = uid[5]
+    cid[1] = cid[6]  # duplicate item inside the batch: treated as a negative (no masking)
+    o = so.StepOracle(Un, Vn, conf, dtype=np.float64)
+    l_o = o.step_neg_shared(uid, cid)
+    U = torch.tensor(Un, requires_grad=True)
+    V = torch.tensor(Vn, requires_grad=True)
+    l_t = _torch_neg_shared(U, V, torch.tensor(uid), torch.tensor(cid), conf)
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    np.testing.assert_allclose(o.last["dU"], U.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(o.last["dV"], V.grad.numpy(), atol=1e-10)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_group_neg_shared_vs_autograd(loss, model):
+    b = 12
+    conf = _conf(loss, b, 0, model)
+    Un, Vn = _tables(seed=4)
+    rs = np.random.RandomState(5)
+    uid = rs.randint(0, 40, b)
+    cid = np.repeat(rs.choice(50, 4, replace=False), 3)  # 4 groups of 3 (chop = 3)
+    cid[-1] = cid[0]  # an item re-appearing later in the batch
+    o = so.StepOracle(Un, Vn, conf, dtype=np.float64)
+    l_o = o.step_group_neg_shared(uid, cid)
+    cid_u, cid_x = so.tf_unique(cid)
+    U = torch.tensor(Un, requires_grad=True)
+    V = torch.tensor(Vn, requires_grad=True)
+    l_t = _torch_group(U, V, torch.tensor(uid), torch.tensor(cid_u), torch.tensor(cid_x, dtype=torch.long), conf)
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    np.testing.assert_allclose(o.last["dU"], U.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(o.last["dV"], V.grad.numpy(), atol=1e-10)
+
+
+def test_tf_unique_first_occurrence_order():
+    u, x = so.tf_unique(np.array([7, 3, 7, 9, 3, 1]))
+    assert u.tolist() == [7, 3, 9, 1] and x.tolist() == [0, 1, 0, 2, 1, 3]
+    u, x = so.tf_unique(np.array([5, 5, 5]))
+    assert u.tolist() == [5] and x.tolist() == [0, 0, 0]
+
+
+def test_hand_computed_toys():
+    # one positive + one negative, d = 1, no normalisation: skip-gram by hand
+    conf = so.OracleConf(batch_size_p=1, num_negatives=1, loss="skip-gram", neg_loss_weight=4., u_reg=0., learn_rate=1.)
+    o = so.StepOracle(np.array([[2.0]]), np.array([[0.5], [-1.0]]), conf, dtype=np.float64)
+    loss = o.step_original([0, 0], [0, 1], [1, -1])
+    s_pos, s_neg = 1.0, -2.0
+    want = np.log1p(np.exp(-s_pos)) + 4.0 * np.log1p(np.exp(s_neg))  # w_neg = lambda/k = 4
+    assert abs(loss - want) < 1e-12
+    # neg_shared log-loss, b = 2: diff[i,j] = S[j,j] - S[i,j]; the diagonal contributes log 2
+    conf = so.OracleConf(batch_size_p=2, num_negatives=0, loss="log-loss", loss_gamma=1., u_reg=0.,
+                         emb_normalization=False)
+    S = np.array([[1.0, 0.2], [-0.3, 0.5]])
+    l, G = so.neg_shared_loss(S, conf)
+    want = (2 * np.log(2) + np.log1p(np.exp(-(0.5 - 0.2))) + np.log1p(np.exp(-(1.0 + 0.3)))) / 4
+    assert abs(l - want) < 1e-12
+    assert abs(G.sum()) < 1e-12  # pairwise: every column's gradient sums to zero
+    # group: row-anchored orientation differs from neg_shared's column-anchored one
+    l2, _ = so.group_neg_shared_loss(S, np.array([0, 1]), conf)
+    want2 = (2 * np.log(2) + np.log1p(np.exp(-(1.0 - 0.2))) + np.log1p(np.exp(-(0.5 + 0.3)))) / 4
+    assert abs(l2 - want2) < 1e-12
+
+
+def test_eval_multiple_formulas():
+    truth = np.array([1, 0, 1, 0, 0, 1, 0, 0])
+    pred = np.array([.9, .8, .7, .6, .5, .4, .3, .2])
+    ap, rec, prec = so.eval_multiple(truth, pred, 4)
+    assert abs(rec - 2 / 3) < 1e-12 and abs(prec - 0.5) < 1e-12
+    assert abs(ap - (1 / 1 + 2 / 3) / 3) < 1e-12
+    assert so.eval_multiple(np.zeros(8), pred, 4) == (0., 0., 0.)
