@@ -103,6 +103,103 @@ int nncf_sampler_set_state(nncf_sampler* s, uint64_t state);
 /* LCG jump-ahead helper: state after `n` draws from `state` (no sampler needed). */
 uint64_t nncf_lcg_jump(uint64_t state, uint64_t n);
 
+
+/* ------------------------------------------------------------------------------------
+ * B2  Scoring / training step  --  replaces the Keras models returned by get_model
+ *     (models/model_framework.py:18-206) for the id-table towers:
+ *       Emb_U[uid] / Emb_C[cid] gathers      model_framework.py:59-63,85-88
+ *       tf.nn.l2_normalize                   model_framework.py:62-63,109-111
+ *       InteractionDot 'mul' / 'matmul'      modules/interaction/interaction_dot.py:92-107
+ *       loss families                        utils/objectives.py:35-220
+ *       activity_l2(u_reg)                   utils/utilities.py:122-135
+ *     and the optimizer step with the north-star's sparse SGD scatter update
+ *     (table[row] -= learn_rate * sum of that row's gradients in the batch).
+ *
+ * Tables are fp32, row-major, `row_stride` floats per row (>= dim, multiple of 4, rows
+ * 16-byte aligned); ids are int32 device arrays; all work is enqueued on `stream`.
+ * Duplicate rows inside a batch are reduced in a fixed order (no float atomics): results
+ * are run-to-run deterministic.
+ * ---------------------------------------------------------------------------------- */
+typedef enum {
+  NNCF_LOSS_SKIP_GRAM = 0,  /* objectives.py:59-64,99-105,202-209 */
+  NNCF_LOSS_MSE = 1,        /* objectives.py:65-70,106-112,210-217 */
+  NNCF_LOSS_LOG_LOSS = 2,   /* objectives.py:54-58,95-98,198-201 */
+  NNCF_LOSS_MAX_MARGIN = 3  /* objectives.py:49-53,90-94,194-197 */
+} nncf_loss;
+
+typedef struct {
+  int32_t batch_size_p;    /* b: positives per step (conf.batch_size_p); multiple of 32 for the shared-negative schemes */
+  int32_t num_negatives;   /* k: sampled negatives per positive (train_scheme=original) */
+  int32_t dim;             /* d = user_dim = item_dim; multiple of 4, <= 128 */
+  int32_t row_stride;      /* floats between table rows */
+  int32_t loss;            /* nncf_loss */
+  int32_t normalize_user;  /* conf.emb_normalization on U_emb (model_framework.py:62-63) */
+  int32_t normalize_item;  /* ... on C_emb (model_framework.py:109-111; not for 'mf') */
+  float loss_gamma;        /* conf.loss_gamma */
+  float neg_loss_weight;   /* conf.neg_loss_weight */
+  float u_reg;             /* conf.u_reg */
+  float learn_rate;        /* SGD step */
+  int64_t user_count;
+  int64_t item_count;
+} nncf_model_cfg;
+
+typedef struct nncf_model nncf_model;
+
+/* Binds caller-owned device tables and allocates the per-step workspace (gradient slabs,
+ * duplicate-row plans, loss partials).  max_steps = largest number of steps a single
+ * nncf_epoch_* call will be asked to run (sizes the per-epoch plan buffers; >= 1). */
+int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_item_table, int device,
+                      int64_t max_steps, nncf_model** out);
+int nncf_model_destroy(nncf_model* m);
+/* learn_rate / loss hyper-parameters may change between steps (same shapes). */
+int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg);
+
+/* model.train_on_batch for train_scheme=original (models/train_original.py:49-58 with the
+ * 'model' head, model_framework.py:123,147-149; loss objectives.py:35-75).
+ *   d_uid[b]         users of the b positives (row j of the negatives reuses user j / k)
+ *   d_cid[b*(1+k)]   items: b positives, then k sampled negatives per positive, consecutively
+ * Labels are implied by the layout (+1 positives; -1 / 0 negatives, train_original.py:13-14).
+ * d_loss[1] receives task loss + regulariser (what train_on_batch returns).
+ * update = 0 evaluates the loss only (SGD(0.) monitor models, model_framework.py:179-193). */
+int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
+                       void* stream);
+
+/* model_neg_shared.train_on_batch (train_neg_shared.py:46-51; model_framework.py:128-129,
+ * 153-155; loss objectives.py:78-117): S = U_b . V_b^T (b x b), diagonal = positives. */
+int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
+                         void* stream);
+
+/* model_group_neg_shared.train_on_batch (train_group_neg_shared.py:53-61; model_framework.py:
+ * 45-48,131-136,158-161; loss objectives.py:163-220): items are de-duplicated on device in
+ * first-occurrence order (tf.unique), S = U_b . V_u^T (b x n_u), positive of row i = cid_x[i].
+ * Optional outputs (may be NULL): d_cid_u[b] (first n_u valid), d_cid_x[b], d_n_u[1]. */
+int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss,
+                               int update, int32_t* d_cid_u, int32_t* d_cid_x, int32_t* d_n_u, void* stream);
+
+/* Trainer hot loops (models/train_original.py:43-68, train_neg_shared.py:46-59,
+ * train_group_neg_shared.py:53-68) over a device-resident, already shuffled link list:
+ * step t uses links [t*b, (t+1)*b).  No host synchronisation inside; d_loss[t] = loss of
+ * step t.  For `original`, d_neg holds n_steps*b*k presampled negatives (the sampler
+ * stream consumed in the reference's order: step t draws [t*b*k, (t+1)*b*k)). */
+int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_neg,
+                        int64_t n_steps, float* d_loss, void* stream);
+int nncf_epoch_neg_shared(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, int64_t n_steps,
+                          float* d_loss, void* stream);
+int nncf_epoch_group_neg_shared(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all,
+                                int64_t n_steps, float* d_loss, int32_t* d_n_u, void* stream);
+
+/* model_neg_shared.predict_on_batch([uid (p,), cid (q,)]) -> (p, q) scores
+ * (utils/objectives.py:310; model_framework.py:128-129): normalised-as-configured U.V^T.
+ * d_out: p*q floats, row-major. */
+int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const int32_t* d_cid, int64_t q,
+                        float* d_out, void* stream);
+
+/* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
+ * segment starts, and tf.unique-style first-occurrence outputs.
+ *   d_order[n], d_seg_start[n+1], d_uniq[n], d_inverse[n], d_counts[2] = {n_segments, n}. */
+int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, int32_t* d_seg_start, int32_t* d_uniq,
+                  int32_t* d_inverse, int32_t* d_counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

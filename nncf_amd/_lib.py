@@ -21,6 +21,28 @@ class NncfError(RuntimeError):
     pass
 
 
+class ModelCfg(ctypes.Structure):
+    """nncf_model_cfg (include/nncf_hip.h)."""
+    _fields_ = [
+        ("batch_size_p", ctypes.c_int32),
+        ("num_negatives", ctypes.c_int32),
+        ("dim", ctypes.c_int32),
+        ("row_stride", ctypes.c_int32),
+        ("loss", ctypes.c_int32),
+        ("normalize_user", ctypes.c_int32),
+        ("normalize_item", ctypes.c_int32),
+        ("loss_gamma", ctypes.c_float),
+        ("neg_loss_weight", ctypes.c_float),
+        ("u_reg", ctypes.c_float),
+        ("learn_rate", ctypes.c_float),
+        ("user_count", ctypes.c_int64),
+        ("item_count", ctypes.c_int64),
+    ]
+
+
+LOSS_CODES = {"skip-gram": 0, "mse": 1, "log-loss": 2, "max-margin": 3}
+
+
 def _declare(lib):
     vp, i32, i64, u64, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
     lib.nncf_last_error.restype = ctypes.c_char_p
@@ -40,6 +62,20 @@ def _declare(lib):
         "nncf_sampler_get_state": [vp, c_u64p],
         "nncf_sampler_set_state": [vp, u64],
     }
+    f32 = ctypes.c_float
+    sig.update({
+        "nncf_model_create": [ctypes.POINTER(ModelCfg), vp, vp, i32, i64, ctypes.POINTER(vp)],
+        "nncf_model_destroy": [vp],
+        "nncf_model_set_hparams": [vp, f32, f32, f32, f32],
+        "nncf_step_original": [vp, vp, vp, vp, i32, vp],
+        "nncf_step_neg_shared": [vp, vp, vp, vp, i32, vp],
+        "nncf_step_group_neg_shared": [vp, vp, vp, vp, i32, vp, vp, vp, vp],
+        "nncf_epoch_original": [vp, vp, vp, vp, i64, vp, vp],
+        "nncf_epoch_neg_shared": [vp, vp, vp, i64, vp, vp],
+        "nncf_epoch_group_neg_shared": [vp, vp, vp, i64, vp, vp, vp],
+        "nncf_predict_scores": [vp, vp, i64, vp, i64, vp, vp],
+        "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp],
+    })
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.restype = i32

@@ -1,0 +1,38 @@
+// Host-side model object behind the B2 entry points (include/nncf_hip.h) and the plan views
+// shared between plan.hip and step.hip.
+#pragma once
+#include <cstdint>
+
+#include "common.h"
+
+namespace nncf {
+
+// Output arrays of the duplicate-row plan for a batch of id lists (one list per step).
+// List L uses order/uniq/inverse at [L*list_stride ..), seg_start at [L*(list_stride+1) ..),
+// counts at [2L ..) = {n_segments, n}.
+struct PlanView {
+  int32_t* order = nullptr;      // positions sorted by (id, position)
+  int32_t* seg_start = nullptr;  // segment s = order[seg_start[s] .. seg_start[s+1])
+  int32_t* uniq = nullptr;       // ids in first-occurrence order (tf.unique()[0])
+  int32_t* inverse = nullptr;    // rank of each position's id          (tf.unique()[1])
+  int32_t* counts = nullptr;
+  int64_t list_stride = 0;
+
+  __host__ __device__ PlanView at(int64_t L) const {
+    PlanView v = *this;
+    v.order += L * list_stride;
+    v.seg_start += L * (list_stride + 1);
+    v.uniq += L * list_stride;
+    v.inverse += L * list_stride;
+    v.counts += L * 2;
+    return v;
+  }
+};
+
+int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb,
+                const PlanView& out, int64_t n_lists, hipStream_t stream);
+
+constexpr int kPlanChunk = 64;  // steps planned per launch by the epoch runners
+constexpr int kTile = 32;       // shared-negative tile edge (rows x columns per workgroup)
+
+}  // namespace nncf

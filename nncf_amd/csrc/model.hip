@@ -1,0 +1,295 @@
+// B2 host side: model object, workspaces, per-step entry points and the epoch runners that
+// replace the trainers' inner loops (models/train_original.py:43-68,
+// train_neg_shared.py:46-59, train_group_neg_shared.py:53-68).
+#include <new>
+
+#include "common.h"
+#include "model.h"
+#include "step.h"
+
+using namespace nncf;
+
+struct nncf_model {
+  nncf_model_cfg cfg;
+  float* U = nullptr;
+  float* V = nullptr;
+  int device = 0;
+  void* arena = nullptr;  // one device allocation, carved below
+  OriginalWs ows;
+  SharedWs sws;
+  PlanView plan_u, plan_v;  // kPlanChunk lists each
+  int64_t cap_u = 0, cap_v = 0;
+};
+
+namespace {
+
+StepArgs make_args(const nncf_model* m) {
+  const nncf_model_cfg& c = m->cfg;
+  StepArgs a;
+  a.U = m->U;
+  a.V = m->V;
+  a.stride = c.row_stride;
+  a.d = c.dim;
+  a.b = c.batch_size_p;
+  a.k = c.num_negatives;
+  a.loss = c.loss;
+  a.norm_u = c.normalize_user;
+  a.norm_v = c.normalize_item;
+  a.gamma = c.loss_gamma;
+  a.lambda = c.neg_loss_weight;
+  a.u_reg = c.u_reg;
+  a.lr = c.learn_rate;
+  return a;
+}
+
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+void carve(nncf_model* m, Carver& c) {
+  const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives, d = m->cfg.dim;
+  const int64_t n = b * (1 + k);
+  const int64_t nb = (b + kTile - 1) / kTile;
+  m->ows.g = c.take<float>(n);
+  m->ows.dUp = c.take<float>(b * d);
+  m->ows.Uhat = c.take<float>(b * d);
+  m->ows.loss_part = c.take<float>(b);
+  m->ows.reg_part = c.take<float>(b);
+  m->sws.dU_part = c.take<float>(nb * b * d);
+  m->sws.dV_part = c.take<float>(nb * b * d);
+  m->sws.c_part = c.take<float>(nb * b);
+  m->sws.r_part = c.take<float>(nb * b);
+  m->sws.Uhat = c.take<float>(b * d);
+  m->sws.Vrow = c.take<float>(b * d);
+  m->sws.loss_part = c.take<float>(nb * nb);
+  m->sws.reg_part = c.take<float>(b);
+  m->cap_u = b;
+  m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
+  auto plan = [&](PlanView& v, int64_t cap) {
+    v.list_stride = cap;
+    v.order = c.take<int32_t>(kPlanChunk * cap);
+    v.seg_start = c.take<int32_t>(kPlanChunk * (cap + 1));
+    v.uniq = c.take<int32_t>(kPlanChunk * cap);
+    v.inverse = c.take<int32_t>(kPlanChunk * cap);
+    v.counts = c.take<int32_t>(kPlanChunk * 2);
+  };
+  plan(m->plan_u, m->cap_u);
+  plan(m->plan_v, m->cap_v);
+}
+
+int check_model(const nncf_model* m) {
+  if (!m) return fail(NNCF_ERR_INVALID, "model is NULL");
+  return NNCF_OK;
+}
+
+int check_shared(const nncf_model* m) {
+  if (m->cfg.batch_size_p % kTile != 0)
+    return fail(NNCF_ERR_INVALID, "batch_size_p = %d must be a multiple of %d for the shared-negative schemes",
+                m->cfg.batch_size_p, kTile);
+  return NNCF_OK;
+}
+
+// Plans for steps [t0, t0+cnt) of an epoch (cnt <= kPlanChunk).
+int plan_chunk(nncf_model* m, int scheme, const int32_t* uid_all, const int32_t* cid_all, const int32_t* neg,
+               int64_t t0, int64_t cnt, hipStream_t stream) {
+  const int b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
+  int rc = launch_plan(uid_all + t0 * b, b, b, nullptr, 0, 0, m->plan_u, cnt, stream);
+  if (rc) return rc;
+  PlanView pv = m->plan_v;
+  if (scheme == 0) return launch_plan(cid_all + t0 * b, b, b, neg + t0 * b * k, (int64_t)b * k, b * k, pv, cnt, stream);
+  return launch_plan(cid_all + t0 * b, b, b, nullptr, 0, 0, pv, cnt, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_item_table, int device,
+                      int64_t max_steps, nncf_model** out) {
+  NNCF_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  NNCF_REQUIRE(cfg && d_user_table && d_item_table, "NULL argument");
+  NNCF_REQUIRE(cfg->batch_size_p > 0, "batch_size_p must be positive");
+  NNCF_REQUIRE(cfg->num_negatives >= 0, "num_negatives must be >= 0");
+  NNCF_REQUIRE(cfg->dim > 0 && cfg->dim % 4 == 0 && cfg->dim <= 128, "dim = %d must be a multiple of 4 and <= 128",
+               cfg->dim);
+  NNCF_REQUIRE(cfg->row_stride >= cfg->dim && cfg->row_stride % 4 == 0, "row_stride = %d must be >= dim and a multiple of 4",
+               cfg->row_stride);
+  NNCF_REQUIRE(cfg->loss >= 0 && cfg->loss <= 3, "[ERROR!] loss %d not specified.", cfg->loss);
+  NNCF_REQUIRE((int64_t)cfg->batch_size_p * (1 + cfg->num_negatives) <= 8192,
+               "batch_size_p * (1 + num_negatives) = %lld exceeds the per-step plan capacity 8192",
+               (long long)cfg->batch_size_p * (1 + cfg->num_negatives));
+  NNCF_REQUIRE(cfg->user_count > 0 && cfg->item_count > 0, "empty table");
+  NNCF_REQUIRE(((uintptr_t)d_user_table & 15) == 0 && ((uintptr_t)d_item_table & 15) == 0, "tables must be 16-byte aligned");
+  (void)max_steps;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NNCF_ERR_HIP, "no HIP device: the step kernels have no CPU fallback");
+  NNCF_REQUIRE(device >= 0 && device < ndev, "device %d out of range", device);
+  nncf_model* m = new (std::nothrow) nncf_model();
+  if (!m) return fail(NNCF_ERR_NOMEM, "out of host memory");
+  m->cfg = *cfg;
+  m->U = d_user_table;
+  m->V = d_item_table;
+  m->device = device;
+  Carver dry;
+  carve(m, dry);
+  int prev = 0;
+  hipGetDevice(&prev);
+  hipSetDevice(device);
+  if (hipMalloc(&m->arena, dry.off + 256) != hipSuccess) {
+    delete m;
+    hipSetDevice(prev);
+    return fail(NNCF_ERR_NOMEM, "device workspace allocation (%zu bytes) failed", dry.off);
+  }
+  hipMemset(m->arena, 0, dry.off + 256);
+  hipSetDevice(prev);
+  Carver real;
+  real.base = static_cast<char*>(m->arena);
+  carve(m, real);
+  *out = m;
+  return NNCF_OK;
+}
+
+int nncf_model_destroy(nncf_model* m) {
+  if (!m) return NNCF_OK;
+  if (m->arena) hipFree(m->arena);
+  delete m;
+  return NNCF_OK;
+}
+
+int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg) {
+  if (int rc = check_model(m)) return rc;
+  m->cfg.learn_rate = learn_rate;
+  m->cfg.loss_gamma = loss_gamma;
+  m->cfg.neg_loss_weight = neg_loss_weight;
+  m->cfg.u_reg = u_reg;
+  return NNCF_OK;
+}
+
+int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
+                       void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
+  NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
+  const int b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, b * (1 + k), nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  return launch_original(make_args(m), d_uid, d_cid, d_cid + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st);
+}
+
+int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
+                         void* stream) {
+  if (int rc = check_model(m)) return rc;
+  if (int rc = check_shared(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
+  const int b = m->cfg.batch_size_p;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  return launch_shared(make_args(m), 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+}
+
+int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
+                               int32_t* d_cid_u, int32_t* d_cid_x, int32_t* d_n_u, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  if (int rc = check_shared(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
+  const int b = m->cfg.batch_size_p;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  rc = launch_shared(make_args(m), 1, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  if (rc) return rc;
+  if (d_cid_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_cid_u, m->plan_v.uniq, sizeof(int32_t) * b, hipMemcpyDeviceToDevice, st));
+  if (d_cid_x) NNCF_HIP_CHECK(hipMemcpyAsync(d_cid_x, m->plan_v.inverse, sizeof(int32_t) * b, hipMemcpyDeviceToDevice, st));
+  if (d_n_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_n_u, m->plan_v.counts, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return NNCF_OK;
+}
+
+int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_neg,
+                        int64_t n_steps, float* d_loss, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_neg && d_loss, "NULL argument");
+  NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
+  NNCF_REQUIRE(n_steps >= 0, "negative step count");
+  const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
+  hipStream_t st = as_stream(stream);
+  const StepArgs a = make_args(m);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc = plan_chunk(m, 0, d_uid_all, d_cid_all, d_neg, t0, cnt, st);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t t = t0 + i;
+      rc = launch_original(a, d_uid_all + t * b, d_cid_all + t * b, d_neg + t * b * k, m->ows, m->plan_u.at(i),
+                           m->plan_v.at(i), d_loss + t, 1, st);
+      if (rc) return rc;
+    }
+  }
+  return NNCF_OK;
+}
+
+static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, const int32_t* d_cid_all, int64_t n_steps,
+                        float* d_loss, int32_t* d_n_u, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  if (int rc = check_shared(m)) return rc;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss, "NULL argument");
+  NNCF_REQUIRE(n_steps >= 0, "negative step count");
+  const int64_t b = m->cfg.batch_size_p;
+  hipStream_t st = as_stream(stream);
+  const StepArgs a = make_args(m);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc = plan_chunk(m, 1, d_uid_all, d_cid_all, nullptr, t0, cnt, st);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t t = t0 + i;
+      rc = launch_shared(a, group, d_uid_all + t * b, d_cid_all + t * b, m->sws, m->plan_u.at(i), m->plan_v.at(i),
+                         d_loss + t, 1, st);
+      if (rc) return rc;
+    }
+    if (d_n_u) {
+      // n_u of each planned step (counts[2*i]) -> d_n_u[t0 + i]
+      NNCF_HIP_CHECK(hipMemcpy2DAsync(d_n_u + t0, sizeof(int32_t), m->plan_v.counts, 2 * sizeof(int32_t),
+                                      sizeof(int32_t), (size_t)cnt, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  return NNCF_OK;
+}
+
+int nncf_epoch_neg_shared(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, int64_t n_steps,
+                          float* d_loss, void* stream) {
+  return epoch_shared(m, 0, d_uid_all, d_cid_all, n_steps, d_loss, nullptr, stream);
+}
+
+int nncf_epoch_group_neg_shared(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, int64_t n_steps,
+                                float* d_loss, int32_t* d_n_u, void* stream) {
+  return epoch_shared(m, 1, d_uid_all, d_cid_all, n_steps, d_loss, d_n_u, stream);
+}
+
+int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const int32_t* d_cid, int64_t q, float* d_out,
+                        void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(p >= 0 && q >= 0, "negative shape");
+  if (p == 0 || q == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_uid && d_cid && d_out, "NULL argument");
+  return launch_predict(make_args(m), d_uid, p, d_cid, q, d_out, as_stream(stream));
+}
+
+}  // extern "C"

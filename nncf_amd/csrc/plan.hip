@@ -1,0 +1,187 @@
+// Duplicate-row plans: for one id list per workgroup, sort positions by (id, position) in
+// LDS, cut segments of equal ids, and derive tf.unique-style first-occurrence outputs
+// (model_framework.py:45-48).  Feeds the deterministic scatter-update of the step kernels:
+// every table row touched by a batch is owned by exactly one segment.
+#include "common.h"
+#include "devutil.h"
+#include "model.h"
+
+namespace nncf {
+
+// Exclusive block scan of one int per thread (NT threads), result via LDS scratch[NT].
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
+  const int tid = threadIdx.x;
+  scratch[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < NT; off <<= 1) {
+    int t = (tid >= off) ? scratch[tid - off] : 0;
+    __syncthreads();
+    scratch[tid] += t;
+    __syncthreads();
+  }
+  const int incl = scratch[tid];
+  *total = scratch[NT - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+// ids of list L = concat(ids_a[L*stride_a .. +na), ids_b[L*stride_b .. +nb)); n = na + nb <= CAP.
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ ids_a, int64_t stride_a, int na,
+                                                  const int32_t* __restrict__ ids_b, int64_t stride_b, int nb,
+                                                  PlanView out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);   // CAP
+  int* seg = reinterpret_cast<int*>(key + CAP);                           // CAP: segment of sorted slot
+  int* aux = seg + CAP;                                                   // CAP: first-occurrence flags / ranks
+  int* scratch = aux + CAP;                                               // NT
+  const int tid = threadIdx.x;
+  const int64_t L = blockIdx.x;
+  const int n = na + nb;
+  ids_a += L * stride_a;
+  if (ids_b) ids_b += L * stride_b;
+  int32_t* order = out.order + L * out.list_stride;
+  int32_t* seg_start = out.seg_start + L * (out.list_stride + 1);
+  int32_t* uniq = out.uniq + L * out.list_stride;
+  int32_t* inverse = out.inverse + L * out.list_stride;
+  int32_t* counts = out.counts + L * 2;
+
+  int m = 2;  // sort size: next power of two >= n
+  while (m < n) m <<= 1;
+  for (int i = tid; i < m; i += NT) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      const uint32_t id = (uint32_t)(i < na ? ids_a[i] : ids_b[i - na]);
+      k = ((unsigned long long)id << 32) | (uint32_t)i;
+    }
+    key[i] = k;
+    aux[i] = 0;
+  }
+  __syncthreads();
+  // bitonic sort, ascending by (id, position)
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (m >> 1); t += NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const bool asc = (i & k) == 0;
+        const unsigned long long a = key[i], b = key[l];
+        if ((a > b) == asc) {
+          key[i] = b;
+          key[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // segment heads -> segment index of every sorted slot
+  constexpr int PER = CAP / NT;
+  int head[PER];
+  int local = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int i = tid * PER + e;
+    int h = 0;
+    if (i < n) h = (i == 0) || ((key[i] >> 32) != (key[i - 1] >> 32));
+    head[e] = h;
+    local += h;
+  }
+  int nseg;
+  int run = block_exclusive_scan<NT>(local, scratch, &nseg);
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int i = tid * PER + e;
+    if (i < n) {
+      run += head[e];
+      const int s = run - 1;
+      seg[i] = s;
+      const int pos = (int)(uint32_t)key[i];
+      order[i] = pos;
+      if (head[e]) {
+        seg_start[s] = i;
+        aux[pos] = 1;  // first occurrence (positions ascend inside a segment)
+      }
+    }
+  }
+  if (tid == 0) {
+    seg_start[nseg] = n;
+    counts[0] = nseg;
+    counts[1] = n;
+  }
+  __syncthreads();
+  // rank of every first occurrence, in position order
+  int flag[PER];
+  local = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int p = tid * PER + e;
+    flag[e] = (p < n) ? aux[p] : 0;
+    local += flag[e];
+  }
+  int dummy;
+  run = block_exclusive_scan<NT>(local, scratch, &dummy);
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int p = tid * PER + e;
+    if (p < n) {
+      if (flag[e]) aux[p] = run;  // rank of the id first seen at p
+      run += flag[e];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) {
+    // head slot of this slot's segment (seg_start was written by this block before the barrier)
+    const int hs = seg_start[seg[i]];
+    const int first_pos = (int)(uint32_t)key[hs];
+    const int rank = aux[first_pos];
+    const int pos = (int)(uint32_t)key[i];
+    inverse[pos] = rank;
+    if (i == hs) uniq[rank] = (int32_t)(key[i] >> 32);
+  }
+}
+
+int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb,
+                const PlanView& out, int64_t n_lists, hipStream_t stream) {
+  const int n = na + nb;
+  if (n_lists <= 0 || n <= 0) return NNCF_OK;
+  if (n <= 1024) {
+    constexpr int CAP = 1024, NT = 256;
+    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;
+    hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+                       ids_b, stride_b, nb, out);
+  } else if (n <= 8192) {
+    constexpr int CAP = 8192, NT = 1024;
+    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;  // 132 KiB of the CU's 160 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+                       ids_b, stride_b, nb, out);
+  } else {
+    return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the in-LDS plan capacity (8192)", n);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+}  // namespace nncf
+
+using namespace nncf;
+
+extern "C" int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, int32_t* d_seg_start,
+                             int32_t* d_uniq, int32_t* d_inverse, int32_t* d_counts, void* stream) {
+  NNCF_REQUIRE(d_ids && d_order && d_seg_start && d_uniq && d_inverse && d_counts, "NULL argument");
+  NNCF_REQUIRE(n > 0 && n <= 8192, "n = %d out of range (1..8192)", n);
+  PlanView v;
+  v.order = d_order;
+  v.seg_start = d_seg_start;
+  v.uniq = d_uniq;
+  v.inverse = d_inverse;
+  v.counts = d_counts;
+  v.list_stride = n;
+  return launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, as_stream(stream));
+}

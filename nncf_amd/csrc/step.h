@@ -1,0 +1,52 @@
+// Kernel argument blocks and workspaces of the step kernels.
+#pragma once
+#include <cstdint>
+
+#include "model.h"
+
+namespace nncf {
+
+// Per-launch scalars (copied by value into the kernarg segment).
+struct StepArgs {
+  float* U;  // user table  (user_count x stride)
+  float* V;  // item table  (item_count x stride)
+  int stride, d;
+  int b, k;
+  int loss, norm_u, norm_v;
+  float gamma, lambda, u_reg, lr;
+};
+
+// train_scheme = original
+struct OriginalWs {
+  float* g;          // [b(1+k)]  d(loss)/d(score) per row
+  float* dUp;        // [b][d]    dL/dUhat summed over each positive's 1+k rows
+  float* Uhat;       // [b][d]    (normalised) user row of each positive
+  float* loss_part;  // [b]
+  float* reg_part;   // [b]
+};
+
+// train_scheme = neg_shared / group_neg_shared (b x N score tile grid, 32 x 32 tiles)
+struct SharedWs {
+  float* dU_part;    // [NBJ][b][d]     partial dL/dUhat per column block
+  float* dV_part;    // [NBI][Npad][d]  partial dL/dVhat per row block
+  float* c_part;     // [NBI][Npad]     neg_shared pairwise: partial column sums of h
+  float* r_part;     // [NBJ][b]        group pairwise: partial row sums of h
+  float* Uhat;       // [b][d]          normalised user rows          (pairwise corrections)
+  float* Vrow;       // [b][d]          normalised item row of each batch row's own item
+  float* loss_part;  // [NBI*NBJ]
+  float* reg_part;   // [b]             |U_raw|^2 per batch row
+};
+
+int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
+                    const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
+                    hipStream_t stream);
+
+// group = 0: neg_shared (columns = the b batch items, positive of row i is column i)
+// group = 1: group_neg_shared (columns = unique items of plan pv, positive = pv.inverse[i])
+int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const SharedWs& ws,
+                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream);
+
+int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32_t* cid, int64_t q, float* out,
+                   hipStream_t stream);
+
+}  // namespace nncf

@@ -1,0 +1,174 @@
+"""Thin Python handle over the B2 entry points of libnncf_hip.so: owns the embedding tables
+(torch CUDA tensors = device memory plumbing) and forwards every step to the HIP kernels.
+No arithmetic of the hot path happens in Python or torch."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()
+
+
+class Engine(object):
+    """One parameter set (user table, item table) + one loss/hyper-parameter configuration.
+
+    Several engines may share tables (`share=other`), which is how the reference's
+    loss-monitor models (SGD(0.) clones, model_framework.py:179-193) are expressed."""
+
+    def __init__(self, user_count, item_count, dim, batch_size_p, num_negatives, loss, loss_gamma,
+                 neg_loss_weight, u_reg, learn_rate, normalize_user, normalize_item, device=0, seed=0,
+                 share=None, init_scale=0.05):
+        if loss not in _lib.LOSS_CODES:
+            raise AssertionError("[ERROR!] loss %s not specified." % loss)  # objectives.py:72
+        self._L = _lib.lib()
+        self.device = torch.device("cuda", device)
+        self.dim = int(dim)
+        self.b = int(batch_size_p)
+        self.k = int(num_negatives)
+        self.user_count, self.item_count = int(user_count), int(item_count)
+        if share is None:
+            gen = torch.Generator().manual_seed(int(seed))
+            # Keras-1 Embedding default init: uniform(-0.05, 0.05) [K-mem]
+            U = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
+            V = (torch.rand(self.item_count, self.dim, generator=gen) * 2 - 1) * init_scale
+            self.U = U.to(self.device).contiguous()
+            self.V = V.to(self.device).contiguous()
+        else:
+            self.U, self.V = share.U, share.V
+        cfg = _lib.ModelCfg(self.b, self.k, self.dim, self.dim, _lib.LOSS_CODES[loss], int(bool(normalize_user)),
+                            int(bool(normalize_item)), float(loss_gamma), float(neg_loss_weight), float(u_reg),
+                            float(learn_rate), self.user_count, self.item_count)
+        self.cfg = cfg
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_model_create(ctypes.byref(cfg), _ptr(self.U), _ptr(self.V), self.device.index, 1,
+                                                 ctypes.byref(self._h)))
+        self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # -- helpers -------------------------------------------------------------------------
+    def ids(self, x):
+        """Host or device integer ids -> contiguous int32 CUDA tensor (Keras casts to int32,
+        model_framework.py:37)."""
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(x).reshape(-1)).astype(np.int32)).to(self.device)
+
+    def set_tables(self, U=None, V=None):
+        if U is not None:
+            self.U.copy_(torch.as_tensor(U, dtype=torch.float32))
+        if V is not None:
+            self.V.copy_(torch.as_tensor(V, dtype=torch.float32))
+
+    def set_hparams(self, learn_rate=None, loss_gamma=None, neg_loss_weight=None, u_reg=None):
+        c = self.cfg
+        if learn_rate is not None:
+            c.learn_rate = learn_rate
+        if loss_gamma is not None:
+            c.loss_gamma = loss_gamma
+        if neg_loss_weight is not None:
+            c.neg_loss_weight = neg_loss_weight
+        if u_reg is not None:
+            c.u_reg = u_reg
+        _lib.check(self._L.nncf_model_set_hparams(self._h, c.learn_rate, c.loss_gamma, c.neg_loss_weight, c.u_reg))
+
+    def _stream(self):
+        return _lib.stream_ptr(torch.cuda.current_stream(self.device))
+
+    # -- single steps (device ids in, device loss out; asynchronous) ----------------------
+    def step_original(self, uid, cid, update=True, loss_out=None):
+        out = self._loss1 if loss_out is None else loss_out
+        assert uid.numel() == self.b and cid.numel() == self.b * (1 + self.k)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_step_original(self._h, _ptr(uid), _ptr(cid), _ptr(out), int(update), self._stream()))
+        return out
+
+    def step_neg_shared(self, uid, cid, update=True, loss_out=None):
+        out = self._loss1 if loss_out is None else loss_out
+        assert uid.numel() == self.b and cid.numel() == self.b
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_step_neg_shared(self._h, _ptr(uid), _ptr(cid), _ptr(out), int(update), self._stream()))
+        return out
+
+    def step_group_neg_shared(self, uid, cid, update=True, loss_out=None, want_unique=False):
+        out = self._loss1 if loss_out is None else loss_out
+        assert uid.numel() == self.b and cid.numel() == self.b
+        cu = cx = nu = None
+        if want_unique:
+            cu = torch.empty(self.b, dtype=torch.int32, device=self.device)
+            cx = torch.empty(self.b, dtype=torch.int32, device=self.device)
+            nu = torch.empty(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_step_group_neg_shared(self._h, _ptr(uid), _ptr(cid), _ptr(out), int(update),
+                                                          _ptr(cu), _ptr(cx), _ptr(nu), self._stream()))
+        if want_unique:
+            return out, cu, cx, nu
+        return out
+
+    # -- whole trainer loops (no host sync inside) ----------------------------------------
+    def epoch_original(self, uid_all, cid_all, neg_all, n_steps, loss_out=None):
+        if loss_out is None:
+            loss_out = torch.empty(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        assert uid_all.numel() >= n_steps * self.b and neg_all.numel() >= n_steps * self.b * self.k
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_epoch_original(self._h, _ptr(uid_all), _ptr(cid_all), _ptr(neg_all), int(n_steps),
+                                                   _ptr(loss_out), self._stream()))
+        return loss_out[:n_steps]
+
+    def epoch_neg_shared(self, uid_all, cid_all, n_steps, loss_out=None):
+        if loss_out is None:
+            loss_out = torch.empty(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        assert uid_all.numel() >= n_steps * self.b and cid_all.numel() >= n_steps * self.b
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_epoch_neg_shared(self._h, _ptr(uid_all), _ptr(cid_all), int(n_steps),
+                                                     _ptr(loss_out), self._stream()))
+        return loss_out[:n_steps]
+
+    def epoch_group_neg_shared(self, uid_all, cid_all, n_steps, loss_out=None, n_u_out=None):
+        if loss_out is None:
+            loss_out = torch.empty(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        assert uid_all.numel() >= n_steps * self.b and cid_all.numel() >= n_steps * self.b
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_epoch_group_neg_shared(self._h, _ptr(uid_all), _ptr(cid_all), int(n_steps),
+                                                           _ptr(loss_out), _ptr(n_u_out), self._stream()))
+        return loss_out[:n_steps]
+
+    def predict_scores(self, uid, cid, out=None):
+        p, q = uid.numel(), cid.numel()
+        if out is None:
+            out = torch.empty((p, q), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_predict_scores(self._h, _ptr(uid), p, _ptr(cid), q, _ptr(out), self._stream()))
+        return out
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.nncf_model_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_ids(ids):
+    """Duplicate-row plan of one id list (tests): returns (order, seg_start, uniq, inverse, nseg)."""
+    L = _lib.lib()
+    ids = ids.to(dtype=torch.int32).contiguous()
+    n = ids.numel()
+    dev = ids.device
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    uniq = torch.empty(n, dtype=torch.int32, device=dev)
+    inverse = torch.empty(n, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.nncf_plan_ids(_ptr(ids), n, _ptr(order), _ptr(seg_start), _ptr(uniq), _ptr(inverse), _ptr(counts),
+                                   _lib.stream_ptr(torch.cuda.current_stream(dev))))
+    nseg = int(counts[0].item())
+    return order.cpu().numpy(), seg_start[:nseg + 1].cpu().numpy(), uniq[:nseg].cpu().numpy(), inverse.cpu().numpy(), nseg

@@ -1,0 +1,180 @@
+"""GPU: the HIP step kernels (through the C ABI) against the numpy oracle on identical inputs.
+Tolerances: loss 1e-5 relative (north_star), table rows 1e-5 relative / 2e-6 absolute after the
+update (fp32 summation order differs between MFMA/shuffle reductions and numpy)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+from oracle import step_oracle as so  # noqa: E402
+from nncf_amd.engine import Engine, plan_ids  # noqa: E402
+
+LOSSES = ["skip-gram", "mse", "log-loss", "max-margin"]
+RTOL_LOSS = 1e-5
+
+
+def _mk(loss, b, k, d, nu, ni, model, seed=0, lr=0.05, u_reg=1e-3):
+    gamma = {"max-margin": 0.1, "log-loss": 10.}.get(loss)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=u_reg, learn_rate=lr,
+                         model_choice=model)
+    eng = Engine(nu, ni, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    return conf, eng, orc
+
+
+def _check_tables(eng, orc):
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+
+
+def test_plan_ids_matches_tf_unique():
+    rs = np.random.RandomState(0)
+    for n, hi in [(1, 5), (2, 1), (37, 10), (512, 60), (512, 100000), (1024, 300), (1500, 200), (5632, 900), (8192, 17000)]:
+        ids = rs.randint(0, hi, n)
+        order, seg_start, uniq, inverse, nseg = plan_ids(torch.as_tensor(ids, device="cuda"))
+        u_ref, x_ref = so.tf_unique(ids)
+        assert nseg == len(u_ref)
+        assert np.array_equal(uniq, u_ref) and np.array_equal(inverse, x_ref)
+        # order: positions sorted by (id, position); segments are maximal runs of equal ids
+        keys = ids[order].astype(np.int64) * 100000 + order
+        assert np.all(np.diff(keys) > 0)
+        assert seg_start[0] == 0 and seg_start[-1] == n
+        for s in range(nseg):
+            seg = ids[order[seg_start[s]:seg_start[s + 1]]]
+            assert len(seg) > 0 and np.all(seg == seg[0])
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_original_step_matches_oracle(loss, model):
+    b, k, d = 64, 5, 20
+    conf, eng, orc = _mk(loss, b, k, d, 50, 40, model)
+    rs = np.random.RandomState(1)
+    for step in range(3):
+        pu, pi = rs.randint(0, 50, b), rs.randint(0, 40, b)
+        negs = rs.randint(0, 40, b * k)
+        uid, cid, y = so.assemble_original(np.stack([pu, pi, np.ones(b, dtype=int)], 1), negs, loss)
+        want = orc.step_original(uid, cid, y)
+        got = eng.step_original(eng.ids(uid[:b]), eng.ids(cid)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_neg_shared_step_matches_oracle(loss, model):
+    b, d = 64, 20
+    conf, eng, orc = _mk(loss, b, 0, d, 50, 300, model, seed=2)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        uid, cid = rs.randint(0, 50, b), rs.randint(0, 300, b)
+        cid[5] = cid[40]  # duplicate item => extra negative column, shared row update
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("model", ["mf", "content"])
+def test_group_neg_shared_step_matches_oracle(loss, model):
+    b, d = 64, 20
+    conf, eng, orc = _mk(loss, b, 0, d, 50, 300, model, seed=4)
+    rs = np.random.RandomState(5)
+    for step in range(3):
+        uid = rs.randint(0, 50, b)
+        cid = np.repeat(rs.choice(300, b // 4, replace=False), 4)
+        cid[-1] = cid[0]
+        want = orc.step_group_neg_shared(uid, cid)
+        out, cu, cx, nu = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid), want_unique=True)
+        got = out.item()
+        n_u = int(nu.item())
+        assert n_u == len(orc.cid_u)
+        assert np.array_equal(cu.cpu().numpy()[:n_u], orc.cid_u)  # tf.unique order, bit-exact
+        assert np.array_equal(cx.cpu().numpy(), orc.cid_x)
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
+
+
+@pytest.mark.parametrize("scheme", ["original", "neg_shared", "group_neg_shared"])
+def test_citeulike_shape_d100_b512(scheme):
+    """BASELINE shapes: b = 512, d = 100 (k = 10 for original), 16K users x 17K items."""
+    b, d, k = 512, 100, 10
+    loss = "log-loss" if scheme == "group_neg_shared" else "skip-gram"
+    conf, eng, orc = _mk(loss, b, k, d, 16000, 17000, "mf", seed=6, lr=0.01, u_reg=1e-6)
+    rs = np.random.RandomState(7)
+    zipf = 1.0 / np.arange(1, 17001)
+    zipf /= zipf.sum()
+    for step in range(2):
+        uid = rs.randint(0, 16000, b)
+        if scheme == "group_neg_shared":
+            cid = np.repeat(rs.choice(17000, b // 4, p=zipf), 4)
+        else:
+            cid = rs.choice(17000, b, p=zipf)
+        if scheme == "original":
+            negs = rs.choice(17000, b * k, p=zipf)
+            u, c, y = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=int)], 1), negs, loss)
+            want = orc.step_original(u, c, y)
+            got = eng.step_original(eng.ids(uid), eng.ids(c)).item()
+        elif scheme == "neg_shared":
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
+
+
+def test_forward_only_leaves_tables_untouched():
+    conf, eng, orc = _mk("skip-gram", 64, 0, 20, 50, 300, "mf", seed=8)
+    U0, V0 = eng.U.clone(), eng.V.clone()
+    rs = np.random.RandomState(9)
+    uid, cid = rs.randint(0, 50, 64), rs.randint(0, 300, 64)
+    want = orc.step_neg_shared(uid, cid, update=False)
+    got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid), update=False).item()
+    assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want))
+    assert torch.equal(U0, eng.U) and torch.equal(V0, eng.V)
+
+
+def test_predict_scores_matches_oracle():
+    for model, loss in [("mf", "skip-gram"), ("mf", "log-loss"), ("content", "log-loss")]:
+        conf, eng, orc = _mk(loss, 64, 0, 100, 300, 500, model, seed=10)
+        rs = np.random.RandomState(11)
+        uid, cid = rs.randint(0, 300, 77), rs.randint(0, 500, 45)  # ragged: not multiples of the tile
+        got = eng.predict_scores(eng.ids(uid), eng.ids(cid)).cpu().numpy()
+        want = orc.predict_neg_shared(uid, cid)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_epoch_runner_equals_step_by_step():
+    """nncf_epoch_* (no host sync, chunked plans) == the same steps issued one by one; bitwise."""
+    b, d, k, steps = 64, 20, 3, 70  # > one plan chunk (64)
+    rs = np.random.RandomState(12)
+    uid_all, cid_all = rs.randint(0, 50, b * steps), rs.randint(0, 300, b * steps)
+    neg_all = rs.randint(0, 300, b * k * steps)
+    for scheme in ("original", "neg_shared", "group_neg_shared"):
+        _, e1, _ = _mk("log-loss", b, k, d, 50, 300, "mf", seed=13)
+        _, e2, _ = _mk("log-loss", b, k, d, 50, 300, "mf", seed=13)
+        ua, ca, na = e1.ids(uid_all), e1.ids(cid_all), e1.ids(neg_all)
+        if scheme == "original":
+            l1 = e1.epoch_original(ua, ca, na, steps).cpu().numpy()
+        elif scheme == "neg_shared":
+            l1 = e1.epoch_neg_shared(ua, ca, steps).cpu().numpy()
+        else:
+            l1 = e1.epoch_group_neg_shared(ua, ca, steps).cpu().numpy()
+        l2 = []
+        for t in range(steps):
+            u, c = ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]
+            if scheme == "original":
+                cc = torch.cat([c, na[t * b * k:(t + 1) * b * k]])
+                l2.append(e2.step_original(u, cc).item())
+            elif scheme == "neg_shared":
+                l2.append(e2.step_neg_shared(u, c).item())
+            else:
+                l2.append(e2.step_group_neg_shared(u, c).item())
+        assert np.array_equal(l1, np.array(l2, dtype=np.float32)), scheme
+        assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V), scheme
