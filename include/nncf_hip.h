@@ -154,6 +154,18 @@ int nncf_model_destroy(nncf_model* m);
 /* learn_rate / loss hyper-parameters may change between steps (same shapes). */
 int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg);
 
+/* Measurement hook (bench.py roofline leg; no reference counterpart): between _begin and
+ * _end every nncf_epoch_* step brackets its dominant kernel (the score kernel of `original`,
+ * the U.V^T tile kernel of the shared-negative schemes) with HIP events on the launch stream,
+ * for at most max_launches launches.  _end synchronises those events and returns the mean
+ * kernel duration in milliseconds. */
+int nncf_model_profile_begin(nncf_model* m, int64_t max_launches);
+int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches);
+
+/* Developer hook: per-workgroup s_memtime stamps of the last tile-kernel launch (only when the
+ * model was created with NNCF_DEBUG_TIMING=1 in the environment).  Synchronous copy. */
+int nncf_model_debug_stamps(nncf_model* m, long long* out_host, int64_t n);
+
 /* model.train_on_batch for train_scheme=original (models/train_original.py:49-58 with the
  * 'model' head, model_framework.py:123,147-149; loss objectives.py:35-75).
  *   d_uid[b]         users of the b positives (row j of the negatives reuses user j / k)

@@ -1,6 +1,7 @@
 // B2 host side: model object, workspaces, per-step entry points and the epoch runners that
 // replace the trainers' inner loops (models/train_original.py:43-68,
 // train_neg_shared.py:46-59, train_group_neg_shared.py:53-68).
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -19,6 +20,7 @@ struct nncf_model {
   SharedWs sws;
   PlanView plan_u, plan_v;  // kPlanChunk lists each
   int64_t cap_u = 0, cap_v = 0;
+  KernelProfiler prof;
 };
 
 namespace {
@@ -71,6 +73,7 @@ void carve(nncf_model* m, Carver& c) {
   m->sws.Vrow = c.take<float>(b * d);
   m->sws.loss_part = c.take<float>(nb * nb);
   m->sws.reg_part = c.take<float>(b);
+  m->sws.dbg = getenv("NNCF_DEBUG_TIMING") ? c.take<long long>(nb * nb * 8) : nullptr;
   m->cap_u = b;
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
   auto plan = [&](PlanView& v, int64_t cap) {
@@ -162,7 +165,50 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
 int nncf_model_destroy(nncf_model* m) {
   if (!m) return NNCF_OK;
   if (m->arena) hipFree(m->arena);
+  for (hipEvent_t e : m->prof.start) hipEventDestroy(e);
+  for (hipEvent_t e : m->prof.stop) hipEventDestroy(e);
   delete m;
+  return NNCF_OK;
+}
+
+int nncf_model_profile_begin(nncf_model* m, int64_t max_launches) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(max_launches > 0 && max_launches <= 65536, "max_launches out of range");
+  KernelProfiler& p = m->prof;
+  while ((int64_t)p.start.size() < max_launches) {
+    hipEvent_t a, b;
+    NNCF_HIP_CHECK(hipEventCreate(&a));
+    NNCF_HIP_CHECK(hipEventCreate(&b));
+    p.start.push_back(a);
+    p.stop.push_back(b);
+  }
+  p.used = 0;
+  p.enabled = true;
+  return NNCF_OK;
+}
+
+int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(avg_ms && launches, "NULL argument");
+  KernelProfiler& p = m->prof;
+  p.enabled = false;
+  double total = 0;
+  for (size_t i = 0; i < p.used; ++i) {
+    NNCF_HIP_CHECK(hipEventSynchronize(p.stop[i]));
+    float ms = 0;
+    NNCF_HIP_CHECK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+    total += ms;
+  }
+  *launches = (int64_t)p.used;
+  *avg_ms = p.used ? total / (double)p.used : 0.0;
+  p.used = 0;
+  return NNCF_OK;
+}
+
+int nncf_model_debug_stamps(nncf_model* m, long long* out_host, int64_t n) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(m->sws.dbg != nullptr, "model was created without NNCF_DEBUG_TIMING=1");
+  NNCF_HIP_CHECK(hipMemcpy(out_host, m->sws.dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
   return NNCF_OK;
 }
 
@@ -238,7 +284,7 @@ int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* 
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
       rc = launch_original(a, d_uid_all + t * b, d_cid_all + t * b, d_neg + t * b * k, m->ows, m->plan_u.at(i),
-                           m->plan_v.at(i), d_loss + t, 1, st);
+                           m->plan_v.at(i), d_loss + t, 1, st, &m->prof);
       if (rc) return rc;
     }
   }
@@ -261,7 +307,7 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
       rc = launch_shared(a, group, d_uid_all + t * b, d_cid_all + t * b, m->sws, m->plan_u.at(i), m->plan_v.at(i),
-                         d_loss + t, 1, st);
+                         d_loss + t, 1, st, &m->prof);
       if (rc) return rc;
     }
     if (d_n_u) {

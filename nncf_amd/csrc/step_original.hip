@@ -175,9 +175,12 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, const i
 
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
                     const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
-                    hipStream_t stream) {
+                    hipStream_t stream, KernelProfiler* prof) {
   const int b = a.b;
+  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
+  if (ev) NNCF_HIP_CHECK(hipEventRecord(*ev, stream));
   hipLaunchKernelGGL(original_score_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos, cid_neg, ws);
+  if (ev) NNCF_HIP_CHECK(hipEventRecord(prof->stop[prof->used++], stream));
   // upper bound on segments: b users + b(1+k) items; 8 half-waves per block; +1 block so the
   // last wave of the grid is always free for the loss reduction.
   const int max_seg = b + b * (1 + a.k);

@@ -30,7 +30,7 @@ namespace nncf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxD = 128;
-constexpr int kMaxDP = kMaxD + 2;  // LDS row pitch d+2: (d+2) mod 4 == 2 => conflict-free fragment reads
+constexpr int kMaxDP = kMaxD + 2;  // LDS row pitch round_up(d,16)+2
 constexpr int kGP = kTile + 1;     // pitch of the gradient tile
 
 __device__ __forceinline__ void lds_store_row(float* dst, int q, int d4, float4 v) {
@@ -40,6 +40,11 @@ __device__ __forceinline__ void lds_store_row(float* dst, int q, int d4, float4 
     p[1] = make_float2(v.z, v.w);
   }
 }
+
+#define NNCF_STAMP(k)                                                              \
+  do {                                                                             \
+    if (ws.dbg && tid == 0) ws.dbg[((int64_t)bi * gridDim.x + bj) * 8 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
 
 __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group, const int32_t* __restrict__ uid,
                                                           const int32_t* __restrict__ cid, SharedWs ws,
@@ -57,54 +62,77 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
   const int b = a.b;
   const int N = group ? pv.counts[0] : b;
   if (bj * kTile >= N) return;
-  const int d = a.d, d4 = d >> 2, DP = d + 2;
+  const int d = a.d, d4 = d >> 2;
+  const int NP = (d + 15) & ~15;  // columns the back-GEMMs sweep (zero-padded past d)
+  const int DP = NP + 2;          // LDS row pitch: DP mod 4 == 2 => conflict-free fragment reads
   const bool pairwise = a.loss >= NNCF_LOSS_LOG_LOSS;
   const int nbj_max = b / kTile;
+  NNCF_STAMP(0);
 
   // ---- gather + normalise rows into LDS (half-wave per row) --------------------------
+  // Lane t of each half-wave fetches the id of the half-wave's t-th row; all row loads are
+  // then issued before the first is consumed: two memory round trips per tile in total.
   {
-    const int hw = tid >> 5, q = tid & 31;
     const int nrows = pairwise ? 3 * kTile : 2 * kTile;
-    for (int idx = hw; idx < nrows; idx += 8) {
-      const int mtx = idx >> 5, r = idx & 31;
-      if (mtx == 0) {
+    const int hw = tid >> 5, q = tid & 31;
+    int myid = -1;
+    {
+      const int idx = hw + 8 * q;  // row handled as this half-wave's q-th
+      if (idx < nrows) {
+        const int mtx = idx >> 5, r = idx & 31;
+        if (mtx == 0) {
+          myid = uid[bi * kTile + r];
+        } else if (mtx == 1) {
+          const int j = bj * kTile + r;
+          if (j < N) myid = group ? pv.uniq[j] : cid[j];
+        } else {
+          // neg_shared pairwise: user rows of this tile's COLUMNS (diag S[j,j] = Uhat_j . Vhat_j)
+          // group pairwise: item row of each of this tile's ROWS (S[i,pos_i] = Uhat_i . Vhat_cid[i])
+          myid = group ? cid[bi * kTile + r] : uid[bj * kTile + r];
+        }
+      }
+    }
+    if (tid < kTile) sPos[tid] = group ? pv.inverse[bi * kTile + tid] : bi * kTile + tid;
+    // zero the pad columns [d, NP) of the two operand tiles (read by the back-GEMMs)
+    for (int e = tid; e < 2 * kTile * (NP - d); e += 256) {
+      const int m = e / (kTile * (NP - d)), rem = e % (kTile * (NP - d));
+      (m ? sV : sU)[(rem / (NP - d)) * DP + d + rem % (NP - d)] = 0.f;
+    }
+    NNCF_STAMP(1);
+    float4 v[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      const int id = __shfl(myid, (lane & 32) + t);
+      const float* tab = (t < 4) ? a.U : (t < 8) ? a.V : (group ? a.V : a.U);
+      v[t] = zero4();
+      if (hw + 8 * t < nrows && id >= 0) v[t] = load_row4(tab, id, a.stride, d4, q);
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      const int idx = hw + 8 * t;
+      if (idx >= nrows) break;
+      const int r = idx & 31;
+      const float ss = half_sum(dot4(v[t], v[t]));
+      const bool norm = (t < 4) ? a.norm_u : (t < 8) ? a.norm_v : (group ? a.norm_v : a.norm_u);
+      const float4 hat = norm ? scale4(v[t], inv_norm(ss)) : v[t];
+      if (t < 4) {
         const int i = bi * kTile + r;
-        const float4 raw = load_row4(a.U, uid[i], a.stride, d4, q);
-        const float ss = half_sum(dot4(raw, raw));
-        const float4 hat = a.norm_u ? scale4(raw, inv_norm(ss)) : raw;
         lds_store_row(sU + r * DP, q, d4, hat);
         if (bj == 0) {
           if (q == 0) ws.reg_part[i] = ss;
           if (pairwise) store_row4(ws.Uhat, i, d, d4, q, hat);
         }
-      } else if (mtx == 1) {
-        const int j = bj * kTile + r;
-        float4 hat = zero4();
-        if (j < N) {
-          const int64_t c = group ? pv.uniq[j] : cid[j];
-          hat = load_row4(a.V, c, a.stride, d4, q);
-        }
-        if (a.norm_v) hat = scale4(hat, inv_norm(half_sum(dot4(hat, hat))));
+      } else if (t < 8) {
         lds_store_row(sV + r * DP, q, d4, hat);
-        if (!group && pairwise && bi == 0) store_row4(ws.Vrow, j, d, d4, q, hat);
-      } else if (!group) {
-        // neg_shared pairwise: user rows of this tile's COLUMNS (diag S[j,j] = Uhat_j . Vhat_j)
-        const int j = bj * kTile + r;
-        float4 hat = load_row4(a.U, uid[j], a.stride, d4, q);
-        if (a.norm_u) hat = scale4(hat, inv_norm(half_sum(dot4(hat, hat))));
-        lds_store_row(sX + r * DP, q, d4, hat);
+        if (!group && pairwise && bi == 0) store_row4(ws.Vrow, bj * kTile + r, d, d4, q, hat);
       } else {
-        // group pairwise: the item row of each of this tile's ROWS (S[i,pos_i] = Uhat_i . Vhat_cid[i])
-        const int i = bi * kTile + r;
-        float4 hat = load_row4(a.V, cid[i], a.stride, d4, q);
-        if (a.norm_v) hat = scale4(hat, inv_norm(half_sum(dot4(hat, hat))));
         lds_store_row(sX + r * DP, q, d4, hat);
-        if (bj == 0) store_row4(ws.Vrow, i, d, d4, q, hat);
+        if (group && bj == 0) store_row4(ws.Vrow, bi * kTile + r, d, d4, q, hat);
       }
     }
-    if (tid < kTile) sPos[tid] = group ? pv.inverse[bi * kTile + tid] : bi * kTile + tid;
   }
   __syncthreads();
+  NNCF_STAMP(2);
 
   // ---- positive scores the pairwise losses anchor on ---------------------------------
   if (pairwise) {
@@ -121,14 +149,33 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
   }
 
   // ---- S tile: one 16x16 sub-tile per wave, K = d in steps of 4 ----------------------
+  // Two independent accumulators (even / odd k-steps) hide the 40-cycle dependent MFMA
+  // latency; the unrolled body lets the LDS fragment reads run ahead of the MFMAs.
   const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc;
   {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float* pa = sU + (wr * 16 + (lane & 15)) * DP + (lane >> 4);
     const float* pb = sV + (wc * 16 + (lane & 15)) * DP + (lane >> 4);
-    for (int kk = 0; kk < d4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
+    int kk = 0;
+    for (; kk + 8 <= d4; kk += 8) {
+      float fa[8], fb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fa[e] = pa[4 * (kk + e)];
+        fb[e] = pb[4 * (kk + e)];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e + 1], fb[e + 1], acc1, 0, 0, 0);
+      }
+    }
+    for (; kk < d4; ++kk) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], pb[4 * kk], acc0, 0, 0, 0);
+    acc = acc0 + acc1;
   }
 
+  NNCF_STAMP(3);
   // ---- loss + gradient, element-wise on the accumulator ------------------------------
   float lsum = 0.f;
   {
@@ -147,9 +194,11 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
       if (valid) {
         switch (a.loss) {
           case NNCF_LOSS_SKIP_GRAM: {
-            const float y = is_pos ? 1.f : -1.f, w = is_pos ? 1.f : wneg;
-            l = w * softplusf(-y * s) * inv_b;
-            h = -w * y * sigmoidf(-y * s) * inv_b;
+            const float y = is_pos ? 1.f : -1.f, w = (is_pos ? 1.f : wneg) * inv_b;
+            float sp, sg;
+            softplus_sigmoid(-y * s, sp, sg);
+            l = w * sp;
+            h = -w * y * sg;
           } break;
           case NNCF_LOSS_MSE: {
             const float y = is_pos ? 1.f : 0.f, w = is_pos ? 1.f : wneg;
@@ -160,9 +209,10 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
             if (is_pos) {
               l = 0.6931471805599453f * inv_m;  // -log sigmoid(0)
             } else {
-              const float x = a.gamma * ((group ? sD[row] : sD[col]) - s);
-              l = softplusf(-x) * inv_m;
-              h = a.gamma * sigmoidf(-x) * inv_m;
+              float sp, sg;
+              softplus_sigmoid(-a.gamma * ((group ? sD[row] : sD[col]) - s), sp, sg);
+              l = sp * inv_m;
+              h = a.gamma * sg * inv_m;
             }
           } break;
           default: {  // max-margin
@@ -184,6 +234,7 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
   lsum = wave_sum(lsum);
   if (lane == 0) sRed[wave] = lsum;
   __syncthreads();
+  NNCF_STAMP(4);
   if (tid == 0) ws.loss_part[bi * nbj_max + bj] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
   if (pairwise && tid < kTile) {
     float t = 0.f;
@@ -196,7 +247,10 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
     }
   }
 
+  NNCF_STAMP(5);
   // ---- back-GEMMs: waves 0,1 -> dU = G . V ; waves 2,3 -> dV = G^T . U ----------------
+  // K = 32 (this tile's columns resp. rows); per pair of 16-wide output tiles the 16 B
+  // fragments are fetched first, then 16 MFMAs on two independent accumulators.
   {
     const bool isV = wave >= 2;
     const int mt = wave & 1;
@@ -206,40 +260,72 @@ __global__ void __launch_bounds__(256) shared_tile_kernel(StepArgs a, int group,
       const int kidx = 4 * kk + (lane >> 4), m = mt * 16 + (lane & 15);
       afrag[kk] = isV ? sG[kidx * kGP + m] : sG[m * kGP + kidx];
     }
-    const float* B = isV ? sU : sV;
-    float* slab = isV ? ws.dV_part + ((int64_t)bi * b + bj * kTile) * d : ws.dU_part + ((int64_t)bj * b + bi * kTile) * d;
-    const int ntiles = (d + 15) >> 4;
+    const float* B = (isV ? sU : sV) + (lane >> 4) * DP + (lane & 15);
+    float* slab = (isV ? ws.dV_part + ((int64_t)bi * b + bj * kTile) * d : ws.dU_part + ((int64_t)bj * b + bi * kTile) * d) +
+                  (int64_t)(mt * 16 + (lane >> 4) * 4) * d + (lane & 15);
+    const int ntiles = NP >> 4;
     for (int nt = 0; nt < ntiles; nt += 2) {
-      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-      const int n0 = nt * 16 + (lane & 15), n1 = n0 + 16;
-      const bool ok0 = n0 < d, ok1 = n1 < d;
-      const int n0c = ok0 ? n0 : 0, n1c = ok1 ? n1 : 0;
+      const bool two = nt + 1 < ntiles;
+      float b0[8], b1[8];
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const float* brow = B + (4 * kk + (lane >> 4)) * DP;
-        const float b0 = ok0 ? brow[n0c] : 0.f;
-        const float b1 = ok1 ? brow[n1c] : 0.f;
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b1, c1, 0, 0, 0);
+        b0[kk] = B[4 * kk * DP + nt * 16];
+        b1[kk] = two ? B[4 * kk * DP + nt * 16 + 16] : 0.f;
       }
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b0[kk], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b1[kk], c1, 0, 0, 0);
+      }
+      const int n0 = nt * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + (lane >> 4) * 4 + r;
-        if (ok0) slab[(int64_t)m * d + n0] = c0[r];
-        if (ok1) slab[(int64_t)m * d + n1] = c1[r];
+        if (n0 < d) slab[(int64_t)r * d + nt * 16] = c0[r];
+        if (two && n0 + 16 < d) slab[(int64_t)r * d + nt * 16 + 16] = c1[r];
       }
     }
   }
+  NNCF_STAMP(6);
 }
 
-// One half-wave per touched table row.  Half-waves [0, nseg_u) own user rows, the next
-// nseg_v own item rows; the last wave of the grid reduces the loss.
+// Sum of `cnt` slab rows (row `row` of slabs 0..cnt-1, slab stride `sstride` rows), lanes of
+// half h take slabs h, h+2, ...; eight loads in flight per lane; halves folded at the end.
+__device__ __forceinline__ float4 slab_sum(const float* __restrict__ base, int64_t sstride, int cnt, int row, int d,
+                                           int d4, int q, int half) {
+  float4 acc = zero4();
+  for (int j0 = 0; j0 < cnt; j0 += 16) {
+    float4 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = j0 + 2 * e + half;
+      t[e] = (j < cnt) ? load_row4(base, (int64_t)j * sstride + row, d, d4, q) : zero4();
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = add4(acc, t[e]);
+  }
+  acc.x += __shfl_xor(acc.x, 32);
+  acc.y += __shfl_xor(acc.y, 32);
+  acc.z += __shfl_xor(acc.z, 32);
+  acc.w += __shfl_xor(acc.w, 32);
+  return acc;
+}
+
+// Sum of cnt scalars part[j * sstride + idx], j < cnt (one load per lane, fixed tree).
+__device__ __forceinline__ float part_sum(const float* __restrict__ part, int64_t sstride, int cnt, int idx, int lane) {
+  float w = 0.f;
+  for (int j = lane; j < cnt; j += 64) w += part[(int64_t)j * sstride + idx];
+  return wave_sum(w);
+}
+
+// One wave per touched table row.  Waves [0, nseg_u) own user rows, the next nseg_v own item
+// rows; the last wave of the grid reduces the loss.
 __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, int group, const int32_t* __restrict__ uid,
                                                            const int32_t* __restrict__ cid, SharedWs ws, PlanView pu,
                                                            PlanView pv, float* __restrict__ loss_out, int update) {
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, q = lane & 31;
-  const int hw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int b = a.b, d = a.d, d4 = d >> 2;
   const int N = group ? pv.counts[0] : b;
   const int nbi = b / kTile, nbj = (N + kTile - 1) / kTile, nbj_max = b / kTile;
@@ -257,23 +343,21 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, int group
   }
   if (!update) return;
 
-  if (hw < nseg_u) {
-    const int s0 = pu.seg_start[hw], s1 = pu.seg_start[hw + 1];
+  if (w < nseg_u) {
+    const int s0 = pu.seg_start[w], s1 = pu.seg_start[w + 1];
     const int64_t u = uid[pu.order[s0]];
+    const float4 uraw = load_row4(a.U, u, a.stride, d4, q);
     float4 acc = zero4();
     for (int t = s0; t < s1; ++t) {
       const int i = pu.order[t];
-      float4 row = zero4();
-      for (int j = 0; j < nbj; ++j) row = add4(row, load_row4(ws.dU_part, (int64_t)j * b + i, d, d4, q));
+      float4 row = slab_sum(ws.dU_part, b, nbj, i, d, d4, q, half);
       if (pairwise) {
-        float w = 0.f;
-        if (!group) for (int r = 0; r < nbi; ++r) w += ws.c_part[(int64_t)r * b + i];
-        else for (int j = 0; j < nbj; ++j) w += ws.r_part[(int64_t)j * b + i];
-        row = fma4(-w, load_row4(ws.Vrow, i, d, d4, q), row);  // - (sum of h) * Vhat of the positive
+        // - (sum of h over the positive's column / row) * Vhat of the positive
+        const float hs = group ? part_sum(ws.r_part, b, nbj, i, lane) : part_sum(ws.c_part, b, nbi, i, lane);
+        row = fma4(-hs, load_row4(ws.Vrow, i, d, d4, q), row);
       }
       acc = add4(acc, row);
     }
-    const float4 uraw = load_row4(a.U, u, a.stride, d4, q);
     float4 g = acc;
     if (a.norm_u) {
       const float ss = half_sum(dot4(uraw, uraw));
@@ -281,45 +365,42 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, int group
       g = norm_backward(scale4(uraw, inv), inv, ss, acc);
     }
     g = fma4(2.f * a.u_reg * (float)(s1 - s0) / (float)b, uraw, g);
-    store_row4(a.U, u, a.stride, d4, q, fma4(-a.lr, g, uraw));
-  } else if (hw < nseg_u + nseg_v) {
-    const int sv = hw - nseg_u;
+    if (half == 0) store_row4(a.U, u, a.stride, d4, q, fma4(-a.lr, g, uraw));
+  } else if (w < nseg_u + nseg_v) {
+    const int sv = w - nseg_u;
     const int s0 = pv.seg_start[sv], s1 = pv.seg_start[sv + 1];
     const int first = pv.order[s0];
     const int64_t c = cid[first];
+    const float4 vraw = load_row4(a.V, c, a.stride, d4, q);
     float4 acc = zero4();
     if (!group) {
       for (int t = s0; t < s1; ++t) {
         const int j = pv.order[t];
-        float4 colv = zero4();
-        for (int r = 0; r < nbi; ++r) colv = add4(colv, load_row4(ws.dV_part, (int64_t)r * b + j, d, d4, q));
+        float4 colv = slab_sum(ws.dV_part, b, nbi, j, d, d4, q, half);
         if (pairwise) {
-          float w = 0.f;
-          for (int r = 0; r < nbi; ++r) w += ws.c_part[(int64_t)r * b + j];
-          colv = fma4(-w, load_row4(ws.Uhat, j, d, d4, q), colv);
+          const float hs = part_sum(ws.c_part, b, nbi, j, lane);
+          colv = fma4(-hs, load_row4(ws.Uhat, j, d, d4, q), colv);
         }
         acc = add4(acc, colv);
       }
     } else {
       const int j = pv.inverse[first];  // this item's column
-      for (int r = 0; r < nbi; ++r) acc = add4(acc, load_row4(ws.dV_part, (int64_t)r * b + j, d, d4, q));
+      acc = slab_sum(ws.dV_part, b, nbi, j, d, d4, q, half);
       if (pairwise) {
         for (int t = s0; t < s1; ++t) {
           const int i = pv.order[t];
-          float w = 0.f;
-          for (int jj = 0; jj < nbj; ++jj) w += ws.r_part[(int64_t)jj * b + i];
-          acc = fma4(-w, load_row4(ws.Uhat, i, d, d4, q), acc);
+          const float hs = part_sum(ws.r_part, b, nbj, i, lane);
+          acc = fma4(-hs, load_row4(ws.Uhat, i, d, d4, q), acc);
         }
       }
     }
-    const float4 vraw = load_row4(a.V, c, a.stride, d4, q);
     float4 g = acc;
     if (a.norm_v) {
       const float ss = half_sum(dot4(vraw, vraw));
       const float inv = inv_norm(ss);
       g = norm_backward(scale4(vraw, inv), inv, ss, acc);
     }
-    store_row4(a.V, c, a.stride, d4, q, fma4(-a.lr, g, vraw));
+    if (half == 0) store_row4(a.V, c, a.stride, d4, q, fma4(-a.lr, g, vraw));
   }
 }
 
@@ -365,10 +446,14 @@ __global__ void __launch_bounds__(256) predict_tile_kernel(StepArgs a, const int
 }
 
 int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const SharedWs& ws,
-                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
+                  KernelProfiler* prof) {
   const int nb = a.b / kTile;
+  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
+  if (ev) NNCF_HIP_CHECK(hipEventRecord(*ev, stream));
   hipLaunchKernelGGL(shared_tile_kernel, dim3(nb, nb), dim3(256), 0, stream, a, group, uid, cid, ws, pv);
-  const int blocks = (2 * a.b + 7) / 8 + 1;
+  if (ev) NNCF_HIP_CHECK(hipEventRecord(prof->stop[prof->used++], stream));
+  const int blocks = (2 * a.b + 3) / 4 + 1;  // one wave per touched row (+ the loss wave)
   hipLaunchKernelGGL(shared_apply_kernel, dim3(blocks), dim3(256), 0, stream, a, group, uid, cid, ws, pu, pv, loss_out,
                      update);
   NNCF_HIP_CHECK(hipGetLastError());

@@ -144,6 +144,15 @@ class Engine(object):
             _lib.check(self._L.nncf_predict_scores(self._h, _ptr(uid), p, _ptr(cid), q, _ptr(out), self._stream()))
         return out
 
+    def profile_begin(self, max_launches):
+        _lib.check(self._L.nncf_model_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        """(mean kernel ms, launches) of the dominant kernel since profile_begin."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._L.nncf_model_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
