@@ -208,9 +208,14 @@ int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const in
 
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
  * segment starts, and tf.unique-style first-occurrence outputs.
- *   d_order[n], d_seg_start[n+1], d_uniq[n], d_inverse[n], d_counts[2] = {n_segments, n}. */
+ *   d_order[n], d_seg_start[n+1], d_uniq[n], d_inverse[n],
+ *   d_counts[4] = {n_segments, n, n_chunks, 0},
+ *   d_desc[4n] = per segment {id, first position, start in d_order, count} (16-byte aligned),
+ *   d_slot_seg[n] = segment of every sorted slot,
+ *   d_chunk_start[n/16 + 2] = slot ranges of whole segments handed to one apply workgroup. */
 int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, int32_t* d_seg_start, int32_t* d_uniq,
-                  int32_t* d_inverse, int32_t* d_counts, void* stream);
+                  int32_t* d_inverse, int32_t* d_counts, int32_t* d_desc, int32_t* d_slot_seg,
+                  int32_t* d_chunk_start, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,8 @@
 // Device-side helpers shared by the step kernels (gfx950, wave64).
+//
+// Embedding rows are handled by 16-lane groups (one DPP row): lane q of the group owns floats
+// [4q, 4q+4) and [64+4q, 64+4q+4) of the row (two 16-byte loads, d <= 128), so that every
+// row-wide reduction is four DPP adds inside one row -- no LDS-crossbar shuffles.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -9,19 +13,26 @@ namespace nncf {
 constexpr int kWave = 64;
 constexpr float kNormEps = 1e-12f;  // tf.nn.l2_normalize epsilon (model_framework.py:63)
 
-// Sum over the 32 lanes of a half-wave (xor offsets < 32 never cross the half boundary).
-__device__ __forceinline__ float half_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 16 lanes of a DPP row; every lane of the row receives the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]  (lane ^ 1)
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]  (lane ^ 2)
+  v += dpp_f<0x141>(v);  // row_half_mirror      (other quad of the 8-lane half row)
+  v += dpp_f<0x140>(v);  // row_mirror           (other half row)
   return v;
 }
 
+// Sum over all 64 lanes (result in every lane).
 __device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
-  return half_sum(v);
+  return v;
 }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -32,30 +43,37 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// One embedding row: lane q (0..31) of a half-wave holds floats [4q, 4q+4) (zeros past d).
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ table, int64_t row, int stride, int d4, int q) {
-  if (q < d4) return reinterpret_cast<const float4*>(table + row * (int64_t)stride)[q];
-  return zero4();
+// One embedding row spread over a 16-lane group.
+struct Row {
+  float4 a, b;
+};
+__device__ __forceinline__ Row row_zero() { return Row{zero4(), zero4()}; }
+__device__ __forceinline__ Row row_load(const float* __restrict__ table, int64_t row, int stride, int d4, int q) {
+  const float4* p = reinterpret_cast<const float4*>(table + row * (int64_t)stride);
+  Row r;
+  r.a = (q < d4) ? p[q] : zero4();
+  r.b = (q + 16 < d4) ? p[q + 16] : zero4();
+  return r;
 }
-__device__ __forceinline__ void store_row4(float* __restrict__ table, int64_t row, int stride, int d4, int q, float4 v) {
-  if (q < d4) reinterpret_cast<float4*>(table + row * (int64_t)stride)[q] = v;
+__device__ __forceinline__ void row_store(float* __restrict__ table, int64_t row, int stride, int d4, int q, Row r) {
+  float4* p = reinterpret_cast<float4*>(table + row * (int64_t)stride);
+  if (q < d4) p[q] = r.a;
+  if (q + 16 < d4) p[q + 16] = r.b;
 }
+__device__ __forceinline__ float row_dot_partial(Row x, Row y) { return dot4(x.a, y.a) + dot4(x.b, y.b); }
+__device__ __forceinline__ float row_dot(Row x, Row y) { return row16_sum(row_dot_partial(x, y)); }
+__device__ __forceinline__ Row row_scale(Row x, float s) { return Row{scale4(x.a, s), scale4(x.b, s)}; }
+__device__ __forceinline__ Row row_fma(float s, Row x, Row c) { return Row{fma4(s, x.a, c.a), fma4(s, x.b, c.b)}; }
+__device__ __forceinline__ Row row_add(Row x, Row y) { return Row{add4(x.a, y.a), add4(x.b, y.b)}; }
 
-// x * rsqrt(max(sum x^2, 1e-12)); returns the scale.  `ss` is the half-wave sum of squares.
-__device__ __forceinline__ float inv_norm(float ss) { return 1.0f / sqrtf(fmaxf(ss, kNormEps)); }
+// x * rsqrt(max(sum x^2, 1e-12)); returns the scale.  `ss` is the row's sum of squares.
+__device__ __forceinline__ float inv_norm(float ss) { return __builtin_amdgcn_rsqf(fmaxf(ss, kNormEps)); }
 
 // Gradient through xhat = x * inv:  (g - xhat (xhat . g)) * inv, or g * inv where the
 // epsilon clamp is active (the scale is then a constant).
-__device__ __forceinline__ float4 norm_backward(float4 xhat, float inv, float ss, float4 g) {
-  if (ss < kNormEps) return scale4(g, inv);
-  const float proj = half_sum(dot4(xhat, g));
-  return scale4(fma4(-proj, xhat, g), inv);
-}
-
-__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-__device__ __forceinline__ float sigmoidf(float x) {
-  const float e = expf(-fabsf(x));
-  return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+__device__ __forceinline__ Row norm_backward(Row xhat, float inv, float ss, Row g) {
+  const float proj = (ss < kNormEps) ? 0.f : row_dot(xhat, g);
+  return row_scale(row_fma(-proj, xhat, g), inv);
 }
 
 // softplus(z) = -log(sigmoid(-z)) and sigmoid(z) from one exponential (hardware exp2/log2

@@ -9,14 +9,19 @@ namespace nncf {
 
 // Output arrays of the duplicate-row plan for a batch of id lists (one list per step).
 // List L uses order/uniq/inverse at [L*list_stride ..), seg_start at [L*(list_stride+1) ..),
-// counts at [2L ..) = {n_segments, n}.
+// counts at [4L ..) = {n_segments, n, n_chunks, 0}.
 struct PlanView {
   int32_t* order = nullptr;      // positions sorted by (id, position)
   int32_t* seg_start = nullptr;  // segment s = order[seg_start[s] .. seg_start[s+1])
   int32_t* uniq = nullptr;       // ids in first-occurrence order (tf.unique()[0])
   int32_t* inverse = nullptr;    // rank of each position's id          (tf.unique()[1])
   int32_t* counts = nullptr;
+  int32_t* desc = nullptr;       // 4 ints per segment: {id, first position, start in order[], count}
+  int32_t* slot_seg = nullptr;   // segment index of every sorted slot
+  int32_t* chunk_start = nullptr;  // sorted-slot ranges of whole segments, ~kChunkSlots slots each
   int64_t list_stride = 0;
+
+  __host__ __device__ int64_t chunk_stride() const { return list_stride / 16 + 2; }
 
   __host__ __device__ PlanView at(int64_t L) const {
     PlanView v = *this;
@@ -24,7 +29,10 @@ struct PlanView {
     v.seg_start += L * (list_stride + 1);
     v.uniq += L * list_stride;
     v.inverse += L * list_stride;
-    v.counts += L * 2;
+    v.counts += L * 4;
+    v.desc += L * list_stride * 4;
+    v.slot_seg += L * list_stride;
+    v.chunk_start += L * chunk_stride();
     return v;
   }
 };
@@ -33,6 +41,7 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
                 const PlanView& out, int64_t n_lists, hipStream_t stream);
 
 constexpr int kPlanChunk = 64;  // steps planned per launch by the epoch runners
+constexpr int kChunkSlots = 16;  // sorted slots (16-lane groups) per apply workgroup
 constexpr int kTile = 32;       // shared-negative tile edge (rows x columns per workgroup)
 
 }  // namespace nncf

@@ -82,7 +82,10 @@ void carve(nncf_model* m, Carver& c) {
     v.seg_start = c.take<int32_t>(kPlanChunk * (cap + 1));
     v.uniq = c.take<int32_t>(kPlanChunk * cap);
     v.inverse = c.take<int32_t>(kPlanChunk * cap);
-    v.counts = c.take<int32_t>(kPlanChunk * 2);
+    v.counts = c.take<int32_t>(kPlanChunk * 4);
+    v.desc = c.take<int32_t>(kPlanChunk * cap * 4);
+    v.slot_seg = c.take<int32_t>(kPlanChunk * cap);
+    v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
   };
   plan(m->plan_u, m->cap_u);
   plan(m->plan_v, m->cap_v);
@@ -312,7 +315,7 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
     }
     if (d_n_u) {
       // n_u of each planned step (counts[2*i]) -> d_n_u[t0 + i]
-      NNCF_HIP_CHECK(hipMemcpy2DAsync(d_n_u + t0, sizeof(int32_t), m->plan_v.counts, 2 * sizeof(int32_t),
+      NNCF_HIP_CHECK(hipMemcpy2DAsync(d_n_u + t0, sizeof(int32_t), m->plan_v.counts, 4 * sizeof(int32_t),
                                       sizeof(int32_t), (size_t)cnt, hipMemcpyDeviceToDevice, st));
     }
   }

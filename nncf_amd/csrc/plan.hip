@@ -45,7 +45,10 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
   int32_t* seg_start = out.seg_start + L * (out.list_stride + 1);
   int32_t* uniq = out.uniq + L * out.list_stride;
   int32_t* inverse = out.inverse + L * out.list_stride;
-  int32_t* counts = out.counts + L * 2;
+  int32_t* counts = out.counts + L * 4;
+  int32_t* slot_seg = out.slot_seg + L * out.list_stride;
+  int32_t* chunk_start = out.chunk_start + L * out.chunk_stride();
+  int4* desc = reinterpret_cast<int4*>(out.desc + L * out.list_stride * 4);
 
   int m = 2;  // sort size: next power of two >= n
   while (m < n) m <<= 1;
@@ -96,6 +99,7 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
       run += head[e];
       const int s = run - 1;
       seg[i] = s;
+      slot_seg[i] = s;
       const int pos = (int)(uint32_t)key[i];
       order[i] = pos;
       if (head[e]) {
@@ -137,7 +141,33 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
     const int rank = aux[first_pos];
     const int pos = (int)(uint32_t)key[i];
     inverse[pos] = rank;
-    if (i == hs) uniq[rank] = (int32_t)(key[i] >> 32);
+    if (i == hs) {
+      const int32_t id = (int32_t)(key[i] >> 32);
+      uniq[rank] = id;
+      desc[seg[i]] = make_int4(id, pos, i, seg_start[seg[i] + 1] - i);
+    }
+  }
+  // Chunks for the apply kernels: sorted-slot ranges that hold whole segments, cut at the
+  // first segment head at or after every multiple of kChunkSlots.
+  __syncthreads();
+  const int nm = (n + kChunkSlots - 1) / kChunkSlots;  // <= CAP / 16 <= NT
+  for (int m = tid; m < nm; m += NT) {
+    const int i = m * kChunkSlots;
+    int bslot = 0;
+    if (m > 0) bslot = (seg[i] != seg[i - 1]) ? i : seg_start[seg[i] + 1];
+    scratch[m] = bslot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0, last = -1;
+    for (int m = 0; m < nm; ++m) {
+      const int bs = scratch[m];
+      if (bs != last && bs < n) chunk_start[c++] = bs;
+      last = bs;
+    }
+    chunk_start[c] = n;
+    counts[2] = c;
+    counts[3] = 0;
   }
 }
 
@@ -173,8 +203,11 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
 using namespace nncf;
 
 extern "C" int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, int32_t* d_seg_start,
-                             int32_t* d_uniq, int32_t* d_inverse, int32_t* d_counts, void* stream) {
-  NNCF_REQUIRE(d_ids && d_order && d_seg_start && d_uniq && d_inverse && d_counts, "NULL argument");
+                             int32_t* d_uniq, int32_t* d_inverse, int32_t* d_counts, int32_t* d_desc,
+                             int32_t* d_slot_seg, int32_t* d_chunk_start, void* stream) {
+  NNCF_REQUIRE(d_ids && d_order && d_seg_start && d_uniq && d_inverse && d_counts && d_desc && d_slot_seg && d_chunk_start,
+               "NULL argument");
+  NNCF_REQUIRE(((uintptr_t)d_desc & 15) == 0, "d_desc must be 16-byte aligned");
   NNCF_REQUIRE(n > 0 && n <= 8192, "n = %d out of range (1..8192)", n);
   PlanView v;
   v.order = d_order;
@@ -182,6 +215,9 @@ extern "C" int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, 
   v.uniq = d_uniq;
   v.inverse = d_inverse;
   v.counts = d_counts;
+  v.desc = d_desc;
+  v.slot_seg = d_slot_seg;
+  v.chunk_start = d_chunk_start;
   v.list_stride = n;
   return launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, as_stream(stream));
 }

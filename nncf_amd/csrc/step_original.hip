@@ -4,16 +4,18 @@
 // (models/model_framework.py:59-63,85-88,123,147-149) -> get_original_loss
 // (utils/objectives.py:35-75), with the sparse SGD update the north-star asks for.
 //
-// Kernel A (score):  one wave per positive p.  The user row is read once, the 1+k item
-//   rows two at a time (one per 32-lane half, 16-byte lanes, coalesced 400/512-byte rows),
-//   dot products by half-wave shuffle reduction.  Emits d(loss)/d(score) for the 1+k rows,
-//   the positive's share of dL/dU (already summed over its 1+k rows), the normalised user
-//   row (needed by the item update) and loss / regulariser partials.
-// Kernel B (apply):  one half-wave per touched table row (segment of the duplicate plan):
+// Kernel A (score):  one wave per positive p.  The user row is read once; the 1+k item rows
+//   four at a time (one per 16-lane group, two 16-byte loads per lane, ids and rows of a
+//   chunk all in flight together); dot products by DPP row reductions.  Emits
+//   d(loss)/d(score) for the 1+k rows, the positive's share of dL/dU (already summed over its
+//   1+k rows), the normalised user row (needed by the item update) and loss / regulariser
+//   partials.
+// Kernel B (apply):  one 16-lane group per touched table row (segment of the duplicate plan):
 //   sums that row's gradient contributions in batch order, goes back through the L2
 //   normalisation, adds the activity-regulariser gradient, and writes the row once.
 // Algorithmic HBM traffic: (2+k) row reads + (2+k) row writes per link = 8d(2+k) bytes
 // (+ ids), SURVEY.md section 8(d).
+#include "chunk_reduce.h"
 #include "common.h"
 #include "devutil.h"
 #include "model.h"
@@ -21,88 +23,103 @@
 
 namespace nncf {
 
+__device__ __forceinline__ float across_groups(float v) {  // sum of the 4 row-groups' values
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+template <int LOSS, bool NU, bool NV>
 __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const int32_t* __restrict__ uid,
                                                              const int32_t* __restrict__ cid_pos,
                                                              const int32_t* __restrict__ cid_neg, OriginalWs ws) {
+  constexpr bool PAIR = LOSS >= NNCF_LOSS_LOG_LOSS;
   const int lane = threadIdx.x & 63;
-  const int half = lane >> 5, q = lane & 31;
+  const int grp = lane >> 4, q = lane & 15;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= a.b) return;
   const int k = a.k, d4 = a.d >> 2;
-  const int64_t u = uid[p];
-  const float4 uraw = load_row4(a.U, u, a.stride, d4, q);
-  const float uss = half_sum(dot4(uraw, uraw));
-  const float uinv = a.norm_u ? inv_norm(uss) : 1.f;
-  const float4 uhat = scale4(uraw, uinv);
+  const int nslots = 1 + k;
+  Row uhat = row_load(a.U, uid[p], a.stride, d4, q);
+  const float uss = row16_sum(row_dot_partial(uhat, uhat));
+  if (NU) uhat = row_scale(uhat, inv_norm(uss));
 
   const float lam_k = a.lambda / (float)k;  // objectives.py:60,66
   const float inv_b = 1.f / (float)a.b, inv_bk = 1.f / ((float)a.b * (float)k);
-  float4 acc = zero4();   // sum_slots g * vhat  (this half's slots)
-  float4 vpos = zero4();  // vhat of the positive (pairwise losses add g_pos * vpos at the end)
+  Row acc = row_zero();   // sum over this group's slots of g * vhat
+  Row vpos = row_zero();  // vhat of the positive (group 0; pairwise losses add g_pos * vpos last)
   float loss = 0.f, gpos_pair = 0.f, s_pos = 0.f;
-  const int nslots = 1 + k;
-  for (int t = 0; t < nslots; t += 2) {
-    const int slot = t + half;
-    const bool live = slot < nslots;
-    int64_t c = 0;
-    if (live) c = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
-    float4 v = live ? load_row4(a.V, c, a.stride, d4, q) : zero4();
-    if (a.norm_v) v = scale4(v, inv_norm(half_sum(dot4(v, v))));
-    const float s = half_sum(dot4(uhat, v));  // interaction_dot.py:92-95
-    if (t == 0) {
-      s_pos = __shfl(s, 0);
-      if (half == 0) vpos = v;
+  for (int t0 = 0; t0 < nslots; t0 += 16) {
+    int ids[4];
+    Row v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int slot = t0 + 4 * e + grp;
+      ids[e] = -1;
+      if (slot < nslots) ids[e] = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
     }
-    float g = 0.f, l = 0.f;
-    if (live) {
-      const bool is_pos = slot == 0;
-      switch (a.loss) {
-        case NNCF_LOSS_SKIP_GRAM: {  // objectives.py:59-64
-          const float y = is_pos ? 1.f : -1.f, w = is_pos ? 1.f : lam_k;
-          l = w * softplusf(-y * s) * inv_b;
-          g = -w * y * sigmoidf(-y * s) * inv_b;
-        } break;
-        case NNCF_LOSS_MSE: {  // objectives.py:65-70
-          const float y = is_pos ? 1.f : 0.f, w = is_pos ? 1.f : lam_k;
-          l = w * (y - s) * (y - s) * inv_b;
-          g = 2.f * w * (s - y) * inv_b;
-        } break;
-        case NNCF_LOSS_LOG_LOSS:  // objectives.py:54-58
-          if (!is_pos) {
-            const float x = a.gamma * (s_pos - s);
-            l = softplusf(-x) * inv_bk;
-            g = a.gamma * sigmoidf(-x) * inv_bk;  // d/ds_neg; the positive gets the negated sum
-          }
-          break;
-        default:  // max-margin, objectives.py:49-53
-          if (!is_pos) {
-            const float act = a.gamma - (s_pos - s);
-            l = fmaxf(act, 0.f) * inv_bk;
-            g = act > 0.f ? inv_bk : 0.f;
-          }
-          break;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (ids[e] >= 0) ? row_load(a.V, ids[e], a.stride, d4, q) : row_zero();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int slot = t0 + 4 * e + grp;
+      const bool live = slot < nslots;
+      if (NV) v[e] = row_scale(v[e], inv_norm(row16_sum(row_dot_partial(v[e], v[e]))));
+      const float s = row_dot(uhat, v[e]);  // interaction_dot.py:92-95
+      if (t0 == 0 && e == 0) {
+        s_pos = __shfl(s, 0);  // slot 0 lives in group 0
+        vpos = v[0];
       }
-      if (a.loss >= NNCF_LOSS_LOG_LOSS && !is_pos) gpos_pair -= g;
-      if (q == 0 && !(a.loss >= NNCF_LOSS_LOG_LOSS && is_pos))
-        ws.g[(slot == 0) ? p : a.b + (int64_t)p * k + (slot - 1)] = g;
+      const bool is_pos = slot == 0;
+      float g = 0.f, l = 0.f;
+      if (LOSS == NNCF_LOSS_SKIP_GRAM) {  // objectives.py:59-64
+        const float y = is_pos ? 1.f : -1.f, w = (is_pos ? 1.f : lam_k) * inv_b;
+        float sp, sg;
+        softplus_sigmoid(-y * s, sp, sg);
+        l = w * sp;
+        g = -w * y * sg;
+      } else if (LOSS == NNCF_LOSS_MSE) {  // objectives.py:65-70
+        const float y = is_pos ? 1.f : 0.f, w = (is_pos ? 1.f : lam_k) * inv_b;
+        l = w * (y - s) * (y - s);
+        g = 2.f * w * (s - y);
+      } else if (LOSS == NNCF_LOSS_LOG_LOSS) {  // objectives.py:54-58
+        float sp, sg;
+        softplus_sigmoid(-a.gamma * (s_pos - s), sp, sg);
+        l = is_pos ? 0.f : sp * inv_bk;
+        g = is_pos ? 0.f : a.gamma * sg * inv_bk;  // d/ds_neg; the positive gets the negated sum
+      } else {  // max-margin, objectives.py:49-53
+        const float act = a.gamma - (s_pos - s);
+        l = is_pos ? 0.f : fmaxf(act, 0.f) * inv_bk;
+        g = (!is_pos && act > 0.f) ? inv_bk : 0.f;
+      }
+      if (!live) {
+        g = 0.f;
+        l = 0.f;
+      }
+      if (PAIR) gpos_pair -= g;
+      if (live && q == 0 && !(PAIR && is_pos)) ws.g[is_pos ? p : a.b + (int64_t)p * k + (slot - 1)] = g;
+      acc = row_fma(g, v[e], acc);
+      loss += l;
     }
-    acc = fma4(g, v, acc);
-    loss += l;
   }
-  // fold the two halves (fixed order: half 0 + half 1)
-  acc.x += __shfl_xor(acc.x, 32);
-  acc.y += __shfl_xor(acc.y, 32);
-  acc.z += __shfl_xor(acc.z, 32);
-  acc.w += __shfl_xor(acc.w, 32);
-  loss += __shfl_xor(loss, 32);
-  if (a.loss >= NNCF_LOSS_LOG_LOSS) {
-    gpos_pair += __shfl_xor(gpos_pair, 32);
-    acc = fma4(gpos_pair, __builtin_bit_cast(float4, vpos), acc);  // vpos lives in half 0
+  // fold the four groups (fixed tree)
+  acc.a.x = across_groups(acc.a.x);
+  acc.a.y = across_groups(acc.a.y);
+  acc.a.z = across_groups(acc.a.z);
+  acc.a.w = across_groups(acc.a.w);
+  acc.b.x = across_groups(acc.b.x);
+  acc.b.y = across_groups(acc.b.y);
+  acc.b.z = across_groups(acc.b.z);
+  acc.b.w = across_groups(acc.b.w);
+  loss = across_groups(loss);
+  if (PAIR) {
+    gpos_pair = across_groups(gpos_pair);
+    acc = row_fma(gpos_pair, vpos, acc);  // valid in group 0 (vpos); only group 0 stores
     if (lane == 0) ws.g[p] = gpos_pair;
   }
-  if (half == 0) {
-    store_row4(ws.dUp, p, a.d, d4, q, acc);
-    store_row4(ws.Uhat, p, a.d, d4, q, uhat);
+  if (grp == 0) {
+    row_store(ws.dUp, p, a.d, d4, q, acc);
+    row_store(ws.Uhat, p, a.d, d4, q, uhat);
     if (q == 0) {
       ws.loss_part[p] = loss;
       ws.reg_part[p] = uss * (float)nslots;  // sum over this positive's 1+k rows of |U_raw|^2
@@ -110,19 +127,18 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
   }
 }
 
-// One half-wave per segment.  Segments [0, nseg_u) are user rows, the rest item rows.
-__global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, const int32_t* __restrict__ uid,
-                                                             const int32_t* __restrict__ cid_pos,
-                                                             const int32_t* __restrict__ cid_neg, OriginalWs ws,
-                                                             PlanView pu, PlanView pv, float* __restrict__ loss_out,
-                                                             int update) {
-  const int lane = threadIdx.x & 63;
-  const int half = lane >> 5, q = lane & 31;
-  const int hw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;  // global half-wave index
+// Workgroups [0, cu) reduce user rows (chunks of the uid plan), [cu, cu + cv) item rows, the
+// last workgroup reduces the loss (chunk_reduce.h).
+template <bool NU, bool NV>
+__global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, OriginalWs ws, PlanView pu, PlanView pv,
+                                                             float* __restrict__ loss_out, int update, int cu) {
+  __shared__ __attribute__((aligned(16))) float sR[kChunkSlots * kChunkPitch];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = tid & 15;
   const int d4 = a.d >> 2, k = a.k, b = a.b;
-  const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
-  if (blockIdx.x == gridDim.x - 1 && (threadIdx.x >> 6) == 3) {
-    // last wave of the grid: loss = sum of per-positive partials + regulariser, fixed order.
+  if (blockIdx.x == gridDim.x - 1) {
+    if (tid >= 64) return;
+    // loss = sum of per-positive partials + regulariser, fixed order.
     float l = 0.f, r = 0.f;
     for (int i = lane; i < b; i += 64) {
       l += ws.loss_part[i];
@@ -135,58 +151,86 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, const i
     return;
   }
   if (!update) return;
-  if (hw < nseg_u) {
-    const int s0 = pu.seg_start[hw], s1 = pu.seg_start[hw + 1];
-    const int64_t u = uid[pu.order[s0]];
-    float4 acc = zero4();
-    for (int i = s0; i < s1; ++i) acc = add4(acc, load_row4(ws.dUp, pu.order[i], a.d, d4, q));
-    const float4 uraw = load_row4(a.U, u, a.stride, d4, q);
-    float4 g = acc;
-    if (a.norm_u) {
-      const float ss = half_sum(dot4(uraw, uraw));
-      const float inv = inv_norm(ss);
-      g = norm_backward(scale4(uraw, inv), inv, ss, acc);
-    }
-    // regulariser: every one of this user's (s1-s0)(1+k) rows adds 2 u_reg U / n, n = b(1+k)
-    const float rc = 2.f * a.u_reg * (float)(s1 - s0) / (float)b;
-    g = fma4(rc, uraw, g);
-    store_row4(a.U, u, a.stride, d4, q, fma4(-a.lr, g, uraw));
-  } else if (hw < nseg_u + nseg_v) {
-    const int sv = hw - nseg_u;
-    const int s0 = pv.seg_start[sv], s1 = pv.seg_start[sv + 1];
-    const int n0 = pv.order[s0];
-    const int64_t c = (n0 < b) ? cid_pos[n0] : cid_neg[n0 - b];
-    float4 acc = zero4();
-    for (int i = s0; i < s1; ++i) {
-      const int n = pv.order[i];
-      const int p = (n < b) ? n : (n - b) / k;
-      acc = fma4(ws.g[n], load_row4(ws.Uhat, p, a.d, d4, q), acc);
-    }
-    const float4 vraw = load_row4(a.V, c, a.stride, d4, q);
-    float4 g = acc;
-    if (a.norm_v) {
-      const float ss = half_sum(dot4(vraw, vraw));
-      const float inv = inv_norm(ss);
-      g = norm_backward(scale4(vraw, inv), inv, ss, acc);
-    }
-    store_row4(a.V, c, a.stride, d4, q, fma4(-a.lr, g, vraw));
+  if ((int)blockIdx.x < cu) {
+    if ((int)blockIdx.x >= pu.counts[2]) return;
+    chunk_reduce(
+        pu, blockIdx.x, sR, [&](int p, bool) { return row_load(ws.dUp, p, a.d, d4, q); },
+        [&](int u, int cnt, Row acc) {
+          const Row uraw = row_load(a.U, u, a.stride, d4, q);
+          Row grad = acc;
+          if (NU) {
+            const float ss = row16_sum(row_dot_partial(uraw, uraw));
+            const float inv = inv_norm(ss);
+            grad = norm_backward(row_scale(uraw, inv), inv, ss, acc);
+          }
+          // regulariser: every one of this user's cnt*(1+k) rows adds 2 u_reg U / n, n = b(1+k)
+          grad = row_fma(2.f * a.u_reg * (float)cnt / (float)b, uraw, grad);
+          row_store(a.U, u, a.stride, d4, q, row_fma(-a.lr, grad, uraw));
+        });
+  } else {
+    const int chunk = blockIdx.x - cu;
+    if (chunk >= pv.counts[2]) return;
+    chunk_reduce(
+        pv, chunk, sR,
+        [&](int n, bool) {
+          const int p = (n < b) ? n : (n - b) / k;
+          return row_scale(row_load(ws.Uhat, p, a.d, d4, q), ws.g[n]);
+        },
+        [&](int c, int, Row acc) {
+          const Row vraw = row_load(a.V, c, a.stride, d4, q);
+          Row grad = acc;
+          if (NV) {
+            const float ss = row16_sum(row_dot_partial(vraw, vraw));
+            const float inv = inv_norm(ss);
+            grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
+          }
+          row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
+        });
   }
 }
+
+namespace {
+
+template <int LOSS, bool NU, bool NV>
+void launch_o(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg, const OriginalWs& ws,
+              const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
+              KernelProfiler* prof) {
+  const int b = a.b;
+  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
+  if (ev) (void)hipEventRecord(*ev, stream);
+  hipLaunchKernelGGL((original_score_kernel<LOSS, NU, NV>), dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos,
+                     cid_neg, ws);
+  if (ev) (void)hipEventRecord(prof->stop[prof->used++], stream);
+  // chunk upper bounds: ceil(n / 16) per id list, + the loss workgroup
+  const int cu = (b + kChunkSlots - 1) / kChunkSlots, cv = (b * (1 + a.k) + kChunkSlots - 1) / kChunkSlots;
+  hipLaunchKernelGGL((original_apply_kernel<NU, NV>), dim3(cu + cv + 1), dim3(256), 0, stream, a, ws, pu, pv, loss_out,
+                     update, cu);
+}
+
+template <int LOSS>
+void launch_on(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
+               const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
+               hipStream_t stream, KernelProfiler* prof) {
+  if (a.norm_u) {
+    if (a.norm_v) launch_o<LOSS, true, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+    else launch_o<LOSS, true, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+  } else {
+    if (a.norm_v) launch_o<LOSS, false, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+    else launch_o<LOSS, false, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+  }
+}
+
+}  // namespace
 
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
                     const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
                     hipStream_t stream, KernelProfiler* prof) {
-  const int b = a.b;
-  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
-  if (ev) NNCF_HIP_CHECK(hipEventRecord(*ev, stream));
-  hipLaunchKernelGGL(original_score_kernel, dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos, cid_neg, ws);
-  if (ev) NNCF_HIP_CHECK(hipEventRecord(prof->stop[prof->used++], stream));
-  // upper bound on segments: b users + b(1+k) items; 8 half-waves per block; +1 block so the
-  // last wave of the grid is always free for the loss reduction.
-  const int max_seg = b + b * (1 + a.k);
-  const int blocks = (max_seg + 7) / 8 + 1;
-  hipLaunchKernelGGL(original_apply_kernel, dim3(blocks), dim3(256), 0, stream, a, uid, cid_pos, cid_neg, ws, pu, pv,
-                     loss_out, update);
+  switch (a.loss) {
+    case NNCF_LOSS_SKIP_GRAM: launch_on<NNCF_LOSS_SKIP_GRAM>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
+    case NNCF_LOSS_MSE: launch_on<NNCF_LOSS_MSE>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
+    case NNCF_LOSS_LOG_LOSS: launch_on<NNCF_LOSS_LOG_LOSS>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
+    default: launch_on<NNCF_LOSS_MAX_MARGIN>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

@@ -175,9 +175,17 @@ def plan_ids(ids):
     seg_start = torch.empty(n + 1, dtype=torch.int32, device=dev)
     uniq = torch.empty(n, dtype=torch.int32, device=dev)
     inverse = torch.empty(n, dtype=torch.int32, device=dev)
-    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    desc = torch.empty(4 * n, dtype=torch.int32, device=dev)
+    slot_seg = torch.empty(n, dtype=torch.int32, device=dev)
+    chunk_start = torch.empty(n // 16 + 2, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(L.nncf_plan_ids(_ptr(ids), n, _ptr(order), _ptr(seg_start), _ptr(uniq), _ptr(inverse), _ptr(counts),
+                                   _ptr(desc), _ptr(slot_seg), _ptr(chunk_start),
                                    _lib.stream_ptr(torch.cuda.current_stream(dev))))
     nseg = int(counts[0].item())
+    nchunks = int(counts[2].item())
+    plan_ids.last_desc = desc[:4 * nseg].cpu().numpy().reshape(nseg, 4)
+    plan_ids.last_slot_seg = slot_seg.cpu().numpy()
+    plan_ids.last_chunks = chunk_start[:nchunks + 1].cpu().numpy()
     return order.cpu().numpy(), seg_start[:nseg + 1].cpu().numpy(), uniq[:nseg].cpu().numpy(), inverse.cpu().numpy(), nseg

@@ -42,9 +42,20 @@ def test_plan_ids_matches_tf_unique():
         keys = ids[order].astype(np.int64) * 100000 + order
         assert np.all(np.diff(keys) > 0)
         assert seg_start[0] == 0 and seg_start[-1] == n
+        desc = plan_ids.last_desc
         for s in range(nseg):
             seg = ids[order[seg_start[s]:seg_start[s + 1]]]
             assert len(seg) > 0 and np.all(seg == seg[0])
+            assert desc[s].tolist() == [seg[0], order[seg_start[s]], seg_start[s], len(seg)]
+            assert np.all(plan_ids.last_slot_seg[seg_start[s]:seg_start[s + 1]] == s)
+        # chunks: whole segments, consecutive, covering [0, n); a chunk only exceeds 16 slots by
+        # the tail of its last segment
+        ch = plan_ids.last_chunks
+        assert ch[0] == 0 and ch[-1] == n and np.all(np.diff(ch) > 0)
+        assert set(ch.tolist()) <= set(seg_start.tolist())
+        for c0, c1 in zip(ch[:-1], ch[1:]):
+            last_head = seg_start[np.searchsorted(seg_start, c1, side="left") - 1]
+            assert last_head - c0 < 16
 
 
 @pytest.mark.parametrize("loss", LOSSES)
