@@ -206,6 +206,17 @@ int nncf_epoch_group_neg_shared(nncf_model* m, const int32_t* d_uid_all, const i
 int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const int32_t* d_cid, int64_t q,
                         float* d_out, void* stream);
 
+/* Evaluator whole@k for one candidate set (utils/objectives.py:296-370,395-421 +
+ * utils/metrics_ranking.py:6-35 eval_multiple).  d_scores: n_users rows of n_cand scores
+ * (row_stride floats apart, e.g. from nncf_predict_scores); truth in CSR over candidate slots
+ * (d_truth_ptr[n_users+1], d_truth_idx sorted ascending inside a user).  Per user with >= 1 true
+ * item: d_metrics[3u..] = {map@k, recall@k, precision@k}, d_valid[u] = 1; others d_valid[u] = 0
+ * (objectives.py:316).  Score ties go to the lower slot (the reference uses random noise).
+ * Limits: n_cand <= 16384, topk <= 1024. */
+int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, int32_t n_cand,
+                   const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
+                   int32_t* d_valid, void* stream);
+
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
  * segment starts, and tf.unique-style first-occurrence outputs.
  *   d_order[n], d_seg_start[n+1], d_uniq[n], d_inverse[n],

@@ -77,6 +77,7 @@ def _declare(lib):
         "nncf_epoch_neg_shared": [vp, vp, vp, i64, vp, vp],
         "nncf_epoch_group_neg_shared": [vp, vp, vp, i64, vp, vp, vp],
         "nncf_predict_scores": [vp, vp, i64, vp, i64, vp, vp],
+        "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })
     for name, args in sig.items():

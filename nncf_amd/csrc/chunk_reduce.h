@@ -25,15 +25,16 @@ __device__ __forceinline__ Row lds_get_row(const float* sR, int r, int q) {
   return v;
 }
 
+// prefetch(id) -> Row           : the table row `id` (issued early so it overlaps `compute`)
 // compute(pos, is_head) -> Row : gradient contribution of batch position `pos` (is_head: pos is
 //                               the first position of its segment)
-// finalize(id, count, Row acc) : write table row `id` (called by one 16-lane group)
-template <class Compute, class Finalize>
-__device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, float* sR, Compute compute,
-                                             Finalize finalize) {
+// finalize(id, count, Row raw, Row acc) : write table row `id` (called by one 16-lane group)
+template <class Prefetch, class Compute, class Finalize>
+__device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, float* sR, Prefetch prefetch,
+                                             Compute compute, Finalize finalize) {
   const int gl = threadIdx.x >> 4, q = threadIdx.x & 15;
   const int c0 = pl.chunk_start[chunk], c1 = pl.chunk_start[chunk + 1];
-  Row open_acc = row_zero();
+  Row open_acc = row_zero(), open_raw = row_zero();
   int open_id = -1, open_end = 0, open_cnt = 0;  // segment this group is accumulating
   for (int base = c0; base < c1; base += kChunkSlots) {
     const int slot = base + gl;
@@ -45,8 +46,9 @@ __device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, floa
     }
     int4 ds = make_int4(0, 0, -1, 0);
     if (live) ds = reinterpret_cast<const int4*>(pl.desc)[sg];  // {id, first pos, start, count}
-    Row r = row_zero();
+    Row r = row_zero(), raw = row_zero();
     if (live) r = compute(pos, ds.z == slot);
+    if (live && ds.z == slot) raw = prefetch(ds.x);
     lds_put_row(sR, gl, q, r);
     __syncthreads();
     const int wend = min(base + kChunkSlots, c1);
@@ -54,7 +56,7 @@ __device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, floa
       const int e = min(open_end, wend);
       for (int s = base; s < e; ++s) open_acc = row_add(open_acc, lds_get_row(sR, s - base, q));
       if (open_end <= wend) {
-        finalize(open_id, open_cnt, open_acc);
+        finalize(open_id, open_cnt, open_raw, open_acc);
         open_id = -1;
       }
     }
@@ -64,9 +66,10 @@ __device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, floa
       const int e = min(send, wend);
       for (int s = slot + 1; s < e; ++s) acc = row_add(acc, lds_get_row(sR, s - base, q));
       if (send <= wend) {
-        finalize(ds.x, ds.w, acc);
+        finalize(ds.x, ds.w, raw, acc);
       } else {
         open_acc = acc;
+        open_raw = raw;
         open_id = ds.x;
         open_end = send;
         open_cnt = ds.w;

@@ -165,9 +165,9 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
       if (bs != last && bs < n) chunk_start[c++] = bs;
       last = bs;
     }
-    chunk_start[c] = n;
     counts[2] = c;
     counts[3] = 0;
+    for (; c <= nm; ++c) chunk_start[c] = n;  // unused chunks are empty ranges [n, n)
   }
 }
 

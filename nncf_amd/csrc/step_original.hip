@@ -152,11 +152,10 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
   }
   if (!update) return;
   if ((int)blockIdx.x < cu) {
-    if ((int)blockIdx.x >= pu.counts[2]) return;
     chunk_reduce(
-        pu, blockIdx.x, sR, [&](int p, bool) { return row_load(ws.dUp, p, a.d, d4, q); },
-        [&](int u, int cnt, Row acc) {
-          const Row uraw = row_load(a.U, u, a.stride, d4, q);
+        pu, blockIdx.x, sR, [&](int u) { return row_load(a.U, u, a.stride, d4, q); },
+        [&](int p, bool) { return row_load(ws.dUp, p, a.d, d4, q); },
+        [&](int u, int cnt, Row uraw, Row acc) {
           Row grad = acc;
           if (NU) {
             const float ss = row16_sum(row_dot_partial(uraw, uraw));
@@ -169,15 +168,13 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
         });
   } else {
     const int chunk = blockIdx.x - cu;
-    if (chunk >= pv.counts[2]) return;
     chunk_reduce(
-        pv, chunk, sR,
+        pv, chunk, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
         [&](int n, bool) {
           const int p = (n < b) ? n : (n - b) / k;
           return row_scale(row_load(ws.Uhat, p, a.d, d4, q), ws.g[n]);
         },
-        [&](int c, int, Row acc) {
-          const Row vraw = row_load(a.V, c, a.stride, d4, q);
+        [&](int c, int, Row vraw, Row acc) {
           Row grad = acc;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));

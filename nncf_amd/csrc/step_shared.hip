@@ -257,17 +257,17 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
 }
 
 // Sum of `cnt` slab rows (row `row` of slabs 0..cnt-1, slab stride `sstride` rows) by one
-// 16-lane group; eight slabs (16 loads per lane) in flight; fixed order.
+// 16-lane group; sixteen slabs (32 loads per lane) in flight; fixed order.
 __device__ __forceinline__ Row slab_sum(const float* __restrict__ base, int64_t sstride, int cnt, int row, int d,
                                         int d4, int q) {
   Row acc = row_zero();
-  for (int j0 = 0; j0 < cnt; j0 += 8) {
-    Row t[8];
+  for (int j0 = 0; j0 < cnt; j0 += 16) {
+    Row t[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 16; ++e)
       t[e] = (j0 + e < cnt) ? row_load(base, (int64_t)(j0 + e) * sstride + row, d, d4, q) : row_zero();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc = row_add(acc, t[e]);
+    for (int e = 0; e < 16; ++e) acc = row_add(acc, t[e]);
   }
   return acc;
 }
@@ -304,9 +304,8 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
   if (!update) return;
 
   if (blockIdx.x < max_chunks) {
-    if ((int)blockIdx.x >= pu.counts[2]) return;
     chunk_reduce(
-        pu, blockIdx.x, sR,
+        pu, blockIdx.x, sR, [&](int u) { return row_load(a.U, u, a.stride, d4, q); },
         [&](int i, bool) {
           Row row = slab_sum(ws.dU_part, b, nbj, i, d, d4, q);
           if (PAIR) {
@@ -316,8 +315,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           }
           return row;
         },
-        [&](int u, int cnt, Row acc) {
-          const Row uraw = row_load(a.U, u, a.stride, d4, q);
+        [&](int u, int cnt, Row uraw, Row acc) {
           Row grad = acc;
           if (NU) {
             const float ss = row16_sum(row_dot_partial(uraw, uraw));
@@ -329,9 +327,8 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
         });
   } else {
     const int chunk = blockIdx.x - max_chunks;
-    if (chunk >= pv.counts[2]) return;
     chunk_reduce(
-        pv, chunk, sR,
+        pv, chunk, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
         [&](int pos, bool is_head) {
           // neg_shared: pos is a column of the tile grid.  group: pos is a batch row of this
           // item's segment; the item's column slab is taken once (with the segment's first
@@ -346,9 +343,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           }
           return colv;
         },
-        [&](int c, int cnt, Row acc) {
-          (void)cnt;
-          const Row vraw = row_load(a.V, c, a.stride, d4, q);
+        [&](int c, int, Row vraw, Row acc) {
           Row grad = acc;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));

@@ -1,0 +1,201 @@
+"""Drop-in for the reference's models/model_framework.py: `get_model(conf, data_helper,
+model_name)` returns the same nine-key model_dict (model_framework.py:195-204) whose values
+expose the Keras-Model subset the trainers and the evaluator use (`train_on_batch`,
+`predict_on_batch`, `predict`), backed by the HIP kernels of libnncf_hip.so instead of a
+Keras/TF graph.
+
+Scope of this build: the id-table towers (`model_name == 'mf'`, model_framework.py:85-88, and
+the user side of every model, :59-63).  The text towers (basic_embedding / cnn_embedding /
+rnn_embedding: MeanPool / CNN / RNN over item content, :89-111) are not built yet and raise.
+All heads share ONE parameter set, as the reference's models share layer objects.
+"""
+import numpy as np
+
+from .engine import Engine
+
+
+def _as_ids(x):
+    return np.ascontiguousarray(np.asarray(x).reshape(-1))
+
+
+class _Head(object):
+    """Common bits of the model objects: shared Engine, sync-and-return-float semantics of
+    Keras' train_on_batch (the reference adds the returned host scalar to `cost`,
+    train_original.py:57-58)."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def _loss(self, t):
+        return float(t.item())  # device -> host sync, as session.run did
+
+
+class OriginalModel(_Head):
+    """model_dict['model'] (model_framework.py:123,147-149): row-wise interaction, first
+    batch_size_p rows positive, negative row j belongs to positive j // k."""
+
+    def __init__(self, engine, update=True):
+        super(OriginalModel, self).__init__(engine)
+        self.update = update
+
+    def train_on_batch(self, x, y=None):
+        uid, cid = _as_ids(x[0]), _as_ids(x[1])
+        b, k = self.engine.b, self.engine.k
+        if uid.size != b * (1 + k) or cid.size != b * (1 + k):
+            raise ValueError("[ERROR] model expects batch_size_p * (1 + num_negatives) = %d rows, got %d"
+                             % (b * (1 + k), uid.size))
+        # The kernels use the trainer's layout (train_original.py:49-56): negatives repeat their
+        # positive's user.  Anything else is not this head's input.
+        if not np.array_equal(uid[b:], np.repeat(uid[:b], k)):
+            raise ValueError("[ERROR] rows %d.. must repeat the users of the positives k times each "
+                             "(train_original.py:50)" % b)
+        e = self.engine
+        return self._loss(e.step_original(e.ids(uid[:b]), e.ids(cid), update=self.update))
+
+
+class NegSharedModel(_Head):
+    """model_dict['model_neg_shared'] (model_framework.py:128-129,153-155)."""
+
+    def __init__(self, engine, update=True):
+        super(NegSharedModel, self).__init__(engine)
+        self.update = update
+
+    def train_on_batch(self, x, y=None):
+        e = self.engine
+        return self._loss(e.step_neg_shared(e.ids(_as_ids(x[0])), e.ids(_as_ids(x[1])), update=self.update))
+
+    def predict_on_batch(self, x):
+        """[uid (p,), cid (q,)] -> float32 (p, q) scores (utils/objectives.py:310)."""
+        e = self.engine
+        return e.predict_scores(e.ids(_as_ids(x[0])), e.ids(_as_ids(x[1]))).cpu().numpy()
+
+    def predict_on_batch_device(self, uid_dev, cid_dev, out=None):
+        return self.engine.predict_scores(uid_dev, cid_dev, out=out)
+
+
+class GroupNegSharedModel(_Head):
+    """model_dict['model_group_neg_shared'] (model_framework.py:131-136,158-161); needs exactly
+    batch_size_p rows (row_cidx_prefx, :38-39,133-134)."""
+
+    def train_on_batch(self, x, y=None):
+        e = self.engine
+        uid, cid = _as_ids(x[0]), _as_ids(x[1])
+        if uid.size != e.b:
+            raise ValueError("[ERROR] model_group_neg_shared needs exactly batch_size_p = %d rows" % e.b)
+        return self._loss(e.step_group_neg_shared(e.ids(uid), e.ids(cid)))
+
+
+class SampledNegSharedModel(_Head):
+    """model_dict['model_sampled_neg_shared'] (model_framework.py:138-143,166-170)."""
+
+    def train_on_batch(self, x, y=None):
+        raise NotImplementedError("train_scheme=sampled_neg_shared is not built yet (SURVEY.md 8(f) rank 4)")
+
+
+class EmbeddingModel(_Head):
+    """model_user_emb / model_item_emb (model_framework.py:173-174): the tower output for a list
+    of ids.  Only the 'given' evaluation scheme uses these; rows are gathered with torch
+    indexing (no arithmetic besides the configured L2 normalisation)."""
+
+    def __init__(self, engine, side):
+        super(EmbeddingModel, self).__init__(engine)
+        self.side = side
+
+    def predict_on_batch(self, x):
+        import torch
+        e = self.engine
+        ids = e.ids(_as_ids(x[0])).long()
+        tab, norm = (e.U, e.cfg.normalize_user) if self.side == "user" else (e.V, e.cfg.normalize_item)
+        rows = tab[ids, :e.dim]
+        if norm:
+            rows = rows * torch.rsqrt(torch.clamp((rows * rows).sum(-1, keepdim=True), min=1e-12))
+        return rows.cpu().numpy()
+
+
+class PredPairsModel(_Head):
+    """model_pred_pairs (model_framework.py:125-126,175-176): row-wise dot of GIVEN embeddings."""
+
+    def predict(self, x, batch_size=4096):
+        U, C = np.asarray(x[0], dtype=np.float32), np.asarray(x[1], dtype=np.float32)
+        return np.sum(U * C, axis=1, keepdims=True)
+
+
+class _LossMonitorDict(dict):
+    """model_all_loss / model_neg_shared_all_loss (model_framework.py:179-193): one SGD(0.)
+    model per loss name, sharing the parameters.  Built on first use."""
+
+    LOSSES = ("skip-gram", "mse", "log-loss", "max-margin")
+
+    def __init__(self, make):
+        super(_LossMonitorDict, self).__init__()
+        self._make = make
+
+    def keys(self):
+        return list(self.LOSSES)
+
+    def __iter__(self):
+        return iter(self.LOSSES)
+
+    def __len__(self):
+        return len(self.LOSSES)
+
+    def __getitem__(self, name):
+        if not dict.__contains__(self, name):
+            if name not in self.LOSSES:
+                raise KeyError(name)
+            dict.__setitem__(self, name, self._make(name))
+        return dict.__getitem__(self, name)
+
+    def items(self):
+        return [(n, self[n]) for n in self.LOSSES]
+
+    iteritems = items
+
+
+def engine_kwargs(conf, data_spec, model_name):
+    normalize = bool(conf.emb_normalization)
+    return dict(
+        user_count=data_spec.user_count, item_count=data_spec.item_count, dim=conf.user_dim,
+        batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
+        loss_gamma=getattr(conf, "loss_gamma", 1), neg_loss_weight=getattr(conf, "neg_loss_weight", 1),
+        u_reg=conf.u_reg, learn_rate=abs(conf.learn_rate),
+        normalize_user=normalize,                              # model_framework.py:62-63
+        normalize_item=normalize and model_name != "mf")        # :109-111 (content branch only)
+
+
+def get_model(conf, data_helper, model_name, device=0, seed=0):
+    """get_model (model_framework.py:18-206)."""
+    data_spec = data_helper.data_spec
+    if model_name != "mf":
+        assert model_name in ("basic_embedding", "cnn_embedding", "rnn_embedding", "pretrained"), \
+            "[ERROR] Model name {} unknown".format(model_name)  # model_framework.py:97
+        raise NotImplementedError(
+            "model_choice=%s: the item text towers (modules/content/*.py) are not built yet; "
+            "use model_choice=mf (id-table towers)" % model_name)
+    assert conf.user_dim == conf.item_dim, "user_dim and item_dim must match for the dot interaction"
+    if getattr(conf, "interaction_bias", None) is not None:
+        raise NotImplementedError("interaction_bias=%r (interaction_dot.py:62-71) is not built yet; "
+                                  "pass {'interaction_bias': None}" % conf.interaction_bias)
+    kw = engine_kwargs(conf, data_spec, model_name)
+    engine = Engine(device=device, seed=seed, **kw)
+
+    def monitor(head_cls):
+        def make(loss_name):
+            kw2 = dict(kw)
+            kw2["loss"] = loss_name
+            kw2["learn_rate"] = 0.0
+            return head_cls(Engine(device=device, share=engine, **kw2), update=False)
+        return make
+
+    model_dict = {
+        "model": OriginalModel(engine),
+        "model_neg_shared": NegSharedModel(engine),
+        "model_group_neg_shared": GroupNegSharedModel(engine),
+        "model_sampled_neg_shared": SampledNegSharedModel(engine),
+        "model_user_emb": EmbeddingModel(engine, "user"),
+        "model_item_emb": EmbeddingModel(engine, "item"),
+        "model_pred_pairs": PredPairsModel(engine),
+        "model_all_loss": _LossMonitorDict(monitor(OriginalModel)),
+        "model_neg_shared_all_loss": _LossMonitorDict(monitor(NegSharedModel)),
+    }
+    return model_dict

@@ -1,0 +1,54 @@
+"""models/train_group_neg_shared.py:7-76 -- group (stratified) negative sharing.
+Per epoch the links are re-ordered by group_shuffle_train (item strata, chop) on the host
+(outside the timing window, as the reference: :42-46); the inner loop (:53-68) runs on the
+device inside nncf_epoch_group_neg_shared, which also de-duplicates each batch's items
+(tf.unique, model_framework.py:45-48)."""
+import time
+
+import numpy as np
+import torch
+
+from .data_utils import group_shuffle_train
+from .train_base import TrainerBase
+
+
+class Trainer(TrainerBase):
+    def __init__(self, model_dict, conf, data_helper):
+        super(Trainer, self).__init__(model_dict, conf, data_helper)
+        self.model_train = model_dict["model_group_neg_shared"]
+        if conf.neg_dist != "unigram":
+            print("[WARNING] Only unigram neg_dist is currently supported "
+                  "for group_neg_shared training. Set neg_dist = unigram.")
+        self.group_shuffling_trick = getattr(conf, "group_shuffling_trick", False)
+        if self.group_shuffling_trick:
+            _num_in_train = np.max(data_helper.data["train"], axis=0) + 1
+            self._iidx = {"user": np.arange(_num_in_train[0]), "item": np.arange(_num_in_train[1])}
+        else:
+            raise NotImplementedError("group_shuffling_trick=False (GroupSampler, data_utils.py:244-408) is not "
+                                      "built yet; every shipped script sets it True")
+
+    def train(self, eval_scheme=None, use_async_eval=True):
+        conf = self.conf
+        b = conf.batch_size_p
+        train = self.data_helper.data["train"]
+        engine = self.model_train.engine
+        self.train_time = []
+        self.mean_n_u = []
+        for epoch in range(conf.max_epoch + 1):
+            cost, it = 0, 0
+            train = group_shuffle_train(train, by="item", chop=conf.chop_size, iidx=self._iidx["item"])
+            n_steps = len(train) // b if epoch > 0 else 0
+            uid, cid = self._upload(train, n_steps)
+            n_u = torch.zeros(max(n_steps, 1), dtype=torch.int32, device=engine.device)
+            torch.cuda.synchronize(engine.device)
+            t_start = time.time()
+            if n_steps:
+                losses = engine.epoch_group_neg_shared(uid, cid, n_steps, n_u_out=n_u)
+                cost = float(losses.double().sum().item())
+                it = n_steps
+            if epoch > 0:
+                self.train_time.append(time.time() - t_start)
+                self.mean_n_u.append(float(n_u[:n_steps].double().mean().item()))
+            self._epoch_report(epoch, it, cost, eval_scheme)
+        self.data_helper.data["train"] = train
+        self._finish()

@@ -1,0 +1,41 @@
+"""models/train_neg_shared.py:8-78 -- negative sharing (no additional negative sampling).
+The inner loop (:46-59) runs on the device inside nncf_epoch_neg_shared."""
+import time
+
+import numpy as np
+import torch
+
+from .train_base import TrainerBase
+
+
+class Trainer(TrainerBase):
+    def __init__(self, model_dict, conf, data_helper):
+        super(Trainer, self).__init__(model_dict, conf, data_helper)
+        self.model_train = model_dict["model_neg_shared"]
+        self.model_all_loss = model_dict["model_neg_shared_all_loss"]
+        self.monitor_rate = getattr(conf, "monitor_rate_all_loss", 0)
+        if conf.neg_dist != "unigram":  # :24-26
+            print("[WARNING] Only unigram neg_dist is currently supported "
+                  "for group_neg_shared training. Set neg_dist = unigram.")
+
+    def train(self, eval_scheme=None, use_async_eval=True):
+        conf = self.conf
+        b = conf.batch_size_p
+        train = self.data_helper.data["train"]
+        engine = self.model_train.engine
+        self.train_time = []
+        for epoch in range(conf.max_epoch + 1):
+            cost, it = 0, 0
+            np.random.shuffle(train)
+            n_steps = len(train) // b if epoch > 0 else 0
+            uid, cid = self._upload(train, n_steps)
+            torch.cuda.synchronize(engine.device)
+            t_start = time.time()
+            if n_steps:
+                losses = engine.epoch_neg_shared(uid, cid, n_steps)
+                cost = float(losses.double().sum().item())
+                it = n_steps
+            if epoch > 0:
+                self.train_time.append(time.time() - t_start)
+            self._epoch_report(epoch, it, cost, eval_scheme)
+        self._finish()
