@@ -124,6 +124,20 @@ def cpu_baseline(args, conf, inp, U0, V0):
             "sample": "%d steps of the same %s workload (numpy fp32 oracle, %.1f s)" % (steps, args.scheme, dt)}
 
 
+def measured_traffic(args, conf, d):
+    """Bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB -> bytes),
+    when one exists for exactly this workload; else None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    key = "%s/%s/b%d/d%d%s" % (args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
+    ent = table.get(key)
+    return ent["bytes_per_launch"] if ent else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +216,8 @@ def main():
     prof_n = min(K, args.profile_launches)
     eng.profile_begin(prof_n)
     run(W, prof_n)
-    kern_ms, launches = eng.profile_end()
+    raw_ms, launches, ov_ms = eng.profile_end()
+    kern_ms = max(raw_ms - ov_ms, 1e-9)   # bracket minus the empty-bracket (marker packet) cost
     n_cols = b
     if args.scheme == "original":
         # HBM-gather bound: 8d(2+k) + 8(1+k) bytes per link; the score kernel
@@ -219,7 +234,10 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "algorithmic_flops_per_launch": flops_per_launch}
     roof["kernel_ms"] = kern_ms
+    roof["event_bracket_ms"] = raw_ms
+    roof["empty_bracket_ms"] = ov_ms
     roof["launches"] = launches
+    roof["traffic"] = measured_traffic(args, conf, d)
 
     cpu = None
     if rank == 0 and args.cpu_seconds > 0:

@@ -158,9 +158,10 @@ int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, fl
  * _end every nncf_epoch_* step brackets its dominant kernel (the score kernel of `original`,
  * the U.V^T tile kernel of the shared-negative schemes) with HIP events on the launch stream,
  * for at most max_launches launches.  _end synchronises those events and returns the mean
- * kernel duration in milliseconds. */
+ * bracket in milliseconds plus the mean of an EMPTY bracket (two events back to back on the
+ * same stream) -- the marker-packet overhead to subtract when comparing with rocprofv3. */
 int nncf_model_profile_begin(nncf_model* m, int64_t max_launches);
-int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches);
+int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches, double* overhead_ms);
 
 /* Developer hook: per-workgroup s_memtime stamps of the last tile-kernel launch (only when the
  * model was created with NNCF_DEBUG_TIMING=1 in the environment).  Synchronous copy. */

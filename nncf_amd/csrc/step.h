@@ -45,7 +45,11 @@ struct KernelProfiler {
   std::vector<hipEvent_t> start, stop;
   size_t used = 0;
   bool enabled = false;
-  hipEvent_t* next_start() { return (enabled && used < start.size()) ? &start[used] : nullptr; }
+  hipStream_t last_stream = nullptr;
+  hipEvent_t* next_start(hipStream_t s) {
+    last_stream = s;
+    return (enabled && used < start.size()) ? &start[used] : nullptr;
+  }
 };
 
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,

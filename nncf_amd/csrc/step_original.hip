@@ -193,7 +193,7 @@ void launch_o(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, con
               const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
               KernelProfiler* prof) {
   const int b = a.b;
-  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
+  hipEvent_t* ev = prof ? prof->next_start(stream) : nullptr;
   if (ev) (void)hipEventRecord(*ev, stream);
   hipLaunchKernelGGL((original_score_kernel<LOSS, NU, NV>), dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos,
                      cid_neg, ws);

@@ -403,7 +403,7 @@ template <int LOSS, bool GROUP, bool NU, bool NV>
 void launch_pair(const StepArgs& a, const int32_t* uid, const int32_t* cid, const SharedWs& ws, const PlanView& pu,
                  const PlanView& pv, float* loss_out, int update, hipStream_t stream, KernelProfiler* prof) {
   const int nb = a.b / kTile;
-  hipEvent_t* ev = prof ? prof->next_start() : nullptr;
+  hipEvent_t* ev = prof ? prof->next_start(stream) : nullptr;
   if (ev) (void)hipEventRecord(*ev, stream);
   hipLaunchKernelGGL((shared_tile_kernel<LOSS, GROUP, NU, NV>), dim3(nb, nb), dim3(512), 0, stream, a, uid, cid, ws, pv);
   if (ev) (void)hipEventRecord(prof->stop[prof->used++], stream);

@@ -148,10 +148,10 @@ class Engine(object):
         _lib.check(self._L.nncf_model_profile_begin(self._h, int(max_launches)))
 
     def profile_end(self):
-        """(mean kernel ms, launches) of the dominant kernel since profile_begin."""
-        ms, n = ctypes.c_double(), ctypes.c_int64()
-        _lib.check(self._L.nncf_model_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
-        return ms.value, n.value
+        """(mean bracket ms, launches, empty-bracket ms) of the dominant kernel since profile_begin."""
+        ms, n, ov = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self._L.nncf_model_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(ov)))
+        return ms.value, n.value, ov.value
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None

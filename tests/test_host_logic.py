@@ -1,0 +1,121 @@
+"""CPU: host logic of the path (conf surface, degree histogram, stratified shuffle, truth CSR,
+synthetic data) and the oracle's metric code against vectors produced by the reference's own
+Python (tools/gen_golden_host.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import step_oracle as so
+from nncf_amd import synthetic
+from nncf_amd.conf import get_conf
+from nncf_amd.data_utils import degree_dist, group_shuffle_train
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def test_eval_multiple_matches_reference_outputs(gold):
+    for c in gold["ev_cases"].tolist():
+        got = so.eval_multiple(gold["ev%d_truth" % c], gold["ev%d_pred" % c], int(gold["ev%d_topk" % c][0]))
+        np.testing.assert_allclose(np.array(got), gold["ev%d_out" % c], rtol=0, atol=1e-12)
+
+
+def test_group_shuffle_matches_reference_up_to_within_group_order(gold):
+    for c in gold["gs_cases"].tolist():
+        train, want = gold["gs%d_train" % c], gold["gs%d_out" % c]
+        col = int(gold["gs%d_by" % c][0])
+        iidx = np.arange(train[:, col].max() + 1)
+        np.random.seed(int(gold["gs%d_seed" % c][0]))
+        got = group_shuffle_train(train.copy(), by="user" if col == 0 else "item", chop=0, iidx=iidx)
+        assert got.shape == want.shape
+        # identical sequence of groups and identical group membership (the reference's unstable
+        # argsort may order rows inside a group differently)
+        assert np.array_equal(got[:, col], want[:, col])
+        for g in np.unique(got[:, col]):
+            a, b = got[got[:, col] == g], want[want[:, col] == g]
+            assert np.array_equal(a[np.lexsort(a.T)], b[np.lexsort(b.T)])
+
+
+def test_group_shuffle_chop_properties():
+    rs = np.random.RandomState(0)
+    n, chop = 1003, 5
+    train = np.stack([rs.randint(0, 90, n), rs.randint(0, 40, n), np.ones(n, dtype=np.int64)], 1)
+    iidx = np.arange(40)
+    rng = np.random.RandomState(3)
+    out = group_shuffle_train(train.copy(), by="item", chop=chop, iidx=iidx, rng=rng)
+    assert sorted(map(tuple, out)) == sorted(map(tuple, train))  # a permutation of the links
+    # iidx is shuffled in place and persists across epochs (data_utils.py:231)
+    assert not np.array_equal(iidx, np.arange(40)) and sorted(iidx) == list(range(40))
+    # every aligned block of `chop` rows spans at most 2 items... no: a block is a contiguous run
+    # of the group-sorted array, so its items are consecutive in group order
+    key = iidx[out[:, 1]]
+    bulk = (n // chop) * chop
+    for s in range(0, bulk, chop):
+        blk = key[s:s + chop]
+        assert np.all(np.diff(blk) >= 0)
+    assert np.all(np.diff(key[bulk:]) >= 0)  # remainder rows stay at the end, in group order
+
+
+def test_degree_dist_follows_get_sampler():
+    train = np.array([[0, 3, 1], [1, 3, 1], [2, 0, 1], [2, 5, 1]])
+    assert degree_dist(train, 1, "unigram").tolist() == [1, 0, 0, 2, 0, 1]
+    assert degree_dist(train, 1, "uniform_no_correction").tolist() == [1, 0, 0, 1, 0, 1]  # suffix ignored (:201)
+    assert degree_dist(train, 0, "unigram").tolist() == [1, 1, 2]
+    with pytest.raises(AssertionError):
+        degree_dist(train, 1, "zipf")
+
+
+def test_conf_defaults_and_override_semantics():
+    c = get_conf("x", "default", None, model_choice="basic_embedding")
+    assert (c.batch_size_p, c.num_negatives, c.loss, c.learn_rate, c.loss_gamma, c.neg_loss_weight) == \
+        (512, 10, "skip-gram", 0.01, 10, 128)
+    assert c.emb_normalization is False and c.chop_size == 2 and c.eval_topk == 50 and c.u_reg == 1e-6
+    # learn_rate / gamma / weight are NOT recomputed from an overridden loss (basic_embedding_conf.py:22-24)
+    c = get_conf("x", "default", {"loss": "max-margin"}, model_choice="basic_embedding")
+    assert c.loss_gamma == 10 and c.emb_normalization is True
+    # 'best' forces num_negatives = 10 unless reset_after_getconf re-applies param_dict (:137-141)
+    c = get_conf("x", "best", {"num_negatives": 0}, model_choice="mf")
+    assert c.num_negatives == 10 and c.max_epoch == 30
+    c = get_conf("x", "best", {"num_negatives": 0, "reset_after_getconf": True}, model_choice="mf")
+    assert c.num_negatives == 0
+    assert get_conf("x", "default", None, model_choice="mf").interaction_bias == "item"
+    with pytest.raises(AssertionError):
+        get_conf("x", "nope")
+
+
+def test_truth_csr_equals_dense_matrix():
+    from nncf_amd.objectives import _truth_csr
+    rs = np.random.RandomState(2)
+    links = np.stack([rs.randint(0, 30, 200), rs.randint(0, 50, 200), np.ones(200, dtype=np.int64)], 1)
+    cand = np.unique(links[:150, 1])
+    ptr, idx = _truth_csr(links, cand, 30)
+    dense = np.zeros((30, len(cand)), dtype=np.int32)
+    slot = {it: i for i, it in enumerate(cand)}
+    for u, i, _ in links:  # objectives.py:412-416
+        if i in slot:
+            dense[u, slot[i]] = 1
+    for u in range(30):
+        assert np.array_equal(np.nonzero(dense[u])[0], idx[ptr[u]:ptr[u + 1]])
+
+
+def test_synthetic_schema():
+    d = synthetic.make_citeulike_like(users=300, items=200, train_links=3000, seed=1, content_len=12, vocab=50)
+    assert set(d) == {"C", "test_items", "train_items", "test", "test_seen", "train"}  # data/readme.txt:3
+    assert d["train"].shape[1] == 3 and d["train"].dtype == np.int64 and np.all(d["train"][:, 2] == 1)
+    assert len(np.unique(d["train"][:, :2], axis=0)) == len(d["train"])      # distinct links
+    assert not set(d["train_items"]) & set(d["test_items"])                    # cold-item split
+    assert set(np.unique(d["train"][:, 1])) == set(d["train_items"])          # every train item has a link
+    assert set(np.unique(d["test"][:, 1])) <= set(d["test_items"])
+    assert len(np.unique(d["train"][:, 0])) == 300                            # every user trains
+    C = d["C"]
+    assert C.shape == (200, 12) and C.min() == 0
+    first_nonzero = (C != 0).argmax(axis=1)
+    for r in range(200):  # zero padding at the beginning (data/readme.txt:5)
+        assert np.all(C[r, first_nonzero[r]:] != 0)
+    spec = synthetic.data_spec_of(d)
+    assert (spec.user_count, spec.item_count, spec.max_content_len) == (300, 200, 12)

@@ -149,3 +149,32 @@ def test_trainer_epochs_match_oracle_loop(small_data, scheme, loss):
     test_res = trainer.history[-1][4]
     assert abs(test_res["recall@50"] - want["recall"]) < 5e-3
     assert trainer.train_time and len(trainer.train_time) == conf.max_epoch
+
+
+def test_topk_kernel_matches_reference_eval_multiple():
+    """nncf_eval_topk against outputs of the reference's own eval_multiple
+    (tests/golden/host_golden.npz, tools/gen_golden_host.py; tie-free scores)."""
+    import ctypes
+    import os
+    from nncf_amd import _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_golden.npz"))
+    L = _lib.lib()
+    for c in g["ev_cases"].tolist():
+        pred, truth, topk = g["ev%d_pred" % c], g["ev%d_truth" % c], int(g["ev%d_topk" % c][0])
+        scores = torch.as_tensor(pred.astype(np.float32)).cuda().reshape(1, -1).contiguous()
+        idx = np.nonzero(truth)[0].astype(np.int32)
+        ptr = torch.as_tensor(np.array([0, len(idx)], dtype=np.int32)).cuda()
+        idx_t = torch.as_tensor(idx if len(idx) else np.zeros(1, dtype=np.int32)).cuda()
+        met = torch.zeros(3, device="cuda")
+        val = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(L.nncf_eval_topk(ctypes.c_void_p(scores.data_ptr()), 1, scores.shape[1], scores.shape[1],
+                                    ctypes.c_void_p(ptr.data_ptr()), ctypes.c_void_p(idx_t.data_ptr()), topk,
+                                    ctypes.c_void_p(met.data_ptr()), ctypes.c_void_p(val.data_ptr()),
+                                    _lib.stream_ptr()))
+        want = g["ev%d_out" % c]
+        if len(idx) == 0:
+            assert int(val.item()) == 0          # dropped from the mean (objectives.py:316)
+            assert want.tolist() == [0., 0., 0.]
+        else:
+            assert int(val.item()) == 1
+            np.testing.assert_allclose(met.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
