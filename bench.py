@@ -138,6 +138,78 @@ def measured_traffic(args, conf, d):
     return ent["bytes_per_launch"] if ent else None
 
 
+def main_sharded(args, conf, rank, world, local_rank):
+    """N > 1: one process per GPU, user/item tables range-sharded, three RCCL all-to-alls per
+    global step (nncf_amd/sharded.py).  Weak scaling: b positives per rank per step."""
+    import torch
+    import torch.distributed as dist
+    from nncf_amd.sharded import HipBackend, ShardedNegShared, partition_links_by_user, shard_size
+    from nncf_amd.synthetic import make_citeulike_like
+    if args.scheme != "neg_shared":
+        raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
+    data = make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7) if args.small else make_citeulike_like()
+    users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
+    b, d = conf.batch_size_p, args.dim
+    mine = partition_links_by_user(data["train"], users, world)[rank].copy()
+    rs = np.random.RandomState(4224 + rank)
+    need = (args.warmup + args.steps) * b
+    chunks, have = [], 0
+    while have < need:
+        rs.shuffle(mine)
+        chunks.append(mine.copy())
+        have += len(mine)
+    stream = np.concatenate(chunks, 0)[:need]
+    kw = dict(user_count=users, item_count=items, dim=d, batch_size_p=b, num_negatives=0, loss=conf.loss,
+              loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
+              learn_rate=conf.learn_rate, normalize_user=conf.normalize_user, normalize_item=conf.normalize_item)
+    us, isz = shard_size(users, world), shard_size(items, world)
+    be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank, seed=rank)
+    tr = ShardedNegShared(be, users, items, b, d)
+    uid, cid = be.ids(stream[:, 0]), be.ids(stream[:, 1])
+    W, K = args.warmup, args.steps
+    losses = torch.zeros(K, dtype=torch.float32, device=be.device)
+
+    def run(first, count, keep):
+        for t in range(first, first + count):
+            l = tr.step(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+            if keep:
+                losses[t - first].copy_(l[0])
+
+    run(0, W, False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, K, True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([t1 - t0], dtype=torch.float64, device=be.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ml = losses.double().mean()
+    dist.all_reduce(ml)
+    mean_loss = float(ml.item()) / world
+    if not np.isfinite(mean_loss):
+        raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)
+    if rank == 0:
+        line = {
+            "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables",
+            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=%s) d=%d, train_scheme=neg_shared, "
+                                   "loss=%s, b=%d per GPU, sparse SGD" % (args.model, d, conf.loss, b),
+                       "global_batch": b * world,
+                       "parallelism": "1 process per GPU; users + their links and item rows range-sharded; "
+                                      "3 RCCL all-to-alls per step (ids, rows, gradients)"},
+            "mean_loss": mean_loss,
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,10 +223,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
-    dist_on = world > 1
+    # NNCF_FORCE_SHARDED=1 runs the sharded (RCCL all-to-all) path even at world_size 1 (smoke run)
+    dist_on = world > 1 or os.environ.get("NNCF_FORCE_SHARDED") == "1"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if dist_on:
         dist.barrier()
@@ -162,6 +236,8 @@ def main():
     from nncf_amd.sampler import MultinomialSampler
 
     conf = conf_for(args)
+    if dist_on:
+        return main_sharded(args, conf, rank, world, local_rank)
     inp = build_inputs(args, conf, rank, world)
     b, k, d = conf.batch_size_p, conf.num_negatives, args.dim
     eng = Engine(inp["users"], inp["items"], d, b, k, conf.loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg,

@@ -182,6 +182,14 @@ int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid
 int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
                          void* stream);
 
+/* Sharded variant of nncf_step_neg_shared (no reference counterpart): the item
+ * "table" bound to the model is a buffer of rows FETCHED from their owner ranks and d_cid indexes
+ * that buffer; user rows are updated in place, item rows are left untouched and their gradients
+ * (after the normalisation backward, before the learning rate) are written to
+ * d_item_grad[row][dim] for every row that occurs in d_cid. */
+int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss,
+                                float* d_item_grad, void* stream);
+
 /* model_group_neg_shared.train_on_batch (train_group_neg_shared.py:53-61; model_framework.py:
  * 45-48,131-136,158-161; loss objectives.py:163-220): items are de-duplicated on device in
  * first-occurrence order (tf.unique), S = U_b . V_u^T (b x n_u), positive of row i = cid_x[i].
@@ -217,6 +225,17 @@ int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const in
 int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, int32_t n_cand,
                    const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
                    int32_t* d_valid, void* stream);
+
+/* Row movers of the sharded path (no reference counterpart).
+ * nncf_gather_rows: d_out[i][0..dim) = table row d_ids[i] (zeros where d_ids[i] < 0).
+ * nncf_scatter_apply: table[d_ids[i]] -= lr * d_rows[i] for every i with d_ids[i] >= 0; rows of
+ *   the same id are summed in list order first (deterministic, no atomics).  n <= 8192;
+ *   d_plan_ws: nncf_scatter_apply_ws_ints(n) int32 of 16-byte aligned scratch. */
+int nncf_gather_rows(const float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_ids, int64_t n,
+                     float* d_out, void* stream);
+int nncf_scatter_apply(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_ids, int32_t n,
+                       const float* d_rows, float lr, int32_t* d_plan_ws, void* stream);
+int64_t nncf_scatter_apply_ws_ints(int32_t n);
 
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
  * segment starts, and tf.unique-style first-occurrence outputs.

@@ -41,6 +41,7 @@ StepArgs make_args(const nncf_model* m) {
   a.lambda = c.neg_loss_weight;
   a.u_reg = c.u_reg;
   a.lr = c.learn_rate;
+  a.gV = nullptr;
   return a;
 }
 
@@ -265,6 +266,22 @@ int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_c
   rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
   if (rc) return rc;
   return launch_shared(make_args(m), 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+}
+
+int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss,
+                                 float* d_item_grad, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  if (int rc = check_shared(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_loss && d_item_grad, "NULL argument");
+  const int b = m->cfg.batch_size_p;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  StepArgs a = make_args(m);
+  a.gV = d_item_grad;
+  return launch_shared(a, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, 1, st);
 }
 
 int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,

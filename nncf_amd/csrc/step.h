@@ -15,6 +15,8 @@ struct StepArgs {
   int b, k;
   int loss, norm_u, norm_v;
   float gamma, lambda, u_reg, lr;
+  float* gV;  // if non-NULL the item rows are NOT updated: dL/dV rows are written to gV[row id][d]
+              // (sharded mode: V is a buffer of fetched rows, gradients go back to their owners)
 };
 
 // train_scheme = original

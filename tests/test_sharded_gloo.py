@@ -1,0 +1,165 @@
+"""CPU, world_size = 2 over gloo: the exchange logic of nncf_amd/sharded.py (routing tables,
+three all-to-alls, owner-side deterministic apply) with a numpy compute backend built on the
+oracle, against a single-process restatement of one synchronous global step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import step_oracle as so
+from nncf_amd.sharded import ShardedNegShared, partition_links_by_user, shard_size
+
+B, D, NU, NI = 32, 8, 40, 60
+STEPS = 3
+
+
+def _conf(loss):
+    return so.OracleConf(batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10. if loss == "log-loss" else None,
+                         u_reg=1e-3, learn_rate=0.1, model_choice="mf")
+
+
+def _tables(seed=0):
+    rs = np.random.RandomState(seed)
+    return (rs.uniform(-.5, .5, (NU, D)).astype(np.float32), rs.uniform(-.5, .5, (NI, D)).astype(np.float32))
+
+
+def _batches(world, seed=1):
+    """per rank: STEPS batches of B links whose users lie in the rank's range."""
+    rs = np.random.RandomState(seed)
+    us = shard_size(NU, world)
+    out = []
+    for r in range(world):
+        lo, hi = r * us, min(NU, (r + 1) * us)
+        out.append([(rs.randint(lo, hi, B), rs.randint(0, NI, B)) for _ in range(STEPS)])
+    return out
+
+
+class NumpyBackend(object):
+    """Test double of HipBackend: same interface, oracle arithmetic, CPU tensors."""
+
+    def __init__(self, conf, Ushard, Vshard):
+        self.conf, self.U, self.V = conf, Ushard, Vshard
+        self.lr = np.float32(conf.learn_rate)
+
+    def unique(self, cid):
+        u, x = so.tf_unique(cid.numpy())
+        uniq = np.full(cid.numel(), -1, dtype=np.int32)
+        uniq[:len(u)] = u
+        return torch.from_numpy(uniq), torch.from_numpy(x.astype(np.int32)), torch.tensor([len(u)])
+
+    def gather_rows(self, ids):
+        i = ids.numpy()
+        out = np.zeros((len(i), self.V.shape[1]), dtype=np.float32)
+        out[i >= 0] = self.V[i[i >= 0]]
+        return torch.from_numpy(out)
+
+    def local_step(self, uid_local, inverse, vrows):
+        o = so.StepOracle(self.U, vrows.numpy(), self.conf, dtype=np.float32)
+        loss = o.step_neg_shared(uid_local.numpy(), inverse.numpy())
+        self.U[...] = o.U                       # user rows are local: updated in place
+        return torch.tensor([loss]), torch.from_numpy(o.last["dV"].astype(np.float32))
+
+    def scatter_apply(self, ids, rows):
+        i, r = ids.numpy(), rows.numpy()
+        acc = {}
+        for k in range(len(i)):                 # list order = (rank, slot): deterministic
+            if i[k] >= 0:
+                acc[i[k]] = acc.get(i[k], np.zeros(r.shape[1], dtype=np.float32)) + r[k]
+        for k, g in acc.items():
+            self.V[k] -= self.lr * g
+
+
+def simulate_global_steps(loss, world):
+    """Single-process restatement: every rank's batch sees the pre-step tables; user rows are
+    disjoint across ranks; item gradients are summed over ranks (rank order) and applied once."""
+    conf = _conf(loss)
+    U, V = _tables()
+    batches = _batches(world)
+    lr = np.float32(conf.learn_rate)
+    losses = []
+    for t in range(STEPS):
+        dV = np.zeros_like(V)
+        newU = U.copy()
+        step_losses = []
+        for r in range(world):
+            uid, cid = batches[r][t]
+            o = so.StepOracle(U, V, conf, dtype=np.float32)
+            step_losses.append(o.step_neg_shared(uid, cid))
+            touched = np.unique(uid)
+            newU[touched] = o.U[touched]
+            dV += o.last["dV"]
+        U = newU
+        V = V - lr * dV
+        losses.append(step_losses)
+    return U, V, losses
+
+
+def _worker(rank, world, port, loss, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conf = _conf(loss)
+    U, V = _tables()
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    be = NumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy())
+    tr = ShardedNegShared(be, NU, NI, B, D)
+    losses = []
+    for uid, cid in _batches(world)[rank]:
+        l = tr.step(torch.from_numpy(uid.astype(np.int32)), torch.from_numpy(cid.astype(np.int32)))
+        losses.append(float(l[0]))
+    ret[rank] = (be.U.copy(), be.V.copy(), losses)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_world2_matches_single_process_restatement(loss):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), loss, ret), nprocs=world, join=True)
+    U, V, losses = simulate_global_steps(loss, world)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_ = ret[r]
+        np.testing.assert_allclose(Ur, U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vr, V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+        for t in range(STEPS):
+            assert abs(lr_[t] - losses[t][r]) < 1e-5 * max(1, abs(losses[t][r]))
+
+
+def test_world1_equals_plain_step():
+    """world_size 1 (no process group): the exchange degenerates to local copies."""
+    conf = _conf("skip-gram")
+    U, V = _tables()
+    be = NumpyBackend(conf, U.copy(), V.copy())
+    tr = ShardedNegShared(be, NU, NI, B, D)
+    o = so.StepOracle(U, V, conf, dtype=np.float32)
+    for uid, cid in _batches(1)[0]:
+        l = tr.step(torch.from_numpy(uid.astype(np.int32)), torch.from_numpy(cid.astype(np.int32)))
+        want = o.step_neg_shared(uid, cid)
+        assert abs(float(l[0]) - want) < 1e-5 * max(1, abs(want))
+    np.testing.assert_allclose(be.U, o.U, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(be.V, o.V, rtol=1e-5, atol=1e-6)
+
+
+def test_partition_links_by_user():
+    rs = np.random.RandomState(0)
+    train = np.stack([rs.randint(0, 37, 300), rs.randint(0, 50, 300), np.ones(300, dtype=np.int64)], 1)
+    parts = partition_links_by_user(train, 37, 4)
+    assert sum(len(p) for p in parts) == 300
+    us = shard_size(37, 4)
+    for r, p in enumerate(parts):
+        assert np.all(p[:, 0] // us == r)
