@@ -124,6 +124,18 @@ def cpu_baseline(args, conf, inp, U0, V0):
             "sample": "%d steps of the same %s workload (numpy fp32 oracle, %.1f s)" % (steps, args.scheme, dt)}
 
 
+def emit(line):
+    """Print the ONE JSON line last: flush C stdio first (RCCL prints its banner through printf,
+    which would otherwise land after Python's output at exit)."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def measured_traffic(args, conf, d):
     """Bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB -> bytes),
@@ -163,9 +175,10 @@ def main_sharded(args, conf, rank, world, local_rank):
               loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
               learn_rate=conf.learn_rate, normalize_user=conf.normalize_user, normalize_item=conf.normalize_item)
     us, isz = shard_size(users, world), shard_size(items, world)
-    be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank, seed=rank)
+    be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank,
+                    world=world, item_shard=isz, item_offset=rank * isz, seed=rank)
     tr = ShardedNegShared(be, users, items, b, d)
-    uid, cid = be.ids(stream[:, 0]), be.ids(stream[:, 1])
+    uid, cid = be.ids(stream[:, 0] - rank * us), be.ids(stream[:, 1])   # user ids relative to my range
     W, K = args.warmup, args.steps
     losses = torch.zeros(K, dtype=torch.float32, device=be.device)
 
@@ -206,7 +219,7 @@ def main_sharded(args, conf, rank, world, local_rank):
             "mean_loss": mean_loss,
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(line))
+        emit(line)
     dist.destroy_process_group()
 
 
@@ -229,6 +242,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if dist_on:
         dist.barrier()
@@ -335,7 +349,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        emit(line)
     if dist_on:
         dist.destroy_process_group()
 

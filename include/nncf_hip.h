@@ -226,15 +226,20 @@ int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, i
                    const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
                    int32_t* d_valid, void* stream);
 
-/* Row movers of the sharded path (no reference counterpart).
- * nncf_gather_rows: d_out[i][0..dim) = table row d_ids[i] (zeros where d_ids[i] < 0).
- * nncf_scatter_apply: table[d_ids[i]] -= lr * d_rows[i] for every i with d_ids[i] >= 0; rows of
- *   the same id are summed in list order first (deterministic, no atomics).  n <= 8192;
- *   d_plan_ws: nncf_scatter_apply_ws_ints(n) int32 of 16-byte aligned scratch. */
+/* Row movers and routing of the sharded path (no reference counterpart).
+ * nncf_shard_route: for a batch's item ids d_cid[n], with item rows owned by rank id / item_shard:
+ *   d_req[n_ranks][cap] = the unique ids to request from each owner (ascending, -1 padded) and
+ *   d_slot_of_pos[n] = request slot (owner * cap + k) holding the row of batch position i.
+ * nncf_gather_rows: d_out[i][0..dim) = table row (d_ids[i] - id_offset) (zeros where d_ids[i] < 0).
+ * nncf_scatter_apply: table[d_ids[i] - id_offset] -= lr * d_rows[i] for every i with d_ids[i] >= 0;
+ *   rows of the same id are summed in list order first (deterministic, no atomics).  n <= 8192.
+ * d_plan_ws: nncf_scatter_apply_ws_ints(n) int32 of 16-byte aligned scratch. */
+int nncf_shard_route(const int32_t* d_cid, int32_t n, int32_t item_shard, int32_t n_ranks, int32_t cap,
+                     int32_t* d_req, int32_t* d_slot_of_pos, int32_t* d_plan_ws, void* stream);
 int nncf_gather_rows(const float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_ids, int64_t n,
-                     float* d_out, void* stream);
+                     int32_t id_offset, float* d_out, void* stream);
 int nncf_scatter_apply(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_ids, int32_t n,
-                       const float* d_rows, float lr, int32_t* d_plan_ws, void* stream);
+                       int32_t id_offset, const float* d_rows, float lr, int32_t* d_plan_ws, void* stream);
 int64_t nncf_scatter_apply_ws_ints(int32_t n);
 
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),

@@ -79,8 +79,9 @@ def _declare(lib):
         "nncf_epoch_group_neg_shared": [vp, vp, vp, i64, vp, vp, vp],
         "nncf_predict_scores": [vp, vp, i64, vp, i64, vp, vp],
         "nncf_step_neg_shared_export": [vp, vp, vp, vp, vp, vp],
-        "nncf_gather_rows": [vp, i32, i32, vp, i64, vp, vp],
-        "nncf_scatter_apply": [vp, i32, i32, vp, i32, vp, f32, vp, vp],
+        "nncf_shard_route": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
+        "nncf_gather_rows": [vp, i32, i32, vp, i64, i32, vp, vp],
+        "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })

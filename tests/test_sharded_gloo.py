@@ -41,36 +41,46 @@ def _batches(world, seed=1):
 class NumpyBackend(object):
     """Test double of HipBackend: same interface, oracle arithmetic, CPU tensors."""
 
-    def __init__(self, conf, Ushard, Vshard):
+    def __init__(self, conf, Ushard, Vshard, world, item_shard, item_offset):
         self.conf, self.U, self.V = conf, Ushard, Vshard
         self.lr = np.float32(conf.learn_rate)
+        self.world, self.cap, self.isz, self.i0 = world, conf.batch_size_p, item_shard, item_offset
+        self.rows_in = torch.zeros(world * self.cap, Vshard.shape[1])
 
-    def unique(self, cid):
-        u, x = so.tf_unique(cid.numpy())
-        uniq = np.full(cid.numel(), -1, dtype=np.int32)
-        uniq[:len(u)] = u
-        return torch.from_numpy(uniq), torch.from_numpy(x.astype(np.int32)), torch.tensor([len(u)])
+    def route(self, cid):
+        c = cid.numpy()
+        req = np.full(self.world * self.cap, -1, dtype=np.int32)
+        slot_of = {}
+        for o in range(self.world):
+            mine = np.unique(c[(c // self.isz) == o])          # ascending ids of owner o
+            for k, it in enumerate(mine):
+                req[o * self.cap + k] = it
+                slot_of[it] = o * self.cap + k
+        return torch.from_numpy(req), torch.from_numpy(np.array([slot_of[x] for x in c], dtype=np.int32))
 
-    def gather_rows(self, ids):
-        i = ids.numpy()
+    def gather_rows(self, req_in):
+        i = req_in.numpy()
         out = np.zeros((len(i), self.V.shape[1]), dtype=np.float32)
-        out[i >= 0] = self.V[i[i >= 0]]
+        out[i >= 0] = self.V[i[i >= 0] - self.i0]
         return torch.from_numpy(out)
 
-    def local_step(self, uid_local, inverse, vrows):
-        o = so.StepOracle(self.U, vrows.numpy(), self.conf, dtype=np.float32)
-        loss = o.step_neg_shared(uid_local.numpy(), inverse.numpy())
+    def rows_landing(self):
+        return self.rows_in
+
+    def local_step(self, uid_local, slot):
+        o = so.StepOracle(self.U, self.rows_in.numpy(), self.conf, dtype=np.float32)
+        loss = o.step_neg_shared(uid_local.numpy(), slot.numpy())
         self.U[...] = o.U                       # user rows are local: updated in place
         return torch.tensor([loss]), torch.from_numpy(o.last["dV"].astype(np.float32))
 
-    def scatter_apply(self, ids, rows):
-        i, r = ids.numpy(), rows.numpy()
+    def scatter_apply(self, req_in, rows):
+        i, r = req_in.numpy(), rows.numpy()
         acc = {}
         for k in range(len(i)):                 # list order = (rank, slot): deterministic
             if i[k] >= 0:
                 acc[i[k]] = acc.get(i[k], np.zeros(r.shape[1], dtype=np.float32)) + r[k]
         for k, g in acc.items():
-            self.V[k] -= self.lr * g
+            self.V[k - self.i0] -= self.lr * g
 
 
 def simulate_global_steps(loss, world):
@@ -105,11 +115,12 @@ def _worker(rank, world, port, loss, ret):
     conf = _conf(loss)
     U, V = _tables()
     us, isz = shard_size(NU, world), shard_size(NI, world)
-    be = NumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy())
+    be = NumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, isz,
+                      rank * isz)
     tr = ShardedNegShared(be, NU, NI, B, D)
     losses = []
     for uid, cid in _batches(world)[rank]:
-        l = tr.step(torch.from_numpy(uid.astype(np.int32)), torch.from_numpy(cid.astype(np.int32)))
+        l = tr.step(torch.from_numpy((uid - rank * us).astype(np.int32)), torch.from_numpy(cid.astype(np.int32)))
         losses.append(float(l[0]))
     ret[rank] = (be.U.copy(), be.V.copy(), losses)
     dist.barrier()
@@ -144,7 +155,7 @@ def test_world1_equals_plain_step():
     """world_size 1 (no process group): the exchange degenerates to local copies."""
     conf = _conf("skip-gram")
     U, V = _tables()
-    be = NumpyBackend(conf, U.copy(), V.copy())
+    be = NumpyBackend(conf, U.copy(), V.copy(), 1, NI, 0)
     tr = ShardedNegShared(be, NU, NI, B, D)
     o = so.StepOracle(U, V, conf, dtype=np.float32)
     for uid, cid in _batches(1)[0]:

@@ -19,7 +19,7 @@ def test_sharded_world1_matches_plain_engine_and_oracle(loss):
     kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=gamma,
               neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=loss != "skip-gram", normalize_item=False)
     plain = Engine(seed=5, init_scale=0.5, **kw)
-    be = HipBackend(kw, nu, ni, 0, seed=0)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0)
     be.U.copy_(plain.U)
     be.V.copy_(plain.V)
     conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=gamma, neg_loss_weight=16., u_reg=1e-3,
@@ -50,12 +50,12 @@ def test_gather_and_scatter_apply_rows():
     ids_t, rows_t = torch.as_tensor(ids).cuda(), torch.as_tensor(rows).cuda()
     out = torch.empty(n, d, device="cuda")
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(L.nncf_gather_rows(p(table), d, d, p(ids_t), n, p(out), _lib.stream_ptr()))
+    _lib.check(L.nncf_gather_rows(p(table), d, d, p(ids_t), n, 0, p(out), _lib.stream_ptr()))
     want = np.where(ids[:, None] >= 0, table.cpu().numpy()[np.maximum(ids, 0)], 0)
     assert np.array_equal(out.cpu().numpy(), want)
     ws = torch.empty(int(L.nncf_scatter_apply_ws_ints(n)), dtype=torch.int32, device="cuda")
     t0 = table.cpu().numpy().copy()
-    _lib.check(L.nncf_scatter_apply(p(table), d, d, p(ids_t), n, p(rows_t), 0.5, p(ws), _lib.stream_ptr()))
+    _lib.check(L.nncf_scatter_apply(p(table), d, d, p(ids_t), n, 0, p(rows_t), 0.5, p(ws), _lib.stream_ptr()))
     ref = t0.copy()
     acc = np.zeros_like(ref)
     for i in range(n):  # list order
@@ -65,5 +65,5 @@ def test_gather_and_scatter_apply_rows():
     np.testing.assert_allclose(table.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
     # run-to-run deterministic
     table2 = torch.as_tensor(t0).cuda()
-    _lib.check(L.nncf_scatter_apply(p(table2), d, d, p(ids_t), n, p(rows_t), 0.5, p(ws), _lib.stream_ptr()))
+    _lib.check(L.nncf_scatter_apply(p(table2), d, d, p(ids_t), n, 0, p(rows_t), 0.5, p(ws), _lib.stream_ptr()))
     assert torch.equal(table, table2)
