@@ -215,6 +215,30 @@ int nncf_epoch_group_neg_shared(nncf_model* m, const int32_t* d_uid_all, const i
 int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const int32_t* d_cid, int64_t q,
                         float* d_out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * MeanPool item tower, gather half (modules/content/mean_pool.py:27-33,51-76; model_choice
+ * basic_embedding, model_framework.py:90-91,98).  Dense / BatchNorm / ReLU on the pooled
+ * (n_u x word_dim) block are done by the host side with library GEMMs (nncf_amd/mean_pool.py).
+ * nncf_meanpool_fwd: d_out[i] = (1/L) * sum_l scale[c] * words[c], c = d_content[i*L + l]
+ *   (divides by L always, mean_pool.py:30; d_row_scale = Embedding row-dropout mask or NULL).
+ * nncf_meanpool_bwd: sparse SGD on the word table through a static inverted index of the
+ *   content matrix (word w -> postings [d_post_ptr[w], d_post_ptr[w+1]) of (item, count), items
+ *   ascending): words[w] -= lr * scale[w] / L * sum_{items i of the batch} count * d_dh[slot_of_item[i]];
+ *   d_slot_of_item[item] = row of d_dh, or -1 for items outside the batch.  Fixed summation order.
+ * ---------------------------------------------------------------------------------- */
+int nncf_meanpool_fwd(const float* d_words, int32_t row_stride, int32_t word_dim, const int32_t* d_content,
+                      int64_t n_items, int32_t L, const float* d_row_scale, float* d_out, void* stream);
+int nncf_meanpool_bwd(float* d_words, int32_t row_stride, int32_t word_dim, int32_t n_words,
+                      const int32_t* d_post_ptr, const int32_t* d_post_item, const int32_t* d_post_cnt,
+                      const int32_t* d_slot_of_item, const float* d_dh, const float* d_row_scale, float lr, int32_t L,
+                      void* stream);
+
+/* Item-gradient export for towers that sit above the item "table" (text towers, sharded rows):
+ * while d_item_grad is non-NULL every nncf_step_* leaves the item rows untouched and writes
+ * dL/d(item row) (after the normalisation backward, before the learning rate) to
+ * d_item_grad[row id][dim] for each row id that occurs in the batch.  NULL restores updates. */
+int nncf_model_set_item_grad_export(nncf_model* m, float* d_item_grad);
+
 /* Evaluator whole@k for one candidate set (utils/objectives.py:296-370,395-421 +
  * utils/metrics_ranking.py:6-35 eval_multiple).  d_scores: n_users rows of n_cand scores
  * (row_stride floats apart, e.g. from nncf_predict_scores); truth in CSR over candidate slots

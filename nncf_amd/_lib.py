@@ -82,6 +82,9 @@ def _declare(lib):
         "nncf_shard_route": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
         "nncf_gather_rows": [vp, i32, i32, vp, i64, i32, vp, vp],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
+        "nncf_meanpool_fwd": [vp, i32, i32, vp, i64, i32, vp, vp, vp],
+        "nncf_meanpool_bwd": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp],
+        "nncf_model_set_item_grad_export": [vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })

@@ -21,6 +21,7 @@ struct nncf_model {
   PlanView plan_u, plan_v;  // kPlanChunk lists each
   int64_t cap_u = 0, cap_v = 0;
   KernelProfiler prof;
+  float* export_gV = nullptr;
 };
 
 namespace {
@@ -41,7 +42,7 @@ StepArgs make_args(const nncf_model* m) {
   a.lambda = c.neg_loss_weight;
   a.u_reg = c.u_reg;
   a.lr = c.learn_rate;
-  a.gV = nullptr;
+  a.gV = m->export_gV;
   return a;
 }
 
@@ -228,6 +229,12 @@ int nncf_model_debug_stamps(nncf_model* m, long long* out_host, int64_t n) {
   if (int rc = check_model(m)) return rc;
   NNCF_REQUIRE(m->sws.dbg != nullptr, "model was created without NNCF_DEBUG_TIMING=1");
   NNCF_HIP_CHECK(hipMemcpy(out_host, m->sws.dbg, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
+  return NNCF_OK;
+}
+
+int nncf_model_set_item_grad_export(nncf_model* m, float* d_item_grad) {
+  if (int rc = check_model(m)) return rc;
+  m->export_gV = d_item_grad;
   return NNCF_OK;
 }
 

@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
             const float inv = inv_norm(ss);
             grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
           }
-          row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
+          if (a.gV) row_store(a.gV, c, a.d, d4, q, grad);
+          else row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
         });
   }
 }

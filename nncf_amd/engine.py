@@ -21,7 +21,7 @@ class Engine(object):
 
     def __init__(self, user_count, item_count, dim, batch_size_p, num_negatives, loss, loss_gamma,
                  neg_loss_weight, u_reg, learn_rate, normalize_user, normalize_item, device=0, seed=0,
-                 share=None, init_scale=0.05):
+                 share=None, init_scale=0.05, tables=None):
         if loss not in _lib.LOSS_CODES:
             raise AssertionError("[ERROR!] loss %s not specified." % loss)  # objectives.py:72
         self._L = _lib.lib()
@@ -30,7 +30,10 @@ class Engine(object):
         self.b = int(batch_size_p)
         self.k = int(num_negatives)
         self.user_count, self.item_count = int(user_count), int(item_count)
-        if share is None:
+        if tables is not None:
+            self.U, self.V = tables  # caller-provided device tensors (e.g. shared U, tower output buffer)
+            assert self.U.is_cuda and self.V.is_cuda and self.U.is_contiguous() and self.V.is_contiguous()
+        elif share is None:
             gen = torch.Generator().manual_seed(int(seed))
             # Keras-1 Embedding default init: uniform(-0.05, 0.05) [K-mem]
             U = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
@@ -77,6 +80,12 @@ class Engine(object):
 
     def _stream(self):
         return _lib.stream_ptr(torch.cuda.current_stream(self.device))
+
+    def set_item_grad_export(self, buf):
+        """While `buf` ([rows][dim] fp32) is set, steps leave item rows untouched and write
+        dL/d(item row) there instead (text towers above the item block, sharded rows)."""
+        self._export = buf
+        _lib.check(self._L.nncf_model_set_item_grad_export(self._h, _ptr(buf)))
 
     # -- single steps (device ids in, device loss out; asynchronous) ----------------------
     def step_original(self, uid, cid, update=True, loss_out=None):
@@ -163,6 +172,28 @@ class Engine(object):
             self.close()
         except Exception:
             pass
+
+
+_plan_ws = {}
+
+
+def plan_unique(ids):
+    """tf.unique of a device id list through the plan kernel: (uniq[n] int32 device, first n_u
+    valid; inverse[n] int32 device; n_u python int -- one host sync)."""
+    L = _lib.lib()
+    n = ids.numel()
+    dev = ids.device
+    key = (dev, n)
+    if key not in _plan_ws:
+        mk = lambda k: torch.empty(k, dtype=torch.int32, device=dev)  # noqa: E731
+        _plan_ws[key] = dict(order=mk(n), seg=mk(n + 1), uniq=mk(n), inv=mk(n), cnt=mk(4), desc=mk(4 * n), ss=mk(n),
+                             ch=mk(n // 16 + 2))
+    w = _plan_ws[key]
+    with torch.cuda.device(dev):
+        _lib.check(L.nncf_plan_ids(_ptr(ids), n, _ptr(w["order"]), _ptr(w["seg"]), _ptr(w["uniq"]), _ptr(w["inv"]),
+                                   _ptr(w["cnt"]), _ptr(w["desc"]), _ptr(w["ss"]), _ptr(w["ch"]),
+                                   _lib.stream_ptr(torch.cuda.current_stream(dev))))
+    return w["uniq"], w["inv"], int(w["cnt"][0].item())
 
 
 def plan_ids(ids):

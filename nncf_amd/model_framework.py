@@ -5,13 +5,14 @@ expose the Keras-Model subset the trainers and the evaluator use (`train_on_batc
 Keras/TF graph.
 
 Scope of this build: the id-table towers (`model_name == 'mf'`, model_framework.py:85-88, and
-the user side of every model, :59-63).  The text towers (basic_embedding / cnn_embedding /
-rnn_embedding: MeanPool / CNN / RNN over item content, :89-111) are not built yet and raise.
+the user side of every model, :59-63) and the mean-pool text tower (`basic_embedding`,
+:90-91,98-111; nncf_amd/mean_pool.py).  cnn_embedding / rnn_embedding raise.
 All heads share ONE parameter set, as the reference's models share layer objects.
 """
 import numpy as np
+import torch
 
-from .engine import Engine
+from .engine import Engine, plan_unique
 
 
 def _as_ids(x):
@@ -52,6 +53,10 @@ class OriginalModel(_Head):
         e = self.engine
         return self._loss(e.step_original(e.ids(uid[:b]), e.ids(cid), update=self.update))
 
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None):
+        """The trainer's inner loop (train_original.py:43-68) on device; per-step losses."""
+        return self.engine.epoch_original(uid_all, cid_all, neg_all, n_steps)
+
 
 class NegSharedModel(_Head):
     """model_dict['model_neg_shared'] (model_framework.py:128-129,153-155)."""
@@ -63,6 +68,9 @@ class NegSharedModel(_Head):
     def train_on_batch(self, x, y=None):
         e = self.engine
         return self._loss(e.step_neg_shared(e.ids(_as_ids(x[0])), e.ids(_as_ids(x[1])), update=self.update))
+
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None):
+        return self.engine.epoch_neg_shared(uid_all, cid_all, n_steps)
 
     def predict_on_batch(self, x):
         """[uid (p,), cid (q,)] -> float32 (p, q) scores (utils/objectives.py:310)."""
@@ -83,6 +91,9 @@ class GroupNegSharedModel(_Head):
         if uid.size != e.b:
             raise ValueError("[ERROR] model_group_neg_shared needs exactly batch_size_p = %d rows" % e.b)
         return self._loss(e.step_group_neg_shared(e.ids(uid), e.ids(cid)))
+
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None, n_u_out=None):
+        return self.engine.epoch_group_neg_shared(uid_all, cid_all, n_steps, n_u_out=n_u_out)
 
 
 class SampledNegSharedModel(_Head):
@@ -152,6 +163,93 @@ class _LossMonitorDict(dict):
     iteritems = items
 
 
+# ----------------------------------------------------------------------------------------
+# heads of the content models (basic_embedding): text tower above the step kernels
+# ----------------------------------------------------------------------------------------
+class _TowerCore(object):
+    """Shared state of the basic_embedding heads: the user table + step workspace live in an
+    Engine whose item "table" is the block of tower outputs for the batch's unique items
+    (model_framework.py:45-48,98-106: content model on tf.unique(cid), re-gathered by cid_x);
+    item gradients are exported and sent back through the tower."""
+
+    def __init__(self, engine, tower, item_count, engine_kw, device):
+        self.engine, self.tower = engine, tower
+        self.item_count = item_count
+        self.gV = torch.zeros_like(engine.V)
+        self._eval = None
+        self._eval_version = -1
+        self._engine_kw, self._device = engine_kw, device
+
+    def step(self, kind, uid_dev, cid_dev, update=True):
+        e = self.engine
+        uniq, inverse, n_u = plan_unique(cid_dev)                  # device tf.unique; n_u -> host
+        E = self.tower.forward(uniq[:n_u], train=True)             # (n_u, d)
+        e.V[:n_u].copy_(E)
+        e.set_item_grad_export(self.gV)
+        if kind == "original":
+            loss = e.step_original(uid_dev, inverse, update=update)
+        elif kind == "neg_shared":
+            loss = e.step_neg_shared(uid_dev, inverse, update=update)
+        else:
+            loss = e.step_group_neg_shared(uid_dev, inverse, update=update)
+        if update:
+            self.tower.backward_update(self.gV[:n_u])
+        return loss
+
+    def eval_engine(self):
+        """Engine over (shared U, inference-mode embeddings of ALL items), refreshed when the
+        tower changed (predict_on_batch runs in the Keras inference phase: BN running stats,
+        no dropout; objectives.py:296-321)."""
+        if self._eval is None:
+            kw = dict(self._engine_kw)
+            kw["item_count"] = self.item_count
+            Vall = torch.zeros(self.item_count, self.engine.dim, dtype=torch.float32, device=self.engine.device)
+            self._eval = Engine(device=self._device, tables=(self.engine.U, Vall), **kw)
+        if self._eval_version != self.tower.version:
+            ids = torch.arange(self.item_count, dtype=torch.int32, device=self.engine.device)
+            for i0 in range(0, self.item_count, 4096):
+                self._eval.V[i0:i0 + 4096].copy_(self.tower.forward(ids[i0:i0 + 4096], train=False))
+            self._eval_version = self.tower.version
+        return self._eval
+
+
+class TowerHead(_Head):
+    def __init__(self, core, kind, update=True):
+        super(TowerHead, self).__init__(core.engine)
+        self.core, self.kind, self.update = core, kind, update
+
+    def train_on_batch(self, x, y=None):
+        e = self.engine
+        uid, cid = _as_ids(x[0]), _as_ids(x[1])
+        if self.kind == "original":
+            b, k = e.b, e.k
+            if uid.size != b * (1 + k) or not np.array_equal(uid[b:], np.repeat(uid[:b], k)):
+                raise ValueError("[ERROR] model expects the trainer's layout: b positives then k negatives per "
+                                 "positive (train_original.py:49-56)")
+            uid = uid[:b]
+        elif uid.size != e.b:
+            raise ValueError("[ERROR] %s needs exactly batch_size_p = %d rows" % (self.kind, e.b))
+        return self._loss(self.core.step(self.kind, e.ids(uid), e.ids(cid), update=self.update))
+
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None, n_u_out=None):
+        e = self.engine
+        b, k = e.b, e.k
+        losses = torch.empty(max(n_steps, 1), dtype=torch.float32, device=e.device)
+        for t in range(n_steps):
+            u, c = uid_all[t * b:(t + 1) * b], cid_all[t * b:(t + 1) * b]
+            if self.kind == "original":
+                c = torch.cat([c, neg_all[t * b * k:(t + 1) * b * k]])
+            losses[t:t + 1].copy_(self.core.step(self.kind, u, c))
+        return losses[:n_steps]
+
+    def predict_on_batch(self, x):
+        ev = self.core.eval_engine()
+        return ev.predict_scores(ev.ids(_as_ids(x[0])), ev.ids(_as_ids(x[1]))).cpu().numpy()
+
+    def predict_on_batch_device(self, uid_dev, cid_dev, out=None):
+        return self.core.eval_engine().predict_scores(uid_dev, cid_dev, out=out)
+
+
 def engine_kwargs(conf, data_spec, model_name):
     normalize = bool(conf.emb_normalization)
     return dict(
@@ -163,19 +261,62 @@ def engine_kwargs(conf, data_spec, model_name):
         normalize_item=normalize and model_name != "mf")        # :109-111 (content branch only)
 
 
+def _get_model_basic_embedding(conf, data_helper, device, seed):
+    from .mean_pool import MeanPoolTower
+    data_spec = data_helper.data_spec
+    if getattr(conf, "pretrain", None) or getattr(conf, "use_content_id", False) or conf.pooling != "average":
+        raise NotImplementedError("basic_embedding is built for pretrain=None, use_content_id=False, "
+                                  "pooling='average' (what the demo scripts run)")
+    idt = conf.item_dense_transform
+    assert idt["dense_hidden_dim"] == conf.item_dim and idt["dense_hidden_actv"] == "relu" and \
+        idt["dense_hidden_dropout"] == 0., "item_dense_transform other than Dense(item_dim)+relu is not built"
+    kw = engine_kwargs(conf, data_spec, "basic_embedding")
+    cap = conf.batch_size_p * (1 + conf.num_negatives)          # most unique items a batch can hold
+    kw["item_count"] = cap
+    engine = Engine(device=device, seed=seed, **kw)
+    tower = MeanPoolTower(data_helper.data["C"], data_spec.word_count, conf.word_dim, conf.item_dim,
+                          abs(conf.learn_rate), engine.device, seed=seed,
+                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.))
+    core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
+
+    def monitor(kind):
+        def make(loss_name):
+            kw2 = dict(kw)
+            kw2["loss"] = loss_name
+            kw2["learn_rate"] = 0.0
+            core2 = _TowerCore(Engine(device=device, tables=(engine.U, engine.V), **kw2), tower, data_spec.item_count,
+                               kw2, device)
+            return TowerHead(core2, kind, update=False)
+        return make
+
+    return {
+        "model": TowerHead(core, "original"),
+        "model_neg_shared": TowerHead(core, "neg_shared"),
+        "model_group_neg_shared": TowerHead(core, "group_neg_shared"),
+        "model_sampled_neg_shared": SampledNegSharedModel(engine),
+        "model_user_emb": EmbeddingModel(engine, "user"),
+        "model_item_emb": EmbeddingModel(engine, "item"),
+        "model_pred_pairs": PredPairsModel(engine),
+        "model_all_loss": _LossMonitorDict(monitor("original")),
+        "model_neg_shared_all_loss": _LossMonitorDict(monitor("neg_shared")),
+    }
+
+
 def get_model(conf, data_helper, model_name, device=0, seed=0):
     """get_model (model_framework.py:18-206)."""
     data_spec = data_helper.data_spec
-    if model_name != "mf":
-        assert model_name in ("basic_embedding", "cnn_embedding", "rnn_embedding", "pretrained"), \
-            "[ERROR] Model name {} unknown".format(model_name)  # model_framework.py:97
-        raise NotImplementedError(
-            "model_choice=%s: the item text towers (modules/content/*.py) are not built yet; "
-            "use model_choice=mf (id-table towers)" % model_name)
     assert conf.user_dim == conf.item_dim, "user_dim and item_dim must match for the dot interaction"
     if getattr(conf, "interaction_bias", None) is not None:
         raise NotImplementedError("interaction_bias=%r (interaction_dot.py:62-71) is not built yet; "
                                   "pass {'interaction_bias': None}" % conf.interaction_bias)
+    if model_name == "basic_embedding":
+        return _get_model_basic_embedding(conf, data_helper, device, seed)
+    if model_name != "mf":
+        assert model_name in ("cnn_embedding", "rnn_embedding", "pretrained"), \
+            "[ERROR] Model name {} unknown".format(model_name)  # model_framework.py:97
+        raise NotImplementedError(
+            "model_choice=%s: the CNN / RNN item towers (modules/content/{cnn,rnn}_model.py) are not built; "
+            "use basic_embedding (mean-pool text tower) or mf (id-table towers)" % model_name)
     kw = engine_kwargs(conf, data_spec, model_name)
     engine = Engine(device=device, seed=seed, **kw)
 

@@ -43,7 +43,7 @@ class Trainer(TrainerBase):
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
             if n_steps:
-                losses = engine.epoch_group_neg_shared(uid, cid, n_steps, n_u_out=n_u)
+                losses = self.model_train.run_epoch(uid, cid, n_steps, n_u_out=n_u)
                 cost = float(losses.double().sum().item())
                 it = n_steps
             if epoch > 0:

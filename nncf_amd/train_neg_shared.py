@@ -32,7 +32,7 @@ class Trainer(TrainerBase):
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
             if n_steps:
-                losses = engine.epoch_neg_shared(uid, cid, n_steps)
+                losses = self.model_train.run_epoch(uid, cid, n_steps)
                 cost = float(losses.double().sum().item())
                 it = n_steps
             if epoch > 0:

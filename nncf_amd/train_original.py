@@ -43,7 +43,7 @@ class Trainer(TrainerBase):
             t_start = time.time()
             if n_steps:
                 neg = sampler.sample_batch_device(n_steps * b * k)
-                losses = engine.epoch_original(uid, cid, neg, n_steps)
+                losses = self.model_train.run_epoch(uid, cid, n_steps, neg_all=neg)
                 cost = float(losses.double().sum().item())  # one host sync per epoch
                 it = n_steps
             if epoch > 0:

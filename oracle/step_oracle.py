@@ -227,6 +227,77 @@ def sampled_neg_shared_loss(S, conf):
     return dt.type(loss), G.astype(dt)
 
 
+
+# ----------------------------------------------------------------------------------------
+# item text tower of model_choice = basic_embedding
+# ----------------------------------------------------------------------------------------
+class TowerOracle(object):
+    """MeanPool (modules/content/mean_pool.py:46-110) as get_model wires it for
+    'basic_embedding' (model_framework.py:90-91,98): word Embedding -> AverageEmbeddings
+    (divides by L always, :27-33) -> Dense(d) -> BatchNormalization (batch statistics over the
+    n_u unique items of the batch, :90-95) -> ReLU -> Dropout(0).
+    [K-mem]: Keras-1 BatchNormalization eps = 1e-3, momentum = 0.99, biased variance, the
+    `running_std` slot holds the variance; Dense init glorot_uniform; Embedding init uniform(+-0.05).
+    All parameters take plain SGD steps (the build's optimiser)."""
+
+    def __init__(self, C, W, Wd, bd, gamma, beta, lr, dtype=np.float32, eps=1e-3, momentum=0.99):
+        self.dt = np.dtype(dtype)
+        self.C = np.asarray(C)
+        self.W = np.array(W, dtype=self.dt)
+        self.Wd = np.array(Wd, dtype=self.dt)
+        self.bd = np.array(bd, dtype=self.dt)
+        self.gamma = np.array(gamma, dtype=self.dt)
+        self.beta = np.array(beta, dtype=self.dt)
+        self.rm = np.zeros_like(self.beta)
+        self.rv = np.ones_like(self.beta)
+        self.lr = self.dt.type(lr)
+        self.eps, self.mom = self.dt.type(eps), self.dt.type(momentum)
+
+    def forward(self, cid_u, train=True, row_scale=None):
+        toks = self.C[np.asarray(cid_u)]                       # (n_u, L)
+        E = self.W[toks]                                       # (n_u, L, wd)
+        if row_scale is not None:
+            E = E * row_scale[toks][..., None]
+        h = E.sum(axis=1) / self.dt.type(toks.shape[1])        # mean_pool.py:30: divide by L always
+        z = h @ self.Wd + self.bd
+        if train:
+            mu = z.mean(axis=0)
+            var = ((z - mu) ** 2).mean(axis=0)
+        else:
+            mu, var = self.rm, self.rv
+        inv = 1.0 / np.sqrt(var + self.eps)
+        xhat = (z - mu) * inv
+        y = self.gamma * xhat + self.beta
+        if train:
+            self.cache = dict(toks=toks, h=h, xhat=xhat, inv=inv, y=y, row_scale=row_scale, mu=mu, var=var)
+        return np.maximum(y, 0).astype(self.dt)
+
+    def backward_update(self, dA):
+        c = self.cache
+        n = self.dt.type(dA.shape[0])
+        dy = dA * (c["y"] > 0)
+        dgamma = (dy * c["xhat"]).sum(axis=0)
+        dbeta = dy.sum(axis=0)
+        dxhat = dy * self.gamma
+        dz = c["inv"] / n * (n * dxhat - dxhat.sum(axis=0) - c["xhat"] * (dxhat * c["xhat"]).sum(axis=0))
+        dWd = c["h"].T @ dz
+        dbd = dz.sum(axis=0)
+        dh = dz @ self.Wd.T
+        L = self.dt.type(c["toks"].shape[1])
+        dW = np.zeros_like(self.W)
+        contrib = np.repeat(dh[:, None, :], c["toks"].shape[1], axis=1) / L
+        if c["row_scale"] is not None:
+            contrib = contrib * c["row_scale"][c["toks"]][..., None]
+        np.add.at(dW, c["toks"], contrib.astype(self.dt))
+        self.grads = dict(W=dW, Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
+        self.W -= self.lr * dW
+        self.Wd -= self.lr * dWd
+        self.bd -= self.lr * dbd
+        self.gamma -= self.lr * dgamma
+        self.beta -= self.lr * dbeta
+        self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
+        self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
+
 # ----------------------------------------------------------------------------------------
 # the model: id-table towers ('mf', model_framework.py:59-63,85-88) + sparse SGD
 # ----------------------------------------------------------------------------------------
@@ -235,11 +306,26 @@ class StepOracle(object):
 
     U: (user_count, d), V: (item_count, d) float arrays (copied, cast to `dtype`)."""
 
-    def __init__(self, U, V, conf, dtype=np.float32):
+    def __init__(self, U, V, conf, dtype=np.float32, tower=None):
         self.dt = np.dtype(dtype)
         self.U = np.array(U, dtype=self.dt, copy=True)
-        self.V = np.array(V, dtype=self.dt, copy=True)
+        self.V = np.array(V, dtype=self.dt, copy=True) if V is not None else None
         self.conf = conf
+        self.tower = tower  # TowerOracle: item rows come from the text tower (model_framework.py:98-106)
+
+    def _tower_in(self, cid):
+        """Content models run on tf.unique(cid) and are re-gathered (model_framework.py:45-48,
+        98-106): expose the compact block as this step's item 'table'."""
+        if self.tower is None:
+            return cid
+        cid_u, cid_x = tf_unique(cid)
+        self.V = self.tower.forward(cid_u, train=True)
+        self._n_u = len(cid_u)
+        return cid_x.astype(np.int64)
+
+    def _tower_out(self, update):
+        if self.tower is not None and update:
+            self.tower.backward_update(self.last["dV"][:self._n_u])
 
     # -- shared pieces -------------------------------------------------------------------
     def _user_side(self, uid):
@@ -280,6 +366,7 @@ class StepOracle(object):
     # -- train_scheme = original (train_original.py:49-58; model 'model', :123,147-149) ---
     def step_original(self, uid, cid, y, update=True):
         uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        cid = self._tower_in(cid)
         y = np.asarray(y).astype(self.dt).reshape(-1)
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid)
@@ -288,11 +375,13 @@ class StepOracle(object):
         self.scores = s
         if update:
             self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g[:, None] * hat_v, g[:, None] * hat_u)
+        self._tower_out(update)
         return float(loss + reg)
 
     # -- train_scheme = neg_shared (train_neg_shared.py:46-51; :128-129,153-155) ----------
     def step_neg_shared(self, uid, cid, update=True):
         uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        cid = self._tower_in(cid)
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid)
         S = hat_u @ hat_v.T                                            # interaction_dot.py:100-103
@@ -300,12 +389,14 @@ class StepOracle(object):
         self.scores = S
         if update:
             self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+        self._tower_out(update)
         return float(loss + reg)
 
     # -- train_scheme = group_neg_shared (train_group_neg_shared.py:53-61; :131-136,158-161)
     def step_group_neg_shared(self, uid, cid, update=True):
         uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
         assert len(uid) == self.conf.batch_size_p                      # row_cidx_prefx, :38-39,133-134
+        cid = self._tower_in(cid)
         cid_u, cid_x = tf_unique(cid)                                  # :45-48
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid_u)                   # compact item block
@@ -314,6 +405,7 @@ class StepOracle(object):
         self.scores, self.cid_u, self.cid_x = S, cid_u, cid_x
         if update:
             self._apply(uid, cid_u, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+        self._tower_out(update)
         return float(loss + reg)
 
     # -- train_scheme = sampled_neg_shared (train_sampled_neg_shared.py:46-52; :138-143,166-170)

@@ -220,3 +220,59 @@ def test_eval_multiple_formulas():
     assert abs(rec - 2 / 3) < 1e-12 and abs(prec - 0.5) < 1e-12
     assert abs(ap - (1 / 1 + 2 / 3) / 3) < 1e-12
     assert so.eval_multiple(np.zeros(8), pred, 4) == (0., 0., 0.)
+
+
+def test_tower_oracle_vs_autograd_full_chain():
+    """basic_embedding: MeanPool tower (mean_pool.py:46-110) + neg_shared log-loss step, every
+    parameter gradient against torch autograd of the formulas as the reference wires them
+    (content model on tf.unique(cid), BN batch statistics over the unique items)."""
+    rs = np.random.RandomState(0)
+    I, L, Wc, wd, d, nu, b = 30, 7, 20, 8, 8, 10, 8
+    C = rs.randint(0, Wc, (I, L))
+    C[:, :2] = 0  # left zero padding (data/readme.txt:5)
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = rs.uniform(-.1, .1, d), rs.uniform(.5, 1.5, d), rs.uniform(-.1, .1, d)
+    U = rs.uniform(-.5, .5, (nu, d))
+    for scheme, loss in (("neg_shared", "log-loss"), ("original", "skip-gram"), ("group_neg_shared", "max-margin")):
+        k = 2 if scheme == "original" else 0
+        conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, u_reg=1e-3, learn_rate=0.1,
+                             model_choice="basic_embedding")
+        tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.1, dtype=np.float64)
+        o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+        cid[3] = cid[0]
+        if scheme == "original":
+            uu, cc, yy = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=int)], 1), rs.randint(0, I, b * k), loss)
+            l_o = o.step_original(uu, cc, yy)
+        elif scheme == "neg_shared":
+            uu, cc = uid, cid
+            l_o = o.step_neg_shared(uid, cid)
+        else:
+            uu, cc = uid, cid
+            l_o = o.step_group_neg_shared(uid, cid)
+        tU = torch.tensor(U, requires_grad=True)
+        tp = [torch.tensor(x, requires_grad=True) for x in (W, Wd, bd, ga, be)]
+        cu, cx = so.tf_unique(cc)
+        h = tp[0][torch.tensor(C[cu])].sum(1) / L
+        z = h @ tp[1] + tp[2]
+        mu = z.mean(0)
+        var = ((z - mu) ** 2).mean(0)
+        E = torch.relu(tp[3] * (z - mu) / torch.sqrt(var + 1e-3) + tp[4])
+
+        class _V(object):  # an "item table" that is the tower output: reuse the id-table formulas
+            pass
+        Vt = E
+        if scheme == "original":
+            l_t = _torch_original(tU, Vt, torch.tensor(uu), torch.tensor(cx, dtype=torch.long),
+                                  torch.tensor(yy, dtype=torch.float64), conf)
+        elif scheme == "neg_shared":
+            l_t = _torch_neg_shared(tU, Vt, torch.tensor(uu), torch.tensor(cx, dtype=torch.long), conf)
+        else:
+            cu2, cx2 = so.tf_unique(cx)
+            l_t = _torch_group(tU, Vt, torch.tensor(uu), torch.tensor(cu2, dtype=torch.long),
+                               torch.tensor(cx2, dtype=torch.long), conf)
+        l_t.backward()
+        assert abs(l_o - l_t.item()) < 1e-10, scheme
+        for name, t in zip(("W", "Wd", "bd", "gamma", "beta"), tp):
+            np.testing.assert_allclose(tw.grads[name], t.grad.numpy(), atol=1e-10, err_msg=scheme + name)
+        np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)

@@ -1,0 +1,97 @@
+"""GPU: model_choice = basic_embedding (mean-pool text tower above the step kernels) against the
+oracle: per-step loss, every parameter after the update, inference-mode scores."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+from oracle import step_oracle as so  # noqa: E402
+from nncf_amd import synthetic  # noqa: E402
+from nncf_amd.conf import get_conf  # noqa: E402
+from nncf_amd.data_utils import get_data  # noqa: E402
+from nncf_amd.model_framework import get_model  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def text_data():
+    return synthetic.make_citeulike_like(users=300, items=260, train_links=5000, seed=3, content_len=24, vocab=120)
+
+
+def _conf(loss, scheme, b=64, k=3, d=24, lr=0.2):
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": loss, "num_negatives": k if scheme == "original" else 0,
+          "neg_loss_weight": 16, "loss_gamma": 0.1 if loss == "max-margin" else 10, "learn_rate": lr,
+          "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d, "item_dim": d,
+          "word_dim": d, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.}
+    return get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+
+
+def _oracle(conf, md, data):
+    core = md["model"].core
+    tw, eng = core.tower, core.engine
+    oc = so.OracleConf(batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
+                       loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
+                       learn_rate=conf.learn_rate, emb_normalization=conf.emb_normalization,
+                       model_choice="basic_embedding")
+    to = so.TowerOracle(data["C"], tw.W.cpu().numpy(), tw.Wd.cpu().numpy(), tw.bd.cpu().numpy(),
+                        tw.gamma.cpu().numpy(), tw.beta.cpu().numpy(), conf.learn_rate, dtype=np.float32)
+    return so.StepOracle(eng.U.cpu().numpy(), None, oc, dtype=np.float32, tower=to), to
+
+
+@pytest.mark.parametrize("scheme,loss", [("neg_shared", "skip-gram"), ("neg_shared", "log-loss"),
+                                         ("original", "skip-gram"), ("original", "log-loss"),
+                                         ("group_neg_shared", "log-loss"), ("group_neg_shared", "max-margin")])
+def test_basic_embedding_steps_match_oracle(text_data, scheme, loss):
+    conf = _conf(loss, scheme)
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    core = head.core
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        if scheme == "original":
+            negs = rs.randint(0, 260, b * k)
+            u, c, y = so.assemble_original(bt, negs, loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        tw = core.tower
+        np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5,
+                                       err_msg="%s step %d" % (name, step))
+    # inference phase (BN running statistics): predict_on_batch == oracle scores
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
+    want = oc2.predict_neg_shared(users, np.arange(len(items)))
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
+def test_basic_embedding_trainer_runs_and_learns(text_data):
+    conf = _conf("skip-gram", "neg_shared", lr=0.5)
+    conf.max_epoch = 3
+    data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in text_data.items()}
+    helper = get_data(data, conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    from nncf_amd.train_neg_shared import Trainer
+    np.random.seed(1)
+    tr = Trainer(md, conf, helper)
+    tr.train("whole")
+    costs = [h[2] for h in tr.history[1:]]
+    assert all(np.isfinite(costs)) and costs[-1] < costs[0]
+    assert tr.history[-1][4]["recall@50"] > 0  # cold-start items are scored through their text
