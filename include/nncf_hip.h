@@ -221,17 +221,35 @@ int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const in
  * (n_u x word_dim) block are done by the host side with library GEMMs (nncf_amd/mean_pool.py).
  * nncf_meanpool_fwd: d_out[i] = (1/L) * sum_l scale[c] * words[c], c = d_content[i*L + l]
  *   (divides by L always, mean_pool.py:30; d_row_scale = Embedding row-dropout mask or NULL).
- * nncf_meanpool_bwd: sparse SGD on the word table through a static inverted index of the
- *   content matrix (word w -> postings [d_post_ptr[w], d_post_ptr[w+1]) of (item, count), items
- *   ascending): words[w] -= lr * scale[w] / L * sum_{items i of the batch} count * d_dh[slot_of_item[i]];
- *   d_slot_of_item[item] = row of d_dh, or -1 for items outside the batch.  Fixed summation order.
+ * nncf_meanpool_bwd: sparse SGD on the word table,
+ *     words[w] -= lr * scale[w] / L * sum_{slots s < *d_n_items} count(w, item s) * d_dh[s],
+ *   d_item_ids[s] = item at batch slot s; static per-item CSR of the content matrix
+ *   (d_item_ptr[items+1], d_item_word ascending inside an item, d_item_cnt uint8);
+ *   scratch d_cnt_t[n_words * cap] and d_touched[n_words] bytes, ALL ZERO on entry and on exit.
+ *   Fixed summation order (slot order), no atomics.
  * ---------------------------------------------------------------------------------- */
 int nncf_meanpool_fwd(const float* d_words, int32_t row_stride, int32_t word_dim, const int32_t* d_content,
                       int64_t n_items, int32_t L, const float* d_row_scale, float* d_out, void* stream);
 int nncf_meanpool_bwd(float* d_words, int32_t row_stride, int32_t word_dim, int32_t n_words,
-                      const int32_t* d_post_ptr, const int32_t* d_post_item, const int32_t* d_post_cnt,
-                      const int32_t* d_slot_of_item, const float* d_dh, const float* d_row_scale, float lr, int32_t L,
-                      void* stream);
+                      const int32_t* d_item_ids, const int32_t* d_n_items, int32_t cap, const int32_t* d_item_ptr,
+                      const int32_t* d_item_word, const uint8_t* d_item_cnt, uint8_t* d_cnt_t, uint8_t* d_touched,
+                      const float* d_dh, const float* d_row_scale, float lr, int32_t L, void* stream);
+
+/* MeanPool item tower, dense half (mean_pool.py:87-97): Dense(item_dim) -> BatchNormalization
+ * (batch statistics over the first *d_n_valid rows; eps, momentum as Keras-1) -> ReLU.
+ * nncf_tower_fwd: d_z[m][item_dim] = d_h.Wd + bd (kept for the backward), d_E = relu(BN(z));
+ *   train != 0: batch statistics, running mean/var updated; train == 0: running statistics.
+ * nncf_tower_bwd: given d_dA = dL/dE: writes d_dh = dL/dh and takes the SGD step on Wd, bd,
+ *   gamma, beta in place.  Must follow the nncf_tower_fwd(train=1) of the same rows (statistics
+ *   are read from d_ws).  d_ws: nncf_tower_ws_floats(word_dim, item_dim) floats.
+ * Rows >= *d_n_valid are padding: computed, excluded from statistics and gradients. */
+int64_t nncf_tower_ws_floats(int32_t word_dim, int32_t item_dim);
+int nncf_tower_fwd(const float* d_h, int32_t m, const int32_t* d_n_valid, int32_t word_dim, int32_t item_dim,
+                   float* d_Wd, float* d_bd, float* d_gamma, float* d_beta, float* d_rm, float* d_rv, float eps,
+                   float momentum, int32_t train, float* d_z, float* d_E, float* d_ws, void* stream);
+int nncf_tower_bwd(const float* d_h, const float* d_z, const float* d_dA, int32_t m, const int32_t* d_n_valid,
+                   int32_t word_dim, int32_t item_dim, float* d_Wd, float* d_bd, float* d_gamma, float* d_beta,
+                   float lr, float* d_dh, float* d_ws, void* stream);
 
 /* Item-gradient export for towers that sit above the item "table" (text towers, sharded rows):
  * while d_item_grad is non-NULL every nncf_step_* leaves the item rows untouched and writes

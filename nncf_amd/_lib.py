@@ -83,8 +83,10 @@ def _declare(lib):
         "nncf_gather_rows": [vp, i32, i32, vp, i64, i32, vp, vp],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
         "nncf_meanpool_fwd": [vp, i32, i32, vp, i64, i32, vp, vp, vp],
-        "nncf_meanpool_bwd": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, f32, i32, vp],
+        "nncf_meanpool_bwd": [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp],
         "nncf_model_set_item_grad_export": [vp, vp],
+        "nncf_tower_fwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp],
+        "nncf_tower_bwd": [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })
@@ -96,6 +98,8 @@ def _declare(lib):
     lib.nncf_sampler_size.argtypes = [vp]
     lib.nncf_scatter_apply_ws_ints.restype = i64
     lib.nncf_scatter_apply_ws_ints.argtypes = [i32]
+    lib.nncf_tower_ws_floats.restype = i64
+    lib.nncf_tower_ws_floats.argtypes = [i32, i32]
 
 
 def lib():

@@ -5,9 +5,9 @@
 // `scale` is the per-word row-dropout mask of Keras' Embedding(dropout=...) (:56-59), NULL = 1.
 // Forward is an HBM gather of n*L word rows (4*L*word_dim bytes per item): one
 // workgroup per item, 16 row-groups each summing every 16th token with all loads in flight.
-// Backward walks a static inverted index (word -> sorted (item, count) postings, built once from
-// the content matrix) so that every word row is reduced by one group in a fixed order -- no
-// atomics, no per-step sort.
+// Backward transposes the batch's bag-of-words into word-major byte counts (from a static per-item
+// CSR of the content matrix) and reduces every touched word row in one workgroup with a fixed
+// summation order -- no float atomics, no per-step sort.
 #include "common.h"
 #include "devutil.h"
 
@@ -49,43 +49,73 @@ __global__ void __launch_bounds__(256) meanpool_fwd_kernel(const float* __restri
   }
 }
 
-// One 16-lane group per word.  slot_of_item[item] = row of dh for items in the batch, -1 else.
-__global__ void __launch_bounds__(256) meanpool_bwd_kernel(float* __restrict__ W, int stride, int wd, int n_words,
-                                                           const int32_t* __restrict__ post_ptr,
-                                                           const int32_t* __restrict__ post_item,
-                                                           const int32_t* __restrict__ post_cnt,
-                                                           const int32_t* __restrict__ slot_of_item,
-                                                           const float* __restrict__ dh, const float* __restrict__ scale,
-                                                           float lr_over_L) {
-  const int q = threadIdx.x & 15, d4 = wd >> 2;
-  const int w = blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (w >= n_words) return;
-  const int p0 = post_ptr[w], p1 = post_ptr[w + 1];
+// Backward, step 1: transpose the batch's bag-of-words into word-major byte counts.
+//   cnt_t[w * cap + s] = occurrences of word w in the item at batch slot s  (s < n_u)
+// from the static per-item CSR (item -> sorted unique (word, count)); touched[w] = 1.
+// Every (w, s) cell is written by exactly one thread: no atomics.
+__global__ void __launch_bounds__(256) meanpool_fill_kernel(const int32_t* __restrict__ item_ids,
+                                                            const int32_t* __restrict__ n_items_ptr,
+                                                            const int32_t* __restrict__ item_ptr,
+                                                            const int32_t* __restrict__ item_word,
+                                                            const uint8_t* __restrict__ item_cnt, int cap,
+                                                            uint8_t* __restrict__ cnt_t, uint8_t* __restrict__ touched) {
+  const int s = blockIdx.x;
+  if (s >= *n_items_ptr) return;
+  const int item = item_ids[s];
+  const int p0 = item_ptr[item], p1 = item_ptr[item + 1];
+  for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    const int w = item_word[p];
+    cnt_t[(int64_t)w * cap + s] = item_cnt[p];
+    touched[w] = 1;
+  }
+}
+
+// Backward, step 2: one workgroup per word.  Its 16 row-groups split the batch slots into
+// contiguous ranges, each adds count * dh[slot] over its range in slot order, the partials are
+// combined in group order: fixed summation order, any number of occurrences in parallel.
+// The workgroup clears the cells it consumed, so cnt_t / touched are all-zero again afterwards.
+__global__ void __launch_bounds__(256) meanpool_word_kernel(float* __restrict__ W, int stride, int wd,
+                                                            const int32_t* __restrict__ n_items_ptr, int cap,
+                                                            uint8_t* __restrict__ cnt_t, uint8_t* __restrict__ touched,
+                                                            const float* __restrict__ dh, const float* __restrict__ scale,
+                                                            float lr_over_L) {
+  __shared__ __attribute__((aligned(16))) float sR[16 * kMpPitch];
+  const int w = blockIdx.x;
+  if (!touched[w]) return;
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, d4 = wd >> 2;
+  const int n = *n_items_ptr;
+  const int per = ((n + 255) / 256) * 16;  // slots per group, multiple of 16
+  uint8_t* row = cnt_t + (int64_t)w * cap;
   Row acc = row_zero();
-  bool any = false;
-  for (int p = p0; p < p1; p += 16) {
-    // 16 postings per round: lane q probes posting p+q, hits are visited in posting order
-    int slot = -1, cnt = 0;
-    if (p + q < p1) {
-      slot = slot_of_item[post_item[p + q]];
-      cnt = post_cnt[p + q];
+  const int lo = grp * per, hi = min(n, lo + per);
+  for (int base = lo; base < hi; base += 16) {
+    int c = 0;
+    if (base + q < hi) {
+      c = row[base + q];
+      if (c) row[base + q] = 0;
     }
-    unsigned long long hits = __ballot(slot >= 0);
-    hits = (hits >> (threadIdx.x & 48)) & 0xFFFFull;  // this group's 16 lanes
+    unsigned long long hits = __ballot(c != 0);
+    hits = (hits >> (tid & 48)) & 0xFFFFull;  // this group's 16 lanes
     while (hits) {
       const int j = __ffsll((long long)hits) - 1;
       hits &= hits - 1;
-      const int src = (threadIdx.x & 48) + j;
-      const int s = __shfl(slot, src);
-      const float c = (float)__shfl(cnt, src);
-      acc = row_fma(c, row_load(dh, s, wd, d4, q), acc);
-      any = true;
+      const float cf = (float)__shfl(c, (tid & 48) + j);
+      acc = row_fma(cf, row_load(dh, base + j, wd, d4, q), acc);
     }
   }
-  if (any) {
+  reinterpret_cast<float4*>(sR + grp * kMpPitch)[q] = acc.a;
+  reinterpret_cast<float4*>(sR + grp * kMpPitch)[q + 16] = acc.b;
+  __syncthreads();
+  if (grp == 0) {
+    Row sum = row_zero();
+    for (int g = 0; g < 16; ++g) {
+      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kMpPitch)[q]);
+      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kMpPitch)[q + 16]);
+    }
     const float sc = scale ? scale[w] : 1.f;
     const Row old = row_load(W, w, stride, d4, q);
-    row_store(W, w, stride, d4, q, row_fma(-lr_over_L * sc, acc, old));
+    row_store(W, w, stride, d4, q, row_fma(-lr_over_L * sc, sum, old));
+    if (tid == 0) touched[w] = 0;
   }
 }
 
@@ -106,15 +136,19 @@ extern "C" int nncf_meanpool_fwd(const float* d_words, int32_t row_stride, int32
 }
 
 extern "C" int nncf_meanpool_bwd(float* d_words, int32_t row_stride, int32_t word_dim, int32_t n_words,
-                                 const int32_t* d_post_ptr, const int32_t* d_post_item, const int32_t* d_post_cnt,
-                                 const int32_t* d_slot_of_item, const float* d_dh, const float* d_row_scale, float lr,
-                                 int32_t L, void* stream) {
-  NNCF_REQUIRE(d_words && d_post_ptr && d_post_item && d_post_cnt && d_slot_of_item && d_dh, "NULL argument");
+                                 const int32_t* d_item_ids, const int32_t* d_n_items, int32_t cap,
+                                 const int32_t* d_item_ptr, const int32_t* d_item_word, const uint8_t* d_item_cnt,
+                                 uint8_t* d_cnt_t, uint8_t* d_touched, const float* d_dh, const float* d_row_scale,
+                                 float lr, int32_t L, void* stream) {
+  NNCF_REQUIRE(d_words && d_item_ids && d_n_items && d_item_ptr && d_item_word && d_item_cnt && d_cnt_t && d_touched &&
+                   d_dh, "NULL argument");
   NNCF_REQUIRE(word_dim > 0 && word_dim % 4 == 0 && word_dim <= 128 && row_stride >= word_dim, "bad word_dim");
-  NNCF_REQUIRE(n_words > 0 && L > 0, "bad shape");
-  hipLaunchKernelGGL(meanpool_bwd_kernel, dim3((unsigned)((n_words + 15) / 16)), dim3(256), 0, as_stream(stream),
-                     d_words, row_stride, word_dim, n_words, d_post_ptr, d_post_item, d_post_cnt, d_slot_of_item, d_dh,
-                     d_row_scale, lr / (float)L);
+  NNCF_REQUIRE(n_words > 0 && L > 0 && cap > 0, "bad shape");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(meanpool_fill_kernel, dim3((unsigned)cap), dim3(256), 0, st, d_item_ids, d_n_items, d_item_ptr,
+                     d_item_word, d_item_cnt, cap, d_cnt_t, d_touched);
+  hipLaunchKernelGGL(meanpool_word_kernel, dim3((unsigned)n_words), dim3(256), 0, st, d_words, row_stride, word_dim,
+                     d_n_items, cap, d_cnt_t, d_touched, d_dh, d_row_scale, lr / (float)L);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

@@ -180,6 +180,11 @@ _plan_ws = {}
 def plan_unique(ids):
     """tf.unique of a device id list through the plan kernel: (uniq[n] int32 device, first n_u
     valid; inverse[n] int32 device; n_u python int -- one host sync)."""
+    uniq, inv, cnt = _plan_unique_impl(ids)
+    return uniq, inv, int(cnt[0].item())
+
+
+def _plan_unique_impl(ids):
     L = _lib.lib()
     n = ids.numel()
     dev = ids.device
@@ -193,7 +198,13 @@ def plan_unique(ids):
         _lib.check(L.nncf_plan_ids(_ptr(ids), n, _ptr(w["order"]), _ptr(w["seg"]), _ptr(w["uniq"]), _ptr(w["inv"]),
                                    _ptr(w["cnt"]), _ptr(w["desc"]), _ptr(w["ss"]), _ptr(w["ch"]),
                                    _lib.stream_ptr(torch.cuda.current_stream(dev))))
-    return w["uniq"], w["inv"], int(w["cnt"][0].item())
+    return w["uniq"], w["inv"], w["cnt"]
+
+
+def plan_unique_device(ids):
+    """As plan_unique, without the host sync: (uniq, inverse, counts) device tensors, counts[0] = n_u."""
+    uniq, inv, _ = _plan_unique_impl(ids)
+    return uniq, inv, _plan_ws[(ids.device, ids.numel())]["cnt"]
 
 
 def plan_ids(ids):

@@ -5,8 +5,8 @@ items -> ReLU -> Dropout(0) -- with explicit forward / backward / SGD update (no
 
 Split of work: the memory-bound halves (gather + mean of n_u*L word rows forward, sparse
 word-table update backward) are HIP kernels (csrc/meanpool.hip); Dense / BatchNorm / ReLU on the
-pooled (n_u x word_dim) block are a few library GEMMs and elementwise ops through torch (the
-plain-library-GEMM allowance).
+pooled (n_u x word_dim) block are five small fused HIP launches (csrc/tower.hip).  torch only
+holds the buffers and does the integer content gather.
 [K-mem] Keras-1 defaults: Embedding init uniform(+-0.05), Dense init glorot_uniform with zero
 bias, BatchNormalization eps 1e-3, momentum 0.99, biased batch variance, running "std" slot
 holds the variance.
@@ -19,30 +19,35 @@ import torch
 from . import _lib
 
 
-def build_inverted_index(C, word_count):
-    """word -> postings (item ascending, count) of the content matrix C (items x L)."""
+def build_item_csr(C):
+    """Static per-item bag of words of the content matrix C (items x L):
+    ptr[items+1], word[nnz] (ascending inside an item), cnt[nnz] (uint8, saturating at 255)."""
     C = np.asarray(C, dtype=np.int64)
-    items = np.repeat(np.arange(C.shape[0], dtype=np.int64), C.shape[1])
-    key = C.reshape(-1) * C.shape[0] + items
+    n_items, L = C.shape
+    wmax = int(C.max()) + 1
+    key = np.repeat(np.arange(n_items, dtype=np.int64), L) * wmax + C.reshape(-1)
     uk, cnt = np.unique(key, return_counts=True)
-    words, its = uk // C.shape[0], uk % C.shape[0]
-    ptr = np.zeros(word_count + 1, dtype=np.int64)
-    np.add.at(ptr, words + 1, 1)
-    return np.cumsum(ptr).astype(np.int32), its.astype(np.int32), cnt.astype(np.int32)
+    items, words = uk // wmax, uk % wmax
+    ptr = np.zeros(n_items + 1, dtype=np.int64)
+    np.add.at(ptr, items + 1, 1)
+    assert cnt.max() <= 255 or L > 255, "token count overflow"
+    return np.cumsum(ptr).astype(np.int32), words.astype(np.int32), np.minimum(cnt, 255).astype(np.uint8)
 
 
 class MeanPoolTower(object):
     def __init__(self, C, word_count, word_dim, item_dim, learn_rate, device, seed=0, dropout_rate=0.0,
-                 eps=1e-3, momentum=0.99):
+                 eps=1e-3, momentum=0.99, max_rows=512):
         self.device = device
         self._L = _lib.lib()
         C = np.ascontiguousarray(np.asarray(C))
         self.item_count, self.Lc = C.shape
+        assert self.Lc <= 255, "max_content_len above 255 needs wider token counts"
         self.word_count, self.wd, self.d = int(word_count), int(word_dim), int(item_dim)
         assert self.wd % 4 == 0 and self.wd <= 128, "word_dim must be a multiple of 4 and <= 128"
         self.lr = float(learn_rate)
         self.eps, self.mom = float(eps), float(momentum)
         self.dropout = float(dropout_rate)
+        self.cap = int(max_rows)
         gen = torch.Generator().manual_seed(int(seed) + 17)
         dev = device
         self.W = ((torch.rand(self.word_count, self.wd, generator=gen) * 2 - 1) * 0.05).to(dev).contiguous()
@@ -54,12 +59,15 @@ class MeanPoolTower(object):
         self.rm = torch.zeros(self.d, device=dev)
         self.rv = torch.ones(self.d, device=dev)
         self.C = torch.as_tensor(C.astype(np.int32)).to(dev).contiguous()
-        ptr, its, cnt = build_inverted_index(C, self.word_count)
-        self.post_ptr = torch.as_tensor(ptr).to(dev)
-        self.post_item = torch.as_tensor(its).to(dev)
-        self.post_cnt = torch.as_tensor(cnt).to(dev)
-        self.slot_of_item = torch.full((self.item_count,), -1, dtype=torch.int32, device=dev)
+        ptr, words, cnt = build_item_csr(C)
+        self.item_ptr = torch.as_tensor(ptr).to(dev)
+        self.item_word = torch.as_tensor(words).to(dev)
+        self.item_cnt = torch.as_tensor(cnt).to(dev)
+        # scratch of the backward transpose: all-zero between calls (the kernels restore it)
+        self.cnt_t = torch.zeros(self.word_count * self.cap, dtype=torch.uint8, device=dev)
+        self.touched = torch.zeros(self.word_count, dtype=torch.uint8, device=dev)
         self._mask_gen = torch.Generator(device=dev).manual_seed(int(seed) + 29)
+        self._ws = None
         self.version = 0  # bumped by every update (the evaluator caches inference embeddings)
 
     def _stream(self):
@@ -80,50 +88,47 @@ class MeanPoolTower(object):
                                                  p(h), self._stream()))
         return h
 
-    def forward(self, item_ids, train=True):
-        """item embeddings (n, item_dim) for int32 device ids; train=True caches for backward."""
+    def forward(self, item_ids, train=True, n_valid=None, out=None):
+        """item embeddings (m, item_dim) for int32 device ids.  Only the first *n_valid rows
+        (a device int32[1], default all m) are real: the rest are padding that is computed but
+        excluded from the BatchNorm statistics -- shapes stay static, nothing syncs to the host.
+        train=True uses batch statistics and keeps what backward_update needs."""
+        m = item_ids.numel()
+        dev = self.device
+        if n_valid is None:
+            n_valid = torch.full((1,), m, dtype=torch.int32, device=dev)
         scale = None
         if train and self.dropout > 0:  # Embedding(dropout=p): whole word rows dropped per batch (:56-59)
             keep = 1.0 - self.dropout
-            scale = (torch.rand(self.word_count, generator=self._mask_gen, device=self.device) < keep).float() / keep
-        h = self._pool(item_ids, scale)
-        z = torch.addmm(self.bd, h, self.Wd)
+            scale = (torch.rand(self.word_count, generator=self._mask_gen, device=dev) < keep).float() / keep
+        # padding slots may hold stale ids: clamp them into range (their rows are masked downstream)
+        ids = torch.where(torch.arange(m, device=dev) < n_valid, item_ids, torch.zeros_like(item_ids)).contiguous()
+        h = self._pool(ids, scale)
+        z = torch.empty(m, self.d, dtype=torch.float32, device=dev)
+        E = out if out is not None else torch.empty(m, self.d, dtype=torch.float32, device=dev)
+        if self._ws is None:
+            self._ws = torch.zeros(int(self._L.nncf_tower_ws_floats(self.wd, self.d)), dtype=torch.float32, device=dev)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(self._L.nncf_tower_fwd(p(h), m, p(n_valid), self.wd, self.d, p(self.Wd), p(self.bd),
+                                              p(self.gamma), p(self.beta), p(self.rm), p(self.rv), self.eps, self.mom,
+                                              int(bool(train)), p(z), p(E), p(self._ws), self._stream()))
         if train:
-            mu = z.mean(0)
-            var = ((z - mu) ** 2).mean(0)
-        else:
-            mu, var = self.rm, self.rv
-        inv = torch.rsqrt(var + self.eps)
-        xhat = (z - mu) * inv
-        y = self.gamma * xhat + self.beta
-        if train:
-            self._cache = (item_ids, h, xhat, inv, y, scale, mu, var)
-        return torch.relu(y)
+            self._cache = (ids, n_valid, h, z, scale)
+        return E
 
     def backward_update(self, dA):
-        item_ids, h, xhat, inv, y, scale, mu, var = self._cache
-        n = float(dA.shape[0])
-        dy = dA * (y > 0)
-        dgamma = (dy * xhat).sum(0)
-        dbeta = dy.sum(0)
-        dxhat = dy * self.gamma
-        dz = inv / n * (n * dxhat - dxhat.sum(0) - xhat * (dxhat * xhat).sum(0))
-        dWd = h.t() @ dz
-        dbd = dz.sum(0)
-        dh = (dz @ self.Wd.t()).contiguous()
-        # sparse SGD on the word table through the inverted index (fixed order, no atomics)
-        ids = item_ids.long()
-        self.slot_of_item[ids] = torch.arange(ids.numel(), dtype=torch.int32, device=self.device)
+        ids, n_valid, h, z, scale = self._cache
+        m = ids.numel()
+        assert m <= self.cap and dA.shape[0] == m and dA.is_contiguous()
+        dh = torch.empty(m, self.wd, dtype=torch.float32, device=self.device)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
         with torch.cuda.device(self.device):
-            _lib.check(self._L.nncf_meanpool_bwd(p(self.W), self.wd, self.wd, self.word_count, p(self.post_ptr),
-                                                 p(self.post_item), p(self.post_cnt), p(self.slot_of_item), p(dh),
-                                                 p(scale), self.lr, self.Lc, self._stream()))
-        self.slot_of_item[ids] = -1
-        self.Wd -= self.lr * dWd
-        self.bd -= self.lr * dbd
-        self.gamma -= self.lr * dgamma
-        self.beta -= self.lr * dbeta
-        self.rm = self.mom * self.rm + (1 - self.mom) * mu
-        self.rv = self.mom * self.rv + (1 - self.mom) * var
+            _lib.check(self._L.nncf_tower_bwd(p(h), p(z), p(dA), m, p(n_valid), self.wd, self.d, p(self.Wd), p(self.bd),
+                                              p(self.gamma), p(self.beta), self.lr, p(dh), p(self._ws), self._stream()))
+            # sparse SGD on the word table (fixed order, no atomics)
+            _lib.check(self._L.nncf_meanpool_bwd(p(self.W), self.wd, self.wd, self.word_count, p(ids), p(n_valid),
+                                                 self.cap, p(self.item_ptr), p(self.item_word), p(self.item_cnt),
+                                                 p(self.cnt_t), p(self.touched), p(dh), p(scale), self.lr, self.Lc,
+                                                 self._stream()))
         self.version += 1

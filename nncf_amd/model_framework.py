@@ -12,7 +12,7 @@ All heads share ONE parameter set, as the reference's models share layer objects
 import numpy as np
 import torch
 
-from .engine import Engine, plan_unique
+from .engine import Engine, plan_unique_device
 
 
 def _as_ids(x):
@@ -176,16 +176,18 @@ class _TowerCore(object):
         self.engine, self.tower = engine, tower
         self.item_count = item_count
         self.gV = torch.zeros_like(engine.V)
+        engine.set_item_grad_export(self.gV)   # item rows are tower outputs: export, never update
         self._eval = None
         self._eval_version = -1
         self._engine_kw, self._device = engine_kw, device
 
     def step(self, kind, uid_dev, cid_dev, update=True):
+        """One training step, fully asynchronous (no host sync): the tower runs on a static block
+        of len(cid) rows of which the first n_u (a device scalar) are real."""
         e = self.engine
-        uniq, inverse, n_u = plan_unique(cid_dev)                  # device tf.unique; n_u -> host
-        E = self.tower.forward(uniq[:n_u], train=True)             # (n_u, d)
-        e.V[:n_u].copy_(E)
-        e.set_item_grad_export(self.gV)
+        uniq, inverse, counts = plan_unique_device(cid_dev)        # device tf.unique
+        m = cid_dev.numel()
+        self.tower.forward(uniq, train=True, n_valid=counts[0:1], out=e.V[:m])   # straight into the item block
         if kind == "original":
             loss = e.step_original(uid_dev, inverse, update=update)
         elif kind == "neg_shared":
@@ -193,7 +195,7 @@ class _TowerCore(object):
         else:
             loss = e.step_group_neg_shared(uid_dev, inverse, update=update)
         if update:
-            self.tower.backward_update(self.gV[:n_u])
+            self.tower.backward_update(self.gV[:m])
         return loss
 
     def eval_engine(self):
@@ -232,14 +234,55 @@ class TowerHead(_Head):
         return self._loss(self.core.step(self.kind, e.ids(uid), e.ids(cid), update=self.update))
 
     def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None, n_u_out=None):
+        """The trainer's inner loop.  The step (plan + tower forward + step kernels + tower
+        backward, ~50 launches of static shape) is captured once in a HIP graph and replayed per
+        batch; NNCF_NO_GRAPH=1 (or word-row dropout, which draws a fresh mask per step) runs it
+        eagerly."""
+        import os
         e = self.engine
         b, k = e.b, e.k
+        n_c = b * (1 + k) if self.kind == "original" else b
         losses = torch.empty(max(n_steps, 1), dtype=torch.float32, device=e.device)
-        for t in range(n_steps):
-            u, c = uid_all[t * b:(t + 1) * b], cid_all[t * b:(t + 1) * b]
+        if n_steps == 0:
+            return losses[:0]
+        if getattr(self, "_bufs", None) is None:
+            self._bufs = (torch.zeros(b, dtype=torch.int32, device=e.device),
+                          torch.zeros(n_c, dtype=torch.int32, device=e.device))
+            self._graph = None
+        ubuf, cbuf = self._bufs
+
+        def load(t):
+            ubuf.copy_(uid_all[t * b:(t + 1) * b])
+            cbuf[:b].copy_(cid_all[t * b:(t + 1) * b])
             if self.kind == "original":
-                c = torch.cat([c, neg_all[t * b * k:(t + 1) * b * k]])
-            losses[t:t + 1].copy_(self.core.step(self.kind, u, c))
+                cbuf[b:].copy_(neg_all[t * b * k:(t + 1) * b * k])
+
+        use_graph = os.environ.get("NNCF_NO_GRAPH") != "1" and self.core.tower.dropout == 0 and n_steps > 3
+        t = 0
+        if use_graph and self._graph is None:
+            load(0)
+            losses[0:1].copy_(self.core.step(self.kind, ubuf, cbuf))   # eager warm-up (lazy inits, allocator)
+            t = 1
+            try:
+                load(1)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._gloss = self.core.step(self.kind, ubuf, cbuf)
+                self._graph = g
+                # capture does not execute: run the captured step for batch 1 now
+                g.replay()
+                losses[1:2].copy_(self._gloss)
+                t = 2
+            except Exception as ex:  # capture unsupported: stay eager
+                print("[WARNING] HIP graph capture failed (%s); running eagerly" % type(ex).__name__)
+                self._graph = False
+        for t in range(t, n_steps):
+            load(t)
+            if use_graph and self._graph:
+                self._graph.replay()
+                losses[t:t + 1].copy_(self._gloss)
+            else:
+                losses[t:t + 1].copy_(self.core.step(self.kind, ubuf, cbuf))
         return losses[:n_steps]
 
     def predict_on_batch(self, x):
@@ -276,7 +319,7 @@ def _get_model_basic_embedding(conf, data_helper, device, seed):
     engine = Engine(device=device, seed=seed, **kw)
     tower = MeanPoolTower(data_helper.data["C"], data_spec.word_count, conf.word_dim, conf.item_dim,
                           abs(conf.learn_rate), engine.device, seed=seed,
-                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.))
+                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
 
     def monitor(kind):
