@@ -251,6 +251,17 @@ int nncf_tower_bwd(const float* d_h, const float* d_z, const float* d_dA, int32_
                    int32_t word_dim, int32_t item_dim, float* d_Wd, float* d_bd, float* d_gamma, float* d_beta,
                    float lr, float* d_dh, float* d_ws, void* stream);
 
+/* Two-phase step for models whose item rows are produced per batch (text towers):
+ *   nncf_plan_item_block: plans the batch (scheme 0 original: d_cid[b(1+k)]; 1 neg_shared,
+ *     2 group_neg_shared: d_cid[b]); d_uniq_global[len(d_cid)] = the batch's unique item ids in
+ *     tf.unique order (padding past *d_n_u points at id 0), *d_n_u = their number.  Batch
+ *     positions are re-indexed to ranks, i.e. to rows of the item block.
+ *   (caller fills rows [0, n_u) of the model's item table with the tower output for those ids)
+ *   nncf_step_planned: the step kernels on (user table, item block) with the stored plans. */
+int nncf_plan_item_block(nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                         int32_t* d_uniq_global, int32_t* d_n_u, void* stream);
+int nncf_step_planned(nncf_model* m, int32_t scheme, const int32_t* d_uid, float* d_loss, int update, void* stream);
+
 /* Item-gradient export for towers that sit above the item "table" (text towers, sharded rows):
  * while d_item_grad is non-NULL every nncf_step_* leaves the item rows untouched and writes
  * dL/d(item row) (after the normalisation backward, before the learning rate) to

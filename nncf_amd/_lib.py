@@ -85,6 +85,8 @@ def _declare(lib):
         "nncf_meanpool_fwd": [vp, i32, i32, vp, i64, i32, vp, vp, vp],
         "nncf_meanpool_bwd": [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp],
         "nncf_model_set_item_grad_export": [vp, vp],
+        "nncf_plan_item_block": [vp, i32, vp, vp, vp, vp, vp],
+        "nncf_step_planned": [vp, i32, vp, vp, i32, vp],
         "nncf_tower_fwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp],
         "nncf_tower_bwd": [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],

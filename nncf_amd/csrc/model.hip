@@ -291,6 +291,35 @@ int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32
   return launch_shared(a, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, 1, st);
 }
 
+int nncf_plan_item_block(nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                         int32_t* d_uniq_global, int32_t* d_n_u, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_uniq_global && d_n_u, "NULL argument");
+  NNCF_REQUIRE(scheme >= 0 && scheme <= 2, "scheme must be 0 (original), 1 (neg_shared) or 2 (group_neg_shared)");
+  const int b = m->cfg.batch_size_p, n = scheme == 0 ? b * (1 + m->cfg.num_negatives) : b;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, n, nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  return launch_plan_localize(m->plan_v, n, d_uniq_global, d_n_u, st);
+}
+
+int nncf_step_planned(nncf_model* m, int32_t scheme, const int32_t* d_uid, float* d_loss, int update, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_loss, "NULL argument");
+  NNCF_REQUIRE(scheme >= 0 && scheme <= 2, "scheme must be 0, 1 or 2");
+  const int b = m->cfg.batch_size_p;
+  hipStream_t st = as_stream(stream);
+  const int32_t* cid_local = m->plan_v.inverse;  // batch position -> row of the item block
+  if (scheme == 0) {
+    NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
+    return launch_original(make_args(m), d_uid, cid_local, cid_local + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st);
+  }
+  if (int rc = check_shared(m)) return rc;
+  return launch_shared(make_args(m), scheme == 2, d_uid, cid_local, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+}
+
 int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
                                int32_t* d_cid_u, int32_t* d_cid_x, int32_t* d_n_u, void* stream) {
   if (int rc = check_model(m)) return rc;

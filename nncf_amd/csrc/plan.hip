@@ -171,6 +171,28 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
   }
 }
 
+// Re-express a plan of GLOBAL ids in LOCAL ids = tf.unique ranks (the item block of a text tower
+// or of fetched rows is indexed by rank): desc[s].id = rank, uniq[j] = j; the global ids of the
+// ranks are copied out first.  One workgroup.
+__global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl, int n, int32_t* __restrict__ uniq_global,
+                                                            int32_t* __restrict__ n_u_out) {
+  const int nseg = pl.counts[0];
+  int4* desc = reinterpret_cast<int4*>(pl.desc);
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    uniq_global[j] = (j < nseg) ? pl.uniq[j] : 0;  // padding ranks point at row 0 (masked by the caller)
+  }
+  for (int s = threadIdx.x; s < nseg; s += blockDim.x) desc[s].x = pl.inverse[desc[s].y];
+  if (threadIdx.x == 0 && n_u_out) *n_u_out = nseg;
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += blockDim.x) pl.uniq[j] = j;
+}
+
+int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream) {
+  hipLaunchKernelGGL(plan_localize_kernel, dim3(1), dim3(256), 0, stream, pl, n, uniq_global, n_u_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
 int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb,
                 const PlanView& out, int64_t n_lists, hipStream_t stream) {
   const int n = na + nb;

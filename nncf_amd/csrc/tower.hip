@@ -49,9 +49,18 @@ __host__ __device__ inline size_t ws_dwd(int) { return ws_dbd(0) + (size_t)kTowe
 inline size_t ws_total(int wd, int d) { return ws_dwd(0) + (size_t)kTowerWG * wd * d; }
 
 __device__ __forceinline__ void stage_weights(float* sW, const float* Wd, int wd, int d) {
-  for (int e = threadIdx.x; e < wd * (d >> 2); e += blockDim.x) {
-    const int k = e / (d >> 2), c = e % (d >> 2);
-    reinterpret_cast<float4*>(sW + k * kTP)[c] = reinterpret_cast<const float4*>(Wd + (size_t)k * d)[c];
+  // wd*d/4 <= 4096 float4: 16 per thread, all loads issued before the first LDS store
+  const int d4 = d >> 2, n4 = wd * d4;
+  float4 t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = threadIdx.x + i * 256;
+    t[i] = (e < n4) ? reinterpret_cast<const float4*>(Wd)[e] : zero4();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int e = threadIdx.x + i * 256;
+    if (e < n4) reinterpret_cast<float4*>(sW + (e / d4) * kTP)[e % d4] = t[i];
   }
 }
 
@@ -136,15 +145,31 @@ __global__ void __launch_bounds__(256) tower_fwd1_kernel(TowerArgs a) {
 __global__ void __launch_bounds__(256) tower_fwd2_kernel(TowerArgs a) {
   __shared__ float sMu[128], sInv[128], sG[128], sB[128];
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2;
+  __shared__ float sPart[kTowerWG * 3 * 128];
+  const int nparts = min((int)kTowerWG, (a.m + 15) >> 4);
+  if (a.train) {  // all partial loads in flight at once, merged from LDS
+    const float4* src = reinterpret_cast<const float4*>(a.ws + ws_stats(0));
+    float4 t[24];  // kTowerWG*3*128/4 = 6144 float4 = 24 per thread
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      const int e = threadIdx.x + i * 256;
+      t[i] = (e < nparts * 96) ? src[e] : zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < nparts * 96) reinterpret_cast<float4*>(sPart)[e] = t[i];
+    }
+    __syncthreads();
+  }
   if (threadIdx.x < a.d) {
     const int c = threadIdx.x;
     float mu, var;
     if (a.train) {
       float n = 0.f, s2 = 0.f;
       mu = 0.f;
-      const int nparts = min((int)kTowerWG, (a.m + 15) >> 4);
       for (int p = 0; p < nparts; ++p) {
-        const float* in = a.ws + ws_stats(0) + (size_t)p * 3 * 128;
+        const float* in = sPart + p * 3 * 128;
         const float nb = in[c], mb = in[128 + c], sb = in[256 + c];
         if (nb > 0.f) {
           const float nn = n + nb, dlt = mb - mu;
@@ -262,22 +287,31 @@ __global__ void __launch_bounds__(256) tower_bwd2_kernel(TowerArgs a) {
     sG[tid] = a.gamma[tid];
     sB[tid] = a.beta[tid];
     float t1 = 0.f, t2 = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-      const float* in = a.ws + ws_bsum(0) + (size_t)p * 2 * 128;
-      t1 += in[tid];
-      t2 += in[128 + tid];
+    for (int p0 = 0; p0 < nparts; p0 += 16) {
+      float u1[16], u2[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float* in = a.ws + ws_bsum(0) + (size_t)(p0 + e) * 2 * 128;
+        u1[e] = (p0 + e < nparts) ? in[tid] : 0.f;
+        u2[e] = (p0 + e < nparts) ? in[128 + tid] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        t1 += u1[e];
+        t2 += u2[e];
+      }
     }
     sA[tid] = t1;   // sum dy       (= dbeta)
     sBq[tid] = t2;  // sum dy*xhat  (= dgamma)
   }
   const float n = (float)nv;
   // this thread's elements of the wd x d weight gradient
-  constexpr int kMaxElems = (128 * 128 + 255) / 256;
-  float gw[kMaxElems];
+  constexpr int kMaxCells = (128 * 32 + 255) / 256;
+  float4 gw[kMaxCells];
 #pragma unroll
-  for (int i = 0; i < kMaxElems; ++i) gw[i] = 0.f;
+  for (int i = 0; i < kMaxCells; ++i) gw[i] = zero4();
   float gb = 0.f;
-  const int nel = a.wd * a.d;
+  const int nel = a.wd * a.d, ncell = a.wd * d4;
   const int nblk = (a.m + 15) >> 4;
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int row = blk * 16 + grp;
@@ -302,31 +336,32 @@ __global__ void __launch_bounds__(256) tower_bwd2_kernel(TowerArgs a) {
     reinterpret_cast<float4*>(sZ + grp * kTP)[q] = dz.a;
     reinterpret_cast<float4*>(sZ + grp * kTP)[q + 16] = dz.b;
     __syncthreads();
-    // dh[row][k] = sum_n dz[n] * Wd[k][n]   (lane owns k = 4q.., 64+4q..)
+    // dh[row][k] = sum_n dz[n] * Wd[k][n]   (lane owns k = 4q.., 64+4q..; float4 LDS reads)
     if (row < a.m) {
       Row o = row_zero();
-      const float* dzr = sZ + grp * kTP;
+      const float4* dzr = reinterpret_cast<const float4*>(sZ + grp * kTP);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = col_of(q, e);
         if (k < a.wd) {
-          const float* wrow = sW + k * kTP;
+          const float4* wrow = reinterpret_cast<const float4*>(sW + k * kTP);
           float acc = 0.f;
-          for (int nn = 0; nn < a.d; ++nn) acc = fmaf(dzr[nn], wrow[nn], acc);
+          for (int n4 = 0; n4 < d4; ++n4) acc += dot4(dzr[n4], wrow[n4]);
           relem(o, e) = acc;
         }
       }
       row_store(a.dh, row, a.wd, wd4, q, o);
     }
-    // dWd[k][n] += sum_r h[r][k] dz[r][n]
+    // dWd[k][n..n+3] += sum_r h[r][k] dz[r][n..n+3]   (thread owns float4 cells of the gradient)
 #pragma unroll
-    for (int i = 0; i < kMaxElems; ++i) {
-      const int el = tid + i * 256;
-      if (el < nel) {
-        const int k = el / a.d, nn = el % a.d;
-        float acc = gw[i];
+    for (int i = 0; i < kMaxCells; ++i) {
+      const int cell = tid + i * 256;
+      if (cell < ncell) {
+        const int k = cell / d4, n4 = cell % d4;
+        float4 acc = gw[i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc = fmaf(sH[r * kTP + k], sZ[r * kTP + nn], acc);
+        for (int r = 0; r < 16; ++r)
+          acc = fma4(sH[r * kTP + k], reinterpret_cast<const float4*>(sZ + r * kTP)[n4], acc);
         gw[i] = acc;
       }
     }
@@ -335,11 +370,11 @@ __global__ void __launch_bounds__(256) tower_bwd2_kernel(TowerArgs a) {
       for (int r = 0; r < 16; ++r) gb += sZ[r * kTP + tid];
     }
   }
-  float* outw = a.ws + ws_dwd(0) + (size_t)blockIdx.x * nel;
+  float4* outw = reinterpret_cast<float4*>(a.ws + ws_dwd(0) + (size_t)blockIdx.x * nel);
 #pragma unroll
-  for (int i = 0; i < kMaxElems; ++i) {
-    const int el = tid + i * 256;
-    if (el < nel) outw[el] = gw[i];
+  for (int i = 0; i < kMaxCells; ++i) {
+    const int cell = tid + i * 256;
+    if (cell < ncell) outw[cell] = gw[i];
   }
   if (tid < a.d) a.ws[ws_dbd(0) + (size_t)blockIdx.x * 128 + tid] = gb;
 }
@@ -349,7 +384,13 @@ __global__ void __launch_bounds__(256) tower_update_kernel(TowerArgs a, int npar
   const int nel = a.wd * a.d;
   if (el < nel) {
     float g = 0.f;
-    for (int p = 0; p < nparts; ++p) g += a.ws[ws_dwd(0) + (size_t)p * nel + el];
+    for (int p0 = 0; p0 < nparts; p0 += 16) {  // 16 loads in flight, summed in partial order
+      float t[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) t[e] = (p0 + e < nparts) ? a.ws[ws_dwd(0) + (size_t)(p0 + e) * nel + el] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g += t[e];
+    }
     a.Wd[el] -= a.lr * g;
   }
   if (blockIdx.x == 0 && threadIdx.x < a.d) {

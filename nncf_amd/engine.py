@@ -145,6 +145,20 @@ class Engine(object):
                                                            _ptr(loss_out), _ptr(n_u_out), self._stream()))
         return loss_out[:n_steps]
 
+    SCHEMES = {"original": 0, "neg_shared": 1, "group_neg_shared": 2}
+
+    def plan_item_block(self, scheme, uid, cid, uniq_out, n_u_out):
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_plan_item_block(self._h, self.SCHEMES[scheme], _ptr(uid), _ptr(cid), _ptr(uniq_out),
+                                                    _ptr(n_u_out), self._stream()))
+
+    def step_planned(self, scheme, uid, update=True, loss_out=None):
+        out = self._loss1 if loss_out is None else loss_out
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_step_planned(self._h, self.SCHEMES[scheme], _ptr(uid), _ptr(out), int(update),
+                                                 self._stream()))
+        return out
+
     def predict_scores(self, uid, cid, out=None):
         p, q = uid.numel(), cid.numel()
         if out is None:

@@ -101,8 +101,7 @@ class MeanPoolTower(object):
         if train and self.dropout > 0:  # Embedding(dropout=p): whole word rows dropped per batch (:56-59)
             keep = 1.0 - self.dropout
             scale = (torch.rand(self.word_count, generator=self._mask_gen, device=dev) < keep).float() / keep
-        # padding slots may hold stale ids: clamp them into range (their rows are masked downstream)
-        ids = torch.where(torch.arange(m, device=dev) < n_valid, item_ids, torch.zeros_like(item_ids)).contiguous()
+        ids = item_ids  # padding slots past n_valid must hold in-range ids (nncf_plan_item_block writes 0)
         h = self._pool(ids, scale)
         z = torch.empty(m, self.d, dtype=torch.float32, device=dev)
         E = out if out is not None else torch.empty(m, self.d, dtype=torch.float32, device=dev)

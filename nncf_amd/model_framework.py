@@ -12,7 +12,7 @@ All heads share ONE parameter set, as the reference's models share layer objects
 import numpy as np
 import torch
 
-from .engine import Engine, plan_unique_device
+from .engine import Engine
 
 
 def _as_ids(x):
@@ -185,15 +185,13 @@ class _TowerCore(object):
         """One training step, fully asynchronous (no host sync): the tower runs on a static block
         of len(cid) rows of which the first n_u (a device scalar) are real."""
         e = self.engine
-        uniq, inverse, counts = plan_unique_device(cid_dev)        # device tf.unique
         m = cid_dev.numel()
-        self.tower.forward(uniq, train=True, n_valid=counts[0:1], out=e.V[:m])   # straight into the item block
-        if kind == "original":
-            loss = e.step_original(uid_dev, inverse, update=update)
-        elif kind == "neg_shared":
-            loss = e.step_neg_shared(uid_dev, inverse, update=update)
-        else:
-            loss = e.step_group_neg_shared(uid_dev, inverse, update=update)
+        if getattr(self, "_uniq", None) is None or self._uniq.numel() != m:
+            self._uniq = torch.zeros(m, dtype=torch.int32, device=e.device)
+            self._n_u = torch.zeros(1, dtype=torch.int32, device=e.device)
+        e.plan_item_block(kind, uid_dev, cid_dev, self._uniq, self._n_u)        # plans + tf.unique on device
+        self.tower.forward(self._uniq, train=True, n_valid=self._n_u, out=e.V[:m])  # straight into the item block
+        loss = e.step_planned(kind, uid_dev, update=update)
         if update:
             self.tower.backward_update(self.gV[:m])
         return loss
