@@ -39,36 +39,52 @@ def parse():
     ap.add_argument("--warmup", type=int, default=390)
     ap.add_argument("--scheme", default="neg_shared", choices=["original", "neg_shared", "group_neg_shared"])
     ap.add_argument("--loss", default=None)
-    ap.add_argument("--model", default="mf", choices=["mf"])
+    ap.add_argument("--model", default="basic_embedding", choices=["basic_embedding", "mf"],
+                    help="basic_embedding = mean-pool text tower (BASELINE configs[1]); mf = id-table towers only")
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--negatives", type=int, default=10)
     ap.add_argument("--chop", type=int, default=5)
+    ap.add_argument("--content-len", type=int, default=200)
+    ap.add_argument("--vocab", type=int, default=8001)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--profile-launches", type=int, default=2000)
+    ap.add_argument("--profile-launches", type=int, default=1000)
+    ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
     return ap.parse_args()
 
 
-def conf_for(args):
-    from oracle.step_oracle import OracleConf  # only for the cpu_baseline leg / defaults table
+def param_dict_for(args):
     loss = args.loss or ("log-loss" if args.scheme == "group_neg_shared" else "skip-gram")
-    gamma = {"max-margin": 0.1, "log-loss": 10.0}.get(loss, 10.0)
-    lam = 8.0 if loss == "mse" else 128.0
-    lr = 0.001 if loss == "mse" else 0.01
-    k = args.negatives if args.scheme == "original" else 0
-    return OracleConf(batch_size_p=args.batch, num_negatives=k, loss=loss, loss_gamma=gamma, neg_loss_weight=lam,
-                      u_reg=1e-6, learn_rate=lr, model_choice=args.model)
+    return {"reset_after_getconf": True, "max_epoch": 1, "loss": loss,
+            "num_negatives": args.negatives if args.scheme == "original" else 0,
+            "neg_loss_weight": 8 if loss == "mse" else 128, "loss_gamma": 0.1 if loss == "max-margin" else 10,
+            "learn_rate": 0.001 if loss == "mse" else 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
+            "batch_size_p": args.batch, "user_dim": args.dim, "item_dim": args.dim, "word_dim": args.dim,
+            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": 0., "interaction_bias": None}
+
+
+def conf_for(args):
+    from oracle.step_oracle import OracleConf  # only for the cpu_baseline leg
+    pd = param_dict_for(args)
+    return OracleConf(batch_size_p=pd["batch_size_p"], num_negatives=pd["num_negatives"], loss=pd["loss"],
+                      loss_gamma=pd["loss_gamma"], neg_loss_weight=pd["neg_loss_weight"], u_reg=pd["u_reg"],
+                      learn_rate=pd["learn_rate"], model_choice=args.model)
+
+
+def make_data(args):
+    from nncf_amd.synthetic import make_citeulike_like
+    text = args.content_len if args.model == "basic_embedding" else 0
+    if args.small:
+        return make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7, content_len=min(text, 40),
+                                   vocab=min(args.vocab, 500))
+    return make_citeulike_like(content_len=text, vocab=args.vocab)
 
 
 def build_inputs(args, conf, rank, world):
     """Shuffled (and for group_neg_shared: stratified) link stream long enough for warmup+steps."""
-    from nncf_amd.synthetic import make_citeulike_like
     from nncf_amd.data_utils import group_shuffle_train, degree_dist
-    if args.small:
-        data = make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7)
-    else:
-        data = make_citeulike_like()
+    data = make_data(args)
     train = data["train"].copy()
     users = int(train[:, 0].max()) + 1
     items = int(data["C"].shape[0])
@@ -92,7 +108,7 @@ def build_inputs(args, conf, rank, world):
     return dict(users=users, items=items, uid=stream[:, 0], cid=stream[:, 1], dist=dist, data=data)
 
 
-def cpu_baseline(args, conf, inp, U0, V0):
+def cpu_baseline(args, conf, inp, U0, V0, tower_params):
     """numpy oracle of the same step on the host cores, bounded sample."""
     from oracle import step_oracle as so
     from oracle.sampler_oracle import OracleSampler
@@ -101,13 +117,16 @@ def cpu_baseline(args, conf, inp, U0, V0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    o = so.StepOracle(U0, V0, conf, dtype=np.float32)
+    tower = None
+    if tower_params is not None:
+        tower = so.TowerOracle(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
+    o = so.StepOracle(U0, V0, conf, dtype=np.float32, tower=tower)
     b, k = conf.batch_size_p, conf.num_negatives
     sampler = OracleSampler(inp["dist"], 1.0, 12345) if args.scheme == "original" else None
     t0 = time.time()
     steps = 0
     max_steps = min(args.steps, len(inp["uid"]) // b)
-    while steps < max_steps and (time.time() - t0 < args.cpu_seconds or steps < 10):
+    while steps < max_steps and (time.time() - t0 < args.cpu_seconds or steps < 5):
         u = inp["uid"][steps * b:(steps + 1) * b]
         c = inp["cid"][steps * b:(steps + 1) * b]
         if args.scheme == "original":
@@ -121,7 +140,7 @@ def cpu_baseline(args, conf, inp, U0, V0):
         steps += 1
     dt = time.time() - t0
     return {"value": steps * b / dt, "unit": "positive-links/s", "cores": int(cores), "kind": "port",
-            "sample": "%d steps of the same %s workload (numpy fp32 oracle, %.1f s)" % (steps, args.scheme, dt)}
+            "sample": "%d steps of the same %s/%s workload (numpy fp32 oracle, %.1f s)" % (steps, args.model, args.scheme, dt)}
 
 
 def emit(line):
@@ -145,7 +164,7 @@ def measured_traffic(args, conf, d):
         table = json.load(open(path))
     except Exception:
         return None
-    key = "%s/%s/b%d/d%d%s" % (args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
+    key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
     ent = table.get(key)
     return ent["bytes_per_launch"] if ent else None
 
@@ -159,6 +178,8 @@ def main_sharded(args, conf, rank, world, local_rank):
     from nncf_amd.synthetic import make_citeulike_like
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
+    args.model = "mf"  # N > 1: id-table towers (sharded); see DESIGN.md section 6
+    conf = conf_for(args)
     data = make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7) if args.small else make_citeulike_like()
     users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
     b, d = conf.batch_size_p, args.dim
@@ -211,8 +232,9 @@ def main_sharded(args, conf, rank, world, local_rank):
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables",
-            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=%s) d=%d, train_scheme=neg_shared, "
-                                   "loss=%s, b=%d per GPU, sparse SGD" % (args.model, d, conf.loss, b),
+            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=mf; the text tower is not "
+                                   "sharded yet) d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
+                                   % (d, conf.loss, b),
                        "global_batch": b * world,
                        "parallelism": "1 process per GPU; users + their links and item rows range-sharded; "
                                       "3 RCCL all-to-alls per step (ids, rows, gradients)"},
@@ -246,7 +268,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if dist_on:
         dist.barrier()
-    from nncf_amd.engine import Engine
     from nncf_amd.sampler import MultinomialSampler
 
     conf = conf_for(args)
@@ -254,9 +275,22 @@ def main():
         return main_sharded(args, conf, rank, world, local_rank)
     inp = build_inputs(args, conf, rank, world)
     b, k, d = conf.batch_size_p, conf.num_negatives, args.dim
-    eng = Engine(inp["users"], inp["items"], d, b, k, conf.loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg,
-                 conf.learn_rate, conf.normalize_user, conf.normalize_item, device=local_rank, seed=0)
-    U0, V0 = eng.U.cpu().numpy().copy(), eng.V.cpu().numpy().copy()
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    from nncf_amd import engine as nengine
+    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice=args.model)
+    helper = get_data(inp["data"], pconf, rand_seed=12345, device=local_rank)
+    md = get_model(pconf, helper, args.model, device=local_rank, seed=0)
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[args.scheme]]
+    eng = head.engine
+    U0 = eng.U.cpu().numpy().copy()
+    V0, tower_params = None, None
+    if args.model == "mf":
+        V0 = eng.V.cpu().numpy().copy()
+    else:
+        tw = head.core.tower
+        tower_params = [t.cpu().numpy().copy() for t in (tw.W, tw.Wd, tw.bd, tw.gamma, tw.beta)]
     uid = eng.ids(inp["uid"])
     cid = eng.ids(inp["cid"])
     W, K = args.warmup, args.steps
@@ -268,21 +302,16 @@ def main():
 
     def run(first, count):
         u, c = uid[first * b:], cid[first * b:]
+        n = None
         if args.scheme == "original":
             # in-loop sampling is inside the reference's timing window (train_original.py:42-70):
             # the whole window's negatives are drawn on device first, same stream order.
             n = neg[first * b * k:(first + count) * b * k]
             sampler.sample_batch_device(count * b * k, out=n)
-            return eng.epoch_original(u, c, n, count)
-        if args.scheme == "neg_shared":
-            return eng.epoch_neg_shared(u, c, count)
-        return eng.epoch_group_neg_shared(u, c, count)
+        return head.run_epoch(u, c, count, neg_all=n)
 
     def sync():
         torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-            torch.cuda.synchronize()
 
     if W > 0:
         run(0, W)
@@ -291,67 +320,69 @@ def main():
     losses = run(W, K)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    if dist_on:
-        dist.barrier()
     elapsed = t1 - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     mean_loss = float(losses.double().mean().item())
     if not np.isfinite(mean_loss):
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)  # utilities.py:33-35
 
     # ---- roofline leg: same steps again, dominant kernel bracketed by HIP events ----------
+    # (eager launches: event records cannot sit inside a captured HIP graph)
+    L = args.content_len if not args.small else min(args.content_len, 40)
+    kernels = {
+        "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
+        "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
+        "meanpool_fwd_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B per unique item (n_u <= b rows)"),
+        "tower_bwd2_kernel": ("valu", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
+    }
+    default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
+        ("shared_tile_kernel" if args.model == "mf" else "tower_bwd2_kernel")
+    names = [args.roofline_kernel or default_kernel]
+    if args.model == "basic_embedding":
+        names += [n for n in ("meanpool_fwd_kernel", "shared_tile_kernel") if n not in names]
     prof_n = min(K, args.profile_launches)
-    eng.profile_begin(prof_n)
-    run(W, prof_n)
-    raw_ms, launches, ov_ms = eng.profile_end()
-    kern_ms = max(raw_ms - ov_ms, 1e-9)   # bracket minus the empty-bracket (marker packet) cost
-    n_cols = b
-    if args.scheme == "original":
-        # HBM-gather bound: 8d(2+k) + 8(1+k) bytes per link; the score kernel
-        # carries the read half of it: (2+k) row reads + ids per link.
-        bytes_per_launch = b * (4 * d * (2 + k) + 8 * (1 + k))
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        roof = {"kernel": "original_score_kernel", "bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": bytes_per_launch}
-    else:
-        flops_per_launch = 6.0 * b * n_cols * d     # S, G.V, G^T.U: 3 GEMMs of 2*b*N*d (upper bound N = b)
-        achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        roof = {"kernel": "shared_tile_kernel", "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "algorithmic_flops_per_launch": flops_per_launch}
-    roof["kernel_ms"] = kern_ms
-    roof["event_bracket_ms"] = raw_ms
-    roof["empty_bracket_ms"] = ov_ms
-    roof["launches"] = launches
+    os.environ["NNCF_NO_GRAPH"] = "1"
+    roofs = []
+    for name in names:
+        nengine.profile_begin(name, prof_n)
+        run(W, prof_n)
+        raw_ms, launches, ov_ms = nengine.profile_end()
+        kern_ms = max(raw_ms - ov_ms, 1e-9)   # bracket minus the empty-bracket (marker packet) cost
+        bound, work, what = kernels.get(name, ("hbm", 0.0, "n/a"))
+        if bound == "hbm":
+            ach, peak, unit = work / (kern_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / (kern_ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        roofs.append({"kernel": name, "bound": "mfma" if bound == "valu" else bound, "achieved": ach, "peak": peak,
+                      "unit": unit, "frac": ach / peak, "traffic": None, "algorithmic_per_launch": work,
+                      "algorithmic_what": what, "kernel_ms": kern_ms, "event_bracket_ms": raw_ms,
+                      "empty_bracket_ms": ov_ms, "launches": launches})
+    os.environ.pop("NNCF_NO_GRAPH", None)
+    roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d)
 
     cpu = None
     if rank == 0 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(args, conf, inp, U0, V0)
+        cpu = cpu_baseline(args, conf, inp, U0, V0, tower_params)
 
     if rank == 0:
         value = K * b * world / elapsed
+        tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, Dense+BN+ReLU)" % (L, args.vocab)
+                     if args.model == "basic_embedding" else "id-table towers (model_choice=mf)")
         line = {
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables",
-            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=%s) d=%d, train_scheme=%s, "
-                                   "loss=%s, b=%d%s, sparse SGD" % (args.model, d, args.scheme, conf.loss, b,
-                                                                   (", k=%d" % k) if k else ""),
-                       "global_batch": b * world,
-                       "parallelism": "1 process per GPU%s" % ("" if world == 1 else ", independent replicas (no exchange yet)")},
+            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
+                    % (", item text" if args.model == "basic_embedding" else ""),
+            "config": {"workload": "CiteULike-a-shaped, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, sparse SGD"
+                                   % (tower_txt, d, args.scheme, conf.loss, b, (", k=%d" % k) if k else ""),
+                       "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
             "roofline": roof,
+            "roofline_other_kernels": roofs[1:],
             "cpu_baseline": cpu,
         }
         emit(line)
-    if dist_on:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

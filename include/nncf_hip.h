@@ -154,14 +154,15 @@ int nncf_model_destroy(nncf_model* m);
 /* learn_rate / loss hyper-parameters may change between steps (same shapes). */
 int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg);
 
-/* Measurement hook (bench.py roofline leg; no reference counterpart): between _begin and
- * _end every nncf_epoch_* step brackets its dominant kernel (the score kernel of `original`,
- * the U.V^T tile kernel of the shared-negative schemes) with HIP events on the launch stream,
- * for at most max_launches launches.  _end synchronises those events and returns the mean
- * bracket in milliseconds plus the mean of an EMPTY bracket (two events back to back on the
- * same stream) -- the marker-packet overhead to subtract when comparing with rocprofv3. */
-int nncf_model_profile_begin(nncf_model* m, int64_t max_launches);
-int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches, double* overhead_ms);
+/* Measurement hook (bench.py roofline leg; no reference counterpart): between _begin and _end
+ * every launch of the named kernel (e.g. "shared_tile_kernel", "original_score_kernel",
+ * "meanpool_word_kernel", "tower_bwd2_kernel") from any entry point is bracketed with HIP events
+ * on its launch stream, for at most max_launches launches.  _end synchronises those events and
+ * returns the mean bracket in milliseconds plus the mean of an EMPTY bracket (two events back to
+ * back on the same stream) -- the marker-packet overhead to subtract when comparing with
+ * rocprofv3.  Process-wide, not thread-safe; do not use while a HIP graph is being captured. */
+int nncf_profile_begin(const char* kernel, int64_t max_launches);
+int nncf_profile_end(double* avg_ms, int64_t* launches, double* overhead_ms);
 
 /* Developer hook: per-workgroup s_memtime stamps of the last tile-kernel launch (only when the
  * model was created with NNCF_DEBUG_TIMING=1 in the environment).  Synchronous copy. */

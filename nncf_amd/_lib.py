@@ -68,9 +68,9 @@ def _declare(lib):
         "nncf_model_destroy": [vp],
         "nncf_model_set_hparams": [vp, f32, f32, f32, f32],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
-        "nncf_model_profile_begin": [vp, i64],
-        "nncf_model_profile_end": [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
-                                   ctypes.POINTER(ctypes.c_double)],
+        "nncf_profile_begin": [ctypes.c_char_p, i64],
+        "nncf_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                             ctypes.POINTER(ctypes.c_double)],
         "nncf_step_original": [vp, vp, vp, vp, i32, vp],
         "nncf_step_neg_shared": [vp, vp, vp, vp, i32, vp],
         "nncf_step_group_neg_shared": [vp, vp, vp, vp, i32, vp, vp, vp, vp],

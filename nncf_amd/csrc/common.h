@@ -51,6 +51,17 @@ inline Affine lcg_power(uint64_t n) {
   return result;
 }
 
+// Library-wide measurement hook (nncf_profile_begin / _end): while a kernel name is selected,
+// every launch site of that kernel brackets the launch with HIP events on the launch stream.
+hipEvent_t* gprof_start(const char* kernel, hipStream_t stream);  // NULL when not selected / full
+void gprof_stop(hipEvent_t* stop, hipStream_t stream);
+struct ProfScope {
+  hipEvent_t* stop;
+  hipStream_t stream;
+  ProfScope(const char* kernel, hipStream_t s) : stop(gprof_start(kernel, s)), stream(s) {}
+  ~ProfScope() { gprof_stop(stop, stream); }
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace nncf

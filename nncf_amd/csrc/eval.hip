@@ -108,8 +108,11 @@ extern "C" int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t ro
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
     attr_set = true;
   }
-  hipLaunchKernelGGL((eval_topk_kernel<NT>), dim3((unsigned)n_users), dim3(NT), lds, as_stream(stream), d_scores,
+  {
+    ProfScope _ps("eval_topk_kernel", as_stream(stream));
+    hipLaunchKernelGGL((eval_topk_kernel<NT>), dim3((unsigned)n_users), dim3(NT), lds, as_stream(stream), d_scores,
                      row_stride, n_cand, d_truth_ptr, d_truth_idx, topk, d_metrics, d_valid);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

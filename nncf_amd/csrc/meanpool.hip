@@ -129,8 +129,11 @@ extern "C" int nncf_meanpool_fwd(const float* d_words, int32_t row_stride, int32
   NNCF_REQUIRE(word_dim > 0 && word_dim % 4 == 0 && word_dim <= 128 && row_stride >= word_dim, "bad word_dim");
   NNCF_REQUIRE(L > 0, "max_content_len must be positive");
   if (n_items <= 0) return NNCF_OK;
-  hipLaunchKernelGGL(meanpool_fwd_kernel, dim3((unsigned)n_items), dim3(256), 0, as_stream(stream), d_words, row_stride,
+  {
+    ProfScope _ps("meanpool_fwd_kernel", as_stream(stream));
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3((unsigned)n_items), dim3(256), 0, as_stream(stream), d_words, row_stride,
                      word_dim, d_content, L, d_row_scale, d_out);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -145,10 +148,16 @@ extern "C" int nncf_meanpool_bwd(float* d_words, int32_t row_stride, int32_t wor
   NNCF_REQUIRE(word_dim > 0 && word_dim % 4 == 0 && word_dim <= 128 && row_stride >= word_dim, "bad word_dim");
   NNCF_REQUIRE(n_words > 0 && L > 0 && cap > 0, "bad shape");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(meanpool_fill_kernel, dim3((unsigned)cap), dim3(256), 0, st, d_item_ids, d_n_items, d_item_ptr,
+  {
+    ProfScope _ps("meanpool_fill_kernel", st);
+    hipLaunchKernelGGL(meanpool_fill_kernel, dim3((unsigned)cap), dim3(256), 0, st, d_item_ids, d_n_items, d_item_ptr,
                      d_item_word, d_item_cnt, cap, d_cnt_t, d_touched);
-  hipLaunchKernelGGL(meanpool_word_kernel, dim3((unsigned)n_words), dim3(256), 0, st, d_words, row_stride, word_dim,
+  }
+  {
+    ProfScope _ps("meanpool_word_kernel", st);
+    hipLaunchKernelGGL(meanpool_word_kernel, dim3((unsigned)n_words), dim3(256), 0, st, d_words, row_stride, word_dim,
                      d_n_items, cap, d_cnt_t, d_touched, d_dh, d_row_scale, lr / (float)L);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

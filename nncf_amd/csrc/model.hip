@@ -20,7 +20,6 @@ struct nncf_model {
   SharedWs sws;
   PlanView plan_u, plan_v;  // kPlanChunk lists each
   int64_t cap_u = 0, cap_v = 0;
-  KernelProfiler prof;
   float* export_gV = nullptr;
 };
 
@@ -170,58 +169,7 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
 int nncf_model_destroy(nncf_model* m) {
   if (!m) return NNCF_OK;
   if (m->arena) hipFree(m->arena);
-  for (hipEvent_t e : m->prof.start) hipEventDestroy(e);
-  for (hipEvent_t e : m->prof.stop) hipEventDestroy(e);
   delete m;
-  return NNCF_OK;
-}
-
-int nncf_model_profile_begin(nncf_model* m, int64_t max_launches) {
-  if (int rc = check_model(m)) return rc;
-  NNCF_REQUIRE(max_launches > 0 && max_launches <= 65536, "max_launches out of range");
-  KernelProfiler& p = m->prof;
-  while ((int64_t)p.start.size() < max_launches) {
-    hipEvent_t a, b;
-    NNCF_HIP_CHECK(hipEventCreate(&a));
-    NNCF_HIP_CHECK(hipEventCreate(&b));
-    p.start.push_back(a);
-    p.stop.push_back(b);
-  }
-  p.used = 0;
-  p.enabled = true;
-  return NNCF_OK;
-}
-
-int nncf_model_profile_end(nncf_model* m, double* avg_ms, int64_t* launches, double* overhead_ms) {
-  if (int rc = check_model(m)) return rc;
-  NNCF_REQUIRE(avg_ms && launches && overhead_ms, "NULL argument");
-  KernelProfiler& p = m->prof;
-  p.enabled = false;
-  double total = 0;
-  for (size_t i = 0; i < p.used; ++i) {
-    NNCF_HIP_CHECK(hipEventSynchronize(p.stop[i]));
-    float ms = 0;
-    NNCF_HIP_CHECK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
-    total += ms;
-  }
-  *launches = (int64_t)p.used;
-  *avg_ms = p.used ? total / (double)p.used : 0.0;
-  // Calibration: the same event pair with nothing between them, on the same stream.  What it
-  // reads is the cost of the two marker packets themselves, which the bracket above includes.
-  const size_t ncal = p.start.size() < 64 ? p.start.size() : 64;
-  double cal = 0;
-  for (size_t i = 0; i < ncal; ++i) {
-    NNCF_HIP_CHECK(hipEventRecord(p.start[i], p.last_stream));
-    NNCF_HIP_CHECK(hipEventRecord(p.stop[i], p.last_stream));
-  }
-  for (size_t i = 0; i < ncal; ++i) {
-    NNCF_HIP_CHECK(hipEventSynchronize(p.stop[i]));
-    float ms = 0;
-    NNCF_HIP_CHECK(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
-    cal += ms;
-  }
-  *overhead_ms = ncal ? cal / (double)ncal : 0.0;
-  p.used = 0;
   return NNCF_OK;
 }
 
@@ -355,7 +303,7 @@ int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* 
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
       rc = launch_original(a, d_uid_all + t * b, d_cid_all + t * b, d_neg + t * b * k, m->ows, m->plan_u.at(i),
-                           m->plan_v.at(i), d_loss + t, 1, st, &m->prof);
+                           m->plan_v.at(i), d_loss + t, 1, st);
       if (rc) return rc;
     }
   }
@@ -378,7 +326,7 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
       rc = launch_shared(a, group, d_uid_all + t * b, d_cid_all + t * b, m->sws, m->plan_u.at(i), m->plan_v.at(i),
-                         d_loss + t, 1, st, &m->prof);
+                         d_loss + t, 1, st);
       if (rc) return rc;
     }
     if (d_n_u) {

@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl, int n, 
 }
 
 int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream) {
-  hipLaunchKernelGGL(plan_localize_kernel, dim3(1), dim3(256), 0, stream, pl, n, uniq_global, n_u_out);
+  {
+    ProfScope _ps("plan_localize_kernel", stream);
+    hipLaunchKernelGGL(plan_localize_kernel, dim3(1), dim3(256), 0, stream, pl, n, uniq_global, n_u_out);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -200,8 +203,11 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
   if (n <= 1024) {
     constexpr int CAP = 1024, NT = 256;
     const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;
-    hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+    {
+      ProfScope _ps("plan_kernel", stream);
+      hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
                        ids_b, stride_b, nb, out);
+    }
   } else if (n <= 8192) {
     constexpr int CAP = 8192, NT = 1024;
     const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;  // 132 KiB of the CU's 160 KiB
@@ -211,8 +217,11 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
-    hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+    {
+      ProfScope _ps("plan_kernel", stream);
+      hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
                        ids_b, stride_b, nb, out);
+    }
   } else {
     return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the in-LDS plan capacity (8192)", n);
   }

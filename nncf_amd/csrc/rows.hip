@@ -83,7 +83,10 @@ extern "C" int nncf_shard_route(const int32_t* d_cid, int32_t n, int32_t item_sh
   NNCF_HIP_CHECK(hipMemsetAsync(d_req, 0xFF, sizeof(int32_t) * (size_t)n_ranks * cap, st));  // -1 everywhere
   int rc = launch_plan(d_cid, 0, n, nullptr, 0, 0, v, 1, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(route_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, item_shard, cap, d_req, d_slot_of_pos);
+  {
+    ProfScope _ps("route_kernel", st);
+    hipLaunchKernelGGL(route_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, item_shard, cap, d_req, d_slot_of_pos);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -93,8 +96,11 @@ extern "C" int nncf_gather_rows(const float* d_table, int32_t row_stride, int32_
   NNCF_REQUIRE(d_table && d_ids && d_out, "NULL argument");
   NNCF_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 128 && row_stride >= dim, "bad row shape");
   if (n <= 0) return NNCF_OK;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, as_stream(stream), d_table,
+  {
+    ProfScope _ps("gather_rows_kernel", as_stream(stream));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, as_stream(stream), d_table,
                      row_stride, dim, d_ids, n, id_offset, d_out);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -111,8 +117,11 @@ extern "C" int nncf_scatter_apply(float* d_table, int32_t row_stride, int32_t di
   int rc = launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, st);
   if (rc) return rc;
   const int chunks = (n + kChunkSlots - 1) / kChunkSlots;
-  hipLaunchKernelGGL(scatter_apply_kernel, dim3(chunks), dim3(256), 0, st, d_table, row_stride, dim, lr, d_rows,
+  {
+    ProfScope _ps("scatter_apply_kernel", st);
+    hipLaunchKernelGGL(scatter_apply_kernel, dim3(chunks), dim3(256), 0, st, d_table, row_stride, dim, lr, d_rows,
                      id_offset, v);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

@@ -251,8 +251,11 @@ int nncf_sampler_sample_slice_dev(nncf_sampler* s, int64_t offset, int64_t count
   int nbits = 1;
   while (nbits < 48 && ((uint64_t)(offset + count) >> nbits)) ++nbits;
   const Affine stride = lcg_power((uint64_t)T);
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound,
+  {
+    ProfScope _ps("sample_kernel", as_stream(stream));
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound,
                      s->d_guide, s->shift, s->state, offset, count, d_out, s->jt, nbits, stride);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

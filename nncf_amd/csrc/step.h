@@ -41,28 +41,14 @@ struct SharedWs {
   long long* dbg;    // optional [tiles][8] s_memtime stamps of the tile kernel (NNCF_DEBUG_TIMING=1)
 };
 
-// Optional per-launch HIP-event bracket around the dominant kernel of a step (bench.py's
-// roofline leg).  Events are recorded on the stream the kernel is launched on.
-struct KernelProfiler {
-  std::vector<hipEvent_t> start, stop;
-  size_t used = 0;
-  bool enabled = false;
-  hipStream_t last_stream = nullptr;
-  hipEvent_t* next_start(hipStream_t s) {
-    last_stream = s;
-    return (enabled && used < start.size()) ? &start[used] : nullptr;
-  }
-};
-
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
                     const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
-                    hipStream_t stream, KernelProfiler* prof = nullptr);
+                    hipStream_t stream);
 
 // group = 0: neg_shared (columns = the b batch items, positive of row i is column i)
 // group = 1: group_neg_shared (columns = unique items of plan pv, positive = pv.inverse[i])
 int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const SharedWs& ws,
-                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
-                  KernelProfiler* prof = nullptr);
+                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream);
 
 int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32_t* cid, int64_t q, float* out,
                    hipStream_t stream);

@@ -191,30 +191,32 @@ namespace {
 
 template <int LOSS, bool NU, bool NV>
 void launch_o(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg, const OriginalWs& ws,
-              const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
-              KernelProfiler* prof) {
+              const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
   const int b = a.b;
-  hipEvent_t* ev = prof ? prof->next_start(stream) : nullptr;
-  if (ev) (void)hipEventRecord(*ev, stream);
-  hipLaunchKernelGGL((original_score_kernel<LOSS, NU, NV>), dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos,
+  {
+    ProfScope _ps("original_score_kernel", stream);
+    hipLaunchKernelGGL((original_score_kernel<LOSS, NU, NV>), dim3((b + 3) / 4), dim3(256), 0, stream, a, uid, cid_pos,
                      cid_neg, ws);
-  if (ev) (void)hipEventRecord(prof->stop[prof->used++], stream);
+  }
   // chunk upper bounds: ceil(n / 16) per id list, + the loss workgroup
   const int cu = (b + kChunkSlots - 1) / kChunkSlots, cv = (b * (1 + a.k) + kChunkSlots - 1) / kChunkSlots;
-  hipLaunchKernelGGL((original_apply_kernel<NU, NV>), dim3(cu + cv + 1), dim3(256), 0, stream, a, ws, pu, pv, loss_out,
+  {
+    ProfScope _ps("original_apply_kernel", stream);
+    hipLaunchKernelGGL((original_apply_kernel<NU, NV>), dim3(cu + cv + 1), dim3(256), 0, stream, a, ws, pu, pv, loss_out,
                      update, cu);
+  }
 }
 
 template <int LOSS>
 void launch_on(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
                const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
-               hipStream_t stream, KernelProfiler* prof) {
+               hipStream_t stream) {
   if (a.norm_u) {
-    if (a.norm_v) launch_o<LOSS, true, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
-    else launch_o<LOSS, true, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+    if (a.norm_v) launch_o<LOSS, true, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream);
+    else launch_o<LOSS, true, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream);
   } else {
-    if (a.norm_v) launch_o<LOSS, false, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
-    else launch_o<LOSS, false, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof);
+    if (a.norm_v) launch_o<LOSS, false, true>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream);
+    else launch_o<LOSS, false, false>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream);
   }
 }
 
@@ -222,12 +224,12 @@ void launch_on(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, co
 
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,
                     const OriginalWs& ws, const PlanView& pu, const PlanView& pv, float* loss_out, int update,
-                    hipStream_t stream, KernelProfiler* prof) {
+                    hipStream_t stream) {
   switch (a.loss) {
-    case NNCF_LOSS_SKIP_GRAM: launch_on<NNCF_LOSS_SKIP_GRAM>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
-    case NNCF_LOSS_MSE: launch_on<NNCF_LOSS_MSE>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
-    case NNCF_LOSS_LOG_LOSS: launch_on<NNCF_LOSS_LOG_LOSS>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
-    default: launch_on<NNCF_LOSS_MAX_MARGIN>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream, prof); break;
+    case NNCF_LOSS_SKIP_GRAM: launch_on<NNCF_LOSS_SKIP_GRAM>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream); break;
+    case NNCF_LOSS_MSE: launch_on<NNCF_LOSS_MSE>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream); break;
+    case NNCF_LOSS_LOG_LOSS: launch_on<NNCF_LOSS_LOG_LOSS>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream); break;
+    default: launch_on<NNCF_LOSS_MAX_MARGIN>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream); break;
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -402,47 +402,49 @@ namespace {
 
 template <int LOSS, bool GROUP, bool NU, bool NV>
 void launch_pair(const StepArgs& a, const int32_t* uid, const int32_t* cid, const SharedWs& ws, const PlanView& pu,
-                 const PlanView& pv, float* loss_out, int update, hipStream_t stream, KernelProfiler* prof) {
+                 const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
   const int nb = a.b / kTile;
-  hipEvent_t* ev = prof ? prof->next_start(stream) : nullptr;
-  if (ev) (void)hipEventRecord(*ev, stream);
-  hipLaunchKernelGGL((shared_tile_kernel<LOSS, GROUP, NU, NV>), dim3(nb, nb), dim3(512), 0, stream, a, uid, cid, ws, pv);
-  if (ev) (void)hipEventRecord(prof->stop[prof->used++], stream);
+  {
+    ProfScope _ps("shared_tile_kernel", stream);
+    hipLaunchKernelGGL((shared_tile_kernel<LOSS, GROUP, NU, NV>), dim3(nb, nb), dim3(512), 0, stream, a, uid, cid, ws, pv);
+  }
   const int max_chunks = (a.b + kChunkSlots - 1) / kChunkSlots;  // per id list; + the loss workgroup
-  hipLaunchKernelGGL((shared_apply_kernel<GROUP, (LOSS >= NNCF_LOSS_LOG_LOSS), NU, NV>), dim3(2 * max_chunks + 1),
+  {
+    ProfScope _ps("shared_apply_kernel", stream);
+    hipLaunchKernelGGL((shared_apply_kernel<GROUP, (LOSS >= NNCF_LOSS_LOG_LOSS), NU, NV>), dim3(2 * max_chunks + 1),
                      dim3(256), 0, stream, a, ws, pu, pv, loss_out, update, max_chunks);
+  }
 }
 
 template <int LOSS, bool GROUP>
 void launch_norm(const StepArgs& a, const int32_t* uid, const int32_t* cid, const SharedWs& ws, const PlanView& pu,
-                 const PlanView& pv, float* loss_out, int update, hipStream_t stream, KernelProfiler* prof) {
+                 const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
   if (a.norm_u) {
-    if (a.norm_v) launch_pair<LOSS, GROUP, true, true>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
-    else launch_pair<LOSS, GROUP, true, false>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
+    if (a.norm_v) launch_pair<LOSS, GROUP, true, true>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
+    else launch_pair<LOSS, GROUP, true, false>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
   } else {
-    if (a.norm_v) launch_pair<LOSS, GROUP, false, true>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
-    else launch_pair<LOSS, GROUP, false, false>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
+    if (a.norm_v) launch_pair<LOSS, GROUP, false, true>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
+    else launch_pair<LOSS, GROUP, false, false>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
   }
 }
 
 template <bool GROUP>
 void launch_loss(const StepArgs& a, const int32_t* uid, const int32_t* cid, const SharedWs& ws, const PlanView& pu,
-                 const PlanView& pv, float* loss_out, int update, hipStream_t stream, KernelProfiler* prof) {
+                 const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
   switch (a.loss) {
-    case NNCF_LOSS_SKIP_GRAM: launch_norm<NNCF_LOSS_SKIP_GRAM, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof); break;
-    case NNCF_LOSS_MSE: launch_norm<NNCF_LOSS_MSE, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof); break;
-    case NNCF_LOSS_LOG_LOSS: launch_norm<NNCF_LOSS_LOG_LOSS, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof); break;
-    default: launch_norm<NNCF_LOSS_MAX_MARGIN, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof); break;
+    case NNCF_LOSS_SKIP_GRAM: launch_norm<NNCF_LOSS_SKIP_GRAM, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream); break;
+    case NNCF_LOSS_MSE: launch_norm<NNCF_LOSS_MSE, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream); break;
+    case NNCF_LOSS_LOG_LOSS: launch_norm<NNCF_LOSS_LOG_LOSS, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream); break;
+    default: launch_norm<NNCF_LOSS_MAX_MARGIN, GROUP>(a, uid, cid, ws, pu, pv, loss_out, update, stream); break;
   }
 }
 
 }  // namespace
 
 int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const SharedWs& ws,
-                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream,
-                  KernelProfiler* prof) {
-  if (group) launch_loss<true>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
-  else launch_loss<false>(a, uid, cid, ws, pu, pv, loss_out, update, stream, prof);
+                  const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+  if (group) launch_loss<true>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
+  else launch_loss<false>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -452,7 +454,10 @@ int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32
   if (p <= 0 || q <= 0) return NNCF_OK;
   const int64_t gy = (p + kTile - 1) / kTile, gx = (q + kTile - 1) / kTile;
   if (gy > 65535) return fail(NNCF_ERR_INVALID, "predict: too many user rows (%lld) for one launch", (long long)p);
-  hipLaunchKernelGGL(predict_tile_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a, uid, p, cid, q, out);
+  {
+    ProfScope _ps("predict_tile_kernel", stream);
+    hipLaunchKernelGGL(predict_tile_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, stream, a, uid, p, cid, q, out);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

@@ -336,18 +336,21 @@ __global__ void __launch_bounds__(256) tower_bwd2_kernel(TowerArgs a) {
     reinterpret_cast<float4*>(sZ + grp * kTP)[q] = dz.a;
     reinterpret_cast<float4*>(sZ + grp * kTP)[q + 16] = dz.b;
     __syncthreads();
-    // dh[row][k] = sum_n dz[n] * Wd[k][n]   (lane owns k = 4q.., 64+4q..; float4 LDS reads)
+    // dh[row][k] = sum_n dz[n] * Wd[k][n]: every lane multiplies its own 8 columns of dz (still
+    // in registers) with row k of the weights (one row for the whole group: conflict-free 16-byte
+    // LDS reads), a DPP row reduction finishes the dot, the owner lane of k keeps it.
     if (row < a.m) {
       Row o = row_zero();
-      const float4* dzr = reinterpret_cast<const float4*>(sZ + grp * kTP);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = col_of(q, e);
-        if (k < a.wd) {
-          const float4* wrow = reinterpret_cast<const float4*>(sW + k * kTP);
-          float acc = 0.f;
-          for (int n4 = 0; n4 < d4; ++n4) acc += dot4(dzr[n4], wrow[n4]);
-          relem(o, e) = acc;
+      for (int k = 0; k < a.wd; ++k) {
+        Row w;
+        w.a = reinterpret_cast<const float4*>(sW + k * kTP)[q];
+        w.b = reinterpret_cast<const float4*>(sW + k * kTP)[q + 16];
+        // columns >= d of the staged weights are uninitialised LDS: never let them into the sum
+        const float v = row16_sum(((q < d4) ? dot4(dz.a, w.a) : 0.f) + ((q + 16 < d4) ? dot4(dz.b, w.b) : 0.f));
+        const int owner = (k < 64) ? (k >> 2) : ((k - 64) >> 2), e = (k & 3) + ((k < 64) ? 0 : 4);
+        if (q == owner) {
+          if (e == 0) o.a.x = v; else if (e == 1) o.a.y = v; else if (e == 2) o.a.z = v; else if (e == 3) o.a.w = v;
+          else if (e == 4) o.b.x = v; else if (e == 5) o.b.y = v; else if (e == 6) o.b.z = v; else o.b.w = v;
         }
       }
       row_store(a.dh, row, a.wd, wd4, q, o);
@@ -439,8 +442,14 @@ extern "C" int nncf_tower_fwd(const float* d_h, int32_t m, const int32_t* d_n_va
     attr = true;
   }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(tower_fwd1_kernel, dim3(grid), dim3(256), lds1, st, a);
-  hipLaunchKernelGGL(tower_fwd2_kernel, dim3(grid), dim3(256), 0, st, a);
+  {
+    ProfScope _ps("tower_fwd1_kernel", st);
+    hipLaunchKernelGGL(tower_fwd1_kernel, dim3(grid), dim3(256), lds1, st, a);
+  }
+  {
+    ProfScope _ps("tower_fwd2_kernel", st);
+    hipLaunchKernelGGL(tower_fwd2_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
   if (train) hipLaunchKernelGGL(tower_running_kernel, dim3(1), dim3(128), 0, st, a);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -464,9 +473,18 @@ extern "C" int nncf_tower_bwd(const float* d_h, const float* d_z, const float* d
     attr = true;
   }
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(tower_bwd1_kernel, dim3(grid), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(tower_bwd2_kernel, dim3(grid), dim3(256), lds2, st, a);
-  hipLaunchKernelGGL(tower_update_kernel, dim3((word_dim * item_dim + 255) / 256), dim3(256), 0, st, a, grid);
+  {
+    ProfScope _ps("tower_bwd1_kernel", st);
+    hipLaunchKernelGGL(tower_bwd1_kernel, dim3(grid), dim3(256), 0, st, a);
+  }
+  {
+    ProfScope _ps("tower_bwd2_kernel", st);
+    hipLaunchKernelGGL(tower_bwd2_kernel, dim3(grid), dim3(256), lds2, st, a);
+  }
+  {
+    ProfScope _ps("tower_update_kernel", st);
+    hipLaunchKernelGGL(tower_update_kernel, dim3((word_dim * item_dim + 255) / 256), dim3(256), 0, st, a, grid);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

@@ -167,15 +167,6 @@ class Engine(object):
             _lib.check(self._L.nncf_predict_scores(self._h, _ptr(uid), p, _ptr(cid), q, _ptr(out), self._stream()))
         return out
 
-    def profile_begin(self, max_launches):
-        _lib.check(self._L.nncf_model_profile_begin(self._h, int(max_launches)))
-
-    def profile_end(self):
-        """(mean bracket ms, launches, empty-bracket ms) of the dominant kernel since profile_begin."""
-        ms, n, ov = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        _lib.check(self._L.nncf_model_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(ov)))
-        return ms.value, n.value, ov.value
-
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -186,6 +177,18 @@ class Engine(object):
             self.close()
         except Exception:
             pass
+
+
+def profile_begin(kernel, max_launches):
+    """Bracket every launch of HIP kernel `kernel` with events (see nncf_profile_begin)."""
+    _lib.check(_lib.lib().nncf_profile_begin(kernel.encode(), int(max_launches)))
+
+
+def profile_end():
+    """(mean bracket ms, launches, empty-bracket ms) since profile_begin."""
+    ms, n, ov = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    _lib.check(_lib.lib().nncf_profile_end(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(ov)))
+    return ms.value, n.value, ov.value
 
 
 _plan_ws = {}
