@@ -178,6 +178,17 @@ int nncf_model_debug_stamps(nncf_model* m, long long* out_host, int64_t n);
 int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
                        void* stream);
 
+/* model.train_on_batch for ARBITRARY row-wise batches: n = b(1+k) independent (user, item, label)
+ * rows in any order, as train_scheme = presample / group_sample / reverse build them
+ * (models/train_presample.py:48-85, train_group_sample.py:75-88, train_reverse.py:59-68).
+ * d_y[n]: +1 / -1 (skip-gram) or 1 / 0 (mse).  Pointwise losses only (the pairwise branches of
+ * get_original_loss assume positives first, objectives.py:47-58) -> NNCF_ERR_INVALID otherwise.
+ * nncf_epoch_rowwise: n_steps such batches back to back, d_*_all[n_steps * n]. */
+int nncf_step_rowwise(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, const int32_t* d_y, float* d_loss,
+                      int update, void* stream);
+int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_y_all,
+                       int64_t n_steps, float* d_loss, void* stream);
+
 /* model_neg_shared.train_on_batch (train_neg_shared.py:46-51; model_framework.py:128-129,
  * 153-155; loss objectives.py:78-117): S = U_b . V_b^T (b x b), diagonal = positives. */
 int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,

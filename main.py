@@ -53,8 +53,14 @@ def main():
         from nncf_amd.train_neg_shared import Trainer
     elif args.train_scheme == "group_neg_shared":
         from nncf_amd.train_group_neg_shared import Trainer
-    elif args.train_scheme in ("reverse", "presample", "group_sample", "sampled_neg_shared"):
-        raise NotImplementedError("train_scheme=%s is not built yet (SURVEY.md 8(f) rank 4)" % args.train_scheme)
+    elif args.train_scheme == "reverse":
+        from nncf_amd.train_reverse import Trainer
+    elif args.train_scheme == "presample":
+        from nncf_amd.train_presample import Trainer
+    elif args.train_scheme == "group_sample":
+        from nncf_amd.train_group_sample import Trainer
+    elif args.train_scheme == "sampled_neg_shared":
+        from nncf_amd.train_sampled_neg_shared import Trainer
     else:
         assert False, "[ERROR] Unknown train_scheme {}".format(args.train_scheme)
     trainer = Trainer(model_dict, conf, data_helper)

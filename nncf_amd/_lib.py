@@ -73,6 +73,8 @@ def _declare(lib):
                              ctypes.POINTER(ctypes.c_double)],
         "nncf_step_original": [vp, vp, vp, vp, i32, vp],
         "nncf_step_neg_shared": [vp, vp, vp, vp, i32, vp],
+        "nncf_step_rowwise": [vp, vp, vp, vp, vp, i32, vp],
+        "nncf_epoch_rowwise": [vp, vp, vp, vp, i64, vp, vp],
         "nncf_step_group_neg_shared": [vp, vp, vp, vp, i32, vp, vp, vp, vp],
         "nncf_epoch_original": [vp, vp, vp, vp, i64, vp, vp],
         "nncf_epoch_neg_shared": [vp, vp, vp, i64, vp, vp],

@@ -40,6 +40,8 @@ struct PlanView {
 int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb,
                 const PlanView& out, int64_t n_lists, hipStream_t stream);
 
+int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,
+                     const PlanView& out1, hipStream_t stream);
 int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream);
 
 constexpr int kPlanChunk = 64;  // steps planned per launch by the epoch runners

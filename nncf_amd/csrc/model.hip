@@ -17,6 +17,7 @@ struct nncf_model {
   int device = 0;
   void* arena = nullptr;  // one device allocation, carved below
   OriginalWs ows;
+  RowwiseWs rws;
   SharedWs sws;
   PlanView plan_u, plan_v;  // kPlanChunk lists each
   int64_t cap_u = 0, cap_v = 0;
@@ -66,6 +67,11 @@ void carve(nncf_model* m, Carver& c) {
   m->ows.Uhat = c.take<float>(b * d);
   m->ows.loss_part = c.take<float>(b);
   m->ows.reg_part = c.take<float>(b);
+  m->rws.g = c.take<float>(n);
+  m->rws.Urow = c.take<float>(n * d);
+  m->rws.Vrow = c.take<float>(n * d);
+  m->rws.loss_part = c.take<float>(n);
+  m->rws.reg_part = c.take<float>(n);
   m->sws.dU_part = c.take<float>(nb * b * d);
   m->sws.dV_part = c.take<float>(nb * b * d);
   m->sws.c_part = c.take<float>(nb * b);
@@ -75,7 +81,7 @@ void carve(nncf_model* m, Carver& c) {
   m->sws.loss_part = c.take<float>(nb * nb);
   m->sws.reg_part = c.take<float>(b);
   m->sws.dbg = getenv("NNCF_DEBUG_TIMING") ? c.take<long long>(nb * nb * 8) : nullptr;
-  m->cap_u = b;
+  m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
   auto plan = [&](PlanView& v, int64_t cap) {
     v.list_stride = cap;
@@ -209,6 +215,44 @@ int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid
   return launch_original(make_args(m), d_uid, d_cid, d_cid + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st);
 }
 
+int nncf_step_rowwise(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, const int32_t* d_y, float* d_loss,
+                      int update, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_y && d_loss, "NULL argument");
+  NNCF_REQUIRE(m->cfg.num_negatives > 0, "row-wise batches need num_negatives > 0 (weights are lambda / k)");
+  const int n = m->cfg.batch_size_p * (1 + m->cfg.num_negatives);
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, 0, n, nullptr, 0, 0, m->plan_u, 1, st);
+  if (rc) return rc;
+  rc = launch_plan(d_cid, 0, n, nullptr, 0, 0, m->plan_v, 1, st);
+  if (rc) return rc;
+  return launch_rowwise(make_args(m), d_uid, d_cid, d_y, m->rws, m->plan_u, m->plan_v, n, d_loss, update, st);
+}
+
+int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_y_all,
+                       int64_t n_steps, float* d_loss, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_y_all && d_loss, "NULL argument");
+  NNCF_REQUIRE(m->cfg.num_negatives > 0 && n_steps >= 0, "bad argument");
+  const int64_t n = (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives);
+  hipStream_t st = as_stream(stream);
+  const StepArgs a = make_args(m);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc = launch_plan(d_uid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_u, cnt, st);
+    if (rc) return rc;
+    rc = launch_plan(d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v, cnt, st);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t t = t0 + i;
+      rc = launch_rowwise(a, d_uid_all + t * n, d_cid_all + t * n, d_y_all + t * n, m->rws, m->plan_u.at(i),
+                          m->plan_v.at(i), (int)n, d_loss + t, 1, st);
+      if (rc) return rc;
+    }
+  }
+  return NNCF_OK;
+}
+
 int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
                          void* stream) {
   if (int rc = check_model(m)) return rc;
@@ -216,9 +260,7 @@ int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_c
   NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
   const int b = m->cfg.batch_size_p;
   hipStream_t st = as_stream(stream);
-  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
-  if (rc) return rc;
-  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
   return launch_shared(make_args(m), 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
 }
@@ -230,9 +272,7 @@ int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32
   NNCF_REQUIRE(d_uid && d_cid && d_loss && d_item_grad, "NULL argument");
   const int b = m->cfg.batch_size_p;
   hipStream_t st = as_stream(stream);
-  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
-  if (rc) return rc;
-  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
   StepArgs a = make_args(m);
   a.gV = d_item_grad;
@@ -246,9 +286,7 @@ int nncf_plan_item_block(nncf_model* m, int32_t scheme, const int32_t* d_uid, co
   NNCF_REQUIRE(scheme >= 0 && scheme <= 2, "scheme must be 0 (original), 1 (neg_shared) or 2 (group_neg_shared)");
   const int b = m->cfg.batch_size_p, n = scheme == 0 ? b * (1 + m->cfg.num_negatives) : b;
   hipStream_t st = as_stream(stream);
-  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
-  if (rc) return rc;
-  rc = launch_plan(d_cid, 0, n, nullptr, 0, 0, m->plan_v, 1, st);
+  int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, n, m->plan_v, st);
   if (rc) return rc;
   return launch_plan_localize(m->plan_v, n, d_uniq_global, d_n_u, st);
 }
@@ -275,9 +313,7 @@ int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_
   NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
   const int b = m->cfg.batch_size_p;
   hipStream_t st = as_stream(stream);
-  int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
-  if (rc) return rc;
-  rc = launch_plan(d_cid, 0, b, nullptr, 0, 0, m->plan_v, 1, st);
+  int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
   rc = launch_shared(make_args(m), 1, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
   if (rc) return rc;

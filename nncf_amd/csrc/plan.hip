@@ -28,16 +28,15 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* to
 
 // ids of list L = concat(ids_a[L*stride_a .. +na), ids_b[L*stride_b .. +nb)); n = na + nb <= CAP.
 template <int CAP, int NT>
-__global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ ids_a, int64_t stride_a, int na,
-                                                  const int32_t* __restrict__ ids_b, int64_t stride_b, int nb,
-                                                  PlanView out) {
+__device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int64_t stride_a, int na,
+                                          const int32_t* __restrict__ ids_b, int64_t stride_b, int nb,
+                                          const PlanView& out, int64_t L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);   // CAP
   int* seg = reinterpret_cast<int*>(key + CAP);                           // CAP: segment of sorted slot
   int* aux = seg + CAP;                                                   // CAP: first-occurrence flags / ranks
   int* scratch = aux + CAP;                                               // NT
   const int tid = threadIdx.x;
-  const int64_t L = blockIdx.x;
   const int n = na + nb;
   ids_a += L * stride_a;
   if (ids_b) ids_b += L * stride_b;
@@ -171,6 +170,21 @@ __global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ id
   }
 }
 
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) plan_kernel(const int32_t* __restrict__ ids_a, int64_t stride_a, int na,
+                                                  const int32_t* __restrict__ ids_b, int64_t stride_b, int nb,
+                                                  PlanView out) {
+  plan_body<CAP, NT>(ids_a, stride_a, na, ids_b, stride_b, nb, out, blockIdx.x);
+}
+
+// Two unrelated lists (a batch's users and items) planned by one launch, one workgroup each.
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) plan_pair_kernel(const int32_t* __restrict__ ids0, int n0, PlanView out0,
+                                                       const int32_t* __restrict__ ids1, int n1, PlanView out1) {
+  if (blockIdx.x == 0) plan_body<CAP, NT>(ids0, 0, n0, nullptr, 0, 0, out0, 0);
+  else plan_body<CAP, NT>(ids1, 0, n1, nullptr, 0, 0, out1, 0);
+}
+
 // Re-express a plan of GLOBAL ids in LOCAL ids = tf.unique ranks (the item block of a text tower
 // or of fetched rows is indexed by rank): desc[s].id = rank, uniq[j] = j; the global ids of the
 // ranks are copied out first.  One workgroup.
@@ -191,6 +205,23 @@ int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_
   {
     ProfScope _ps("plan_localize_kernel", stream);
     hipLaunchKernelGGL(plan_localize_kernel, dim3(1), dim3(256), 0, stream, pl, n, uniq_global, n_u_out);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,
+                     const PlanView& out1, hipStream_t stream) {
+  if (n0 > 1024 || n1 > 1024) {  // big lists: two launches
+    int rc = launch_plan(ids0, 0, n0, nullptr, 0, 0, out0, 1, stream);
+    if (rc) return rc;
+    return launch_plan(ids1, 0, n1, nullptr, 0, 0, out1, 1, stream);
+  }
+  constexpr int CAP = 1024, NT = 256;
+  const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;
+  {
+    ProfScope _ps("plan_kernel", stream);
+    hipLaunchKernelGGL((plan_pair_kernel<CAP, NT>), dim3(2), dim3(NT), lds, stream, ids0, n0, out0, ids1, n1, out1);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

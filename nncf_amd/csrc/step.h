@@ -28,6 +28,15 @@ struct OriginalWs {
   float* reg_part;   // [b]
 };
 
+// general row-wise batches (presample / group_sample / reverse)
+struct RowwiseWs {
+  float* g;          // [n]
+  float* Urow;       // [n][d] (normalised) user row of every batch row
+  float* Vrow;       // [n][d] (normalised) item row of every batch row
+  float* loss_part;  // [n]
+  float* reg_part;   // [n]  |U_raw|^2
+};
+
 // train_scheme = neg_shared / group_neg_shared (b x N score tile grid, 32 x 32 tiles)
 struct SharedWs {
   float* dU_part;    // [NBJ][b][d]     partial dL/dUhat per column block
@@ -49,6 +58,9 @@ int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_po
 // group = 1: group_neg_shared (columns = unique items of plan pv, positive = pv.inverse[i])
 int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const SharedWs& ws,
                   const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream);
+
+int launch_rowwise(const StepArgs& a, const int32_t* uid, const int32_t* cid, const int32_t* y, const RowwiseWs& ws,
+                   const PlanView& pu, const PlanView& pv, int n, float* loss_out, int update, hipStream_t stream);
 
 int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32_t* cid, int64_t q, float* out,
                    hipStream_t stream);

@@ -95,6 +95,25 @@ class Engine(object):
             _lib.check(self._L.nncf_step_original(self._h, _ptr(uid), _ptr(cid), _ptr(out), int(update), self._stream()))
         return out
 
+    def step_rowwise(self, uid, cid, y, update=True, loss_out=None):
+        out = self._loss1 if loss_out is None else loss_out
+        n = self.b * (1 + self.k)
+        assert uid.numel() == n and cid.numel() == n and y.numel() == n
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_step_rowwise(self._h, _ptr(uid), _ptr(cid), _ptr(y), _ptr(out), int(update),
+                                                 self._stream()))
+        return out
+
+    def epoch_rowwise(self, uid_all, cid_all, y_all, n_steps, loss_out=None):
+        if loss_out is None:
+            loss_out = torch.empty(max(n_steps, 1), dtype=torch.float32, device=self.device)
+        n = self.b * (1 + self.k)
+        assert min(uid_all.numel(), cid_all.numel(), y_all.numel()) >= n_steps * n
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_epoch_rowwise(self._h, _ptr(uid_all), _ptr(cid_all), _ptr(y_all), int(n_steps),
+                                                  _ptr(loss_out), self._stream()))
+        return loss_out[:n_steps]
+
     def step_neg_shared(self, uid, cid, update=True, loss_out=None):
         out = self._loss1 if loss_out is None else loss_out
         assert uid.numel() == self.b and cid.numel() == self.b

@@ -19,6 +19,11 @@ def _as_ids(x):
     return np.ascontiguousarray(np.asarray(x).reshape(-1))
 
 
+def _labels_positive_first(y, b):
+    yy = np.asarray(y[0] if isinstance(y, (list, tuple)) else y).reshape(-1)
+    return yy.size == 0 or (np.all(yy[:b] == 1) and np.all(yy[b:] != 1))
+
+
 class _Head(object):
     """Common bits of the model objects: shared Engine, sync-and-return-float semantics of
     Keras' train_on_batch (the reference adds the returned host scalar to `cost`,
@@ -45,13 +50,18 @@ class OriginalModel(_Head):
         if uid.size != b * (1 + k) or cid.size != b * (1 + k):
             raise ValueError("[ERROR] model expects batch_size_p * (1 + num_negatives) = %d rows, got %d"
                              % (b * (1 + k), uid.size))
-        # The kernels use the trainer's layout (train_original.py:49-56): negatives repeat their
-        # positive's user.  Anything else is not this head's input.
-        if not np.array_equal(uid[b:], np.repeat(uid[:b], k)):
-            raise ValueError("[ERROR] rows %d.. must repeat the users of the positives k times each "
-                             "(train_original.py:50)" % b)
         e = self.engine
-        return self._loss(e.step_original(e.ids(uid[:b]), e.ids(cid), update=self.update))
+        if np.array_equal(uid[b:], np.repeat(uid[:b], k)) and (y is None or _labels_positive_first(y, b)):
+            # the trainer's layout (train_original.py:49-56): per-positive kernel
+            return self._loss(e.step_original(e.ids(uid[:b]), e.ids(cid), update=self.update))
+        # any other row order (presample / group_sample / reverse): general row-wise kernels
+        if y is None:
+            raise ValueError("[ERROR] row-wise batches need their labels")
+        yy = np.asarray(y[0] if isinstance(y, (list, tuple)) else y).reshape(-1)
+        return self._loss(e.step_rowwise(e.ids(uid), e.ids(cid), e.ids(yy), update=self.update))
+
+    def run_epoch_rowwise(self, uid_all, cid_all, y_all, n_steps):
+        return self.engine.epoch_rowwise(uid_all, cid_all, y_all, n_steps)
 
     def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None):
         """The trainer's inner loop (train_original.py:43-68) on device; per-step losses."""
@@ -97,10 +107,47 @@ class GroupNegSharedModel(_Head):
 
 
 class SampledNegSharedModel(_Head):
-    """model_dict['model_sampled_neg_shared'] (model_framework.py:138-143,166-170)."""
+    """model_dict['model_sampled_neg_shared'] (model_framework.py:138-143,166-170): b positives
+    scored row-wise plus the SAME k sampled items as negatives for every positive
+    (get_sampled_neg_shared_loss, objectives.py:120-161).  That is get_original_loss with every
+    positive's k negatives being the shared ones, except that this head uses the user rows
+    un-normalised (U_emb_front, :64-65) -- so it runs the per-positive kernels on an engine with
+    normalize_user = 0 and the negatives replicated per positive; the duplicate plan folds the b
+    copies of each negative into one row update."""
+
+    def __init__(self, engine, make_unnormalised):
+        super(SampledNegSharedModel, self).__init__(engine)
+        self._make = make_unnormalised
+        self._e2 = None
+
+    def _engine2(self):
+        if self._e2 is None:
+            self._e2 = self._make()
+        return self._e2
 
     def train_on_batch(self, x, y=None):
-        raise NotImplementedError("train_scheme=sampled_neg_shared is not built yet (SURVEY.md 8(f) rank 4)")
+        e = self._engine2()
+        b, k = e.b, e.k
+        uid, cid = _as_ids(x[0]), _as_ids(x[1])
+        if uid.size != b + k or cid.size != b + k:
+            raise ValueError("[ERROR] model_sampled_neg_shared expects batch_size_p + num_negatives = %d rows" % (b + k))
+        full = np.concatenate([cid[:b], np.tile(cid[b:], b)])
+        return self._loss(e.step_original(e.ids(uid[:b]), e.ids(full)))
+
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_shared_all=None):
+        """neg_shared_all: int32 device [n_steps * k], the k shared negatives of every step."""
+        e = self._engine2()
+        b, k = e.b, e.k
+        neg = neg_shared_all[:n_steps * k].view(n_steps, 1, k).expand(n_steps, b, k).reshape(-1).contiguous()
+        return e.epoch_original(uid_all, cid_all, neg, n_steps)
+
+
+class _Unbuilt(object):
+    def __init__(self, what):
+        self.what = what
+
+    def train_on_batch(self, x, y=None):
+        raise NotImplementedError("%s is not built yet" % self.what)
 
 
 class EmbeddingModel(_Head):
@@ -334,7 +381,7 @@ def _get_model_basic_embedding(conf, data_helper, device, seed):
         "model": TowerHead(core, "original"),
         "model_neg_shared": TowerHead(core, "neg_shared"),
         "model_group_neg_shared": TowerHead(core, "group_neg_shared"),
-        "model_sampled_neg_shared": SampledNegSharedModel(engine),
+        "model_sampled_neg_shared": _Unbuilt("model_sampled_neg_shared with a text tower"),
         "model_user_emb": EmbeddingModel(engine, "user"),
         "model_item_emb": EmbeddingModel(engine, "item"),
         "model_pred_pairs": PredPairsModel(engine),
@@ -373,7 +420,8 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
         "model": OriginalModel(engine),
         "model_neg_shared": NegSharedModel(engine),
         "model_group_neg_shared": GroupNegSharedModel(engine),
-        "model_sampled_neg_shared": SampledNegSharedModel(engine),
+        "model_sampled_neg_shared": SampledNegSharedModel(
+            engine, lambda: Engine(device=device, share=engine, **dict(kw, normalize_user=False))),
         "model_user_emb": EmbeddingModel(engine, "user"),
         "model_item_emb": EmbeddingModel(engine, "item"),
         "model_pred_pairs": PredPairsModel(engine),

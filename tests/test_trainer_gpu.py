@@ -61,7 +61,7 @@ def test_model_dict_surface_and_train_on_batch(small_data):
     assert abs(got - want) <= 1e-5 * max(1, abs(want))
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
     with pytest.raises(ValueError):
-        md["model"].train_on_batch([uid[::-1].copy(), cid], [y])  # not the trainer's layout
+        md["model"].train_on_batch([uid[:-1], cid[:-1]], [y[:-1]])  # not batch_size_p * (1 + k) rows
     with pytest.raises(ValueError):
         md["model_group_neg_shared"].train_on_batch([uid[:b - 1], cid[:b - 1]], [y[:b - 1]])
     # predict_on_batch of the neg_shared head: (p, q) scores
