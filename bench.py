@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--profile-launches", type=int, default=1000)
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
+    ap.add_argument("--large", action="store_true",
+                    help="BASELINE config-4 shape on one GPU: 10M users x 1M items, d=128, id tables (mf), random "
+                         "Zipf links; tables 5.6 GB -- the HBM-bound regime")
     return ap.parse_args()
 
 
@@ -72,8 +75,22 @@ def conf_for(args):
                       learn_rate=pd["learn_rate"], model_choice=args.model)
 
 
+def make_large(args):
+    """config-4-shaped id-table problem: only the links the run consumes are materialised."""
+    users, items = 10000000, 1000000
+    rs = np.random.RandomState(20170813)
+    n = (args.warmup + args.steps) * args.batch
+    zipf = lambda size, count: np.minimum((count * rs.power(0.35, size)).astype(np.int64), count - 1)  # noqa: E731
+    train = np.stack([zipf(n, users), zipf(n, items), np.ones(n, dtype=np.int64)], 1)
+    train[0, 0], train[0, 1] = users - 1, items - 1   # table sizes come from the max ids (data_utils.py:23-25)
+    return {"C": np.zeros((items, 1), dtype=np.int64), "train": train, "test": train[:1000].copy(),
+            "test_seen": train[:1000].copy(), "train_items": np.arange(items), "test_items": np.arange(items)}
+
+
 def make_data(args):
     from nncf_amd.synthetic import make_citeulike_like
+    if args.large:
+        return make_large(args)
     text = args.content_len if args.model == "basic_embedding" else 0
     if args.small:
         return make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7, content_len=min(text, 40),
@@ -247,6 +264,8 @@ def main_sharded(args, conf, rank, world, local_rank):
 
 def main():
     args = parse()
+    if args.large:
+        args.model, args.dim = "mf", 128
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -284,10 +303,11 @@ def main():
     md = get_model(pconf, helper, args.model, device=local_rank, seed=0)
     head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[args.scheme]]
     eng = head.engine
-    U0 = eng.U.cpu().numpy().copy()
+    want_cpu = rank == 0 and args.cpu_seconds > 0 and not args.large   # the oracle copies whole tables
+    U0 = eng.U.cpu().numpy().copy() if want_cpu else None
     V0, tower_params = None, None
     if args.model == "mf":
-        V0 = eng.V.cpu().numpy().copy()
+        V0 = eng.V.cpu().numpy().copy() if want_cpu else None
     else:
         tw = head.core.tower
         tower_params = [t.cpu().numpy().copy() for t in (tw.W, tw.Wd, tw.bd, tw.gamma, tw.beta)]
@@ -361,7 +381,7 @@ def main():
     roof["traffic"] = measured_traffic(args, conf, d)
 
     cpu = None
-    if rank == 0 and args.cpu_seconds > 0:
+    if want_cpu:
         cpu = cpu_baseline(args, conf, inp, U0, V0, tower_params)
 
     if rank == 0:
@@ -372,10 +392,12 @@ def main():
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
-                    % (", item text" if args.model == "basic_embedding" else ""),
-            "config": {"workload": "CiteULike-a-shaped, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, sparse SGD"
-                                   % (tower_txt, d, args.scheme, conf.loss, b, (", k=%d" % k) if k else ""),
+            "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init parameters" if args.large
+                     else "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
+                     % (", item text" if args.model == "basic_embedding" else "")),
+            "config": {"workload": "%s, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, sparse SGD"
+                                   % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", tower_txt, d,
+                                      args.scheme, conf.loss, b, (", k=%d" % k) if k else ""),
                        "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
             "roofline": roof,

@@ -34,12 +34,18 @@ class Engine(object):
             self.U, self.V = tables  # caller-provided device tensors (e.g. shared U, tower output buffer)
             assert self.U.is_cuda and self.V.is_cuda and self.U.is_contiguous() and self.V.is_contiguous()
         elif share is None:
-            gen = torch.Generator().manual_seed(int(seed))
             # Keras-1 Embedding default init: uniform(-0.05, 0.05) [K-mem]
-            U = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
-            V = (torch.rand(self.item_count, self.dim, generator=gen) * 2 - 1) * init_scale
-            self.U = U.to(self.device).contiguous()
-            self.V = V.to(self.device).contiguous()
+            if (self.user_count + self.item_count) * self.dim > 2e8:
+                # multi-GB tables (config 4): initialise on the device
+                gen = torch.Generator(device=self.device).manual_seed(int(seed))
+                mk = lambda r: (torch.rand(r, self.dim, generator=gen, device=self.device) * 2 - 1) * init_scale  # noqa: E731
+                self.U, self.V = mk(self.user_count).contiguous(), mk(self.item_count).contiguous()
+            else:
+                gen = torch.Generator().manual_seed(int(seed))
+                U = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
+                V = (torch.rand(self.item_count, self.dim, generator=gen) * 2 - 1) * init_scale
+                self.U = U.to(self.device).contiguous()
+                self.V = V.to(self.device).contiguous()
         else:
             self.U, self.V = share.U, share.V
         cfg = _lib.ModelCfg(self.b, self.k, self.dim, self.dim, _lib.LOSS_CODES[loss], int(bool(normalize_user)),
