@@ -346,21 +346,21 @@ def main():
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)  # utilities.py:33-35
 
     # ---- roofline leg: same steps again, dominant kernel bracketed by HIP events ----------
-    # (eager launches: event records cannot sit inside a captured HIP graph)
     L = args.content_len if not args.small else min(args.content_len, 40)
     kernels = {
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
-        "meanpool_fwd_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B per unique item (n_u <= b rows)"),
-        "tower_bwd2_kernel": ("valu", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
+        "tower_pool_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B per unique item (n_u <= b rows)"),
+        "tower_word_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B of gradient rows per unique item (n_u <= b)"),
+        "tower_bwd_kernel": ("mfma", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
     }
     default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
-        ("shared_tile_kernel" if args.model == "mf" else "tower_bwd2_kernel")
+        ("shared_tile_kernel" if args.model == "mf" else "tower_word_kernel")
     names = [args.roofline_kernel or default_kernel]
     if args.model == "basic_embedding":
-        names += [n for n in ("meanpool_fwd_kernel", "shared_tile_kernel") if n not in names]
+        names += [n for n in ("tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel", "shared_tile_kernel")
+                  if n not in names]
     prof_n = min(K, args.profile_launches)
-    os.environ["NNCF_NO_GRAPH"] = "1"
     roofs = []
     for name in names:
         nengine.profile_begin(name, prof_n)
@@ -372,11 +372,10 @@ def main():
             ach, peak, unit = work / (kern_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
             ach, peak, unit = work / (kern_ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
-        roofs.append({"kernel": name, "bound": "mfma" if bound == "valu" else bound, "achieved": ach, "peak": peak,
+        roofs.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak,
                       "unit": unit, "frac": ach / peak, "traffic": None, "algorithmic_per_launch": work,
                       "algorithmic_what": what, "kernel_ms": kern_ms, "event_bracket_ms": raw_ms,
                       "empty_bracket_ms": ov_ms, "launches": launches})
-    os.environ.pop("NNCF_NO_GRAPH", None)
     roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d)
 

@@ -156,7 +156,7 @@ int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, fl
 
 /* Measurement hook (bench.py roofline leg; no reference counterpart): between _begin and _end
  * every launch of the named kernel (e.g. "shared_tile_kernel", "original_score_kernel",
- * "meanpool_word_kernel", "tower_bwd2_kernel") from any entry point is bracketed with HIP events
+ * "tower_word_kernel", "tower_bwd_kernel") from any entry point is bracketed with HIP events
  * on its launch stream, for at most max_launches launches.  _end synchronises those events and
  * returns the mean bracket in milliseconds plus the mean of an EMPTY bracket (two events back to
  * back on the same stream) -- the marker-packet overhead to subtract when comparing with
@@ -228,40 +228,80 @@ int nncf_predict_scores(nncf_model* m, const int32_t* d_uid, int64_t p, const in
                         float* d_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * MeanPool item tower, gather half (modules/content/mean_pool.py:27-33,51-76; model_choice
- * basic_embedding, model_framework.py:90-91,98).  Dense / BatchNorm / ReLU on the pooled
- * (n_u x word_dim) block are done by the host side with library GEMMs (nncf_amd/mean_pool.py).
- * nncf_meanpool_fwd: d_out[i] = (1/L) * sum_l scale[c] * words[c], c = d_content[i*L + l]
- *   (divides by L always, mean_pool.py:30; d_row_scale = Embedding row-dropout mask or NULL).
- * nncf_meanpool_bwd: sparse SGD on the word table,
- *     words[w] -= lr * scale[w] / L * sum_{slots s < *d_n_items} count(w, item s) * d_dh[s],
- *   d_item_ids[s] = item at batch slot s; static per-item CSR of the content matrix
- *   (d_item_ptr[items+1], d_item_word ascending inside an item, d_item_cnt uint8);
- *   scratch d_cnt_t[n_words * cap] and d_touched[n_words] bytes, ALL ZERO on entry and on exit.
- *   Fixed summation order (slot order), no atomics.
+ * basic_embedding item tower (modules/content/mean_pool.py:27-33,46-110; model_choice
+ * basic_embedding, models/model_framework.py:90-91,98-106): word Embedding -> mean over the
+ * max_content_len tokens (divides by L always, mean_pool.py:30) -> Dense(item_dim) ->
+ * BatchNormalization (batch statistics over the batch's unique items; Keras-1 eps / momentum)
+ * -> ReLU, with in-place sparse SGD.  The object borrows the caller's parameter arrays (device
+ * memory, 16-byte aligned) and owns its scratch.
+ *   content[item_count][content_len]   int32 word ids of every item (pad id included)
+ *   item_ptr[item_count+1], item_word[], item_cnt[]: CSR of the same matrix, item -> distinct
+ *     (word, occurrences <= 255) pairs -- the backward's transpose reads it.
+ *   max_rows: most rows a train-mode block can hold (batch_size_p * (1 + num_negatives)).
  * ---------------------------------------------------------------------------------- */
-int nncf_meanpool_fwd(const float* d_words, int32_t row_stride, int32_t word_dim, const int32_t* d_content,
-                      int64_t n_items, int32_t L, const float* d_row_scale, float* d_out, void* stream);
-int nncf_meanpool_bwd(float* d_words, int32_t row_stride, int32_t word_dim, int32_t n_words,
-                      const int32_t* d_item_ids, const int32_t* d_n_items, int32_t cap, const int32_t* d_item_ptr,
-                      const int32_t* d_item_word, const uint8_t* d_item_cnt, uint8_t* d_cnt_t, uint8_t* d_touched,
-                      const float* d_dh, const float* d_row_scale, float lr, int32_t L, void* stream);
+typedef struct nncf_tower nncf_tower;
 
-/* MeanPool item tower, dense half (mean_pool.py:87-97): Dense(item_dim) -> BatchNormalization
- * (batch statistics over the first *d_n_valid rows; eps, momentum as Keras-1) -> ReLU.
- * nncf_tower_fwd: d_z[m][item_dim] = d_h.Wd + bd (kept for the backward), d_E = relu(BN(z));
- *   train != 0: batch statistics, running mean/var updated; train == 0: running statistics.
- * nncf_tower_bwd: given d_dA = dL/dE: writes d_dh = dL/dh and takes the SGD step on Wd, bd,
- *   gamma, beta in place.  Must follow the nncf_tower_fwd(train=1) of the same rows (statistics
- *   are read from d_ws).  d_ws: nncf_tower_ws_floats(word_dim, item_dim) floats.
- * Rows >= *d_n_valid are padding: computed, excluded from statistics and gradients. */
-int64_t nncf_tower_ws_floats(int32_t word_dim, int32_t item_dim);
-int nncf_tower_fwd(const float* d_h, int32_t m, const int32_t* d_n_valid, int32_t word_dim, int32_t item_dim,
-                   float* d_Wd, float* d_bd, float* d_gamma, float* d_beta, float* d_rm, float* d_rv, float eps,
-                   float momentum, int32_t train, float* d_z, float* d_E, float* d_ws, void* stream);
-int nncf_tower_bwd(const float* d_h, const float* d_z, const float* d_dA, int32_t m, const int32_t* d_n_valid,
-                   int32_t word_dim, int32_t item_dim, float* d_Wd, float* d_bd, float* d_gamma, float* d_beta,
-                   float lr, float* d_dh, float* d_ws, void* stream);
+typedef struct nncf_tower_cfg {
+  int32_t word_count;
+  int32_t word_dim;     /* multiple of 4, <= 128 */
+  int32_t item_dim;     /* multiple of 4, <= 128 */
+  int32_t content_len;  /* L */
+  int32_t max_rows;     /* multiple of 8, <= 8192 */
+  int64_t item_count;
+  float bn_eps;
+  float bn_momentum;
+  float learn_rate;
+} nncf_tower_cfg;
+
+typedef struct nncf_tower_params {
+  float* words;    /* [word_count][word_dim] */
+  float* dense_w;  /* [word_dim][item_dim] */
+  float* dense_b;  /* [item_dim] */
+  float* bn_gamma;
+  float* bn_beta;
+  float* bn_mean;  /* running statistics */
+  float* bn_var;
+  const int32_t* content;
+  const int32_t* item_ptr;
+  const int32_t* item_word;
+  const uint8_t* item_cnt;
+} nncf_tower_params;
+
+int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* params, int device, nncf_tower** out);
+int nncf_tower_destroy(nncf_tower* t);
+int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate);
+/* Embedding(dropout=rate) of Keras 1 (mean_pool.py:56-59; 0.5 in the 'best' preset,
+ * basic_embedding_conf.py:112): per train-mode forward a fresh mask drops whole word rows
+ * (survivors scaled by 1/(1-rate)).  The mask is a counter-based hash of (seed, forward index,
+ * word) evaluated inside the kernels; dropped rows are neither loaded nor updated.  Resets the
+ * forward index to 0.  nncf_tower_dropout_scale writes the per-word scale (0 or 1/(1-rate)) the
+ * step_index-th train-mode forward since then uses / used -- for checkers. */
+int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed);
+int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, void* stream);
+
+/* d_out[m][item_dim] = tower(d_item_ids).  train == 0: inference phase (running statistics, any
+ * m).  train != 0: batch statistics over the first *d_n_valid rows (NULL = all m; rows past it
+ * come out zero), running statistics updated, m <= max_rows; prepare_backward != 0 also lays out
+ * what nncf_tower_backward needs and MUST then be followed by it.  d_row_scale: an explicit per-word scale
+ * overriding the built-in row-dropout mask, or NULL. */
+int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, const int32_t* d_n_valid, int train,
+                       int prepare_backward, const float* d_row_scale, float* d_out, void* stream);
+/* d_dA[m][item_dim] = dL/d(out) of the last prepared forward: SGD step on words, dense_w,
+ * dense_b, bn_gamma, bn_beta (fixed summation order, no atomics). */
+int nncf_tower_backward(nncf_tower* t, const float* d_dA, void* stream);
+
+/* One training step of basic_embedding (scheme 0 original: d_cid[b(1+k)] positives then
+ * negatives; 1 neg_shared, 2 group_neg_shared: d_cid[b]): duplicate plans + tf.unique ->
+ * tower forward of the unique items into the model's item table (rows = tf.unique ranks) ->
+ * step kernels (user rows updated, item gradients exported: the model must have
+ * nncf_model_set_item_grad_export set) -> tower backward.  update == 0: loss only.
+ * nncf_tower_epoch: the trainer's inner loop, n_steps consecutive batches, plans made 64 steps
+ * at a time; d_loss[n_steps]; d_n_u[n_steps] (optional) = unique items per step. */
+int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                    float* d_loss, int update, const float* d_row_scale, void* stream);
+int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all,
+                     const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss,
+                     int32_t* d_n_u, void* stream);
 
 /* Two-phase step for models whose item rows are produced per batch (text towers):
  *   nncf_plan_item_block: plans the batch (scheme 0 original: d_cid[b(1+k)]; 1 neg_shared,

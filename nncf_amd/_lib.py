@@ -40,6 +40,28 @@ class ModelCfg(ctypes.Structure):
     ]
 
 
+class TowerCfg(ctypes.Structure):
+    """nncf_tower_cfg (include/nncf_hip.h)."""
+    _fields_ = [
+        ("word_count", ctypes.c_int32),
+        ("word_dim", ctypes.c_int32),
+        ("item_dim", ctypes.c_int32),
+        ("content_len", ctypes.c_int32),
+        ("max_rows", ctypes.c_int32),
+        ("item_count", ctypes.c_int64),
+        ("bn_eps", ctypes.c_float),
+        ("bn_momentum", ctypes.c_float),
+        ("learn_rate", ctypes.c_float),
+    ]
+
+
+class TowerParams(ctypes.Structure):
+    """nncf_tower_params (include/nncf_hip.h): borrowed device pointers."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "words", "dense_w", "dense_b", "bn_gamma", "bn_beta", "bn_mean", "bn_var",
+        "content", "item_ptr", "item_word", "item_cnt")]
+
+
 LOSS_CODES = {"skip-gram": 0, "mse": 1, "log-loss": 2, "max-margin": 3}
 
 
@@ -84,13 +106,18 @@ def _declare(lib):
         "nncf_shard_route": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
         "nncf_gather_rows": [vp, i32, i32, vp, i64, i32, vp, vp],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
-        "nncf_meanpool_fwd": [vp, i32, i32, vp, i64, i32, vp, vp, vp],
-        "nncf_meanpool_bwd": [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, i32, vp],
+        "nncf_tower_create": [ctypes.POINTER(TowerCfg), ctypes.POINTER(TowerParams), i32, ctypes.POINTER(vp)],
+        "nncf_tower_destroy": [vp],
+        "nncf_tower_set_learn_rate": [vp, f32],
+        "nncf_tower_set_dropout": [vp, f32, u64],
+        "nncf_tower_dropout_scale": [vp, u64, vp, vp],
+        "nncf_tower_forward": [vp, vp, i64, vp, i32, i32, vp, vp, vp],
+        "nncf_tower_backward": [vp, vp, vp],
+        "nncf_tower_step": [vp, vp, i32, vp, vp, vp, i32, vp, vp],
+        "nncf_tower_epoch": [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp],
         "nncf_model_set_item_grad_export": [vp, vp],
         "nncf_plan_item_block": [vp, i32, vp, vp, vp, vp, vp],
         "nncf_step_planned": [vp, i32, vp, vp, i32, vp],
-        "nncf_tower_fwd": [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp],
-        "nncf_tower_bwd": [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })
@@ -102,8 +129,6 @@ def _declare(lib):
     lib.nncf_sampler_size.argtypes = [vp]
     lib.nncf_scatter_apply_ws_ints.restype = i64
     lib.nncf_scatter_apply_ws_ints.argtypes = [i32]
-    lib.nncf_tower_ws_floats.restype = i64
-    lib.nncf_tower_ws_floats.argtypes = [i32, i32]
 
 
 def lib():

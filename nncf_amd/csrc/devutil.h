@@ -60,6 +60,19 @@ __device__ __forceinline__ void row_store(float* __restrict__ table, int64_t row
   if (q < d4) p[q] = r.a;
   if (q + 16 < d4) p[q + 16] = r.b;
 }
+// relu(x * mul + add), per-column mul / add at ma[c] / ma[128 + c]  (BatchNorm + ReLU on load)
+__device__ __forceinline__ float4 bn_relu4(float4 x, float4 m, float4 c) {
+  return make_float4(fmaxf(fmaf(x.x, m.x, c.x), 0.f), fmaxf(fmaf(x.y, m.y, c.y), 0.f), fmaxf(fmaf(x.z, m.z, c.z), 0.f),
+                     fmaxf(fmaf(x.w, m.w, c.w), 0.f));
+}
+__device__ __forceinline__ Row row_load_bn(const float* __restrict__ z, const float* __restrict__ ma, int64_t row,
+                                            int stride, int d4, int q) {
+  Row r = row_load(z, row, stride, d4, q);
+  const float4* m4 = reinterpret_cast<const float4*>(ma);
+  if (q < d4) r.a = bn_relu4(r.a, m4[q], m4[32 + q]);
+  if (q + 16 < d4) r.b = bn_relu4(r.b, m4[q + 16], m4[48 + q]);
+  return r;
+}
 __device__ __forceinline__ float row_dot_partial(Row x, Row y) { return dot4(x.a, y.a) + dot4(x.b, y.b); }
 __device__ __forceinline__ float row_dot(Row x, Row y) { return row16_sum(row_dot_partial(x, y)); }
 __device__ __forceinline__ Row row_scale(Row x, float s) { return Row{scale4(x.a, s), scale4(x.b, s)}; }

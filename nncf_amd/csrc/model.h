@@ -42,7 +42,22 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
 
 int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,
                      const PlanView& out1, hipStream_t stream);
-int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream);
+// n_lists plans at pl.at(0..): uniq_global + L*uniq_stride, n_u_out[L]
+int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream,
+                         int64_t n_lists = 1, int64_t uniq_stride = 0);
+
+// Bump allocator over one device allocation (dry run with base == nullptr sizes it).
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
 
 constexpr int kPlanChunk = 64;  // steps planned per launch by the epoch runners
 constexpr int kChunkSlots = 16;  // sorted slots (16-lane groups) per apply workgroup

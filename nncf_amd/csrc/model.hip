@@ -10,22 +10,8 @@
 
 using namespace nncf;
 
-struct nncf_model {
-  nncf_model_cfg cfg;
-  float* U = nullptr;
-  float* V = nullptr;
-  int device = 0;
-  void* arena = nullptr;  // one device allocation, carved below
-  OriginalWs ows;
-  RowwiseWs rws;
-  SharedWs sws;
-  PlanView plan_u, plan_v;  // kPlanChunk lists each
-  int64_t cap_u = 0, cap_v = 0;
-  float* export_gV = nullptr;
-};
 
-namespace {
-
+namespace nncf {
 StepArgs make_args(const nncf_model* m) {
   const nncf_model_cfg& c = m->cfg;
   StepArgs a;
@@ -45,18 +31,11 @@ StepArgs make_args(const nncf_model* m) {
   a.gV = m->export_gV;
   return a;
 }
+}  // namespace nncf
 
-struct Carver {
-  size_t off = 0;
-  char* base = nullptr;
-  template <typename T>
-  T* take(size_t n) {
-    off = (off + 255) & ~(size_t)255;
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += n * sizeof(T);
-    return p;
-  }
-};
+namespace {
+
+
 
 void carve(nncf_model* m, Carver& c) {
   const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives, d = m->cfg.dim;

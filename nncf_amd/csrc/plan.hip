@@ -188,23 +188,28 @@ __global__ void __launch_bounds__(NT) plan_pair_kernel(const int32_t* __restrict
 // Re-express a plan of GLOBAL ids in LOCAL ids = tf.unique ranks (the item block of a text tower
 // or of fetched rows is indexed by rank): desc[s].id = rank, uniq[j] = j; the global ids of the
 // ranks are copied out first.  One workgroup.
-__global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl, int n, int32_t* __restrict__ uniq_global,
-                                                            int32_t* __restrict__ n_u_out) {
+__global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl0, int n, int32_t* __restrict__ uniq_global,
+                                                            int64_t uniq_stride, int32_t* __restrict__ n_u_out) {
+  const PlanView pl = pl0.at(blockIdx.x);
+  uniq_global += blockIdx.x * uniq_stride;
   const int nseg = pl.counts[0];
   int4* desc = reinterpret_cast<int4*>(pl.desc);
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     uniq_global[j] = (j < nseg) ? pl.uniq[j] : 0;  // padding ranks point at row 0 (masked by the caller)
   }
   for (int s = threadIdx.x; s < nseg; s += blockDim.x) desc[s].x = pl.inverse[desc[s].y];
-  if (threadIdx.x == 0 && n_u_out) *n_u_out = nseg;
+  if (threadIdx.x == 0 && n_u_out) n_u_out[blockIdx.x] = nseg;
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += blockDim.x) pl.uniq[j] = j;
 }
 
-int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream) {
+int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream,
+                         int64_t n_lists, int64_t uniq_stride) {
+  if (n_lists <= 0) return NNCF_OK;
   {
     ProfScope _ps("plan_localize_kernel", stream);
-    hipLaunchKernelGGL(plan_localize_kernel, dim3(1), dim3(256), 0, stream, pl, n, uniq_global, n_u_out);
+    hipLaunchKernelGGL(plan_localize_kernel, dim3((unsigned)n_lists), dim3(256), 0, stream, pl, n, uniq_global,
+                       uniq_stride, n_u_out);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -17,7 +17,23 @@ struct StepArgs {
   float gamma, lambda, u_reg, lr;
   float* gV;  // if non-NULL the item rows are NOT updated: dL/dV rows are written to gV[row id][d]
               // (sharded mode: V is a buffer of fetched rows, gradients go back to their owners)
+  // text tower: item row = relu(bn_z[row] * bn_ma[c] + bn_ma[128 + c]) -- BatchNorm + ReLU applied
+  // on load from the pre-activation block, the normalised block is never materialised.  NULL = V.
+  const float* bn_z = nullptr;
+  const float* bn_ma = nullptr;
 };
+
+}  // namespace nncf
+#ifdef __HIPCC__
+#include "devutil.h"
+namespace nncf {
+// row `id` of the step's item table (plain table, or BatchNorm + ReLU of the tower's block)
+__device__ __forceinline__ Row item_row(const StepArgs& a, int64_t id, int d4, int q) {
+  return a.bn_z ? row_load_bn(a.bn_z, a.bn_ma, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
+}
+}  // namespace nncf
+#endif
+namespace nncf {
 
 // train_scheme = original
 struct OriginalWs {
@@ -66,3 +82,22 @@ int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32
                    hipStream_t stream);
 
 }  // namespace nncf
+
+// The model object behind the B2 entry points (include/nncf_hip.h).
+struct nncf_model {
+  nncf_model_cfg cfg;
+  float* U = nullptr;
+  float* V = nullptr;
+  int device = 0;
+  void* arena = nullptr;  // one device allocation, carved below
+  nncf::OriginalWs ows;
+  nncf::RowwiseWs rws;
+  nncf::SharedWs sws;
+  nncf::PlanView plan_u, plan_v;  // kPlanChunk lists each
+  int64_t cap_u = 0, cap_v = 0;
+  float* export_gV = nullptr;
+};
+
+namespace nncf {
+StepArgs make_args(const nncf_model* m);
+}

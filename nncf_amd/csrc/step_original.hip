@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
       if (slot < nslots) ids[e] = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (ids[e] >= 0) ? row_load(a.V, ids[e], a.stride, d4, q) : row_zero();
+    for (int e = 0; e < 4; ++e) v[e] = (ids[e] >= 0) ? item_row(a, ids[e], d4, q) : row_zero();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int slot = t0 + 4 * e + grp;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
   } else {
     const int chunk = blockIdx.x - cu;
     chunk_reduce(
-        pv, chunk, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
+        pv, chunk, sR, [&](int c) { return item_row(a, c, d4, q); },
         [&](int n, bool) {
           const int p = (n < b) ? n : (n - b) / k;
           return row_scale(row_load(ws.Uhat, p, a.d, d4, q), ws.g[n]);

@@ -95,9 +95,9 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
     if (tid < kTile) sPos[tid] = GROUP ? pv.inverse[bi * kTile + tid] : bi * kTile + tid;
     NNCF_STAMP(1);
     Row r0 = row_load(a.U, id0, a.stride, d4, q);
-    Row r1 = (id1 >= 0) ? row_load(a.V, id1, a.stride, d4, q) : row_zero();
+    Row r1 = (id1 >= 0) ? item_row(a, id1, d4, q) : row_zero();
     Row r2 = row_zero();
-    if (PAIR) r2 = row_load(GROUP ? a.V : a.U, id2, a.stride, d4, q);
+    if (PAIR) r2 = GROUP ? item_row(a, id2, d4, q) : row_load(a.U, id2, a.stride, d4, q);
     if (NU || bj == 0) {
       const float ss = row16_sum(row_dot_partial(r0, r0));
       if (bj == 0 && q == 0) ws.reg_part[gi] = ss;
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
   } else {
     const int chunk = blockIdx.x - max_chunks;
     chunk_reduce(
-        pv, chunk, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
+        pv, chunk, sR, [&](int c) { return item_row(a, c, d4, q); },
         [&](int pos, bool is_head) {
           // neg_shared: pos is a column of the tile grid.  group: pos is a batch row of this
           // item's segment; the item's column slab is taken once (with the segment's first

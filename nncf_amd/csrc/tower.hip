@@ -1,68 +1,108 @@
-// MeanPool item tower, the dense half: Dense(item_dim) -> BatchNormalization (batch statistics
-// over the batch's unique items) -> ReLU, forward and backward with in-place SGD
-// (modules/content/mean_pool.py:87-97).  The pooled block is at most a few thousand rows of
-// <= 128 floats, so this is latency- not FLOP-bound: five small launches, each row handled by
-// one 16-lane group (two 16-byte accesses per lane), weights staged in LDS, every cross-row
-// reduction done in a fixed order through per-workgroup partials (no atomics):
-//   fwd1  z = h.Wd + bd, per-workgroup Welford partials (count, mean, M2) of every column
-//   fwd2  merge partials (Chan) -> mu, var; E = relu(gamma (z-mu) rsqrt(var+eps) + beta);
-//         running statistics (momentum) by workgroup 0
-//   bwd1  dy = dA * [y > 0]; partial column sums of dy and dy*xhat
-//   bwd2  dz = gamma inv / n (n dy - sum dy - xhat sum dy xhat); dh = dz.Wd^T;
-//         partial dWd = h^T.dz, dbd = sum dz
-//   upd   Wd, bd, gamma, beta -= lr * (partials summed in workgroup order)
-// Only the first *n_valid rows are real (device scalar): padding rows are computed but masked
-// out of every statistic and gradient, so shapes are static and nothing syncs to the host.
+// basic_embedding item tower (modules/content/mean_pool.py:27-33,46-110; model_choice =
+// 'basic_embedding', models/model_framework.py:98-106): word Embedding -> mean over the L tokens
+// -> Dense(item_dim) -> BatchNormalization (batch statistics over the batch's unique items) ->
+// ReLU, forward and backward with in-place sparse SGD, as ONE native object that also drives the
+// step kernels (the tower's output block is the step's item table, item gradients come back
+// through the export buffer).  Per training step, after the batched duplicate plans:
+//
+//   tower_pool_kernel   one workgroup per unique item: gather-mean of its L word rows
+//                       (4*L*word_dim bytes, the path's dominant traffic), z = h.Wd + bd from the
+//                       pooled row still in LDS, and the item's (word, count) pairs transposed into
+//                       the word-major count matrix the backward reads
+//   tower_stats_kernel  per-workgroup Welford partials of every column of z
+//   tower_bn_kernel     merge (Chan) -> mu, var; E = relu(gamma (z-mu) rsqrt(var+eps) + beta);
+//                       running statistics
+//   (step kernels: shared tile + apply, or original score + apply)
+//   tower_sums_kernel   dy = dA * [E > 0]; partial column sums of dy and dy*xhat
+//   tower_bwd_kernel    role A: dz rows -> LDS, dh = dz.Wd^T   (fp32 MFMA 16x16x4, 16 rows per WG)
+//                       role B: dWd = h^T.dz, dbd = sum dz     (fp32 MFMA, one 16x16 tile of the
+//                               gradient per workgroup, rows split over its 4 waves)
+//   tower_word_kernel   one wave per word: adds count * dh[slot] over the batch slots that hold
+//                       the word (fixed order, no float atomics) and takes the SGD step on its row;
+//                       extra workgroups apply the Dense / BN parameter gradients
+//
+// Only the first *n_valid rows of a block are real (device scalar): shapes are static, nothing
+// syncs to the host, every cross-row reduction has a fixed order.
 // [K-mem] Keras-1 BatchNormalization: eps 1e-3, momentum 0.99, biased variance.
+#include <new>
+
 #include "common.h"
 #include "devutil.h"
+#include "model.h"
+#include "step.h"
 
 namespace nncf {
 
-constexpr int kTP = 128;      // LDS pitch of staged rows / weight rows
-constexpr int kTowerWG = 64;  // at most this many workgroups (partials are summed over them)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTP = 128;       // LDS pitch of pooled rows
+constexpr int kZP = 132;       // LDS pitch of dz rows (16-byte aligned, 4 banks apart)
+constexpr int kTowerWG = 64;   // at most this many workgroups emit statistics partials
+constexpr int kRowsPerK = 1024;  // rows per K-part of the weight-gradient tiles
 
 struct TowerArgs {
-  const float* h;     // [m][wd]
-  float* z;           // [m][d]
-  const float* dA;    // [m][d]
-  float* E;           // [m][d] out (fwd)
-  float* dh;          // [m][wd] out (bwd)
-  float* Wd;          // [wd][d]
+  // parameters
+  float* W;      // [n_words][wd]
+  float* Wd;     // [wd][d]
   float* bd;
   float* gamma;
   float* beta;
   float* rm;
   float* rv;
-  float* ws;          // workspace, see offsets below
-  const int32_t* n_valid;
-  int m, wd, d, train;
+  const int32_t* content;    // [item_count][L]
+  const int32_t* item_ptr;   // CSR of the content matrix: item -> (word, count) pairs
+  const int32_t* item_word;
+  const uint8_t* item_cnt;
+  const float* scale;        // per-word row-dropout scale (Embedding(dropout=...), :56-59) or NULL
+  // per call
+  const int32_t* ids;        // [m] item ids of the block's rows
+  const int32_t* n_valid;    // rows [0, *n_valid) are real; NULL = all m
+  float* h;                  // [m][wd]
+  float* z;                  // [m][d]
+  float* E;                  // [m][d]
+  const float* dA;           // [m][d]
+  float* dh;                 // [m][wd]
+  float* ws;
+  uint8_t* cnt_t;            // [n_words][cap] word-major token counts of the batch (all-zero between steps)
+  int m, wd, d, L, cap, n_words, train, fill;
   float eps, momentum, lr;
+  float keep;                    // row-dropout retain probability (1 = off)
+  unsigned long long drop_seed;  // this step's mask seed
 };
 
-// workspace layout (floats)
-__host__ __device__ inline size_t ws_stats(int) { return 0; }                        // [WG][3][128]
-__host__ __device__ inline size_t ws_muinv(int) { return (size_t)kTowerWG * 3 * 128; }  // mu[128], inv[128], var[128]
-__host__ __device__ inline size_t ws_bsum(int) { return ws_muinv(0) + 3 * 128; }      // [WG][2][128]
-__host__ __device__ inline size_t ws_dbd(int) { return ws_bsum(0) + (size_t)kTowerWG * 2 * 128; }  // [WG][128]
-__host__ __device__ inline size_t ws_dwd(int) { return ws_dbd(0) + (size_t)kTowerWG * 128; }       // [WG][wd*d]
-inline size_t ws_total(int wd, int d) { return ws_dwd(0) + (size_t)kTowerWG * wd * d; }
-
-__device__ __forceinline__ void stage_weights(float* sW, const float* Wd, int wd, int d) {
-  // wd*d/4 <= 4096 float4: 16 per thread, all loads issued before the first LDS store
-  const int d4 = d >> 2, n4 = wd * d4;
-  float4 t[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = threadIdx.x + i * 256;
-    t[i] = (e < n4) ? reinterpret_cast<const float4*>(Wd)[e] : zero4();
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int e = threadIdx.x + i * 256;
-    if (e < n4) reinterpret_cast<float4*>(sW + (e / d4) * kTP)[e % d4] = t[i];
-  }
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
 }
+
+// Embedding(dropout = 1 - keep) of Keras 1 (mean_pool.py:56-59): whole word rows are dropped
+// per batch, survivors scaled by 1/keep.  The mask is a counter-based hash of (step seed, word),
+// evaluated where it is needed -- no mask array, and dropped rows are never loaded.  An explicit
+// mask (a.scale) overrides it.  [K-mem] the reference draws its mask from TF's RNG: the stream
+// cannot match, only the distribution.
+__device__ __forceinline__ float word_scale(const TowerArgs& a, int w) {
+  if (a.scale) return a.scale[w];
+  if (a.keep >= 1.f) return 1.f;
+  const unsigned long long x = splitmix64(a.drop_seed + (unsigned long long)w * 0x9E3779B97F4A7C15ull);
+  const float u = (float)(x >> 40) * (1.f / 16777216.f);
+  return u < a.keep ? 1.f / a.keep : 0.f;
+}
+
+// workspace layout (floats)
+__host__ __device__ inline size_t ws_stats() { return 0; }                                     // [WG][3][128]
+__host__ __device__ inline size_t ws_muinv() { return (size_t)kTowerWG * 3 * 128; }             // mu, inv, var, mul, add
+__host__ __device__ inline size_t ws_bsum() { return ws_muinv() + 5 * 128; }                    // [WG][2][128]
+__host__ __device__ inline size_t ws_bfin() { return ws_bsum() + (size_t)kTowerWG * 2 * 128; }  // sum dy, sum dy*xhat
+__host__ __device__ inline size_t ws_cnt() { return ws_bfin() + 2 * 128; }                      // 4 arrival counters
+__host__ __device__ inline size_t ws_gb(int) { return ws_cnt() + 4; }                           // [ks][128]
+__host__ __device__ inline size_t ws_gw(int ks) { return ws_gb(0) + (size_t)ks * 128; }         // [ks][wd*d]
+inline size_t ws_total(int wd, int d, int ks) { return ws_gw(ks) + (size_t)ks * wd * d; }
+
+__device__ __forceinline__ int valid_rows(const TowerArgs& a) { return a.n_valid ? min(*a.n_valid, a.m) : a.m; }
 
 // column c of lane q's Row element e (e = 0..7): floats [4q,4q+4) then [64+4q, 64+4q+4)
 __device__ __forceinline__ int col_of(int q, int e) { return (e < 4 ? 4 * q : 64 + 4 * q - 4) + e; }
@@ -70,421 +110,864 @@ __device__ __forceinline__ float& relem(Row& r, int e) {
   return e == 0 ? r.a.x : e == 1 ? r.a.y : e == 2 ? r.a.z : e == 3 ? r.a.w : e == 4 ? r.b.x : e == 5 ? r.b.y : e == 6 ? r.b.z : r.b.w;
 }
 
-__global__ void __launch_bounds__(256) tower_fwd1_kernel(TowerArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW = smem;                    // [wd][kTP]
-  float* sH = sW + a.wd * kTP;         // [16][kTP]
-  float* sS = sH + 16 * kTP;           // [16][3][kTP] welford partials of the groups
-  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15;
-  const int wd4 = a.wd >> 2, d4 = a.d >> 2, nv = *a.n_valid;
-  stage_weights(sW, a.Wd, a.wd, a.d);
-  Row bias = row_load(a.bd, 0, a.d, d4, q);
-  Row cnt = row_zero(), mean = row_zero(), m2 = row_zero();
-  const int nblk = (a.m + 15) >> 4;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int row = blk * 16 + grp;
-    __syncthreads();
-    Row hr = row < a.m ? row_load(a.h, row, a.wd, wd4, q) : row_zero();
-    reinterpret_cast<float4*>(sH + grp * kTP)[q] = hr.a;
-    reinterpret_cast<float4*>(sH + grp * kTP)[q + 16] = hr.b;
-    __syncthreads();
-    Row z = bias;
-    const float* hrow = sH + grp * kTP;
-    for (int k = 0; k < a.wd; ++k) {
-      const float hk = hrow[k];
-      Row w;
-      w.a = reinterpret_cast<const float4*>(sW + k * kTP)[q];
-      w.b = reinterpret_cast<const float4*>(sW + k * kTP)[q + 16];
-      z = row_fma(hk, w, z);
-    }
-    if (row < a.m) row_store(a.z, row, a.d, d4, q, z);
-    if (a.train && row < nv) {  // Welford update, per column
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float& c = relem(cnt, e);
-        float& mu = relem(mean, e);
-        float& s2 = relem(m2, e);
-        const float x = relem(z, e);
-        c += 1.f;
-        const float dlt = x - mu;
-        mu += dlt / c;
-        s2 += dlt * (x - mu);
-      }
-    }
-  }
-  if (!a.train) return;
-  // combine the 16 groups in group order (Chan), then emit this workgroup's partial
+// "Last workgroup done" reduction: every workgroup publishes its partial, the one that arrives
+// last (device-scope counter) merges all partials in partial order -- the result does not depend
+// on arrival order -- and re-arms the counter.  Returns true in every thread of that workgroup.
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
+  __shared__ int s_last;
+  __threadfence();
   __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = col_of(q, e);
-    sS[(grp * 3 + 0) * kTP + c] = relem(cnt, e);
-    sS[(grp * 3 + 1) * kTP + c] = relem(mean, e);
-    sS[(grp * 3 + 2) * kTP + c] = relem(m2, e);
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == gridDim.x - 1);
+    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (threadIdx.x < a.d) {
-    const int c = threadIdx.x;
-    float n = 0.f, mu = 0.f, s2 = 0.f;
-    for (int g = 0; g < 16; ++g) {
-      const float nb = sS[(g * 3 + 0) * kTP + c], mb = sS[(g * 3 + 1) * kTP + c], sb = sS[(g * 3 + 2) * kTP + c];
-      if (nb > 0.f) {
-        const float nn = n + nb, dlt = mb - mu;
-        mu += dlt * nb / nn;
-        s2 += sb + dlt * dlt * n * nb / nn;
-        n = nn;
-      }
-    }
-    float* out = a.ws + ws_stats(0) + (size_t)blockIdx.x * 3 * 128;
-    out[c] = n;
-    out[128 + c] = mu;
-    out[256 + c] = s2;
-  }
+  if (s_last) __threadfence();
+  return s_last != 0;
 }
 
-__global__ void __launch_bounds__(256) tower_fwd2_kernel(TowerArgs a) {
-  __shared__ float sMu[128], sInv[128], sG[128], sB[128];
-  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2;
-  __shared__ float sPart[kTowerWG * 3 * 128];
-  const int nparts = min((int)kTowerWG, (a.m + 15) >> 4);
-  if (a.train) {  // all partial loads in flight at once, merged from LDS
-    const float4* src = reinterpret_cast<const float4*>(a.ws + ws_stats(0));
-    float4 t[24];  // kTowerWG*3*128/4 = 6144 float4 = 24 per thread
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      const int e = threadIdx.x + i * 256;
-      t[i] = (e < nparts * 96) ? src[e] : zero4();
-    }
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      const int e = threadIdx.x + i * 256;
-      if (e < nparts * 96) reinterpret_cast<float4*>(sPart)[e] = t[i];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < a.d) {
-    const int c = threadIdx.x;
-    float mu, var;
-    if (a.train) {
-      float n = 0.f, s2 = 0.f;
-      mu = 0.f;
-      for (int p = 0; p < nparts; ++p) {
-        const float* in = sPart + p * 3 * 128;
-        const float nb = in[c], mb = in[128 + c], sb = in[256 + c];
-        if (nb > 0.f) {
-          const float nn = n + nb, dlt = mb - mu;
-          mu += dlt * nb / nn;
-          s2 += sb + dlt * dlt * n * nb / nn;
-          n = nn;
-        }
-      }
-      var = s2 / fmaxf(n, 1.f);
-      if (blockIdx.x == 0) {
-        float* mi = a.ws + ws_muinv(0);
-        mi[c] = mu;
-        mi[128 + c] = rsqrtf(var + a.eps);
-        mi[256 + c] = var;
-      }
-    } else {
-      mu = a.rm[c];
-      var = a.rv[c];
-    }
-    sMu[c] = mu;
-    sInv[c] = rsqrtf(var + a.eps);
-    sG[c] = a.gamma[c];
-    sB[c] = a.beta[c];
-  }
-  __syncthreads();
-  const int nblk = (a.m + 15) >> 4;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int row = blk * 16 + grp;
-    if (row >= a.m) continue;
-    Row z = row_load(a.z, row, a.d, d4, q), o = row_zero();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = col_of(q, e);
-      if (c < a.d) relem(o, e) = fmaxf(sG[c] * (relem(z, e) - sMu[c]) * sInv[c] + sB[c], 0.f);
-    }
-    row_store(a.E, row, a.d, d4, q, o);
-  }
-}
+// ---- forward ---------------------------------------------------------------------------------
 
-// running statistics (Keras moving_average_update), after fwd2 published mu / var
-__global__ void tower_running_kernel(TowerArgs a) {
-  const int c = threadIdx.x;
-  if (c < a.d) {
-    const float* mi = a.ws + ws_muinv(0);
-    a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mi[c];
-    a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * mi[256 + c];
-  }
-}
-
-__global__ void __launch_bounds__(256) tower_bwd1_kernel(TowerArgs a) {
-  __shared__ float sS[16 * 2 * kTP];
-  __shared__ float sMu[128], sInv[128], sG[128], sB[128];
-  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2, nv = *a.n_valid;
-  if (threadIdx.x < a.d) {
-    const float* mi = a.ws + ws_muinv(0);
-    sMu[threadIdx.x] = mi[threadIdx.x];
-    sInv[threadIdx.x] = mi[128 + threadIdx.x];
-    sG[threadIdx.x] = a.gamma[threadIdx.x];
-    sB[threadIdx.x] = a.beta[threadIdx.x];
-  }
-  __syncthreads();
-  Row s1 = row_zero(), s2 = row_zero();
-  const int nblk = (a.m + 15) >> 4;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int row = blk * 16 + grp;
-    if (row >= nv) continue;
-    const Row z = row_load(a.z, row, a.d, d4, q), g = row_load(a.dA, row, a.d, d4, q);
-    Row zz = z, gg = g;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = col_of(q, e);
-      if (c < a.d) {
-        const float xh = (relem(zz, e) - sMu[c]) * sInv[c];
-        const float dy = (sG[c] * xh + sB[c] > 0.f) ? relem(gg, e) : 0.f;
-        relem(s1, e) += dy;
-        relem(s2, e) += dy * xh;
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = col_of(q, e);
-    sS[(grp * 2 + 0) * kTP + c] = relem(s1, e);
-    sS[(grp * 2 + 1) * kTP + c] = relem(s2, e);
-  }
-  __syncthreads();
-  if (threadIdx.x < a.d) {
-    const int c = threadIdx.x;
-    float t1 = 0.f, t2 = 0.f;
-    for (int g = 0; g < 16; ++g) {
-      t1 += sS[(g * 2 + 0) * kTP + c];
-      t2 += sS[(g * 2 + 1) * kTP + c];
-    }
-    float* out = a.ws + ws_bsum(0) + (size_t)blockIdx.x * 2 * 128;
-    out[c] = t1;
-    out[128 + c] = t2;
-  }
-}
-
-__global__ void __launch_bounds__(256) tower_bwd2_kernel(TowerArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW = smem;               // [wd][kTP]
-  float* sH = sW + a.wd * kTP;    // [16][kTP]
-  float* sZ = sH + 16 * kTP;      // [16][kTP]  dz rows
-  __shared__ float sMu[128], sInv[128], sG[128], sB[128], sA[128], sBq[128];
+// One workgroup per block row s: h[s] = (1/L) sum_l scale[c] W[c], c = content[ids[s]][l]
+// (AverageEmbeddings divides by L always: the mask compares ids with -1, mean_pool.py:30; the pad
+// id 0 contributes its row), then z[s] = h[s].Wd + bd.  Inference (train = 0) finishes the row:
+// E[s] = relu(BN_running(z[s])).
+__global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
+  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ __attribute__((aligned(16))) float sH[kTP];
+  __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
+  __shared__ int sTok[256];
+  __shared__ float sSc[256];
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
-  const int wd4 = a.wd >> 2, d4 = a.d >> 2, nv = *a.n_valid;
-  const int nparts = min((int)kTowerWG, (a.m + 15) >> 4);
-  stage_weights(sW, a.Wd, a.wd, a.d);
-  if (tid < a.d) {
-    const float* mi = a.ws + ws_muinv(0);
-    sMu[tid] = mi[tid];
-    sInv[tid] = mi[128 + tid];
-    sG[tid] = a.gamma[tid];
-    sB[tid] = a.beta[tid];
-    float t1 = 0.f, t2 = 0.f;
-    for (int p0 = 0; p0 < nparts; p0 += 16) {
-      float u1[16], u2[16];
+  const int wd4 = a.wd >> 2, d4 = a.d >> 2;
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  const int item = a.ids[s];
+  // this thread's slice of the dense weights: columns [4c4, 4c4+4), rows kp*kper .. +kper.
+  // Issued first: independent of the pooling below, so the two latencies overlap.
+  const int c4 = tid & 31, kp = tid >> 5, kper = (a.wd + 7) >> 3;
+  float4 w[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float* in = a.ws + ws_bsum(0) + (size_t)(p0 + e) * 2 * 128;
-        u1[e] = (p0 + e < nparts) ? in[tid] : 0.f;
-        u2[e] = (p0 + e < nparts) ? in[128 + tid] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        t1 += u1[e];
-        t2 += u2[e];
-      }
+  for (int i = 0; i < 16; ++i) {
+    const int k = kp * kper + i;
+    w[i] = (i < kper && k < a.wd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+  }
+  // all L tokens (and their dropout scales) in one round trip, parked in LDS
+  const int32_t* toks = a.content + (int64_t)item * a.L;
+  if (tid < a.L) {
+    const int tk = toks[tid];
+    sTok[tid] = tk;
+    sSc[tid] = a.train ? word_scale(a, tk) : 1.f;
+  }
+  // backward preparation, loads first: this item's (word, count) pairs
+  int fp0 = 0, fp1 = 0, fw = 0;
+  unsigned fc = 0;
+  if (a.fill) {
+    fp0 = a.item_ptr[item];
+    fp1 = a.item_ptr[item + 1];
+    if (fp0 + tid < fp1) {
+      fw = a.item_word[fp0 + tid];
+      fc = a.item_cnt[fp0 + tid];
     }
+  }
+  __syncthreads();
+  Row acc = row_zero();
+  const int nper = (a.L + 15) >> 4;  // tokens per group
+  for (int i0 = 0; i0 < nper; i0 += 7) {  // 7 word rows of this group in flight
+    float sc[7];
+    Row r[7];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      const int l = grp + 16 * (i0 + e);
+      const bool ok = (i0 + e < nper) && l < a.L;
+      sc[e] = ok ? sSc[l] : 0.f;
+      r[e] = (sc[e] != 0.f) ? row_load(a.W, sTok[l], a.wd, wd4, q) : row_zero();
+    }
+#pragma unroll
+    for (int e = 0; e < 7; ++e) acc = row_fma(sc[e], r[e], acc);
+  }
+  reinterpret_cast<float4*>(sR + grp * kTP)[q] = acc.a;
+  reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = acc.b;
+  __syncthreads();
+  if (grp == 0) {
+    Row sum = row_zero();
+    for (int g = 0; g < 16; ++g) {
+      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
+      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+    }
+    sum = row_scale(sum, 1.f / (float)a.L);
+    if (a.train) row_store(a.h, s, a.wd, wd4, q, sum);
+    reinterpret_cast<float4*>(sH)[q] = sum.a;  // chunks past wd are the zeros row_load produced
+    reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
+  }
+  __syncthreads();
+  float4 part = zero4();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = kp * kper + i;
+    if (i < kper && k < a.wd) part = fma4(sH[k], w[i], part);
+  }
+  sP[kp * 32 + c4] = part;
+  __syncthreads();
+  if (tid < d4) {
+    float4 z = reinterpret_cast<const float4*>(a.bd)[tid];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) z = add4(z, sP[p * 32 + tid]);
+    if (a.train) {
+      reinterpret_cast<float4*>(a.z + (int64_t)s * a.d)[tid] = z;
+    } else {
+      const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
+      const float4 mu = reinterpret_cast<const float4*>(a.rm)[tid], var = reinterpret_cast<const float4*>(a.rv)[tid];
+      float4 o;
+      o.x = fmaxf(g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x, 0.f);
+      o.y = fmaxf(g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y, 0.f);
+      o.z = fmaxf(g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z, 0.f);
+      o.w = fmaxf(g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w, 0.f);
+      reinterpret_cast<float4*>(a.E + (int64_t)s * a.d)[tid] = o;
+    }
+  }
+  // backward preparation: cnt_t[w * cap + s] = occurrences of word w in this item.  Every
+  // (w, s) cell is written by exactly one thread: no atomics.  Dropped words get no gradient.
+  if (a.fill) {
+    if (fp0 + tid < fp1 && word_scale(a, fw) != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = (uint8_t)fc;
+    for (int p = fp0 + tid + 256; p < fp1; p += 256) {
+      const int wv = a.item_word[p];
+      if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = a.item_cnt[p];
+    }
+  }
+}
+
+// Column sums over the real rows of a block, 1024 threads = 64 row groups per workgroup, eight
+// rows of a group in flight; `elem(row, z, out1, out2)` adds a row's contribution.  Groups are
+// combined inside a wave by shuffles, waves through LDS in wave order.  Result in threads c < d.
+template <bool WITH_DA, typename F>
+__device__ __forceinline__ void column_sums(const TowerArgs& a, int nv, F&& elem, float* sS, float& t1, float& t2) {
+  constexpr int NB = WITH_DA ? 4 : 8;  // rows in flight (64 VGPRs of loads either way)
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, wave = tid >> 6, d4 = a.d >> 2;
+  Row s1 = row_zero(), s2 = row_zero();
+  const int stride = 64 * gridDim.x;
+  for (int r0 = blockIdx.x * 64 + grp; r0 < nv; r0 += NB * stride) {
+    Row z[NB], g[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int row = r0 + e * stride;
+      z[e] = (row < nv) ? row_load(a.z, row, a.d, d4, q) : row_zero();
+      if (WITH_DA) g[e] = (row < nv) ? row_load(a.dA, row, a.d, d4, q) : row_zero();
+    }
+#pragma unroll
+    for (int e = 0; e < NB; ++e)
+      if (r0 + e * stride < nv) elem(z[e], WITH_DA ? g[e] : z[e], s1, s2);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v1 = relem(s1, e), v2 = relem(s2, e);
+    v1 += __shfl_xor(v1, 16);
+    v1 += __shfl_xor(v1, 32);
+    v2 += __shfl_xor(v2, 16);
+    v2 += __shfl_xor(v2, 32);
+    if (grp == 4 * wave) {  // first group of the wave
+      const int c = col_of(q, e);
+      sS[(wave * 2 + 0) * kTP + c] = v1;
+      sS[(wave * 2 + 1) * kTP + c] = v2;
+    }
+  }
+  __syncthreads();
+  t1 = 0.f;
+  t2 = 0.f;
+  if (tid < a.d) {
+    for (int w = 0; w < 16; ++w) {
+      t1 += sS[(w * 2 + 0) * kTP + tid];
+      t2 += sS[(w * 2 + 1) * kTP + tid];
+    }
+  }
+}
+
+// partial column sums of every workgroup -> totals, in workgroup order (threads c < d)
+__device__ __forceinline__ void merge_partials(const float* part, int nparts, int c, float& t1, float& t2) {
+  t1 = 0.f;
+  t2 = 0.f;
+  for (int p0 = 0; p0 < nparts; p0 += 16) {
+    float u1[16], u2[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float* in = part + (size_t)(p0 + e) * 2 * 128;
+      u1[e] = (p0 + e < nparts) ? in[c] : 0.f;
+      u2[e] = (p0 + e < nparts) ? in[128 + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      t1 += u1[e];
+      t2 += u2[e];
+    }
+  }
+}
+
+// BatchNorm statistics of z over the real rows: shifted sums (shift = row 0, a sample of the same
+// distribution: no cancellation) -> mu, inv = rsqrt(var + eps), var, and the fused scale / shift
+// mul = gamma inv, add = beta - mu mul; running statistics (Keras moving_average_update).
+// One workgroup does a block of up to 1024 rows alone; larger blocks use several and the last one
+// to arrive merges their partials.
+__global__ void __launch_bounds__(1024) tower_stats_kernel(TowerArgs a) {
+  __shared__ float sS[16 * 2 * kTP];
+  const int nv = valid_rows(a), d4 = a.d >> 2, q = threadIdx.x & 15;
+  const Row x0 = row_load(a.z, 0, a.d, d4, q);
+  float t1, t2;
+  column_sums<false>(a, nv, [&](Row z, Row, Row& s1, Row& s2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Row xx = x0;
+      const float dlt = relem(z, e) - relem(xx, e);
+      relem(s1, e) += dlt;
+      relem(s2, e) += dlt * dlt;
+    }
+  }, sS, t1, t2);
+  const int c = threadIdx.x;
+  if (gridDim.x > 1) {
+    float* part = a.ws + ws_stats();
+    if (c < a.d) {
+      part[(size_t)blockIdx.x * 2 * 128 + c] = t1;
+      part[(size_t)blockIdx.x * 2 * 128 + 128 + c] = t2;
+    }
+    if (!last_block_arrives(reinterpret_cast<unsigned*>(a.ws + ws_cnt()))) return;
+    if (c < a.d) merge_partials(part, gridDim.x, c, t1, t2);
+  }
+  if (c < a.d) {
+    const float rn = 1.f / (float)max(nv, 1);
+    const float m1 = t1 * rn;
+    const float mu = a.z[c] + m1, var = fmaxf(t2 * rn - m1 * m1, 0.f), inv = rsqrtf(var + a.eps);
+    float* mi = a.ws + ws_muinv();
+    const float mul = a.gamma[c] * inv;
+    mi[c] = mu;
+    mi[128 + c] = inv;
+    mi[256 + c] = var;
+    mi[384 + c] = mul;
+    mi[512 + c] = a.beta[c] - mu * mul;
+    a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mu;
+    a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * var;
+  } else if (c < 128) {  // pad columns of the fused scale / shift
+    a.ws[ws_muinv() + 384 + c] = 0.f;
+    a.ws[ws_muinv() + 512 + c] = 0.f;
+  }
+}
+
+// E = relu(z * mul + add) for standalone forwards (the training step applies it on load).
+__global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
+  __shared__ float sMul[128], sAdd[128];
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2, nv = valid_rows(a);
+  const int row = blockIdx.x * 16 + grp;
+  Row z = (row < nv) ? row_load(a.z, row, a.d, d4, q) : row_zero();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    sMul[c] = a.ws[ws_muinv() + 384 + c];
+    sAdd[c] = a.ws[ws_muinv() + 512 + c];
+  }
+  __syncthreads();
+  if (row >= a.m) return;
+  Row o = row_zero();  // rows past n_valid: zeros (never referenced by the step, kept finite)
+  if (row < nv) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col_of(q, e);
+      relem(o, e) = fmaxf(fmaf(relem(z, e), sMul[c], sAdd[c]), 0.f);
+    }
+  }
+  row_store(a.E, row, a.d, d4, q, o);
+}
+
+// ---- backward --------------------------------------------------------------------------------
+
+// dy = dA * [y > 0]; column sums of dy (= dbeta) and dy * xhat (= dgamma) over the real rows.
+__global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
+  __shared__ float sS[16 * 2 * kTP];
+  __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128];
+  const int nv = valid_rows(a), q = threadIdx.x & 15;
+  if (threadIdx.x < 128) {
+    const float* mi = a.ws + ws_muinv();
+    const bool ok = threadIdx.x < a.d;
+    sMu[threadIdx.x] = ok ? mi[threadIdx.x] : 0.f;
+    sInv[threadIdx.x] = ok ? mi[128 + threadIdx.x] : 0.f;
+    sMul[threadIdx.x] = ok ? mi[384 + threadIdx.x] : 0.f;
+    sAdd[threadIdx.x] = ok ? mi[512 + threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  float t1, t2;
+  column_sums<true>(a, nv, [&](Row z, Row g, Row& s1, Row& s2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col_of(q, e);
+      const float x = relem(z, e);
+      const float dy = (fmaf(x, sMul[c], sAdd[c]) > 0.f) ? relem(g, e) : 0.f;
+      relem(s1, e) += dy;
+      relem(s2, e) += dy * (x - sMu[c]) * sInv[c];
+    }
+  }, sS, t1, t2);
+  const int c = threadIdx.x;
+  if (gridDim.x > 1) {
+    float* part = a.ws + ws_bsum();
+    if (c < a.d) {
+      part[(size_t)blockIdx.x * 2 * 128 + c] = t1;
+      part[(size_t)blockIdx.x * 2 * 128 + 128 + c] = t2;
+    }
+    if (!last_block_arrives(reinterpret_cast<unsigned*>(a.ws + ws_cnt()) + 1)) return;
+    if (c < a.d) merge_partials(part, gridDim.x, c, t1, t2);
+  }
+  if (c < a.d) {
+    a.ws[ws_bfin() + c] = t1;        // sum dy       (= dbeta)
+    a.ws[ws_bfin() + 128 + c] = t2;  // sum dy*xhat  (= dgamma)
+  }
+}
+
+// dz = gamma inv / n (n dy - sum dy - xhat sum dy xhat) and the two products that need it.
+// Blocks [0, nA): role A, 16 rows each; blocks [nA, ...): role B, tile (it, jt) x K-part.
+__global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int ks) {
+  __shared__ float sMu[128], sInv[128], sG[128], sMul[128], sAdd[128], sA[128], sBq[128];
+  __shared__ __attribute__((aligned(16))) float sZ[16 * kZP];
+  __shared__ f32x4 sAcc[4 * 64];
+  __shared__ float sCol[4 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = valid_rows(a);
+  const int d4 = a.d >> 2;
+  if (blockIdx.x < nA && blockIdx.x * 16 >= nv) return;
+  if (tid < 128) {
+    float mu = 0.f, inv = 0.f, g = 0.f, mul = 0.f, add = 0.f, t1 = 0.f, t2 = 0.f;
+    if (tid < a.d) {
+      const float* mi = a.ws + ws_muinv();
+      mu = mi[tid];
+      inv = mi[128 + tid];
+      mul = mi[384 + tid];
+      add = mi[512 + tid];
+      g = a.gamma[tid];
+      t1 = a.ws[ws_bfin() + tid];
+      t2 = a.ws[ws_bfin() + 128 + tid];
+    }
+    sMu[tid] = mu;
+    sInv[tid] = inv;
+    sG[tid] = g;  // gamma = 0 past d: those columns of dz are exactly 0
+    sMul[tid] = mul;
+    sAdd[tid] = add;
     sA[tid] = t1;   // sum dy       (= dbeta)
     sBq[tid] = t2;  // sum dy*xhat  (= dgamma)
   }
-  const float n = (float)nv;
-  // this thread's elements of the wd x d weight gradient
-  constexpr int kMaxCells = (128 * 32 + 255) / 256;
-  float4 gw[kMaxCells];
-#pragma unroll
-  for (int i = 0; i < kMaxCells; ++i) gw[i] = zero4();
-  float gb = 0.f;
-  const int nel = a.wd * a.d, ncell = a.wd * d4;
-  const int nblk = (a.m + 15) >> 4;
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int row = blk * 16 + grp;
-    __syncthreads();
-    Row hr = row_zero(), dz = row_zero();
+  __syncthreads();
+  const float n = (float)nv, rn = 1.f / n;
+  const int x = lane & 15, kq = lane >> 4;
+
+  if (blockIdx.x < nA) {
+    // ---- role A: dh[r][kw] = sum_c dz[r][c] Wd[kw][c] for 16 rows ------------------------------
+    const int r0 = blockIdx.x * 16, grp = tid >> 4, q = tid & 15, row = r0 + grp;
+    Row dz = row_zero();
     if (row < nv) {
-      hr = row_load(a.h, row, a.wd, wd4, q);
-      const Row z = row_load(a.z, row, a.d, d4, q), g = row_load(a.dA, row, a.d, d4, q);
-      Row zz = z, gg = g;
+      Row zz = row_load(a.z, row, a.d, d4, q), gg = row_load(a.dA, row, a.d, d4, q);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = col_of(q, e);
-        if (c < a.d) {
-          const float xh = (relem(zz, e) - sMu[c]) * sInv[c];
-          const float dy = (sG[c] * xh + sB[c] > 0.f) ? relem(gg, e) : 0.f;
-          relem(dz, e) = sG[c] * sInv[c] / n * (n * dy - sA[c] - xh * sBq[c]);
-        }
+        const float xh = (relem(zz, e) - sMu[c]) * sInv[c];
+        const float dy = (fmaf(relem(zz, e), sMul[c], sAdd[c]) > 0.f) ? relem(gg, e) : 0.f;
+        relem(dz, e) = sG[c] * sInv[c] * rn * (n * dy - sA[c] - xh * sBq[c]);
       }
     }
-    reinterpret_cast<float4*>(sH + grp * kTP)[q] = hr.a;
-    reinterpret_cast<float4*>(sH + grp * kTP)[q + 16] = hr.b;
-    reinterpret_cast<float4*>(sZ + grp * kTP)[q] = dz.a;
-    reinterpret_cast<float4*>(sZ + grp * kTP)[q + 16] = dz.b;
+    reinterpret_cast<float4*>(sZ + grp * kZP)[q] = dz.a;
+    reinterpret_cast<float4*>(sZ + grp * kZP)[q + 16] = dz.b;
     __syncthreads();
-    // dh[row][k] = sum_n dz[n] * Wd[k][n]: every lane multiplies its own 8 columns of dz (still
-    // in registers) with row k of the weights (one row for the whole group: conflict-free 16-byte
-    // LDS reads), a DPP row reduction finishes the dot, the owner lane of k keeps it.
-    if (row < a.m) {
-      Row o = row_zero();
-      for (int k = 0; k < a.wd; ++k) {
-        Row w;
-        w.a = reinterpret_cast<const float4*>(sW + k * kTP)[q];
-        w.b = reinterpret_cast<const float4*>(sW + k * kTP)[q + 16];
-        // columns >= d of the staged weights are uninitialised LDS: never let them into the sum
-        const float v = row16_sum(((q < d4) ? dot4(dz.a, w.a) : 0.f) + ((q + 16 < d4) ? dot4(dz.b, w.b) : 0.f));
-        const int owner = (k < 64) ? (k >> 2) : ((k - 64) >> 2), e = (k & 3) + ((k < 64) ? 0 : 4);
-        if (q == owner) {
-          if (e == 0) o.a.x = v; else if (e == 1) o.a.y = v; else if (e == 2) o.a.z = v; else if (e == 3) o.a.w = v;
-          else if (e == 4) o.b.x = v; else if (e == 5) o.b.y = v; else if (e == 6) o.b.z = v; else o.b.w = v;
+    // MFMA 16x16x4: A lane (i = x, k = kq) = dz[r0+i][c], B lane (j = x, k = kq) = Wd[kw0+j][c].
+    // The K index is free to permute as long as A and B agree: component e of the float4 at
+    // column 16t + 4kq serves k-step (t, e), so both operands are 16-byte row-contiguous loads.
+    const int nct = (a.wd + 15) >> 4, nt = (a.d + 15) >> 4;
+    for (int ct = wave; ct < nct; ct += 4) {
+      const int kw = ct * 16 + x;
+      const float4* wrow = reinterpret_cast<const float4*>(a.Wd + (int64_t)kw * a.d);
+      float4 bf[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int col = 16 * t + 4 * kq;
+        bf[t] = (t < nt && kw < a.wd && col < a.d) ? wrow[col >> 2] : zero4();
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t < nt) {
+          const float4 af = *reinterpret_cast<const float4*>(sZ + x * kZP + 16 * t + 4 * kq);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[t].x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[t].y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[t].z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[t].w, acc1, 0, 0, 0);
         }
       }
-      row_store(a.dh, row, a.wd, wd4, q, o);
-    }
-    // dWd[k][n..n+3] += sum_r h[r][k] dz[r][n..n+3]   (thread owns float4 cells of the gradient)
+      const f32x4 acc = acc0 + acc1;
 #pragma unroll
-    for (int i = 0; i < kMaxCells; ++i) {
-      const int cell = tid + i * 256;
-      if (cell < ncell) {
-        const int k = cell / d4, n4 = cell % d4;
-        float4 acc = gw[i];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc = fma4(sH[r * kTP + k], reinterpret_cast<const float4*>(sZ + r * kTP)[n4], acc);
-        gw[i] = acc;
+      for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x]
+        const int rr = r0 + 4 * kq + r;
+        if (rr < nv && kw < a.wd) a.dh[(int64_t)rr * a.wd + kw] = acc[r];
       }
     }
-    if (tid < a.d) {
+    return;
+  }
+
+  // ---- role B: dWd[kw][c] = sum_r h[r][kw] dz[r][c] for one 16x16 tile, rows of one K-part ------
+  const int tb = blockIdx.x - nA, tile = tb / ks, kpart = tb % ks;
+  const int nct = (a.d + 15) >> 4;
+  const int it = tile / nct, jt = tile % nct;
+  const int kw = it * 16 + x, cn = jt * 16 + x;  // A lane: h column kw; B lane: dz column cn
+  const float mu = sMu[cn], inv = sInv[cn], g = sG[cn], mul = sMul[cn], add = sAdd[cn], sa = sA[cn], sbq = sBq[cn];
+  const float coef = g * inv * rn;
+  const int rbeg = kpart * kRowsPerK, rend = min(nv, rbeg + kRowsPerK);
+  const bool okh = kw < a.wd, okc = cn < a.d;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float colsum = 0.f;
+  // waves take the 4-row k-steps round robin; 16 steps (48 loads) in flight
+  for (int st0 = wave; rbeg + 4 * st0 < rend; st0 += 64) {
+    float hv[16], zv[16], gv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) gb += sZ[r * kTP + tid];
+    for (int u = 0; u < 16; ++u) {
+      const int r = rbeg + 4 * (st0 + 4 * u) + kq;
+      const bool ok = r < rend;
+      hv[u] = (ok && okh) ? a.h[(int64_t)r * a.wd + kw] : 0.f;
+      zv[u] = (ok && okc) ? a.z[(int64_t)r * a.d + cn] : 0.f;
+      gv[u] = (ok && okc) ? a.dA[(int64_t)r * a.d + cn] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = rbeg + 4 * (st0 + 4 * u) + kq;
+      const float xh = (zv[u] - mu) * inv;
+      const float dy = (fmaf(zv[u], mul, add) > 0.f) ? gv[u] : 0.f;
+      const float dzv = (r < rend) ? coef * (n * dy - sa - xh * sbq) : 0.f;
+      colsum += dzv;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u], dzv, acc, 0, 0, 0);
     }
   }
-  float4* outw = reinterpret_cast<float4*>(a.ws + ws_dwd(0) + (size_t)blockIdx.x * nel);
+  sAcc[wave * 64 + lane] = acc;
+  colsum += __shfl_xor(colsum, 16);
+  colsum += __shfl_xor(colsum, 32);
+  if (kq == 0) sCol[wave * 16 + x] = colsum;
+  __syncthreads();
+  if (wave == 0) {
+    const f32x4 tot = ((sAcc[lane] + sAcc[64 + lane]) + sAcc[128 + lane]) + sAcc[192 + lane];
+    float* gw = a.ws + ws_gw(ks) + (size_t)kpart * a.wd * a.d;
 #pragma unroll
-  for (int i = 0; i < kMaxCells; ++i) {
-    const int cell = tid + i * 256;
-    if (cell < ncell) outw[cell] = gw[i];
+    for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWd[it*16 + i][cn]
+      const int kwi = it * 16 + 4 * kq + r;
+      if (kwi < a.wd && okc) gw[(int64_t)kwi * a.d + cn] = tot[r];
+    }
+    if (it == 0 && kq == 0 && okc)
+      a.ws[ws_gb(0) + (size_t)kpart * 128 + cn] = ((sCol[x] + sCol[16 + x]) + sCol[32 + x]) + sCol[48 + x];
   }
-  if (tid < a.d) a.ws[ws_dbd(0) + (size_t)blockIdx.x * 128 + tid] = gb;
 }
 
-__global__ void __launch_bounds__(256) tower_update_kernel(TowerArgs a, int nparts) {
-  const int el = blockIdx.x * 256 + threadIdx.x;
-  const int nel = a.wd * a.d;
-  if (el < nel) {
-    float g = 0.f;
-    for (int p0 = 0; p0 < nparts; p0 += 16) {  // 16 loads in flight, summed in partial order
-      float t[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) t[e] = (p0 + e < nparts) ? a.ws[ws_dwd(0) + (size_t)(p0 + e) * nel + el] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) g += t[e];
+// Word-table backward + parameter update.
+// Blocks [0, G), G = ceil(n_words / 8): workgroup g owns the 8 words g, g + G, g + 2G, ... (frequent
+// words have neighbouring ids: striding spreads them over workgroups).  Row w of cnt_t holds, per
+// batch slot, how often word w occurs in that slot's item.  Wave v scans slots [64v, 64v+64) of
+// all 8 rows (8 coalesced byte loads in flight), lists the non-zero cells by ballot + prefix
+// count, loads the listed dh rows 16 at a time (every lane owns two columns: no cross-lane
+// reduction) and accumulates count * dh[slot] per word in its LDS stripe; after a barrier wave j
+// adds the 8 stripes of word j in wave order and writes W[w] -= lr/L * scale[w] * sum.  Fixed
+// summation order, no float atomics, any number of occurrences.  Consumed cells are cleared:
+// cnt_t is all-zero again afterwards.
+// Remaining blocks: Wd, bd, gamma, beta -= lr * gradient (K-parts / partials summed in order).
+constexpr int kWordsPerWG = 8;
+constexpr int kListCap = 256;
+__global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, float lr_over_L) {
+  __shared__ int sList[8 * kListCap];
+  __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
+  __shared__ int sHit[kWordsPerWG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = (a.n_words + kWordsPerWG - 1) / kWordsPerWG;
+  if ((int)blockIdx.x >= G) {
+    const int el = ((int)blockIdx.x - G) * 512 + tid, nel = a.wd * a.d;
+    if (el < nel) {
+      float g = 0.f;
+      for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
+      a.Wd[el] -= a.lr * g;
     }
-    a.Wd[el] -= a.lr * g;
+    if ((int)blockIdx.x == G && tid < a.d) {
+      float gb = 0.f;
+      for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
+      const float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
+      a.bd[tid] -= a.lr * gb;
+      a.beta[tid] -= a.lr * t1;
+      a.gamma[tid] -= a.lr * t2;
+    }
+    return;
   }
-  if (blockIdx.x == 0 && threadIdx.x < a.d) {
-    const int c = threadIdx.x;
-    float gb = 0.f, t1 = 0.f, t2 = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-      gb += a.ws[ws_dbd(0) + (size_t)p * 128 + c];
-      t1 += a.ws[ws_bsum(0) + (size_t)p * 2 * 128 + c];
-      t2 += a.ws[ws_bsum(0) + (size_t)p * 2 * 128 + 128 + c];
+  const int n = valid_rows(a), d2 = a.wd >> 1;
+  const int my_w = blockIdx.x + wave * G;  // the word this wave finishes
+  float2 wold = make_float2(0.f, 0.f);
+  if (my_w < a.n_words && lane < d2) wold = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
+  if (tid < kWordsPerWG) sHit[tid] = 0;
+  float2* accw = sAccW + wave * kWordsPerWG * 64;
+#pragma unroll
+  for (int j = 0; j < kWordsPerWG; ++j) accw[j * 64 + lane] = make_float2(0.f, 0.f);
+  int* list = sList + wave * kListCap;
+  const float2* dh2 = reinterpret_cast<const float2*>(a.dh);
+  __syncthreads();
+  for (int base = 0; base < n; base += 512) {
+    const int slot = base + 64 * wave + lane;
+    unsigned c[kWordsPerWG];
+#pragma unroll
+    for (int j = 0; j < kWordsPerWG; ++j) {
+      const int w = blockIdx.x + j * G;
+      c[j] = (w < a.n_words && slot < n) ? a.cnt_t[(int64_t)w * a.cap + slot] : 0u;
     }
-    a.bd[c] -= a.lr * gb;
-    a.beta[c] -= a.lr * t1;
-    a.gamma[c] -= a.lr * t2;
+    // list the non-zero cells word by word (ballot + prefix count); the list holds kListCap
+    // entries: it is drained whenever the next word might not fit (rare: > 256 hits per 64 slots)
+    int cnt = 0;
+    auto drain = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int e0 = 0; e0 < cnt; e0 += 16) {  // 16 rows of dh in flight
+        int ent[16];
+        float2 r[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          r[u] = (ent[u] && lane < d2) ? dh2[(int64_t)((ent[u] >> 8) & 0xFFFF) * d2 + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (ent[u]) {  // uniform across the wave
+            const float cf = (float)(ent[u] & 255);
+            float2* p = accw + (ent[u] >> 24) * 64 + lane;
+            float2 t = *p;
+            t.x = fmaf(cf, r[u].x, t.x);
+            t.y = fmaf(cf, r[u].y, t.y);
+            *p = t;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      cnt = 0;
+    };
+#pragma unroll
+    for (int j = 0; j < kWordsPerWG; ++j) {
+      const unsigned long long mask = __ballot(c[j] != 0);
+      const int pc = __popcll(mask);
+      if (cnt + pc > kListCap) drain();
+      if (c[j]) {
+        a.cnt_t[(int64_t)(blockIdx.x + j * G) * a.cap + slot] = 0;
+        list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (slot << 8) | (int)c[j];
+      }
+      if (mask && lane == 0) sHit[j] = 1;
+      cnt += pc;
+    }
+    drain();
+  }
+  __syncthreads();
+  if (my_w < a.n_words && sHit[wave] && lane < d2) {
+    float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane];
+      sum.x += t.x;
+      sum.y += t.y;
+    }
+    const float sc = lr_over_L * word_scale(a, my_w);
+    wold.x = fmaf(-sc, sum.x, wold.x);
+    wold.y = fmaf(-sc, sum.y, wold.y);
+    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
   }
 }
 
-static int check_tower(const TowerArgs& a) {
-  NNCF_REQUIRE(a.wd > 0 && a.wd % 4 == 0 && a.wd <= 128 && a.d > 0 && a.d % 4 == 0 && a.d <= 128, "bad tower dims");
-  NNCF_REQUIRE(a.m > 0, "no rows");
-  NNCF_REQUIRE(a.h && a.z && a.Wd && a.bd && a.gamma && a.beta && a.rm && a.rv && a.ws && a.n_valid, "NULL argument");
-  return NNCF_OK;
+__global__ void tower_scale_kernel(TowerArgs a, float* __restrict__ out) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < a.n_words) out[w] = word_scale(a, w);
 }
 
 }  // namespace nncf
 
 using namespace nncf;
 
-extern "C" int64_t nncf_tower_ws_floats(int32_t word_dim, int32_t item_dim) { return (int64_t)ws_total(word_dim, item_dim); }
+// ---- the tower object --------------------------------------------------------------------------
 
-extern "C" int nncf_tower_fwd(const float* d_h, int32_t m, const int32_t* d_n_valid, int32_t word_dim, int32_t item_dim,
-                              float* d_Wd, float* d_bd, float* d_gamma, float* d_beta, float* d_rm, float* d_rv,
-                              float eps, float momentum, int32_t train, float* d_z, float* d_E, float* d_ws,
-                              void* stream) {
+struct nncf_tower {
+  nncf_tower_cfg cfg;
+  nncf_tower_params prm;
+  int device = 0;
+  int ks = 1;
+  void* arena = nullptr;
+  float *h = nullptr, *z = nullptr, *dh = nullptr, *ws = nullptr;
+  uint8_t* cnt_t = nullptr;
+  int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
+  bool fwd_cached = false;
+  TowerArgs last{};
+  float drop_rate = 0.f;
+  uint64_t drop_seed = 0, drop_step = 0;  // train-mode forwards since nncf_tower_set_dropout
+};
+
+namespace {
+
+void carve_tower(nncf_tower* t, Carver& c) {
+  const int64_t cap = t->cfg.max_rows, wd = t->cfg.word_dim, d = t->cfg.item_dim;
+  t->h = c.take<float>(cap * wd);
+  t->z = c.take<float>(cap * d);
+  t->dh = c.take<float>(cap * wd);
+  t->ws = c.take<float>(ws_total((int)wd, (int)d, t->ks));
+  t->cnt_t = c.take<uint8_t>((int64_t)t->cfg.word_count * cap);
+  t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
+  t->n_u = c.take<int32_t>(kPlanChunk);
+}
+
+TowerArgs base_args(const nncf_tower* t) {
   TowerArgs a{};
-  a.h = d_h; a.z = d_z; a.E = d_E; a.Wd = d_Wd; a.bd = d_bd; a.gamma = d_gamma; a.beta = d_beta; a.rm = d_rm; a.rv = d_rv;
-  a.ws = d_ws; a.n_valid = d_n_valid; a.m = m; a.wd = word_dim; a.d = item_dim; a.train = train; a.eps = eps;
-  a.momentum = momentum;
-  if (int rc = check_tower(a)) return rc;
-  NNCF_REQUIRE(d_E != nullptr, "NULL output");
-  const int nblk = (m + 15) / 16, grid = nblk < kTowerWG ? nblk : kTowerWG;
-  const size_t lds1 = ((size_t)word_dim * kTP + 16 * kTP + 16 * 3 * kTP) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_fwd1_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 16 + 48) * kTP * 4));
-    attr = true;
+  const nncf_tower_params& p = t->prm;
+  a.W = p.words; a.Wd = p.dense_w; a.bd = p.dense_b; a.gamma = p.bn_gamma; a.beta = p.bn_beta;
+  a.rm = p.bn_mean; a.rv = p.bn_var;
+  a.content = p.content; a.item_ptr = p.item_ptr; a.item_word = p.item_word; a.item_cnt = p.item_cnt;
+  a.h = t->h; a.z = t->z; a.dh = t->dh; a.ws = t->ws; a.cnt_t = t->cnt_t;
+  a.wd = t->cfg.word_dim; a.d = t->cfg.item_dim; a.L = t->cfg.content_len; a.cap = t->cfg.max_rows;
+  a.n_words = t->cfg.word_count;
+  a.eps = t->cfg.bn_eps; a.momentum = t->cfg.bn_momentum; a.lr = t->cfg.learn_rate;
+  a.keep = 1.f;
+  return a;
+}
+
+inline unsigned long long step_seed(const nncf_tower* t, uint64_t step) {
+  return splitmix64(t->drop_seed * 0x9E3779B97F4A7C15ull + step + 1);
+}
+
+inline int stat_grid(int m) { return (m + 1023) / 1024; }  // workgroups of the column-sum kernels (<= 8)
+
+// forward of a block: rows of ids -> E.  train: batch statistics, h / z kept, optional fill.
+int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_valid, int train, int fill,
+                  const float* scale, float* E, hipStream_t st) {
+  TowerArgs a = base_args(t);
+  a.ids = ids; a.m = m; a.n_valid = n_valid; a.train = train; a.fill = fill; a.scale = scale; a.E = E;
+  if (train && t->drop_rate > 0.f) {
+    a.keep = 1.f - t->drop_rate;
+    a.drop_seed = step_seed(t, t->drop_step++);
   }
-  hipStream_t st = as_stream(stream);
   {
-    ProfScope _ps("tower_fwd1_kernel", st);
-    hipLaunchKernelGGL(tower_fwd1_kernel, dim3(grid), dim3(256), lds1, st, a);
+    ProfScope _ps("tower_pool_kernel", st);
+    hipLaunchKernelGGL(tower_pool_kernel, dim3((unsigned)m), dim3(256), 0, st, a);
   }
-  {
-    ProfScope _ps("tower_fwd2_kernel", st);
-    hipLaunchKernelGGL(tower_fwd2_kernel, dim3(grid), dim3(256), 0, st, a);
+  if (train) {
+    {
+      ProfScope _ps("tower_stats_kernel", st);
+      hipLaunchKernelGGL(tower_stats_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
+    }
+    if (E) {
+      ProfScope _ps("tower_bn_kernel", st);
+      hipLaunchKernelGGL(tower_bn_kernel, dim3((m + 15) / 16), dim3(256), 0, st, a);
+    }
+    t->last = a;
+    t->fwd_cached = true;
   }
-  if (train) hipLaunchKernelGGL(tower_running_kernel, dim3(1), dim3(128), 0, st, a);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
 
-extern "C" int nncf_tower_bwd(const float* d_h, const float* d_z, const float* d_dA, int32_t m, const int32_t* d_n_valid,
-                              int32_t word_dim, int32_t item_dim, float* d_Wd, float* d_bd, float* d_gamma,
-                              float* d_beta, float lr, float* d_dh, float* d_ws, void* stream) {
-  TowerArgs a{};
-  a.h = d_h; a.z = const_cast<float*>(d_z); a.dA = d_dA; a.dh = d_dh; a.Wd = d_Wd; a.bd = d_bd; a.gamma = d_gamma;
-  a.beta = d_beta; a.rm = d_bd; a.rv = d_bd; a.ws = d_ws; a.n_valid = d_n_valid; a.m = m; a.wd = word_dim;
-  a.d = item_dim; a.train = 1; a.lr = lr;
-  if (int rc = check_tower(a)) return rc;
-  NNCF_REQUIRE(d_dA && d_dh, "NULL argument");
-  const int nblk = (m + 15) / 16, grid = nblk < kTowerWG ? nblk : kTowerWG;
-  const size_t lds2 = ((size_t)word_dim * kTP + 32 * kTP) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_bwd2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (128 + 32) * kTP * 4));
-    attr = true;
-  }
-  hipStream_t st = as_stream(stream);
+// backward of the block of the last train-mode forward (which must have run with fill = 1)
+int tower_backward(nncf_tower* t, const float* dA, hipStream_t st) {
+  TowerArgs a = t->last;
+  a.dA = dA;
+  const int m = a.m;
+  const int ks = (m + kRowsPerK - 1) / kRowsPerK;
+  const int nA = (m + 15) / 16;
+  const int ntile = ((a.wd + 15) / 16) * ((a.d + 15) / 16);
   {
-    ProfScope _ps("tower_bwd1_kernel", st);
-    hipLaunchKernelGGL(tower_bwd1_kernel, dim3(grid), dim3(256), 0, st, a);
+    ProfScope _ps("tower_sums_kernel", st);
+    hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
   }
   {
-    ProfScope _ps("tower_bwd2_kernel", st);
-    hipLaunchKernelGGL(tower_bwd2_kernel, dim3(grid), dim3(256), lds2, st, a);
+    ProfScope _ps("tower_bwd_kernel", st);
+    hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks);
   }
   {
-    ProfScope _ps("tower_update_kernel", st);
-    hipLaunchKernelGGL(tower_update_kernel, dim3((word_dim * item_dim + 255) / 256), dim3(256), 0, st, a, grid);
+    ProfScope _ps("tower_word_kernel", st);
+    const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.wd * a.d + 511) / 512;
+    hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
+
+int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
+  if (!t || !m) return fail(NNCF_ERR_INVALID, "tower / model is NULL");
+  NNCF_REQUIRE(scheme >= 0 && scheme <= 2, "scheme must be 0 (original), 1 (neg_shared) or 2 (group_neg_shared)");
+  NNCF_REQUIRE(m->cfg.dim == t->cfg.item_dim && m->cfg.row_stride == m->cfg.dim, "model dim / stride != tower item_dim");
+  NNCF_REQUIRE(m->export_gV != nullptr, "the model must export item gradients (nncf_model_set_item_grad_export)");
+  const int64_t n = scheme == 0 ? (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives) : m->cfg.batch_size_p;
+  NNCF_REQUIRE(n <= t->cfg.max_rows && n <= m->cfg.item_count, "batch of %lld item slots exceeds max_rows / item block",
+               (long long)n);
+  if (scheme == 0) NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
+  else NNCF_REQUIRE(m->cfg.batch_size_p % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
+  return NNCF_OK;
+}
+
+// one planned step: plans pu / pv (localized), the block's global ids and count on device
+int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid, const PlanView& pu,
+                    const PlanView& pv, const int32_t* uniq_g, const int32_t* n_u, int n, float* loss, int update,
+                    const float* scale, hipStream_t st) {
+  // the normalised block is never written: the step kernels apply BatchNorm + ReLU when they
+  // load an item row from z
+  int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st);
+  if (rc) return rc;
+  const int b = m->cfg.batch_size_p;
+  const int32_t* cid_local = pv.inverse;  // batch position -> row of the item block
+  StepArgs sa = make_args(m);
+  sa.bn_z = t->z;
+  sa.bn_ma = t->ws + ws_muinv() + 384;
+  if (scheme == 0)
+    rc = launch_original(sa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
+  else
+    rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
+  if (rc || !update) return rc;
+  return tower_backward(t, m->export_gV, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, int device, nncf_tower** out) {
+  NNCF_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  NNCF_REQUIRE(cfg && prm, "NULL argument");
+  NNCF_REQUIRE(cfg->word_dim > 0 && cfg->word_dim % 4 == 0 && cfg->word_dim <= 128, "word_dim = %d must be a multiple of 4 and <= 128", cfg->word_dim);
+  NNCF_REQUIRE(cfg->item_dim > 0 && cfg->item_dim % 4 == 0 && cfg->item_dim <= 128, "item_dim = %d must be a multiple of 4 and <= 128", cfg->item_dim);
+  NNCF_REQUIRE(cfg->word_count > 0 && cfg->item_count > 0 && cfg->content_len > 0, "empty vocabulary / catalogue / content");
+  NNCF_REQUIRE(cfg->content_len <= 256, "content_len = %d above 256 is not built (token counts are bytes)", cfg->content_len);
+  NNCF_REQUIRE(cfg->max_rows > 0 && cfg->max_rows % 8 == 0 && cfg->max_rows <= 8192, "max_rows = %d must be a multiple of 8, <= 8192", cfg->max_rows);
+  NNCF_REQUIRE(prm->words && prm->dense_w && prm->dense_b && prm->bn_gamma && prm->bn_beta && prm->bn_mean && prm->bn_var &&
+                   prm->content && prm->item_ptr && prm->item_word && prm->item_cnt, "NULL parameter pointer");
+  NNCF_REQUIRE((((uintptr_t)prm->words | (uintptr_t)prm->dense_w | (uintptr_t)prm->dense_b | (uintptr_t)prm->bn_gamma |
+                 (uintptr_t)prm->bn_beta | (uintptr_t)prm->bn_mean | (uintptr_t)prm->bn_var) & 15) == 0,
+               "parameter arrays must be 16-byte aligned");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NNCF_ERR_HIP, "no HIP device: the tower kernels have no CPU fallback");
+  NNCF_REQUIRE(device >= 0 && device < ndev, "device %d out of range", device);
+  nncf_tower* t = new (std::nothrow) nncf_tower();
+  if (!t) return fail(NNCF_ERR_NOMEM, "out of host memory");
+  t->cfg = *cfg;
+  t->prm = *prm;
+  t->device = device;
+  t->ks = (cfg->max_rows + kRowsPerK - 1) / kRowsPerK;
+  Carver dry;
+  carve_tower(t, dry);
+  int prev = 0;
+  hipGetDevice(&prev);
+  hipSetDevice(device);
+  if (hipMalloc(&t->arena, dry.off + 256) != hipSuccess) {
+    delete t;
+    hipSetDevice(prev);
+    return fail(NNCF_ERR_NOMEM, "device workspace allocation (%zu bytes) failed", dry.off);
+  }
+  hipMemset(t->arena, 0, dry.off + 256);
+  hipSetDevice(prev);
+  Carver real;
+  real.base = static_cast<char*>(t->arena);
+  carve_tower(t, real);
+  *out = t;
+  return NNCF_OK;
+}
+
+int nncf_tower_destroy(nncf_tower* t) {
+  if (!t) return NNCF_OK;
+  if (t->arena) hipFree(t->arena);
+  delete t;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  t->cfg.learn_rate = learn_rate;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(rate >= 0.f && rate < 1.f, "dropout rate %g out of [0, 1)", (double)rate);
+  t->drop_rate = rate;
+  t->drop_seed = seed;
+  t->drop_step = 0;
+  return NNCF_OK;
+}
+
+int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, void* stream) {
+  NNCF_REQUIRE(t && d_out, "NULL argument");
+  TowerArgs a = base_args(t);
+  if (t->drop_rate > 0.f) {
+    a.keep = 1.f - t->drop_rate;
+    a.drop_seed = step_seed(t, step_index);
+  }
+  hipLaunchKernelGGL(tower_scale_kernel, dim3((a.n_words + 255) / 256), dim3(256), 0, as_stream(stream), a, d_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, const int32_t* d_n_valid, int train,
+                       int prepare_backward, const float* d_row_scale, float* d_out, void* stream) {
+  NNCF_REQUIRE(t && d_item_ids && d_out, "NULL argument");
+  NNCF_REQUIRE(m >= 0, "negative row count");
+  if (m == 0) return NNCF_OK;
+  NNCF_REQUIRE(!train || m <= t->cfg.max_rows, "train-mode block of %lld rows exceeds max_rows = %d", (long long)m, t->cfg.max_rows);
+  hipStream_t st = as_stream(stream);
+  if (train) return tower_forward(t, d_item_ids, (int)m, d_n_valid, 1, prepare_backward != 0, d_row_scale, d_out, st);
+  for (int64_t i0 = 0; i0 < m; i0 += 1 << 20) {  // inference rows are independent: any m
+    const int64_t cnt = m - i0 < (1 << 20) ? m - i0 : (1 << 20);
+    if (int rc = tower_forward(t, d_item_ids + i0, (int)cnt, nullptr, 0, 0, nullptr, d_out + i0 * t->cfg.item_dim, st)) return rc;
+  }
+  return NNCF_OK;
+}
+
+int nncf_tower_backward(nncf_tower* t, const float* d_dA, void* stream) {
+  NNCF_REQUIRE(t && d_dA, "NULL argument");
+  NNCF_REQUIRE(t->fwd_cached && t->last.fill, "nncf_tower_backward must follow a train-mode nncf_tower_forward");
+  NNCF_REQUIRE(((uintptr_t)d_dA & 15) == 0, "d_dA must be 16-byte aligned");
+  t->fwd_cached = false;
+  TowerArgs& a = t->last;
+  a.lr = t->cfg.learn_rate;
+  return tower_backward(t, d_dA, as_stream(stream));
+}
+
+int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                    float* d_loss, int update, const float* d_row_scale, void* stream) {
+  if (int rc = check_pair(t, m, scheme)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
+  const int b = m->cfg.batch_size_p, n = scheme == 0 ? b * (1 + m->cfg.num_negatives) : b;
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, n, m->plan_v, st);
+  if (rc) return rc;
+  rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st);
+  if (rc) return rc;
+  rc = tower_step_body(t, m, scheme, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st);
+  t->fwd_cached = false;
+  return rc;
+}
+
+int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,
+                     const int32_t* d_neg_all, int64_t n_steps, float* d_loss, int32_t* d_n_u, void* stream) {
+  if (int rc = check_pair(t, m, scheme)) return rc;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss, "NULL argument");
+  NNCF_REQUIRE(scheme != 0 || d_neg_all, "train_scheme=original needs the presampled negatives");
+  NNCF_REQUIRE(n_steps >= 0, "negative step count");
+  const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
+  const int n = (int)(scheme == 0 ? b * (1 + k) : b);
+  const int64_t cap = t->cfg.max_rows;
+  hipStream_t st = as_stream(stream);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc = launch_plan(d_uid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_u, cnt, st);
+    if (rc) return rc;
+    if (scheme == 0)
+      rc = launch_plan(d_cid_all + t0 * b, b, (int)b, d_neg_all + t0 * b * k, b * k, (int)(b * k), m->plan_v, cnt, st);
+    else
+      rc = launch_plan(d_cid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_v, cnt, st);
+    if (rc) return rc;
+    rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, cnt, cap);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t s = t0 + i;
+      rc = tower_step_body(t, m, scheme, d_uid_all + s * b, m->plan_u.at(i), m->plan_v.at(i), t->uniq_g + i * cap,
+                           t->n_u + i, n, d_loss + s, 1, nullptr, st);
+      if (rc) return rc;
+    }
+    if (d_n_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_n_u + t0, t->n_u, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, st));
+  }
+  t->fwd_cached = false;
+  return NNCF_OK;
+}
+
+}  // extern "C"

@@ -3,10 +3,9 @@
 (divides by L always, :27-33) -> Dense(item_dim) -> BatchNormalization over the batch's unique
 items -> ReLU -> Dropout(0) -- with explicit forward / backward / SGD update (no autograd).
 
-Split of work: the memory-bound halves (gather + mean of n_u*L word rows forward, sparse
-word-table update backward) are HIP kernels (csrc/meanpool.hip); Dense / BatchNorm / ReLU on the
-pooled (n_u x word_dim) block are five small fused HIP launches (csrc/tower.hip).  torch only
-holds the buffers and does the integer content gather.
+Everything runs in csrc/tower.hip behind the nncf_tower_* C ABI (gather-mean + Dense in one
+kernel, BatchNorm/ReLU, MFMA backward, per-word sparse SGD); torch only holds the parameter
+buffers.
 [K-mem] Keras-1 defaults: Embedding init uniform(+-0.05), Dense init glorot_uniform with zero
 bias, BatchNormalization eps 1e-3, momentum 0.99, biased batch variance, running "std" slot
 holds the variance.
@@ -35,6 +34,9 @@ def build_item_csr(C):
 
 
 class MeanPoolTower(object):
+    """Parameters live in torch tensors (so tests / checkpoints can read them); the native tower
+    object (nncf_tower_*) borrows their pointers and owns every scratch buffer."""
+
     def __init__(self, C, word_count, word_dim, item_dim, learn_rate, device, seed=0, dropout_rate=0.0,
                  eps=1e-3, momentum=0.99, max_rows=512):
         self.device = device
@@ -47,28 +49,39 @@ class MeanPoolTower(object):
         self.lr = float(learn_rate)
         self.eps, self.mom = float(eps), float(momentum)
         self.dropout = float(dropout_rate)
-        self.cap = int(max_rows)
+        self.cap = (int(max_rows) + 7) // 8 * 8
         gen = torch.Generator().manual_seed(int(seed) + 17)
         dev = device
         self.W = ((torch.rand(self.word_count, self.wd, generator=gen) * 2 - 1) * 0.05).to(dev).contiguous()
         lim = float(np.sqrt(6.0 / (self.wd + self.d)))  # glorot_uniform
         self.Wd = ((torch.rand(self.wd, self.d, generator=gen) * 2 - 1) * lim).to(dev).contiguous()
-        self.bd = torch.zeros(self.d, device=dev)
-        self.gamma = torch.ones(self.d, device=dev)
-        self.beta = torch.zeros(self.d, device=dev)
-        self.rm = torch.zeros(self.d, device=dev)
-        self.rv = torch.ones(self.d, device=dev)
+        # one allocation for the five small vectors, each 512-byte aligned
+        vec = torch.zeros(5, 128, device=dev)
+        self.bd, self.gamma, self.beta, self.rm, self.rv = (vec[i, :self.d] for i in range(5))
+        self.gamma.fill_(1.0)
+        self.rv.fill_(1.0)
+        self._vec = vec
         self.C = torch.as_tensor(C.astype(np.int32)).to(dev).contiguous()
         ptr, words, cnt = build_item_csr(C)
         self.item_ptr = torch.as_tensor(ptr).to(dev)
         self.item_word = torch.as_tensor(words).to(dev)
         self.item_cnt = torch.as_tensor(cnt).to(dev)
-        # scratch of the backward transpose: all-zero between calls (the kernels restore it)
-        self.cnt_t = torch.zeros(self.word_count * self.cap, dtype=torch.uint8, device=dev)
-        self.touched = torch.zeros(self.word_count, dtype=torch.uint8, device=dev)
-        self._mask_gen = torch.Generator(device=dev).manual_seed(int(seed) + 29)
-        self._ws = None
         self.version = 0  # bumped by every update (the evaluator caches inference embeddings)
+        cfg = _lib.TowerCfg(self.word_count, self.wd, self.d, self.Lc, self.cap, self.item_count, self.eps, self.mom,
+                            self.lr)
+        prm = _lib.TowerParams(*[t.data_ptr() for t in (self.W, self.Wd, self.bd, self.gamma, self.beta, self.rm,
+                                                        self.rv, self.C, self.item_ptr, self.item_word, self.item_cnt)])
+        h = ctypes.c_void_p()
+        idx = torch.device(dev).index or 0
+        _lib.check(self._L.nncf_tower_create(ctypes.byref(cfg), ctypes.byref(prm), idx, ctypes.byref(h)))
+        self.handle = h
+        if self.dropout > 0:
+            self.set_dropout(self.dropout, int(seed) + 29)
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self._L.nncf_tower_destroy(h)
 
     def _stream(self):
         return _lib.stream_ptr(torch.cuda.current_stream(self.device))
@@ -79,55 +92,38 @@ class MeanPoolTower(object):
                 getattr(self, name).copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
         self.version += 1
 
-    def _pool(self, item_ids, scale):
-        toks = self.C[item_ids.long()].contiguous()                       # (n, L) int32 gather
-        h = torch.empty(toks.shape[0], self.wd, dtype=torch.float32, device=self.device)
+    def set_dropout(self, rate, seed=0):
+        """Embedding(dropout=rate) row dropout (mean_pool.py:56-59), mask generated inside the
+        kernels from (seed, train-forward index, word)."""
+        self.dropout = float(rate)
+        _lib.check(self._L.nncf_tower_set_dropout(self.handle, self.dropout, int(seed)))
+
+    def dropout_scale(self, step_index):
+        """per-word scale of the step_index-th train-mode forward since set_dropout (checkers)."""
+        out = torch.empty(self.word_count, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_dropout_scale(self.handle, int(step_index), ctypes.c_void_p(out.data_ptr()),
+                                                        self._stream()))
+        return out
+
+    def forward(self, item_ids, train=True, n_valid=None, out=None, prepare_backward=True, row_scale=None):
+        """item embeddings (m, item_dim) for int32 device ids.  train=True: batch statistics over
+        the first *n_valid rows (a device int32[1], default all m; rows past it come out zero),
+        running statistics updated, and (prepare_backward) the state backward_update needs.
+        train=False: inference phase (running statistics), any m."""
+        m = item_ids.numel()
+        assert item_ids.dtype == torch.int32 and item_ids.is_contiguous()
+        E = out if out is not None else torch.empty(m, self.d, dtype=torch.float32, device=self.device)
+        scale = row_scale if train else None   # explicit mask (kept alive until the backward ran)
+        self._scale = scale
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
         with torch.cuda.device(self.device):
-            _lib.check(self._L.nncf_meanpool_fwd(p(self.W), self.wd, self.wd, p(toks), toks.shape[0], self.Lc, p(scale),
-                                                 p(h), self._stream()))
-        return h
-
-    def forward(self, item_ids, train=True, n_valid=None, out=None):
-        """item embeddings (m, item_dim) for int32 device ids.  Only the first *n_valid rows
-        (a device int32[1], default all m) are real: the rest are padding that is computed but
-        excluded from the BatchNorm statistics -- shapes stay static, nothing syncs to the host.
-        train=True uses batch statistics and keeps what backward_update needs."""
-        m = item_ids.numel()
-        dev = self.device
-        if n_valid is None:
-            n_valid = torch.full((1,), m, dtype=torch.int32, device=dev)
-        scale = None
-        if train and self.dropout > 0:  # Embedding(dropout=p): whole word rows dropped per batch (:56-59)
-            keep = 1.0 - self.dropout
-            scale = (torch.rand(self.word_count, generator=self._mask_gen, device=dev) < keep).float() / keep
-        ids = item_ids  # padding slots past n_valid must hold in-range ids (nncf_plan_item_block writes 0)
-        h = self._pool(ids, scale)
-        z = torch.empty(m, self.d, dtype=torch.float32, device=dev)
-        E = out if out is not None else torch.empty(m, self.d, dtype=torch.float32, device=dev)
-        if self._ws is None:
-            self._ws = torch.zeros(int(self._L.nncf_tower_ws_floats(self.wd, self.d)), dtype=torch.float32, device=dev)
-        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
-        with torch.cuda.device(dev):
-            _lib.check(self._L.nncf_tower_fwd(p(h), m, p(n_valid), self.wd, self.d, p(self.Wd), p(self.bd),
-                                              p(self.gamma), p(self.beta), p(self.rm), p(self.rv), self.eps, self.mom,
-                                              int(bool(train)), p(z), p(E), p(self._ws), self._stream()))
-        if train:
-            self._cache = (ids, n_valid, h, z, scale)
+            _lib.check(self._L.nncf_tower_forward(self.handle, p(item_ids), m, p(n_valid), int(bool(train)),
+                                                  int(bool(train and prepare_backward)), p(scale), p(E), self._stream()))
         return E
 
     def backward_update(self, dA):
-        ids, n_valid, h, z, scale = self._cache
-        m = ids.numel()
-        assert m <= self.cap and dA.shape[0] == m and dA.is_contiguous()
-        dh = torch.empty(m, self.wd, dtype=torch.float32, device=self.device)
-        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+        assert dA.is_contiguous() and dA.dtype == torch.float32
         with torch.cuda.device(self.device):
-            _lib.check(self._L.nncf_tower_bwd(p(h), p(z), p(dA), m, p(n_valid), self.wd, self.d, p(self.Wd), p(self.bd),
-                                              p(self.gamma), p(self.beta), self.lr, p(dh), p(self._ws), self._stream()))
-            # sparse SGD on the word table (fixed order, no atomics)
-            _lib.check(self._L.nncf_meanpool_bwd(p(self.W), self.wd, self.wd, self.word_count, p(ids), p(n_valid),
-                                                 self.cap, p(self.item_ptr), p(self.item_word), p(self.item_cnt),
-                                                 p(self.cnt_t), p(self.touched), p(dh), p(scale), self.lr, self.Lc,
-                                                 self._stream()))
+            _lib.check(self._L.nncf_tower_backward(self.handle, ctypes.c_void_p(dA.data_ptr()), self._stream()))
         self.version += 1

@@ -12,7 +12,8 @@ All heads share ONE parameter set, as the reference's models share layer objects
 import numpy as np
 import torch
 
-from .engine import Engine
+from . import _lib
+from .engine import Engine, _ptr
 
 
 def _as_ids(x):
@@ -228,20 +229,30 @@ class _TowerCore(object):
         self._eval_version = -1
         self._engine_kw, self._device = engine_kw, device
 
-    def step(self, kind, uid_dev, cid_dev, update=True):
-        """One training step, fully asynchronous (no host sync): the tower runs on a static block
-        of len(cid) rows of which the first n_u (a device scalar) are real."""
-        e = self.engine
-        m = cid_dev.numel()
-        if getattr(self, "_uniq", None) is None or self._uniq.numel() != m:
-            self._uniq = torch.zeros(m, dtype=torch.int32, device=e.device)
-            self._n_u = torch.zeros(1, dtype=torch.int32, device=e.device)
-        e.plan_item_block(kind, uid_dev, cid_dev, self._uniq, self._n_u)        # plans + tf.unique on device
-        self.tower.forward(self._uniq, train=True, n_valid=self._n_u, out=e.V[:m])  # straight into the item block
-        loss = e.step_planned(kind, uid_dev, update=update)
+    _SCHEME = {"original": 0, "neg_shared": 1, "group_neg_shared": 2}
+
+    def step(self, kind, uid_dev, cid_dev, update=True, loss_out=None):
+        """One training step, fully asynchronous (no host sync), one C call: plans + tf.unique,
+        tower forward of the unique items into the engine's item block, step kernels, tower
+        backward (nncf_tower_step)."""
+        e, tw = self.engine, self.tower
+        out = loss_out if loss_out is not None else e._loss1
+        with torch.cuda.device(e.device):
+            _lib.check(e._L.nncf_tower_step(tw.handle, e._h, self._SCHEME[kind], _ptr(uid_dev), _ptr(cid_dev), _ptr(out),
+                                            int(update), None, e._stream()))
         if update:
-            self.tower.backward_update(self.gV[:m])
-        return loss
+            tw.version += 1
+        return out
+
+    def epoch(self, kind, uid_all, cid_all, neg_all, n_steps, losses, n_u_out=None):
+        """The trainer's inner loop in one C call (nncf_tower_epoch): every launch of every step
+        is enqueued from native code, plans are made 64 steps at a time."""
+        e, tw = self.engine, self.tower
+        with torch.cuda.device(e.device):
+            _lib.check(e._L.nncf_tower_epoch(tw.handle, e._h, self._SCHEME[kind], _ptr(uid_all), _ptr(cid_all),
+                                             _ptr(neg_all), int(n_steps), _ptr(losses), _ptr(n_u_out), e._stream()))
+        tw.version += 1
+        return losses
 
     def eval_engine(self):
         """Engine over (shared U, inference-mode embeddings of ALL items), refreshed when the
@@ -255,7 +266,7 @@ class _TowerCore(object):
         if self._eval_version != self.tower.version:
             ids = torch.arange(self.item_count, dtype=torch.int32, device=self.engine.device)
             for i0 in range(0, self.item_count, 4096):
-                self._eval.V[i0:i0 + 4096].copy_(self.tower.forward(ids[i0:i0 + 4096], train=False))
+                self.tower.forward(ids[i0:i0 + 4096], train=False, out=self._eval.V[i0:i0 + 4096])
             self._eval_version = self.tower.version
         return self._eval
 
@@ -279,55 +290,20 @@ class TowerHead(_Head):
         return self._loss(self.core.step(self.kind, e.ids(uid), e.ids(cid), update=self.update))
 
     def run_epoch(self, uid_all, cid_all, n_steps, neg_all=None, n_u_out=None):
-        """The trainer's inner loop.  The step (plan + tower forward + step kernels + tower
-        backward, ~50 launches of static shape) is captured once in a HIP graph and replayed per
-        batch; NNCF_NO_GRAPH=1 (or word-row dropout, which draws a fresh mask per step) runs it
-        eagerly."""
-        import os
+        """The trainer's inner loop: one native call per epoch (loss monitors, which never update,
+        go batch by batch)."""
         e = self.engine
         b, k = e.b, e.k
-        n_c = b * (1 + k) if self.kind == "original" else b
         losses = torch.empty(max(n_steps, 1), dtype=torch.float32, device=e.device)
         if n_steps == 0:
             return losses[:0]
-        if getattr(self, "_bufs", None) is None:
-            self._bufs = (torch.zeros(b, dtype=torch.int32, device=e.device),
-                          torch.zeros(n_c, dtype=torch.int32, device=e.device))
-            self._graph = None
-        ubuf, cbuf = self._bufs
-
-        def load(t):
-            ubuf.copy_(uid_all[t * b:(t + 1) * b])
-            cbuf[:b].copy_(cid_all[t * b:(t + 1) * b])
+        if self.update:
+            return self.core.epoch(self.kind, uid_all, cid_all, neg_all, n_steps, losses, n_u_out)[:n_steps]
+        for t in range(n_steps):
+            cid = cid_all[t * b:(t + 1) * b]
             if self.kind == "original":
-                cbuf[b:].copy_(neg_all[t * b * k:(t + 1) * b * k])
-
-        use_graph = os.environ.get("NNCF_NO_GRAPH") != "1" and self.core.tower.dropout == 0 and n_steps > 3
-        t = 0
-        if use_graph and self._graph is None:
-            load(0)
-            losses[0:1].copy_(self.core.step(self.kind, ubuf, cbuf))   # eager warm-up (lazy inits, allocator)
-            t = 1
-            try:
-                load(1)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._gloss = self.core.step(self.kind, ubuf, cbuf)
-                self._graph = g
-                # capture does not execute: run the captured step for batch 1 now
-                g.replay()
-                losses[1:2].copy_(self._gloss)
-                t = 2
-            except Exception as ex:  # capture unsupported: stay eager
-                print("[WARNING] HIP graph capture failed (%s); running eagerly" % type(ex).__name__)
-                self._graph = False
-        for t in range(t, n_steps):
-            load(t)
-            if use_graph and self._graph:
-                self._graph.replay()
-                losses[t:t + 1].copy_(self._gloss)
-            else:
-                losses[t:t + 1].copy_(self.core.step(self.kind, ubuf, cbuf))
+                cid = torch.cat([cid, neg_all[t * b * k:(t + 1) * b * k]])
+            self.core.step(self.kind, uid_all[t * b:(t + 1) * b], cid, update=self.update, loss_out=losses[t:t + 1])
         return losses[:n_steps]
 
     def predict_on_batch(self, x):

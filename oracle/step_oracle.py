@@ -312,6 +312,7 @@ class StepOracle(object):
         self.V = np.array(V, dtype=self.dt, copy=True) if V is not None else None
         self.conf = conf
         self.tower = tower  # TowerOracle: item rows come from the text tower (model_framework.py:98-106)
+        self.row_scale = None  # per-word scale of Embedding row dropout for the next step (mean_pool.py:56-59)
 
     def _tower_in(self, cid):
         """Content models run on tf.unique(cid) and are re-gathered (model_framework.py:45-48,
@@ -319,7 +320,7 @@ class StepOracle(object):
         if self.tower is None:
             return cid
         cid_u, cid_x = tf_unique(cid)
-        self.V = self.tower.forward(cid_u, train=True)
+        self.V = self.tower.forward(cid_u, train=True, row_scale=self.row_scale)
         self._n_u = len(cid_u)
         return cid_x.astype(np.int64)
 

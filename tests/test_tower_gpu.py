@@ -98,3 +98,92 @@ def test_basic_embedding_trainer_runs_and_learns(text_data):
     E = tw.forward(torch.arange(260, dtype=torch.int32, device=tw.device), train=False)
     assert float((E > 0).float().mean()) > 0.05          # the tower is alive
     assert 0 < tr.history[-1][4]["recall@50"] <= 1     # cold-start items are scored through their text
+
+
+def test_epoch_runner_equals_step_by_step(text_data):
+    """nncf_tower_epoch (plans batched 64 steps at a time) == nncf_tower_step per batch, bitwise."""
+    for scheme, loss in (("neg_shared", "skip-gram"), ("original", "log-loss"), ("group_neg_shared", "log-loss")):
+        conf = _conf(loss, scheme)
+        b, k = conf.batch_size_p, conf.num_negatives
+        mds = [get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2) for _ in range(2)]
+        key = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]
+        rs = np.random.RandomState(11)
+        steps = 70                                           # crosses a 64-step plan chunk
+        train = text_data["train"]
+        bt = train[rs.choice(len(train), steps * b, replace=True)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        negs = rs.randint(0, 260, steps * b * max(k, 1)).astype(np.int32)
+        h0, h1 = mds[0][key], mds[1][key]
+        e = h0.engine
+        uid_all, cid_all, neg_all = e.ids(bt[:, 0]), e.ids(bt[:, 1]), e.ids(negs)
+        got = h0.run_epoch(uid_all, cid_all, steps, neg_all=neg_all if scheme == "original" else None).cpu().numpy()
+        want = np.zeros(steps, dtype=np.float32)
+        for t in range(steps):
+            u, c = bt[t * b:(t + 1) * b, 0], bt[t * b:(t + 1) * b, 1]
+            if scheme == "original":
+                c = np.concatenate([c, negs[t * b * k:(t + 1) * b * k]])
+                u = np.concatenate([u, np.repeat(u, k)])
+            want[t] = h1.train_on_batch([u, c], None)
+        np.testing.assert_array_equal(got, want)
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+            np.testing.assert_array_equal(getattr(h0.core.tower, name).cpu().numpy(),
+                                          getattr(h1.core.tower, name).cpu().numpy(), err_msg=name)
+        np.testing.assert_array_equal(h0.engine.U.cpu().numpy(), h1.engine.U.cpu().numpy())
+
+
+def test_large_block_original_matches_oracle():
+    """More than 1024 unique items in one batch: several K-parts of the weight-gradient tiles,
+    more than 64 statistics blocks."""
+    data = synthetic.make_citeulike_like(users=400, items=3000, train_links=9000, seed=4, content_len=20, vocab=150)
+    conf = _conf("skip-gram", "original", b=512, k=3, d=32, lr=0.1)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, data)
+    head = md["model"]
+    rs = np.random.RandomState(3)
+    for step in range(2):
+        bt = data["train"][rs.choice(len(data["train"]), 512, replace=False)]
+        negs = rs.randint(0, 3000, 512 * 3)
+        u, c, y = so.assemble_original(bt, negs, "skip-gram")
+        assert len(np.unique(c)) > 1024
+        want = orc.step_original(u, c, y)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        tw = head.core.tower
+        np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5,
+                                       err_msg="%s step %d" % (name, step))
+
+
+def test_row_dropout_matches_oracle_with_same_mask(text_data):
+    """Embedding(dropout=p) row dropout: the kernels' hash mask, materialised through
+    nncf_tower_dropout_scale, fed to the oracle -> same losses and parameters; masks differ per
+    step and keep about (1-p) of the words."""
+    conf = _conf("skip-gram", "neg_shared", lr=0.1)
+    conf.word_emb_dropout_rate = 0.4
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2)
+    head = md["model_neg_shared"]
+    tw = head.core.tower
+    assert tw.dropout == pytest.approx(0.4)
+    orc, to = _oracle(conf, md, text_data)
+    e = head.engine
+    steps, b = 4, conf.batch_size_p
+    bt = text_data["train"][np.random.RandomState(5).choice(len(text_data["train"]), steps * b, replace=False)]
+    masks = [tw.dropout_scale(t).cpu().numpy() for t in range(steps)]
+    assert not np.array_equal(masks[0], masks[1])
+    for mk in masks:
+        assert set(np.unique(mk)) <= {0.0, np.float32(1 / 0.6)}
+    assert 0.45 < np.mean(np.concatenate(masks) > 0) < 0.75
+    got = head.run_epoch(e.ids(bt[:, 0]), e.ids(bt[:, 1]), steps).cpu().numpy()
+    for t in range(steps):
+        orc.row_scale = masks[t]
+        want = orc.step_neg_shared(bt[t * b:(t + 1) * b, 0], bt[t * b:(t + 1) * b, 1])
+        assert abs(got[t] - want) <= 2e-5 * max(1, abs(want)), (t, got[t], want)
+    for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+        np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5, err_msg=name)
+    # inference ignores the mask
+    items = torch.arange(0, 260, 5, dtype=torch.int32, device=tw.device)
+    np.testing.assert_allclose(tw.forward(items, train=False).cpu().numpy(), to.forward(items.cpu().numpy(), train=False),
+                               rtol=2e-4, atol=2e-5)
