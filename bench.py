@@ -3,17 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of b = 512 positive links of the
-synthetic CiteULike-a-shaped data set (16K users x 17K items x 200K links, d = 100):
-gather -> U.V^T shared-negative tile -> loss gradient -> back-GEMMs -> sparse SGD scatter
-update, with all inputs (link list, tables) resident in HBM before the timed region and no
-host synchronisation between steps (the trainer loop models/train_neg_shared.py:46-59 runs
-inside nncf_epoch_neg_shared).  Prints ONE JSON line (rank 0).
+A "step" is one pass of the hot path over one batch of b = 512 positive links of the synthetic
+CiteULike-a-shaped data set (16K users x 17K items x 200K links, item text L = 200, d = 100) of
+BASELINE configs[1]: basic_embedding, train_scheme = neg_shared, as the demo scripts run it
+(--conf_choice best: word-row dropout 0.5) --
+    duplicate plan + tf.unique -> text tower forward of the batch's unique items (word-row gather +
+    mean, Dense, BatchNorm statistics; BN + ReLU applied when the step kernels load an item row)
+    -> U.V^T shared-negative tile -> loss gradient -> back-GEMMs -> sparse SGD on the user rows
+    -> tower backward (BN / Dense by MFMA, sparse SGD on the word table)
+with all inputs (link list, content matrix, parameters) resident in HBM before the timed region
+and no host synchronisation between steps: the trainer loop (models/train_neg_shared.py:46-59)
+runs inside one native call (nncf_tower_epoch / nncf_epoch_*).  --model mf runs the id-table
+towers alone; --gpus N > 1 runs the item-sharded id-table path.  Prints ONE JSON line (rank 0).
 
 The line also carries
-  roofline     -- the dominant kernel (the U.V^T tile kernel): algorithmic flops per launch
-                  (6*b*b*d) / its mean duration measured with HIP events on
-                  the launch stream in a second pass over the same steps;
+  roofline     -- the dominant kernel of the step by time: algorithmic bytes / flops per launch
+                  (stated in `algorithmic_what`) / its mean duration measured with
+                  HIP events on the launch stream in a second pass over the same steps
+                  (roofline_other_kernels: the same for the other heavy kernels);
   cpu_baseline -- the numpy oracle of the same step (oracle/step_oracle.py, kind "port")
                   timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -47,6 +54,9 @@ def parse():
     ap.add_argument("--chop", type=int, default=5)
     ap.add_argument("--content-len", type=int, default=200)
     ap.add_argument("--vocab", type=int, default=8001)
+    ap.add_argument("--dropout", type=float, default=0.5,
+                    help="word-row dropout of the text tower in training; 0.5 = the 'best' preset every demo script "
+                         "runs with (basic_embedding_conf.py:112, scripts/demos/run_*.sh --conf_choice best)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-launches", type=int, default=1000)
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
@@ -64,7 +74,7 @@ def param_dict_for(args):
             "neg_loss_weight": 8 if loss == "mse" else 128, "loss_gamma": 0.1 if loss == "max-margin" else 10,
             "learn_rate": 0.001 if loss == "mse" else 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
             "batch_size_p": args.batch, "user_dim": args.dim, "item_dim": args.dim, "word_dim": args.dim,
-            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": 0., "interaction_bias": None}
+            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None}
 
 
 def conf_for(args):
@@ -143,7 +153,11 @@ def cpu_baseline(args, conf, inp, U0, V0, tower_params):
     t0 = time.time()
     steps = 0
     max_steps = min(args.steps, len(inp["uid"]) // b)
+    drop = args.dropout if tower is not None else 0.0
+    mask_rs = np.random.RandomState(29)
     while steps < max_steps and (time.time() - t0 < args.cpu_seconds or steps < 5):
+        if drop > 0:   # Embedding(dropout): a fresh row mask per batch (mean_pool.py:56-59)
+            o.row_scale = ((mask_rs.rand(tower.W.shape[0]) < 1 - drop) / (1 - drop)).astype(np.float32)
         u = inp["uid"][steps * b:(steps + 1) * b]
         c = inp["cid"][steps * b:(steps + 1) * b]
         if args.scheme == "original":
@@ -347,11 +361,13 @@ def main():
 
     # ---- roofline leg: same steps again, dominant kernel bracketed by HIP events ----------
     L = args.content_len if not args.small else min(args.content_len, 40)
+    keep = 1.0 - (args.dropout if args.model == "basic_embedding" else 0.0)
     kernels = {
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
-        "tower_pool_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B per unique item (n_u <= b rows)"),
-        "tower_word_kernel": ("hbm", 4.0 * b * L * d, "4*L*word_dim B of gradient rows per unique item (n_u <= b)"),
+        "tower_pool_kernel": ("hbm", 4.0 * b * L * d * keep, "4*L*word_dim*(1-dropout) B per unique item (n_u <= b rows)"),
+        "tower_word_kernel": ("hbm", 4.0 * b * L * d * keep,
+                              "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)"),
         "tower_bwd_kernel": ("mfma", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
     }
     default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
@@ -366,6 +382,8 @@ def main():
         nengine.profile_begin(name, prof_n)
         run(W, prof_n)
         raw_ms, launches, ov_ms = nengine.profile_end()
+        if launches == 0:
+            continue
         kern_ms = max(raw_ms - ov_ms, 1e-9)   # bracket minus the empty-bracket (marker packet) cost
         bound, work, what = kernels.get(name, ("hbm", 0.0, "n/a"))
         if bound == "hbm":
@@ -385,7 +403,8 @@ def main():
 
     if rank == 0:
         value = K * b * world / elapsed
-        tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, Dense+BN+ReLU)" % (L, args.vocab)
+        tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
+                     % (L, args.vocab, args.dropout)
                      if args.model == "basic_embedding" else "id-table towers (model_choice=mf)")
         line = {
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",

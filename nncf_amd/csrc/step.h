@@ -17,10 +17,14 @@ struct StepArgs {
   float gamma, lambda, u_reg, lr;
   float* gV;  // if non-NULL the item rows are NOT updated: dL/dV rows are written to gV[row id][d]
               // (sharded mode: V is a buffer of fetched rows, gradients go back to their owners)
-  // text tower: item row = relu(bn_z[row] * bn_ma[c] + bn_ma[128 + c]) -- BatchNorm + ReLU applied
-  // on load from the pre-activation block, the normalised block is never materialised.  NULL = V.
+  // text tower: item row = relu(bn_z[row] * mul[c] + add[c]) -- BatchNorm + ReLU applied on load
+  // from the pre-activation block, the normalised block is never materialised.  NULL = V.
+  // bn_stats: five 128-float vectors mu, inv, var, mul, add.
   const float* bn_z = nullptr;
-  const float* bn_ma = nullptr;
+  const float* bn_stats = nullptr;
+  // if non-NULL the apply kernel of the shared schemes also emits, per item chunk, the column sums
+  // of dy = dL/dE * [E > 0] and dy * xhat (the BatchNorm backward's reductions): [chunk][2][128]
+  float* bn_part = nullptr;
 };
 
 }  // namespace nncf
@@ -29,7 +33,7 @@ struct StepArgs {
 namespace nncf {
 // row `id` of the step's item table (plain table, or BatchNorm + ReLU of the tower's block)
 __device__ __forceinline__ Row item_row(const StepArgs& a, int64_t id, int d4, int q) {
-  return a.bn_z ? row_load_bn(a.bn_z, a.bn_ma, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
+  return a.bn_z ? row_load_bn(a.bn_z, a.bn_stats + 384, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
 }
 }  // namespace nncf
 #endif

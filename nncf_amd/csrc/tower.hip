@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
 
 // dz = gamma inv / n (n dy - sum dy - xhat sum dy xhat) and the two products that need it.
 // Blocks [0, nA): role A, 16 rows each; blocks [nA, ...): role B, tile (it, jt) x K-part.
-__global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int ks) {
+__global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int ks, int nfused) {
   __shared__ float sMu[128], sInv[128], sG[128], sMul[128], sAdd[128], sA[128], sBq[128];
   __shared__ __attribute__((aligned(16))) float sZ[16 * kZP];
   __shared__ f32x4 sAcc[4 * 64];
@@ -438,8 +438,12 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
       mul = mi[384 + tid];
       add = mi[512 + tid];
       g = a.gamma[tid];
-      t1 = a.ws[ws_bfin() + tid];
-      t2 = a.ws[ws_bfin() + 128 + tid];
+      if (nfused) {  // partials of the step's apply kernel, one per item chunk, in chunk order
+        merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
+      } else {
+        t1 = a.ws[ws_bfin() + tid];
+        t2 = a.ws[ws_bfin() + 128 + tid];
+      }
     }
     sMu[tid] = mu;
     sInv[tid] = inv;
@@ -567,7 +571,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 // Remaining blocks: Wd, bd, gamma, beta -= lr * gradient (K-parts / partials summed in order).
 constexpr int kWordsPerWG = 8;
 constexpr int kListCap = 256;
-__global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, float lr_over_L) {
+__global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
   __shared__ int sHit[kWordsPerWG];
@@ -583,7 +587,8 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, fl
     if ((int)blockIdx.x == G && tid < a.d) {
       float gb = 0.f;
       for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
-      const float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
+      float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
+      if (nfused) merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
       a.bd[tid] -= a.lr * gb;
       a.beta[tid] -= a.lr * t1;
       a.gamma[tid] -= a.lr * t2;
@@ -758,25 +763,26 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 }
 
 // backward of the block of the last train-mode forward (which must have run with fill = 1)
-int tower_backward(nncf_tower* t, const float* dA, hipStream_t st) {
+// nfused > 0: the BN backward's column sums arrive as nfused partials from the step's apply kernel
+int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0) {
   TowerArgs a = t->last;
   a.dA = dA;
   const int m = a.m;
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
   const int ntile = ((a.wd + 15) / 16) * ((a.d + 15) / 16);
-  {
+  if (!nfused) {
     ProfScope _ps("tower_sums_kernel", st);
     hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
   }
   {
     ProfScope _ps("tower_bwd_kernel", st);
-    hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks);
+    hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks, nfused);
   }
   {
     ProfScope _ps("tower_word_kernel", st);
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.wd * a.d + 511) / 512;
-    hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, a.lr / (float)a.L);
+    hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -807,13 +813,17 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   const int32_t* cid_local = pv.inverse;  // batch position -> row of the item block
   StepArgs sa = make_args(m);
   sa.bn_z = t->z;
-  sa.bn_ma = t->ws + ws_muinv() + 384;
+  sa.bn_stats = t->ws + ws_muinv();
+  // shared schemes: the apply kernel's item chunks (b / 16 of them) emit the BN backward's sums
+  const int chunks = (b + kChunkSlots - 1) / kChunkSlots;
+  const int nfused = (scheme != 0 && update && chunks <= kTowerWG) ? chunks : 0;
+  if (nfused) sa.bn_part = t->ws + ws_bsum();
   if (scheme == 0)
     rc = launch_original(sa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
   else
     rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
   if (rc || !update) return rc;
-  return tower_backward(t, m->export_gV, st);
+  return tower_backward(t, m->export_gV, st, nfused);
 }
 
 }  // namespace
