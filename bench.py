@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.5,
                     help="word-row dropout of the text tower in training; 0.5 = the 'best' preset every demo script "
                          "runs with (basic_embedding_conf.py:112, scripts/demos/run_*.sh --conf_choice best)")
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "adam", "sparse_adam"],
+                    help="sgd = the north-star's sparse SGD (headline); adam = Keras Adam, the reference's dense "
+                         "default; sparse_adam = utils/optimizer.py")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--profile-launches", type=int, default=1000)
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
@@ -74,7 +77,7 @@ def param_dict_for(args):
             "neg_loss_weight": 8 if loss == "mse" else 128, "loss_gamma": 0.1 if loss == "max-margin" else 10,
             "learn_rate": 0.001 if loss == "mse" else 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
             "batch_size_p": args.batch, "user_dim": args.dim, "item_dim": args.dim, "word_dim": args.dim,
-            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None}
+            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None, "optimizer": args.optimizer}
 
 
 def conf_for(args):
@@ -82,7 +85,7 @@ def conf_for(args):
     pd = param_dict_for(args)
     return OracleConf(batch_size_p=pd["batch_size_p"], num_negatives=pd["num_negatives"], loss=pd["loss"],
                       loss_gamma=pd["loss_gamma"], neg_loss_weight=pd["neg_loss_weight"], u_reg=pd["u_reg"],
-                      learn_rate=pd["learn_rate"], model_choice=args.model)
+                      learn_rate=pd["learn_rate"], model_choice=args.model, optimizer=args.optimizer)
 
 
 def make_large(args):
@@ -413,9 +416,11 @@ def main():
             "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init parameters" if args.large
                      else "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
                      % (", item text" if args.model == "basic_embedding" else "")),
-            "config": {"workload": "%s, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, sparse SGD"
+            "config": {"workload": "%s, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, %s"
                                    % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", tower_txt, d,
-                                      args.scheme, conf.loss, b, (", k=%d" % k) if k else ""),
+                                      args.scheme, conf.loss, b, (", k=%d" % k) if k else "",
+                                      {"sgd": "sparse SGD", "adam": "Keras Adam (dense)",
+                                       "sparse_adam": "lazy-sparse Adam"}[args.optimizer]),
                        "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
             "roofline": roof,

@@ -151,6 +151,18 @@ typedef struct nncf_model nncf_model;
 int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_item_table, int device,
                       int64_t max_steps, nncf_model** out);
 int nncf_model_destroy(nncf_model* m);
+/* Optimiser of the model's tables.  mode 0: sparse SGD on the touched rows (the build's default,
+ * BASELINE north-star).  mode 1: lazy-sparse Adam of utils/optimizer.py:108-134 (the reference
+ * selects it with learn_rate < 0, basic_embedding_conf.py:61-66): only the rows of the batch move;
+ * duplicate ids are summed first (TF's _apply_sparse_duplicate_indices).  mode 2: Keras Adam
+ * (basic_embedding_conf.py:59-60): dense -- rows without a gradient still decay their moments and
+ * move.  lr_t = learn_rate sqrt(1 - beta2^t) / (1 - beta1^t), p -= lr_t m / (sqrt(v) + epsilon).
+ * d_m_*, d_v_*: zero-initialised arrays shaped like the tables (item arrays may be NULL while
+ * item gradients are exported).  Resets the step counter t. */
+int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_user,
+                             float* d_v_user, float* d_m_item, float* d_v_item);
+int nncf_model_get_step(nncf_model* m, int64_t* out);
+
 /* learn_rate / loss hyper-parameters may change between steps (same shapes). */
 int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg);
 
@@ -277,6 +289,13 @@ int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate);
  * forward index to 0.  nncf_tower_dropout_scale writes the per-word scale (0 or 1/(1-rate)) the
  * step_index-th train-mode forward since then uses / used -- for checkers. */
 int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed);
+/* Optimiser of the tower's parameters, modes as nncf_model_set_optimizer.  d_m_words / d_v_words:
+ * shaped like the word table; d_m_dense / d_v_dense: word_dim*item_dim + 384 floats (dense_w, then
+ * dense_b, bn_gamma, bn_beta at 128-float pitch), all zero-initialised.  Mode 1 steps only the
+ * word rows that received a gradient; the Dense / BatchNorm parameters always take full Adam
+ * steps.  Inside nncf_tower_step / _epoch the model's step counter supplies t. */
+int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_words,
+                             float* d_v_words, float* d_m_dense, float* d_v_dense);
 int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, void* stream);
 
 /* d_out[m][item_dim] = tower(d_item_ids).  train == 0: inference phase (running statistics, any

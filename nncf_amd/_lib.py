@@ -89,6 +89,8 @@ def _declare(lib):
         "nncf_model_create": [ctypes.POINTER(ModelCfg), vp, vp, i32, i64, ctypes.POINTER(vp)],
         "nncf_model_destroy": [vp],
         "nncf_model_set_hparams": [vp, f32, f32, f32, f32],
+        "nncf_model_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],
+        "nncf_model_get_step": [vp, ctypes.POINTER(ctypes.c_int64)],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
         "nncf_profile_begin": [ctypes.c_char_p, i64],
         "nncf_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
@@ -110,6 +112,7 @@ def _declare(lib):
         "nncf_tower_destroy": [vp],
         "nncf_tower_set_learn_rate": [vp, f32],
         "nncf_tower_set_dropout": [vp, f32, u64],
+        "nncf_tower_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],
         "nncf_tower_dropout_scale": [vp, u64, vp, vp],
         "nncf_tower_forward": [vp, vp, i64, vp, i32, i32, vp, vp, vp],
         "nncf_tower_backward": [vp, vp, vp],

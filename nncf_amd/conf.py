@@ -3,9 +3,13 @@
 for mf) and get_conf (:170-179).  Only fields consumed on the sampling + scoring path are kept;
 text-tower presets (pretrain files, gating) are out of scope.
 
-Optimizer: the reference compiles Keras Adam(learn_rate) (basic_embedding_conf.py:59-60).  This
-build implements the north-star's sparse SGD scatter update; `conf.optimizer` is the string
-'sgd' and `conf.learn_rate` its step size.
+Optimizer: `conf.optimizer` is a string here (the reference stores a Keras / TF object):
+  'sgd'          sparse SGD scatter update -- the build's default (BASELINE north-star);
+  'adam'         Keras Adam(learn_rate), what the reference compiles for learn_rate > 0
+                 (basic_embedding_conf.py:59-60): dense, every row of every table moves each step;
+  'sparse_adam'  utils/optimizer.py AdamOptimizer(-learn_rate), what the reference switches to for
+                 learn_rate < 0 (:61-66); chosen automatically for a negative learn_rate.
+Pass {'optimizer': 'adam'} in param_dict for the reference's default optimiser.
 """
 
 
@@ -57,7 +61,11 @@ class Conf(object):
     def _post_init(self):
         if self.emb_normalization is None:  # :52-56
             self.emb_normalization = True if self.loss == "max-margin" or self.loss == "log-loss" else False
-        self.optimizer = "sgd"
+        opt = self.__dict__.get("optimizer")
+        if opt is None:
+            opt = "sgd" if self.learn_rate > 0 else "sparse_adam"  # :59-66 (lr < 0 selects the sparse variant)
+        assert opt in ("sgd", "adam", "sparse_adam"), "[ERROR] optimizer %r unknown" % (opt,)
+        self.optimizer = opt
         self.pretrain = None
         self.item_dense_transform = {"dense_hidden_dim": self.user_dim, "dense_hidden_dropout": 0.,
                                      "dense_hidden_actv": "relu"}  # :83-86

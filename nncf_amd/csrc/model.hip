@@ -1,6 +1,7 @@
 // B2 host side: model object, workspaces, per-step entry points and the epoch runners that
 // replace the trainers' inner loops (models/train_original.py:43-68,
 // train_neg_shared.py:46-59, train_group_neg_shared.py:53-68).
+#include <cmath>
 #include <cstdlib>
 #include <new>
 
@@ -29,7 +30,32 @@ StepArgs make_args(const nncf_model* m) {
   a.u_reg = c.u_reg;
   a.lr = c.learn_rate;
   a.gV = m->export_gV;
+  a.opt = m->opt;
+  if (m->opt) {  // the step about to be taken is number adam_t + 1
+    const double t = (double)(m->adam_t + 1);
+    a.beta1 = m->beta1;
+    a.beta2 = m->beta2;
+    a.eps = m->eps;
+    a.lr_t = (float)((double)c.learn_rate * std::sqrt(1.0 - std::pow((double)m->beta2, t)) /
+                     (1.0 - std::pow((double)m->beta1, t)));
+    a.step_no = (int)(m->adam_t + 1);
+    a.au = m->au;
+    a.av = m->av;
+  }
   return a;
+}
+
+// After the kernels of an update step: dense Adam moves every row that got no gradient, then the
+// optimiser's step counter advances.
+int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st) {
+  if (!m->opt) return NNCF_OK;
+  if (m->opt == 2) {
+    if (int rc = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc;
+    if (!m->export_gV)
+      if (int rc = launch_adam_idle(a, m->V, m->av, m->cfg.item_count, st)) return rc;
+  }
+  m->adam_t++;
+  return NNCF_OK;
 }
 }  // namespace nncf
 
@@ -154,6 +180,7 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
 int nncf_model_destroy(nncf_model* m) {
   if (!m) return NNCF_OK;
   if (m->arena) hipFree(m->arena);
+  if (m->stamps) hipFree(m->stamps);
   delete m;
   return NNCF_OK;
 }
@@ -168,6 +195,46 @@ int nncf_model_debug_stamps(nncf_model* m, long long* out_host, int64_t n) {
 int nncf_model_set_item_grad_export(nncf_model* m, float* d_item_grad) {
   if (int rc = check_model(m)) return rc;
   m->export_gV = d_item_grad;
+  return NNCF_OK;
+}
+
+int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_user,
+                             float* d_v_user, float* d_m_item, float* d_v_item) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(mode >= 0 && mode <= 2, "optimizer mode must be 0 (sgd), 1 (lazy-sparse adam) or 2 (dense adam)");
+  if (mode) {
+    NNCF_REQUIRE(d_m_user && d_v_user, "Adam needs the user table's moment arrays");
+    NNCF_REQUIRE(m->export_gV || (d_m_item && d_v_item), "Adam needs the item table's moment arrays");
+    NNCF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && epsilon > 0.f, "bad Adam constants");
+  }
+  m->opt = mode;
+  m->beta1 = beta1;
+  m->beta2 = beta2;
+  m->eps = epsilon;
+  m->adam_t = 0;
+  m->au = AdamTable{d_m_user, d_v_user, nullptr};
+  m->av = AdamTable{d_m_item, d_v_item, nullptr};
+  if (mode == 2) {
+    const size_t n = (size_t)(m->cfg.user_count + m->cfg.item_count);
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(m->device);
+    if (!m->stamps && hipMalloc(&m->stamps, n * sizeof(int32_t)) != hipSuccess) {
+      hipSetDevice(prev);
+      return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
+    }
+    hipMemset(m->stamps, 0, n * sizeof(int32_t));  // steps are numbered from 1
+    hipSetDevice(prev);
+    m->au.stamp = m->stamps;
+    m->av.stamp = m->stamps + m->cfg.user_count;
+  }
+  return NNCF_OK;
+}
+
+int nncf_model_get_step(nncf_model* m, int64_t* out) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(out != nullptr, "out is NULL");
+  *out = m->adam_t;
   return NNCF_OK;
 }
 
@@ -191,7 +258,11 @@ int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid
   if (rc) return rc;
   rc = launch_plan(d_cid, 0, b * (1 + k), nullptr, 0, 0, m->plan_v, 1, st);
   if (rc) return rc;
-  return launch_original(make_args(m), d_uid, d_cid, d_cid + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st);
+  {
+    const StepArgs sa = make_args(m);
+    if (int rc2 = launch_original(sa, d_uid, d_cid, d_cid + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    return update ? finish_update(m, sa, st) : NNCF_OK;
+  }
 }
 
 int nncf_step_rowwise(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, const int32_t* d_y, float* d_loss,
@@ -205,7 +276,11 @@ int nncf_step_rowwise(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid,
   if (rc) return rc;
   rc = launch_plan(d_cid, 0, n, nullptr, 0, 0, m->plan_v, 1, st);
   if (rc) return rc;
-  return launch_rowwise(make_args(m), d_uid, d_cid, d_y, m->rws, m->plan_u, m->plan_v, n, d_loss, update, st);
+  {
+    const StepArgs sa = make_args(m);
+    if (int rc2 = launch_rowwise(sa, d_uid, d_cid, d_y, m->rws, m->plan_u, m->plan_v, n, d_loss, update, st)) return rc2;
+    return update ? finish_update(m, sa, st) : NNCF_OK;
+  }
 }
 
 int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_y_all,
@@ -215,7 +290,6 @@ int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d
   NNCF_REQUIRE(m->cfg.num_negatives > 0 && n_steps >= 0, "bad argument");
   const int64_t n = (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives);
   hipStream_t st = as_stream(stream);
-  const StepArgs a = make_args(m);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
     int rc = launch_plan(d_uid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_u, cnt, st);
@@ -224,9 +298,11 @@ int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
+      const StepArgs a = make_args(m);
       rc = launch_rowwise(a, d_uid_all + t * n, d_cid_all + t * n, d_y_all + t * n, m->rws, m->plan_u.at(i),
                           m->plan_v.at(i), (int)n, d_loss + t, 1, st);
       if (rc) return rc;
+      if ((rc = finish_update(m, a, st))) return rc;
     }
   }
   return NNCF_OK;
@@ -241,7 +317,11 @@ int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_c
   hipStream_t st = as_stream(stream);
   int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
-  return launch_shared(make_args(m), 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  {
+    const StepArgs sa = make_args(m);
+    if (int rc2 = launch_shared(sa, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    return update ? finish_update(m, sa, st) : NNCF_OK;
+  }
 }
 
 int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss,
@@ -255,7 +335,13 @@ int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32
   if (rc) return rc;
   StepArgs a = make_args(m);
   a.gV = d_item_grad;
-  return launch_shared(a, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, 1, st);
+  rc = launch_shared(a, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, 1, st);
+  if (rc) return rc;
+  if (m->opt == 2) {  // item rows belong to their owners: only the user table is stepped here
+    if (int rc2 = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc2;
+  }
+  if (m->opt) m->adam_t++;
+  return NNCF_OK;
 }
 
 int nncf_plan_item_block(nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
@@ -279,10 +365,18 @@ int nncf_step_planned(nncf_model* m, int32_t scheme, const int32_t* d_uid, float
   const int32_t* cid_local = m->plan_v.inverse;  // batch position -> row of the item block
   if (scheme == 0) {
     NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
-    return launch_original(make_args(m), d_uid, cid_local, cid_local + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st);
+    {
+    const StepArgs sa = make_args(m);
+    if (int rc2 = launch_original(sa, d_uid, cid_local, cid_local + b, m->ows, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    return update ? finish_update(m, sa, st) : NNCF_OK;
+  }
   }
   if (int rc = check_shared(m)) return rc;
-  return launch_shared(make_args(m), scheme == 2, d_uid, cid_local, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  {
+    const StepArgs sa = make_args(m);
+    if (int rc2 = launch_shared(sa, scheme == 2, d_uid, cid_local, m->sws, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    return update ? finish_update(m, sa, st) : NNCF_OK;
+  }
 }
 
 int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, float* d_loss, int update,
@@ -294,7 +388,10 @@ int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_
   hipStream_t st = as_stream(stream);
   int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
-  rc = launch_shared(make_args(m), 1, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  const StepArgs sa = make_args(m);
+  rc = launch_shared(sa, 1, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  if (rc) return rc;
+  if (update) rc = finish_update(m, sa, st);
   if (rc) return rc;
   if (d_cid_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_cid_u, m->plan_v.uniq, sizeof(int32_t) * b, hipMemcpyDeviceToDevice, st));
   if (d_cid_x) NNCF_HIP_CHECK(hipMemcpyAsync(d_cid_x, m->plan_v.inverse, sizeof(int32_t) * b, hipMemcpyDeviceToDevice, st));
@@ -310,16 +407,17 @@ int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* 
   NNCF_REQUIRE(n_steps >= 0, "negative step count");
   const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
   hipStream_t st = as_stream(stream);
-  const StepArgs a = make_args(m);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
     int rc = plan_chunk(m, 0, d_uid_all, d_cid_all, d_neg, t0, cnt, st);
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
+      const StepArgs a = make_args(m);
       rc = launch_original(a, d_uid_all + t * b, d_cid_all + t * b, d_neg + t * b * k, m->ows, m->plan_u.at(i),
                            m->plan_v.at(i), d_loss + t, 1, st);
       if (rc) return rc;
+      if ((rc = finish_update(m, a, st))) return rc;
     }
   }
   return NNCF_OK;
@@ -333,16 +431,17 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
   NNCF_REQUIRE(n_steps >= 0, "negative step count");
   const int64_t b = m->cfg.batch_size_p;
   hipStream_t st = as_stream(stream);
-  const StepArgs a = make_args(m);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
     int rc = plan_chunk(m, 1, d_uid_all, d_cid_all, nullptr, t0, cnt, st);
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
+      const StepArgs a = make_args(m);
       rc = launch_shared(a, group, d_uid_all + t * b, d_cid_all + t * b, m->sws, m->plan_u.at(i), m->plan_v.at(i),
                          d_loss + t, 1, st);
       if (rc) return rc;
+      if ((rc = finish_update(m, a, st))) return rc;
     }
     if (d_n_u) {
       // n_u of each planned step (counts[2*i]) -> d_n_u[t0 + i]

@@ -7,6 +7,14 @@
 
 namespace nncf {
 
+// Adam state of one table: first / second moments (table-shaped) and, for dense Adam, the step
+// at which each row last received a gradient.
+struct AdamTable {
+  float* m = nullptr;
+  float* v = nullptr;
+  int32_t* stamp = nullptr;
+};
+
 // Per-launch scalars (copied by value into the kernarg segment).
 struct StepArgs {
   float* U;  // user table  (user_count x stride)
@@ -25,6 +33,13 @@ struct StepArgs {
   // if non-NULL the apply kernel of the shared schemes also emits, per item chunk, the column sums
   // of dy = dL/dE * [E > 0] and dy * xhat (the BatchNorm backward's reductions): [chunk][2][128]
   float* bn_part = nullptr;
+  // optimiser: 0 sparse SGD (north-star); 1 lazy-sparse Adam on the touched rows
+  // (utils/optimizer.py:108-134); 2 dense Adam = Keras Adam (basic_embedding_conf.py:59-60): the
+  // touched rows here, every other row by adam_idle_kernel with a zero gradient.
+  int opt = 0;
+  float lr_t = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;  // lr_t = lr sqrt(1-b2^t)/(1-b1^t)
+  int step_no = 0;
+  AdamTable au, av;
 };
 
 }  // namespace nncf
@@ -34,6 +49,30 @@ namespace nncf {
 // row `id` of the step's item table (plain table, or BatchNorm + ReLU of the tower's block)
 __device__ __forceinline__ Row item_row(const StepArgs& a, int64_t id, int d4, int q) {
   return a.bn_z ? row_load_bn(a.bn_z, a.bn_stats + 384, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
+}
+// The optimiser step on one table row (called by one 16-lane group): raw row, complete gradient.
+__device__ __forceinline__ float4 adam4(float4 g, float4& m, float4& v, float4 p, float b1, float b2, float lr_t, float eps) {
+  m = make_float4(fmaf(b1, m.x, (1.f - b1) * g.x), fmaf(b1, m.y, (1.f - b1) * g.y), fmaf(b1, m.z, (1.f - b1) * g.z),
+                  fmaf(b1, m.w, (1.f - b1) * g.w));
+  v = make_float4(fmaf(b2, v.x, (1.f - b2) * g.x * g.x), fmaf(b2, v.y, (1.f - b2) * g.y * g.y),
+                  fmaf(b2, v.z, (1.f - b2) * g.z * g.z), fmaf(b2, v.w, (1.f - b2) * g.w * g.w));
+  return make_float4(p.x - lr_t * m.x / (sqrtf(v.x) + eps), p.y - lr_t * m.y / (sqrtf(v.y) + eps),
+                     p.z - lr_t * m.z / (sqrtf(v.z) + eps), p.w - lr_t * m.w / (sqrtf(v.w) + eps));
+}
+__device__ __forceinline__ void apply_update(const StepArgs& a, const AdamTable& st, float* table, int64_t id, Row raw,
+                                             Row grad, int d4, int q) {
+  if (a.opt == 0) {
+    row_store(table, id, a.stride, d4, q, row_fma(-a.lr, grad, raw));
+    return;
+  }
+  Row m = row_load(st.m, id, a.stride, d4, q), v = row_load(st.v, id, a.stride, d4, q);
+  Row p;
+  p.a = adam4(grad.a, m.a, v.a, raw.a, a.beta1, a.beta2, a.lr_t, a.eps);
+  p.b = adam4(grad.b, m.b, v.b, raw.b, a.beta1, a.beta2, a.lr_t, a.eps);
+  row_store(st.m, id, a.stride, d4, q, m);
+  row_store(st.v, id, a.stride, d4, q, v);
+  row_store(table, id, a.stride, d4, q, p);
+  if (st.stamp && q == 0) st.stamp[id] = a.step_no;
 }
 }  // namespace nncf
 #endif
@@ -82,6 +121,9 @@ int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_
 int launch_rowwise(const StepArgs& a, const int32_t* uid, const int32_t* cid, const int32_t* y, const RowwiseWs& ws,
                    const PlanView& pu, const PlanView& pv, int n, float* loss_out, int update, hipStream_t stream);
 
+// dense Adam: rows of (table, state) whose stamp != a.step_no take a zero-gradient step
+int launch_adam_idle(const StepArgs& a, float* table, const AdamTable& st, int64_t rows, hipStream_t stream);
+
 int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32_t* cid, int64_t q, float* out,
                    hipStream_t stream);
 
@@ -100,8 +142,16 @@ struct nncf_model {
   nncf::PlanView plan_u, plan_v;  // kPlanChunk lists each
   int64_t cap_u = 0, cap_v = 0;
   float* export_gV = nullptr;
+  // optimiser (nncf_model_set_optimizer)
+  int opt = 0;
+  float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  int64_t adam_t = 0;  // update steps taken (Keras `iterations`)
+  nncf::AdamTable au, av;
+  int32_t* stamps = nullptr;  // owned: user_count + item_count ints (dense Adam)
 };
 
 namespace nncf {
 StepArgs make_args(const nncf_model* m);
+// after the kernels of an update step: dense-Adam idle rows, optimiser step counter
+int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st);
 }

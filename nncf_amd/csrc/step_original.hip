@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
           }
           // regulariser: every one of this user's cnt*(1+k) rows adds 2 u_reg U / n, n = b(1+k)
           grad = row_fma(2.f * a.u_reg * (float)cnt / (float)b, uraw, grad);
-          row_store(a.U, u, a.stride, d4, q, row_fma(-a.lr, grad, uraw));
+          apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
         });
   } else {
     const int chunk = blockIdx.x - cu;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
             grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
           }
           if (a.gV) row_store(a.gV, c, a.d, d4, q, grad);
-          else row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
+          else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
         });
   }
 }

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
             grad = norm_backward(row_scale(uraw, inv), inv, ss, acc);
           }
           grad = row_fma(2.f * a.u_reg * (float)cnt / (float)n, uraw, grad);
-          row_store(a.U, u, a.stride, d4, q, row_fma(-a.lr, grad, uraw));
+          apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
         });
   } else {
     chunk_reduce(
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
             grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
           }
           if (a.gV) row_store(a.gV, c, a.d, d4, q, grad);
-          else row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
+          else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
         });
   }
 }

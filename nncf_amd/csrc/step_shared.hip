@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
             grad = norm_backward(row_scale(uraw, inv), inv, ss, acc);
           }
           grad = row_fma(2.f * a.u_reg * (float)cnt / (float)b, uraw, grad);
-          row_store(a.U, u, a.stride, d4, q, row_fma(-a.lr, grad, uraw));
+          apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
         });
   } else {
     const int chunk = blockIdx.x - max_chunks;
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
             grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
           }
           if (a.gV) row_store(a.gV, c, d, d4, q, grad);
-          else row_store(a.V, c, a.stride, d4, q, row_fma(-a.lr, grad, vraw));
+          else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
           if (bn && a.bn_part) {
             auto acc4 = [](float4 y, float4 g, float4 z, float4 mu, float4 iv, float4& t1, float4& t2) {
               const float4 dy = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f,

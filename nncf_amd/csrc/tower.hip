@@ -24,6 +24,7 @@
 // Only the first *n_valid rows of a block are real (device scalar): shapes are static, nothing
 // syncs to the host, every cross-row reduction has a fixed order.
 // [K-mem] Keras-1 BatchNormalization: eps 1e-3, momentum 0.99, biased variance.
+#include <cmath>
 #include <new>
 
 #include "common.h"
@@ -68,7 +69,21 @@ struct TowerArgs {
   float eps, momentum, lr;
   float keep;                    // row-dropout retain probability (1 = off)
   unsigned long long drop_seed;  // this step's mask seed
+  // optimiser (StepArgs::opt): Adam state of the word table and of the packed dense parameters
+  // [Wd (wd*d) | bd (128) | gamma (128) | beta (128)]
+  int opt, step_no;
+  float lr_t, beta1, beta2, aeps;
+  AdamTable aw;
+  float* mD;
+  float* vD;
 };
+
+__device__ __forceinline__ float adam1(float g, float* m, float* v, float p, const TowerArgs& a) {
+  const float mm = fmaf(a.beta1, *m, (1.f - a.beta1) * g), vv = fmaf(a.beta2, *v, (1.f - a.beta2) * g * g);
+  *m = mm;
+  *v = vv;
+  return p - a.lr_t * mm / (sqrtf(vv) + a.aeps);
+}
 
 __host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
   x ^= x >> 30;
@@ -582,16 +597,23 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     if (el < nel) {
       float g = 0.f;
       for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
-      a.Wd[el] -= a.lr * g;
+      a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
     }
     if ((int)blockIdx.x == G && tid < a.d) {
       float gb = 0.f;
       for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
       float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
       if (nfused) merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
-      a.bd[tid] -= a.lr * gb;
-      a.beta[tid] -= a.lr * t1;
-      a.gamma[tid] -= a.lr * t2;
+      if (a.opt) {
+        float *mm = a.mD + nel, *vv = a.vD + nel;
+        a.bd[tid] = adam1(gb, mm + tid, vv + tid, a.bd[tid], a);
+        a.gamma[tid] = adam1(t2, mm + 128 + tid, vv + 128 + tid, a.gamma[tid], a);
+        a.beta[tid] = adam1(t1, mm + 256 + tid, vv + 256 + tid, a.beta[tid], a);
+      } else {
+        a.bd[tid] -= a.lr * gb;
+        a.beta[tid] -= a.lr * t1;
+        a.gamma[tid] -= a.lr * t2;
+      }
     }
     return;
   }
@@ -667,9 +689,21 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       sum.x += t.x;
       sum.y += t.y;
     }
-    const float sc = lr_over_L * word_scale(a, my_w);
-    wold.x = fmaf(-sc, sum.x, wold.x);
-    wold.y = fmaf(-sc, sum.y, wold.y);
+    if (a.opt) {  // gradient = scale[w] / L * sum
+      const float gs = word_scale(a, my_w) / (float)a.L;
+      float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
+      float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
+      float2 mm = *mp, vv = *vp;
+      wold.x = adam1(gs * sum.x, &mm.x, &vv.x, wold.x, a);
+      wold.y = adam1(gs * sum.y, &mm.y, &vv.y, wold.y, a);
+      *mp = mm;
+      *vp = vv;
+      if (a.aw.stamp && lane == 0) a.aw.stamp[my_w] = a.step_no;
+    } else {
+      const float sc = lr_over_L * word_scale(a, my_w);
+      wold.x = fmaf(-sc, sum.x, wold.x);
+      wold.y = fmaf(-sc, sum.y, wold.y);
+    }
     reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
   }
 }
@@ -698,6 +732,13 @@ struct nncf_tower {
   TowerArgs last{};
   float drop_rate = 0.f;
   uint64_t drop_seed = 0, drop_step = 0;  // train-mode forwards since nncf_tower_set_dropout
+  // optimiser (nncf_tower_set_optimizer)
+  int opt = 0;
+  float beta1 = 0.9f, beta2 = 0.999f, aeps = 1e-8f;
+  int64_t adam_t = 0;  // standalone backward calls; inside a model step the model's counter rules
+  AdamTable aw;
+  float *mD = nullptr, *vD = nullptr;
+  int32_t* stamps = nullptr;
 };
 
 namespace {
@@ -764,9 +805,22 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 
 // backward of the block of the last train-mode forward (which must have run with fill = 1)
 // nfused > 0: the BN backward's column sums arrive as nfused partials from the step's apply kernel
-int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0) {
+// step_t: the optimiser step this backward belongs to (1-based)
+int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0) {
   TowerArgs a = t->last;
   a.dA = dA;
+  a.opt = t->opt;
+  if (t->opt) {
+    const double tt = (double)(step_t > 0 ? step_t : t->adam_t + 1);
+    a.beta1 = t->beta1;
+    a.beta2 = t->beta2;
+    a.aeps = t->aeps;
+    a.lr_t = (float)((double)a.lr * std::sqrt(1.0 - std::pow((double)t->beta2, tt)) / (1.0 - std::pow((double)t->beta1, tt)));
+    a.step_no = (int)tt;
+    a.aw = t->aw;
+    a.mD = t->mD;
+    a.vD = t->vD;
+  }
   const int m = a.m;
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
@@ -785,6 +839,13 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
+  if (t->opt == 2) {  // dense Adam: words without a gradient this step
+    StepArgs sa{};
+    sa.stride = a.wd; sa.d = a.wd; sa.beta1 = a.beta1; sa.beta2 = a.beta2; sa.eps = a.aeps; sa.lr_t = a.lr_t;
+    sa.step_no = a.step_no;
+    if (int rc = launch_adam_idle(sa, a.W, a.aw, a.n_words, st)) return rc;
+  }
+  if (t->opt && step_t <= 0) t->adam_t++;
   return NNCF_OK;
 }
 
@@ -823,7 +884,9 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   else
     rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
   if (rc || !update) return rc;
-  return tower_backward(t, m->export_gV, st, nfused);
+  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0);
+  if (rc) return rc;
+  return finish_update(m, sa, st);
 }
 
 }  // namespace
@@ -876,6 +939,7 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
 int nncf_tower_destroy(nncf_tower* t) {
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
+  if (t->stamps) hipFree(t->stamps);
   delete t;
   return NNCF_OK;
 }
@@ -883,6 +947,37 @@ int nncf_tower_destroy(nncf_tower* t) {
 int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   t->cfg.learn_rate = learn_rate;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_words,
+                             float* d_v_words, float* d_m_dense, float* d_v_dense) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(mode >= 0 && mode <= 2, "optimizer mode must be 0 (sgd), 1 (lazy-sparse adam) or 2 (dense adam)");
+  if (mode) {
+    NNCF_REQUIRE(d_m_words && d_v_words && d_m_dense && d_v_dense, "Adam needs the moment arrays");
+    NNCF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && epsilon > 0.f, "bad Adam constants");
+  }
+  t->opt = mode;
+  t->beta1 = beta1;
+  t->beta2 = beta2;
+  t->aeps = epsilon;
+  t->adam_t = 0;
+  t->aw = AdamTable{d_m_words, d_v_words, nullptr};
+  t->mD = d_m_dense;
+  t->vD = d_v_dense;
+  if (mode == 2) {
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(t->device);
+    if (!t->stamps && hipMalloc(&t->stamps, sizeof(int32_t) * (size_t)t->cfg.word_count) != hipSuccess) {
+      hipSetDevice(prev);
+      return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
+    }
+    hipMemset(t->stamps, 0, sizeof(int32_t) * (size_t)t->cfg.word_count);
+    hipSetDevice(prev);
+    t->aw.stamp = t->stamps;
+  }
   return NNCF_OK;
 }
 

@@ -58,6 +58,25 @@ class Engine(object):
                                                  ctypes.byref(self._h)))
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
 
+    OPT_CODES = {"sgd": 0, "sparse_adam": 1, "adam": 2}
+
+    def set_optimizer(self, kind, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None):
+        """'sgd' | 'sparse_adam' (utils/optimizer.py:108-134) | 'adam' (Keras Adam,
+        basic_embedding_conf.py:59-60).  `state`: moment tensors of another engine over the same
+        tables (heads of one model share one optimiser, model_framework.py:24)."""
+        mode = self.OPT_CODES[kind]
+        if mode and state is None:
+            z = torch.zeros_like
+            state = {"mU": z(self.U), "vU": z(self.U)}
+            if getattr(self, "_export", None) is None:
+                state.update(mV=z(self.V), vV=z(self.V))
+        self.opt_state = state if mode else None
+        st = state or {}
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_model_set_optimizer(self._h, mode, beta1, beta2, epsilon, _ptr(st.get("mU")),
+                                                        _ptr(st.get("vU")), _ptr(st.get("mV")), _ptr(st.get("vV"))))
+        self.optimizer = kind
+
     # -- helpers -------------------------------------------------------------------------
     def ids(self, x):
         """Host or device integer ids -> contiguous int32 CUDA tensor (Keras casts to int32,

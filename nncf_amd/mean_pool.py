@@ -92,6 +92,21 @@ class MeanPoolTower(object):
                 getattr(self, name).copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
         self.version += 1
 
+    def set_optimizer(self, kind, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """'sgd' | 'sparse_adam' | 'adam' for the tower's parameters (see Engine.set_optimizer)."""
+        mode = {"sgd": 0, "sparse_adam": 1, "adam": 2}[kind]
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+        self.opt_state = None
+        if mode:
+            nd = self.wd * self.d + 384
+            z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)  # noqa: E731
+            self.opt_state = {"mW": z(self.word_count, self.wd), "vW": z(self.word_count, self.wd), "mD": z(nd), "vD": z(nd)}
+        st = self.opt_state or {}
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_optimizer(self.handle, mode, beta1, beta2, epsilon, p(st.get("mW")),
+                                                        p(st.get("vW")), p(st.get("mD")), p(st.get("vD"))))
+        self.optimizer = kind
+
     def set_dropout(self, rate, seed=0):
         """Embedding(dropout=rate) row dropout (mean_pool.py:56-59), mask generated inside the
         kernels from (seed, train-forward index, word)."""

@@ -342,6 +342,10 @@ def _get_model_basic_embedding(conf, data_helper, device, seed):
                           abs(conf.learn_rate), engine.device, seed=seed,
                           dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
+    opt = getattr(conf, "optimizer", "sgd")
+    if opt != "sgd":
+        engine.set_optimizer(opt)   # after the export buffer is set: no item-table moments
+        tower.set_optimizer(opt)
 
     def monitor(kind):
         def make(loss_name):
@@ -383,6 +387,15 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
             "use basic_embedding (mean-pool text tower) or mf (id-table towers)" % model_name)
     kw = engine_kwargs(conf, data_spec, model_name)
     engine = Engine(device=device, seed=seed, **kw)
+    opt = getattr(conf, "optimizer", "sgd")
+    if opt != "sgd":
+        engine.set_optimizer(opt)
+
+    def make_unnormalised():
+        e2 = Engine(device=device, share=engine, **dict(kw, normalize_user=False))
+        if opt != "sgd":
+            e2.set_optimizer(opt, state=engine.opt_state)   # one optimiser for all heads (model_framework.py:24)
+        return e2
 
     def monitor(head_cls):
         def make(loss_name):
@@ -396,8 +409,7 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
         "model": OriginalModel(engine),
         "model_neg_shared": NegSharedModel(engine),
         "model_group_neg_shared": GroupNegSharedModel(engine),
-        "model_sampled_neg_shared": SampledNegSharedModel(
-            engine, lambda: Engine(device=device, share=engine, **dict(kw, normalize_user=False))),
+        "model_sampled_neg_shared": SampledNegSharedModel(engine, make_unnormalised),
         "model_user_emb": EmbeddingModel(engine, "user"),
         "model_item_emb": EmbeddingModel(engine, "item"),
         "model_pred_pairs": PredPairsModel(engine),

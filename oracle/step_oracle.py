@@ -34,7 +34,7 @@ class OracleConf(object):
 
     def __init__(self, batch_size_p=512, num_negatives=10, loss="skip-gram", loss_gamma=None,
                  neg_loss_weight=None, u_reg=1e-6, learn_rate=0.01, emb_normalization=None,
-                 model_choice="mf"):
+                 model_choice="mf", optimizer="sgd", beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.batch_size_p = int(batch_size_p)
         self.num_negatives = int(num_negatives)
         assert loss in LOSSES, "[ERROR!] loss %s not specified." % loss
@@ -48,6 +48,10 @@ class OracleConf(object):
             emb_normalization = loss in ("max-margin", "log-loss")
         self.emb_normalization = bool(emb_normalization)
         self.model_choice = model_choice
+        # 'sgd' (the build's sparse SGD) | 'adam' (Keras Adam, basic_embedding_conf.py:59-60: dense)
+        # | 'sparse_adam' (utils/optimizer.py:108-134; duplicate ids summed first)
+        assert optimizer in ("sgd", "adam", "sparse_adam")
+        self.optimizer, self.beta1, self.beta2, self.epsilon = optimizer, beta1, beta2, epsilon
         # model_framework.py:62-63 normalises U for every model; :109-111 normalises the item
         # side only inside the content-model branch (not for 'mf', :85-88).
         self.normalize_user = self.emb_normalization
@@ -231,6 +235,34 @@ def sampled_neg_shared_loss(S, conf):
 # ----------------------------------------------------------------------------------------
 # item text tower of model_choice = basic_embedding
 # ----------------------------------------------------------------------------------------
+def adam_lr_t(lr, beta1, beta2, t):
+    """lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)  (utils/optimizer.py:109-111; Keras Adam [K-mem])."""
+    return float(lr) * np.sqrt(1.0 - float(beta2) ** t) / (1.0 - float(beta1) ** t)
+
+
+class AdamSlot(object):
+    """First / second moments of one parameter array and the Adam step on it.
+    rows=None: dense step (Keras Adam; utils/optimizer.py:99-106 _apply_dense).
+    rows=index array: only those rows move (utils/optimizer.py:108-134 _apply_sparse on the
+    de-duplicated, summed IndexedSlices)."""
+
+    def __init__(self, like):
+        self.m = np.zeros_like(like)
+        self.v = np.zeros_like(like)
+
+    def step(self, p, g, lr_t, conf, rows=None):
+        dt = p.dtype.type
+        b1, b2, eps, lr_t = dt(conf.beta1), dt(conf.beta2), dt(conf.epsilon), dt(lr_t)
+        if rows is None:
+            self.m[...] = b1 * self.m + (dt(1) - b1) * g
+            self.v[...] = b2 * self.v + (dt(1) - b2) * g * g
+            p -= lr_t * self.m / (np.sqrt(self.v) + eps)
+        else:
+            self.m[rows] = b1 * self.m[rows] + (dt(1) - b1) * g[rows]
+            self.v[rows] = b2 * self.v[rows] + (dt(1) - b2) * g[rows] * g[rows]
+            p[rows] -= lr_t * self.m[rows] / (np.sqrt(self.v[rows]) + eps)
+
+
 class TowerOracle(object):
     """MeanPool (modules/content/mean_pool.py:46-110) as get_model wires it for
     'basic_embedding' (model_framework.py:90-91,98): word Embedding -> AverageEmbeddings
@@ -272,7 +304,8 @@ class TowerOracle(object):
             self.cache = dict(toks=toks, h=h, xhat=xhat, inv=inv, y=y, row_scale=row_scale, mu=mu, var=var)
         return np.maximum(y, 0).astype(self.dt)
 
-    def backward_update(self, dA):
+    def backward_update(self, dA, conf=None, t=None):
+        """conf / t: OracleConf with optimizer != 'sgd' and the 1-based optimiser step."""
         c = self.cache
         n = self.dt.type(dA.shape[0])
         dy = dA * (c["y"] > 0)
@@ -290,11 +323,25 @@ class TowerOracle(object):
             contrib = contrib * c["row_scale"][c["toks"]][..., None]
         np.add.at(dW, c["toks"], contrib.astype(self.dt))
         self.grads = dict(W=dW, Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
-        self.W -= self.lr * dW
-        self.Wd -= self.lr * dWd
-        self.bd -= self.lr * dbd
-        self.gamma -= self.lr * dgamma
-        self.beta -= self.lr * dbeta
+        if conf is None or conf.optimizer == "sgd":
+            self.W -= self.lr * dW
+            self.Wd -= self.lr * dWd
+            self.bd -= self.lr * dbd
+            self.gamma -= self.lr * dgamma
+            self.beta -= self.lr * dbeta
+        else:
+            if not hasattr(self, "slots"):
+                self.slots = {k: AdamSlot(getattr(self, k)) for k in ("W", "Wd", "bd", "gamma", "beta")}
+            lr_t = adam_lr_t(self.lr, conf.beta1, conf.beta2, t)
+            rows = None
+            if conf.optimizer == "sparse_adam":   # words of the batch that were not dropped
+                toks = c["toks"].reshape(-1)
+                if c["row_scale"] is not None:
+                    toks = toks[c["row_scale"][toks] != 0]
+                rows = np.unique(toks)
+            self.slots["W"].step(self.W, dW, lr_t, conf, rows)
+            for k, g in (("Wd", dWd), ("bd", dbd), ("gamma", dgamma), ("beta", dbeta)):
+                self.slots[k].step(getattr(self, k), g.astype(self.dt), lr_t, conf)
         self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
         self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
 
@@ -312,6 +359,8 @@ class StepOracle(object):
         self.V = np.array(V, dtype=self.dt, copy=True) if V is not None else None
         self.conf = conf
         self.tower = tower  # TowerOracle: item rows come from the text tower (model_framework.py:98-106)
+        self.t = 0  # optimiser steps taken (Keras `iterations`)
+        self.slot_u = self.slot_v = None
         self.row_scale = None  # per-word scale of Embedding row dropout for the next step (mean_pool.py:56-59)
 
     def _tower_in(self, cid):
@@ -326,7 +375,7 @@ class StepOracle(object):
 
     def _tower_out(self, update):
         if self.tower is not None and update:
-            self.tower.backward_update(self.last["dV"][:self._n_u])
+            self.tower.backward_update(self.last["dV"][:self._n_u], self.conf, self.t)
 
     # -- shared pieces -------------------------------------------------------------------
     def _user_side(self, uid):
@@ -360,8 +409,21 @@ class StepOracle(object):
         np.add.at(dU, uid, g_u.astype(self.dt))
         np.add.at(dV, cid, g_v.astype(self.dt))
         tu, tv = np.unique(uid), np.unique(cid)
-        self.U[tu] -= lr * dU[tu]
-        self.V[tv] -= lr * dV[tv]
+        opt = getattr(self.conf, "optimizer", "sgd")
+        if opt == "sgd":
+            self.U[tu] -= lr * dU[tu]
+            if self.tower is None:
+                self.V[tv] -= lr * dV[tv]
+        else:
+            self.t += 1
+            lr_t = adam_lr_t(self.conf.learn_rate, self.conf.beta1, self.conf.beta2, self.t)
+            if self.slot_u is None:
+                self.slot_u = AdamSlot(self.U)
+                self.slot_v = AdamSlot(self.V) if self.tower is None else None
+            sparse = opt == "sparse_adam"
+            self.slot_u.step(self.U, dU, lr_t, self.conf, tu if sparse else None)
+            if self.tower is None:
+                self.slot_v.step(self.V, dV, lr_t, self.conf, tv if sparse else None)
         self.last = dict(g_u=g_u, g_v=g_v, dU=dU, dV=dV)
 
     # -- train_scheme = original (train_original.py:49-58; model 'model', :123,147-149) ---

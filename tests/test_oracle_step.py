@@ -276,3 +276,54 @@ def test_tower_oracle_vs_autograd_full_chain():
         for name, t in zip(("W", "Wd", "bd", "gamma", "beta"), tp):
             np.testing.assert_allclose(tw.grads[name], t.grad.numpy(), atol=1e-10, err_msg=scheme + name)
         np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_adam_slot_against_torch_adam(kind):
+    """AdamSlot (Keras / TF formula lr_t m / (sqrt v + eps)) against torch.optim.Adam /
+    SparseAdam, which differ only in where epsilon sits (eps vs eps / sqrt(1 - b2^t)): with
+    eps = 1e-8 and |g| ~ 1 the two agree to ~1e-6 relative."""
+    rs = np.random.RandomState(0)
+    p0 = rs.randn(12, 5)
+    conf = so.OracleConf(optimizer=kind, learn_rate=0.01)
+    p = p0.copy()
+    slot = so.AdamSlot(p)
+    tp = torch.nn.Parameter(torch.tensor(p0))
+    opt = (torch.optim.Adam if kind == "adam" else torch.optim.SparseAdam)([tp], lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    for t in range(1, 8):
+        rows = np.unique(rs.randint(0, 12, 5))
+        g = np.zeros_like(p)
+        g[rows] = np.sign(rs.randn(len(rows), 5)) * (0.5 + rs.rand(len(rows), 5))
+        slot.step(p, g, so.adam_lr_t(0.01, 0.9, 0.999, t), conf, rows if kind == "sparse_adam" else None)
+        if kind == "adam":
+            tp.grad = torch.tensor(g)
+        else:
+            tp.grad = torch.sparse_coo_tensor(torch.tensor(rows)[None], torch.tensor(g[rows]), size=p.shape)
+        opt.step()
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=2e-6, atol=1e-9)
+    if kind == "sparse_adam":   # untouched rows never move, their moments never decay
+        q = p0.copy()
+        s2 = so.AdamSlot(q)
+        g = np.zeros_like(q)
+        g[3] = 1.0
+        s2.step(q, g, 0.01, conf, np.array([3]))
+        assert np.array_equal(np.delete(q, 3, 0), np.delete(p0, 3, 0))
+
+
+def test_step_oracle_adam_moves_idle_rows_only_when_dense():
+    rs = np.random.RandomState(1)
+    U, V = rs.randn(20, 8).astype(np.float32), rs.randn(30, 8).astype(np.float32)
+    uid, cid = rs.randint(0, 10, 16), rs.randint(0, 15, 16)
+    for kind in ("adam", "sparse_adam"):
+        o = so.StepOracle(U, V, so.OracleConf(batch_size_p=16, num_negatives=0, optimizer=kind), dtype=np.float32)
+        o.step_neg_shared(uid, cid)
+        U1 = o.U.copy()
+        o.step_neg_shared(uid[::-1] * 0 + 19, cid)      # user 19 only
+        idle = np.setdiff1d(np.arange(20), [19])
+        moved = np.abs(o.U[idle] - U1[idle]).max()
+        touched_before = np.unique(uid)
+        if kind == "adam":   # momentum keeps moving the rows of step 1
+            assert np.abs(o.U[touched_before] - U1[touched_before]).max() > 0
+        else:
+            assert moved == 0
+        assert o.t == 2

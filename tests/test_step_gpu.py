@@ -189,3 +189,60 @@ def test_epoch_runner_equals_step_by_step():
                 l2.append(e2.step_group_neg_shared(u, c).item())
         assert np.array_equal(l1, np.array(l2, dtype=np.float32)), scheme
         assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V), scheme
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+@pytest.mark.parametrize("scheme", ["original", "neg_shared", "group_neg_shared"])
+def test_adam_steps_match_oracle(kind, scheme):
+    """Keras Adam (dense: idle rows move too) and the lazy-sparse TF variant against the oracle over
+    several steps (moments, bias correction, duplicate ids summed), tables and moments compared."""
+    b, k, d, nu, ni = 64, 3, 24, 90, 200
+    loss = "log-loss" if scheme == "group_neg_shared" else "skip-gram"
+    gamma = {"log-loss": 10.}.get(loss)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=1e-3, learn_rate=0.01,
+                         model_choice="mf", optimizer=kind)
+    eng = Engine(nu, ni, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=3, init_scale=0.5)
+    eng.set_optimizer(kind)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(5)
+    for step in range(5):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni // 2, b)      # half of the items stay idle
+        if scheme == "group_neg_shared":
+            cid = np.repeat(cid[::4], 4)
+        if scheme == "original":
+            negs = rs.randint(0, ni // 2, b * k)
+            u, c, y = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=np.int64)], 1), negs, loss)
+            want = orc.step_original(u, c, y)
+            got = eng.step_original(eng.ids(uid), eng.ids(c)).item()
+        elif scheme == "neg_shared":
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        # Adam divides by sqrt(v): a tiny gradient difference is amplified where v ~ g^2
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(eng.opt_state["mU"].cpu().numpy(), orc.slot_u.m, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(eng.opt_state["vV"].cpu().numpy(), orc.slot_v.v, rtol=2e-4, atol=1e-9)
+    idle = np.arange(ni // 2, ni)
+    if kind == "sparse_adam":
+        assert np.all(eng.opt_state["mV"].cpu().numpy()[idle] == 0)
+
+
+def test_adam_epoch_runner_equals_step_by_step():
+    b, d, k, steps = 64, 20, 3, 70
+    rs = np.random.RandomState(12)
+    uid_all, cid_all = rs.randint(0, 50, b * steps), rs.randint(0, 300, b * steps)
+    for kind in ("adam", "sparse_adam"):
+        _, e1, _ = _mk("skip-gram", b, k, d, 50, 300, "mf", seed=13, lr=0.01)
+        _, e2, _ = _mk("skip-gram", b, k, d, 50, 300, "mf", seed=13, lr=0.01)
+        e1.set_optimizer(kind)
+        e2.set_optimizer(kind)
+        ua, ca = e1.ids(uid_all), e1.ids(cid_all)
+        l1 = e1.epoch_neg_shared(ua, ca, steps).cpu().numpy()
+        l2 = [e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)]
+        assert np.array_equal(l1, np.array(l2, dtype=np.float32)), kind
+        assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V), kind

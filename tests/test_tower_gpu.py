@@ -187,3 +187,28 @@ def test_row_dropout_matches_oracle_with_same_mask(text_data):
     items = torch.arange(0, 260, 5, dtype=torch.int32, device=tw.device)
     np.testing.assert_allclose(tw.forward(items, train=False).cpu().numpy(), to.forward(items.cpu().numpy(), train=False),
                                rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_basic_embedding_adam_matches_oracle(text_data, kind):
+    conf = _conf("skip-gram", "neg_shared", lr=0.01)
+    conf.optimizer = kind
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2)
+    head = md["model_neg_shared"]
+    tw = head.core.tower
+    orc, to = _oracle(conf, md, text_data)
+    orc.conf.optimizer = kind
+    b = conf.batch_size_p
+    rs = np.random.RandomState(9)
+    for step in range(4):
+        bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
+        # dense_b is left out: its gradient through BatchNorm is exactly zero in real arithmetic, so
+        # what Adam normalises to +-lr_t is rounding noise (in the reference as well); BatchNorm
+        # removes the bias from the output, so nothing downstream depends on it.
+        for name in ("W", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=5e-4, atol=5e-5,
+                                       err_msg="%s step %d" % (name, step))
