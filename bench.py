@@ -177,6 +177,16 @@ def cpu_baseline(args, conf, inp, U0, V0, tower_params):
             "sample": "%d steps of the same %s/%s workload (numpy fp32 oracle, %.1f s)" % (steps, args.model, args.scheme, dt)}
 
 
+_T0 = time.time()
+
+
+def trace(msg):
+    """stage timestamps on stderr (NNCF_BENCH_TRACE=1)"""
+    if os.environ.get("NNCF_BENCH_TRACE") == "1":
+        sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
 def emit(line):
     """Print the ONE JSON line last: flush C stdio first (RCCL prints its banner through printf,
     which would otherwise land after Python's output at exit)."""
@@ -203,16 +213,115 @@ def measured_traffic(args, conf, d):
     return ent["bytes_per_launch"] if ent else None
 
 
+def main_data_parallel(args, rank, world, local_rank):
+    """N > 1, model_choice = basic_embedding: one process per GPU, users + their links partitioned
+    by user range, text tower replicated, ONE RCCL all-reduce of the tower gradients per global
+    step (nncf_amd/sharded.py: DataParallelTower).  Weak scaling: b positives per rank per step."""
+    import torch
+    import torch.distributed as dist
+    from nncf_amd import engine as nengine
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    from nncf_amd.sharded import DataParallelTower, HipTowerReplica, partition_links_by_user
+    trace("data-parallel: making data")
+    data = make_data(args)
+    trace("data made")
+    users = int(data["train"][:, 0].max()) + 1
+    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice="basic_embedding")
+    b, d = pconf.batch_size_p, args.dim
+    mine = partition_links_by_user(data["train"], users, world)[rank].copy()
+    rs = np.random.RandomState(4224 + rank)
+    W, K = args.warmup, args.steps
+    need = (W + K) * b
+    chunks, have = [], 0
+    while have < need:
+        rs.shuffle(mine)
+        chunks.append(mine.copy())
+        have += len(mine)
+    stream = np.concatenate(chunks, 0)[:need]
+    helper = get_data(data, pconf, rand_seed=12345, device=local_rank)
+    md = get_model(pconf, helper, "basic_embedding", device=local_rank, seed=0)   # same seed: identical replicas
+    trace("model built")
+    rep = HipTowerReplica(md, args.scheme)
+    if pconf.word_emb_dropout_rate > 0:
+        rep.tower.set_dropout(pconf.word_emb_dropout_rate, 29 + rank)            # each rank its own row masks
+    tr = DataParallelTower(rep)
+    eng = rep.engine
+    uid, cid = eng.ids(stream[:, 0]), eng.ids(stream[:, 1])
+    losses = torch.zeros(K, dtype=torch.float32, device=eng.device)
+
+    def run(first, count, keep):
+        for t in range(first, first + count):
+            tr.step(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b], losses[t - first:t - first + 1] if keep else None)
+
+    trace("warmup")
+    run(0, W, False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    trace("timed region")
+    t0 = time.perf_counter()
+    run(W, K, True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    trace("timed region done")
+    dist.barrier()
+    t = torch.tensor([t1 - t0], dtype=torch.float64, device=eng.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ml = losses.double().mean()
+    dist.all_reduce(ml)
+    mean_loss = float(ml.item()) / world
+    if not np.isfinite(mean_loss):
+        raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)
+    # roofline leg (all ranks step together; rank 0's brackets are reported)
+    L = args.content_len if not args.small else min(args.content_len, 40)
+    keep = 1.0 - args.dropout
+    name = args.roofline_kernel or "tower_word_kernel"
+    prof_n = min(K, args.profile_launches)
+    nengine.profile_begin(name, prof_n)
+    run(W, prof_n, False)
+    raw_ms, launches, ov_ms = nengine.profile_end()
+    kern_ms = max(raw_ms - ov_ms, 1e-9)
+    work = 4.0 * b * L * d * keep
+    ach = work / (kern_ms * 1e-3) / 1e9
+    if rank == 0:
+        line = {
+            "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links, item text), random-init parameters",
+            "config": {"workload": "CiteULike-a-shaped, basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row "
+                                   "dropout %g, Dense+BN+ReLU) d=%d, train_scheme=%s, loss=%s, b=%d per GPU, sparse SGD"
+                                   % (L, args.vocab, args.dropout, d, args.scheme, pconf.loss, b),
+                       "global_batch": b * world,
+                       "parallelism": "1 process per GPU; users + their links partitioned by user range, text tower "
+                                      "replicated; one RCCL all-reduce of the tower gradients (%.2f MB) per step"
+                                      % (rep.grad.numel() * 4 / 1e6)},
+            "mean_loss": mean_loss,
+            "roofline": {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_per_launch": work,
+                         "algorithmic_what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)",
+                         "kernel_ms": kern_ms, "event_bracket_ms": raw_ms, "empty_bracket_ms": ov_ms, "launches": launches},
+            "cpu_baseline": None,
+        }
+        emit(line)
+    dist.destroy_process_group()
+
+
 def main_sharded(args, conf, rank, world, local_rank):
-    """N > 1: one process per GPU, user/item tables range-sharded, three RCCL all-to-alls per
-    global step (nncf_amd/sharded.py).  Weak scaling: b positives per rank per step."""
+    """N > 1, --model mf: one process per GPU, user/item tables range-sharded, three RCCL all-to-alls
+    per global step (nncf_amd/sharded.py: ShardedNegShared; the north-star's config-4 path).
+    Weak scaling: b positives per rank per step."""
     import torch
     import torch.distributed as dist
     from nncf_amd.sharded import HipBackend, ShardedNegShared, partition_links_by_user, shard_size
     from nncf_amd.synthetic import make_citeulike_like
+    if args.model == "basic_embedding":
+        return main_data_parallel(args, rank, world, local_rank)
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
-    args.model = "mf"  # N > 1: id-table towers (sharded); see DESIGN.md section 6
     conf = conf_for(args)
     data = make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7) if args.small else make_citeulike_like()
     users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
@@ -266,8 +375,8 @@ def main_sharded(args, conf, rank, world, local_rank):
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables",
-            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=mf; the text tower is not "
-                                   "sharded yet) d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
+            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=mf), item table sharded by id "
+                                   "range, d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
                                    % (d, conf.loss, b),
                        "global_batch": b * world,
                        "parallelism": "1 process per GPU; users + their links and item rows range-sharded; "
@@ -301,9 +410,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("NCCL_DEBUG", "WARN")
+        trace("init_process_group")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if dist_on:
         dist.barrier()
+        trace("process group up")
     from nncf_amd.sampler import MultinomialSampler
 
     conf = conf_for(args)

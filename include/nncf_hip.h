@@ -298,6 +298,16 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
                              float* d_v_words, float* d_m_dense, float* d_v_dense);
 int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, void* stream);
 
+/* Data-parallel training (one process per GPU, tower replicated): while d_grad is non-NULL the
+ * backward applies nothing and writes the step's gradients to d_grad -- nncf_tower_grad_floats()
+ * floats: [words (word_count*word_dim) | dense_w (word_dim*item_dim) | dense_b, bn_gamma, bn_beta
+ * (128 each)], every element written, zeros for words outside the batch.  After the all-reduce,
+ * nncf_tower_apply_grads takes the optimiser step with scale * d_grad (step_t: 1-based Adam step,
+ * 0 = the tower's own counter). */
+int64_t nncf_tower_grad_floats(const nncf_tower* t);
+int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad);
+int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream);
+
 /* d_out[m][item_dim] = tower(d_item_ids).  train == 0: inference phase (running statistics, any
  * m).  train != 0: batch statistics over the first *d_n_valid rows (NULL = all m; rows past it
  * come out zero), running statistics updated, m <= max_rows; prepare_backward != 0 also lays out

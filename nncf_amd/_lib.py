@@ -112,6 +112,8 @@ def _declare(lib):
         "nncf_tower_destroy": [vp],
         "nncf_tower_set_learn_rate": [vp, f32],
         "nncf_tower_set_dropout": [vp, f32, u64],
+        "nncf_tower_set_grad_export": [vp, vp],
+        "nncf_tower_apply_grads": [vp, vp, f32, i64, vp],
         "nncf_tower_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],
         "nncf_tower_dropout_scale": [vp, u64, vp, vp],
         "nncf_tower_forward": [vp, vp, i64, vp, i32, i32, vp, vp, vp],
@@ -128,6 +130,8 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
+    lib.nncf_tower_grad_floats.restype = i64
+    lib.nncf_tower_grad_floats.argtypes = [vp]
     lib.nncf_sampler_size.restype = i64
     lib.nncf_sampler_size.argtypes = [vp]
     lib.nncf_scatter_apply_ws_ints.restype = i64

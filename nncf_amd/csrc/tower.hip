@@ -76,6 +76,9 @@ struct TowerArgs {
   AdamTable aw;
   float* mD;
   float* vD;
+  // data-parallel training: if non-NULL the backward applies nothing and writes the gradients
+  // [words (n_words*wd) | dense_w (wd*d) | dense_b, bn_gamma, bn_beta (128 each)] here
+  float* gexp;
 };
 
 __device__ __forceinline__ float adam1(float g, float* m, float* v, float p, const TowerArgs& a) {
@@ -597,14 +600,20 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     if (el < nel) {
       float g = 0.f;
       for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
-      a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
+      if (a.gexp) a.gexp[(size_t)a.n_words * a.wd + el] = g;
+      else a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
     }
     if ((int)blockIdx.x == G && tid < a.d) {
       float gb = 0.f;
       for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
       float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
       if (nfused) merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
-      if (a.opt) {
+      if (a.gexp) {
+        float* gd = a.gexp + (size_t)a.n_words * a.wd + nel;
+        gd[tid] = gb;
+        gd[128 + tid] = t2;
+        gd[256 + tid] = t1;
+      } else if (a.opt) {
         float *mm = a.mD + nel, *vv = a.vD + nel;
         a.bd[tid] = adam1(gb, mm + tid, vv + tid, a.bd[tid], a);
         a.gamma[tid] = adam1(t2, mm + 128 + tid, vv + 128 + tid, a.gamma[tid], a);
@@ -681,6 +690,8 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     drain();
   }
   __syncthreads();
+  if (a.gexp && my_w < a.n_words && lane < d2 && !sHit[wave])
+    reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(0.f, 0.f);
   if (my_w < a.n_words && sHit[wave] && lane < d2) {
     float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
@@ -688,6 +699,11 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane];
       sum.x += t.x;
       sum.y += t.y;
+    }
+    if (a.gexp) {
+      const float gs = word_scale(a, my_w) / (float)a.L;
+      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(gs * sum.x, gs * sum.y);
+      return;
     }
     if (a.opt) {  // gradient = scale[w] / L * sum
       const float gs = word_scale(a, my_w) / (float)a.L;
@@ -706,6 +722,31 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     }
     reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
   }
+}
+
+// Data-parallel training: parameters -= step(scale * g) from an exported (and all-reduced)
+// gradient buffer.  Lazy-sparse Adam skips exactly-zero gradient elements of the word table.
+__global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const float* __restrict__ g, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t nW = (size_t)a.n_words * a.wd, nel = (size_t)a.wd * a.d;
+  if (i < nW) {
+    const float gv = scale * g[i];
+    if (!a.opt) a.W[i] -= a.lr * gv;
+    else if (a.opt == 2 || gv != 0.f) a.W[i] = adam1(gv, a.aw.m + i, a.aw.v + i, a.W[i], a);
+    return;
+  }
+  const size_t j = i - nW;
+  if (j >= nel + 384) return;
+  float* p;
+  if (j < nel) {
+    p = a.Wd + j;
+  } else {
+    const size_t c = (j - nel) & 127, which = (j - nel) >> 7;
+    if ((int)c >= a.d) return;
+    p = (which == 0 ? a.bd : which == 1 ? a.gamma : a.beta) + c;
+  }
+  const float gv = scale * g[i];
+  *p = a.opt ? adam1(gv, a.mD + j, a.vD + j, *p, a) : *p - a.lr * gv;
 }
 
 __global__ void tower_scale_kernel(TowerArgs a, float* __restrict__ out) {
@@ -739,6 +780,7 @@ struct nncf_tower {
   AdamTable aw;
   float *mD = nullptr, *vD = nullptr;
   int32_t* stamps = nullptr;
+  float* gexp = nullptr;
 };
 
 namespace {
@@ -809,8 +851,9 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0) {
   TowerArgs a = t->last;
   a.dA = dA;
-  a.opt = t->opt;
-  if (t->opt) {
+  a.gexp = t->gexp;
+  a.opt = t->gexp ? 0 : t->opt;
+  if (a.opt) {
     const double tt = (double)(step_t > 0 ? step_t : t->adam_t + 1);
     a.beta1 = t->beta1;
     a.beta2 = t->beta2;
@@ -839,13 +882,13 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
-  if (t->opt == 2) {  // dense Adam: words without a gradient this step
+  if (a.opt == 2) {  // dense Adam: words without a gradient this step
     StepArgs sa{};
     sa.stride = a.wd; sa.d = a.wd; sa.beta1 = a.beta1; sa.beta2 = a.beta2; sa.eps = a.aeps; sa.lr_t = a.lr_t;
     sa.step_no = a.step_no;
     if (int rc = launch_adam_idle(sa, a.W, a.aw, a.n_words, st)) return rc;
   }
-  if (t->opt && step_t <= 0) t->adam_t++;
+  if (a.opt && step_t <= 0) t->adam_t++;
   return NNCF_OK;
 }
 
@@ -978,6 +1021,37 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
     hipSetDevice(prev);
     t->aw.stamp = t->stamps;
   }
+  return NNCF_OK;
+}
+
+int64_t nncf_tower_grad_floats(const nncf_tower* t) {
+  return t ? (int64_t)t->cfg.word_count * t->cfg.word_dim + (int64_t)t->cfg.word_dim * t->cfg.item_dim + 384 : 0;
+}
+
+int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  t->gexp = d_grad;
+  return NNCF_OK;
+}
+
+int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream) {
+  NNCF_REQUIRE(t && d_grad, "NULL argument");
+  TowerArgs a = base_args(t);
+  a.opt = t->opt;
+  if (t->opt) {
+    const double tt = (double)(step_t > 0 ? step_t : t->adam_t + 1);
+    a.beta1 = t->beta1; a.beta2 = t->beta2; a.aeps = t->aeps;
+    a.lr_t = (float)((double)a.lr * std::sqrt(1.0 - std::pow((double)t->beta2, tt)) / (1.0 - std::pow((double)t->beta1, tt)));
+    a.step_no = (int)tt;
+    a.aw = t->aw; a.mD = t->mD; a.vD = t->vD;
+    if (step_t <= 0) t->adam_t++;
+  }
+  const int64_t n = nncf_tower_grad_floats(t);
+  {
+    ProfScope _ps("tower_apply_kernel", as_stream(stream));
+    hipLaunchKernelGGL(tower_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, d_grad, scale);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
 

@@ -155,3 +155,62 @@ class ShardedNegShared(object):
         self._a2a(self._g_in, g_out)                               # all-to-all #3: gradients -> owners
         be.scatter_apply(self._req_in, self._g_in)                 # deterministic (rank, slot) order
         return loss
+
+
+# ------------------------------------------------------------------------------------------
+# basic_embedding on several GPUs: data parallel
+# ------------------------------------------------------------------------------------------
+class HipTowerReplica(object):
+    """This rank's replica of a basic_embedding model (user table + text tower) on its GPU,
+    stepping through nncf_tower_step with the tower's gradients exported instead of applied."""
+
+    def __init__(self, model_dict, scheme="neg_shared"):
+        from . import _lib
+        self._lib = _lib
+        key = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]
+        self.head = model_dict[key]
+        self.core, self.scheme = self.head.core, scheme
+        self.engine, self.tower = self.core.engine, self.core.tower
+        L = _lib.lib()
+        n = int(L.nncf_tower_grad_floats(self.tower.handle))
+        self.grad = torch.zeros(n, dtype=torch.float32, device=self.engine.device)
+        _lib.check(L.nncf_tower_set_grad_export(self.tower.handle, ctypes.c_void_p(self.grad.data_ptr())))
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.engine.device)
+
+    def step(self, uid, cid, loss_out=None):
+        return self.core.step(self.scheme, uid, cid, update=True, loss_out=loss_out if loss_out is not None else self._loss)
+
+    def apply(self, scale=1.0):
+        e = self.engine
+        with torch.cuda.device(e.device):
+            self._lib.check(self._lib.lib().nncf_tower_apply_grads(self.tower.handle, ctypes.c_void_p(self.grad.data_ptr()),
+                                                                   float(scale), 0, e._stream()))
+
+
+class DataParallelTower(object):
+    """Synchronous data-parallel SGD for model_choice = basic_embedding (no reference counterpart).
+
+    The model's large state is the user table; the item side is a text tower whose parameters
+    (word table, Dense, BatchNorm: ~3 MB at CiteULike shape) are shared by every item, so item-id
+    sharding has nothing to shard: every rank keeps a replica of the tower.  Users and their links
+    are partitioned by user range (user rows are local, never exchanged).  One global step:
+      1. every rank runs its batch through the whole step (plan, tower forward, U.V^T tile, sparse
+         SGD on its user rows, tower backward) with the tower's gradients written to one flat buffer;
+      2. ONE all-reduce (sum) of that buffer -- the only data-path collective, a real exchange: the
+         parameters are shared;
+      3. every rank applies the summed gradient (same arithmetic on every rank: replicas stay
+         bit-identical).
+    BatchNorm uses each rank's batch statistics (as every data-parallel BN does); running statistics
+    stay local.  Weak scaling: b positives per rank."""
+
+    def __init__(self, replica, group=None):
+        self.be = replica
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def step(self, uid, cid, loss_out=None):
+        loss = self.be.step(uid, cid, loss_out)
+        if self.world > 1:
+            dist.all_reduce(self.be.grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.be.apply(1.0)
+        return loss

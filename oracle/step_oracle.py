@@ -323,6 +323,10 @@ class TowerOracle(object):
             contrib = contrib * c["row_scale"][c["toks"]][..., None]
         np.add.at(dW, c["toks"], contrib.astype(self.dt))
         self.grads = dict(W=dW, Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
+        self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
+        self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
+        if getattr(self, "export_only", False):   # data-parallel: gradients leave, nothing is applied
+            return
         if conf is None or conf.optimizer == "sgd":
             self.W -= self.lr * dW
             self.Wd -= self.lr * dWd
@@ -342,8 +346,23 @@ class TowerOracle(object):
             self.slots["W"].step(self.W, dW, lr_t, conf, rows)
             for k, g in (("Wd", dWd), ("bd", dbd), ("gamma", dgamma), ("beta", dbeta)):
                 self.slots[k].step(getattr(self, k), g.astype(self.dt), lr_t, conf)
-        self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
-        self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
+
+    def flat_grads(self):
+        """[W | Wd | bd, gamma, beta at 128-float pitch] -- the layout of nncf_tower_grad_floats."""
+        g = self.grads
+        pad = lambda v: np.concatenate([v, np.zeros(128 - len(v), dtype=self.dt)])  # noqa: E731
+        return np.concatenate([g["W"].reshape(-1), g["Wd"].reshape(-1), pad(g["bd"]), pad(g["gamma"]),
+                               pad(g["beta"])]).astype(self.dt)
+
+    def apply_flat(self, flat, scale=1.0):
+        """sparse-SGD step with scale * flat (after the data-parallel all-reduce)."""
+        nW, nD, d = self.W.size, self.Wd.size, len(self.bd)
+        f = np.asarray(flat, dtype=self.dt) * self.dt.type(scale)
+        self.W -= self.lr * f[:nW].reshape(self.W.shape)
+        self.Wd -= self.lr * f[nW:nW + nD].reshape(self.Wd.shape)
+        self.bd -= self.lr * f[nW + nD:nW + nD + d]
+        self.gamma -= self.lr * f[nW + nD + 128:nW + nD + 128 + d]
+        self.beta -= self.lr * f[nW + nD + 256:nW + nD + 256 + d]
 
 # ----------------------------------------------------------------------------------------
 # the model: id-table towers ('mf', model_framework.py:59-63,85-88) + sparse SGD

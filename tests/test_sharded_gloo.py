@@ -174,3 +174,101 @@ def test_partition_links_by_user():
     us = shard_size(37, 4)
     for r, p in enumerate(parts):
         assert np.all(p[:, 0] // us == r)
+
+
+# ------------------------------------------------------------------------------------------
+# basic_embedding, data parallel: DataParallelTower over gloo with an oracle-backed replica
+# ------------------------------------------------------------------------------------------
+from nncf_amd.sharded import DataParallelTower  # noqa: E402
+
+TW_ITEMS, TW_L, TW_VOCAB = 50, 6, 30
+
+
+def _tower_setup(seed=3):
+    rs = np.random.RandomState(seed)
+    C = rs.randint(0, TW_VOCAB, (TW_ITEMS, TW_L))
+    W = rs.uniform(-.5, .5, (TW_VOCAB, D)).astype(np.float32)
+    Wd = rs.uniform(-.5, .5, (D, D)).astype(np.float32)
+    U = rs.uniform(-.5, .5, (NU, D)).astype(np.float32)
+    return C, W, Wd, U
+
+
+def _tower_oracle(conf):
+    C, W, Wd, U = _tower_setup()
+    to = so.TowerOracle(C, W, Wd, np.zeros(D, np.float32), np.ones(D, np.float32), np.zeros(D, np.float32), conf.learn_rate,
+                        dtype=np.float32)
+    to.export_only = True
+    return so.StepOracle(U, None, conf, dtype=np.float32, tower=to), to
+
+
+class NumpyTowerReplica(object):
+    """Test double of HipTowerReplica: oracle arithmetic, gradients exported to a flat CPU tensor."""
+
+    def __init__(self, conf):
+        self.orc, self.to = _tower_oracle(conf)
+        self.grad = torch.zeros(self.to.W.size + self.to.Wd.size + 384)
+
+    def step(self, uid, cid, loss_out=None):
+        loss = self.orc.step_neg_shared(uid.numpy(), cid.numpy())
+        self.grad.copy_(torch.from_numpy(self.to.flat_grads()))
+        return torch.tensor([loss])
+
+    def apply(self, scale=1.0):
+        self.to.apply_flat(self.grad.numpy(), scale)
+
+
+def _tower_batches(world, seed=4):
+    rs = np.random.RandomState(seed)
+    us = shard_size(NU, world)
+    return [[(rs.randint(r * us, min(NU, (r + 1) * us), B), rs.randint(0, TW_ITEMS, B)) for _ in range(STEPS)]
+            for r in range(world)]
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conf = so.OracleConf(batch_size_p=B, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.1,
+                         model_choice="basic_embedding")
+    rep = NumpyTowerReplica(conf)
+    tr = DataParallelTower(rep)
+    losses = []
+    for uid, cid in _tower_batches(world)[rank]:
+        losses.append(float(tr.step(torch.from_numpy(uid), torch.from_numpy(cid))[0]))
+    ret[rank] = (rep.orc.U.copy(), {k: getattr(rep.to, k).copy() for k in ("W", "Wd", "bd", "gamma", "beta")}, losses)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_tower_world2():
+    """Two ranks, one all-reduce per step: replicas stay identical and equal a single-process
+    restatement (every rank's gradient from the same pre-step parameters, summed, applied once);
+    user rows are touched only by their owner."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    conf = so.OracleConf(batch_size_p=B, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.1,
+                         model_choice="basic_embedding")
+    reps = [NumpyTowerReplica(conf) for _ in range(world)]
+    batches = _tower_batches(world)
+    losses = [[] for _ in range(world)]
+    for t in range(STEPS):
+        flats = []
+        for r in range(world):
+            losses[r].append(float(reps[r].step(torch.from_numpy(batches[r][t][0]), torch.from_numpy(batches[r][t][1]))[0]))
+            flats.append(reps[r].grad.numpy().copy())
+        total = np.sum(flats, axis=0)
+        for r in range(world):
+            reps[r].to.apply_flat(total)
+    us = shard_size(NU, world)
+    for r in range(world):
+        Ur, params, lr_ = ret[r]
+        np.testing.assert_allclose(lr_, losses[r], rtol=1e-5)
+        for k, v in params.items():
+            np.testing.assert_allclose(v, getattr(reps[r].to, k), rtol=1e-5, atol=1e-6, err_msg=k)
+            np.testing.assert_array_equal(v, ret[0][1][k])                  # replicas bit-identical
+        own = slice(r * us, (r + 1) * us)
+        np.testing.assert_allclose(Ur[own], reps[r].orc.U[own], rtol=1e-5, atol=1e-6)
+        other = np.setdiff1d(np.arange(NU), np.arange(NU)[own])
+        np.testing.assert_array_equal(Ur[other], _tower_setup()[3][other])   # never touched here
