@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the PMC summaries tools/profile_round.sh leaves behind.
+
+    python tools/make_traffic.py <dir with <tag>_*_pmc_fetch.txt / _pmc_write.txt> <tag> <out.json>
+
+bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are KiB per dispatch;
+FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (it counts 32-B requests as
+half of what 16-B/lane coalesced reads move)."""
+import json
+import os
+import sys
+
+# bench key -> (profile name stem, kernel whose traffic bench.py reports)
+CASES = {
+    "basic_embedding/neg_shared/skip-gram/b512/d100": ("basic_embedding_neg_shared", "tower_word_kernel"),
+    "mf/neg_shared/skip-gram/b512/d100": ("mf_neg_shared", "shared_tile_kernel"),
+}
+
+
+def pmc_mean(path, kernel, counter):
+    if not os.path.exists(path):
+        return None
+    seen = False
+    for line in open(path):
+        if line.startswith("# PMC counters"):
+            seen = True
+            continue
+        if seen and kernel in line and counter in line:
+            return float(line.split()[-1])
+    return None
+
+
+def main():
+    d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    table = {}
+    for key, (stem, kernel) in CASES.items():
+        f = pmc_mean(os.path.join(d, "%s_%s_pmc_fetch.txt" % (tag, stem)), kernel, "FETCH_SIZE")
+        w = pmc_mean(os.path.join(d, "%s_%s_pmc_write.txt" % (tag, stem)), kernel, "WRITE_SIZE")
+        if f is None or w is None:
+            continue
+        table[key] = {
+            "kernel": kernel, "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
+            "bytes_per_launch": int(round((2 * f + w) * 1024)),
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes "
+                   "(profiles/%s_%s_pmc_*.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024" % (tag, stem),
+            "round": int(tag.lstrip("r") or 0),
+        }
+    json.dump(table, open(out, "w"), indent=1)
+    print(json.dumps(table, indent=1))
+
+
+if __name__ == "__main__":
+    main()
