@@ -125,3 +125,105 @@ def group_shuffle_train(train, by="item", chop=0, iidx=None, rng=None):
         rng.shuffle(bulk)
         train = np.vstack([bulk.reshape((-1, train.shape[-1])), train[bulk_len:]])
     return train
+
+
+class GroupSampler(object):
+    """First sample a group (item), then its positive members (users); `sample_with_negs` also
+    draws a rounded-in-expectation number of negative members per group
+    (configs/data_utils.py:244-408; used when conf.group_shuffling_trick is False,
+    train_group_neg_shared.py:24-27,56 and train_group_sample.py:30-35).
+
+    RNG streams as in the reference: groups from a B1 sampler over the group column
+    (unigram, power 1, rand_seed 0), negative members from a B1 sampler over the member column,
+    positive members by `np.random.choice(members, chop)` (with replacement) on NumPy's GLOBAL
+    state, random rounding by Python's `random.random()`.  The reference reads
+    `conf.neg_sampling_power` from a module global that does not exist, so the member sampler's
+    power is always the 0.75 fallback (:276-281): kept.
+
+    `sampler_factory(ratings, neg_dist, neg_sampling_power, column, batch_mode)` defaults to
+    `get_sampler` (the HIP sampler); tests inject a CPU checker."""
+
+    def __init__(self, train, group_by="item", chop=1, neg_dist="unigram", neg_sign=0, sampler_factory=None, device=0):
+        if neg_dist == "uniform_no_correction":
+            neg_dist, no_correction = "uniform", True
+        else:
+            no_correction = False
+        self.train, self.group_by, self.chop = train, group_by, int(chop)
+        self.neg_dist, self.neg_sign = neg_dist, neg_sign
+        assert group_by in ("item", "user"), "[ERROR] Illegal group_by {}".format(group_by)
+        gc, mc = (1, 0) if group_by == "item" else (0, 1)
+        if sampler_factory is None:
+            def sampler_factory(ratings, neg_dist, neg_sampling_power, column, batch_mode):
+                return get_sampler(ratings, neg_dist=neg_dist, neg_sampling_power=neg_sampling_power, column=column,
+                                   batch_mode=batch_mode, device=device)
+        self.group_sampler = sampler_factory(train, "unigram", 1.0, gc, True)
+        self.member_neg_sampler = sampler_factory(train, neg_dist, 0.75, mc, True)
+        groups = np.unique(train[:, gc])
+        if neg_dist == "unigram" or no_correction:
+            self.p_n_div_p_d = {int(g): 1.0 for g in groups}
+        elif neg_dist == "uniform":
+            dist = np.bincount(train[:, gc].astype(np.int64), minlength=int(groups.max()) + 1).astype(float)
+            dist /= np.sum(dist)
+            self.p_n_div_p_d = {int(g): 1.0 / len(groups) / dist[int(g)] for g in groups}
+        else:
+            assert False, "[ERROR] Illegal neg_dist {}".format(neg_dist)
+        # members of every group in train order (:300-303)
+        order = np.argsort(train[:, gc], kind="stable")
+        g_sorted, m_sorted = train[order, gc], train[order, mc]
+        starts = np.flatnonzero(np.r_[True, g_sorted[1:] != g_sorted[:-1]])
+        ends = np.r_[starts[1:], len(g_sorted)]
+        self.group_members = {int(g_sorted[s]): m_sorted[s:e] for s, e in zip(starts, ends)}
+
+    def sample(self, batch_size_p, strict_return_shape=True):
+        if strict_return_shape:
+            num_groups = int(np.ceil(float(batch_size_p) / self.chop))
+        else:
+            num_groups = batch_size_p // self.chop
+        sampled_groups = np.asarray(self.group_sampler(num_groups))
+        members = [np.random.choice(self.group_members[int(g)], self.chop) for g in sampled_groups]
+        batch = np.vstack((np.hstack(members), np.repeat(sampled_groups, self.chop))).T
+        batch = np.hstack((batch, np.ones((batch.shape[0], 1), dtype=int)))
+        if self.group_by == "user":
+            batch = batch[:, [1, 0, 2]]
+        return batch[:batch_size_p] if strict_return_shape else batch
+
+    def sample_with_negs(self, batch_size_p, k, strict_return_shape=True):
+        """first ~batch_size_p rows positives (response 1), the rest negatives (response neg_sign)."""
+        import random
+        whole = batch_size_p * (1 + k)
+        if strict_return_shape:
+            num_groups = int(np.ceil(float(batch_size_p) / self.chop))
+        else:
+            num_groups = batch_size_p // self.chop
+        g_pos, m_pos, g_neg, m_neg = [], [], [], []
+
+        def sample_members_for_groups(groups):
+            for g in groups:
+                g = int(g)
+                m_pos.append(np.random.choice(self.group_members[g], self.chop))
+                g_pos.extend([g] * self.chop)
+                x = k * self.chop * self.p_n_div_p_d[g]
+                n_neg = int(x) + (random.random() < x - int(x))   # random rounding (:345)
+                if n_neg > 0:
+                    g_neg.extend([g] * n_neg)
+                    m_neg.append(np.asarray(self.member_neg_sampler(n_neg)))
+
+        sample_members_for_groups(self.group_sampler(num_groups))
+        rounds = 0
+        while strict_return_shape:
+            rounds += 1
+            assert rounds <= 10, "[WARNING] the code here should be optimized if this is shown."
+            size_diff = whole - (len(g_pos) + len(g_neg))
+            if size_diff <= 0:
+                break
+            n_more = size_diff if size_diff <= 100 else size_diff // (self.chop * (1 + k)) + 100
+            sample_members_for_groups(self.group_sampler(n_more))
+        pos = np.vstack((np.hstack(m_pos), g_pos)).T
+        pos = np.hstack((pos, np.ones((pos.shape[0], 1), dtype=int)))
+        neg = np.vstack((np.hstack(m_neg), g_neg)).T
+        neg = np.hstack((neg, self.neg_sign * np.ones((neg.shape[0], 1), dtype=int)))
+        batch = np.vstack((pos, neg))
+        if self.group_by == "user":
+            batch = batch[:, [1, 0, 2]]
+        # the reference's non-strict return names an undefined variable (:408); the batch is meant
+        return batch[:whole] if strict_return_shape else batch

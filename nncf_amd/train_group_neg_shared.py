@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-from .data_utils import group_shuffle_train
+from .data_utils import GroupSampler, group_shuffle_train
 from .train_base import TrainerBase
 
 
@@ -23,9 +23,10 @@ class Trainer(TrainerBase):
         if self.group_shuffling_trick:
             _num_in_train = np.max(data_helper.data["train"], axis=0) + 1
             self._iidx = {"user": np.arange(_num_in_train[0]), "item": np.arange(_num_in_train[1])}
-        else:
-            raise NotImplementedError("group_shuffling_trick=False (GroupSampler, data_utils.py:244-408) is not "
-                                      "built yet; every shipped script sets it True")
+        else:   # train_group_neg_shared.py:24-27
+            self.group_sampler = GroupSampler(data_helper.data["train"], group_by="item", chop=conf.chop_size,
+                                              device=self.model_train.engine.device.index)
+            self.group_sample = self.group_sampler.sample
 
     def train(self, eval_scheme=None, use_async_eval=True):
         conf = self.conf
@@ -36,9 +37,20 @@ class Trainer(TrainerBase):
         self.mean_n_u = []
         for epoch in range(conf.max_epoch + 1):
             cost, it = 0, 0
-            train = group_shuffle_train(train, by="item", chop=conf.chop_size, iidx=self._iidx["item"])
+            in_window = 0.0
             n_steps = len(train) // b if epoch > 0 else 0
-            uid, cid = self._upload(train, n_steps)
+            if self.group_shuffling_trick:
+                train = group_shuffle_train(train, by="item", chop=conf.chop_size, iidx=self._iidx["item"])
+                uid, cid = self._upload(train, n_steps)
+            else:
+                # every batch is drawn from the GroupSampler (:56); the reference draws inside its
+                # timed loop, here the epoch's batches are drawn first (same RNG call order: nothing
+                # else consumes the streams in between) and their cost is added to the window
+                t0 = time.time()
+                rows = [self.group_sample(b) for _ in range(n_steps)]
+                in_window = time.time() - t0
+                rows = np.concatenate(rows, 0) if rows else np.zeros((0, 3), dtype=np.int64)
+                uid, cid = self._upload(rows, n_steps)
             n_u = torch.zeros(max(n_steps, 1), dtype=torch.int32, device=engine.device)
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
@@ -47,7 +59,7 @@ class Trainer(TrainerBase):
                 cost = float(losses.double().sum().item())
                 it = n_steps
             if epoch > 0:
-                self.train_time.append(time.time() - t_start)
+                self.train_time.append(time.time() - t_start + in_window)
                 self.mean_n_u.append(float(n_u[:n_steps].double().mean().item()))
             self._epoch_report(epoch, it, cost, eval_scheme)
         self.data_helper.data["train"] = train

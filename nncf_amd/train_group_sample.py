@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-from .data_utils import group_shuffle_train
+from .data_utils import GroupSampler, group_shuffle_train
 from .train_rowwise import RowwiseTrainer
 
 
@@ -15,8 +15,12 @@ class Trainer(RowwiseTrainer):
     def __init__(self, model_dict, conf, data_helper):
         super(Trainer, self).__init__(model_dict, conf, data_helper)
         assert conf.loss not in ["log-loss", "max-margin"], "[ERROR] group_sample does not support pairwise losses"
-        if not getattr(conf, "group_shuffling_trick", False):
-            raise NotImplementedError("group_shuffling_trick=False (GroupSampler, data_utils.py:244-408) is not built")
+        self.group_shuffling_trick = getattr(conf, "group_shuffling_trick", False)
+        if not self.group_shuffling_trick:   # train_group_sample.py:30-35
+            self.group_sampler = GroupSampler(data_helper.data["train"], group_by="item", chop=conf.chop_size,
+                                              neg_dist=conf.neg_dist, neg_sign=self.neg_sign,
+                                              device=self.model_train.engine.device.index)
+            return
         self.sample_batch = data_helper.sampler_dict["sample_batch"]
         self.sample_batch_u = data_helper.sampler_dict["sample_batch_u"]
         _num_in_train = np.max(data_helper.data["train"], axis=0) + 1
@@ -29,6 +33,12 @@ class Trainer(RowwiseTrainer):
     def build_epoch(self, epoch):
         conf = self.conf
         b, k = conf.batch_size_p, conf.num_negatives
+        if not self.group_shuffling_trick:   # :86-88: every batch straight from the GroupSampler
+            n_steps = len(self.data_helper.data["train"]) // b if epoch > 0 else 0
+            t0 = time.time()
+            rows = [self.group_sampler.sample_with_negs(b, k) for _ in range(n_steps)]
+            rows = np.concatenate(rows, 0) if rows else np.zeros((0, 3), dtype=np.int64)
+            return rows, time.time() - t0
         train = group_shuffle_train(self.data_helper.data["train"], by=self.by, chop=conf.chop_size,
                                     iidx=self._iidx[self.by])
         self.data_helper.data["train"] = train

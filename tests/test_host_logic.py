@@ -119,3 +119,34 @@ def test_synthetic_schema():
         assert np.all(C[r, first_nonzero[r]:] != 0)
     spec = synthetic.data_spec_of(d)
     assert (spec.user_count, spec.item_count, spec.max_content_len) == (300, 200, 12)
+
+
+def test_group_sampler_matches_reference_golden():
+    """nncf_amd.data_utils.GroupSampler against batches the reference's own class produced here
+    (tools/gen_golden_group_sampler.py): same sampler streams (CPU checker of the B1 sampler
+    injected), same NumPy / random seeds -> identical batches."""
+    import random
+    from oracle import sampler_oracle as so
+    from nncf_amd.data_utils import GroupSampler, degree_dist
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "group_sampler_golden.npz"))
+    train = g["train"]
+
+    def factory(ratings, neg_dist, neg_sampling_power, column, batch_mode):
+        s = so.OracleSampler(degree_dist(ratings, column, neg_dist), neg_sampling_power, 0)
+        return s.sample_batch
+
+    names = ["unigram", "uniform", "uniform_no_correction"]
+    for case in range(int(g["n_cases"][0])):
+        chop, nd = [int(x) for x in g["c%d_cfg" % case]]
+        gs = GroupSampler(train, group_by="item", chop=chop, neg_dist=names[nd], neg_sign=-1, sampler_factory=factory)
+        np.random.seed(100 + case)
+        random.seed(200 + case)
+        assert np.array_equal(gs.sample(64), g["c%d_a" % case]), case
+        assert np.array_equal(gs.sample(50), g["c%d_b" % case]), case
+        assert np.array_equal(gs.sample_with_negs(32, 3), g["c%d_c" % case]), case
+        assert np.array_equal(gs.sample_with_negs(40, 2), g["c%d_d" % case]), case
+    gs = GroupSampler(train, group_by="user", chop=3, neg_dist="unigram", neg_sign=0, sampler_factory=factory)
+    np.random.seed(999)
+    random.seed(998)
+    assert np.array_equal(gs.sample(30), g["u_a"])
+    assert np.array_equal(gs.sample_with_negs(30, 2), g["u_c"])

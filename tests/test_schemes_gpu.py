@@ -155,3 +155,56 @@ def test_scheme_trainers_match_oracle_loops(small_data, scheme):
         assert abs(g - w) <= 2e-5 * max(1, abs(w)), (scheme, got, costs)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("scheme", ["group_neg_shared", "group_sample"])
+def test_group_sampler_trainers_match_oracle_loops(small_data, scheme):
+    """group_shuffling_trick = False: every batch comes from GroupSampler (HIP sampler streams +
+    NumPy member draws).  The trainer against the reference's loop written out on the oracle with
+    a CPU GroupSampler fed by the checker sampler: same seeds -> same batches -> same cost."""
+    import random
+    import importlib
+    from nncf_amd.data_utils import GroupSampler
+    loss = "log-loss" if scheme == "group_neg_shared" else "skip-gram"
+    conf = _conf(loss, epochs=2)
+    conf.group_shuffling_trick = False
+    if scheme == "group_neg_shared":
+        conf.num_negatives = 0
+    data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in small_data.items()}
+    helper = get_data(data, conf, reverse_samping=True, rand_seed=3)
+    md = get_model(conf, helper, "mf", seed=4)
+    eng = md["model"].engine
+    oc = _oconf(conf)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), oc, dtype=np.float32)
+    Trainer = importlib.import_module("nncf_amd.train_" + scheme).Trainer
+    np.random.seed(11)
+    random.seed(12)
+    tr = Trainer(md, conf, helper)
+    # the reference seeds these samplers from time(NULL) (rand_seed = 0, nodesampler.cpp:59-60);
+    # pin their LCG states for the comparison
+    tr.group_sampler.group_sampler.__self__.state = 0
+    tr.group_sampler.member_neg_sampler.__self__.state = 0
+    tr.train(None)
+    # the same loop on the oracle
+    def factory(ratings, neg_dist, power, column, batch_mode):
+        return OracleSampler(degree_dist(ratings, column, neg_dist), power, 0).sample_batch
+    neg_sign = -1 if loss == "skip-gram" else 0
+    gs = GroupSampler(small_data["train"], group_by="item", chop=conf.chop_size, neg_dist=conf.neg_dist, neg_sign=neg_sign,
+                      sampler_factory=factory)
+    np.random.seed(11)
+    random.seed(12)
+    b, k = conf.batch_size_p, conf.num_negatives
+    n_steps = len(small_data["train"]) // b
+    for epoch in (1, 2):
+        cost = 0.0
+        for _ in range(n_steps):
+            if scheme == "group_neg_shared":
+                rows = gs.sample(b)
+                cost += orc.step_group_neg_shared(rows[:, 0], rows[:, 1])
+            else:
+                rows = gs.sample_with_negs(b, k)
+                cost += orc.step_original(rows[:, 0], rows[:, 1], rows[:, 2])
+        got = tr.history[epoch][2]
+        assert abs(got - cost / n_steps) <= 2e-5 * max(1, abs(cost / n_steps)), (epoch, got, cost / n_steps)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
