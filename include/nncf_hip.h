@@ -349,6 +349,18 @@ int nncf_step_planned(nncf_model* m, int32_t scheme, const int32_t* d_uid, float
  * d_item_grad[row id][dim] for each row id that occurs in the batch.  NULL restores updates. */
 int nncf_model_set_item_grad_export(nncf_model* m, float* d_item_grad);
 
+/* Device-side stratified shuffle of a link list (group_shuffle_train, configs/data_utils.py:218-241;
+ * "group_shuffling_trick"): rows grouped by item (by_user = 0) or user (1), groups in random order,
+ * rows inside a group in random order; chop > 0: the first floor(n/chop)*chop rows are then cut into
+ * runs of `chop` rows shuffled as units, the tail stays last.  Randomness: counter-based hash of
+ * (seed, index) -- the reference's distribution, not NumPy's stream.  d_perm_out (optional):
+ * source row of every output row.  d_ws: nncf_group_shuffle_ws_bytes(n) bytes of scratch.
+ * n < 2^31.  Inputs and outputs must not alias. */
+int64_t nncf_group_shuffle_ws_bytes(int64_t n);
+int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, int64_t n, int32_t by_user, int32_t chop,
+                       uint64_t seed, int32_t* d_uid_out, int32_t* d_cid_out, int32_t* d_perm_out, void* d_ws,
+                       int64_t ws_bytes, void* stream);
+
 /* Evaluator whole@k for one candidate set (utils/objectives.py:296-370,395-421 +
  * utils/metrics_ranking.py:6-35 eval_multiple).  d_scores: n_users rows of n_cand scores
  * (row_stride floats apart, e.g. from nncf_predict_scores); truth in CSR over candidate slots

@@ -123,6 +123,7 @@ def _declare(lib):
         "nncf_model_set_item_grad_export": [vp, vp],
         "nncf_plan_item_block": [vp, i32, vp, vp, vp, vp, vp],
         "nncf_step_planned": [vp, i32, vp, vp, i32, vp],
+        "nncf_group_shuffle": [vp, vp, i64, i32, i32, u64, vp, vp, vp, vp, i64, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })
@@ -132,6 +133,8 @@ def _declare(lib):
         fn.argtypes = args
     lib.nncf_tower_grad_floats.restype = i64
     lib.nncf_tower_grad_floats.argtypes = [vp]
+    lib.nncf_group_shuffle_ws_bytes.restype = i64
+    lib.nncf_group_shuffle_ws_bytes.argtypes = [i64]
     lib.nncf_sampler_size.restype = i64
     lib.nncf_sampler_size.argtypes = [vp]
     lib.nncf_scatter_apply_ws_ints.restype = i64

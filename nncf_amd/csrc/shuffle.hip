@@ -1,0 +1,144 @@
+// Device-side stratified shuffle: group_shuffle_train (configs/data_utils.py:218-241) for link
+// lists that live in HBM (config 4: 10^9 links; the reference shuffles on the host with NumPy).
+//   1. a uniformly random order of the rows            (np.random.shuffle(train), :232)
+//   2. a STABLE sort by a random key of the row's group (iidx shuffled :231, argsort :234; rows of
+//      one item / user become contiguous, groups in random order, rows inside a group random)
+//   3. chop > 0: the first floor(n / chop) * chop rows are cut into runs of `chop` rows and the
+//      runs are shuffled as units; the ragged tail stays at the end (:235-240)
+// Three radix sorts (rocPRIM through hipCUB) over (key, row index) pairs and one gather.  The
+// random numbers are a counter-based hash of (seed, index): same distribution as the reference,
+// not NumPy's Mersenne stream (whose within-group order is NumPy-build specific anyway: the
+// reference's argsort is unstable).
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace nncf {
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t i) {
+  return (uint32_t)(mix64(seed + i * 0x9E3779B97F4A7C15ull) >> 32);
+}
+
+__global__ void row_keys_kernel(uint64_t seed, int64_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    keys[i] = hash32(seed, (uint64_t)i);
+    vals[i] = (uint32_t)i;
+  }
+}
+
+__global__ void group_keys_kernel(uint64_t seed, int64_t n, const int32_t* __restrict__ group, const uint32_t* __restrict__ rows,
+                                  uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t g = (uint32_t)group[rows[i]];
+    keys[i] = ((uint64_t)hash32(seed, g) << 32) | g;  // equal hash: still one group after the other
+  }
+}
+
+__global__ void run_keys_kernel(uint64_t seed, int64_t n, int64_t bulk, int chop, uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t hi = (i < bulk) ? (uint64_t)(hash32(seed, (uint64_t)(i / chop)) >> 1) : 0x80000000ull;  // tail last
+    keys[i] = (hi << 32) | (uint64_t)i;
+  }
+}
+
+__global__ void gather_links_kernel(int64_t n, const uint32_t* __restrict__ rows, const int32_t* __restrict__ uid,
+                                    const int32_t* __restrict__ cid, int32_t* __restrict__ uid_out,
+                                    int32_t* __restrict__ cid_out, int32_t* __restrict__ perm_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t r = rows[i];
+    uid_out[i] = uid[r];
+    cid_out[i] = cid[r];
+    if (perm_out) perm_out[i] = (int32_t)r;
+  }
+}
+
+struct ShuffleWs {
+  uint32_t *k32a, *k32b, *va, *vb;
+  uint64_t *k64a, *k64b;
+  void* temp;
+  size_t temp_bytes, total;
+};
+
+static ShuffleWs carve_ws(char* base, int64_t n) {
+  ShuffleWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base ? base + off : nullptr;
+    off += bytes;
+    return p;
+  };
+  w.k64a = reinterpret_cast<uint64_t*>(take(8 * (size_t)n));
+  w.k64b = reinterpret_cast<uint64_t*>(take(8 * (size_t)n));
+  w.va = reinterpret_cast<uint32_t*>(take(4 * (size_t)n));
+  w.vb = reinterpret_cast<uint32_t*>(take(4 * (size_t)n));
+  w.k32a = reinterpret_cast<uint32_t*>(w.k64a);  // the 32-bit pass runs before the 64-bit ones
+  w.k32b = reinterpret_cast<uint32_t*>(w.k64b);
+  size_t t32 = 0, t64 = 0;
+  hipcub::DeviceRadixSort::SortPairs(nullptr, t32, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (int)n);
+  hipcub::DeviceRadixSort::SortPairs(nullptr, t64, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                     (uint32_t*)nullptr, (int)n);
+  w.temp_bytes = t32 > t64 ? t32 : t64;
+  w.temp = take(w.temp_bytes);
+  w.total = off + 256;
+  return w;
+}
+
+}  // namespace nncf
+
+using namespace nncf;
+
+extern "C" int64_t nncf_group_shuffle_ws_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return (int64_t)carve_ws(nullptr, n).total;
+}
+
+extern "C" int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, int64_t n, int32_t by_user, int32_t chop,
+                                  uint64_t seed, int32_t* d_uid_out, int32_t* d_cid_out, int32_t* d_perm_out, void* d_ws,
+                                  int64_t ws_bytes, void* stream) {
+  NNCF_REQUIRE(n >= 0 && n < (1ll << 31), "n = %lld out of range", (long long)n);
+  if (n == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_uid && d_cid && d_uid_out && d_cid_out && d_ws, "NULL argument");
+  NNCF_REQUIRE(d_uid != d_uid_out && d_cid != d_cid_out, "in-place shuffle is not supported");
+  NNCF_REQUIRE(chop >= 0, "chop must be >= 0");
+  NNCF_REQUIRE(ws_bytes >= nncf_group_shuffle_ws_bytes(n), "workspace too small: need %lld bytes",
+               (long long)nncf_group_shuffle_ws_bytes(n));
+  hipStream_t st = as_stream(stream);
+  char* base = reinterpret_cast<char*>(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
+  ShuffleWs w = carve_ws(base, n);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  const uint64_t s0 = mix64(seed), s1 = mix64(seed + 1), s2 = mix64(seed + 2);
+  // 1. random row order
+  hipLaunchKernelGGL(row_keys_kernel, dim3(grid), dim3(256), 0, st, s0, n, w.k32a, w.va);
+  size_t tb = w.temp_bytes;
+  NNCF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.k32a, w.k32b, w.va, w.vb, (int)n, 0, 32, st));
+  // 2. stable sort by random group key (rows now in vb)
+  hipLaunchKernelGGL(group_keys_kernel, dim3(grid), dim3(256), 0, st, s1, n, by_user ? d_uid : d_cid, w.vb, w.k64a);
+  tb = w.temp_bytes;
+  NNCF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.k64a, w.k64b, w.vb, w.va, (int)n, 0, 64, st));
+  const uint32_t* rows = w.va;
+  // 3. runs of `chop` rows shuffled as units
+  if (chop > 0) {
+    const int64_t bulk = (n / chop) * chop;
+    hipLaunchKernelGGL(run_keys_kernel, dim3(grid), dim3(256), 0, st, s2, n, bulk, chop, w.k64a);
+    tb = w.temp_bytes;
+    NNCF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(w.temp, tb, w.k64a, w.k64b, w.va, w.vb, (int)n, 0, 64, st));
+    rows = w.vb;
+  }
+  hipLaunchKernelGGL(gather_links_kernel, dim3(grid), dim3(256), 0, st, n, rows, d_uid, d_cid, d_uid_out, d_cid_out, d_perm_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}

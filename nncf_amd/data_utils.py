@@ -127,6 +127,27 @@ def group_shuffle_train(train, by="item", chop=0, iidx=None, rng=None):
     return train
 
 
+def group_shuffle_train_device(uid, cid, by="item", chop=0, seed=0, want_perm=False):
+    """group_shuffle_train for link lists resident in HBM (int32 device tensors uid, cid): three
+    rocPRIM radix sorts + a gather (csrc/shuffle.hip, nncf_group_shuffle).  Same distribution as
+    the host version, its own counter-based random numbers.  Returns (uid', cid'[, perm])."""
+    import ctypes
+    import torch
+    from . import _lib
+    L = _lib.lib()
+    n = uid.numel()
+    assert cid.numel() == n and uid.dtype == torch.int32 and cid.dtype == torch.int32 and uid.is_cuda
+    uo, co = torch.empty_like(uid), torch.empty_like(cid)
+    perm = torch.empty_like(uid) if want_perm else None
+    nbytes = int(L.nncf_group_shuffle_ws_bytes(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=uid.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+    with torch.cuda.device(uid.device):
+        _lib.check(L.nncf_group_shuffle(p(uid), p(cid), n, int(by == "user"), int(chop), int(seed) & (2**64 - 1), p(uo), p(co),
+                                        p(perm), p(ws), nbytes, _lib.stream_ptr(torch.cuda.current_stream(uid.device))))
+    return (uo, co, perm) if want_perm else (uo, co)
+
+
 class GroupSampler(object):
     """First sample a group (item), then its positive members (users); `sample_with_negs` also
     draws a rounded-in-expectation number of negative members per group

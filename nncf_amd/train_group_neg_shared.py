@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-from .data_utils import GroupSampler, group_shuffle_train
+from .data_utils import GroupSampler, group_shuffle_train, group_shuffle_train_device
 from .train_base import TrainerBase
 
 
@@ -39,7 +39,15 @@ class Trainer(TrainerBase):
             cost, it = 0, 0
             in_window = 0.0
             n_steps = len(train) // b if epoch > 0 else 0
-            if self.group_shuffling_trick:
+            if self.group_shuffling_trick and getattr(conf, "device_shuffle", False):
+                # link list stays in HBM: stratified shuffle by rocPRIM sorts (csrc/shuffle.hip)
+                if epoch == 0:
+                    self._dev_links = (
+                        torch.as_tensor(np.ascontiguousarray(train[:, 0]).astype(np.int32)).to(engine.device),
+                        torch.as_tensor(np.ascontiguousarray(train[:, 1]).astype(np.int32)).to(engine.device))
+                uid, cid = group_shuffle_train_device(self._dev_links[0], self._dev_links[1], by="item", chop=conf.chop_size,
+                                                      seed=getattr(conf, "shuffle_seed", 0) * 1000003 + epoch)
+            elif self.group_shuffling_trick:
                 train = group_shuffle_train(train, by="item", chop=conf.chop_size, iidx=self._iidx["item"])
                 uid, cid = self._upload(train, n_steps)
             else:

@@ -102,3 +102,45 @@ def test_seed_zero_is_time_seeded():
     x = s.sample_batch(100)
     assert x.min() >= 0 and x.max() < 10
     s.close()
+
+
+def test_device_group_shuffle_properties():
+    """nncf_group_shuffle: a permutation of the links; chop = 0: every group's rows contiguous, group
+    order and within-group order change with the seed; chop = c: the aligned runs of the chop = 0
+    result (same seed) shuffled as units, ragged tail kept last (data_utils.py:218-241)."""
+    import torch
+    from nncf_amd.data_utils import group_shuffle_train_device
+    rs = np.random.RandomState(0)
+    for n, nu, ni, by in [(20003, 500, 300, "item"), (777, 50, 40, "user"), (5, 3, 2, "item"), (1, 1, 1, "item")]:
+        u = rs.randint(0, nu, n).astype(np.int32)
+        c = (rs.zipf(1.4, n) % ni).astype(np.int32)
+        du, dc = torch.as_tensor(u).cuda(), torch.as_tensor(c).cuda()
+        uo, co, perm = [t.cpu().numpy() for t in group_shuffle_train_device(du, dc, by=by, chop=0, seed=7, want_perm=True)]
+        assert np.array_equal(np.sort(perm), np.arange(n))                       # a permutation ...
+        assert np.array_equal(uo, u[perm]) and np.array_equal(co, c[perm])       # ... applied to both columns
+        g = uo if by == "user" else co
+        starts = np.flatnonzero(np.r_[True, g[1:] != g[:-1]])
+        assert len(starts) == len(np.unique(g))                                   # groups contiguous
+        u2, c2, perm2 = [t.cpu().numpy() for t in group_shuffle_train_device(du, dc, by=by, chop=0, seed=8, want_perm=True)]
+        if n > 100:
+            assert not np.array_equal(perm, perm2)
+            g2 = u2 if by == "user" else c2
+            first = lambda x: x[np.flatnonzero(np.r_[True, x[1:] != x[:-1]])]  # noqa: E731
+            assert not np.array_equal(first(g), first(g2))                        # group order differs
+        for chop in (1, 4, 5):
+            uc, cc, pc = [t.cpu().numpy() for t in group_shuffle_train_device(du, dc, by=by, chop=chop, seed=7, want_perm=True)]
+            bulk = (n // chop) * chop
+            assert np.array_equal(pc[bulk:], perm[bulk:])                         # tail untouched
+            runs0 = perm[:bulk].reshape(-1, chop)
+            runs1 = pc[:bulk].reshape(-1, chop)
+            key = lambda r: tuple(r.tolist())  # noqa: E731
+            assert sorted(map(key, runs0)) == sorted(map(key, runs1))             # same runs, other order
+            if bulk // chop > 20:
+                assert not np.array_equal(runs0, runs1)
+    # uniformity smoke: position of a fixed row inside its group over seeds is spread out
+    u = np.zeros(64, dtype=np.int32)
+    c = np.zeros(64, dtype=np.int32)
+    du, dc = torch.as_tensor(u).cuda(), torch.as_tensor(c).cuda()
+    pos = [int(np.flatnonzero(group_shuffle_train_device(du, dc, seed=s, want_perm=True)[2].cpu().numpy() == 0)[0])
+           for s in range(40)]
+    assert len(set(pos)) > 15
