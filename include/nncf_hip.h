@@ -263,6 +263,13 @@ typedef struct nncf_tower_cfg {
   float bn_eps;
   float bn_momentum;
   float learn_rate;
+  /* cnn_embedding (modules/content/cnn_model.py:11-145, one Convolution1D layer with a single odd
+   * filter length, border_mode 'same', -> BatchNorm over (items, positions) -> relu ->
+   * Dropout(conv_dropout) -> average pooling over the whole length, then the Dense/BN/ReLU tail):
+   * conv_filters > 0 selects it (multiple of 4, <= 128); 0 = the mean-pool tower. */
+  int32_t conv_filters;
+  int32_t filter_len;
+  float conv_dropout;
 } nncf_tower_cfg;
 
 typedef struct nncf_tower_params {
@@ -277,11 +284,24 @@ typedef struct nncf_tower_params {
   const int32_t* item_ptr;
   const int32_t* item_word;
   const uint8_t* item_cnt;
+  /* cnn_embedding only (NULL otherwise) */
+  float* conv_w;   /* [filter_len][word_dim][conv_filters] as Keras stores it; dense_w is then
+                      [conv_filters][item_dim] */
+  float* conv_b;   /* [conv_filters] */
+  float* bn1_gamma;
+  float* bn1_beta;
+  float* bn1_mean;
+  float* bn1_var;
+  const uint8_t* item_spos;   /* [item_count][content_len]: positions of an item's tokens sorted by
+                                 (word, position) */
+  const uint8_t* item_start;  /* per CSR entry: index of its first position in the item's row of item_spos */
 } nncf_tower_params;
 
 int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* params, int device, nncf_tower** out);
 int nncf_tower_destroy(nncf_tower* t);
 int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate);
+/* cnn_embedding: call after the host changed conv_w (the tower keeps a transposed copy). */
+int nncf_tower_sync_params(nncf_tower* t, void* stream);
 /* Embedding(dropout=rate) of Keras 1 (mean_pool.py:56-59; 0.5 in the 'best' preset,
  * basic_embedding_conf.py:112): per train-mode forward a fresh mask drops whole word rows
  * (survivors scaled by 1/(1-rate)).  The mask is a counter-based hash of (seed, forward index,
@@ -293,10 +313,14 @@ int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed);
  * shaped like the word table; d_m_dense / d_v_dense: word_dim*item_dim + 384 floats (dense_w, then
  * dense_b, bn_gamma, bn_beta at 128-float pitch), all zero-initialised.  Mode 1 steps only the
  * word rows that received a gradient; the Dense / BatchNorm parameters always take full Adam
- * steps.  Inside nncf_tower_step / _epoch the model's step counter supplies t. */
+ * steps.  CNN tower: the dense arrays continue with filter_len*word_dim*conv_filters + 384 floats
+ * (conv_w, then conv_b, bn1_gamma, bn1_beta at 128-float pitch); dense_w is conv_filters*item_dim.  Inside nncf_tower_step / _epoch the model's step counter supplies t. */
 int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_words,
                              float* d_v_words, float* d_m_dense, float* d_v_dense);
 int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, void* stream);
+/* CNN tower: the Dropout(conv_dropout) mask (0 or 1/(1-rate)) of the step_index-th train-mode
+ * forward since nncf_tower_set_dropout, for the first m rows: d_out[m][content_len][conv_filters]. */
+int nncf_tower_conv_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d_out, void* stream);
 
 /* Data-parallel training (one process per GPU, tower replicated): while d_grad is non-NULL the
  * backward applies nothing and writes the step's gradients to d_grad -- nncf_tower_grad_floats()

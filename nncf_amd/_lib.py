@@ -52,6 +52,9 @@ class TowerCfg(ctypes.Structure):
         ("bn_eps", ctypes.c_float),
         ("bn_momentum", ctypes.c_float),
         ("learn_rate", ctypes.c_float),
+        ("conv_filters", ctypes.c_int32),
+        ("filter_len", ctypes.c_int32),
+        ("conv_dropout", ctypes.c_float),
     ]
 
 
@@ -59,7 +62,8 @@ class TowerParams(ctypes.Structure):
     """nncf_tower_params (include/nncf_hip.h): borrowed device pointers."""
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "words", "dense_w", "dense_b", "bn_gamma", "bn_beta", "bn_mean", "bn_var",
-        "content", "item_ptr", "item_word", "item_cnt")]
+        "content", "item_ptr", "item_word", "item_cnt",
+        "conv_w", "conv_b", "bn1_gamma", "bn1_beta", "bn1_mean", "bn1_var", "item_spos", "item_start")]
 
 
 LOSS_CODES = {"skip-gram": 0, "mse": 1, "log-loss": 2, "max-margin": 3}
@@ -112,6 +116,8 @@ def _declare(lib):
         "nncf_tower_destroy": [vp],
         "nncf_tower_set_learn_rate": [vp, f32],
         "nncf_tower_set_dropout": [vp, f32, u64],
+        "nncf_tower_sync_params": [vp, vp],
+        "nncf_tower_conv_mask": [vp, u64, i64, vp, vp],
         "nncf_tower_set_grad_export": [vp, vp],
         "nncf_tower_apply_grads": [vp, vp, f32, i64, vp],
         "nncf_tower_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],

@@ -71,6 +71,34 @@ class Conf(object):
                                      "dense_hidden_actv": "relu"}  # :83-86
 
 
+class CnnConf(Conf):
+    """configs/cnn_embedding_conf.py:10-93 (defaults) for model_choice = cnn_embedding."""
+
+    model_choice = "cnn_embedding"
+
+    def __init__(self, data_name, param_dict=None):
+        Conf.__init__(self, data_name, param_dict=None)
+        self.max_epoch = 40
+        self.u_reg = 1e-5
+        # content model related (cnn_embedding_conf.py:41-48)
+        self.num_filters = [50]
+        self.filter_lengths = [[1, 3, 5]]
+        self.poolings = ["average"]
+        self.pool_lengths = [-1]
+        self.conv_dropout_rate = 0.3
+        self.conv_activation = "relu"
+        self.conv_batch_normalization = True
+        if param_dict is not None:
+            self.__dict__.update(param_dict)
+        self.emb_normalization = self.__dict__.get("emb_normalization") if param_dict and "emb_normalization" in param_dict else None
+        self._post_init()
+
+    def _post_init(self):
+        Conf._post_init(self)
+        self.contextual_spatial_gated_input = None
+        self.contextual_temporal_gated_input = None
+
+
 class MfConf(Conf):
     """configs/pretrained_conf.py:10-41 -- the conf main.py uses for model_choice == 'mf' (:48-49)."""
 
@@ -120,7 +148,7 @@ def get_conf(data_name, conf_choice, param_dict=None, model_choice="basic_embedd
     'default': Conf(param_dict).  'best': the citeulike preset (max_epoch 30, u_reg 1e-6,
     num_negatives 10; word dropout 0.5 for the text tower) and -- when param_dict contains
     'reset_after_getconf' -- param_dict applied once more on top (:137-141)."""
-    cls = MfConf if model_choice == "mf" else Conf
+    cls = MfConf if model_choice == "mf" else CnnConf if model_choice == "cnn_embedding" else Conf
     conf_seed, conf_var = _get_conf_base(param_dict)
     if conf_choice == "default":
         conf = cls(data_name, param_dict=param_dict)
@@ -132,6 +160,11 @@ def get_conf(data_name, conf_choice, param_dict=None, model_choice="basic_embedd
         conf.u_reg = 1e-6
         if cls is MfConf:
             conf.interaction_bias = None
+        elif cls is CnnConf:   # cnn_embedding_conf.py:107-130 (citeulike_title_and_abstract)
+            conf.num_filters = [50]
+            conf.word_emb_dropout_rate = 0.5
+            conf.filter_lengths = [3]
+            conf.conv_dropout_rate = 0.1
         else:
             conf.word_emb_dropout_rate = 0.5
         if param_dict is not None and "reset_after_getconf" in param_dict:

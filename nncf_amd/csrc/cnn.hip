@@ -1,0 +1,678 @@
+// Convolutional front of the cnn_embedding item tower (modules/content/cnn_model.py:11-145, the
+// 'best' preset: one Convolution1D layer, filter_lengths [3], cnn_embedding_conf.py:129):
+//   word Embedding (+ row dropout) -> Convolution1D(F, fl, 'same', linear) -> BatchNormalization
+//   over (items, positions) per filter -> relu -> Dropout(conv_dropout) -> AveragePooling1D over
+//   the whole length -> [Dense -> BatchNorm -> ReLU: the tail shared with MeanPool, tower.hip].
+// One workgroup per unique item (per 112 positions in the backward); the convolution is a GEMM
+// [L x fl*wd] . [fl*wd x F] per item on fp32 MFMA (v_mfma_f32_16x16x4_f32) with the gathered word
+// rows of the item staged once in LDS (each shifted tap re-reads them) and the filter fragments
+// held in registers across the item's 13 row tiles.  Per training step:
+//   cnn_conv_fwd    gather (dropped rows never loaded) -> LDS; Y = conv + b -> HBM; per-item sums
+//                   of (y-b), (y-b)^2 per filter; transposes the item's bag of words for the backward
+//   cnn_stats       BatchNorm statistics over n_u*L positions -> mu, inv, mul, add; running stats
+//   cnn_pool_dense  a = relu(y*mul+add) * dropout mask, mean over L -> h; z = h.Wd + bd
+//   (tower tail + step kernels + tower_bwd: dL/dh)
+//   cnn_bwd_sums    per-item sums of da and da*xhat (da = dh/L * mask * [a>0]) -> cnn_merge
+//   cnn_conv_bwd    dY = BN backward of da -> LDS; dX = sum_tap dY(shifted).Wk[tap]^T (MFMA) -> HBM;
+//                   partial dWk[tap] = X(shifted)^T.dY (MFMA) per workgroup
+//   cnn_presum      per item: dX rows summed per distinct word (static sorted-position index)
+//   cnn_update      dWk partials summed in workgroup order; SGD / Adam on Wk (+ transposed copy),
+//                   conv bias, BN1 gamma / beta
+//   tower_word_kernel (tower.hip) then reduces the per-(item, word) rows per word as for MeanPool.
+// Everything has a fixed summation order (no float atomics); conv dropout is a counter-based hash.
+#include "tower.h"
+
+namespace nncf {
+
+__host__ __device__ inline int conv_pitch(int w) { return ((w + 15) & ~15) + 4; }  // floats; rows 16 B apart mod 256 B
+
+__device__ __forceinline__ float conv_keep(const TowerArgs& a, int64_t pos_index, int c) {
+  if (a.cnn.keep >= 1.f) return 1.f;
+  const unsigned long long x = splitmix64(a.cnn.seed + ((unsigned long long)pos_index * 128ull + (unsigned)c) * 0x9E3779B97F4A7C15ull);
+  const float u = (float)(x >> 40) * (1.f / 16777216.f);
+  return u < a.cnn.keep ? 1.f / a.cnn.keep : 0.f;
+}
+
+// tokens of the item + their row-dropout scales -> LDS; gathered (scaled) word rows for positions
+// [p_lo, p_lo + rows) -> sX rows (zero outside [0, L) and past wd)
+__device__ __forceinline__ void stage_tokens(const TowerArgs& a, int item, int* sTok, float* sSc) {
+  const int tid = threadIdx.x;
+  if (tid < a.L) {
+    const int tk = a.content[(int64_t)item * a.L + tid];
+    sTok[tid] = tk;
+    sSc[tid] = a.train ? word_scale(a, tk) : 1.f;
+  }
+}
+__device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, const float* sSc, float* sX, int XP,
+                                           int p_lo, int rows) {
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, wd4 = a.wd >> 2, xp4 = XP >> 2;
+  for (int r0 = grp; r0 < rows; r0 += 64) {  // 4 rows of this group in flight
+    Row v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = r0 + 16 * e, p = p_lo + r;
+      const bool ok = r < rows && p >= 0 && p < a.L && sSc[p >= 0 && p < a.L ? p : 0] != 0.f;
+      v[e] = ok ? row_scale(row_load(a.W, sTok[p], a.wd, wd4, q), sSc[p]) : row_zero();
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = r0 + 16 * e;
+      if (r < rows) {
+        float4* dst = reinterpret_cast<float4*>(sX + (int64_t)r * XP);
+        if (q < xp4) dst[q] = v[e].a;  // chunks past wd are the zeros row_load produced
+        if (q + 16 < xp4) dst[q + 16] = v[e].b;
+      }
+    }
+  }
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int sTok[256];
+  __shared__ float sSc[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, kq = lane >> 4;
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  const int item = a.ids[s];
+  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L;
+  const int XP = conv_pitch(a.wd);
+  const int nMt = (L + 15) >> 4, nKt = (a.wd + 15) >> 4, nNt = (F + 15) >> 4;
+  const int rows = 16 * nMt + fl - 1;
+  float* sX = smem;
+  stage_tokens(a, item, sTok, sSc);
+  // backward preparation: cnt_t[w][s] = 1 + ordinal of word w among the item's distinct words
+  if (a.fill) {
+    const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
+    for (int e = e0 + tid; e < e1; e += 256) {
+      const int wv = a.item_word[e];
+      if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = (uint8_t)(e - e0 + 1);
+    }
+  }
+  __syncthreads();
+  stage_rows(a, sTok, sSc, sX, XP, -pad, rows);
+  __syncthreads();
+  const int KW = fl * a.wd;
+  for (int nt = wave; nt < nNt; nt += 4) {
+    const int col = nt * 16 + x;
+    f32x4 acc[16];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < fl; ++tap) {
+      // B fragments of this tap: Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e
+      // of the float4 at column 16t+4kq serves k-step (t, e) on both operands)
+      float4 bf[8];
+      const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c0 = 16 * t + 4 * kq;
+        bf[t] = (t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
+      }
+#pragma unroll
+      for (int mt = 0; mt < 16; ++mt) {
+        if (mt < nMt) {
+          const float* arow = sX + (int64_t)(16 * mt + x + tap) * XP + 4 * kq;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            if (t < nKt) {
+              const float4 af = *reinterpret_cast<const float4*>(arow + 16 * t);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[t].x, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[t].y, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[t].z, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[t].w, acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // epilogue: D[i = 4kq + r][j = x] -> Y[s][p = 16mt + i][col]; statistics of (y - b)
+    const float bias = col < F ? a.cnn.bc[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) {
+      if (mt < nMt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * mt + 4 * kq + r;
+          if (p < L && col < F) {
+            const float v = acc[mt][r];
+            a.cnn.Y[((int64_t)s * L + p) * F + col] = v + bias;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 16);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    if (kq == 0 && a.train) {
+      a.cnn.part1[(int64_t)s * 256 + col] = s1;
+      a.cnn.part1[(int64_t)s * 256 + 128 + col] = s2;
+    }
+  }
+}
+
+// column totals of per-slot partials [n][2][128] in slot order (1024 threads: 8 slot groups x 128)
+__device__ __forceinline__ void merge_slot_partials(const float* part, int n, float* sRed, float& t1, float& t2) {
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+  float a1 = 0.f, a2 = 0.f;
+  for (int s0 = g; s0 < n; s0 += 8 * 8) {
+    float u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int s = s0 + 8 * e;
+      u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
+      u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a1 += u1[e];
+      a2 += u2[e];
+    }
+  }
+  sRed[(g * 2 + 0) * 128 + c] = a1;
+  sRed[(g * 2 + 1) * 128 + c] = a2;
+  __syncthreads();
+  t1 = 0.f;
+  t2 = 0.f;
+  if (threadIdx.x < 128) {
+    for (int gg = 0; gg < 8; ++gg) {
+      t1 += sRed[(gg * 2 + 0) * 128 + c];
+      t2 += sRed[(gg * 2 + 1) * 128 + c];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
+  __shared__ float sRed[8 * 2 * 128];
+  const int nv = valid_rows(a), c = threadIdx.x;
+  float t1, t2;
+  merge_slot_partials(a.cnn.part1, nv, sRed, t1, t2);
+  if (c < 128) {
+    float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
+    if (c < a.cnn.F) {
+      const float rn = 1.f / (float)max(nv * a.L, 1);
+      const float m1 = t1 * rn;
+      mu = a.cnn.bc[c] + m1;
+      var = fmaxf(t2 * rn - m1 * m1, 0.f);
+      inv = rsqrtf(var + a.eps);
+      mul = a.cnn.g1[c] * inv;
+      add = a.cnn.b1[c] - mu * mul;
+      a.cnn.rm1[c] = a.momentum * a.cnn.rm1[c] + (1.f - a.momentum) * mu;
+      a.cnn.rv1[c] = a.momentum * a.cnn.rv1[c] + (1.f - a.momentum) * var;
+    }
+    a.cnn.st1[c] = mu;
+    a.cnn.st1[128 + c] = inv;
+    a.cnn.st1[256 + c] = var;
+    a.cnn.st1[384 + c] = mul;
+    a.cnn.st1[512 + c] = add;
+  }
+}
+
+// a = relu(y*mul+add) * dropout, mean over the L positions -> h[s]; z[s] = h[s].Wd + bd
+// (train) or E[s] = relu(BN_running(z[s])) (inference).
+__global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
+  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ __attribute__((aligned(16))) float sH[kTP];
+  __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
+  __shared__ float sMul[128], sAdd[128];
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
+  const int F = a.cnn.F, f4 = F >> 2, d4 = a.d >> 2, L = a.L;
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  const int c4 = tid & 31, kp = tid >> 5, kper = (F + 7) >> 3;
+  float4 w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = kp * kper + i;
+    w[i] = (i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+  }
+  if (tid < 128) {
+    float mul = 0.f, add = 0.f;
+    if (tid < F) {
+      if (a.train) {
+        mul = a.cnn.st1[384 + tid];
+        add = a.cnn.st1[512 + tid];
+      } else {
+        mul = a.cnn.g1[tid] * rsqrtf(a.cnn.rv1[tid] + a.eps);
+        add = a.cnn.b1[tid] - a.cnn.rm1[tid] * mul;
+      }
+    }
+    sMul[tid] = mul;
+    sAdd[tid] = add;
+  }
+  __syncthreads();
+  Row acc = row_zero();
+  const bool drop = a.train && a.cnn.keep < 1.f;
+  for (int p0 = grp; p0 < L; p0 += 64) {
+    Row y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = p0 + 16 * e;
+      if (p < L) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = col_of(q, k);
+          float v = fmaxf(fmaf(relem(y[e], k), sMul[c], sAdd[c]), 0.f);
+          if (drop && v != 0.f) v *= conv_keep(a, (int64_t)s * L + p, c);
+          relem(acc, k) += v;
+        }
+      }
+    }
+  }
+  reinterpret_cast<float4*>(sR + grp * kTP)[q] = acc.a;
+  reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = acc.b;
+  __syncthreads();
+  if (grp == 0) {
+    Row sum = row_zero();
+    for (int g = 0; g < 16; ++g) {
+      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
+      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+    }
+    sum = row_scale(sum, 1.f / (float)L);
+    if (a.train) row_store(a.h, s, F, f4, q, sum);
+    reinterpret_cast<float4*>(sH)[q] = sum.a;
+    reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
+  }
+  __syncthreads();
+  float4 part = zero4();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = kp * kper + i;
+    if (i < kper && k < F) part = fma4(sH[k], w[i], part);
+  }
+  sP[kp * 32 + c4] = part;
+  __syncthreads();
+  if (tid < d4) {
+    float4 z = reinterpret_cast<const float4*>(a.bd)[tid];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) z = add4(z, sP[p * 32 + tid]);
+    if (a.train) {
+      reinterpret_cast<float4*>(a.z + (int64_t)s * a.d)[tid] = z;
+    } else {
+      const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
+      const float4 mu = reinterpret_cast<const float4*>(a.rm)[tid], var = reinterpret_cast<const float4*>(a.rv)[tid];
+      float4 o;
+      o.x = fmaxf(g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x, 0.f);
+      o.y = fmaxf(g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y, 0.f);
+      o.z = fmaxf(g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z, 0.f);
+      o.w = fmaxf(g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w, 0.f);
+      reinterpret_cast<float4*>(a.E + (int64_t)s * a.d)[tid] = o;
+    }
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------
+
+// da[p][c] = dh[s][c] / L * dropout(s, p, c) * [y*mul+add > 0]
+__device__ __forceinline__ float conv_da(const TowerArgs& a, float dhc, float pre, int64_t pos_index, int c) {
+  if (!(pre > 0.f) || dhc == 0.f) return 0.f;
+  return dhc * conv_keep(a, pos_index, c);
+}
+
+__global__ void __launch_bounds__(256) cnn_bwd_sums_kernel(TowerArgs a) {
+  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128];
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, F = a.cnn.F, f4 = F >> 2, L = a.L;
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  if (tid < 128) {
+    sMu[tid] = a.cnn.st1[tid];
+    sInv[tid] = a.cnn.st1[128 + tid];
+    sMul[tid] = a.cnn.st1[384 + tid];
+    sAdd[tid] = a.cnn.st1[512 + tid];
+  }
+  const Row dhr = row_scale(row_load(a.dh, s, F, f4, q), 1.f / (float)L);
+  __syncthreads();
+  Row s1 = row_zero(), s2 = row_zero();
+  for (int p0 = grp; p0 < L; p0 += 64) {
+    Row y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p = p0 + 16 * e;
+      if (p < L) {
+        Row dd = dhr;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int c = col_of(q, k);
+          const float yv = relem(y[e], k);
+          const float da = conv_da(a, relem(dd, k), fmaf(yv, sMul[c], sAdd[c]), (int64_t)s * L + p, c);
+          relem(s1, k) += da;
+          relem(s2, k) += da * (yv - sMu[c]) * sInv[c];
+        }
+      }
+    }
+  }
+  float* out = a.cnn.bpart + (int64_t)s * 256;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    reinterpret_cast<float4*>(sR + grp * kTP)[q] = half ? s2.a : s1.a;
+    reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = half ? s2.b : s1.b;
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+      for (int g = 0; g < 16; ++g) t += sR[g * kTP + tid];
+      out[half * 128 + tid] = t;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
+  __shared__ float sRed[8 * 2 * 128];
+  float t1, t2;
+  merge_slot_partials(a.cnn.bpart, valid_rows(a), sRed, t1, t2);
+  if (threadIdx.x < 128) {
+    a.cnn.st1[640 + threadIdx.x] = t1;  // sum da        (= dbeta1)
+    a.cnn.st1[768 + threadIdx.x] = t2;  // sum da*xhat   (= dgamma1)
+  }
+}
+
+// One workgroup per (slot, block of kConvLB positions).
+__global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int sTok[256];
+  __shared__ float sSc[256];
+  __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128], sS1[128], sS2[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, kq = lane >> 4;
+  const int grp = tid >> 4, q = tid & 15;
+  const int s = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int nv = valid_rows(a);
+  if (s >= nv) return;
+  const int item = a.ids[s];
+  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, f4 = F >> 2;
+  const int XP = conv_pitch(a.wd), FP = conv_pitch(F);
+  const int p0 = blk * kConvLB;
+  const int rows = kConvLB + fl - 1;       // positions [p0 - pad, p0 + kConvLB + pad)
+  float* sX = smem;                        // [rows][XP]  gathered (scaled) word rows
+  float* sD = smem + (int64_t)rows * XP;   // [rows][FP]  dY
+  stage_tokens(a, item, sTok, sSc);
+  if (tid < 128) {
+    sMu[tid] = a.cnn.st1[tid];
+    sInv[tid] = a.cnn.st1[128 + tid];
+    sMul[tid] = a.cnn.st1[384 + tid];
+    sAdd[tid] = a.cnn.st1[512 + tid];
+    sS1[tid] = a.cnn.st1[640 + tid];
+    sS2[tid] = a.cnn.st1[768 + tid];
+  }
+  const Row dhr = row_scale(row_load(a.dh, s, F, f4, q), 1.f / (float)L);
+  __syncthreads();
+  stage_rows(a, sTok, sSc, sX, XP, p0 - pad, rows);
+  // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
+  {
+    const float N = (float)nv * (float)L, rN = 1.f / N;
+    const int fp4 = FP >> 2;
+    for (int r0 = grp; r0 < rows; r0 += 64) {
+      Row y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = r0 + 16 * e, p = p0 - pad + r;
+        y[e] = (r < rows && p >= 0 && p < L) ? row_load(a.cnn.Y, (int64_t)s * L + p, F, f4, q) : row_zero();
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = r0 + 16 * e, p = p0 - pad + r;
+        if (r < rows) {
+          Row o = row_zero();
+          if (p >= 0 && p < L) {
+            Row dd = dhr;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int c = col_of(q, k);
+              const float yv = relem(y[e], k);
+              const float da = conv_da(a, relem(dd, k), fmaf(yv, sMul[c], sAdd[c]), (int64_t)s * L + p, c);
+              relem(o, k) = sMul[c] * rN * (N * da - sS1[c] - (yv - sMu[c]) * sInv[c] * sS2[c]);
+            }
+          }
+          float4* dst = reinterpret_cast<float4*>(sD + (int64_t)r * FP);
+          if (q < fp4) dst[q] = o.a;  // mul = 0 past F: those columns are exactly 0
+          if (q + 16 < fp4) dst[q + 16] = o.b;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nMb = kConvLB / 16;
+  // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ------------------------
+  {
+    const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
+    for (int kt = wave; kt < nKw; kt += 4) {
+      const int kcol = kt * 16 + x;
+      f32x4 acc[kConvLB / 16];
+#pragma unroll
+      for (int mt = 0; mt < nMb; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tap = 0; tap < fl; ++tap) {
+        float4 bf[8];
+        const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wk + ((int64_t)tap * a.wd + kcol) * F);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const int c0 = 16 * t + 4 * kq;
+          bf[t] = (t < nFt && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
+        }
+#pragma unroll
+        for (int mt = 0; mt < nMb; ++mt) {
+          const float* arow = sD + (int64_t)(16 * mt + x + (fl - 1 - tap)) * FP + 4 * kq;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            if (t < nFt) {
+              const float4 af = *reinterpret_cast<const float4*>(arow + 16 * t);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[t].x, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[t].y, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[t].z, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[t].w, acc[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < nMb; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = p0 + 16 * mt + 4 * kq + r;
+          if (p < L && kcol < a.wd) a.cnn.dX[((int64_t)s * L + p) * a.wd + kcol] = acc[mt][r] * sSc[p];
+        }
+      }
+    }
+  }
+  // ---- (b) partial dWk[tap][k][f] = sum_{p in block} X[p + tap - pad][k] dY[p][f] --------------
+  {
+    const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
+    const int ntile = fl * nKw * nFt;
+    float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
+    for (int tt = wave; tt < ntile; tt += 4) {
+      const int tap = tt / (nKw * nFt), kt = (tt / nFt) % nKw, ft = tt % nFt;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* pa = sX + (int64_t)(kq + tap) * XP + kt * 16 + x;   // position p0 + 4st + kq, shifted by the tap
+      const float* pb = sD + (int64_t)(kq + pad) * FP + ft * 16 + x;
+#pragma unroll 4
+      for (int st = 0; st < kConvLB / 4; ++st)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[(int64_t)4 * st * XP], pb[(int64_t)4 * st * FP], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWk[tap][kt*16 + i][ft*16 + x]
+        const int k = kt * 16 + 4 * kq + r, f = ft * 16 + x;
+        if (k < a.wd && f < F) gw[((int64_t)tap * a.wd + k) * F + f] = acc[r];
+      }
+    }
+    if (tid < 128) {  // column sums of dY over the block's own positions (conv bias gradient)
+      float t = 0.f;
+      if (tid < F)
+        for (int r = pad; r < pad + kConvLB; ++r) t += sD[(int64_t)r * FP + tid];
+      a.cnn.gbpart[(int64_t)blockIdx.x * 128 + tid] = t;
+    }
+  }
+}
+
+// per item: rows of dX summed per distinct word, through the static sorted-position index
+__global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, wd4 = a.wd >> 2, L = a.L;
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  const int item = a.ids[s];
+  const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
+  const uint8_t* spos = a.cnn.item_spos + (int64_t)item * L;
+  for (int e = e0 + grp; e < e1; e += 16) {
+    const int start = a.cnn.item_start[e], cnt = a.item_cnt[e];
+    Row sum = row_zero();
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      Row r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        r[u] = (t0 + u < cnt) ? row_load(a.cnn.dX, (int64_t)s * L + spos[start + t0 + u], a.wd, wd4, q) : row_zero();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sum = row_add(sum, r[u]);
+    }
+    row_store(a.cnn.dXw, (int64_t)s * L + (e - e0), a.wd, wd4, q, sum);
+  }
+}
+
+__global__ void __launch_bounds__(256) cnn_update_kernel(TowerArgs a, int nblk) {
+  const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
+  const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x blocks, contiguous
+  const int nb = (nel + 255) / 256;
+  if ((int)blockIdx.x < nb) {
+    const int el = blockIdx.x * 256 + threadIdx.x;
+    if (el >= nel) return;
+    float g = 0.f;
+    for (int p0 = 0; p0 < nparts; p0 += 16) {  // partials in workgroup order, 16 loads in flight
+      float u[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = (p0 + e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + e) * nel + el] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) g += u[e];
+    }
+    const float nw = a.opt ? adam1(g, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * g;
+    a.cnn.Wk[el] = nw;
+    const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
+    a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + k] = nw;
+    return;
+  }
+  const int c = threadIdx.x;
+  if (c >= F) return;
+  float gb = 0.f;
+  for (int p = 0; p < nparts; ++p) gb += a.cnn.gbpart[(int64_t)p * 128 + c];
+  const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
+  if (a.opt) {
+    float *mm = a.cnn.mC + nel, *vv = a.cnn.vC + nel;
+    a.cnn.bc[c] = adam1(gb, mm + c, vv + c, a.cnn.bc[c], a);
+    a.cnn.g1[c] = adam1(d2, mm + 128 + c, vv + 128 + c, a.cnn.g1[c], a);
+    a.cnn.b1[c] = adam1(d1, mm + 256 + c, vv + 256 + c, a.cnn.b1[c], a);
+  } else {
+    a.cnn.bc[c] -= a.lr * gb;
+    a.cnn.g1[c] -= a.lr * d2;
+    a.cnn.b1[c] -= a.lr * d1;
+  }
+}
+
+__global__ void cnn_transpose_kernel(CnnArgs c, int wd) {
+  const int nel = c.fl * wd * c.F, el = blockIdx.x * blockDim.x + threadIdx.x;
+  if (el < nel) {
+    const int f = el % c.F, k = (el / c.F) % wd, tap = el / (c.F * wd);
+    c.Wt[(int64_t)f * c.fl * wd + tap * wd + k] = c.Wk[el];
+  }
+}
+
+__global__ void cnn_mask_kernel(TowerArgs a, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = conv_keep(a, i / a.cnn.F, (int)(i % a.cnn.F));
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+static int conv_blocks(int L) { return (L + kConvLB - 1) / kConvLB; }
+
+size_t cnn_carve(nncf_tower* t, Carver& c) {
+  const int64_t cap = t->cfg.max_rows, L = t->cfg.content_len, wd = t->cfg.word_dim, F = t->cfg.conv_filters;
+  const int64_t fl = t->cfg.filter_len, nblk = conv_blocks((int)L);
+  CnnArgs& a = t->cnn;
+  a.Wt = c.take<float>(F * fl * wd);
+  a.Y = c.take<float>(cap * L * F);
+  a.dX = c.take<float>(cap * L * wd);
+  a.dXw = c.take<float>(cap * L * wd);
+  a.part1 = c.take<float>(cap * 256);
+  a.st1 = c.take<float>(7 * 128);
+  a.bpart = c.take<float>(cap * 256);
+  a.gWpart = c.take<float>(cap * nblk * fl * wd * F);
+  a.gbpart = c.take<float>(cap * nblk * 128);
+  return c.off;
+}
+
+int cnn_sync_weights(nncf_tower* t, hipStream_t st) {
+  const int nel = t->cnn.fl * t->cfg.word_dim * t->cnn.F;
+  hipLaunchKernelGGL(cnn_transpose_kernel, dim3((nel + 255) / 256), dim3(256), 0, st, t->cnn, t->cfg.word_dim);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+static int set_lds(const void* fn, size_t bytes) {
+  NNCF_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NNCF_OK;
+}
+
+int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  const int L = a.L, fl = a.cnn.fl;
+  const size_t lds = (size_t)(16 * ((L + 15) / 16) + fl - 1) * conv_pitch(a.wd) * sizeof(float);
+  NNCF_REQUIRE(lds <= 150 * 1024, "content_len x word_dim tile of %zu bytes exceeds the LDS", lds);
+  if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel), lds)) return rc;
+  {
+    ProfScope _ps("cnn_conv_fwd_kernel", st);
+    hipLaunchKernelGGL(cnn_conv_fwd_kernel, dim3((unsigned)a.m), dim3(256), lds, st, a);
+  }
+  if (a.train) {
+    ProfScope _ps("cnn_stats_kernel", st);
+    hipLaunchKernelGGL(cnn_stats_kernel, dim3(1), dim3(1024), 0, st, a);
+  }
+  {
+    ProfScope _ps("cnn_pool_dense_kernel", st);
+    hipLaunchKernelGGL(cnn_pool_dense_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+// after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) rows
+int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  const int nblk = conv_blocks(a.L), fl = a.cnn.fl;
+  const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch(a.wd) + conv_pitch(a.cnn.F)) * sizeof(float);
+  NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tile of %zu bytes exceeds the LDS", lds);
+  if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_bwd_kernel), lds)) return rc;
+  {
+    ProfScope _ps("cnn_bwd_sums_kernel", st);
+    hipLaunchKernelGGL(cnn_bwd_sums_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  }
+  {
+    ProfScope _ps("cnn_merge_kernel", st);
+    hipLaunchKernelGGL(cnn_merge_kernel, dim3(1), dim3(1024), 0, st, a);
+  }
+  {
+    ProfScope _ps("cnn_conv_bwd_kernel", st);
+    hipLaunchKernelGGL(cnn_conv_bwd_kernel, dim3((unsigned)(a.m * nblk)), dim3(256), lds, st, a, nblk);
+  }
+  {
+    ProfScope _ps("cnn_presum_kernel", st);
+    hipLaunchKernelGGL(cnn_presum_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  }
+  {
+    ProfScope _ps("cnn_update_kernel", st);
+    const int nel = fl * a.wd * a.cnn.F;
+    hipLaunchKernelGGL(cnn_update_kernel, dim3((nel + 255) / 256 + 1), dim3(256), 0, st, a, nblk);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int cnn_mask(nncf_tower* t, TowerArgs& a, int64_t m, float* out, hipStream_t st) {
+  const int64_t n = m * a.L * a.cnn.F;
+  hipLaunchKernelGGL(cnn_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n, out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+
+}  // namespace nncf

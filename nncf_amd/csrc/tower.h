@@ -1,0 +1,186 @@
+// Shared declarations of the item-tower kernels (tower.hip: mean-pool tower and the common
+// Dense / BatchNorm / ReLU tail; cnn.hip: the convolutional front of cnn_embedding).
+#pragma once
+#include <cmath>
+
+#include "common.h"
+#include "devutil.h"
+#include "model.h"
+#include "step.h"
+
+namespace nncf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTP = 128;       // LDS pitch of pooled rows
+constexpr int kZP = 132;       // LDS pitch of dz rows (16-byte aligned, 4 banks apart)
+constexpr int kTowerWG = 64;   // at most this many workgroups emit statistics partials
+constexpr int kRowsPerK = 1024;  // rows per K-part of the weight-gradient tiles
+
+// Convolutional front of the cnn_embedding tower (cnn.hip); F == 0: mean-pool tower.
+struct CnnArgs {
+  int F, fl;                 // filters, filter length (odd)
+  float keep;                // Dropout(conv_dropout_rate) retain probability (1 = off)
+  unsigned long long seed;   // this step's conv-dropout seed
+  float* Wk;                 // [fl][wd][F]   Keras layout (fl, 1, wd, F)
+  float* Wt;                 // [F][fl*wd]    transposed copy (owned by the tower)
+  float *bc, *g1, *b1, *rm1, *rv1;
+  float* Y;                  // [m*L][F]      conv output before BatchNorm
+  float* dX;                 // [m*L][wd]     dL/d(word row at every position), dropout scale applied
+  float* dXw;                // [m*L][wd]     the same summed per (slot, distinct word)
+  float* part1;              // [m][2][128]   per-slot sums of (y-b), (y-b)^2
+  float* st1;                // 7 x 128: mu, inv, var, mul, add, sum da, sum da*xhat
+  float* bpart;              // [m][2][128]
+  float* gWpart;             // [m*nblk][fl*wd*F]
+  float* gbpart;             // [m*nblk][128]
+  const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)
+  const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
+  float *mC, *vC;            // Adam moments of [Wk | bc, g1, b1 (128 each)]
+};
+constexpr int kConvLB = 112;  // positions per workgroup of the conv backward
+
+struct TowerArgs {
+  // parameters
+  float* W;      // [n_words][wd]
+  float* Wd;     // [wd][d]
+  float* bd;
+  float* gamma;
+  float* beta;
+  float* rm;
+  float* rv;
+  const int32_t* content;    // [item_count][L]
+  const int32_t* item_ptr;   // CSR of the content matrix: item -> (word, count) pairs
+  const int32_t* item_word;
+  const uint8_t* item_cnt;
+  const float* scale;        // per-word row-dropout scale (Embedding(dropout=...), :56-59) or NULL
+  // per call
+  const int32_t* ids;        // [m] item ids of the block's rows
+  const int32_t* n_valid;    // rows [0, *n_valid) are real; NULL = all m
+  float* h;                  // [m][wd]
+  float* z;                  // [m][d]
+  float* E;                  // [m][d]
+  const float* dA;           // [m][d]
+  float* dh;                 // [m][wd]
+  float* ws;
+  uint8_t* cnt_t;            // [n_words][cap] word-major token counts of the batch (all-zero between steps)
+  int m, wd, d, L, cap, n_words, train, fill;
+  int hd;          // width of the pooled block h = input width of the Dense layer (wd, or the conv filters)
+  int skip_words;  // tower_word_kernel: only the Dense / BN parameter update blocks run
+  float eps, momentum, lr;
+  float keep;                    // row-dropout retain probability (1 = off)
+  unsigned long long drop_seed;  // this step's mask seed
+  // optimiser (StepArgs::opt): Adam state of the word table and of the packed dense parameters
+  // [Wd (wd*d) | bd (128) | gamma (128) | beta (128)]
+  int opt, step_no;
+  float lr_t, beta1, beta2, aeps;
+  AdamTable aw;
+  float* mD;
+  float* vD;
+  // data-parallel training: if non-NULL the backward applies nothing and writes the gradients
+  // [words (n_words*wd) | dense_w (wd*d) | dense_b, bn_gamma, bn_beta (128 each)] here
+  float* gexp;
+  CnnArgs cnn;
+};
+
+__device__ __forceinline__ float adam1(float g, float* m, float* v, float p, const TowerArgs& a) {
+  const float mm = fmaf(a.beta1, *m, (1.f - a.beta1) * g), vv = fmaf(a.beta2, *v, (1.f - a.beta2) * g * g);
+  *m = mm;
+  *v = vv;
+  return p - a.lr_t * mm / (sqrtf(vv) + a.aeps);
+}
+
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// Embedding(dropout = 1 - keep) of Keras 1 (mean_pool.py:56-59): whole word rows are dropped
+// per batch, survivors scaled by 1/keep.  The mask is a counter-based hash of (step seed, word),
+// evaluated where it is needed -- no mask array, and dropped rows are never loaded.  An explicit
+// mask (a.scale) overrides it.  [K-mem] the reference draws its mask from TF's RNG: the stream
+// cannot match, only the distribution.
+__device__ __forceinline__ float word_scale(const TowerArgs& a, int w) {
+  if (a.scale) return a.scale[w];
+  if (a.keep >= 1.f) return 1.f;
+  const unsigned long long x = splitmix64(a.drop_seed + (unsigned long long)w * 0x9E3779B97F4A7C15ull);
+  const float u = (float)(x >> 40) * (1.f / 16777216.f);
+  return u < a.keep ? 1.f / a.keep : 0.f;
+}
+
+// workspace layout (floats)
+__host__ __device__ inline size_t ws_stats() { return 0; }                                     // [WG][3][128]
+__host__ __device__ inline size_t ws_muinv() { return (size_t)kTowerWG * 3 * 128; }             // mu, inv, var, mul, add
+__host__ __device__ inline size_t ws_bsum() { return ws_muinv() + 5 * 128; }                    // [WG][2][128]
+__host__ __device__ inline size_t ws_bfin() { return ws_bsum() + (size_t)kTowerWG * 2 * 128; }  // sum dy, sum dy*xhat
+__host__ __device__ inline size_t ws_cnt() { return ws_bfin() + 2 * 128; }                      // 4 arrival counters
+__host__ __device__ inline size_t ws_gb(int) { return ws_cnt() + 4; }                           // [ks][128]
+__host__ __device__ inline size_t ws_gw(int ks) { return ws_gb(0) + (size_t)ks * 128; }         // [ks][wd*d]
+inline size_t ws_total(int wd, int d, int ks) { return ws_gw(ks) + (size_t)ks * wd * d; }
+
+__device__ __forceinline__ int valid_rows(const TowerArgs& a) { return a.n_valid ? min(*a.n_valid, a.m) : a.m; }
+
+// column c of lane q's Row element e (e = 0..7): floats [4q,4q+4) then [64+4q, 64+4q+4)
+__device__ __forceinline__ int col_of(int q, int e) { return (e < 4 ? 4 * q : 64 + 4 * q - 4) + e; }
+__device__ __forceinline__ float& relem(Row& r, int e) {
+  return e == 0 ? r.a.x : e == 1 ? r.a.y : e == 2 ? r.a.z : e == 3 ? r.a.w : e == 4 ? r.b.x : e == 5 ? r.b.y : e == 6 ? r.b.z : r.b.w;
+}
+
+// "Last workgroup done" reduction: every workgroup publishes its partial, the one that arrives
+// last (device-scope counter) merges all partials in partial order -- the result does not depend
+// on arrival order -- and re-arms the counter.  Returns true in every thread of that workgroup.
+__device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == gridDim.x - 1);
+    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_last) __threadfence();
+  return s_last != 0;
+}
+
+}  // namespace nncf
+
+// ---- the tower object --------------------------------------------------------------------------
+struct nncf_tower {
+  nncf_tower_cfg cfg;
+  nncf_tower_params prm;
+  int device = 0;
+  int ks = 1;
+  void* arena = nullptr;
+  float *h = nullptr, *z = nullptr, *dh = nullptr, *ws = nullptr;
+  uint8_t* cnt_t = nullptr;
+  int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
+  bool fwd_cached = false;
+  nncf::TowerArgs last{};
+  float drop_rate = 0.f;
+  uint64_t drop_seed = 0, drop_step = 0;  // train-mode forwards since nncf_tower_set_dropout
+  // optimiser (nncf_tower_set_optimizer)
+  int opt = 0;
+  float beta1 = 0.9f, beta2 = 0.999f, aeps = 1e-8f;
+  int64_t adam_t = 0;  // standalone backward calls; inside a model step the model's counter rules
+  nncf::AdamTable aw;
+  float *mD = nullptr, *vD = nullptr;
+  int32_t* stamps = nullptr;
+  float* gexp = nullptr;
+  // convolutional front (cfg.conv_filters > 0)
+  nncf::CnnArgs cnn{};
+  float conv_drop = 0.f;
+  uint64_t conv_step = 0;  // train-mode forwards since nncf_tower_set_dropout (conv mask index)
+};
+
+namespace nncf {
+// cnn.hip
+size_t cnn_carve(nncf_tower* t, Carver& c);
+int cnn_sync_weights(nncf_tower* t, hipStream_t st);
+int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st);
+int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st);
+int cnn_mask(nncf_tower* t, TowerArgs& a, int64_t m, float* out, hipStream_t st);
+}  // namespace nncf

@@ -24,126 +24,11 @@
 // Only the first *n_valid rows of a block are real (device scalar): shapes are static, nothing
 // syncs to the host, every cross-row reduction has a fixed order.
 // [K-mem] Keras-1 BatchNormalization: eps 1e-3, momentum 0.99, biased variance.
-#include <cmath>
 #include <new>
 
-#include "common.h"
-#include "devutil.h"
-#include "model.h"
-#include "step.h"
+#include "tower.h"
 
 namespace nncf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kTP = 128;       // LDS pitch of pooled rows
-constexpr int kZP = 132;       // LDS pitch of dz rows (16-byte aligned, 4 banks apart)
-constexpr int kTowerWG = 64;   // at most this many workgroups emit statistics partials
-constexpr int kRowsPerK = 1024;  // rows per K-part of the weight-gradient tiles
-
-struct TowerArgs {
-  // parameters
-  float* W;      // [n_words][wd]
-  float* Wd;     // [wd][d]
-  float* bd;
-  float* gamma;
-  float* beta;
-  float* rm;
-  float* rv;
-  const int32_t* content;    // [item_count][L]
-  const int32_t* item_ptr;   // CSR of the content matrix: item -> (word, count) pairs
-  const int32_t* item_word;
-  const uint8_t* item_cnt;
-  const float* scale;        // per-word row-dropout scale (Embedding(dropout=...), :56-59) or NULL
-  // per call
-  const int32_t* ids;        // [m] item ids of the block's rows
-  const int32_t* n_valid;    // rows [0, *n_valid) are real; NULL = all m
-  float* h;                  // [m][wd]
-  float* z;                  // [m][d]
-  float* E;                  // [m][d]
-  const float* dA;           // [m][d]
-  float* dh;                 // [m][wd]
-  float* ws;
-  uint8_t* cnt_t;            // [n_words][cap] word-major token counts of the batch (all-zero between steps)
-  int m, wd, d, L, cap, n_words, train, fill;
-  float eps, momentum, lr;
-  float keep;                    // row-dropout retain probability (1 = off)
-  unsigned long long drop_seed;  // this step's mask seed
-  // optimiser (StepArgs::opt): Adam state of the word table and of the packed dense parameters
-  // [Wd (wd*d) | bd (128) | gamma (128) | beta (128)]
-  int opt, step_no;
-  float lr_t, beta1, beta2, aeps;
-  AdamTable aw;
-  float* mD;
-  float* vD;
-  // data-parallel training: if non-NULL the backward applies nothing and writes the gradients
-  // [words (n_words*wd) | dense_w (wd*d) | dense_b, bn_gamma, bn_beta (128 each)] here
-  float* gexp;
-};
-
-__device__ __forceinline__ float adam1(float g, float* m, float* v, float p, const TowerArgs& a) {
-  const float mm = fmaf(a.beta1, *m, (1.f - a.beta1) * g), vv = fmaf(a.beta2, *v, (1.f - a.beta2) * g * g);
-  *m = mm;
-  *v = vv;
-  return p - a.lr_t * mm / (sqrtf(vv) + a.aeps);
-}
-
-__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
-  x ^= x >> 30;
-  x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 27;
-  x *= 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return x;
-}
-
-// Embedding(dropout = 1 - keep) of Keras 1 (mean_pool.py:56-59): whole word rows are dropped
-// per batch, survivors scaled by 1/keep.  The mask is a counter-based hash of (step seed, word),
-// evaluated where it is needed -- no mask array, and dropped rows are never loaded.  An explicit
-// mask (a.scale) overrides it.  [K-mem] the reference draws its mask from TF's RNG: the stream
-// cannot match, only the distribution.
-__device__ __forceinline__ float word_scale(const TowerArgs& a, int w) {
-  if (a.scale) return a.scale[w];
-  if (a.keep >= 1.f) return 1.f;
-  const unsigned long long x = splitmix64(a.drop_seed + (unsigned long long)w * 0x9E3779B97F4A7C15ull);
-  const float u = (float)(x >> 40) * (1.f / 16777216.f);
-  return u < a.keep ? 1.f / a.keep : 0.f;
-}
-
-// workspace layout (floats)
-__host__ __device__ inline size_t ws_stats() { return 0; }                                     // [WG][3][128]
-__host__ __device__ inline size_t ws_muinv() { return (size_t)kTowerWG * 3 * 128; }             // mu, inv, var, mul, add
-__host__ __device__ inline size_t ws_bsum() { return ws_muinv() + 5 * 128; }                    // [WG][2][128]
-__host__ __device__ inline size_t ws_bfin() { return ws_bsum() + (size_t)kTowerWG * 2 * 128; }  // sum dy, sum dy*xhat
-__host__ __device__ inline size_t ws_cnt() { return ws_bfin() + 2 * 128; }                      // 4 arrival counters
-__host__ __device__ inline size_t ws_gb(int) { return ws_cnt() + 4; }                           // [ks][128]
-__host__ __device__ inline size_t ws_gw(int ks) { return ws_gb(0) + (size_t)ks * 128; }         // [ks][wd*d]
-inline size_t ws_total(int wd, int d, int ks) { return ws_gw(ks) + (size_t)ks * wd * d; }
-
-__device__ __forceinline__ int valid_rows(const TowerArgs& a) { return a.n_valid ? min(*a.n_valid, a.m) : a.m; }
-
-// column c of lane q's Row element e (e = 0..7): floats [4q,4q+4) then [64+4q, 64+4q+4)
-__device__ __forceinline__ int col_of(int q, int e) { return (e < 4 ? 4 * q : 64 + 4 * q - 4) + e; }
-__device__ __forceinline__ float& relem(Row& r, int e) {
-  return e == 0 ? r.a.x : e == 1 ? r.a.y : e == 2 ? r.a.z : e == 3 ? r.a.w : e == 4 ? r.b.x : e == 5 ? r.b.y : e == 6 ? r.b.z : r.b.w;
-}
-
-// "Last workgroup done" reduction: every workgroup publishes its partial, the one that arrives
-// last (device-scope counter) merges all partials in partial order -- the result does not depend
-// on arrival order -- and re-arms the counter.  Returns true in every thread of that workgroup.
-__device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (prev == gridDim.x - 1);
-    if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (s_last) __threadfence();
-  return s_last != 0;
-}
 
 // ---- forward ---------------------------------------------------------------------------------
 
@@ -164,12 +49,12 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   const int item = a.ids[s];
   // this thread's slice of the dense weights: columns [4c4, 4c4+4), rows kp*kper .. +kper.
   // Issued first: independent of the pooling below, so the two latencies overlap.
-  const int c4 = tid & 31, kp = tid >> 5, kper = (a.wd + 7) >> 3;
+  const int c4 = tid & 31, kp = tid >> 5, kper = (a.hd + 7) >> 3;
   float4 w[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = kp * kper + i;
-    w[i] = (i < kper && k < a.wd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+    w[i] = (i < kper && k < a.hd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
   }
   // all L tokens (and their dropout scales) in one round trip, parked in LDS
   const int32_t* toks = a.content + (int64_t)item * a.L;
@@ -224,7 +109,7 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = kp * kper + i;
-    if (i < kper && k < a.wd) part = fma4(sH[k], w[i], part);
+    if (i < kper && k < a.hd) part = fma4(sH[k], w[i], part);
   }
   sP[kp * 32 + c4] = part;
   __syncthreads();
@@ -495,7 +380,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
     // MFMA 16x16x4: A lane (i = x, k = kq) = dz[r0+i][c], B lane (j = x, k = kq) = Wd[kw0+j][c].
     // The K index is free to permute as long as A and B agree: component e of the float4 at
     // column 16t + 4kq serves k-step (t, e), so both operands are 16-byte row-contiguous loads.
-    const int nct = (a.wd + 15) >> 4, nt = (a.d + 15) >> 4;
+    const int nct = (a.hd + 15) >> 4, nt = (a.d + 15) >> 4;
     for (int ct = wave; ct < nct; ct += 4) {
       const int kw = ct * 16 + x;
       const float4* wrow = reinterpret_cast<const float4*>(a.Wd + (int64_t)kw * a.d);
@@ -503,7 +388,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const int col = 16 * t + 4 * kq;
-        bf[t] = (t < nt && kw < a.wd && col < a.d) ? wrow[col >> 2] : zero4();
+        bf[t] = (t < nt && kw < a.hd && col < a.d) ? wrow[col >> 2] : zero4();
       }
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -520,7 +405,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x]
         const int rr = r0 + 4 * kq + r;
-        if (rr < nv && kw < a.wd) a.dh[(int64_t)rr * a.wd + kw] = acc[r];
+        if (rr < nv && kw < a.hd) a.dh[(int64_t)rr * a.hd + kw] = acc[r];
       }
     }
     return;
@@ -534,7 +419,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
   const float mu = sMu[cn], inv = sInv[cn], g = sG[cn], mul = sMul[cn], add = sAdd[cn], sa = sA[cn], sbq = sBq[cn];
   const float coef = g * inv * rn;
   const int rbeg = kpart * kRowsPerK, rend = min(nv, rbeg + kRowsPerK);
-  const bool okh = kw < a.wd, okc = cn < a.d;
+  const bool okh = kw < a.hd, okc = cn < a.d;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float colsum = 0.f;
   // waves take the 4-row k-steps round robin; 16 steps (48 loads) in flight
@@ -544,7 +429,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
     for (int u = 0; u < 16; ++u) {
       const int r = rbeg + 4 * (st0 + 4 * u) + kq;
       const bool ok = r < rend;
-      hv[u] = (ok && okh) ? a.h[(int64_t)r * a.wd + kw] : 0.f;
+      hv[u] = (ok && okh) ? a.h[(int64_t)r * a.hd + kw] : 0.f;
       zv[u] = (ok && okc) ? a.z[(int64_t)r * a.d + cn] : 0.f;
       gv[u] = (ok && okc) ? a.dA[(int64_t)r * a.d + cn] : 0.f;
     }
@@ -565,11 +450,11 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
   __syncthreads();
   if (wave == 0) {
     const f32x4 tot = ((sAcc[lane] + sAcc[64 + lane]) + sAcc[128 + lane]) + sAcc[192 + lane];
-    float* gw = a.ws + ws_gw(ks) + (size_t)kpart * a.wd * a.d;
+    float* gw = a.ws + ws_gw(ks) + (size_t)kpart * a.hd * a.d;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWd[it*16 + i][cn]
       const int kwi = it * 16 + 4 * kq + r;
-      if (kwi < a.wd && okc) gw[(int64_t)kwi * a.d + cn] = tot[r];
+      if (kwi < a.hd && okc) gw[(int64_t)kwi * a.d + cn] = tot[r];
     }
     if (it == 0 && kq == 0 && okc)
       a.ws[ws_gb(0) + (size_t)kpart * 128 + cn] = ((sCol[x] + sCol[16 + x]) + sCol[32 + x]) + sCol[48 + x];
@@ -596,7 +481,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = (a.n_words + kWordsPerWG - 1) / kWordsPerWG;
   if ((int)blockIdx.x >= G) {
-    const int el = ((int)blockIdx.x - G) * 512 + tid, nel = a.wd * a.d;
+    const int el = ((int)blockIdx.x - G) * 512 + tid, nel = a.hd * a.d;
     if (el < nel) {
       float g = 0.f;
       for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
@@ -626,6 +511,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     }
     return;
   }
+  if (a.skip_words) return;
   const int n = valid_rows(a), d2 = a.wd >> 1;
   const int my_w = blockIdx.x + wave * G;  // the word this wave finishes
   float2 wold = make_float2(0.f, 0.f);
@@ -635,7 +521,11 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
 #pragma unroll
   for (int j = 0; j < kWordsPerWG; ++j) accw[j * 64 + lane] = make_float2(0.f, 0.f);
   int* list = sList + wave * kListCap;
-  const float2* dh2 = reinterpret_cast<const float2*>(a.dh);
+  // mean-pool tower: a cell holds the word's count in the slot's item, the gradient row is
+  // dh[slot] weighted by it.  CNN tower: a cell holds 1 + the word's ordinal among the item's
+  // distinct words, the gradient row is dXw[slot*L + ordinal] (already summed over positions).
+  const bool cnn = a.cnn.F > 0;
+  const float2* dh2 = reinterpret_cast<const float2*>(cnn ? a.cnn.dXw : a.dh);
   __syncthreads();
   for (int base = 0; base < n; base += 512) {
     const int slot = base + 64 * wave + lane;
@@ -659,11 +549,13 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
         for (int u = 0; u < 16; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-          r[u] = (ent[u] && lane < d2) ? dh2[(int64_t)((ent[u] >> 8) & 0xFFFF) * d2 + lane] : make_float2(0.f, 0.f);
+          r[u] = (ent[u] && lane < d2)
+                     ? dh2[(cnn ? (int64_t)((ent[u] >> 8) & 0xFFFF) * a.L + ((ent[u] & 255) - 1) : (int64_t)((ent[u] >> 8) & 0xFFFF)) * d2 + lane]
+                     : make_float2(0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           if (ent[u]) {  // uniform across the wave
-            const float cf = (float)(ent[u] & 255);
+            const float cf = cnn ? 1.f : (float)(ent[u] & 255);
             float2* p = accw + (ent[u] >> 24) * 64 + lane;
             float2 t = *p;
             t.x = fmaf(cf, r[u].x, t.x);
@@ -700,13 +592,13 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       sum.x += t.x;
       sum.y += t.y;
     }
+    // gradient = scale[w] / L * sum (mean-pool); the CNN rows already carry scale and 1/L
+    const float gs = cnn ? 1.f : word_scale(a, my_w) / (float)a.L;
     if (a.gexp) {
-      const float gs = word_scale(a, my_w) / (float)a.L;
       reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(gs * sum.x, gs * sum.y);
       return;
     }
-    if (a.opt) {  // gradient = scale[w] / L * sum
-      const float gs = word_scale(a, my_w) / (float)a.L;
+    if (a.opt) {
       float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
       float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
       float2 mm = *mp, vv = *vp;
@@ -716,7 +608,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       *vp = vv;
       if (a.aw.stamp && lane == 0) a.aw.stamp[my_w] = a.step_no;
     } else {
-      const float sc = lr_over_L * word_scale(a, my_w);
+      const float sc = cnn ? a.lr : lr_over_L * word_scale(a, my_w);
       wold.x = fmaf(-sc, sum.x, wold.x);
       wold.y = fmaf(-sc, sum.y, wold.y);
     }
@@ -728,7 +620,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
 // gradient buffer.  Lazy-sparse Adam skips exactly-zero gradient elements of the word table.
 __global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const float* __restrict__ g, float scale) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t nW = (size_t)a.n_words * a.wd, nel = (size_t)a.wd * a.d;
+  const size_t nW = (size_t)a.n_words * a.wd, nel = (size_t)a.hd * a.d;
   if (i < nW) {
     const float gv = scale * g[i];
     if (!a.opt) a.W[i] -= a.lr * gv;
@@ -760,37 +652,18 @@ using namespace nncf;
 
 // ---- the tower object --------------------------------------------------------------------------
 
-struct nncf_tower {
-  nncf_tower_cfg cfg;
-  nncf_tower_params prm;
-  int device = 0;
-  int ks = 1;
-  void* arena = nullptr;
-  float *h = nullptr, *z = nullptr, *dh = nullptr, *ws = nullptr;
-  uint8_t* cnt_t = nullptr;
-  int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
-  bool fwd_cached = false;
-  TowerArgs last{};
-  float drop_rate = 0.f;
-  uint64_t drop_seed = 0, drop_step = 0;  // train-mode forwards since nncf_tower_set_dropout
-  // optimiser (nncf_tower_set_optimizer)
-  int opt = 0;
-  float beta1 = 0.9f, beta2 = 0.999f, aeps = 1e-8f;
-  int64_t adam_t = 0;  // standalone backward calls; inside a model step the model's counter rules
-  AdamTable aw;
-  float *mD = nullptr, *vD = nullptr;
-  int32_t* stamps = nullptr;
-  float* gexp = nullptr;
-};
 
 namespace {
 
 void carve_tower(nncf_tower* t, Carver& c) {
   const int64_t cap = t->cfg.max_rows, wd = t->cfg.word_dim, d = t->cfg.item_dim;
-  t->h = c.take<float>(cap * wd);
+  const int64_t hd = t->cfg.conv_filters > 0 ? (int64_t)t->cfg.conv_filters : wd;  // Dense input width
+  const int64_t wide = hd > wd ? hd : wd;
+  t->h = c.take<float>(cap * wide);
   t->z = c.take<float>(cap * d);
-  t->dh = c.take<float>(cap * wd);
-  t->ws = c.take<float>(ws_total((int)wd, (int)d, t->ks));
+  t->dh = c.take<float>(cap * wide);
+  t->ws = c.take<float>(ws_total((int)wide, (int)d, t->ks));
+  if (t->cfg.conv_filters > 0) cnn_carve(t, c);
   t->cnt_t = c.take<uint8_t>((int64_t)t->cfg.word_count * cap);
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
@@ -803,10 +676,13 @@ TowerArgs base_args(const nncf_tower* t) {
   a.rm = p.bn_mean; a.rv = p.bn_var;
   a.content = p.content; a.item_ptr = p.item_ptr; a.item_word = p.item_word; a.item_cnt = p.item_cnt;
   a.h = t->h; a.z = t->z; a.dh = t->dh; a.ws = t->ws; a.cnt_t = t->cnt_t;
-  a.wd = t->cfg.word_dim; a.d = t->cfg.item_dim; a.L = t->cfg.content_len; a.cap = t->cfg.max_rows;
+  a.wd = t->cfg.word_dim; a.hd = t->cfg.word_dim; a.d = t->cfg.item_dim; a.L = t->cfg.content_len; a.cap = t->cfg.max_rows;
   a.n_words = t->cfg.word_count;
   a.eps = t->cfg.bn_eps; a.momentum = t->cfg.bn_momentum; a.lr = t->cfg.learn_rate;
   a.keep = 1.f;
+  a.cnn = t->cnn;
+  a.cnn.keep = 1.f;
+  if (t->cnn.F > 0) a.hd = t->cnn.F;
   return a;
 }
 
@@ -825,7 +701,13 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     a.keep = 1.f - t->drop_rate;
     a.drop_seed = step_seed(t, t->drop_step++);
   }
-  {
+  if (a.cnn.F > 0) {
+    if (train && t->conv_drop > 0.f) {
+      a.cnn.keep = 1.f - t->conv_drop;
+      a.cnn.seed = splitmix64(step_seed(t, t->conv_step++) ^ 0xC0117D8097ull);
+    }
+    if (int rc = cnn_forward(t, a, st)) return rc;
+  } else {
     ProfScope _ps("tower_pool_kernel", st);
     hipLaunchKernelGGL(tower_pool_kernel, dim3((unsigned)m), dim3(256), 0, st, a);
   }
@@ -867,7 +749,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   const int m = a.m;
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
-  const int ntile = ((a.wd + 15) / 16) * ((a.d + 15) / 16);
+  const int ntile = ((a.hd + 15) / 16) * ((a.d + 15) / 16);
   if (!nfused) {
     ProfScope _ps("tower_sums_kernel", st);
     hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
@@ -876,9 +758,16 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     ProfScope _ps("tower_bwd_kernel", st);
     hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks, nfused);
   }
+  if (a.cnn.F > 0) {  // dL/dh -> conv backward -> per-(item, word) gradient rows
+    a.cnn.keep = t->last.cnn.keep;
+    a.cnn.seed = t->last.cnn.seed;
+    a.cnn.mC = t->cnn.mC;
+    a.cnn.vC = t->cnn.vC;
+    if (int rc = cnn_backward(t, a, st)) return rc;
+  }
   {
     ProfScope _ps("tower_word_kernel", st);
-    const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.wd * a.d + 511) / 512;
+    const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
     hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
@@ -947,6 +836,17 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   NNCF_REQUIRE(cfg->max_rows > 0 && cfg->max_rows % 8 == 0 && cfg->max_rows <= 8192, "max_rows = %d must be a multiple of 8, <= 8192", cfg->max_rows);
   NNCF_REQUIRE(prm->words && prm->dense_w && prm->dense_b && prm->bn_gamma && prm->bn_beta && prm->bn_mean && prm->bn_var &&
                    prm->content && prm->item_ptr && prm->item_word && prm->item_cnt, "NULL parameter pointer");
+  if (cfg->conv_filters > 0) {
+    NNCF_REQUIRE(cfg->conv_filters % 4 == 0 && cfg->conv_filters <= 128, "conv_filters = %d must be a multiple of 4 and <= 128", cfg->conv_filters);
+    NNCF_REQUIRE(cfg->filter_len >= 1 && cfg->filter_len % 2 == 1 && cfg->filter_len <= 7, "filter_len = %d must be odd, 1..7", cfg->filter_len);
+    NNCF_REQUIRE(cfg->content_len <= 254, "content_len above 254 is not built for the CNN tower");
+    NNCF_REQUIRE(cfg->conv_dropout >= 0.f && cfg->conv_dropout < 1.f, "conv_dropout out of [0, 1)");
+    NNCF_REQUIRE(prm->conv_w && prm->conv_b && prm->bn1_gamma && prm->bn1_beta && prm->bn1_mean && prm->bn1_var &&
+                     prm->item_spos && prm->item_start, "NULL CNN parameter pointer");
+    NNCF_REQUIRE(((uintptr_t)prm->conv_w & 15) == 0, "conv_w must be 16-byte aligned");
+  } else {
+    NNCF_REQUIRE(cfg->conv_filters == 0, "negative conv_filters");
+  }
   NNCF_REQUIRE((((uintptr_t)prm->words | (uintptr_t)prm->dense_w | (uintptr_t)prm->dense_b | (uintptr_t)prm->bn_gamma |
                  (uintptr_t)prm->bn_beta | (uintptr_t)prm->bn_mean | (uintptr_t)prm->bn_var) & 15) == 0,
                "parameter arrays must be 16-byte aligned");
@@ -960,6 +860,15 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   t->prm = *prm;
   t->device = device;
   t->ks = (cfg->max_rows + kRowsPerK - 1) / kRowsPerK;
+  if (cfg->conv_filters > 0) {
+    CnnArgs& c = t->cnn;
+    c.F = cfg->conv_filters;
+    c.fl = cfg->filter_len;
+    c.keep = 1.f;
+    c.Wk = prm->conv_w; c.bc = prm->conv_b; c.g1 = prm->bn1_gamma; c.b1 = prm->bn1_beta; c.rm1 = prm->bn1_mean;
+    c.rv1 = prm->bn1_var; c.item_spos = prm->item_spos; c.item_start = prm->item_start;
+    t->conv_drop = cfg->conv_dropout;
+  }
   Carver dry;
   carve_tower(t, dry);
   int prev = 0;
@@ -975,6 +884,17 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   Carver real;
   real.base = static_cast<char*>(t->arena);
   carve_tower(t, real);
+  if (cfg->conv_filters > 0) {
+    hipGetDevice(&prev);
+    hipSetDevice(device);
+    const int rc = cnn_sync_weights(t, nullptr);
+    hipDeviceSynchronize();
+    hipSetDevice(prev);
+    if (rc) {
+      nncf_tower_destroy(t);
+      return rc;
+    }
+  }
   *out = t;
   return NNCF_OK;
 }
@@ -985,6 +905,23 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (t->stamps) hipFree(t->stamps);
   delete t;
   return NNCF_OK;
+}
+
+int nncf_tower_sync_params(nncf_tower* t, void* stream) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  if (t->cnn.F > 0) return cnn_sync_weights(t, as_stream(stream));
+  return NNCF_OK;
+}
+
+int nncf_tower_conv_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d_out, void* stream) {
+  NNCF_REQUIRE(t && d_out, "NULL argument");
+  NNCF_REQUIRE(t->cnn.F > 0, "not a CNN tower");
+  TowerArgs a = base_args(t);
+  if (t->conv_drop > 0.f) {
+    a.cnn.keep = 1.f - t->conv_drop;
+    a.cnn.seed = splitmix64(step_seed(t, step_index) ^ 0xC0117D8097ull);
+  }
+  return cnn_mask(t, a, m, d_out, as_stream(stream));
 }
 
 int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate) {
@@ -1009,6 +946,11 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
   t->aw = AdamTable{d_m_words, d_v_words, nullptr};
   t->mD = d_m_dense;
   t->vD = d_v_dense;
+  if (t->cnn.F > 0 && mode) {  // conv / BN1 moments follow the Dense / BN2 block
+    const int64_t off = (int64_t)t->cnn.F * t->cfg.item_dim + 384;
+    t->cnn.mC = d_m_dense + off;
+    t->cnn.vC = d_v_dense + off;
+  }
   if (mode == 2) {
     int prev = 0;
     hipGetDevice(&prev);
@@ -1030,6 +972,7 @@ int64_t nncf_tower_grad_floats(const nncf_tower* t) {
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(t->cnn.F == 0 || !d_grad, "gradient export is not built for the CNN tower");
   t->gexp = d_grad;
   return NNCF_OK;
 }
@@ -1061,6 +1004,7 @@ int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed) {
   t->drop_rate = rate;
   t->drop_seed = seed;
   t->drop_step = 0;
+  t->conv_step = 0;
   return NNCF_OK;
 }
 
@@ -1084,8 +1028,9 @@ int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, cons
   NNCF_REQUIRE(!train || m <= t->cfg.max_rows, "train-mode block of %lld rows exceeds max_rows = %d", (long long)m, t->cfg.max_rows);
   hipStream_t st = as_stream(stream);
   if (train) return tower_forward(t, d_item_ids, (int)m, d_n_valid, 1, prepare_backward != 0, d_row_scale, d_out, st);
-  for (int64_t i0 = 0; i0 < m; i0 += 1 << 20) {  // inference rows are independent: any m
-    const int64_t cnt = m - i0 < (1 << 20) ? m - i0 : (1 << 20);
+  const int64_t chunk = t->cnn.F > 0 ? t->cfg.max_rows : (1 << 20);  // the CNN keeps a block's conv output
+  for (int64_t i0 = 0; i0 < m; i0 += chunk) {  // inference rows are independent: any m
+    const int64_t cnt = m - i0 < chunk ? m - i0 : chunk;
     if (int rc = tower_forward(t, d_item_ids + i0, (int)cnt, nullptr, 0, 0, nullptr, d_out + i0 * t->cfg.item_dim, st)) return rc;
   }
   return NNCF_OK;

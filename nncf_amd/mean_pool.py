@@ -38,7 +38,10 @@ class MeanPoolTower(object):
     object (nncf_tower_*) borrows their pointers and owns every scratch buffer."""
 
     def __init__(self, C, word_count, word_dim, item_dim, learn_rate, device, seed=0, dropout_rate=0.0,
-                 eps=1e-3, momentum=0.99, max_rows=512):
+                 eps=1e-3, momentum=0.99, max_rows=512, conv=None):
+        """conv: None (MeanPool) or dict(filters=F, filter_len=fl, dropout=p): the CNN tower of
+        cnn_embedding (modules/content/cnn_model.py) -- one Convolution1D('same') + BatchNorm + relu +
+        Dropout + average pooling in front of the same Dense/BN/ReLU tail."""
         self.device = device
         self._L = _lib.lib()
         C = np.ascontiguousarray(np.asarray(C))
@@ -53,8 +56,10 @@ class MeanPoolTower(object):
         gen = torch.Generator().manual_seed(int(seed) + 17)
         dev = device
         self.W = ((torch.rand(self.word_count, self.wd, generator=gen) * 2 - 1) * 0.05).to(dev).contiguous()
-        lim = float(np.sqrt(6.0 / (self.wd + self.d)))  # glorot_uniform
-        self.Wd = ((torch.rand(self.wd, self.d, generator=gen) * 2 - 1) * lim).to(dev).contiguous()
+        self.conv = dict(conv) if conv else None
+        self.hd = int(self.conv["filters"]) if self.conv else self.wd          # Dense input width
+        lim = float(np.sqrt(6.0 / (self.hd + self.d)))  # glorot_uniform
+        self.Wd = ((torch.rand(self.hd, self.d, generator=gen) * 2 - 1) * lim).to(dev).contiguous()
         # one allocation for the five small vectors, each 512-byte aligned
         vec = torch.zeros(5, 128, device=dev)
         self.bd, self.gamma, self.beta, self.rm, self.rv = (vec[i, :self.d] for i in range(5))
@@ -67,15 +72,38 @@ class MeanPoolTower(object):
         self.item_word = torch.as_tensor(words).to(dev)
         self.item_cnt = torch.as_tensor(cnt).to(dev)
         self.version = 0  # bumped by every update (the evaluator caches inference embeddings)
+        extra = [None] * 8
+        F = fl = 0
+        cdrop = 0.0
+        if self.conv:
+            F, fl, cdrop = int(self.conv["filters"]), int(self.conv["filter_len"]), float(self.conv.get("dropout", 0.0))
+            assert F % 4 == 0 and F <= 128 and fl % 2 == 1, "conv filters must be a multiple of 4 (<= 128), filter_len odd"
+            # Convolution1D init='he_normal' (cnn_model.py:88): std = sqrt(2 / fan_in), fan_in = fl * word_dim [K-mem]
+            self.Wc = (torch.randn(fl, self.wd, F, generator=gen) * float(np.sqrt(2.0 / (fl * self.wd)))).to(dev).contiguous()
+            vec1 = torch.zeros(5, 128, device=dev)
+            self.bc, self.g1, self.b1, self.rm1, self.rv1 = (vec1[i, :F] for i in range(5))
+            self.g1.fill_(1.0)
+            self.rv1.fill_(1.0)
+            self._vec1 = vec1
+            # static index of every item's tokens: positions sorted by (word, position), and for each
+            # CSR entry (item, word) where its positions start in that order
+            spos = np.argsort(C, axis=1, kind="stable").astype(np.uint8)
+            cnt64 = cnt.astype(np.int64)
+            csum = np.cumsum(cnt64) - cnt64                       # exclusive prefix over all entries
+            starts = (csum - np.repeat(csum[ptr[:-1]], np.diff(ptr))).astype(np.uint8)
+            self.item_spos = torch.as_tensor(spos).to(dev).contiguous()
+            self.item_start = torch.as_tensor(starts).to(dev)
+            extra = [self.Wc, self.bc, self.g1, self.b1, self.rm1, self.rv1, self.item_spos, self.item_start]
         cfg = _lib.TowerCfg(self.word_count, self.wd, self.d, self.Lc, self.cap, self.item_count, self.eps, self.mom,
-                            self.lr)
-        prm = _lib.TowerParams(*[t.data_ptr() for t in (self.W, self.Wd, self.bd, self.gamma, self.beta, self.rm,
-                                                        self.rv, self.C, self.item_ptr, self.item_word, self.item_cnt)])
+                            self.lr, F, fl, cdrop)
+        prm = _lib.TowerParams(*([t.data_ptr() for t in (self.W, self.Wd, self.bd, self.gamma, self.beta, self.rm,
+                                                         self.rv, self.C, self.item_ptr, self.item_word, self.item_cnt)] +
+                                 [(t.data_ptr() if t is not None else None) for t in extra]))
         h = ctypes.c_void_p()
         idx = torch.device(dev).index or 0
         _lib.check(self._L.nncf_tower_create(ctypes.byref(cfg), ctypes.byref(prm), idx, ctypes.byref(h)))
         self.handle = h
-        if self.dropout > 0:
+        if self.dropout > 0 or cdrop > 0:
             self.set_dropout(self.dropout, int(seed) + 29)
 
     def __del__(self):
@@ -86,11 +114,22 @@ class MeanPoolTower(object):
     def _stream(self):
         return _lib.stream_ptr(torch.cuda.current_stream(self.device))
 
-    def set_params(self, W=None, Wd=None, bd=None, gamma=None, beta=None):
-        for name, v in (("W", W), ("Wd", Wd), ("bd", bd), ("gamma", gamma), ("beta", beta)):
+    def set_params(self, **kw):
+        """W, Wd, bd, gamma, beta (+ Wc, bc, g1, b1 for the CNN tower) from host arrays."""
+        for name, v in kw.items():
             if v is not None:
                 getattr(self, name).copy_(torch.as_tensor(np.asarray(v), dtype=torch.float32))
+        if self.conv and "Wc" in kw:
+            _lib.check(self._L.nncf_tower_sync_params(self.handle, self._stream()))
         self.version += 1
+
+    def conv_mask(self, step_index, m):
+        """Dropout(conv_dropout) mask of the step_index-th train-mode forward, first m rows (checkers)."""
+        out = torch.empty(m, self.Lc, self.hd, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_conv_mask(self.handle, int(step_index), m, ctypes.c_void_p(out.data_ptr()),
+                                                    self._stream()))
+        return out
 
     def set_optimizer(self, kind, beta1=0.9, beta2=0.999, epsilon=1e-8):
         """'sgd' | 'sparse_adam' | 'adam' for the tower's parameters (see Engine.set_optimizer)."""
@@ -98,7 +137,9 @@ class MeanPoolTower(object):
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
         self.opt_state = None
         if mode:
-            nd = self.wd * self.d + 384
+            nd = self.hd * self.d + 384
+            if self.conv:
+                nd += self.Wc.numel() + 384
             z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)  # noqa: E731
             self.opt_state = {"mW": z(self.word_count, self.wd), "vW": z(self.word_count, self.wd), "mD": z(nd), "vD": z(nd)}
         st = self.opt_state or {}

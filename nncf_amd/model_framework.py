@@ -325,11 +325,32 @@ def engine_kwargs(conf, data_spec, model_name):
         normalize_item=normalize and model_name != "mf")        # :109-111 (content branch only)
 
 
-def _get_model_basic_embedding(conf, data_helper, device, seed):
+def _conv_spec(conf):
+    """The convolutional front of cnn_embedding as this build runs it (cnn_model.py:61-111): one
+    Convolution1D layer, a single odd filter length, BatchNorm, relu, whole-length average pooling."""
+    fls, nfs = list(conf.filter_lengths), list(conf.num_filters)
+    ok = (len(fls) == 1 and not isinstance(fls[0], (list, tuple)) and int(fls[0]) % 2 == 1 and len(nfs) == 1 and
+          list(conf.poolings) == ["average"] and list(conf.pool_lengths)[0] <= 0 and conf.conv_activation == "relu" and
+          conf.conv_batch_normalization and not getattr(conf, "no_BN", False) and
+          not getattr(conf, "contextual_spatial_gated_input", None) and
+          not getattr(conf, "contextual_temporal_gated_input", None))
+    if not ok:
+        raise NotImplementedError(
+            "cnn_embedding is built for ONE Convolution1D layer with a single odd filter length (e.g. "
+            "filter_lengths=[3], the 'best' preset), conv BatchNorm + relu, poolings=['average'] over the whole "
+            "length, no gating; got filter_lengths=%r num_filters=%r poolings=%r pool_lengths=%r"
+            % (fls, nfs, conf.poolings, conf.pool_lengths))
+    if int(nfs[0]) % 4:
+        raise NotImplementedError("num_filters = %d: the HIP kernels need a multiple of 4 (48 / 52 / 100 ...)" % nfs[0])
+    return dict(filters=int(nfs[0]), filter_len=int(fls[0]), dropout=float(conf.conv_dropout_rate))
+
+
+def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     from .mean_pool import MeanPoolTower
     data_spec = data_helper.data_spec
-    if getattr(conf, "pretrain", None) or getattr(conf, "use_content_id", False) or conf.pooling != "average":
-        raise NotImplementedError("basic_embedding is built for pretrain=None, use_content_id=False, "
+    if getattr(conf, "pretrain", None) or getattr(conf, "use_content_id", False) or \
+            (conv is None and conf.pooling != "average"):
+        raise NotImplementedError("the text towers are built for pretrain=None, use_content_id=False, "
                                   "pooling='average' (what the demo scripts run)")
     idt = conf.item_dense_transform
     assert idt["dense_hidden_dim"] == conf.item_dim and idt["dense_hidden_actv"] == "relu" and \
@@ -340,7 +361,7 @@ def _get_model_basic_embedding(conf, data_helper, device, seed):
     engine = Engine(device=device, seed=seed, **kw)
     tower = MeanPoolTower(data_helper.data["C"], data_spec.word_count, conf.word_dim, conf.item_dim,
                           abs(conf.learn_rate), engine.device, seed=seed,
-                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap)
+                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap, conv=conv)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
     opt = getattr(conf, "optimizer", "sgd")
     if opt != "sgd":
@@ -379,12 +400,14 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
                                   "pass {'interaction_bias': None}" % conf.interaction_bias)
     if model_name == "basic_embedding":
         return _get_model_basic_embedding(conf, data_helper, device, seed)
+    if model_name == "cnn_embedding":   # model_framework.py:92-93
+        return _get_model_basic_embedding(conf, data_helper, device, seed, conv=_conv_spec(conf))
     if model_name != "mf":
-        assert model_name in ("cnn_embedding", "rnn_embedding", "pretrained"), \
+        assert model_name in ("rnn_embedding", "pretrained"), \
             "[ERROR] Model name {} unknown".format(model_name)  # model_framework.py:97
         raise NotImplementedError(
-            "model_choice=%s: the CNN / RNN item towers (modules/content/{cnn,rnn}_model.py) are not built; "
-            "use basic_embedding (mean-pool text tower) or mf (id-table towers)" % model_name)
+            "model_choice=%s: the RNN item tower (modules/content/rnn_model.py) is not built; "
+            "use cnn_embedding, basic_embedding (text towers) or mf (id-table towers)" % model_name)
     kw = engine_kwargs(conf, data_spec, model_name)
     engine = Engine(device=device, seed=seed, **kw)
     opt = getattr(conf, "optimizer", "sgd")

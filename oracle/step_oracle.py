@@ -285,12 +285,31 @@ class TowerOracle(object):
         self.lr = self.dt.type(lr)
         self.eps, self.mom = self.dt.type(eps), self.dt.type(momentum)
 
-    def forward(self, cid_u, train=True, row_scale=None):
-        toks = self.C[np.asarray(cid_u)]                       # (n_u, L)
+    PARAMS = ("W", "Wd", "bd", "gamma", "beta")
+
+    def _front_forward(self, toks, row_scale, train):
+        """tokens (n, L) -> pooled block h (n, hd): here the mean of the word rows."""
         E = self.W[toks]                                       # (n_u, L, wd)
         if row_scale is not None:
             E = E * row_scale[toks][..., None]
-        h = E.sum(axis=1) / self.dt.type(toks.shape[1])        # mean_pool.py:30: divide by L always
+        return E.sum(axis=1) / self.dt.type(toks.shape[1])     # mean_pool.py:30: divide by L always
+
+    def _front_backward(self, dh):
+        """dL/dh -> gradients of the front's parameters (dict), from self.cache."""
+        c = self.cache
+        L = self.dt.type(c["toks"].shape[1])
+        dW = np.zeros_like(self.W)
+        contrib = np.repeat(dh[:, None, :], c["toks"].shape[1], axis=1) / L
+        if c["row_scale"] is not None:
+            contrib = contrib * c["row_scale"][c["toks"]][..., None]
+        np.add.at(dW, c["toks"], contrib.astype(self.dt))
+        return dict(W=dW)
+
+    def forward(self, cid_u, train=True, row_scale=None):
+        toks = self.C[np.asarray(cid_u)]                       # (n_u, L)
+        if train:
+            self.cache = dict(toks=toks, row_scale=row_scale)
+        h = self._front_forward(toks, row_scale, train)
         z = h @ self.Wd + self.bd
         if train:
             mu = z.mean(axis=0)
@@ -301,7 +320,7 @@ class TowerOracle(object):
         xhat = (z - mu) * inv
         y = self.gamma * xhat + self.beta
         if train:
-            self.cache = dict(toks=toks, h=h, xhat=xhat, inv=inv, y=y, row_scale=row_scale, mu=mu, var=var)
+            self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
         return np.maximum(y, 0).astype(self.dt)
 
     def backward_update(self, dA, conf=None, t=None):
@@ -316,26 +335,19 @@ class TowerOracle(object):
         dWd = c["h"].T @ dz
         dbd = dz.sum(axis=0)
         dh = dz @ self.Wd.T
-        L = self.dt.type(c["toks"].shape[1])
-        dW = np.zeros_like(self.W)
-        contrib = np.repeat(dh[:, None, :], c["toks"].shape[1], axis=1) / L
-        if c["row_scale"] is not None:
-            contrib = contrib * c["row_scale"][c["toks"]][..., None]
-        np.add.at(dW, c["toks"], contrib.astype(self.dt))
-        self.grads = dict(W=dW, Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
+        self.grads = dict(Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
+        self.grads.update(self._front_backward(dh.astype(self.dt)))
+        dW = self.grads["W"]
         self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
         self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
         if getattr(self, "export_only", False):   # data-parallel: gradients leave, nothing is applied
             return
         if conf is None or conf.optimizer == "sgd":
-            self.W -= self.lr * dW
-            self.Wd -= self.lr * dWd
-            self.bd -= self.lr * dbd
-            self.gamma -= self.lr * dgamma
-            self.beta -= self.lr * dbeta
+            for k in self.PARAMS:
+                getattr(self, k).__isub__(self.lr * self.grads[k].astype(self.dt))
         else:
             if not hasattr(self, "slots"):
-                self.slots = {k: AdamSlot(getattr(self, k)) for k in ("W", "Wd", "bd", "gamma", "beta")}
+                self.slots = {k: AdamSlot(getattr(self, k)) for k in self.PARAMS}
             lr_t = adam_lr_t(self.lr, conf.beta1, conf.beta2, t)
             rows = None
             if conf.optimizer == "sparse_adam":   # words of the batch that were not dropped
@@ -344,8 +356,9 @@ class TowerOracle(object):
                     toks = toks[c["row_scale"][toks] != 0]
                 rows = np.unique(toks)
             self.slots["W"].step(self.W, dW, lr_t, conf, rows)
-            for k, g in (("Wd", dWd), ("bd", dbd), ("gamma", dgamma), ("beta", dbeta)):
-                self.slots[k].step(getattr(self, k), g.astype(self.dt), lr_t, conf)
+            for k in self.PARAMS:
+                if k != "W":
+                    self.slots[k].step(getattr(self, k), self.grads[k].astype(self.dt), lr_t, conf)
 
     def flat_grads(self):
         """[W | Wd | bd, gamma, beta at 128-float pitch] -- the layout of nncf_tower_grad_floats."""
@@ -363,6 +376,88 @@ class TowerOracle(object):
         self.bd -= self.lr * f[nW + nD:nW + nD + d]
         self.gamma -= self.lr * f[nW + nD + 128:nW + nD + 128 + d]
         self.beta -= self.lr * f[nW + nD + 256:nW + nD + 256 + d]
+
+class CnnTowerOracle(TowerOracle):
+    """CNN item tower of model_choice = cnn_embedding (modules/content/cnn_model.py:11-145) for one
+    convolution layer with a single filter length (the 'best' preset: filter_lengths [3],
+    cnn_embedding_conf.py:129): word Embedding (+ row dropout) -> Convolution1D(num_filters,
+    filter_length, border_mode 'same', linear, :82-88) -> BatchNormalization over (items, positions)
+    per filter (:89-95) -> conv_activation relu -> Dropout(conv_dropout_rate) (:96-97) ->
+    AveragePooling1D over the whole length (:100-104) -> Flatten -> Dense(item_dim) -> BatchNorm
+    -> ReLU (:112-126), the same tail as MeanPool.
+    Wc: (fl, wd, F) as Keras stores it (fl, 1, wd, F); conv_mask(n, L, F): the dropout mask
+    INCLUDING its 1/keep scale for the next train-mode forward (None = no dropout).
+    [K-mem] TF 'SAME' padding for odd fl: (fl-1)/2 zeros on each side."""
+
+    PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta")
+
+    def __init__(self, C, W, Wc, bc, g1, b1, Wd, bd, gamma, beta, lr, dtype=np.float32, eps=1e-3, momentum=0.99):
+        TowerOracle.__init__(self, C, W, Wd, bd, gamma, beta, lr, dtype=dtype, eps=eps, momentum=momentum)
+        self.Wc = np.array(Wc, dtype=self.dt)
+        self.bc = np.array(bc, dtype=self.dt)
+        self.g1 = np.array(g1, dtype=self.dt)
+        self.b1 = np.array(b1, dtype=self.dt)
+        self.rm1 = np.zeros_like(self.b1)
+        self.rv1 = np.ones_like(self.b1)
+        self.conv_mask = None
+        assert self.Wc.shape[0] % 2 == 1, "odd filter lengths only"
+
+    def _front_forward(self, toks, row_scale, train):
+        fl, pad = self.Wc.shape[0], self.Wc.shape[0] // 2
+        n, L = toks.shape
+        X = self.W[toks]
+        if row_scale is not None:
+            X = X * row_scale[toks][..., None]
+        Xp = np.zeros((n, L + 2 * pad, X.shape[2]), dtype=self.dt)
+        Xp[:, pad:pad + L] = X
+        Y = np.zeros((n, L, self.Wc.shape[2]), dtype=self.dt) + self.bc
+        for tap in range(fl):
+            Y += Xp[:, tap:tap + L] @ self.Wc[tap]
+        if train:
+            mu = Y.mean(axis=(0, 1))
+            var = ((Y - mu) ** 2).mean(axis=(0, 1))
+        else:
+            mu, var = self.rm1, self.rv1
+        inv = 1.0 / np.sqrt(var + self.eps)
+        xh = (Y - mu) * inv
+        y1 = self.g1 * xh + self.b1
+        a = np.maximum(y1, 0)
+        mask = self.conv_mask[:n] if (train and self.conv_mask is not None) else None   # rows = block slots
+        if mask is not None:
+            a = a * mask
+        if train:
+            self.cache.update(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var)
+        return (a.sum(axis=1) / self.dt.type(L)).astype(self.dt)
+
+    def _front_backward(self, dh):
+        c = self.cache
+        fl, pad = self.Wc.shape[0], self.Wc.shape[0] // 2
+        n, Lp, wd = c["Xp"].shape
+        L = Lp - 2 * pad
+        da = np.repeat(dh[:, None, :], L, axis=1) / self.dt.type(L)
+        if c["mask"] is not None:
+            da = da * c["mask"]
+        dy1 = da * (c["y1"] > 0)
+        N = self.dt.type(n * L)
+        dg1 = (dy1 * c["xh1"]).sum(axis=(0, 1))
+        db1 = dy1.sum(axis=(0, 1))
+        dxh = dy1 * self.g1
+        dY = c["inv1"] / N * (N * dxh - dxh.sum(axis=(0, 1)) - c["xh1"] * (dxh * c["xh1"]).sum(axis=(0, 1)))
+        dY = dY.astype(self.dt)
+        dWc = np.zeros_like(self.Wc)
+        dXp = np.zeros_like(c["Xp"])
+        for tap in range(fl):
+            dWc[tap] = np.einsum("nlk,nlf->kf", c["Xp"][:, tap:tap + L], dY)
+            dXp[:, tap:tap + L] += dY @ self.Wc[tap].T
+        dX = dXp[:, pad:pad + L]
+        if c["row_scale"] is not None:
+            dX = dX * c["row_scale"][c["toks"]][..., None]
+        dW = np.zeros_like(self.W)
+        np.add.at(dW, c["toks"], dX.astype(self.dt))
+        self.rm1 = self.mom * self.rm1 + (1 - self.mom) * c["mu1"]
+        self.rv1 = self.mom * self.rv1 + (1 - self.mom) * c["var1"]
+        return dict(W=dW, Wc=dWc, bc=dY.sum(axis=(0, 1)), g1=dg1, b1=db1)
+
 
 # ----------------------------------------------------------------------------------------
 # the model: id-table towers ('mf', model_framework.py:59-63,85-88) + sparse SGD

@@ -327,3 +327,47 @@ def test_step_oracle_adam_moves_idle_rows_only_when_dense():
         else:
             assert moved == 0
         assert o.t == 2
+
+
+def test_cnn_tower_oracle_vs_autograd_full_chain():
+    """CnnTowerOracle (explicit forward / backward) against torch autograd of the same graph written
+    with torch ops (conv1d 'same', batch_norm over (items, positions), relu, mask, mean, linear,
+    batch_norm, relu), float64, through a neg_shared step."""
+    rs = np.random.RandomState(3)
+    n_items, L, V, wd, F, d, b, nu, fl = 40, 9, 30, 6, 7, 5, 16, 12, 3
+    C = rs.randint(0, V, (n_items, L))
+    W = rs.randn(V, wd) * 0.5
+    Wc = rs.randn(fl, wd, F) * 0.4
+    bc = rs.randn(F) * 0.1
+    g1, b1 = 1 + 0.1 * rs.randn(F), 0.1 * rs.randn(F)
+    Wd = rs.randn(F, d) * 0.5
+    bd, gamma, beta = rs.randn(d) * 0.1, 1 + 0.1 * rs.randn(d), 0.1 * rs.randn(d)
+    U = rs.randn(nu, d) * 0.5
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, n_items, b)
+    scale = ((rs.rand(V) < 0.7) / 0.7)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="log-loss", u_reg=1e-3, learn_rate=0.1,
+                         model_choice="basic_embedding")
+    to = so.CnnTowerOracle(C, W, Wc, bc, g1, b1, Wd, bd, gamma, beta, 0.1, dtype=np.float64)
+    cid_u, cid_x = so.tf_unique(cid)
+    mask = ((rs.rand(len(cid_u), L, F) < 0.8) / 0.8)
+    to.conv_mask = mask
+    orc = so.StepOracle(U, None, conf, dtype=np.float64, tower=to)
+    orc.row_scale = scale
+    loss = orc.step_neg_shared(uid, cid)
+
+    T = lambda x: torch.tensor(np.asarray(x, dtype=np.float64), requires_grad=True)  # noqa: E731
+    tW, tWc, tbc, tg1, tb1, tWd, tbd, tga, tbe, tU = map(T, (W, Wc, bc, g1, b1, Wd, bd, gamma, beta, U))
+    toks = torch.tensor(C[cid_u])
+    X = tW[toks] * torch.tensor(scale)[toks][..., None]                         # (n, L, wd)
+    Y = torch.nn.functional.conv1d(X.transpose(1, 2), tWc.permute(2, 1, 0), bias=tbc, padding=fl // 2).transpose(1, 2)
+    mu, var = Y.mean(dim=(0, 1)), Y.var(dim=(0, 1), unbiased=False)
+    a = torch.relu(tg1 * (Y - mu) / torch.sqrt(var + 1e-3) + tb1) * torch.tensor(mask)
+    h = a.mean(dim=1)
+    z = h @ tWd + tbd
+    E = torch.relu(tga * (z - z.mean(0)) / torch.sqrt(z.var(0, unbiased=False) + 1e-3) + tbe)
+    lt = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cid_x), conf)
+    lt.backward()
+    assert abs(loss - float(lt)) < 1e-9 * max(1, abs(loss))
+    for name, tp in (("W", tW), ("Wc", tWc), ("bc", tbc), ("g1", tg1), ("b1", tb1), ("Wd", tWd), ("bd", tbd),
+                     ("gamma", tga), ("beta", tbe)):
+        np.testing.assert_allclose(to.grads[name], tp.grad.numpy(), rtol=1e-7, atol=1e-10, err_msg=name)

@@ -212,3 +212,79 @@ def test_basic_embedding_adam_matches_oracle(text_data, kind):
         for name in ("W", "Wd", "gamma", "beta"):
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=5e-4, atol=5e-5,
                                        err_msg="%s step %d" % (name, step))
+
+
+# ---- cnn_embedding -------------------------------------------------------------------------------
+
+def _conf_cnn(loss, scheme, b=64, k=3, d=24, F=20, fl=3, lr=0.1, wdrop=0.0, cdrop=0.0):
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": loss, "num_negatives": k if scheme == "original" else 0,
+          "neg_loss_weight": 16, "loss_gamma": 0.1 if loss == "max-margin" else 10, "learn_rate": lr,
+          "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d, "item_dim": d,
+          "word_dim": 16, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": wdrop, "num_filters": [F],
+          "filter_lengths": [fl], "conv_dropout_rate": cdrop}
+    return get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+
+
+def _oracle_cnn(conf, md, data):
+    core = md["model"].core
+    tw, eng = core.tower, core.engine
+    oc = so.OracleConf(batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
+                       loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
+                       learn_rate=conf.learn_rate, emb_normalization=conf.emb_normalization,
+                       model_choice="basic_embedding", optimizer=conf.optimizer)
+    g = lambda t: t.cpu().numpy()  # noqa: E731
+    to = so.CnnTowerOracle(data["C"], g(tw.W), g(tw.Wc), g(tw.bc), g(tw.g1), g(tw.b1), g(tw.Wd), g(tw.bd), g(tw.gamma),
+                           g(tw.beta), conf.learn_rate, dtype=np.float32)
+    return so.StepOracle(g(eng.U), None, oc, dtype=np.float32, tower=to), to
+
+
+CNN_PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta", "rm", "rv", "rm1", "rv1")
+
+
+@pytest.mark.parametrize("scheme,loss,fl,drop", [("neg_shared", "skip-gram", 3, False), ("neg_shared", "log-loss", 3, True),
+                                                 ("group_neg_shared", "log-loss", 5, False), ("original", "skip-gram", 1, True),
+                                                 ("group_neg_shared", "max-margin", 3, True)])
+def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop):
+    """cnn_embedding (conv + BN + relu + dropout + average pooling in front of Dense/BN/ReLU) against
+    CnnTowerOracle: loss, every parameter and the running statistics after each step; the kernels'
+    row-dropout and conv-dropout hash masks are materialised and fed to the oracle."""
+    conf = _conf_cnn(loss, scheme, fl=fl, wdrop=0.3 if drop else 0.0, cdrop=0.2 if drop else 0.0)
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "cnn_embedding", seed=2)
+    orc, to = _oracle_cnn(conf, md, text_data)
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        if drop:
+            orc.row_scale = tw.dropout_scale(step).cpu().numpy()
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy()
+        if scheme == "original":
+            negs = rs.randint(0, 260, b * k)
+            u, c, y = so.assemble_original(bt, negs, loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        for name in CNN_PARAMS:
+            if name == "bc":   # gradient through BatchNorm is rounding noise around zero
+                np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
+                continue
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=3e-4, atol=3e-5,
+                                       err_msg="%s step %d" % (name, step))
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
