@@ -46,8 +46,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=390)
     ap.add_argument("--scheme", default="neg_shared", choices=["original", "neg_shared", "group_neg_shared"])
     ap.add_argument("--loss", default=None)
-    ap.add_argument("--model", default="basic_embedding", choices=["basic_embedding", "mf"],
-                    help="basic_embedding = mean-pool text tower (BASELINE configs[1]); mf = id-table towers only")
+    ap.add_argument("--model", default="basic_embedding", choices=["basic_embedding", "cnn_embedding", "mf"],
+                    help="basic_embedding = mean-pool text tower (BASELINE configs[1]); cnn_embedding = CNN text tower "
+                         "(configs[4]: use --scheme group_neg_shared); mf = id-table towers only")
+    ap.add_argument("--conv-dropout", type=float, default=0.1, help="cnn_embedding: Dropout after the conv ('best' preset)")
+    ap.add_argument("--filter-len", type=int, default=3, help="cnn_embedding: Convolution1D filter length ('best' preset)")
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--negatives", type=int, default=10)
@@ -77,7 +80,9 @@ def param_dict_for(args):
             "neg_loss_weight": 8 if loss == "mse" else 128, "loss_gamma": 0.1 if loss == "max-margin" else 10,
             "learn_rate": 0.001 if loss == "mse" else 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
             "batch_size_p": args.batch, "user_dim": args.dim, "item_dim": args.dim, "word_dim": args.dim,
-            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None, "optimizer": args.optimizer}
+            "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None,
+            "optimizer": args.optimizer, "num_filters": [args.dim], "filter_lengths": [args.filter_len],
+            "conv_dropout_rate": args.conv_dropout}
 
 
 def conf_for(args):
@@ -104,7 +109,7 @@ def make_data(args):
     from nncf_amd.synthetic import make_citeulike_like
     if args.large:
         return make_large(args)
-    text = args.content_len if args.model == "basic_embedding" else 0
+    text = args.content_len if args.model != "mf" else 0
     if args.small:
         return make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7, content_len=min(text, 40),
                                    vocab=min(args.vocab, 500))
@@ -149,7 +154,8 @@ def cpu_baseline(args, conf, inp, U0, V0, tower_params):
         cores = os.cpu_count() or 1
     tower = None
     if tower_params is not None:
-        tower = so.TowerOracle(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
+        cls = so.CnnTowerOracle if args.model == "cnn_embedding" else so.TowerOracle
+        tower = cls(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
     o = so.StepOracle(U0, V0, conf, dtype=np.float32, tower=tower)
     b, k = conf.batch_size_p, conf.num_negatives
     sampler = OracleSampler(inp["dist"], 1.0, 12345) if args.scheme == "original" else None
@@ -161,6 +167,9 @@ def cpu_baseline(args, conf, inp, U0, V0, tower_params):
     while steps < max_steps and (time.time() - t0 < args.cpu_seconds or steps < 5):
         if drop > 0:   # Embedding(dropout): a fresh row mask per batch (mean_pool.py:56-59)
             o.row_scale = ((mask_rs.rand(tower.W.shape[0]) < 1 - drop) / (1 - drop)).astype(np.float32)
+        if args.model == "cnn_embedding" and args.conv_dropout > 0:   # Dropout(conv_dropout_rate), cnn_model.py:97
+            kc = 1 - args.conv_dropout
+            tower.conv_mask = ((mask_rs.rand(b * (1 + k), tower.C.shape[1], tower.Wc.shape[2]) < kc) / kc).astype(np.float32)
         u = inp["uid"][steps * b:(steps + 1) * b]
         c = inp["cid"][steps * b:(steps + 1) * b]
         if args.scheme == "original":
@@ -320,6 +329,8 @@ def main_sharded(args, conf, rank, world, local_rank):
     from nncf_amd.synthetic import make_citeulike_like
     if args.model == "basic_embedding":
         return main_data_parallel(args, rank, world, local_rank)
+    if args.model != "mf":
+        raise SystemExit("--gpus > 1 is built for --model basic_embedding (data parallel) and --model mf (item-sharded)")
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
     conf = conf_for(args)
@@ -438,7 +449,9 @@ def main():
         V0 = eng.V.cpu().numpy().copy() if want_cpu else None
     else:
         tw = head.core.tower
-        tower_params = [t.cpu().numpy().copy() for t in (tw.W, tw.Wd, tw.bd, tw.gamma, tw.beta)]
+        names_p = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta") if args.model == "cnn_embedding" else \
+            ("W", "Wd", "bd", "gamma", "beta")
+        tower_params = [getattr(tw, n).cpu().numpy().copy() for n in names_p]
     uid = eng.ids(inp["uid"])
     cid = eng.ids(inp["cid"])
     W, K = args.warmup, args.steps
@@ -448,6 +461,8 @@ def main():
         sampler = MultinomialSampler(inp["dist"], inp["dist"].size, 1.0, 12345, device=local_rank)
         neg = torch.empty((W + K) * b * k, dtype=torch.int32, device=eng.device)
 
+    n_u_buf = torch.zeros(W + K + 1, dtype=torch.int32, device=eng.device) if args.model != "mf" else None
+
     def run(first, count):
         u, c = uid[first * b:], cid[first * b:]
         n = None
@@ -456,6 +471,8 @@ def main():
             # the whole window's negatives are drawn on device first, same stream order.
             n = neg[first * b * k:(first + count) * b * k]
             sampler.sample_batch_device(count * b * k, out=n)
+        if n_u_buf is not None:
+            return head.run_epoch(u, c, count, neg_all=n, n_u_out=n_u_buf[first:first + count])
         return head.run_epoch(u, c, count, neg_all=n)
 
     def sync():
@@ -475,8 +492,12 @@ def main():
 
     # ---- roofline leg: same steps again, dominant kernel bracketed by HIP events ----------
     L = args.content_len if not args.small else min(args.content_len, 40)
-    keep = 1.0 - (args.dropout if args.model == "basic_embedding" else 0.0)
+    keep = 1.0 - (args.dropout if args.model != "mf" else 0.0)
+    mean_n_u = float(n_u_buf[W:W + K].double().mean().item()) if n_u_buf is not None else float(b)
+    conv_flop = 2.0 * mean_n_u * L * args.filter_len * d * d   # per launch, n_u = mean unique items of the timed steps
     kernels = {
+        "cnn_conv_fwd_kernel": ("mfma", conv_flop, "2*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % mean_n_u),
+        "cnn_conv_bwd_kernel": ("mfma", 2 * conv_flop, "dX and dWk: 4*n_u*L*fl*word_dim*F flop, n_u = %.1f" % mean_n_u),
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
         "tower_pool_kernel": ("hbm", 4.0 * b * L * d * keep, "4*L*word_dim*(1-dropout) B per unique item (n_u <= b rows)"),
@@ -485,11 +506,13 @@ def main():
         "tower_bwd_kernel": ("mfma", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
     }
     default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
-        ("shared_tile_kernel" if args.model == "mf" else "tower_word_kernel")
+        {"mf": "shared_tile_kernel", "cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, "tower_word_kernel")
     names = [args.roofline_kernel or default_kernel]
     if args.model == "basic_embedding":
         names += [n for n in ("tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel", "shared_tile_kernel")
                   if n not in names]
+    if args.model == "cnn_embedding":
+        names += [n for n in ("cnn_conv_fwd_kernel", "tower_word_kernel", "shared_tile_kernel") if n not in names]
     prof_n = min(K, args.profile_launches)
     roofs = []
     for name in names:
@@ -519,14 +542,17 @@ def main():
         value = K * b * world / elapsed
         tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
                      % (L, args.vocab, args.dropout)
-                     if args.model == "basic_embedding" else "id-table towers (model_choice=mf)")
+                     if args.model == "basic_embedding" else
+                     "cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %d)+BN+ReLU+"
+                     "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_len, args.conv_dropout)
+                     if args.model == "cnn_embedding" else "id-table towers (model_choice=mf)")
         line = {
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init parameters" if args.large
                      else "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
-                     % (", item text" if args.model == "basic_embedding" else "")),
+                     % (", item text" if args.model != "mf" else "")),
             "config": {"workload": "%s, %s d=%d, train_scheme=%s, loss=%s, b=%d%s, %s"
                                    % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", tower_txt, d,
                                       args.scheme, conf.loss, b, (", k=%d" % k) if k else "",
@@ -534,6 +560,7 @@ def main():
                                        "sparse_adam": "lazy-sparse Adam"}[args.optimizer]),
                        "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
+            "mean_unique_items_per_step": mean_n_u if args.model != "mf" else None,
             "roofline": roof,
             "roofline_other_kernels": roofs[1:],
             "cpu_baseline": cpu,

@@ -24,7 +24,21 @@
 
 namespace nncf {
 
-__host__ __device__ inline int conv_pitch(int w) { return ((w + 15) & ~15) + 4; }  // floats; rows 16 B apart mod 256 B
+// LDS row pitches (floats) for the two MFMA operand read patterns (MI355X_MICROARCH.md, LDS):
+//  * rows read as 16-byte fragments along K by ds_read_b128 (lane = 16 kq + row): conflict-free in
+//    all four 16-lane groups when pitch/4 = 2 (mod 16), i.e. pitch = 8 (mod 64);
+//  * rows read one dword per lane by ds_read_b32 (lanes 0-31 = 2 K-rows x 16 columns, 32 banks):
+//    conflict-free when pitch = 16 (mod 32).
+__host__ __device__ inline int conv_pitch(int w) {   // ds_read_b128 pattern
+  int p = (w + 15) & ~15;
+  while (p % 64 != 8) p += 4;
+  return p;
+}
+__host__ __device__ inline int conv_pitch32(int w) {  // ds_read_b32 pattern
+  int p = (w + 15) & ~15;
+  while (p % 32 != 16) p += 4;
+  return p;
+}
 
 __device__ __forceinline__ float conv_keep(const TowerArgs& a, int64_t pos_index, int c) {
   if (a.cnn.keep >= 1.f) return 1.f;
@@ -68,22 +82,35 @@ __device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, 
 
 // ---- forward ---------------------------------------------------------------------------------
 
+// Two workgroups per item (kFwdSplit): each computes half of the positions, so that a group-shared
+// batch of ~100 unique items still fills the 256 CUs.
+constexpr int kFwdSplit = 2;
+constexpr int kFwdMt = 8;  // row tiles of 16 positions per workgroup: L <= 2 * 8 * 16 = 256
+
+// NMT / NKT: row tiles per workgroup and 16-column K groups of the word dimension as compile-time
+// loop bounds.  MASK = false: the shape matches exactly (the LDS tile is zero-padded past L and
+// past wd, so no per-fragment guards remain between the MFMAs); MASK = true: any smaller shape.
+template <int NMT, int NKT, bool MASK>
 __global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
   __shared__ float sSc[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, kq = lane >> 4;
-  const int s = blockIdx.x;
+  const int s = blockIdx.x / kFwdSplit, half = blockIdx.x % kFwdSplit;
   if (s >= valid_rows(a)) return;
   const int item = a.ids[s];
   const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L;
   const int XP = conv_pitch(a.wd);
-  const int nMt = (L + 15) >> 4, nKt = (a.wd + 15) >> 4, nNt = (F + 15) >> 4;
-  const int rows = 16 * nMt + fl - 1;
+  const int nMtAll = (L + 15) >> 4, nMtH = (nMtAll + kFwdSplit - 1) / kFwdSplit;
+  const int mt0 = half * nMtH;  // this workgroup's row tiles: [mt0, mt0 + nMt)
+  const int nMt = MASK ? min(nMtH, nMtAll - mt0) : NMT, nKt = MASK ? (a.wd + 15) >> 4 : NKT;
+  const int nNt = (F + 15) >> 4;
+  const int p_base = 16 * mt0;
+  const int rows = 16 * nMtH + fl - 1;
   float* sX = smem;
   stage_tokens(a, item, sTok, sSc);
   // backward preparation: cnt_t[w][s] = 1 + ordinal of word w among the item's distinct words
-  if (a.fill) {
+  if (a.fill && half == 0) {
     const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
     for (int e = e0 + tid; e < e1; e += 256) {
       const int wv = a.item_word[e];
@@ -91,50 +118,65 @@ __global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
     }
   }
   __syncthreads();
-  stage_rows(a, sTok, sSc, sX, XP, -pad, rows);
+  if (!(a.cnn.dbg & 2)) stage_rows(a, sTok, sSc, sX, XP, p_base - pad, rows);
   __syncthreads();
   const int KW = fl * a.wd;
   for (int nt = wave; nt < nNt; nt += 4) {
     const int col = nt * 16 + x;
-    f32x4 acc[16];
+    f32x4 acc[NMT];
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tap = 0; tap < fl; ++tap) {
-      // B fragments of this tap: Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e
-      // of the float4 at column 16t+4kq serves k-step (t, e) on both operands)
-      float4 bf[8];
-      const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
+    for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tap0 = 0; tap0 < ((a.cnn.dbg & 1) ? 0 : fl); tap0 += 3) {
+      // B fragments of up to three taps at once (all their loads in flight before the first MFMA):
+      // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
+      // 16t+4kq serves k-step (t, e) on both operands)
+      float4 bf[3][NKT];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int c0 = 16 * t + 4 * kq;
-        bf[t] = (t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
+      for (int tt = 0; tt < 3; ++tt) {
+        const int tap = tap0 + tt;
+        const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+          const int c0 = 16 * t + 4 * kq;
+          bf[tt][t] = (tap < fl && t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
+        }
       }
 #pragma unroll
-      for (int mt = 0; mt < 16; ++mt) {
-        if (mt < nMt) {
-          const float* arow = sX + (int64_t)(16 * mt + x + tap) * XP + 4 * kq;
+      for (int tt = 0; tt < 3; ++tt) {
+        const int tap = tap0 + tt;
+        if (tap < fl) {
+          const float* abase = sX + (int64_t)(x + tap) * XP + 4 * kq;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            if (t < nKt) {
-              const float4 af = *reinterpret_cast<const float4*>(arow + 16 * t);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[t].x, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[t].y, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[t].z, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[t].w, acc[mt], 0, 0, 0);
+          for (int t = 0; t < NKT; ++t) {
+            if (!MASK || t < nKt) {
+              // all row tiles' A fragments first, then the MFMAs interleaved over the tiles: no two
+              // consecutive MFMAs touch the same accumulator
+              float4 af[NMT];
+#pragma unroll
+              for (int mt = 0; mt < NMT; ++mt)
+                af[mt] = (!MASK || mt < nMt) ? *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * XP + 16 * t) : zero4();
+#pragma unroll
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].x, bf[tt][t].x, acc[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].y, bf[tt][t].y, acc[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].z, bf[tt][t].z, acc[mt], 0, 0, 0);
+#pragma unroll
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].w, bf[tt][t].w, acc[mt], 0, 0, 0);
             }
           }
         }
       }
     }
-    // epilogue: D[i = 4kq + r][j = x] -> Y[s][p = 16mt + i][col]; statistics of (y - b)
+    // epilogue: D[i = 4kq + r][j = x] -> Y[s][p = p_base + 16mt + i][col]; statistics of (y - b)
     const float bias = col < F ? a.cnn.bc[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 16; ++mt) {
+    for (int mt = 0; mt < NMT; ++mt) {
       if (mt < nMt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int p = 16 * mt + 4 * kq + r;
+          const int p = p_base + 16 * mt + 4 * kq + r;
           if (p < L && col < F) {
             const float v = acc[mt][r];
             a.cnn.Y[((int64_t)s * L + p) * F + col] = v + bias;
@@ -149,8 +191,8 @@ __global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
     s2 += __shfl_xor(s2, 16);
     s2 += __shfl_xor(s2, 32);
     if (kq == 0 && a.train) {
-      a.cnn.part1[(int64_t)s * 256 + col] = s1;
-      a.cnn.part1[(int64_t)s * 256 + 128 + col] = s2;
+      a.cnn.part1[(int64_t)blockIdx.x * 256 + col] = s1;
+      a.cnn.part1[(int64_t)blockIdx.x * 256 + 128 + col] = s2;
     }
   }
 }
@@ -190,7 +232,7 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int nv = valid_rows(a), c = threadIdx.x;
   float t1, t2;
-  merge_slot_partials(a.cnn.part1, nv, sRed, t1, t2);
+  merge_slot_partials(a.cnn.part1, nv * kFwdSplit, sRed, t1, t2);
   if (c < 128) {
     float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
     if (c < a.cnn.F) {
@@ -375,7 +417,9 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   }
 }
 
-// One workgroup per (slot, block of kConvLB positions).
+// One workgroup per (slot, block of kConvLB positions).  NFT: 16-column groups of the filter
+// dimension as a compile-time bound of (a)'s K loop (MASK = false: exactly ceil(F/16) == NFT).
+template <int NFT, bool MASK>
 __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
@@ -388,7 +432,7 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   if (s >= nv) return;
   const int item = a.ids[s];
   const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, f4 = F >> 2;
-  const int XP = conv_pitch(a.wd), FP = conv_pitch(F);
+  const int XP = conv_pitch32(a.wd), FP = conv_pitch32(F);  // (b) reads both tiles dword-wise, 2 per MFMA
   const int p0 = blk * kConvLB;
   const int rows = kConvLB + fl - 1;       // positions [p0 - pad, p0 + kConvLB + pad)
   float* sX = smem;                        // [rows][XP]  gathered (scaled) word rows
@@ -443,30 +487,43 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ------------------------
   {
     const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-    for (int kt = wave; kt < nKw; kt += 4) {
+    for (int kt = wave; kt < ((a.cnn.dbg & 4) ? 0 : nKw); kt += 4) {
       const int kcol = kt * 16 + x;
       f32x4 acc[kConvLB / 16];
 #pragma unroll
       for (int mt = 0; mt < nMb; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int tap = 0; tap < fl; ++tap) {
-        float4 bf[8];
-        const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wk + ((int64_t)tap * a.wd + kcol) * F);
+      for (int tap0 = 0; tap0 < fl; tap0 += 3) {
+        float4 bf[3][NFT];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const int c0 = 16 * t + 4 * kq;
-          bf[t] = (t < nFt && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
+        for (int tt = 0; tt < 3; ++tt) {
+          const int tap = tap0 + tt;
+          const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wk + ((int64_t)tap * a.wd + kcol) * F);
+#pragma unroll
+          for (int t = 0; t < NFT; ++t) {
+            const int c0 = 16 * t + 4 * kq;
+            bf[tt][t] = (tap < fl && t < nFt && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
+          }
         }
 #pragma unroll
-        for (int mt = 0; mt < nMb; ++mt) {
-          const float* arow = sD + (int64_t)(16 * mt + x + (fl - 1 - tap)) * FP + 4 * kq;
+        for (int tt = 0; tt < 3; ++tt) {
+          const int tap = tap0 + tt;
+          if (tap < fl) {
+            const float* abase = sD + (int64_t)(x + (fl - 1 - tap)) * FP + 4 * kq;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            if (t < nFt) {
-              const float4 af = *reinterpret_cast<const float4*>(arow + 16 * t);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[t].x, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[t].y, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[t].z, acc[mt], 0, 0, 0);
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[t].w, acc[mt], 0, 0, 0);
+            for (int t = 0; t < NFT; ++t) {
+              if (!MASK || t < nFt) {
+                float4 af[kConvLB / 16];
+#pragma unroll
+                for (int mt = 0; mt < nMb; ++mt) af[mt] = *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * FP + 16 * t);
+#pragma unroll
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].x, bf[tt][t].x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].y, bf[tt][t].y, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].z, bf[tt][t].z, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].w, bf[tt][t].w, acc[mt], 0, 0, 0);
+              }
             }
           }
         }
@@ -486,19 +543,39 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
     const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
     const int ntile = fl * nKw * nFt;
     float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
-    for (int tt = wave; tt < ntile; tt += 4) {
-      const int tap = tt / (nKw * nFt), kt = (tt / nFt) % nKw, ft = tt % nFt;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* pa = sX + (int64_t)(kq + tap) * XP + kt * 16 + x;   // position p0 + 4st + kq, shifted by the tap
-      const float* pb = sD + (int64_t)(kq + pad) * FP + ft * 16 + x;
-#pragma unroll 4
-      for (int st = 0; st < kConvLB / 4; ++st)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[(int64_t)4 * st * XP], pb[(int64_t)4 * st * FP], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWk[tap][kt*16 + i][ft*16 + x]
-        const int k = kt * 16 + 4 * kq + r, f = ft * 16 + x;
-        if (k < a.wd && f < F) gw[((int64_t)tap * a.wd + k) * F + f] = acc[r];
+    // 2 x 2 register blocking: a wave computes tiles (kt, kt+1) x (ft, ft+1) of one tap together --
+    // two A and two B dwords from LDS feed four MFMAs on independent accumulators
+    const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1;
+    const int nblock = fl * nKp * nFp;
+    for (int bb = wave; bb < ((a.cnn.dbg & 8) ? 0 : nblock); bb += 4) {
+      const int tap = bb / (nKp * nFp), kp = (bb / nFp) % nKp, fp = bb % nFp;
+      const int kt0 = 2 * kp, ft0 = 2 * fp;
+      const bool k1 = kt0 + 1 < nKw, f1 = ft0 + 1 < nFt;
+      f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+      const float* pa0 = sX + (int64_t)(kq + tap) * XP + kt0 * 16 + x;   // position p0 + 4st + kq, shifted by the tap
+      const float* pa1 = pa0 + (k1 ? 16 : 0);
+      const float* pb0 = sD + (int64_t)(kq + pad) * FP + ft0 * 16 + x;
+      const float* pb1 = pb0 + (f1 ? 16 : 0);
+#pragma unroll 7
+      for (int st = 0; st < kConvLB / 4; ++st) {
+        const float a0 = pa0[(int64_t)4 * st * XP], a1 = pa1[(int64_t)4 * st * XP];
+        const float b0 = pb0[(int64_t)4 * st * FP], b1 = pb1[(int64_t)4 * st * FP];
+        acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc11, 0, 0, 0);
       }
+      auto put = [&](const f32x4& acc, int kt, int ft) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWk[tap][kt*16 + i][ft*16 + x]
+          const int k = kt * 16 + 4 * kq + r, f = ft * 16 + x;
+          if (k < a.wd && f < F) gw[((int64_t)tap * a.wd + k) * F + f] = acc[r];
+        }
+      };
+      put(acc00, kt0, ft0);
+      if (f1) put(acc01, kt0, ft0 + 1);
+      if (k1) put(acc10, kt0 + 1, ft0);
+      if (k1 && f1) put(acc11, kt0 + 1, ft0 + 1);
     }
     if (tid < 128) {  // column sums of dY over the block's own positions (conv bias gradient)
       float t = 0.f;
@@ -509,54 +586,120 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   }
 }
 
-// per item: rows of dX summed per distinct word, through the static sorted-position index
+// per item: rows of dX summed per distinct word, through the static sorted-position index.  The
+// item's entry table and position order are staged in LDS first, so the row loads are the only
+// dependent round trip.  Words with up to kLight occurrences: one 16-lane group per entry, four
+// entries of a group in flight.  Heavier words (the pad word, typically): all 16 groups share the
+// positions, partial rows combined in group order through LDS.
+constexpr int kLight = 4;
 __global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
-  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, wd4 = a.wd >> 2, L = a.L;
+  __shared__ uint8_t sPos[256], sStart[256], sCnt[256];
+  __shared__ int sHeavy[64], sNH;
+  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, wd4 = a.wd >> 2, L = a.L;
   const int s = blockIdx.x;
   if (s >= valid_rows(a)) return;
   const int item = a.ids[s];
-  const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
-  const uint8_t* spos = a.cnn.item_spos + (int64_t)item * L;
-  for (int e = e0 + grp; e < e1; e += 16) {
-    const int start = a.cnn.item_start[e], cnt = a.item_cnt[e];
+  const int e0 = a.item_ptr[item], ne = a.item_ptr[item + 1] - e0;
+  if (tid == 0) sNH = 0;
+  __syncthreads();
+  if (tid < L) sPos[tid] = a.cnn.item_spos[(int64_t)item * L + tid];
+  if (tid < ne) {
+    const int cn = a.item_cnt[e0 + tid];
+    sStart[tid] = a.cnn.item_start[e0 + tid];
+    sCnt[tid] = (uint8_t)cn;
+    if (cn > kLight) sHeavy[atomicAdd(&sNH, 1)] = tid;  // at most L / (kLight + 1) < 64 of them; order irrelevant
+  }
+  __syncthreads();
+  const float* dXs = a.cnn.dX + (int64_t)s * L * a.wd;
+  for (int eb = grp; eb < ne; eb += 64) {
+    Row r[4][kLight];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = eb + 16 * u;
+      const int cn = (e < ne && sCnt[e] <= kLight) ? sCnt[e] : 0;
+#pragma unroll
+      for (int t = 0; t < kLight; ++t) r[u][t] = (t < cn) ? row_load(dXs, sPos[sStart[e] + t], a.wd, wd4, q) : row_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = eb + 16 * u;
+      if (e < ne && sCnt[e] <= kLight) {
+        Row sum = r[u][0];
+#pragma unroll
+        for (int t = 1; t < kLight; ++t) sum = row_add(sum, r[u][t]);
+        row_store(a.cnn.dXw, (int64_t)s * L + e, a.wd, wd4, q, sum);
+      }
+    }
+  }
+  const int nh = sNH;
+  for (int hi = 0; hi < nh; ++hi) {
+    const int e = sHeavy[hi], st = sStart[e], cn = sCnt[e];
     Row sum = row_zero();
-    for (int t0 = 0; t0 < cnt; t0 += 4) {
+    for (int t0 = grp; t0 < cn; t0 += 64) {  // this group's positions, 4 in flight
       Row r[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        r[u] = (t0 + u < cnt) ? row_load(a.cnn.dX, (int64_t)s * L + spos[start + t0 + u], a.wd, wd4, q) : row_zero();
+      for (int u = 0; u < 4; ++u) r[u] = (t0 + 16 * u < cn) ? row_load(dXs, sPos[st + t0 + 16 * u], a.wd, wd4, q) : row_zero();
 #pragma unroll
       for (int u = 0; u < 4; ++u) sum = row_add(sum, r[u]);
     }
-    row_store(a.cnn.dXw, (int64_t)s * L + (e - e0), a.wd, wd4, q, sum);
+    __syncthreads();
+    reinterpret_cast<float4*>(sR + grp * kTP)[q] = sum.a;
+    reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = sum.b;
+    __syncthreads();
+    if (grp == 0) {
+      Row tot = row_zero();
+      for (int g = 0; g < 16; ++g) {
+        tot.a = add4(tot.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
+        tot.b = add4(tot.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+      }
+      row_store(a.cnn.dXw, (int64_t)s * L + e, a.wd, wd4, q, tot);
+    }
   }
 }
 
-__global__ void __launch_bounds__(256) cnn_update_kernel(TowerArgs a, int nblk) {
+// Weight-gradient partials [nparts][nel] -> sums in partial order.  128 elements x 8 part-groups per
+// workgroup: part-group g adds parts g, g+8, ... (16 loads in flight), the groups are combined in
+// group order through LDS.  The last workgroup handles the conv bias and the BN1 scale / shift.
+__global__ void __launch_bounds__(1024) cnn_update_kernel(TowerArgs a, int nblk) {
+  __shared__ float sG[8 * 128];
   const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
   const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x blocks, contiguous
-  const int nb = (nel + 255) / 256;
+  const int nb = (nel + 127) / 128;
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   if ((int)blockIdx.x < nb) {
-    const int el = blockIdx.x * 256 + threadIdx.x;
-    if (el >= nel) return;
-    float g = 0.f;
-    for (int p0 = 0; p0 < nparts; p0 += 16) {  // partials in workgroup order, 16 loads in flight
-      float u[16];
+    const int el = blockIdx.x * 128 + c;
+    float acc = 0.f;
+    if (el < nel) {
+      for (int p0 = g; p0 < nparts; p0 += 8 * 16) {
+        float u[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) u[e] = (p0 + e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + e) * nel + el] : 0.f;
+        for (int e = 0; e < 16; ++e) u[e] = (p0 + 8 * e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + 8 * e) * nel + el] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) g += u[e];
+        for (int e = 0; e < 16; ++e) acc += u[e];
+      }
     }
-    const float nw = a.opt ? adam1(g, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * g;
-    a.cnn.Wk[el] = nw;
-    const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
-    a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + k] = nw;
+    sG[g * 128 + c] = acc;
+    __syncthreads();
+    if (g == 0 && el < nel) {
+      float gsum = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) gsum += sG[gg * 128 + c];
+      const float nw = a.opt ? adam1(gsum, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * gsum;
+      a.cnn.Wk[el] = nw;
+      const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
+      a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + k] = nw;
+    }
     return;
   }
-  const int c = threadIdx.x;
-  if (c >= F) return;
+  float acc = 0.f;
+  for (int p = g; p < nparts; p += 8) acc += a.cnn.gbpart[(int64_t)p * 128 + c];
+  sG[g * 128 + c] = acc;
+  __syncthreads();
+  if (g != 0 || c >= F) return;
   float gb = 0.f;
-  for (int p = 0; p < nparts; ++p) gb += a.cnn.gbpart[(int64_t)p * 128 + c];
+#pragma unroll
+  for (int gg = 0; gg < 8; ++gg) gb += sG[gg * 128 + c];
   const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
   if (a.opt) {
     float *mm = a.cnn.mC + nel, *vv = a.cnn.vC + nel;
@@ -595,7 +738,7 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
   a.Y = c.take<float>(cap * L * F);
   a.dX = c.take<float>(cap * L * wd);
   a.dXw = c.take<float>(cap * L * wd);
-  a.part1 = c.take<float>(cap * 256);
+  a.part1 = c.take<float>(cap * kFwdSplit * 256);
   a.st1 = c.take<float>(7 * 128);
   a.bpart = c.take<float>(cap * 256);
   a.gWpart = c.take<float>(cap * nblk * fl * wd * F);
@@ -617,12 +760,24 @@ static int set_lds(const void* fn, size_t bytes) {
 
 int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int L = a.L, fl = a.cnn.fl;
-  const size_t lds = (size_t)(16 * ((L + 15) / 16) + fl - 1) * conv_pitch(a.wd) * sizeof(float);
+  const int nMtH = (((L + 15) / 16) + kFwdSplit - 1) / kFwdSplit;
+  const size_t lds = (size_t)(16 * nMtH + fl - 1) * conv_pitch(a.wd) * sizeof(float);
+  NNCF_REQUIRE(nMtH <= kFwdMt, "content_len too long for the conv forward tile");
   NNCF_REQUIRE(lds <= 150 * 1024, "content_len x word_dim tile of %zu bytes exceeds the LDS", lds);
-  if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel), lds)) return rc;
+  const int nKt = (a.wd + 15) / 16;
   {
     ProfScope _ps("cnn_conv_fwd_kernel", st);
-    hipLaunchKernelGGL(cnn_conv_fwd_kernel, dim3((unsigned)a.m), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)a.m * kFwdSplit);
+    if (nMtH == 7 && nKt == 7) {  // L in (192, 224], word_dim in (96, 112]: the CiteULike shape
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 7, false>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 7, false>), grid, dim3(256), lds, st, a);
+    } else if (nMtH <= 4 && nKt <= 4) {
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<4, 4, true>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 4, true>), grid, dim3(256), lds, st, a);
+    } else {
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<kFwdMt, 8, true>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<kFwdMt, 8, true>), grid, dim3(256), lds, st, a);
+    }
   }
   if (a.train) {
     ProfScope _ps("cnn_stats_kernel", st);
@@ -639,9 +794,13 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
 // after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) rows
 int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int nblk = conv_blocks(a.L), fl = a.cnn.fl;
-  const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch(a.wd) + conv_pitch(a.cnn.F)) * sizeof(float);
+  const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch32(a.wd) + conv_pitch32(a.cnn.F)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tile of %zu bytes exceeds the LDS", lds);
-  if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_bwd_kernel), lds)) return rc;
+  const int nFt = (a.cnn.F + 15) / 16;
+  const void* bwd_fn = nFt == 7 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<7, false>)
+                       : nFt <= 4 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<4, true>)
+                                  : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<8, true>);
+  if (int rc = set_lds(bwd_fn, lds)) return rc;
   {
     ProfScope _ps("cnn_bwd_sums_kernel", st);
     hipLaunchKernelGGL(cnn_bwd_sums_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
@@ -652,7 +811,10 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);
-    hipLaunchKernelGGL(cnn_conv_bwd_kernel, dim3((unsigned)(a.m * nblk)), dim3(256), lds, st, a, nblk);
+    const dim3 grid((unsigned)(a.m * nblk));
+    if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(256), lds, st, a, nblk);
+    else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(256), lds, st, a, nblk);
+    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(256), lds, st, a, nblk);
   }
   {
     ProfScope _ps("cnn_presum_kernel", st);
@@ -661,7 +823,7 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   {
     ProfScope _ps("cnn_update_kernel", st);
     const int nel = fl * a.wd * a.cnn.F;
-    hipLaunchKernelGGL(cnn_update_kernel, dim3((nel + 255) / 256 + 1), dim3(256), 0, st, a, nblk);
+    hipLaunchKernelGGL(cnn_update_kernel, dim3((nel + 127) / 128 + 1), dim3(1024), 0, st, a, nblk);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -36,6 +36,7 @@ struct CnnArgs {
   const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)
   const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
   float *mC, *vC;            // Adam moments of [Wk | bc, g1, b1 (128 each)]
+  int dbg;                   // NNCF_CNN_DBG (timing experiments only): 1 skip MFMA loops, 2 skip the gather
 };
 constexpr int kConvLB = 112;  // positions per workgroup of the conv backward
 

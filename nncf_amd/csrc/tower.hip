@@ -24,6 +24,7 @@
 // Only the first *n_valid rows of a block are real (device scalar): shapes are static, nothing
 // syncs to the host, every cross-row reduction has a fixed order.
 // [K-mem] Keras-1 BatchNormalization: eps 1e-3, momentum 0.99, biased variance.
+#include <cstdlib>
 #include <new>
 
 #include "tower.h"
@@ -868,6 +869,7 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
     c.Wk = prm->conv_w; c.bc = prm->conv_b; c.g1 = prm->bn1_gamma; c.b1 = prm->bn1_beta; c.rm1 = prm->bn1_mean;
     c.rv1 = prm->bn1_var; c.item_spos = prm->item_spos; c.item_start = prm->item_start;
     t->conv_drop = cfg->conv_dropout;
+    if (const char* e = getenv("NNCF_CNN_DBG")) c.dbg = atoi(e);
   }
   Carver dry;
   carve_tower(t, dry);

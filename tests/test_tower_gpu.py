@@ -288,3 +288,33 @@ def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop):
     E = to.forward(items, train=False)
     oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
+
+
+def test_cnn_embedding_citeulike_tile_shape():
+    """L = 200, word_dim = filters = 100: the shape whose conv forward runs the unmasked <7, 7> tile
+    specialisation (two workgroups per item, 7 row tiles x 7 K groups each) and whose backward uses
+    two position blocks per item."""
+    data = synthetic.make_citeulike_like(users=200, items=150, train_links=3000, seed=9, content_len=200, vocab=400)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 32,
+          "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.5,
+          "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
+    conf = get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+    md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    orc, to = _oracle_cnn(conf, md, data)
+    head = md["model_neg_shared"]
+    tw = head.core.tower
+    rs = np.random.RandomState(1)
+    for step in range(2):
+        bt = data["train"][rs.choice(len(data["train"]), 32, replace=False)]
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy()
+        to.conv_mask = tw.conv_mask(step, 32).cpu().numpy()
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        for name in CNN_PARAMS:
+            if name == "bc":
+                np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
+                continue
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=3e-4, atol=3e-5,
+                                       err_msg="%s step %d" % (name, step))
