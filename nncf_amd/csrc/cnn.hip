@@ -40,10 +40,22 @@ __host__ __device__ inline int conv_pitch32(int w) {  // ds_read_b32 pattern
   return p;
 }
 
+// Dropout(conv_dropout) mask element: a 32-bit multiply-xorshift hash of (step seed, position,
+// filter) -- 64-bit multiplies are quarter-rate chains on the VALU and this runs once per element
+// of the (n_u x L x F) activation block in three kernels.
 __device__ __forceinline__ float conv_keep(const TowerArgs& a, int64_t pos_index, int c) {
   if (a.cnn.keep >= 1.f) return 1.f;
-  const unsigned long long x = splitmix64(a.cnn.seed + ((unsigned long long)pos_index * 128ull + (unsigned)c) * 0x9E3779B97F4A7C15ull);
-  const float u = (float)(x >> 40) * (1.f / 16777216.f);
+  uint32_t x = ((uint32_t)pos_index * 128u + (uint32_t)c) ^ (uint32_t)a.cnn.seed;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  x += (uint32_t)(a.cnn.seed >> 32);
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  const float u = (float)(x >> 8) * (1.f / 16777216.f);
   return u < a.cnn.keep ? 1.f / a.cnn.keep : 0.f;
 }
 
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
   __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
-  __shared__ float sMul[128], sAdd[128];
+  __shared__ __attribute__((aligned(16))) float sMul[128], sAdd[128];
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
   const int F = a.cnn.F, f4 = F >> 2, d4 = a.d >> 2, L = a.L;
   const int s = blockIdx.x;
@@ -289,18 +301,24 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   __syncthreads();
   Row acc = row_zero();
   const bool drop = a.train && a.cnn.keep < 1.f;
-  for (int p0 = grp; p0 < L; p0 += 64) {
-    Row y[4];
+  // this lane's eight columns are the same for every row: scale / shift live in registers
+  Row rmul, radd;
+  rmul.a = reinterpret_cast<const float4*>(sMul)[q];
+  rmul.b = reinterpret_cast<const float4*>(sMul)[q + 16];
+  radd.a = reinterpret_cast<const float4*>(sAdd)[q];
+  radd.b = reinterpret_cast<const float4*>(sAdd)[q + 16];
+  for (int p0 = grp; p0 < L; p0 += 112) {
+    Row y[7];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+    for (int e = 0; e < 7; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 7; ++e) {
       const int p = p0 + 16 * e;
       if (p < L) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int c = col_of(q, k);
-          float v = fmaxf(fmaf(relem(y[e], k), sMul[c], sAdd[c]), 0.f);
+          float v = fmaxf(fmaf(relem(y[e], k), relem(rmul, k), relem(radd, k)), 0.f);
           if (drop && v != 0.f) v *= conv_keep(a, (int64_t)s * L + p, c);
           relem(acc, k) += v;
         }
@@ -371,13 +389,15 @@ __global__ void __launch_bounds__(256) cnn_bwd_sums_kernel(TowerArgs a) {
   }
   const Row dhr = row_scale(row_load(a.dh, s, F, f4, q), 1.f / (float)L);
   __syncthreads();
+  Row rmu = row_load(a.cnn.st1, 0, 128, 32, q), rinv = row_load(a.cnn.st1 + 128, 0, 128, 32, q);
+  Row rmul = row_load(a.cnn.st1 + 384, 0, 128, 32, q), radd = row_load(a.cnn.st1 + 512, 0, 128, 32, q);
   Row s1 = row_zero(), s2 = row_zero();
-  for (int p0 = grp; p0 < L; p0 += 64) {
-    Row y[4];
+  for (int p0 = grp; p0 < L; p0 += 112) {
+    Row y[7];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+    for (int e = 0; e < 7; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 7; ++e) {
       const int p = p0 + 16 * e;
       if (p < L) {
         Row dd = dhr;
@@ -385,9 +405,9 @@ __global__ void __launch_bounds__(256) cnn_bwd_sums_kernel(TowerArgs a) {
         for (int k = 0; k < 8; ++k) {
           const int c = col_of(q, k);
           const float yv = relem(y[e], k);
-          const float da = conv_da(a, relem(dd, k), fmaf(yv, sMul[c], sAdd[c]), (int64_t)s * L + p, c);
+          const float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
           relem(s1, k) += da;
-          relem(s2, k) += da * (yv - sMu[c]) * sInv[c];
+          relem(s2, k) += da * (yv - relem(rmu, k)) * relem(rinv, k);
         }
       }
     }
@@ -452,6 +472,9 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
   {
     const float N = (float)nv * (float)L, rN = 1.f / N;
+    Row rmu = row_load(a.cnn.st1, 0, 128, 32, q), rinv = row_load(a.cnn.st1 + 128, 0, 128, 32, q);
+    Row rmul = row_load(a.cnn.st1 + 384, 0, 128, 32, q), radd = row_load(a.cnn.st1 + 512, 0, 128, 32, q);
+    Row rs1 = row_load(a.cnn.st1 + 640, 0, 128, 32, q), rs2 = row_load(a.cnn.st1 + 768, 0, 128, 32, q);
     const int fp4 = FP >> 2;
     for (int r0 = grp; r0 < rows; r0 += 64) {
       Row y[4];
@@ -471,8 +494,8 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
             for (int k = 0; k < 8; ++k) {
               const int c = col_of(q, k);
               const float yv = relem(y[e], k);
-              const float da = conv_da(a, relem(dd, k), fmaf(yv, sMul[c], sAdd[c]), (int64_t)s * L + p, c);
-              relem(o, k) = sMul[c] * rN * (N * da - sS1[c] - (yv - sMu[c]) * sInv[c] * sS2[c]);
+              const float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
+              relem(o, k) = relem(rmul, k) * rN * (N * da - relem(rs1, k) - (yv - relem(rmu, k)) * relem(rinv, k) * relem(rs2, k));
             }
           }
           float4* dst = reinterpret_cast<float4*>(sD + (int64_t)r * FP);
@@ -541,7 +564,6 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   // ---- (b) partial dWk[tap][k][f] = sum_{p in block} X[p + tap - pad][k] dY[p][f] --------------
   {
     const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-    const int ntile = fl * nKw * nFt;
     float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
     // 2 x 2 register blocking: a wave computes tiles (kt, kt+1) x (ft, ft+1) of one tap together --
     // two A and two B dwords from LDS feed four MFMAs on independent accumulators

@@ -17,6 +17,7 @@ python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_s
 python3 bench.py --scheme group_neg_shared --cpu-seconds 6 --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared.json
 python3 bench.py --scheme original --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_original.json
 python3 bench.py --optimizer adam --cpu-seconds 0 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_adam.json
+python3 bench.py --model cnn_embedding --scheme group_neg_shared --cpu-seconds 8 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared.json
 python3 bench.py --model mf --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared.json
 python3 bench.py --model mf --scheme original --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_original.json
 python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_group_neg_shared.json
@@ -27,6 +28,7 @@ run_prof basic_embedding_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --steps 390 --w
 run_prof basic_embedding_neg_shared_pmc_write "--pmc WRITE_SIZE" --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof basic_embedding_group_neg_shared_kernel_trace "--stats" --scheme group_neg_shared --steps 780 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof basic_embedding_original_kernel_trace "--stats" --scheme original --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
+run_prof cnn_embedding_group_neg_shared_kernel_trace "--stats" --model cnn_embedding --scheme group_neg_shared --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_kernel_trace "--stats" --model mf --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_write "--pmc WRITE_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
