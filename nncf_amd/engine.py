@@ -26,29 +26,40 @@ class Engine(object):
             raise AssertionError("[ERROR!] loss %s not specified." % loss)  # objectives.py:72
         self._L = _lib.lib()
         self.device = torch.device("cuda", device)
-        self.dim = int(dim)
+        # the kernels move rows as 16-byte chunks: a dimension that is not a multiple of 4 (the
+        # reference's default is 50) is zero-padded to the next one.  Pad columns start at zero, get a
+        # zero gradient from every term of every loss (dot products, norms and the regulariser ignore
+        # them) and therefore stay zero under SGD and Adam: the model is exactly the dim-wide one.
+        self.dim = int(dim)                       # logical width (what the reference calls user_dim)
+        self.dim_p = (self.dim + 3) // 4 * 4      # physical row width of the tables
         self.b = int(batch_size_p)
         self.k = int(num_negatives)
         self.user_count, self.item_count = int(user_count), int(item_count)
         if tables is not None:
             self.U, self.V = tables  # caller-provided device tensors (e.g. shared U, tower output buffer)
             assert self.U.is_cuda and self.V.is_cuda and self.U.is_contiguous() and self.V.is_contiguous()
+            assert self.U.shape[1] == self.dim_p and self.V.shape[1] == self.dim_p, "tables must be dim_p wide"
         elif share is None:
             # Keras-1 Embedding default init: uniform(-0.05, 0.05) [K-mem]
             if (self.user_count + self.item_count) * self.dim > 2e8:
                 # multi-GB tables (config 4): initialise on the device
                 gen = torch.Generator(device=self.device).manual_seed(int(seed))
-                mk = lambda r: (torch.rand(r, self.dim, generator=gen, device=self.device) * 2 - 1) * init_scale  # noqa: E731
+                def mk(r):
+                    t = torch.zeros(r, self.dim_p, device=self.device)
+                    t[:, :self.dim] = (torch.rand(r, self.dim, generator=gen, device=self.device) * 2 - 1) * init_scale
+                    return t
                 self.U, self.V = mk(self.user_count).contiguous(), mk(self.item_count).contiguous()
             else:
                 gen = torch.Generator().manual_seed(int(seed))
-                U = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
-                V = (torch.rand(self.item_count, self.dim, generator=gen) * 2 - 1) * init_scale
+                U = torch.zeros(self.user_count, self.dim_p)
+                V = torch.zeros(self.item_count, self.dim_p)
+                U[:, :self.dim] = (torch.rand(self.user_count, self.dim, generator=gen) * 2 - 1) * init_scale
+                V[:, :self.dim] = (torch.rand(self.item_count, self.dim, generator=gen) * 2 - 1) * init_scale
                 self.U = U.to(self.device).contiguous()
                 self.V = V.to(self.device).contiguous()
         else:
             self.U, self.V = share.U, share.V
-        cfg = _lib.ModelCfg(self.b, self.k, self.dim, self.dim, _lib.LOSS_CODES[loss], int(bool(normalize_user)),
+        cfg = _lib.ModelCfg(self.b, self.k, self.dim_p, self.dim_p, _lib.LOSS_CODES[loss], int(bool(normalize_user)),
                             int(bool(normalize_item)), float(loss_gamma), float(neg_loss_weight), float(u_reg),
                             float(learn_rate), self.user_count, self.item_count)
         self.cfg = cfg

@@ -47,19 +47,30 @@ class MeanPoolTower(object):
         C = np.ascontiguousarray(np.asarray(C))
         self.item_count, self.Lc = C.shape
         assert self.Lc <= 255, "max_content_len above 255 needs wider token counts"
-        self.word_count, self.wd, self.d = int(word_count), int(word_dim), int(item_dim)
-        assert self.wd % 4 == 0 and self.wd <= 128, "word_dim must be a multiple of 4 and <= 128"
+        # logical widths as configured, physical widths padded to a multiple of 4 with zero columns /
+        # rows (see Engine: zero pads get zero gradients from every layer, BatchNorm maps an all-zero
+        # channel to zero, so the padded model is exactly the configured one)
+        pad4 = lambda v: (int(v) + 3) // 4 * 4  # noqa: E731
+        self.word_count = int(word_count)
+        self.wd_l, self.d_l = int(word_dim), int(item_dim)
+        self.wd, self.d = pad4(word_dim), pad4(item_dim)
+        assert self.wd <= 128 and self.d <= 128, "word_dim / item_dim above 128 are not built"
         self.lr = float(learn_rate)
         self.eps, self.mom = float(eps), float(momentum)
         self.dropout = float(dropout_rate)
         self.cap = (int(max_rows) + 7) // 8 * 8
         gen = torch.Generator().manual_seed(int(seed) + 17)
         dev = device
-        self.W = ((torch.rand(self.word_count, self.wd, generator=gen) * 2 - 1) * 0.05).to(dev).contiguous()
+        W = torch.zeros(self.word_count, self.wd)
+        W[:, :self.wd_l] = (torch.rand(self.word_count, self.wd_l, generator=gen) * 2 - 1) * 0.05
+        self.W = W.to(dev).contiguous()
         self.conv = dict(conv) if conv else None
-        self.hd = int(self.conv["filters"]) if self.conv else self.wd          # Dense input width
-        lim = float(np.sqrt(6.0 / (self.hd + self.d)))  # glorot_uniform
-        self.Wd = ((torch.rand(self.hd, self.d, generator=gen) * 2 - 1) * lim).to(dev).contiguous()
+        self.hd_l = int(self.conv["filters"]) if self.conv else self.wd_l     # Dense input width
+        self.hd = pad4(self.hd_l)
+        lim = float(np.sqrt(6.0 / (self.hd_l + self.d_l)))  # glorot_uniform
+        Wd = torch.zeros(self.hd, self.d)
+        Wd[:self.hd_l, :self.d_l] = (torch.rand(self.hd_l, self.d_l, generator=gen) * 2 - 1) * lim
+        self.Wd = Wd.to(dev).contiguous()
         # one allocation for the five small vectors, each 512-byte aligned
         vec = torch.zeros(5, 128, device=dev)
         self.bd, self.gamma, self.beta, self.rm, self.rv = (vec[i, :self.d] for i in range(5))
@@ -76,10 +87,12 @@ class MeanPoolTower(object):
         F = fl = 0
         cdrop = 0.0
         if self.conv:
-            F, fl, cdrop = int(self.conv["filters"]), int(self.conv["filter_len"]), float(self.conv.get("dropout", 0.0))
-            assert F % 4 == 0 and F <= 128 and fl % 2 == 1, "conv filters must be a multiple of 4 (<= 128), filter_len odd"
+            F, fl, cdrop = self.hd, int(self.conv["filter_len"]), float(self.conv.get("dropout", 0.0))
+            assert F <= 128 and fl % 2 == 1, "conv filters above 128 / even filter lengths are not built"
             # Convolution1D init='he_normal' (cnn_model.py:88): std = sqrt(2 / fan_in), fan_in = fl * word_dim [K-mem]
-            self.Wc = (torch.randn(fl, self.wd, F, generator=gen) * float(np.sqrt(2.0 / (fl * self.wd)))).to(dev).contiguous()
+            Wc = torch.zeros(fl, self.wd, F)
+            Wc[:, :self.wd_l, :self.hd_l] = torch.randn(fl, self.wd_l, self.hd_l, generator=gen) * float(np.sqrt(2.0 / (fl * self.wd_l)))
+            self.Wc = Wc.to(dev).contiguous()
             vec1 = torch.zeros(5, 128, device=dev)
             self.bc, self.g1, self.b1, self.rm1, self.rv1 = (vec1[i, :F] for i in range(5))
             self.g1.fill_(1.0)

@@ -261,7 +261,7 @@ class _TowerCore(object):
         if self._eval is None:
             kw = dict(self._engine_kw)
             kw["item_count"] = self.item_count
-            Vall = torch.zeros(self.item_count, self.engine.dim, dtype=torch.float32, device=self.engine.device)
+            Vall = torch.zeros(self.item_count, self.engine.dim_p, dtype=torch.float32, device=self.engine.device)
             self._eval = Engine(device=self._device, tables=(self.engine.U, Vall), **kw)
         if self._eval_version != self.tower.version:
             ids = torch.arange(self.item_count, dtype=torch.int32, device=self.engine.device)
@@ -340,8 +340,6 @@ def _conv_spec(conf):
             "filter_lengths=[3], the 'best' preset), conv BatchNorm + relu, poolings=['average'] over the whole "
             "length, no gating; got filter_lengths=%r num_filters=%r poolings=%r pool_lengths=%r"
             % (fls, nfs, conf.poolings, conf.pool_lengths))
-    if int(nfs[0]) % 4:
-        raise NotImplementedError("num_filters = %d: the HIP kernels need a multiple of 4 (48 / 52 / 100 ...)" % nfs[0])
     return dict(filters=int(nfs[0]), filter_len=int(fls[0]), dropout=float(conf.conv_dropout_rate))
 
 

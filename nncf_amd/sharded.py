@@ -55,7 +55,7 @@ class HipBackend(object):
         kw = dict(engine_kwargs)
         kw["user_count"] = local_users
         self.b = kw["batch_size_p"]
-        self.dim = kw["dim"]
+        self.dim = (int(kw["dim"]) + 3) // 4 * 4   # physical row width (Engine pads to a multiple of 4)
         self.world, self.cap = int(world), self.b
         self.item_shard, self.i0 = int(item_shard), int(item_offset)
         # the model's "item table" is the landing buffer of fetched rows: world * cap request slots
@@ -64,7 +64,9 @@ class HipBackend(object):
         self.U = self.engine.U                      # local user shard
         self.rows_in = self.engine.V                # [world*cap][d], filled by all-to-all #2
         gen = torch.Generator().manual_seed(int(seed) + 1)
-        self.V = ((torch.rand(local_items, self.dim, generator=gen) * 2 - 1) * 0.05).to(self.device).contiguous()
+        V = torch.zeros(local_items, self.dim)
+        V[:, :int(kw["dim"])] = (torch.rand(local_items, int(kw["dim"]), generator=gen) * 2 - 1) * 0.05
+        self.V = V.to(self.device).contiguous()
         self.lr = float(kw["learn_rate"])
         n = self.world * self.cap
         if n > 8192:

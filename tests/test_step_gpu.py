@@ -246,3 +246,28 @@ def test_adam_epoch_runner_equals_step_by_step():
         l2 = [e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)]
         assert np.array_equal(l1, np.array(l2, dtype=np.float32)), kind
         assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V), kind
+
+
+def test_dim_50_is_padded_exactly():
+    """user_dim = item_dim = 50 (the reference's default): tables are 52 wide with zero pad columns;
+    steps equal the oracle run on the 50 logical columns; pads stay exactly zero (SGD and Adam)."""
+    b, k, nu, ni = 64, 3, 80, 120
+    for kind in ("sgd", "adam"):
+        conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss="log-loss", loss_gamma=10., u_reg=1e-3, learn_rate=0.02,
+                             model_choice="mf", optimizer=kind)
+        eng = Engine(nu, ni, 50, b, k, "log-loss", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                     conf.normalize_user, conf.normalize_item, seed=3, init_scale=0.5)
+        assert (eng.dim, eng.dim_p, tuple(eng.U.shape)) == (50, 52, (nu, 52))
+        if kind != "sgd":
+            eng.set_optimizer(kind)
+        orc = so.StepOracle(eng.U.cpu().numpy()[:, :50], eng.V.cpu().numpy()[:, :50], conf, dtype=np.float32)
+        rs = np.random.RandomState(5)
+        for step in range(3):
+            uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            assert abs(got - want) <= 2e-5 * max(1, abs(want)), (kind, step, got, want)
+        tol = dict(rtol=2e-4, atol=2e-5) if kind == "adam" else dict(rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(eng.U.cpu().numpy()[:, :50], orc.U, **tol)
+        np.testing.assert_allclose(eng.V.cpu().numpy()[:, :50], orc.V, **tol)
+        assert np.all(eng.U.cpu().numpy()[:, 50:] == 0) and np.all(eng.V.cpu().numpy()[:, 50:] == 0)

@@ -318,3 +318,50 @@ def test_cnn_embedding_citeulike_tile_shape():
                 continue
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=3e-4, atol=3e-5,
                                        err_msg="%s step %d" % (name, step))
+
+
+@pytest.mark.parametrize("model", ["basic_embedding", "cnn_embedding"])
+def test_dims_not_multiple_of_4_are_padded_exactly(text_data, model):
+    """The reference's default widths are 50: the wrappers zero-pad every width to a multiple of 4.
+    The padded model against the oracle run at the CONFIGURED widths (parameters sliced to the
+    logical dims): same losses, same logical parameters; pad rows / columns stay exactly zero."""
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "log-loss", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.1, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
+          "user_dim": 18, "item_dim": 18, "word_dim": 10, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.,
+          "num_filters": [14], "filter_lengths": [3], "conv_dropout_rate": 0.}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), model, seed=2)
+    head = md["model_neg_shared"]
+    tw, eng = head.core.tower, head.engine
+    assert (eng.dim, eng.dim_p, tw.wd_l, tw.wd, tw.d) == (18, 20, 10, 12, 20)
+    g = lambda t: t.cpu().numpy()  # noqa: E731
+    oc = so.OracleConf(batch_size_p=64, num_negatives=0, loss="log-loss", loss_gamma=10, neg_loss_weight=16, u_reg=1e-4,
+                       learn_rate=0.1, emb_normalization=conf.emb_normalization, model_choice="basic_embedding")
+    d, wd, hd = 18, 10, tw.hd_l
+    if model == "cnn_embedding":
+        to = so.CnnTowerOracle(text_data["C"], g(tw.W)[:, :wd], g(tw.Wc)[:, :wd, :hd], g(tw.bc)[:hd], g(tw.g1)[:hd], g(tw.b1)[:hd],
+                               g(tw.Wd)[:hd, :d], g(tw.bd)[:d], g(tw.gamma)[:d], g(tw.beta)[:d], 0.1, dtype=np.float32)
+        names = {"W": (slice(None), slice(0, wd)), "Wc": (slice(None), slice(0, wd), slice(0, hd)), "g1": (slice(0, hd),),
+                 "b1": (slice(0, hd),), "Wd": (slice(0, hd), slice(0, d)), "gamma": (slice(0, d),), "beta": (slice(0, d),)}
+    else:
+        to = so.TowerOracle(text_data["C"], g(tw.W)[:, :wd], g(tw.Wd)[:hd, :d], g(tw.bd)[:d], g(tw.gamma)[:d], g(tw.beta)[:d],
+                            0.1, dtype=np.float32)
+        names = {"W": (slice(None), slice(0, wd)), "Wd": (slice(0, hd), slice(0, d)), "gamma": (slice(0, d),), "beta": (slice(0, d),)}
+    orc = so.StepOracle(g(eng.U)[:, :d], None, oc, dtype=np.float32, tower=to)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        bt = text_data["train"][rs.choice(len(text_data["train"]), 64, replace=False)]
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+    np.testing.assert_allclose(g(eng.U)[:, :d], orc.U, rtol=2e-5, atol=5e-6)
+    assert np.all(g(eng.U)[:, d:] == 0)
+    for name, sl in names.items():
+        full = g(getattr(tw, name))
+        np.testing.assert_allclose(full[sl], getattr(to, name), rtol=3e-4, atol=3e-5, err_msg=name)
+        mask = np.ones(full.shape, dtype=bool)
+        mask[sl] = False
+        if name not in ("gamma", "g1"):            # BatchNorm scales of pad channels keep their initial 1
+            assert np.all(full[mask] == 0), name
+    E = head.core.eval_engine().V.cpu().numpy()
+    assert np.all(E[:, d:] == 0)
