@@ -538,6 +538,18 @@ def main():
     if want_cpu:
         cpu = cpu_baseline(args, conf, inp, U0, V0, tower_params)
 
+    # Recall@50 (the second half of BASELINE's metric) of the model as trained so far: whole@50
+    # evaluator on the GPU (U.V^T over the candidate items + per-user top-k), outside every timed region
+    recall = None
+    if rank == 0 and not args.large:
+        from nncf_amd.objectives import Evaluator
+        pconf.eval_topk = 50
+        tr_res, te_res = Evaluator(helper, helper.data_spec, pconf).run(md["model_neg_shared"], verbose=False,
+                                                                        eval_scheme="whole")
+        recall = {"train": float(tr_res["recall@50"]), "test_cold_items": float(te_res["recall@50"]),
+                  "after_steps": int(W + K + prof_n * len(names)),
+                  "note": "whole@50 after the warm-up, timed and roofline passes of this run (a short run, not a converged model)"}
+
     if rank == 0:
         value = K * b * world / elapsed
         tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
@@ -561,6 +573,7 @@ def main():
                        "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
             "mean_unique_items_per_step": mean_n_u if args.model != "mf" else None,
+            "recall_at_50": recall,
             "roofline": roof,
             "roofline_other_kernels": roofs[1:],
             "cpu_baseline": cpu,

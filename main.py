@@ -43,6 +43,10 @@ def main():
         p = eval_scheme.find("@")
         conf.eval_topk = int(eval_scheme[p + 1:])
         eval_scheme = eval_scheme[:p]
+    if conf.optimizer == "sgd":
+        print("[INFO] optimizer = sgd: this build's default is the sparse SGD scatter update; the reference compiles "
+              "Keras Adam(learn_rate) -- pass {'optimizer': 'adam'} (or 'sparse_adam') in --param_dict for it. "
+              "The demo scripts' learn_rate 0.01 is an Adam step size: plain SGD barely moves with it.")
     data_helper = get_data(args.data_name, conf, reverse_samping=True, rand_seed=12345, device=device)
     print(conf.__dict__)
     model_dict = get_model(conf, data_helper, args.model_choice, device=device)
