@@ -286,6 +286,7 @@ int nncf_step_rowwise(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid,
 int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_y_all,
                        int64_t n_steps, float* d_loss, void* stream) {
   if (int rc = check_model(m)) return rc;
+  if (n_steps == 0) return NNCF_OK;  // nothing to do: buffers may be empty (NULL)
   NNCF_REQUIRE(d_uid_all && d_cid_all && d_y_all && d_loss, "NULL argument");
   NNCF_REQUIRE(m->cfg.num_negatives > 0 && n_steps >= 0, "bad argument");
   const int64_t n = (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives);
@@ -402,6 +403,7 @@ int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_
 int nncf_epoch_original(nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all, const int32_t* d_neg,
                         int64_t n_steps, float* d_loss, void* stream) {
   if (int rc = check_model(m)) return rc;
+  if (n_steps == 0) return NNCF_OK;
   NNCF_REQUIRE(d_uid_all && d_cid_all && d_neg && d_loss, "NULL argument");
   NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
   NNCF_REQUIRE(n_steps >= 0, "negative step count");
@@ -427,6 +429,7 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
                         float* d_loss, int32_t* d_n_u, void* stream) {
   if (int rc = check_model(m)) return rc;
   if (int rc = check_shared(m)) return rc;
+  if (n_steps == 0) return NNCF_OK;
   NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss, "NULL argument");
   NNCF_REQUIRE(n_steps >= 0, "negative step count");
   const int64_t b = m->cfg.batch_size_p;

@@ -1024,9 +1024,10 @@ int nncf_tower_dropout_scale(nncf_tower* t, uint64_t step_index, float* d_out, v
 
 int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, const int32_t* d_n_valid, int train,
                        int prepare_backward, const float* d_row_scale, float* d_out, void* stream) {
-  NNCF_REQUIRE(t && d_item_ids && d_out, "NULL argument");
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE(m >= 0, "negative row count");
-  if (m == 0) return NNCF_OK;
+  if (m == 0) return NNCF_OK;  // empty block: buffers may be NULL
+  NNCF_REQUIRE(d_item_ids && d_out, "NULL argument");
   NNCF_REQUIRE(!train || m <= t->cfg.max_rows, "train-mode block of %lld rows exceeds max_rows = %d", (long long)m, t->cfg.max_rows);
   hipStream_t st = as_stream(stream);
   if (train) return tower_forward(t, d_item_ids, (int)m, d_n_valid, 1, prepare_backward != 0, d_row_scale, d_out, st);
@@ -1066,6 +1067,7 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,
                      const int32_t* d_neg_all, int64_t n_steps, float* d_loss, int32_t* d_n_u, void* stream) {
   if (int rc = check_pair(t, m, scheme)) return rc;
+  if (n_steps == 0) return NNCF_OK;
   NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss, "NULL argument");
   NNCF_REQUIRE(scheme != 0 || d_neg_all, "train_scheme=original needs the presampled negatives");
   NNCF_REQUIRE(n_steps >= 0, "negative step count");

@@ -271,3 +271,36 @@ def test_dim_50_is_padded_exactly():
         np.testing.assert_allclose(eng.U.cpu().numpy()[:, :50], orc.U, **tol)
         np.testing.assert_allclose(eng.V.cpu().numpy()[:, :50], orc.V, **tol)
         assert np.all(eng.U.cpu().numpy()[:, 50:] == 0) and np.all(eng.V.cpu().numpy()[:, 50:] == 0)
+
+
+def test_edge_cases_degenerate_batches():
+    """Collisions and empties: a batch that is one (user, item) pair repeated, a batch with one user and
+    all-distinct items, an epoch of zero steps, a prediction with zero rows, invalid shapes."""
+    b, k, d, nu, ni = 64, 3, 16, 40, 90
+    for loss in ("skip-gram", "log-loss"):
+        conf, eng, orc = _mk(loss, b, k, d, nu, ni, "mf", seed=2)
+        uid, cid = np.full(b, 7), np.full(b, 11)                          # every row the same pair
+        assert abs(eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item() - orc.step_neg_shared(uid, cid)) < 2e-5 * 10
+        _check_tables(eng, orc)
+        want = orc.step_group_neg_shared(uid, cid)                        # n_u = 1: a single shared item
+        got, cu, cx, n_u = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid), want_unique=True)
+        assert int(n_u.item()) == 1 and abs(got.item() - want) <= 2e-5 * max(1, abs(want))
+        _check_tables(eng, orc)
+        uid2, cid2 = np.full(b, 3), np.arange(b)                          # one user, b different items
+        negs = np.full(b * k, 5)                                          # one negative for everybody
+        u, c, y = so.assemble_original(np.stack([uid2, cid2, np.ones(b, dtype=np.int64)], 1), negs, loss)
+        want = orc.step_original(u, c, y)
+        got = eng.step_original(eng.ids(uid2), eng.ids(c)).item()
+        assert abs(got - want) <= 2e-5 * max(1, abs(want))
+        _check_tables(eng, orc)
+    U0, V0 = eng.U.clone(), eng.V.clone()
+    empty = torch.zeros(0, dtype=torch.int32, device=eng.device)
+    assert eng.epoch_neg_shared(empty, empty, 0).numel() == 0           # zero steps: nothing runs
+    assert eng.epoch_original(empty, empty, empty, 0).numel() == 0
+    assert torch.equal(eng.U, U0) and torch.equal(eng.V, V0)
+    assert tuple(eng.predict_scores(empty, eng.ids(np.arange(5))).shape) == (0, 5)
+    with pytest.raises(ValueError):                                       # b not a multiple of the tile edge
+        Engine(nu, ni, d, 48, 0, "skip-gram", 10., 128., 1e-6, 0.1, False, False).step_neg_shared(
+            eng.ids(np.zeros(48)), eng.ids(np.zeros(48)))
+    with pytest.raises(AssertionError):
+        Engine(nu, ni, d, 64, 0, "hinge", 10., 128., 1e-6, 0.1, False, False)   # objectives.py:72

@@ -365,3 +365,32 @@ def test_dims_not_multiple_of_4_are_padded_exactly(text_data, model):
             assert np.all(full[mask] == 0), name
     E = head.core.eval_engine().V.cpu().numpy()
     assert np.all(E[:, d:] == 0)
+
+
+def test_tower_edge_cases(text_data):
+    """A batch whose items are all the same item (n_u = 1: BatchNorm over one row), an item made of
+    pad tokens only, inference on zero rows."""
+    data = dict(text_data)
+    C = data["C"].copy()
+    C[5, :] = 0                                                            # all-pad item
+    data["C"] = C
+    for model in ("basic_embedding", "cnn_embedding"):
+        conf = _conf_cnn("skip-gram", "neg_shared") if model == "cnn_embedding" else _conf("skip-gram", "neg_shared")
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
+        orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data)
+        head = md["model_neg_shared"]
+        b = conf.batch_size_p
+        rs = np.random.RandomState(0)
+        for cid in (np.full(b, 5), np.full(b, 17), np.r_[np.full(b // 2, 5), rs.randint(0, 260, b // 2)]):
+            uid = rs.randint(0, 300, b)
+            want = orc.step_neg_shared(uid, cid)
+            got = head.train_on_batch([uid, cid], None)
+            assert np.isfinite(got) and abs(got - want) <= 5e-5 * max(1, abs(want)), (model, got, want)
+        tw = head.core.tower
+        # (BatchNorm over ONE row puts every pre-activation exactly on the ReLU threshold: which side
+        # rounding noise falls on is not comparable between implementations -- losses are, and
+        # every parameter must stay finite)
+        for name in ("W", "Wd", "gamma", "beta", "rm", "rv"):
+            assert np.all(np.isfinite(getattr(tw, name).cpu().numpy())), name
+        empty = torch.zeros(0, dtype=torch.int32, device=tw.device)
+        assert tuple(tw.forward(empty, train=False).shape) == (0, tw.d)
