@@ -1,6 +1,7 @@
 // Error state, version and device probing for libnncf_hip.so.
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -81,18 +82,18 @@ int nncf_profile_end(double* avg_ms, int64_t* launches, double* overhead_ms) {
   // Calibration: the same event pair with nothing between them, on the same stream: the cost of
   // the two marker packets themselves, which every bracket above includes.
   const size_t ncal = g_prof.start.size() < 64 ? g_prof.start.size() : 64;
-  double cal = 0;
+  NNCF_HIP_CHECK(hipStreamSynchronize(g_prof.last));
   for (size_t i = 0; i < ncal; ++i) {
     NNCF_HIP_CHECK(hipEventRecord(g_prof.start[i], g_prof.last));
     NNCF_HIP_CHECK(hipEventRecord(g_prof.stop[i], g_prof.last));
   }
+  std::vector<float> cal(ncal, 0.f);
   for (size_t i = 0; i < ncal; ++i) {
     NNCF_HIP_CHECK(hipEventSynchronize(g_prof.stop[i]));
-    float ms = 0;
-    NNCF_HIP_CHECK(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
-    cal += ms;
+    NNCF_HIP_CHECK(hipEventElapsedTime(&cal[i], g_prof.start[i], g_prof.stop[i]));
   }
-  *overhead_ms = ncal ? cal / (double)ncal : 0.0;
+  std::sort(cal.begin(), cal.end());
+  *overhead_ms = ncal ? (double)cal[ncal / 2] : 0.0;  // median: a stray slow pair must not shift it
   g_prof.used = 0;
   return NNCF_OK;
 }

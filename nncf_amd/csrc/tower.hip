@@ -475,6 +475,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 // Remaining blocks: Wd, bd, gamma, beta -= lr * gradient (K-parts / partials summed in order).
 constexpr int kWordsPerWG = 8;
 constexpr int kListCap = 256;
+template <bool CNN>
 __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
   // mean-pool tower: a cell holds the word's count in the slot's item, the gradient row is
   // dh[slot] weighted by it.  CNN tower: a cell holds 1 + the word's ordinal among the item's
   // distinct words, the gradient row is dXw[slot*L + ordinal] (already summed over positions).
-  const bool cnn = a.cnn.F > 0;
+  constexpr bool cnn = CNN;
   const float2* dh2 = reinterpret_cast<const float2*>(cnn ? a.cnn.dXw : a.dh);
   __syncthreads();
   for (int base = 0; base < n; base += 512) {
@@ -769,7 +770,8 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   {
     ProfScope _ps("tower_word_kernel", st);
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
-    hipLaunchKernelGGL(tower_word_kernel, dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   if (a.opt == 2) {  // dense Adam: words without a gradient this step
