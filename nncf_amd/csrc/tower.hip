@@ -608,12 +608,22 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       wold.y = adam1(gs * sum.y, &mm.y, &vv.y, wold.y, a);
       *mp = mm;
       *vp = vv;
-      if (a.aw.stamp && lane == 0) a.aw.stamp[my_w] = a.step_no;
     } else {
       const float sc = cnn ? a.lr : lr_over_L * word_scale(a, my_w);
       wold.x = fmaf(-sc, sum.x, wold.x);
       wold.y = fmaf(-sc, sum.y, wold.y);
     }
+    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
+  } else if (a.opt == 2 && !a.gexp && my_w < a.n_words && lane < d2) {
+    // dense Adam (Keras): a word without a gradient this step still takes the zero-gradient step
+    // -- done here, where the word is visited anyway, instead of in a separate pass over the table
+    float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
+    float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
+    float2 mm = *mp, vv = *vp;
+    wold.x = adam1(0.f, &mm.x, &vv.x, wold.x, a);
+    wold.y = adam1(0.f, &mm.y, &vv.y, wold.y, a);
+    *mp = mm;
+    *vp = vv;
     reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
   }
 }
@@ -774,12 +784,6 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
-  if (a.opt == 2) {  // dense Adam: words without a gradient this step
-    StepArgs sa{};
-    sa.stride = a.wd; sa.d = a.wd; sa.beta1 = a.beta1; sa.beta2 = a.beta2; sa.eps = a.aeps; sa.lr_t = a.lr_t;
-    sa.step_no = a.step_no;
-    if (int rc = launch_adam_idle(sa, a.W, a.aw, a.n_words, st)) return rc;
-  }
   if (a.opt && step_t <= 0) t->adam_t++;
   return NNCF_OK;
 }
