@@ -163,6 +163,15 @@ int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float bet
                              float* d_v_user, float* d_m_item, float* d_v_item);
 int nncf_model_get_step(nncf_model* m, int64_t* out);
 
+/* InteractionDot bias (modules/interaction/interaction_dot.py:62-71,96-107; conf.interaction_bias
+ * 'user' | 'item' | 'both'): every score becomes U.V + d_user_bias[uid] + d_item_bias[cid] (training
+ * steps and nncf_predict_scores); the biases take the model's optimiser step (call after
+ * nncf_model_set_optimizer; Adam needs zero-initialised moment arrays of the same lengths).
+ * d_item_bias has n_items entries indexed by CATALOGUE id also when the item table is a per-batch
+ * block (text towers).  NULL pointers switch a bias off. */
+int nncf_model_set_bias(nncf_model* m, float* d_user_bias, float* d_item_bias, int64_t n_items, float* d_m_user,
+                        float* d_v_user, float* d_m_item, float* d_v_item);
+
 /* learn_rate / loss hyper-parameters may change between steps (same shapes). */
 int nncf_model_set_hparams(nncf_model* m, float learn_rate, float loss_gamma, float neg_loss_weight, float u_reg);
 

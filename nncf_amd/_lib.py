@@ -95,6 +95,7 @@ def _declare(lib):
         "nncf_model_set_hparams": [vp, f32, f32, f32, f32],
         "nncf_model_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],
         "nncf_model_get_step": [vp, ctypes.POINTER(ctypes.c_int64)],
+        "nncf_model_set_bias": [vp, vp, vp, i64, vp, vp, vp, vp],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
         "nncf_profile_begin": [ctypes.c_char_p, i64],
         "nncf_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),

@@ -41,7 +41,11 @@ StepArgs make_args(const nncf_model* m) {
     a.step_no = (int)(m->adam_t + 1);
     a.au = m->au;
     a.av = m->av;
+    a.abu = m->abu;
+    a.abc = m->abc;
   }
+  a.ub = m->ub;
+  a.cb = m->cb;
   return a;
 }
 
@@ -53,6 +57,8 @@ int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st) {
     if (int rc = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc;
     if (!m->export_gV)
       if (int rc = launch_adam_idle(a, m->V, m->av, m->cfg.item_count, st)) return rc;
+    if (int rc = launch_bias_idle(a, m->ub, m->abu, m->cfg.user_count, st)) return rc;
+    if (int rc = launch_bias_idle(a, m->cb, m->abc, m->bias_items, st)) return rc;
   }
   m->adam_t++;
   return NNCF_OK;
@@ -67,6 +73,7 @@ void carve(nncf_model* m, Carver& c) {
   const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives, d = m->cfg.dim;
   const int64_t n = b * (1 + k);
   const int64_t nb = (b + kTile - 1) / kTile;
+  m->ows.gu = c.take<float>(b);
   m->ows.g = c.take<float>(n);
   m->ows.dUp = c.take<float>(b * d);
   m->ows.Uhat = c.take<float>(b * d);
@@ -85,6 +92,8 @@ void carve(nncf_model* m, Carver& c) {
   m->sws.Vrow = c.take<float>(b * d);
   m->sws.loss_part = c.take<float>(nb * nb);
   m->sws.reg_part = c.take<float>(b);
+  m->sws.gr_part = c.take<float>(nb * b);
+  m->sws.gc_part = c.take<float>(nb * b);
   m->sws.dbg = getenv("NNCF_DEBUG_TIMING") ? c.take<long long>(nb * nb * 8) : nullptr;
   m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
@@ -181,6 +190,7 @@ int nncf_model_destroy(nncf_model* m) {
   if (!m) return NNCF_OK;
   if (m->arena) hipFree(m->arena);
   if (m->stamps) hipFree(m->stamps);
+  if (m->bias_stamps) hipFree(m->bias_stamps);
   delete m;
   return NNCF_OK;
 }
@@ -227,6 +237,38 @@ int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float bet
     hipSetDevice(prev);
     m->au.stamp = m->stamps;
     m->av.stamp = m->stamps + m->cfg.user_count;
+  }
+  return NNCF_OK;
+}
+
+int nncf_model_set_bias(nncf_model* m, float* d_user_bias, float* d_item_bias, int64_t n_items, float* d_m_user,
+                        float* d_v_user, float* d_m_item, float* d_v_item) {
+  if (int rc = check_model(m)) return rc;
+  NNCF_REQUIRE(!d_item_bias || n_items > 0, "item bias needs the catalogue size");
+  if (m->opt) {
+    NNCF_REQUIRE(!d_user_bias || (d_m_user && d_v_user), "Adam needs the user-bias moment arrays");
+    NNCF_REQUIRE(!d_item_bias || (d_m_item && d_v_item), "Adam needs the item-bias moment arrays");
+  }
+  m->ub = d_user_bias;
+  m->cb = d_item_bias;
+  m->bias_items = d_item_bias ? n_items : 0;
+  m->abu = AdamTable{d_m_user, d_v_user, nullptr};
+  m->abc = AdamTable{d_m_item, d_v_item, nullptr};
+  if (m->opt == 2 && (d_user_bias || d_item_bias)) {
+    const size_t n = (size_t)(m->cfg.user_count + m->bias_items);
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(m->device);
+    if (m->bias_stamps) hipFree(m->bias_stamps);
+    m->bias_stamps = nullptr;
+    if (hipMalloc(&m->bias_stamps, n * sizeof(int32_t)) != hipSuccess) {
+      hipSetDevice(prev);
+      return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
+    }
+    hipMemset(m->bias_stamps, 0, n * sizeof(int32_t));
+    hipSetDevice(prev);
+    m->abu.stamp = m->bias_stamps;
+    m->abc.stamp = m->bias_stamps + m->cfg.user_count;
   }
   return NNCF_OK;
 }

@@ -40,6 +40,13 @@ struct StepArgs {
   float lr_t = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;  // lr_t = lr sqrt(1-b2^t)/(1-b1^t)
   int step_no = 0;
   AdamTable au, av;
+  // InteractionDot bias (interaction_dot.py:62-71,96-107): score += ub[user] + cb[item]; NULL = none.
+  // item_gid: global item id of item-table row i when the "table" is a per-batch block (text
+  // towers); NULL = i.  abu / abc: Adam state of the two bias vectors.
+  float* ub = nullptr;
+  float* cb = nullptr;
+  const int32_t* item_gid = nullptr;
+  AdamTable abu, abc;
 };
 
 }  // namespace nncf
@@ -50,6 +57,11 @@ namespace nncf {
 __device__ __forceinline__ Row item_row(const StepArgs& a, int64_t id, int d4, int q) {
   return a.bn_z ? row_load_bn(a.bn_z, a.bn_stats + 384, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
 }
+__device__ __forceinline__ float user_bias(const StepArgs& a, int64_t u) { return a.ub ? a.ub[u] : 0.f; }
+__device__ __forceinline__ float item_bias(const StepArgs& a, int64_t i) {
+  return a.cb ? a.cb[a.item_gid ? a.item_gid[i] : i] : 0.f;
+}
+
 // The optimiser step on one table row (called by one 16-lane group): raw row, complete gradient.
 __device__ __forceinline__ float4 adam4(float4 g, float4& m, float4& v, float4 p, float b1, float b2, float lr_t, float eps) {
   m = make_float4(fmaf(b1, m.x, (1.f - b1) * g.x), fmaf(b1, m.y, (1.f - b1) * g.y), fmaf(b1, m.z, (1.f - b1) * g.z),
@@ -80,6 +92,7 @@ namespace nncf {
 
 // train_scheme = original
 struct OriginalWs {
+  float* gu;         // [b]       sum of d(loss)/d(score) over each positive's 1+k rows (user-bias gradient)
   float* g;          // [b(1+k)]  d(loss)/d(score) per row
   float* dUp;        // [b][d]    dL/dUhat summed over each positive's 1+k rows
   float* Uhat;       // [b][d]    (normalised) user row of each positive
@@ -106,6 +119,8 @@ struct SharedWs {
   float* Vrow;       // [b][d]          normalised item row of each batch row's own item
   float* loss_part;  // [NBI*NBJ]
   float* reg_part;   // [b]             |U_raw|^2 per batch row
+  float* gr_part;    // [NBJ][b]        bias: partial row sums of h (dL/dS off the pairwise corrections)
+  float* gc_part;    // [NBI][Npad]     bias: partial column sums of h
   long long* dbg;    // optional [tiles][8] s_memtime stamps of the tile kernel (NNCF_DEBUG_TIMING=1)
 };
 
@@ -120,6 +135,12 @@ int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_
 
 int launch_rowwise(const StepArgs& a, const int32_t* uid, const int32_t* cid, const int32_t* y, const RowwiseWs& ws,
                    const PlanView& pu, const PlanView& pv, int n, float* loss_out, int update, hipStream_t stream);
+
+// InteractionDot bias update (bias.hip).  scheme 0 original, 1 neg_shared, 2 group_neg_shared, 3 row-wise
+int launch_bias_update(const StepArgs& a, int scheme, const PlanView& pu, const PlanView& pv, const OriginalWs* ows,
+                       const SharedWs* sws, const RowwiseWs* rws, hipStream_t stream);
+
+int launch_bias_idle(const StepArgs& a, float* bias, const AdamTable& st, int64_t n, hipStream_t stream);
 
 // dense Adam: rows of (table, state) whose stamp != a.step_no take a zero-gradient step
 int launch_adam_idle(const StepArgs& a, float* table, const AdamTable& st, int64_t rows, hipStream_t stream);
@@ -148,6 +169,11 @@ struct nncf_model {
   int64_t adam_t = 0;  // update steps taken (Keras `iterations`)
   nncf::AdamTable au, av;
   int32_t* stamps = nullptr;  // owned: user_count + item_count ints (dense Adam)
+  // InteractionDot bias (nncf_model_set_bias)
+  float *ub = nullptr, *cb = nullptr;
+  nncf::AdamTable abu, abc;
+  int64_t bias_items = 0;     // length of cb (the catalogue, also when the item table is a per-batch block)
+  int32_t* bias_stamps = nullptr;  // owned: user_count + bias_items ints (dense Adam)
 };
 
 namespace nncf {

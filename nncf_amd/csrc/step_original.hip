@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
   Row acc = row_zero();   // sum over this group's slots of g * vhat
   Row vpos = row_zero();  // vhat of the positive (group 0; pairwise losses add g_pos * vpos last)
   float loss = 0.f, gpos_pair = 0.f, s_pos = 0.f;
+  const float ubv = user_bias(a, uid[p]);  // interaction_dot.py:96-99
+  float gsum = 0.f;                         // sum of g over this group's slots (user-bias gradient)
   for (int t0 = 0; t0 < nslots; t0 += 16) {
     int ids[4];
     Row v[4];
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
       const int slot = t0 + 4 * e + grp;
       const bool live = slot < nslots;
       if (NV) v[e] = row_scale(v[e], inv_norm(row16_sum(row_dot_partial(v[e], v[e]))));
-      const float s = row_dot(uhat, v[e]);  // interaction_dot.py:92-95
+      const float s = row_dot(uhat, v[e]) + ubv + (ids[e] >= 0 ? item_bias(a, ids[e]) : 0.f);  // interaction_dot.py:92-99
       if (t0 == 0 && e == 0) {
         s_pos = __shfl(s, 0);  // slot 0 lives in group 0
         vpos = v[0];
@@ -99,6 +101,7 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
       if (PAIR) gpos_pair -= g;
       if (live && q == 0 && !(PAIR && is_pos)) ws.g[is_pos ? p : a.b + (int64_t)p * k + (slot - 1)] = g;
       acc = row_fma(g, v[e], acc);
+      gsum += g;
       loss += l;
     }
   }
@@ -112,6 +115,8 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
   acc.b.z = across_groups(acc.b.z);
   acc.b.w = across_groups(acc.b.w);
   loss = across_groups(loss);
+  gsum = across_groups(gsum);
+  if (lane == 0 && a.ub) ws.gu[p] = PAIR ? 0.f : gsum;  // pairwise: the user bias cancels in s_pos - s_neg
   if (PAIR) {
     gpos_pair = across_groups(gpos_pair);
     acc = row_fma(gpos_pair, vpos, acc);  // valid in group 0 (vpos); only group 0 stores
@@ -232,6 +237,7 @@ int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_po
     default: launch_on<NNCF_LOSS_MAX_MARGIN>(a, uid, cid_pos, cid_neg, ws, pu, pv, loss_out, update, stream); break;
   }
   NNCF_HIP_CHECK(hipGetLastError());
+  if (update) return launch_bias_update(a, 0, pu, pv, &ws, nullptr, nullptr, stream);
   return NNCF_OK;
 }
 

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) rowwise_score_kernel(StepArgs a, const in
   const float uss = row16_sum(row_dot_partial(u, u));
   if (NU) u = row_scale(u, inv_norm(uss));
   if (NV) v = row_scale(v, inv_norm(row16_sum(row_dot_partial(v, v))));
-  const float s = row_dot(u, v);
+  const float s = row_dot(u, v) + user_bias(a, uid[row]) + item_bias(a, cid[row]);  // interaction_dot.py:92-99
   const float yy = (float)y[row];
   const float wv = a.lambda / (float)a.k, inv_b = 1.f / (float)a.b;
   float l, g;
@@ -136,6 +136,7 @@ int launch_rowwise(const StepArgs& a, const int32_t* uid, const int32_t* cid, co
   else return fail(NNCF_ERR_INVALID, "row-wise batches support the pointwise losses only (skip-gram, mse): the pairwise "
                                      "losses need the positives-first layout (objectives.py:47-58)");
   NNCF_HIP_CHECK(hipGetLastError());
+  if (update) return launch_bias_update(a, 3, pu, pv, nullptr, nullptr, &ws, stream);
   return NNCF_OK;
 }
 

@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
   __shared__ float sD[kTile];
   __shared__ float sRed[8];
   __shared__ int sPos[kTile];
+  __shared__ float sBu[kTile], sBv[kTile];  // InteractionDot bias of the tile's rows / columns
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.y, bj = blockIdx.x;
@@ -107,8 +108,14 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
     if (PAIR && (GROUP ? NV : NU)) r2 = row_scale(r2, inv_norm(row16_sum(row_dot_partial(r2, r2))));
     lds_store_row(sU + grp * DP, q, NP >> 2, r0);
     lds_store_row(sV + grp * DP, q, NP >> 2, r1);
+    const float bu = user_bias(a, id0), bv = id1 >= 0 ? item_bias(a, id1) : 0.f;
+    if (q == 0) {
+      sBu[grp] = bu;
+      sBv[grp] = bv;
+    }
     if (PAIR) {
-      const float pos_score = GROUP ? row_dot(r0, r2) : row_dot(r2, r1);
+      // group: S[i, pos_i] = U_i . V_cid[i] + ub[uid_i] + cb[cid_i]; neg_shared: S[j, j] of column j
+      const float pos_score = GROUP ? row_dot(r0, r2) + bu + item_bias(a, id2) : row_dot(r2, r1) + user_bias(a, id2) + bv;
       if (q == 0) sD[grp] = pos_score;
       if (bj == 0) row_store(ws.Uhat, gi, d, d4, q, r0);
       if (GROUP) {
@@ -165,7 +172,7 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
     for (int rr = 0; rr < 2; ++rr) {
       const int r = 2 * kh + rr;
       const int row = wr * 16 + (lane >> 4) * 4 + r;
-      const float s = kh ? (rr ? acc[3] : acc[2]) : (rr ? acc[1] : acc[0]);
+      const float s = (kh ? (rr ? acc[3] : acc[2]) : (rr ? acc[1] : acc[0])) + sBu[row] + sBv[col];
       const bool is_pos = sPos[row] == gj;
       float l = 0.f, h = 0.f;
       if (LOSS == NNCF_LOSS_SKIP_GRAM) {
@@ -212,6 +219,17 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
     } else {
       for (int c = 0; c < kTile; ++c) t += sG[tid * kGP + c];  // row sum over this tile's columns
       ws.r_part[(int64_t)bj * b + bi * kTile + tid] = t;
+    }
+  }
+  if ((a.ub || a.cb) && tid < 2 * kTile) {  // bias gradients: row and column sums of h over this tile
+    float t = 0.f;
+    if (tid < kTile) {
+      for (int c = 0; c < kTile; ++c) t += sG[tid * kGP + c];
+      ws.gr_part[(int64_t)bj * b + bi * kTile + tid] = t;
+    } else {
+      const int c = tid - kTile;
+      for (int r = 0; r < kTile; ++r) t += sG[r * kGP + c];
+      ws.gc_part[(int64_t)bi * b + bj * kTile + c] = t;
     }
   }
   NNCF_STAMP(5);
@@ -435,10 +453,11 @@ __global__ void __launch_bounds__(256) predict_tile_kernel(StepArgs a, const int
   const float* pb = sV + (wc * 16 + (lane & 15)) * DP + (lane >> 4);
   for (int kk = 0; kk < d4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
   const int64_t gj = bj * kTile + wc * 16 + (lane & 15);
+  const float bv = (gj < qn) ? item_bias(a, cid[gj]) : 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t gi = bi * kTile + wr * 16 + (lane >> 4) * 4 + r;
-    if (gi < p && gj < qn) out[gi * qn + gj] = acc[r];
+    if (gi < p && gj < qn) out[gi * qn + gj] = acc[r] + user_bias(a, uid[gi]) + bv;
   }
 }
 
@@ -490,6 +509,7 @@ int launch_shared(const StepArgs& a, int group, const int32_t* uid, const int32_
   if (group) launch_loss<true>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
   else launch_loss<false>(a, uid, cid, ws, pu, pv, loss_out, update, stream);
   NNCF_HIP_CHECK(hipGetLastError());
+  if (update) return launch_bias_update(a, group ? 2 : 1, pu, pv, nullptr, &ws, nullptr, stream);
   return NNCF_OK;
 }
 

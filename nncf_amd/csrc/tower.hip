@@ -814,6 +814,7 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   StepArgs sa = make_args(m);
   sa.bn_z = t->z;
   sa.bn_stats = t->ws + ws_muinv();
+  sa.item_gid = uniq_g;  // InteractionDot item bias is indexed by catalogue id, the block by tf.unique rank
   // shared schemes: the apply kernel's item chunks (b / 16 of them) emit the BN backward's sums
   const int chunks = (b + kChunkSlots - 1) / kChunkSlots;
   const int nfused = (scheme != 0 && update && chunks <= kTowerWG) ? chunks : 0;

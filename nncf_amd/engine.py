@@ -21,7 +21,7 @@ class Engine(object):
 
     def __init__(self, user_count, item_count, dim, batch_size_p, num_negatives, loss, loss_gamma,
                  neg_loss_weight, u_reg, learn_rate, normalize_user, normalize_item, device=0, seed=0,
-                 share=None, init_scale=0.05, tables=None):
+                 share=None, init_scale=0.05, tables=None, interaction_bias=None, bias_item_count=None, bias_state=None):
         if loss not in _lib.LOSS_CODES:
             raise AssertionError("[ERROR!] loss %s not specified." % loss)  # objectives.py:72
         self._L = _lib.lib()
@@ -68,6 +68,35 @@ class Engine(object):
             _lib.check(self._L.nncf_model_create(ctypes.byref(cfg), _ptr(self.U), _ptr(self.V), self.device.index, 1,
                                                  ctypes.byref(self._h)))
         self._loss1 = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # InteractionDot bias (interaction_dot.py:62-71): zero-initialised vectors over users / the
+        # catalogue; engines over the same parameters share them (bias_state / share)
+        assert interaction_bias in (None, "user", "item", "both"), "ERROR! Unknown interation bias"
+        self.interaction_bias = interaction_bias
+        self.opt_state, self.optimizer = None, "sgd"
+        self.bias = None
+        if interaction_bias:
+            if bias_state is None and share is not None:
+                bias_state = getattr(share, "bias", None)
+            if bias_state is None:
+                n_items = int(bias_item_count if bias_item_count is not None else self.item_count)
+                z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)  # noqa: E731
+                bias_state = {"ub": z(self.user_count) if interaction_bias in ("user", "both") else None,
+                              "cb": z(n_items) if interaction_bias in ("item", "both") else None, "n_items": n_items}
+            self.bias = bias_state
+            self._bind_bias()
+
+    def _bind_bias(self):
+        b = self.bias
+        if b is None:
+            return
+        mode = self.OPT_CODES[self.optimizer]
+        if mode and "m_ub" not in b:
+            z = lambda t: torch.zeros_like(t) if t is not None else None  # noqa: E731
+            b.update(m_ub=z(b["ub"]), v_ub=z(b["ub"]), m_cb=z(b["cb"]), v_cb=z(b["cb"]))
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_model_set_bias(self._h, _ptr(b["ub"]), _ptr(b["cb"]), int(b["n_items"]),
+                                                   _ptr(b.get("m_ub")), _ptr(b.get("v_ub")), _ptr(b.get("m_cb")),
+                                                   _ptr(b.get("v_cb"))))
 
     OPT_CODES = {"sgd": 0, "sparse_adam": 1, "adam": 2}
 
@@ -87,6 +116,7 @@ class Engine(object):
             _lib.check(self._L.nncf_model_set_optimizer(self._h, mode, beta1, beta2, epsilon, _ptr(st.get("mU")),
                                                         _ptr(st.get("vU")), _ptr(st.get("mV")), _ptr(st.get("vV"))))
         self.optimizer = kind
+        self._bind_bias()   # bias moments / stamps follow the optimiser
 
     # -- helpers -------------------------------------------------------------------------
     def ids(self, x):

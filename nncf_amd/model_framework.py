@@ -262,7 +262,7 @@ class _TowerCore(object):
             kw = dict(self._engine_kw)
             kw["item_count"] = self.item_count
             Vall = torch.zeros(self.item_count, self.engine.dim_p, dtype=torch.float32, device=self.engine.device)
-            self._eval = Engine(device=self._device, tables=(self.engine.U, Vall), **kw)
+            self._eval = Engine(device=self._device, tables=(self.engine.U, Vall), bias_state=self.engine.bias, **kw)
         if self._eval_version != self.tower.version:
             ids = torch.arange(self.item_count, dtype=torch.int32, device=self.engine.device)
             for i0 in range(0, self.item_count, 4096):
@@ -322,7 +322,9 @@ def engine_kwargs(conf, data_spec, model_name):
         loss_gamma=getattr(conf, "loss_gamma", 1), neg_loss_weight=getattr(conf, "neg_loss_weight", 1),
         u_reg=conf.u_reg, learn_rate=abs(conf.learn_rate),
         normalize_user=normalize,                              # model_framework.py:62-63
-        normalize_item=normalize and model_name != "mf")        # :109-111 (content branch only)
+        normalize_item=normalize and model_name != "mf",        # :109-111 (content branch only)
+        interaction_bias=getattr(conf, "interaction_bias", None),   # :119-121
+        bias_item_count=data_spec.item_count)
 
 
 def _conv_spec(conf):
@@ -371,7 +373,7 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
             kw2 = dict(kw)
             kw2["loss"] = loss_name
             kw2["learn_rate"] = 0.0
-            core2 = _TowerCore(Engine(device=device, tables=(engine.U, engine.V), **kw2), tower, data_spec.item_count,
+            core2 = _TowerCore(Engine(device=device, tables=(engine.U, engine.V), bias_state=engine.bias, **kw2), tower, data_spec.item_count,
                                kw2, device)
             return TowerHead(core2, kind, update=False)
         return make
@@ -393,9 +395,6 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
     """get_model (model_framework.py:18-206)."""
     data_spec = data_helper.data_spec
     assert conf.user_dim == conf.item_dim, "user_dim and item_dim must match for the dot interaction"
-    if getattr(conf, "interaction_bias", None) is not None:
-        raise NotImplementedError("interaction_bias=%r (interaction_dot.py:62-71) is not built yet; "
-                                  "pass {'interaction_bias': None}" % conf.interaction_bias)
     if model_name == "basic_embedding":
         return _get_model_basic_embedding(conf, data_helper, device, seed)
     if model_name == "cnn_embedding":   # model_framework.py:92-93

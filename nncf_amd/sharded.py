@@ -53,6 +53,9 @@ class HipBackend(object):
         self._lib = _lib
         self.device = torch.device("cuda", device)
         kw = dict(engine_kwargs)
+        if kw.get("interaction_bias"):
+            raise NotImplementedError("interaction_bias is not built for the item-sharded path")
+        kw.pop("bias_item_count", None)
         kw["user_count"] = local_users
         self.b = kw["batch_size_p"]
         self.dim = (int(kw["dim"]) + 3) // 4 * 4   # physical row width (Engine pads to a multiple of 4)

@@ -34,7 +34,7 @@ class OracleConf(object):
 
     def __init__(self, batch_size_p=512, num_negatives=10, loss="skip-gram", loss_gamma=None,
                  neg_loss_weight=None, u_reg=1e-6, learn_rate=0.01, emb_normalization=None,
-                 model_choice="mf", optimizer="sgd", beta1=0.9, beta2=0.999, epsilon=1e-8):
+                 model_choice="mf", optimizer="sgd", beta1=0.9, beta2=0.999, epsilon=1e-8, interaction_bias=None):
         self.batch_size_p = int(batch_size_p)
         self.num_negatives = int(num_negatives)
         assert loss in LOSSES, "[ERROR!] loss %s not specified." % loss
@@ -52,6 +52,9 @@ class OracleConf(object):
         # | 'sparse_adam' (utils/optimizer.py:108-134; duplicate ids summed first)
         assert optimizer in ("sgd", "adam", "sparse_adam")
         self.optimizer, self.beta1, self.beta2, self.epsilon = optimizer, beta1, beta2, epsilon
+        # InteractionDot bias (interaction_dot.py:48-49,62-71): None | 'user' | 'item' | 'both'; zero init
+        assert interaction_bias in ("user", "item", "both", None), "ERROR! Unknown interation bias"
+        self.interaction_bias = interaction_bias
         # model_framework.py:62-63 normalises U for every model; :109-111 normalises the item
         # side only inside the content-model branch (not for 'mf', :85-88).
         self.normalize_user = self.emb_normalization
@@ -475,14 +478,23 @@ class StepOracle(object):
         self.tower = tower  # TowerOracle: item rows come from the text tower (model_framework.py:98-106)
         self.t = 0  # optimiser steps taken (Keras `iterations`)
         self.slot_u = self.slot_v = None
+        ib = getattr(conf, "interaction_bias", None)
+        self.ub = np.zeros(self.U.shape[0], dtype=self.dt) if ib in ("user", "both") else None
+        self.cb = None   # sized on first use (item count: the table, or set_item_count for tower models)
+        self._want_cb = ib in ("item", "both")
+        self.slot_ub = self.slot_cb = None
+        if self._want_cb and self.V is not None:
+            self.cb = np.zeros(self.V.shape[0], dtype=self.dt)
         self.row_scale = None  # per-word scale of Embedding row dropout for the next step (mean_pool.py:56-59)
 
     def _tower_in(self, cid):
         """Content models run on tf.unique(cid) and are re-gathered (model_framework.py:45-48,
         98-106): expose the compact block as this step's item 'table'."""
+        self._gid = None          # global item id of every row of the item block (bias lookups)
         if self.tower is None:
             return cid
         cid_u, cid_x = tf_unique(cid)
+        self._gid = cid_u
         self.V = self.tower.forward(cid_u, train=True, row_scale=self.row_scale)
         self._n_u = len(cid_u)
         return cid_x.astype(np.int64)
@@ -511,7 +523,34 @@ class StepOracle(object):
             hat, inv = raw, None
         return raw, hat, inv
 
-    def _apply(self, uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g_uhat, g_vhat):
+    def _bias(self, uid, cid):
+        """(ubias[uid], cbias[global id of item-block row cid]) or zeros (interaction_dot.py:96-99,104-107)."""
+        bu = self.ub[uid] if self.ub is not None else np.zeros(len(uid), dtype=self.dt)
+        if self._want_cb and self.cb is None:
+            raise ValueError("item bias with a text tower: set oracle.cb = zeros(item_count) first")
+        gid = self._gid[cid] if self._gid is not None else cid
+        bc = self.cb[gid] if self.cb is not None else np.zeros(len(cid), dtype=self.dt)
+        return bu.astype(self.dt), bc.astype(self.dt)
+
+    def _apply_bias(self, uid, cid, gb_u, gb_v, lr_t):
+        """gb_u[i] / gb_v[j]: dL/d(score) summed over the scores user row i / item row j takes part in."""
+        opt = getattr(self.conf, "optimizer", "sgd")
+        lr = self.dt.type(self.conf.learn_rate)
+        for tab, ids, gb, name in ((self.ub, uid, gb_u, "slot_ub"),
+                                   (self.cb, (self._gid[cid] if self._gid is not None else cid), gb_v, "slot_cb")):
+            if tab is None:
+                continue
+            d = np.zeros_like(tab)
+            np.add.at(d, ids, gb.astype(self.dt))
+            touched = np.unique(ids)
+            if opt == "sgd":
+                tab[touched] -= lr * d[touched]
+            else:
+                if getattr(self, name) is None:
+                    setattr(self, name, AdamSlot(tab))
+                getattr(self, name).step(tab, d, lr_t, self.conf, touched if opt == "sparse_adam" else None)
+
+    def _apply(self, uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g_uhat, g_vhat, gb_u=None, gb_v=None):
         """Back through the normalisation, add the regulariser gradient, scatter-SGD."""
         lr = self.dt.type(self.conf.learn_rate)
         n = self.dt.type(len(uid))
@@ -538,6 +577,8 @@ class StepOracle(object):
             self.slot_u.step(self.U, dU, lr_t, self.conf, tu if sparse else None)
             if self.tower is None:
                 self.slot_v.step(self.V, dV, lr_t, self.conf, tv if sparse else None)
+        if gb_u is not None:
+            self._apply_bias(uid, cid, gb_u, gb_v, adam_lr_t(self.conf.learn_rate, self.conf.beta1, self.conf.beta2, max(self.t, 1)))
         self.last = dict(g_u=g_u, g_v=g_v, dU=dU, dV=dV)
 
     # -- train_scheme = original (train_original.py:49-58; model 'model', :123,147-149) ---
@@ -547,11 +588,12 @@ class StepOracle(object):
         y = np.asarray(y).astype(self.dt).reshape(-1)
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid)
-        s = np.sum(hat_u * hat_v, axis=1)                              # interaction_dot.py:92-95
+        bu, bc = self._bias(uid, cid)
+        s = np.sum(hat_u * hat_v, axis=1) + bu + bc                    # interaction_dot.py:92-99
         loss, g = original_loss(s, y, self.conf)
         self.scores = s
         if update:
-            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g[:, None] * hat_v, g[:, None] * hat_u)
+            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g[:, None] * hat_v, g[:, None] * hat_u, g, g)
         self._tower_out(update)
         return float(loss + reg)
 
@@ -561,11 +603,12 @@ class StepOracle(object):
         cid = self._tower_in(cid)
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid)
-        S = hat_u @ hat_v.T                                            # interaction_dot.py:100-103
+        bu, bc = self._bias(uid, cid)
+        S = hat_u @ hat_v.T + bu[:, None] + bc[None, :]                # interaction_dot.py:100-107
         loss, G = neg_shared_loss(S, self.conf)
         self.scores = S
         if update:
-            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+            self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u, G.sum(axis=1), G.sum(axis=0))
         self._tower_out(update)
         return float(loss + reg)
 
@@ -577,11 +620,12 @@ class StepOracle(object):
         cid_u, cid_x = tf_unique(cid)                                  # :45-48
         raw_u, hat_u, inv_u, reg = self._user_side(uid)
         raw_v, hat_v, inv_v = self._item_side(cid_u)                   # compact item block
-        S = hat_u @ hat_v.T                                            # (b, n_u)
+        bu, bc = self._bias(uid, cid_u)
+        S = hat_u @ hat_v.T + bu[:, None] + bc[None, :]                # (b, n_u)
         loss, G = group_neg_shared_loss(S, cid_x, self.conf)
         self.scores, self.cid_u, self.cid_x = S, cid_u, cid_x
         if update:
-            self._apply(uid, cid_u, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u)
+            self._apply(uid, cid_u, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u, G.sum(axis=1), G.sum(axis=0))
         self._tower_out(update)
         return float(loss + reg)
 
@@ -608,9 +652,12 @@ class StepOracle(object):
 
     # -- inference heads (model_framework.py:153,173-176) --------------------------------
     def predict_neg_shared(self, uid, cid):
-        _, hat_u, _, _ = self._user_side(np.asarray(uid, dtype=np.int64))
-        _, hat_v, _ = self._item_side(np.asarray(cid, dtype=np.int64))
-        return hat_u @ hat_v.T
+        uid, cid = np.asarray(uid, dtype=np.int64), np.asarray(cid, dtype=np.int64)
+        _, hat_u, _, _ = self._user_side(uid)
+        _, hat_v, _ = self._item_side(cid)
+        self._gid = None
+        bu, bc = self._bias(uid, cid)
+        return hat_u @ hat_v.T + bu[:, None] + bc[None, :]
 
 
 # ----------------------------------------------------------------------------------------

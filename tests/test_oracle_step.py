@@ -20,7 +20,7 @@ def _t_normalize(x):
     return x * torch.rsqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=1e-12))
 
 
-def _torch_original(U, V, uid, cid, y, conf):
+def _torch_original(U, V, uid, cid, y, conf, ub=None, cb=None):
     b, k = conf.batch_size_p, conf.num_negatives
     e = U[uid]
     reg = conf.u_reg * (e * e).mean(0).sum()
@@ -28,6 +28,8 @@ def _torch_original(U, V, uid, cid, y, conf):
     v = V[cid]
     v = _t_normalize(v) if conf.normalize_item else v
     pred = (u * v).sum(1, keepdim=True)
+    if ub is not None:
+        pred = pred + ub[uid].reshape(-1, 1) + cb[cid].reshape(-1, 1)     # interaction_dot.py:96-99
     y = y.reshape(-1, 1)
     lam, gamma = conf.neg_loss_weight, conf.loss_gamma
     pos, neg = pred[:b], pred[b:]
@@ -46,7 +48,7 @@ def _torch_original(U, V, uid, cid, y, conf):
     return task + reg
 
 
-def _torch_neg_shared(U, V, uid, cid, conf):
+def _torch_neg_shared(U, V, uid, cid, conf, ub=None, cb=None):
     b = conf.batch_size_p
     e = U[uid]
     reg = conf.u_reg * (e * e).mean(0).sum()
@@ -54,6 +56,8 @@ def _torch_neg_shared(U, V, uid, cid, conf):
     v = V[cid]
     v = _t_normalize(v) if conf.normalize_item else v
     pred = u @ v.t()
+    if ub is not None:
+        pred = pred + ub[uid].reshape(-1, 1) + cb[cid].reshape(1, -1)     # interaction_dot.py:104-107
     lam, gamma = conf.neg_loss_weight, conf.loss_gamma
     eye = torch.eye(b, dtype=pred.dtype)
     if conf.loss == "max-margin":
@@ -75,7 +79,7 @@ def _torch_neg_shared(U, V, uid, cid, conf):
     return task + reg
 
 
-def _torch_group(U, V, uid, cid_u, cid_x, conf):
+def _torch_group(U, V, uid, cid_u, cid_x, conf, ub=None, cb=None):
     b = conf.batch_size_p
     e = U[uid]
     reg = conf.u_reg * (e * e).mean(0).sum()
@@ -83,6 +87,8 @@ def _torch_group(U, V, uid, cid_u, cid_x, conf):
     v = V[cid_u]
     v = _t_normalize(v) if conf.normalize_item else v
     pred = u @ v.t()
+    if ub is not None:
+        pred = pred + ub[uid].reshape(-1, 1) + cb[cid_u].reshape(1, -1)
     nu = pred.shape[1]
     lam, gamma = conf.neg_loss_weight, conf.loss_gamma
     rows = torch.arange(b)
@@ -371,3 +377,40 @@ def test_cnn_tower_oracle_vs_autograd_full_chain():
     for name, tp in (("W", tW), ("Wc", tWc), ("bc", tbc), ("g1", tg1), ("b1", tb1), ("Wd", tWd), ("bd", tbd),
                      ("gamma", tga), ("beta", tbe)):
         np.testing.assert_allclose(to.grads[name], tp.grad.numpy(), rtol=1e-7, atol=1e-10, err_msg=name)
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "mse", "log-loss", "max-margin"])
+def test_interaction_bias_vs_autograd(loss):
+    """interaction_bias = 'both' (interaction_dot.py:62-71,96-107): ubias[uid] + cbias[cid] added to
+    every score; the oracle's bias gradients (row / column sums of dL/dscore) against torch autograd
+    for the three schemes."""
+    rs = np.random.RandomState(4)
+    U, V = _tables()
+    nu, ni, b, k = U.shape[0], V.shape[0], 8, 2
+    ub0, cb0 = rs.randn(nu) * 0.1, rs.randn(ni) * 0.1
+    for scheme in ("original", "neg_shared", "group_neg_shared"):
+        conf = so.OracleConf(batch_size_p=b, num_negatives=k if scheme == "original" else 0, loss=loss, u_reg=1e-3,
+                             learn_rate=0.1, model_choice="mf", interaction_bias="both")
+        o = so.StepOracle(U, V, conf, dtype=np.float64)
+        o.ub[:] = ub0
+        o.cb[:] = cb0
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        cid[3] = cid[0]
+        uid[5] = uid[1]
+        tU, tV, tub, tcb = [torch.tensor(x, requires_grad=True) for x in (U, V, ub0, cb0)]
+        if scheme == "original":
+            uu, cc, yy = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=int)], 1), rs.randint(0, ni, b * k), loss)
+            lo = o.step_original(uu, cc, yy)
+            lt = _torch_original(tU, tV, torch.tensor(uu), torch.tensor(cc), torch.tensor(yy, dtype=torch.float64), conf, tub, tcb)
+        elif scheme == "neg_shared":
+            lo = o.step_neg_shared(uid, cid)
+            lt = _torch_neg_shared(tU, tV, torch.tensor(uid), torch.tensor(cid), conf, tub, tcb)
+        else:
+            lo = o.step_group_neg_shared(uid, cid)
+            cu, cx = so.tf_unique(cid)
+            lt = _torch_group(tU, tV, torch.tensor(uid), torch.tensor(cu), torch.tensor(cx), conf, tub, tcb)
+        lt.backward()
+        assert abs(lo - float(lt.detach())) < 1e-9 * max(1, abs(lo)), (scheme, lo, float(lt.detach()))
+        np.testing.assert_allclose(o.ub, ub0 - 0.1 * tub.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=scheme)
+        np.testing.assert_allclose(o.cb, cb0 - 0.1 * tcb.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=scheme)
+        np.testing.assert_allclose(o.U, U - 0.1 * tU.grad.numpy(), rtol=1e-8, atol=1e-11, err_msg=scheme)

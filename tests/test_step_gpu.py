@@ -304,3 +304,79 @@ def test_edge_cases_degenerate_batches():
             eng.ids(np.zeros(48)), eng.ids(np.zeros(48)))
     with pytest.raises(AssertionError):
         Engine(nu, ni, d, 64, 0, "hinge", 10., 128., 1e-6, 0.1, False, False)   # objectives.py:72
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("scheme", ["original", "neg_shared", "group_neg_shared"])
+def test_interaction_bias_matches_oracle(scheme, loss):
+    """interaction_bias = 'both' (interaction_dot.py:62-71): scores, losses, table rows and both bias
+    vectors after several steps; duplicates in users and items; predictions include the biases."""
+    b, k, d, nu, ni = 64, 3, 16, 50, 90
+    gamma = {"max-margin": 0.1, "log-loss": 10.}.get(loss)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=1e-3, learn_rate=0.05,
+                         model_choice="mf", interaction_bias="both")
+    eng = Engine(nu, ni, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=1, init_scale=0.5, interaction_bias="both")
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(3)
+    eng.bias["ub"].copy_(torch.as_tensor(rs.randn(nu).astype(np.float32) * 0.2))
+    eng.bias["cb"].copy_(torch.as_tensor(rs.randn(ni).astype(np.float32) * 0.2))
+    orc.ub[:] = eng.bias["ub"].cpu().numpy()
+    orc.cb[:] = eng.bias["cb"].cpu().numpy()
+    for step in range(3):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        if scheme == "group_neg_shared":
+            cid = np.repeat(cid[::4], 4)
+        if scheme == "original":
+            negs = rs.randint(0, ni, b * k)
+            u, c, y = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=np.int64)], 1), negs, loss)
+            want = orc.step_original(u, c, y)
+            got = eng.step_original(eng.ids(uid), eng.ids(c)).item()
+        elif scheme == "neg_shared":
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
+        np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=1e-5, atol=2e-6)
+    users, items = np.arange(20), np.arange(0, ni, 2)
+    got = eng.predict_scores(eng.ids(users), eng.ids(items)).cpu().numpy()
+    np.testing.assert_allclose(got, orc.predict_neg_shared(users, items), rtol=1e-5, atol=2e-6)
+
+
+def test_interaction_bias_adam_and_rowwise():
+    """bias under Keras Adam / lazy-sparse Adam (moments, idle entries) and through the row-wise kernels."""
+    b, k, d, nu, ni = 64, 3, 16, 50, 90
+    for kind in ("adam", "sparse_adam"):
+        conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss="skip-gram", u_reg=1e-3, learn_rate=0.01, model_choice="mf",
+                             interaction_bias="item", optimizer=kind)
+        eng = Engine(nu, ni, d, b, k, "skip-gram", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                     conf.normalize_user, conf.normalize_item, seed=1, init_scale=0.5, interaction_bias="item")
+        eng.set_optimizer(kind)
+        orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+        rs = np.random.RandomState(3)
+        for step in range(4):
+            uid, cid = rs.randint(0, nu, b), rs.randint(0, ni // 2, b)
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            assert abs(got - want) <= 2e-5 * max(1, abs(want)), (kind, step, got, want)
+            np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-4, atol=2e-5)
+        assert eng.bias["ub"] is None
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss="mse", u_reg=1e-3, learn_rate=0.05, model_choice="mf",
+                         interaction_bias="both")
+    eng = Engine(nu, ni, d, b, k, "mse", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=1, init_scale=0.5, interaction_bias="both")
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    n = b * (1 + k)
+    rs = np.random.RandomState(0)
+    for step in range(3):
+        uid, cid = rs.randint(0, nu, n), rs.randint(0, ni, n)
+        y = np.where(rs.rand(n) < 0.3, 1, 0)
+        want = orc.step_original(uid, cid, y)
+        got = eng.step_rowwise(eng.ids(uid), eng.ids(cid), eng.ids(y)).item()
+        assert abs(got - want) <= 2e-5 * max(1, abs(want))
+        np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=1e-5, atol=2e-6)

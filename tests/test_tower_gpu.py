@@ -394,3 +394,47 @@ def test_tower_edge_cases(text_data):
             assert np.all(np.isfinite(getattr(tw, name).cpu().numpy())), name
         empty = torch.zeros(0, dtype=torch.int32, device=tw.device)
         assert tuple(tw.forward(empty, train=False).shape) == (0, tw.d)
+
+
+@pytest.mark.parametrize("scheme,loss", [("neg_shared", "skip-gram"), ("group_neg_shared", "log-loss"), ("original", "mse")])
+def test_interaction_bias_with_text_tower(text_data, scheme, loss):
+    """interaction_bias = 'both' above a text tower: the item bias is indexed by catalogue id while the
+    step kernels see tf.unique ranks of a per-batch block."""
+    conf = _conf(loss, scheme)
+    conf.interaction_bias = "both"
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    orc.conf.interaction_bias = "both"
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    eng = head.engine
+    rs = np.random.RandomState(7)
+    eng.bias["ub"].copy_(torch.as_tensor(rs.randn(300).astype(np.float32) * 0.2))
+    eng.bias["cb"].copy_(torch.as_tensor(rs.randn(260).astype(np.float32) * 0.2))
+    orc.ub, orc._want_cb = eng.bias["ub"].cpu().numpy().copy(), True
+    orc.cb = eng.bias["cb"].cpu().numpy().copy()
+    b, k = conf.batch_size_p, conf.num_negatives
+    train = text_data["train"]
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(head.core.tower.W.cpu().numpy(), to.W, rtol=2e-4, atol=2e-5)
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
+    oc2.ub, oc2.cb = orc.ub, orc.cb[items]
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=2e-4, atol=2e-5)
