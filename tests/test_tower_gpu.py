@@ -438,3 +438,52 @@ def test_interaction_bias_with_text_tower(text_data, scheme, loss):
     oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
     oc2.ub, oc2.cb = orc.ub, orc.cb[items]
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=2e-4, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def citeulike_data():
+    return synthetic.make_citeulike_like(content_len=200, vocab=8001)     # 16K users x 17K items x 200K links + text
+
+
+@pytest.mark.parametrize("model,scheme", [("basic_embedding", "neg_shared"), ("basic_embedding", "group_neg_shared"),
+                                          ("basic_embedding", "original"), ("cnn_embedding", "group_neg_shared")])
+def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
+    """BASELINE configs[0..2] and [4] at their full shape (b = 512, d = 100, L = 200, k = 10, word-row
+    dropout 0.5, conv dropout 0.1) for two steps against the oracle: loss, user table, tower parameters."""
+    data = citeulike_data
+    loss = "log-loss" if scheme == "group_neg_shared" else "skip-gram"
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": loss, "num_negatives": 10 if scheme == "original" else 0,
+          "neg_loss_weight": 128, "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
+          "batch_size_p": 512, "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6,
+          "word_emb_dropout_rate": 0.5, "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data)
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    b, k = 512, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = data["train"]
+    n_items = data["C"].shape[0]
+    for step in range(2):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy()
+        if model == "cnn_embedding":
+            to.conv_mask = tw.conv_mask(step, b).cpu().numpy()
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, n_items, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)        # north-star: 1e-5
+    np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
+    names = ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta") if model == "cnn_embedding" else ("W", "Wd", "gamma", "beta")
+    for name in names:
+        np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=1e-5, err_msg=name)
