@@ -57,6 +57,63 @@ namespace nncf {
 __device__ __forceinline__ Row item_row(const StepArgs& a, int64_t id, int d4, int q) {
   return a.bn_z ? row_load_bn(a.bn_z, a.bn_stats + 384, id, a.stride, d4, q) : row_load(a.V, id, a.stride, d4, q);
 }
+// Text tower above the item "table": the apply kernels read the pre-activation rows, apply
+// BatchNorm + ReLU themselves and -- the BatchNorm backward's reductions riding along -- emit per
+// workgroup the column sums of dy = dL/dE * [E > 0] and dy * xhat over the rows they finalise.
+struct BnTail {
+  bool on, sums;
+  Row mul, add, mu, inv, s1, s2;
+};
+__device__ __forceinline__ void bn_tail_init(BnTail& t, const StepArgs& a, int q) {
+  t.on = a.bn_z != nullptr;
+  t.sums = t.on && a.bn_part != nullptr;
+  t.mul = t.add = t.mu = t.inv = t.s1 = t.s2 = row_zero();
+  if (t.on) {
+    t.mu = row_load(a.bn_stats, 0, 128, 32, q);
+    t.inv = row_load(a.bn_stats + 128, 0, 128, 32, q);
+    t.mul = row_load(a.bn_stats + 384, 0, 128, 32, q);
+    t.add = row_load(a.bn_stats + 512, 0, 128, 32, q);
+  }
+}
+__device__ __forceinline__ Row bn_tail_row(const BnTail& t, Row loaded) {
+  if (!t.on) return loaded;
+  Row v;
+  v.a = bn_relu4(loaded.a, t.mul.a, t.add.a);
+  v.b = bn_relu4(loaded.b, t.mul.b, t.add.b);
+  return v;
+}
+__device__ __forceinline__ void bn_tail_acc4(float4 y, float4 g, float4 z, float4 mu, float4 iv, float4& t1, float4& t2) {
+  const float4 dy = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+  t1 = add4(t1, dy);
+  t2.x = fmaf(dy.x, (z.x - mu.x) * iv.x, t2.x);
+  t2.y = fmaf(dy.y, (z.y - mu.y) * iv.y, t2.y);
+  t2.z = fmaf(dy.z, (z.z - mu.z) * iv.z, t2.z);
+  t2.w = fmaf(dy.w, (z.w - mu.w) * iv.w, t2.w);
+}
+__device__ __forceinline__ void bn_tail_acc(BnTail& t, const StepArgs&, Row vraw, Row grad, Row loaded) {
+  if (!t.sums) return;
+  bn_tail_acc4(vraw.a, grad.a, loaded.a, t.mu.a, t.inv.a, t.s1.a, t.s2.a);
+  bn_tail_acc4(vraw.b, grad.b, loaded.b, t.mu.b, t.inv.b, t.s1.b, t.s2.b);
+}
+// every thread of the 256-thread workgroup calls this: the 16 groups in group order -> bn_part[chunk]
+__device__ __forceinline__ void bn_tail_flush(const BnTail& t, const StepArgs& a, float* sR, int chunk) {
+  if (!t.sums) return;
+  const int gl = threadIdx.x >> 4, q = threadIdx.x & 15;
+  float* out = a.bn_part + (int64_t)chunk * 2 * 128;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    reinterpret_cast<float4*>(sR + gl * 128)[q] = half ? t.s2.a : t.s1.a;
+    reinterpret_cast<float4*>(sR + gl * 128)[q + 16] = half ? t.s2.b : t.s1.b;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float v = 0.f;
+      for (int g = 0; g < 16; ++g) v += sR[g * 128 + threadIdx.x];
+      out[half * 128 + threadIdx.x] = v;
+    }
+  }
+}
+
 __device__ __forceinline__ float user_bias(const StepArgs& a, int64_t u) { return a.ub ? a.ub[u] : 0.f; }
 __device__ __forceinline__ float item_bias(const StepArgs& a, int64_t i) {
   return a.cb ? a.cb[a.item_gid ? a.item_gid[i] : i] : 0.f;

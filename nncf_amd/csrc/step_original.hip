@@ -173,13 +173,16 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
         });
   } else {
     const int chunk = blockIdx.x - cu;
+    BnTail bt;
+    bn_tail_init(bt, a, q);
     chunk_reduce(
-        pv, chunk, sR, [&](int c) { return item_row(a, c, d4, q); },
+        pv, chunk, sR, [&](int c) { return row_load(bt.on ? a.bn_z : a.V, c, a.stride, d4, q); },
         [&](int n, bool) {
           const int p = (n < b) ? n : (n - b) / k;
           return row_scale(row_load(ws.Uhat, p, a.d, d4, q), ws.g[n]);
         },
-        [&](int c, int, Row vraw, Row acc) {
+        [&](int c, int, Row loaded, Row acc) {
+          const Row vraw = bn_tail_row(bt, loaded);
           Row grad = acc;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));
@@ -188,7 +191,9 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
           }
           if (a.gV) row_store(a.gV, c, a.d, d4, q, grad);
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
+          bn_tail_acc(bt, a, vraw, grad, loaded);
         });
+    bn_tail_flush(bt, a, sR, chunk);
   }
 }
 

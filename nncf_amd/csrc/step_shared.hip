@@ -345,19 +345,10 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
         });
   } else {
     const int chunk = blockIdx.x - max_chunks;
-    // text tower: rows come from the pre-activation block; BatchNorm + ReLU here, and the BN
-    // backward's column sums over the rows this workgroup finalises
-    const bool bn = a.bn_z != nullptr;
-    Row bmul = row_zero(), badd = row_zero(), bmu = row_zero(), binv = row_zero();
-    if (bn) {
-      bmu = row_load(a.bn_stats, 0, 128, 32, q);
-      binv = row_load(a.bn_stats + 128, 0, 128, 32, q);
-      bmul = row_load(a.bn_stats + 384, 0, 128, 32, q);
-      badd = row_load(a.bn_stats + 512, 0, 128, 32, q);
-    }
-    Row s1 = row_zero(), s2 = row_zero();
+    BnTail bt;
+    bn_tail_init(bt, a, q);  // text tower: rows come from the pre-activation block (BatchNorm + ReLU here)
     chunk_reduce(
-        pv, chunk, sR, [&](int c) { return row_load(bn ? a.bn_z : a.V, c, a.stride, d4, q); },
+        pv, chunk, sR, [&](int c) { return row_load(bt.on ? a.bn_z : a.V, c, a.stride, d4, q); },
         [&](int pos, bool is_head) {
           // neg_shared: pos is a column of the tile grid.  group: pos is a batch row of this
           // item's segment; the item's column slab is taken once (with the segment's first
@@ -373,11 +364,7 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           return colv;
         },
         [&](int c, int, Row loaded, Row acc) {
-          Row vraw = loaded;
-          if (bn) {
-            vraw.a = bn_relu4(loaded.a, bmul.a, badd.a);
-            vraw.b = bn_relu4(loaded.b, bmul.b, badd.b);
-          }
+          const Row vraw = bn_tail_row(bt, loaded);
           Row grad = acc;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));
@@ -386,35 +373,9 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           }
           if (a.gV) row_store(a.gV, c, d, d4, q, grad);
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
-          if (bn && a.bn_part) {
-            auto acc4 = [](float4 y, float4 g, float4 z, float4 mu, float4 iv, float4& t1, float4& t2) {
-              const float4 dy = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f,
-                                            y.w > 0.f ? g.w : 0.f);
-              t1 = add4(t1, dy);
-              t2.x = fmaf(dy.x, (z.x - mu.x) * iv.x, t2.x);
-              t2.y = fmaf(dy.y, (z.y - mu.y) * iv.y, t2.y);
-              t2.z = fmaf(dy.z, (z.z - mu.z) * iv.z, t2.z);
-              t2.w = fmaf(dy.w, (z.w - mu.w) * iv.w, t2.w);
-            };
-            acc4(vraw.a, grad.a, loaded.a, bmu.a, binv.a, s1.a, s2.a);
-            acc4(vraw.b, grad.b, loaded.b, bmu.b, binv.b, s1.b, s2.b);
-          }
+          bn_tail_acc(bt, a, vraw, grad, loaded);
         });
-    if (bn && a.bn_part) {  // the 16 groups in group order -> this chunk's partial
-      const int gl = tid >> 4;
-      float* out = a.bn_part + (int64_t)chunk * 2 * 128;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        lds_put_row(sR, gl, q, half ? s2 : s1);
-        __syncthreads();
-        if (tid < 128) {
-          float t = 0.f;
-          for (int g = 0; g < kChunkSlots; ++g) t += sR[g * kChunkPitch + tid];
-          out[half * 128 + tid] = t;
-        }
-      }
-    }
+    bn_tail_flush(bt, a, sR, chunk);
   }
 }
 

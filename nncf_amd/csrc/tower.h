@@ -158,6 +158,7 @@ struct nncf_tower {
   void* arena = nullptr;
   float *h = nullptr, *z = nullptr, *dh = nullptr, *ws = nullptr;
   uint8_t* cnt_t = nullptr;
+  float* bpart = nullptr;
   int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
   bool fwd_cached = false;
   nncf::TowerArgs last{};

@@ -207,6 +207,27 @@ __device__ __forceinline__ void merge_partials(const float* part, int nparts, in
   }
 }
 
+// column totals of the shifted sums -> mu, inv, var, fused scale / shift, running statistics
+__device__ __forceinline__ void stats_finalize(const TowerArgs& a, int c, float t1, float t2, int nv) {
+  if (c < a.d) {
+    const float rn = 1.f / (float)max(nv, 1);
+    const float m1 = t1 * rn;
+    const float mu = a.z[c] + m1, var = fmaxf(t2 * rn - m1 * m1, 0.f), inv = rsqrtf(var + a.eps);
+    float* mi = a.ws + ws_muinv();
+    const float mul = a.gamma[c] * inv;
+    mi[c] = mu;
+    mi[128 + c] = inv;
+    mi[256 + c] = var;
+    mi[384 + c] = mul;
+    mi[512 + c] = a.beta[c] - mu * mul;
+    a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mu;
+    a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * var;
+  } else if (c < 128) {  // pad columns of the fused scale / shift
+    a.ws[ws_muinv() + 384 + c] = 0.f;
+    a.ws[ws_muinv() + 512 + c] = 0.f;
+  }
+}
+
 // BatchNorm statistics of z over the real rows: shifted sums (shift = row 0, a sample of the same
 // distribution: no cancellation) -> mu, inv = rsqrt(var + eps), var, and the fused scale / shift
 // mul = gamma inv, add = beta - mu mul; running statistics (Keras moving_average_update).
@@ -227,32 +248,21 @@ __global__ void __launch_bounds__(1024) tower_stats_kernel(TowerArgs a) {
     }
   }, sS, t1, t2);
   const int c = threadIdx.x;
-  if (gridDim.x > 1) {
+  if (gridDim.x > 1) {  // blocks of more than 1024 rows: partials, finished by tower_stats_merge_kernel
     float* part = a.ws + ws_stats();
     if (c < a.d) {
       part[(size_t)blockIdx.x * 2 * 128 + c] = t1;
       part[(size_t)blockIdx.x * 2 * 128 + 128 + c] = t2;
     }
-    if (!last_block_arrives(reinterpret_cast<unsigned*>(a.ws + ws_cnt()))) return;
-    if (c < a.d) merge_partials(part, gridDim.x, c, t1, t2);
+    return;
   }
-  if (c < a.d) {
-    const float rn = 1.f / (float)max(nv, 1);
-    const float m1 = t1 * rn;
-    const float mu = a.z[c] + m1, var = fmaxf(t2 * rn - m1 * m1, 0.f), inv = rsqrtf(var + a.eps);
-    float* mi = a.ws + ws_muinv();
-    const float mul = a.gamma[c] * inv;
-    mi[c] = mu;
-    mi[128 + c] = inv;
-    mi[256 + c] = var;
-    mi[384 + c] = mul;
-    mi[512 + c] = a.beta[c] - mu * mul;
-    a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mu;
-    a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * var;
-  } else if (c < 128) {  // pad columns of the fused scale / shift
-    a.ws[ws_muinv() + 384 + c] = 0.f;
-    a.ws[ws_muinv() + 512 + c] = 0.f;
-  }
+  stats_finalize(a, c, t1, t2, nv);
+}
+
+__global__ void __launch_bounds__(128) tower_stats_merge_kernel(TowerArgs a, int nparts) {
+  float t1 = 0.f, t2 = 0.f;
+  if ((int)threadIdx.x < a.d) merge_partials(a.ws + ws_stats(), nparts, threadIdx.x, t1, t2);
+  stats_finalize(a, threadIdx.x, t1, t2, valid_rows(a));
 }
 
 // E = relu(z * mul + add) for standalone forwards (the training step applies it on load).
@@ -319,6 +329,41 @@ __global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
   if (c < a.d) {
     a.ws[ws_bfin() + c] = t1;        // sum dy       (= dbeta)
     a.ws[ws_bfin() + 128 + c] = t2;  // sum dy*xhat  (= dgamma)
+  }
+}
+
+// Totals of per-chunk partials [n][2][128] emitted by an apply kernel (blocks of more than 64 item
+// chunks: train_scheme = original) -> sum dy / sum dy*xhat, in chunk order.  One workgroup:
+// 8 chunk groups x 128 columns, 8 loads in flight each, groups combined in order.
+__global__ void __launch_bounds__(1024) tower_merge_kernel(TowerArgs a, const float* __restrict__ part, int n) {
+  __shared__ float sRed[8 * 2 * 128];
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+  float a1 = 0.f, a2 = 0.f;
+  for (int s0 = g; s0 < n; s0 += 64) {
+    float u1[8], u2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int s = s0 + 8 * e;
+      u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
+      u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a1 += u1[e];
+      a2 += u2[e];
+    }
+  }
+  sRed[(g * 2 + 0) * 128 + c] = a1;
+  sRed[(g * 2 + 1) * 128 + c] = a2;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int gg = 0; gg < 8; ++gg) {
+      t1 += sRed[(gg * 2 + 0) * 128 + c];
+      t2 += sRed[(gg * 2 + 1) * 128 + c];
+    }
+    a.ws[ws_bfin() + c] = t1;
+    a.ws[ws_bfin() + 128 + c] = t2;
   }
 }
 
@@ -677,6 +722,7 @@ void carve_tower(nncf_tower* t, Carver& c) {
   t->ws = c.take<float>(ws_total((int)wide, (int)d, t->ks));
   if (t->cfg.conv_filters > 0) cnn_carve(t, c);
   t->cnt_t = c.take<uint8_t>((int64_t)t->cfg.word_count * cap);
+  t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
 }
@@ -727,6 +773,7 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     {
       ProfScope _ps("tower_stats_kernel", st);
       hipLaunchKernelGGL(tower_stats_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
+      if (stat_grid(m) > 1) hipLaunchKernelGGL(tower_stats_merge_kernel, dim3(1), dim3(128), 0, st, a, stat_grid(m));
     }
     if (E) {
       ProfScope _ps("tower_bn_kernel", st);
@@ -742,7 +789,8 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 // backward of the block of the last train-mode forward (which must have run with fill = 1)
 // nfused > 0: the BN backward's column sums arrive as nfused partials from the step's apply kernel
 // step_t: the optimiser step this backward belongs to (1-based)
-int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0) {
+int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0,
+                   bool sums_done = false) {
   TowerArgs a = t->last;
   a.dA = dA;
   a.gexp = t->gexp;
@@ -762,7 +810,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
   const int ntile = ((a.hd + 15) / 16) * ((a.d + 15) / 16);
-  if (!nfused) {
+  if (!nfused && !sums_done) {
     ProfScope _ps("tower_sums_kernel", st);
     hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
   }
@@ -819,12 +867,20 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   const int chunks = (b + kChunkSlots - 1) / kChunkSlots;
   const int nfused = (scheme != 0 && update && chunks <= kTowerWG) ? chunks : 0;
   if (nfused) sa.bn_part = t->ws + ws_bsum();
+  const bool big = scheme == 0 && update;   // thousands of rows: partials per item chunk, merged by one workgroup
+  const int cv = (n + kChunkSlots - 1) / kChunkSlots;
+  if (big) sa.bn_part = t->bpart;
   if (scheme == 0)
     rc = launch_original(sa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
   else
     rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
   if (rc || !update) return rc;
-  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0);
+  if (big) {
+    TowerArgs ma = t->last;
+    ProfScope _ps("tower_merge_kernel", st);
+    hipLaunchKernelGGL(tower_merge_kernel, dim3(1), dim3(1024), 0, st, ma, t->bpart, cv);
+  }
+  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
   if (rc) return rc;
   return finish_update(m, sa, st);
 }
