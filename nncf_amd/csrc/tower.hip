@@ -589,6 +589,11 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // The list is word-major: consecutive entries of one word accumulate in registers and reach
+      // the word's LDS stripe once per run (a read-modify-write per entry would chain every hit of
+      // a popular word through LDS latency).
+      int curj = -1;
+      float2 run = make_float2(0.f, 0.f);
       for (int e0 = 0; e0 < cnt; e0 += 16) {  // 16 rows of dh in flight
         int ent[16];
         float2 r[16];
@@ -602,14 +607,30 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           if (ent[u]) {  // uniform across the wave
+            const int j = ent[u] >> 24;
+            if (j != curj) {
+              if (curj >= 0) {
+                float2* p = accw + curj * 64 + lane;
+                float2 t = *p;
+                t.x += run.x;
+                t.y += run.y;
+                *p = t;
+              }
+              curj = j;
+              run = make_float2(0.f, 0.f);
+            }
             const float cf = cnn ? 1.f : (float)(ent[u] & 255);
-            float2* p = accw + (ent[u] >> 24) * 64 + lane;
-            float2 t = *p;
-            t.x = fmaf(cf, r[u].x, t.x);
-            t.y = fmaf(cf, r[u].y, t.y);
-            *p = t;
+            run.x = fmaf(cf, r[u].x, run.x);
+            run.y = fmaf(cf, r[u].y, run.y);
           }
         }
+      }
+      if (curj >= 0) {
+        float2* p = accw + curj * 64 + lane;
+        float2 t = *p;
+        t.x += run.x;
+        t.y += run.y;
+        *p = t;
       }
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
