@@ -487,3 +487,26 @@ def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
     names = ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta") if model == "cnn_embedding" else ("W", "Wd", "gamma", "beta")
     for name in names:
         np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=1e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_cnn_embedding_adam_matches_oracle(text_data, kind):
+    conf = _conf_cnn("skip-gram", "neg_shared", lr=0.01)
+    conf.optimizer = kind
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    head = md["model_neg_shared"]
+    tw = head.core.tower
+    orc, to = _oracle_cnn(conf, md, text_data)
+    b = conf.batch_size_p
+    rs = np.random.RandomState(9)
+    for step in range(4):
+        bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
+        # conv / dense biases sit in front of a BatchNorm: their gradients are rounding noise that Adam
+        # normalises to +-lr_t (see test_basic_embedding_adam_matches_oracle)
+        for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4,
+                                       err_msg="%s step %d" % (name, step))
