@@ -34,5 +34,6 @@ run_prof mf_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --model mf --steps 390 --war
 run_prof mf_neg_shared_pmc_write "--pmc WRITE_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_original_kernel_trace "--stats" --model mf --scheme original --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_group_neg_shared_kernel_trace "--stats" --model mf --scheme group_neg_shared --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
+bash tools/pmc_mfma.sh $TAG > /dev/null 2>&1
 python3 tools/make_traffic.py $OUT $TAG $OUT/${TAG}_traffic.json > /dev/null
 ls -la $OUT/${TAG}_*
