@@ -62,6 +62,21 @@ struct ProfScope {
   ~ProfScope() { gprof_stop(stop, stream); }
 };
 
+// Makes `device` current for the scope and restores the caller's device on every exit path.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t status;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    status = hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace nncf

@@ -169,16 +169,18 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   m->device = device;
   Carver dry;
   carve(m, dry);
-  int prev = 0;
-  hipGetDevice(&prev);
-  hipSetDevice(device);
-  if (hipMalloc(&m->arena, dry.off + 256) != hipSuccess) {
-    delete m;
-    hipSetDevice(prev);
-    return fail(NNCF_ERR_NOMEM, "device workspace allocation (%zu bytes) failed", dry.off);
+  {
+    DeviceGuard guard(device);
+    if (guard.status != hipSuccess || hipMalloc(&m->arena, dry.off + 256) != hipSuccess) {
+      delete m;
+      return fail(NNCF_ERR_NOMEM, "device workspace allocation (%zu bytes) failed", dry.off);
+    }
+    if (hipMemset(m->arena, 0, dry.off + 256) != hipSuccess) {
+      (void)hipFree(m->arena);
+      delete m;
+      return fail(NNCF_ERR_HIP, "clearing the device workspace failed");
+    }
   }
-  hipMemset(m->arena, 0, dry.off + 256);
-  hipSetDevice(prev);
   Carver real;
   real.base = static_cast<char*>(m->arena);
   carve(m, real);
@@ -226,15 +228,10 @@ int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float bet
   m->av = AdamTable{d_m_item, d_v_item, nullptr};
   if (mode == 2) {
     const size_t n = (size_t)(m->cfg.user_count + m->cfg.item_count);
-    int prev = 0;
-    hipGetDevice(&prev);
-    hipSetDevice(m->device);
-    if (!m->stamps && hipMalloc(&m->stamps, n * sizeof(int32_t)) != hipSuccess) {
-      hipSetDevice(prev);
+    DeviceGuard guard(m->device);
+    if (!m->stamps && hipMalloc(&m->stamps, n * sizeof(int32_t)) != hipSuccess)
       return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
-    }
-    hipMemset(m->stamps, 0, n * sizeof(int32_t));  // steps are numbered from 1
-    hipSetDevice(prev);
+    NNCF_HIP_CHECK(hipMemset(m->stamps, 0, n * sizeof(int32_t)));  // steps are numbered from 1
     m->au.stamp = m->stamps;
     m->av.stamp = m->stamps + m->cfg.user_count;
   }
@@ -256,17 +253,12 @@ int nncf_model_set_bias(nncf_model* m, float* d_user_bias, float* d_item_bias, i
   m->abc = AdamTable{d_m_item, d_v_item, nullptr};
   if (m->opt == 2 && (d_user_bias || d_item_bias)) {
     const size_t n = (size_t)(m->cfg.user_count + m->bias_items);
-    int prev = 0;
-    hipGetDevice(&prev);
-    hipSetDevice(m->device);
-    if (m->bias_stamps) hipFree(m->bias_stamps);
+    DeviceGuard guard(m->device);
+    if (m->bias_stamps) (void)hipFree(m->bias_stamps);
     m->bias_stamps = nullptr;
-    if (hipMalloc(&m->bias_stamps, n * sizeof(int32_t)) != hipSuccess) {
-      hipSetDevice(prev);
+    if (hipMalloc(&m->bias_stamps, n * sizeof(int32_t)) != hipSuccess)
       return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
-    }
-    hipMemset(m->bias_stamps, 0, n * sizeof(int32_t));
-    hipSetDevice(prev);
+    NNCF_HIP_CHECK(hipMemset(m->bias_stamps, 0, n * sizeof(int32_t)));
     m->abu.stamp = m->bias_stamps;
     m->abc.stamp = m->bias_stamps + m->cfg.user_count;
   }

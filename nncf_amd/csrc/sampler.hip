@@ -187,16 +187,14 @@ int nncf_sampler_create(const double* dist, int64_t n, double power, uint64_t se
     s->jt.p[j] = f;
     f = compose(f, f);
   }
-  int prev = 0;
-  hipGetDevice(&prev);
+  DeviceGuard guard(device);
   auto cleanup = [&](int code) {
-    if (s->d_bound) hipFree(s->d_bound);
-    if (s->d_guide) hipFree(s->d_guide);
+    if (s->d_bound) (void)hipFree(s->d_bound);
+    if (s->d_guide) (void)hipFree(s->d_guide);
     delete s;
-    hipSetDevice(prev);
     return code;
   };
-  if (hipSetDevice(device) != hipSuccess) return cleanup(fail(NNCF_ERR_HIP, "hipSetDevice(%d) failed", device));
+  if (guard.status != hipSuccess) return cleanup(fail(NNCF_ERR_HIP, "hipSetDevice(%d) failed", device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->sm_count = prop.multiProcessorCount;
   if (hipMalloc(&s->d_bound, sizeof(int32_t) * (size_t)n) != hipSuccess ||
@@ -205,7 +203,6 @@ int nncf_sampler_create(const double* dist, int64_t n, double power, uint64_t se
   if (hipMemcpy(s->d_bound, s->bound.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->d_guide, guide.data(), sizeof(int32_t) * guide.size(), hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(fail(NNCF_ERR_HIP, "upload of sampler tables failed"));
-  hipSetDevice(prev);
   *out = s;
   return NNCF_OK;
 }
@@ -279,9 +276,8 @@ int nncf_sampler_sample_batch(nncf_sampler* s, int64_t n, int32_t* out_host, voi
   NNCF_REQUIRE(n >= 0, "negative batch size %lld", (long long)n);
   if (n == 0) return NNCF_OK;
   NNCF_REQUIRE(out_host != nullptr, "out is NULL");
-  int prev = 0;
-  hipGetDevice(&prev);
-  NNCF_HIP_CHECK(hipSetDevice(s->device));
+  DeviceGuard guard(s->device);
+  NNCF_HIP_CHECK(guard.status);
   if (s->scratch_cap < n) {
     if (s->d_scratch) hipFree(s->d_scratch);
     s->d_scratch = nullptr;
@@ -296,7 +292,6 @@ int nncf_sampler_sample_batch(nncf_sampler* s, int64_t n, int32_t* out_host, voi
   NNCF_HIP_CHECK(hipMemcpyAsync(out_host, s->d_scratch, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost,
                                 as_stream(stream)));
   NNCF_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-  hipSetDevice(prev);
   return NNCF_OK;
 }
 

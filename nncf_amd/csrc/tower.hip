@@ -957,25 +957,22 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   }
   Carver dry;
   carve_tower(t, dry);
-  int prev = 0;
-  hipGetDevice(&prev);
-  hipSetDevice(device);
-  if (hipMalloc(&t->arena, dry.off + 256) != hipSuccess) {
+  DeviceGuard guard(device);
+  if (guard.status != hipSuccess || hipMalloc(&t->arena, dry.off + 256) != hipSuccess) {
     delete t;
-    hipSetDevice(prev);
     return fail(NNCF_ERR_NOMEM, "device workspace allocation (%zu bytes) failed", dry.off);
   }
-  hipMemset(t->arena, 0, dry.off + 256);
-  hipSetDevice(prev);
+  if (hipMemset(t->arena, 0, dry.off + 256) != hipSuccess) {
+    (void)hipFree(t->arena);
+    delete t;
+    return fail(NNCF_ERR_HIP, "clearing the device workspace failed");
+  }
   Carver real;
   real.base = static_cast<char*>(t->arena);
   carve_tower(t, real);
   if (cfg->conv_filters > 0) {
-    hipGetDevice(&prev);
-    hipSetDevice(device);
-    const int rc = cnn_sync_weights(t, nullptr);
-    hipDeviceSynchronize();
-    hipSetDevice(prev);
+    int rc = cnn_sync_weights(t, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(NNCF_ERR_HIP, "conv weight upload failed");
     if (rc) {
       nncf_tower_destroy(t);
       return rc;
@@ -1038,15 +1035,10 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
     t->cnn.vC = d_v_dense + off;
   }
   if (mode == 2) {
-    int prev = 0;
-    hipGetDevice(&prev);
-    hipSetDevice(t->device);
-    if (!t->stamps && hipMalloc(&t->stamps, sizeof(int32_t) * (size_t)t->cfg.word_count) != hipSuccess) {
-      hipSetDevice(prev);
+    DeviceGuard guard(t->device);
+    if (!t->stamps && hipMalloc(&t->stamps, sizeof(int32_t) * (size_t)t->cfg.word_count) != hipSuccess)
       return fail(NNCF_ERR_NOMEM, "stamp allocation failed");
-    }
-    hipMemset(t->stamps, 0, sizeof(int32_t) * (size_t)t->cfg.word_count);
-    hipSetDevice(prev);
+    NNCF_HIP_CHECK(hipMemset(t->stamps, 0, sizeof(int32_t) * (size_t)t->cfg.word_count));
     t->aw.stamp = t->stamps;
   }
   return NNCF_OK;
