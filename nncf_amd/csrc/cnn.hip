@@ -72,17 +72,18 @@ __device__ __forceinline__ void stage_tokens(const TowerArgs& a, int item, int* 
 __device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, const float* sSc, float* sX, int XP,
                                            int p_lo, int rows) {
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, wd4 = a.wd >> 2, xp4 = XP >> 2;
-  for (int r0 = grp; r0 < rows; r0 += 64) {  // 4 rows of this group in flight
+  const int ng = blockDim.x >> 4;
+  for (int r0 = grp; r0 < rows; r0 += 4 * ng) {  // 4 rows of this group in flight
     Row v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = r0 + 16 * e, p = p_lo + r;
+      const int r = r0 + ng * e, p = p_lo + r;
       const bool ok = r < rows && p >= 0 && p < a.L && sSc[p >= 0 && p < a.L ? p : 0] != 0.f;
       v[e] = ok ? row_scale(row_load(a.W, sTok[p], a.wd, wd4, q), sSc[p]) : row_zero();
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = r0 + 16 * e;
+      const int r = r0 + ng * e;
       if (r < rows) {
         float4* dst = reinterpret_cast<float4*>(sX + (int64_t)r * XP);
         if (q < xp4) dst[q] = v[e].a;  // chunks past wd are the zeros row_load produced
@@ -97,13 +98,17 @@ __device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, 
 // Two workgroups per item (kFwdSplit): each computes half of the positions, so that a group-shared
 // batch of ~100 unique items still fills the 256 CUs.
 constexpr int kFwdSplit = 2;
+// Eight waves per workgroup, two per SIMD: a workgroup is alone on its CU at these batch sizes, and
+// with one wave per SIMD nothing covered the operand loads and the epilogue stores (41 % of the
+// cycles waiting, profiles/r01_cnn_embedding_group_neg_shared_pmc_mfma.txt).
+constexpr int kConvThreads = 512, kConvWaves = kConvThreads / 64;
 constexpr int kFwdMt = 8;  // row tiles of 16 positions per workgroup: L <= 2 * 8 * 16 = 256
 
 // NMT / NKT: row tiles per workgroup and 16-column K groups of the word dimension as compile-time
 // loop bounds.  MASK = false: the shape matches exactly (the LDS tile is zero-padded past L and
 // past wd, so no per-fragment guards remain between the MFMAs); MASK = true: any smaller shape.
 template <int NMT, int NKT, bool MASK>
-__global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
+__global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
   __shared__ float sSc[256];
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
   // backward preparation: cnt_t[w][s] = 1 + ordinal of word w among the item's distinct words
   if (a.fill && half == 0) {
     const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
-    for (int e = e0 + tid; e < e1; e += 256) {
+    for (int e = e0 + tid; e < e1; e += kConvThreads) {
       const int wv = a.item_word[e];
       if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = (uint8_t)(e - e0 + 1);
     }
@@ -133,7 +138,7 @@ __global__ void __launch_bounds__(256) cnn_conv_fwd_kernel(TowerArgs a) {
   if (!(a.cnn.dbg & 2)) stage_rows(a, sTok, sSc, sX, XP, p_base - pad, rows);
   __syncthreads();
   const int KW = fl * a.wd;
-  for (int nt = wave; nt < nNt; nt += 4) {
+  for (int nt = wave; nt < nNt; nt += kConvWaves) {
     const int col = nt * 16 + x;
     f32x4 acc[NMT];
 #pragma unroll
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
 // One workgroup per (slot, block of kConvLB positions).  NFT: 16-column groups of the filter
 // dimension as a compile-time bound of (a)'s K loop (MASK = false: exactly ceil(F/16) == NFT).
 template <int NFT, bool MASK>
-__global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
+__global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
   __shared__ float sSc[256];
@@ -476,16 +481,17 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
     Row rmul = row_load(a.cnn.st1 + 384, 0, 128, 32, q), radd = row_load(a.cnn.st1 + 512, 0, 128, 32, q);
     Row rs1 = row_load(a.cnn.st1 + 640, 0, 128, 32, q), rs2 = row_load(a.cnn.st1 + 768, 0, 128, 32, q);
     const int fp4 = FP >> 2;
-    for (int r0 = grp; r0 < rows; r0 += 64) {
+    constexpr int ng = kConvThreads / 16;
+    for (int r0 = grp; r0 < rows; r0 += 4 * ng) {
       Row y[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int r = r0 + 16 * e, p = p0 - pad + r;
+        const int r = r0 + ng * e, p = p0 - pad + r;
         y[e] = (r < rows && p >= 0 && p < L) ? row_load(a.cnn.Y, (int64_t)s * L + p, F, f4, q) : row_zero();
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int r = r0 + 16 * e, p = p0 - pad + r;
+        const int r = r0 + ng * e, p = p0 - pad + r;
         if (r < rows) {
           Row o = row_zero();
           if (p >= 0 && p < L) {
@@ -510,7 +516,7 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
   // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ------------------------
   {
     const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-    for (int kt = wave; kt < ((a.cnn.dbg & 4) ? 0 : nKw); kt += 4) {
+    for (int kt = wave; kt < ((a.cnn.dbg & 4) ? 0 : nKw); kt += kConvWaves) {
       const int kcol = kt * 16 + x;
       f32x4 acc[kConvLB / 16];
 #pragma unroll
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
     // two A and two B dwords from LDS feed four MFMAs on independent accumulators
     const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1;
     const int nblock = fl * nKp * nFp;
-    for (int bb = wave; bb < ((a.cnn.dbg & 8) ? 0 : nblock); bb += 4) {
+    for (int bb = wave; bb < ((a.cnn.dbg & 8) ? 0 : nblock); bb += kConvWaves) {
       const int tap = bb / (nKp * nFp), kp = (bb / nFp) % nKp, fp = bb % nFp;
       const int kt0 = 2 * kp, ft0 = 2 * fp;
       const bool k1 = kt0 + 1 < nKw, f1 = ft0 + 1 < nFt;
@@ -583,9 +589,9 @@ __global__ void __launch_bounds__(256) cnn_conv_bwd_kernel(TowerArgs a, int nblk
         const float a0 = pa0[(int64_t)4 * st * XP], a1 = pa1[(int64_t)4 * st * XP];
         const float b0 = pb0[(int64_t)4 * st * FP], b1 = pb1[(int64_t)4 * st * FP];
         acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc11, 0, 0, 0);
+        if (f1) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc01, 0, 0, 0);  // wave-uniform: the odd
+        if (k1) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc10, 0, 0, 0);  // last tile row / column
+        if (k1 && f1) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc11, 0, 0, 0);
       }
       auto put = [&](const f32x4& acc, int kt, int ft) {
 #pragma unroll
@@ -792,13 +798,13 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)a.m * kFwdSplit);
     if (nMtH == 7 && nKt == 7) {  // L in (192, 224], word_dim in (96, 112]: the CiteULike shape
       if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 7, false>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 7, false>), grid, dim3(256), lds, st, a);
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 7, false>), grid, dim3(kConvThreads), lds, st, a);
     } else if (nMtH <= 4 && nKt <= 4) {
       if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<4, 4, true>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 4, true>), grid, dim3(256), lds, st, a);
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 4, true>), grid, dim3(kConvThreads), lds, st, a);
     } else {
       if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<kFwdMt, 8, true>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<kFwdMt, 8, true>), grid, dim3(256), lds, st, a);
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<kFwdMt, 8, true>), grid, dim3(kConvThreads), lds, st, a);
     }
   }
   if (a.train) {
@@ -834,9 +840,9 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);
     const dim3 grid((unsigned)(a.m * nblk));
-    if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(256), lds, st, a, nblk);
-    else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(256), lds, st, a, nblk);
-    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(256), lds, st, a, nblk);
+    if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(kConvThreads), lds, st, a, nblk);
+    else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
+    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
   }
   {
     ProfScope _ps("cnn_presum_kernel", st);
