@@ -10,9 +10,11 @@
 //   cnn_conv_fwd    gather (dropped rows never loaded) -> LDS; Y = conv + b -> HBM; per-item sums
 //                   of (y-b), (y-b)^2 per filter; transposes the item's bag of words for the backward
 //   cnn_stats       BatchNorm statistics over n_u*L positions -> mu, inv, mul, add; running stats
-//   cnn_pool_dense  a = relu(y*mul+add) * dropout mask, mean over L -> h; z = h.Wd + bd
+//   cnn_pool_dense  a = relu(y*mul+add) * dropout mask, mean over L -> h; z = h.Wd + bd; per-item sums
+//                   of mask and mask*xhat for the backward
 //   (tower tail + step kernels + tower_bwd: dL/dh)
-//   cnn_bwd_sums    per-item sums of da and da*xhat (da = dh/L * mask * [a>0]) -> cnn_merge
+//   cnn_merge       sums of da and da*xhat (da = dh/L * mask * [a>0]) over (items, positions) from the
+//                   per-item mask sums the pooling pass left behind, weighted with dh
 //   cnn_conv_bwd    dY = BN backward of da -> LDS; dX = sum_tap dY(shifted).Wk[tap]^T (MFMA) -> HBM;
 //                   partial dWk[tap] = X(shifted)^T.dY (MFMA) per workgroup
 //   cnn_presum      per item: dX rows summed per distinct word (static sorted-position index)
@@ -20,6 +22,8 @@
 //                   conv bias, BN1 gamma / beta
 //   tower_word_kernel (tower.hip) then reduces the per-(item, word) rows per word as for MeanPool.
 // Everything has a fixed summation order (no float atomics); conv dropout is a counter-based hash.
+#include <type_traits>
+
 #include "tower.h"
 
 namespace nncf {
@@ -112,7 +116,8 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
   __shared__ float sSc[256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops and their guards stay on the SALU
   const int s = blockIdx.x / kFwdSplit, half = blockIdx.x % kFwdSplit;
   if (s >= valid_rows(a)) return;
   const int item = a.ids[s];
@@ -273,15 +278,21 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
 
 // a = relu(y*mul+add) * dropout, mean over the L positions -> h[s]; z[s] = h[s].Wd + bd
 // (train) or E[s] = relu(BN_running(z[s])) (inference).
+// Backward preparation: da[p][c] = dh[s][c]/L * m[p][c] with m = dropout scale * [y*mul+add > 0] known
+// here already, so the BN1 backward sums over positions factor as
+//   sum_p da = dh[s][c]/L * M1[s][c],  sum_p da*xhat = dh[s][c]/L * M2[s][c],
+// M1 = sum_p m, M2 = sum_p m*xhat: both are emitted per item by this pass over Y, and the backward
+// needs no pass of its own for them (cnn_merge_kernel weighs them with dh).
 __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
-  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ __attribute__((aligned(16))) float sR[3][16 * kTP];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
   __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
-  __shared__ __attribute__((aligned(16))) float sMul[128], sAdd[128];
+  __shared__ __attribute__((aligned(16))) float sMul[128], sAdd[128], sMu[128], sInv[128];
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
   const int F = a.cnn.F, f4 = F >> 2, d4 = a.d >> 2, L = a.L;
   const int s = blockIdx.x;
   if (s >= valid_rows(a)) return;
+  const bool prep = a.train && a.fill;
   const int c4 = tid & 31, kp = tid >> 5, kper = (F + 7) >> 3;
   float4 w[16];
 #pragma unroll
@@ -302,9 +313,11 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
     }
     sMul[tid] = mul;
     sAdd[tid] = add;
+    sMu[tid] = prep ? a.cnn.st1[tid] : 0.f;
+    sInv[tid] = prep ? a.cnn.st1[128 + tid] : 0.f;
   }
   __syncthreads();
-  Row acc = row_zero();
+  Row acc = row_zero(), m1 = row_zero(), m2 = row_zero();
   const bool drop = a.train && a.cnn.keep < 1.f;
   // this lane's eight columns are the same for every row: scale / shift live in registers
   Row rmul, radd;
@@ -312,6 +325,11 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   rmul.b = reinterpret_cast<const float4*>(sMul)[q + 16];
   radd.a = reinterpret_cast<const float4*>(sAdd)[q];
   radd.b = reinterpret_cast<const float4*>(sAdd)[q + 16];
+  Row rmu, rinv;
+  rmu.a = reinterpret_cast<const float4*>(sMu)[q];
+  rmu.b = reinterpret_cast<const float4*>(sMu)[q + 16];
+  rinv.a = reinterpret_cast<const float4*>(sInv)[q];
+  rinv.b = reinterpret_cast<const float4*>(sInv)[q + 16];
   for (int p0 = grp; p0 < L; p0 += 112) {
     Row y[7];
 #pragma unroll
@@ -323,21 +341,43 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int c = col_of(q, k);
-          float v = fmaxf(fmaf(relem(y[e], k), relem(rmul, k), relem(radd, k)), 0.f);
-          if (drop && v != 0.f) v *= conv_keep(a, (int64_t)s * L + p, c);
-          relem(acc, k) += v;
+          const float yv = relem(y[e], k);
+          const float pre = fmaf(yv, relem(rmul, k), relem(radd, k));
+          float m = 0.f;
+          if (pre > 0.f) m = drop ? conv_keep(a, (int64_t)s * L + p, c) : 1.f;
+          relem(acc, k) = fmaf(pre, m, relem(acc, k));
+          if (prep) {
+            relem(m1, k) += m;
+            relem(m2, k) = fmaf(m, (yv - relem(rmu, k)) * relem(rinv, k), relem(m2, k));
+          }
         }
       }
     }
   }
-  reinterpret_cast<float4*>(sR + grp * kTP)[q] = acc.a;
-  reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = acc.b;
+  reinterpret_cast<float4*>(sR[0] + grp * kTP)[q] = acc.a;
+  reinterpret_cast<float4*>(sR[0] + grp * kTP)[q + 16] = acc.b;
+  if (prep) {
+    reinterpret_cast<float4*>(sR[1] + grp * kTP)[q] = m1.a;
+    reinterpret_cast<float4*>(sR[1] + grp * kTP)[q + 16] = m1.b;
+    reinterpret_cast<float4*>(sR[2] + grp * kTP)[q] = m2.a;
+    reinterpret_cast<float4*>(sR[2] + grp * kTP)[q + 16] = m2.b;
+  }
   __syncthreads();
+  if (prep && (grp == 1 || grp == 2)) {  // M1 / M2 of this item, groups in order
+    Row sum = row_zero();
+    for (int g = 0; g < 16; ++g) {
+      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR[grp] + g * kTP)[q]);
+      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[grp] + g * kTP)[q + 16]);
+    }
+    float4* out = reinterpret_cast<float4*>(a.cnn.bpart + (int64_t)s * 256 + (grp - 1) * 128);
+    out[q] = sum.a;  // chunks past F hold zeros (mul = 0 there: pre = add = 0, never > 0)
+    out[q + 16] = sum.b;
+  }
   if (grp == 0) {
     Row sum = row_zero();
     for (int g = 0; g < 16; ++g) {
-      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
-      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q]);
+      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q + 16]);
     }
     sum = row_scale(sum, 1.f / (float)L);
     if (a.train) row_store(a.h, s, F, f4, q, sum);
@@ -380,63 +420,40 @@ __device__ __forceinline__ float conv_da(const TowerArgs& a, float dhc, float pr
   return dhc * conv_keep(a, pos_index, c);
 }
 
-__global__ void __launch_bounds__(256) cnn_bwd_sums_kernel(TowerArgs a) {
-  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
-  __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128];
-  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, F = a.cnn.F, f4 = F >> 2, L = a.L;
-  const int s = blockIdx.x;
-  if (s >= valid_rows(a)) return;
-  if (tid < 128) {
-    sMu[tid] = a.cnn.st1[tid];
-    sInv[tid] = a.cnn.st1[128 + tid];
-    sMul[tid] = a.cnn.st1[384 + tid];
-    sAdd[tid] = a.cnn.st1[512 + tid];
-  }
-  const Row dhr = row_scale(row_load(a.dh, s, F, f4, q), 1.f / (float)L);
-  __syncthreads();
-  Row rmu = row_load(a.cnn.st1, 0, 128, 32, q), rinv = row_load(a.cnn.st1 + 128, 0, 128, 32, q);
-  Row rmul = row_load(a.cnn.st1 + 384, 0, 128, 32, q), radd = row_load(a.cnn.st1 + 512, 0, 128, 32, q);
-  Row s1 = row_zero(), s2 = row_zero();
-  for (int p0 = grp; p0 < L; p0 += 112) {
-    Row y[7];
+// BN1 backward sums over (items, positions) per filter from the per-item factors of the forward:
+// sum da = sum_s dh[s][c]/L * M1[s][c], sum da*xhat = sum_s dh[s][c]/L * M2[s][c], slots in order
+// (1024 threads: 8 slot groups x 128 columns, 8 slots of a group in flight).
+__global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
+  __shared__ float sRed[8 * 2 * 128];
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7, n = valid_rows(a), F = a.cnn.F;
+  const float rL = 1.f / (float)a.L;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < F) {
+    for (int s0 = g; s0 < n; s0 += 8 * 8) {
+      float u1[8], u2[8], dv[8];
 #pragma unroll
-    for (int e = 0; e < 7; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+      for (int e = 0; e < 8; ++e) {
+        const int s = s0 + 8 * e;
+        u1[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + c] : 0.f;
+        u2[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + 128 + c] : 0.f;
+        dv[e] = s < n ? a.dh[(int64_t)s * F + c] * rL : 0.f;
+      }
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
-      const int p = p0 + 16 * e;
-      if (p < L) {
-        Row dd = dhr;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int c = col_of(q, k);
-          const float yv = relem(y[e], k);
-          const float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
-          relem(s1, k) += da;
-          relem(s2, k) += da * (yv - relem(rmu, k)) * relem(rinv, k);
-        }
+      for (int e = 0; e < 8; ++e) {
+        a1 = fmaf(dv[e], u1[e], a1);
+        a2 = fmaf(dv[e], u2[e], a2);
       }
     }
   }
-  float* out = a.cnn.bpart + (int64_t)s * 256;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();
-    reinterpret_cast<float4*>(sR + grp * kTP)[q] = half ? s2.a : s1.a;
-    reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = half ? s2.b : s1.b;
-    __syncthreads();
-    if (tid < 128) {
-      float t = 0.f;
-      for (int g = 0; g < 16; ++g) t += sR[g * kTP + tid];
-      out[half * 128 + tid] = t;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
-  __shared__ float sRed[8 * 2 * 128];
-  float t1, t2;
-  merge_slot_partials(a.cnn.bpart, valid_rows(a), sRed, t1, t2);
+  sRed[(g * 2 + 0) * 128 + c] = a1;
+  sRed[(g * 2 + 1) * 128 + c] = a2;
+  __syncthreads();
   if (threadIdx.x < 128) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int gg = 0; gg < 8; ++gg) {
+      t1 += sRed[(gg * 2 + 0) * 128 + c];
+      t2 += sRed[(gg * 2 + 1) * 128 + c];
+    }
     a.cnn.st1[640 + threadIdx.x] = t1;  // sum da        (= dbeta1)
     a.cnn.st1[768 + threadIdx.x] = t2;  // sum da*xhat   (= dgamma1)
   }
@@ -450,7 +467,8 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
   __shared__ int sTok[256];
   __shared__ float sSc[256];
   __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128], sS1[128], sS2[128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, kq = lane >> 4;
+  __shared__ int sNext;
+  const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
   const int grp = tid >> 4, q = tid & 15;
   const int s = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const int nv = valid_rows(a);
@@ -463,6 +481,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
   float* sX = smem;                        // [rows][XP]  gathered (scaled) word rows
   float* sD = smem + (int64_t)rows * XP;   // [rows][FP]  dY
   stage_tokens(a, item, sTok, sSc);
+  if (tid == 0) sNext = 0;
   if (tid < 128) {
     sMu[tid] = a.cnn.st1[tid];
     sInv[tid] = a.cnn.st1[128 + tid];
@@ -513,10 +532,34 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
   }
   __syncthreads();
   const int nMb = kConvLB / 16;
-  // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ------------------------
-  {
-    const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-    for (int kt = wave; kt < ((a.cnn.dbg & 4) ? 0 : nKw); kt += kConvWaves) {
+  // The two MFMA parts only read the LDS tiles, so their pieces -- (a) one 16-column strip of dX,
+  // (b) one 2 x 2 tile block of one tap's dWk -- go through ONE queue that the eight waves drain as
+  // they become free (LDS counter; which wave computes a piece does not change its value).  The
+  // long (a) strips are handed out first, then (b) blocks from full to ragged: the four SIMDs finish
+  // together, and waves drift out of phase, so one wave's operand loads and stores sit under the
+  // other's MFMAs.  Static per-wave loops left one SIMD half idle and the waves in lock step.
+  const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
+  const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1, nKf = nKw >> 1, nFf = nFt >> 1;
+  const int nblock = fl * nKp * nFp;
+  const int nA = (a.cnn.dbg & 4) ? 0 : nKw, nB = (a.cnn.dbg & 8) ? 0 : nblock;
+  float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
+  if (tid >= kConvThreads - 128) {  // column sums of dY over the block's own positions (conv bias
+    const int c = tid - (kConvThreads - 128);  // gradient): the last two waves, before they join the queue
+    float t = 0.f;
+    if (c < F) {
+#pragma unroll 8
+      for (int r = pad; r < pad + kConvLB; ++r) t += sD[(int64_t)r * FP + c];
+    }
+    a.cnn.gbpart[(int64_t)blockIdx.x * 128 + c] = t;
+  }
+  for (;;) {
+    int piece = 0;
+    if (lane == 0) piece = atomicAdd(&sNext, 1);
+    piece = __builtin_amdgcn_readfirstlane(piece);
+    if (piece >= nA + nB) break;
+    if (piece < nA) {
+      // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ----------------------
+      const int kt = piece;
       const int kcol = kt * 16 + x;
       f32x4 acc[kConvLB / 16];
 #pragma unroll
@@ -565,34 +608,75 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
           if (p < L && kcol < a.wd) a.cnn.dX[((int64_t)s * L + p) * a.wd + kcol] = acc[mt][r] * sSc[p];
         }
       }
-    }
-  }
-  // ---- (b) partial dWk[tap][k][f] = sum_{p in block} X[p + tap - pad][k] dY[p][f] --------------
-  {
-    const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-    float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
-    // 2 x 2 register blocking: a wave computes tiles (kt, kt+1) x (ft, ft+1) of one tap together --
-    // two A and two B dwords from LDS feed four MFMAs on independent accumulators
-    const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1;
-    const int nblock = fl * nKp * nFp;
-    for (int bb = wave; bb < ((a.cnn.dbg & 8) ? 0 : nblock); bb += kConvWaves) {
-      const int tap = bb / (nKp * nFp), kp = (bb / nFp) % nKp, fp = bb % nFp;
+    } else {
+      // ---- (b) partial dWk[tap][k][f] = sum_{p in block} X[p + tap - pad][k] dY[p][f] ------------
+      // 2 x 2 register blocking: a wave computes tiles (kt, kt+1) x (ft, ft+1) of one tap together --
+      // two A and two B dwords from LDS feed four MFMAs on independent accumulators.  Order: all
+      // taps of the full blocks, then the blocks ragged in F, in K, in both.
+      const int j = piece - nA, tap = j % fl;
+      int r = j / fl, kp, fp;
+      if (r < nKf * nFf) {
+        kp = r / nFf;
+        fp = r % nFf;
+      } else {
+        r -= nKf * nFf;
+        const int nRf = (nFp > nFf) ? nKf : 0;  // blocks whose second F tile is missing
+        if (r < nRf) {
+          kp = r;
+          fp = nFf;
+        } else if (r - nRf < ((nKp > nKf) ? nFf : 0)) {
+          kp = nKf;
+          fp = r - nRf;
+        } else {
+          kp = nKf;
+          fp = nFf;
+        }
+      }
       const int kt0 = 2 * kp, ft0 = 2 * fp;
       const bool k1 = kt0 + 1 < nKw, f1 = ft0 + 1 < nFt;
       f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
       const float* pa0 = sX + (int64_t)(kq + tap) * XP + kt0 * 16 + x;   // position p0 + 4st + kq, shifted by the tap
-      const float* pa1 = pa0 + (k1 ? 16 : 0);
       const float* pb0 = sD + (int64_t)(kq + pad) * FP + ft0 * 16 + x;
-      const float* pb1 = pb0 + (f1 ? 16 : 0);
-#pragma unroll 7
-      for (int st = 0; st < kConvLB / 4; ++st) {
-        const float a0 = pa0[(int64_t)4 * st * XP], a1 = pa1[(int64_t)4 * st * XP];
-        const float b0 = pb0[(int64_t)4 * st * FP], b1 = pb1[(int64_t)4 * st * FP];
-        acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc00, 0, 0, 0);
-        if (f1) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc01, 0, 0, 0);  // wave-uniform: the odd
-        if (k1) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc10, 0, 0, 0);  // last tile row / column
-        if (k1 && f1) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc11, 0, 0, 0);
-      }
+      // K loop over the block's positions in groups of four k-steps, the next group's operands
+      // loaded before the current group's MFMAs (straight-line code per (k1, f1) case: a guard per
+      // MFMA would end the basic block and with it the overlap)
+      auto kloop = [&](auto K1, auto F1) {
+        constexpr bool kk = decltype(K1)::value, ff = decltype(F1)::value;
+        constexpr int NS = kConvLB / 4, G = 2, NG = NS / G;
+        static_assert(NS % G == 0, "kConvLB must be a multiple of 8");
+        float A0[2][G], A1[2][G], B0[2][G], B1[2][G];
+        auto load = [&](int g, int buf) {
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const int st = g * G + u;
+            A0[buf][u] = pa0[(int64_t)4 * st * XP];
+            B0[buf][u] = pb0[(int64_t)4 * st * FP];
+            if (kk) A1[buf][u] = pa0[(int64_t)4 * st * XP + 16];
+            if (ff) B1[buf][u] = pb0[(int64_t)4 * st * FP + 16];
+          }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const int b = g & 1;
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[b][u], B0[b][u], acc00, 0, 0, 0);
+            if (ff) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[b][u], B1[b][u], acc01, 0, 0, 0);
+            if (kk) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[b][u], B0[b][u], acc10, 0, 0, 0);
+            if (kk && ff) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[b][u], B1[b][u], acc11, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      using T = std::true_type;
+      using N = std::false_type;
+      if (k1 && f1) kloop(T{}, T{});
+      else if (k1) kloop(T{}, N{});
+      else if (f1) kloop(N{}, T{});
+      else kloop(N{}, N{});
       auto put = [&](const f32x4& acc, int kt, int ft) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWk[tap][kt*16 + i][ft*16 + x]
@@ -604,12 +688,6 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       if (f1) put(acc01, kt0, ft0 + 1);
       if (k1) put(acc10, kt0 + 1, ft0);
       if (k1 && f1) put(acc11, kt0 + 1, ft0 + 1);
-    }
-    if (tid < 128) {  // column sums of dY over the block's own positions (conv bias gradient)
-      float t = 0.f;
-      if (tid < F)
-        for (int r = pad; r < pad + kConvLB; ++r) t += sD[(int64_t)r * FP + tid];
-      a.cnn.gbpart[(int64_t)blockIdx.x * 128 + tid] = t;
     }
   }
 }
@@ -829,10 +907,6 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
                        : nFt <= 4 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<4, true>)
                                   : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<8, true>);
   if (int rc = set_lds(bwd_fn, lds)) return rc;
-  {
-    ProfScope _ps("cnn_bwd_sums_kernel", st);
-    hipLaunchKernelGGL(cnn_bwd_sums_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
-  }
   {
     ProfScope _ps("cnn_merge_kernel", st);
     hipLaunchKernelGGL(cnn_merge_kernel, dim3(1), dim3(1024), 0, st, a);
