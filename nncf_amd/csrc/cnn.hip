@@ -139,30 +139,35 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
       if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = (uint8_t)(e - e0 + 1);
     }
   }
+  const int KW = fl * a.wd;
+  // B fragments of up to three taps at once (all their loads in flight before the first MFMA):
+  // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
+  // 16t+4kq serves k-step (t, e) on both operands)
+  float4 bf[3][NKT];
+  auto load_b = [&](int nt, int tap0) {
+    const int col = nt * 16 + x;
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const int tap = tap0 + tt;
+      const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        const int c0 = 16 * t + 4 * kq;
+        bf[tt][t] = (tap < fl && t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
+      }
+    }
+  };
+  // the wave's first strip is known now: its filter fragments travel while the rows are staged
+  if (wave < nNt) load_b(wave, 0);
   __syncthreads();
   if (!(a.cnn.dbg & 2)) stage_rows(a, sTok, sSc, sX, XP, p_base - pad, rows);
   __syncthreads();
-  const int KW = fl * a.wd;
   for (int nt = wave; nt < nNt; nt += kConvWaves) {
-    const int col = nt * 16 + x;
     f32x4 acc[NMT];
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int tap0 = 0; tap0 < ((a.cnn.dbg & 1) ? 0 : fl); tap0 += 3) {
-      // B fragments of up to three taps at once (all their loads in flight before the first MFMA):
-      // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
-      // 16t+4kq serves k-step (t, e) on both operands)
-      float4 bf[3][NKT];
-#pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        const int tap = tap0 + tt;
-        const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-          const int c0 = 16 * t + 4 * kq;
-          bf[tt][t] = (tap < fl && t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
-        }
-      }
+      if (nt != wave || tap0 != 0) load_b(nt, tap0);
 #pragma unroll
       for (int tt = 0; tt < 3; ++tt) {
         const int tap = tap0 + tt;
@@ -178,43 +183,50 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
               for (int mt = 0; mt < NMT; ++mt)
                 af[mt] = (!MASK || mt < nMt) ? *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * XP + 16 * t) : zero4();
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].x, bf[tt][t].x, acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].x, af[mt].x, acc[mt], 0, 0, 0);
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].y, bf[tt][t].y, acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].y, af[mt].y, acc[mt], 0, 0, 0);
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].z, bf[tt][t].z, acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].z, af[mt].z, acc[mt], 0, 0, 0);
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].w, bf[tt][t].w, acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
             }
           }
         }
       }
     }
-    // epilogue: D[i = 4kq + r][j = x] -> Y[s][p = p_base + 16mt + i][col]; statistics of (y - b)
-    const float bias = col < F ? a.cnn.bc[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    // epilogue.  The filter fragment is the MFMA's A operand, so D[i = 4kq + r][j = x] is filter
+    // 16nt + 4kq + r at position p_base + 16mt + x: a lane owns four consecutive filters of one
+    // position -- one 16-byte store per row tile.  Statistics of (y - b) per filter: over the row
+    // tiles in the lane, then over the 16 position lanes.
+    const int f0 = nt * 16 + 4 * kq;
+    const float4 bias = f0 < F ? *reinterpret_cast<const float4*>(a.cnn.bc + f0) : zero4();
+    float4 s1 = zero4(), s2 = zero4();
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
-      if (mt < nMt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = p_base + 16 * mt + 4 * kq + r;
-          if (p < L && col < F) {
-            const float v = acc[mt][r];
-            a.cnn.Y[((int64_t)s * L + p) * F + col] = v + bias;
-            s1 += v;
-            s2 += v * v;
-          }
-        }
+      const int p = p_base + 16 * mt + x;
+      if (mt < nMt && p < L && f0 < F) {
+        const float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+        *reinterpret_cast<float4*>(a.cnn.Y + ((int64_t)s * L + p) * F + f0) = add4(v, bias);
+        s1 = add4(s1, v);
+        s2 = fma4v(v, v, s2);
       }
     }
-    s1 += __shfl_xor(s1, 16);
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 16);
-    s2 += __shfl_xor(s2, 32);
-    if (kq == 0 && a.train) {
-      a.cnn.part1[(int64_t)blockIdx.x * 256 + col] = s1;
-      a.cnn.part1[(int64_t)blockIdx.x * 256 + 128 + col] = s2;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      s1.x += __shfl_xor(s1.x, m);
+      s1.y += __shfl_xor(s1.y, m);
+      s1.z += __shfl_xor(s1.z, m);
+      s1.w += __shfl_xor(s1.w, m);
+      s2.x += __shfl_xor(s2.x, m);
+      s2.y += __shfl_xor(s2.y, m);
+      s2.z += __shfl_xor(s2.z, m);
+      s2.w += __shfl_xor(s2.w, m);
+    }
+    if (x == 0 && a.train) {  // columns past F: zeros (their filter fragments are zero)
+      float* part = a.cnn.part1 + (int64_t)blockIdx.x * 256;
+      *reinterpret_cast<float4*>(part + f0) = s1;
+      *reinterpret_cast<float4*>(part + 128 + f0) = s2;
     }
   }
 }
@@ -588,24 +600,28 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 #pragma unroll
                 for (int mt = 0; mt < nMb; ++mt) af[mt] = *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * FP + 16 * t);
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].x, bf[tt][t].x, acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].x, af[mt].x, acc[mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].y, bf[tt][t].y, acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].y, af[mt].y, acc[mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].z, bf[tt][t].z, acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].z, af[mt].z, acc[mt], 0, 0, 0);
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt].w, bf[tt][t].w, acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
               }
             }
           }
         }
       }
+      // the filter fragment is the A operand: D[i = 4kq + r][j = x] = dX[p0 + 16mt + x][16kt + 4kq + r],
+      // four consecutive columns of one position per lane -- one 16-byte store per row tile
+      const int k0 = kt * 16 + 4 * kq;
 #pragma unroll
       for (int mt = 0; mt < nMb; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = p0 + 16 * mt + 4 * kq + r;
-          if (p < L && kcol < a.wd) a.cnn.dX[((int64_t)s * L + p) * a.wd + kcol] = acc[mt][r] * sSc[p];
+        const int p = p0 + 16 * mt + x;
+        if (p < L && k0 < a.wd) {
+          const float sc = sSc[p];
+          *reinterpret_cast<float4*>(a.cnn.dX + ((int64_t)s * L + p) * a.wd + k0) =
+              make_float4(acc[mt][0] * sc, acc[mt][1] * sc, acc[mt][2] * sc, acc[mt][3] * sc);
         }
       }
     } else {
@@ -663,10 +679,11 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 #pragma unroll
           for (int u = 0; u < G; ++u) {
             const int b = g & 1;
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[b][u], B0[b][u], acc00, 0, 0, 0);
-            if (ff) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[b][u], B1[b][u], acc01, 0, 0, 0);
-            if (kk) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[b][u], B0[b][u], acc10, 0, 0, 0);
-            if (kk && ff) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[b][u], B1[b][u], acc11, 0, 0, 0);
+            // dY is the MFMA's A operand: D[i = 4kq + r][j = x] = dWk[tap][16kt + x][16ft + 4kq + r]
+            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(B0[b][u], A0[b][u], acc00, 0, 0, 0);
+            if (ff) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(B1[b][u], A0[b][u], acc01, 0, 0, 0);
+            if (kk) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(B0[b][u], A1[b][u], acc10, 0, 0, 0);
+            if (kk && ff) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(B1[b][u], A1[b][u], acc11, 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -677,12 +694,10 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       else if (k1) kloop(T{}, N{});
       else if (f1) kloop(N{}, T{});
       else kloop(N{}, N{});
-      auto put = [&](const f32x4& acc, int kt, int ft) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {  // D[i = 4kq + r][j = x] = dWk[tap][kt*16 + i][ft*16 + x]
-          const int k = kt * 16 + 4 * kq + r, f = ft * 16 + x;
-          if (k < a.wd && f < F) gw[((int64_t)tap * a.wd + k) * F + f] = acc[r];
-        }
+      auto put = [&](const f32x4& acc, int kt, int ft) {  // one 16-byte store per tile and lane
+        const int k = kt * 16 + x, f = ft * 16 + 4 * kq;
+        if (k < a.wd && f < F)
+          *reinterpret_cast<float4*>(gw + ((int64_t)tap * a.wd + k) * F + f) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       };
       put(acc00, kt0, ft0);
       if (f1) put(acc01, kt0, ft0 + 1);
