@@ -709,14 +709,18 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 
 // per item: rows of dX summed per distinct word, through the static sorted-position index.  The
 // item's entry table and position order are staged in LDS first, so the row loads are the only
-// dependent round trip.  Words with up to kLight occurrences: one 16-lane group per entry, four
-// entries of a group in flight.  Heavier words (the pad word, typically): all 16 groups share the
-// positions, partial rows combined in group order through LDS.
+// dependent round trip.  Work units = chunks of up to kLight positions of one word: a word with up
+// to kLight occurrences is one unit whose sum goes straight to dXw; a heavier word (the pad id,
+// typically half the item) is cut into chunks whose sums meet in LDS and are added in chunk order
+// afterwards.  One 16-lane group per unit, four units of a group in flight: every word of the item,
+// however often it occurs, is covered by the same one or two rounds of loads.
 constexpr int kLight = 4;
+constexpr int kMaxChunks = 104;  // chunks of heavy words per item: sum ceil(c/4) over words with c >= 5, sum c <= L <= 255
 __global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
   __shared__ uint8_t sPos[256], sStart[256], sCnt[256];
-  __shared__ int sHeavy[64], sNH;
-  __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ int sHeavy[64], sHBase[65], sNH;
+  __shared__ uint8_t sUnitH[kMaxChunks];                           // chunk -> index into sHeavy
+  __shared__ __attribute__((aligned(16))) float sPart[kMaxChunks * kTP];
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, wd4 = a.wd >> 2, L = a.L;
   const int s = blockIdx.x;
   if (s >= valid_rows(a)) return;
@@ -729,53 +733,73 @@ __global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
     const int cn = a.item_cnt[e0 + tid];
     sStart[tid] = a.cnn.item_start[e0 + tid];
     sCnt[tid] = (uint8_t)cn;
-    if (cn > kLight) sHeavy[atomicAdd(&sNH, 1)] = tid;  // at most L / (kLight + 1) < 64 of them; order irrelevant
+    if (cn > kLight) sHeavy[atomicAdd(&sNH, 1)] = tid;  // at most L / (kLight + 1) < 64 of them; the order only
+  }                                                     // decides where a word's chunks sit in LDS
+  __syncthreads();
+  const int nh = sNH;
+  if (tid == 0) {
+    int acc = 0;
+    for (int hi = 0; hi < nh; ++hi) {
+      sHBase[hi] = acc;
+      acc += (sCnt[sHeavy[hi]] + kLight - 1) / kLight;
+    }
+    sHBase[nh] = acc;
+  }
+  __syncthreads();
+  const int nchunk = sHBase[nh];
+  if (tid < nchunk) {
+    int hi = 0;
+    while (sHBase[hi + 1] <= tid) ++hi;
+    sUnitH[tid] = (uint8_t)hi;
   }
   __syncthreads();
   const float* dXs = a.cnn.dX + (int64_t)s * L * a.wd;
-  for (int eb = grp; eb < ne; eb += 64) {
+  // units [0, ne): the item's entries (heavy ones skipped here); units [ne, ne + nchunk): heavy chunks
+  const int nunit = ne + nchunk;
+  for (int ub = grp; ub < nunit; ub += 64) {
     Row r[4][kLight];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = eb + 16 * u;
-      const int cn = (e < ne && sCnt[e] <= kLight) ? sCnt[e] : 0;
+      const int un = ub + 16 * u;
+      int st = 0, cn = 0;
+      if (un < ne) {
+        if (sCnt[un] <= kLight) {
+          st = sStart[un];
+          cn = sCnt[un];
+        }
+      } else if (un < nunit) {
+        const int ch = un - ne, hi = sUnitH[ch], e = sHeavy[hi], off = (ch - sHBase[hi]) * kLight;
+        st = sStart[e] + off;
+        cn = min(kLight, (int)sCnt[e] - off);
+      }
 #pragma unroll
-      for (int t = 0; t < kLight; ++t) r[u][t] = (t < cn) ? row_load(dXs, sPos[sStart[e] + t], a.wd, wd4, q) : row_zero();
+      for (int t = 0; t < kLight; ++t) r[u][t] = (t < cn) ? row_load(dXs, sPos[st + t], a.wd, wd4, q) : row_zero();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = eb + 16 * u;
-      if (e < ne && sCnt[e] <= kLight) {
-        Row sum = r[u][0];
+      const int un = ub + 16 * u;
+      if (un >= nunit || (un < ne && sCnt[un] > kLight)) continue;
+      Row sum = r[u][0];
 #pragma unroll
-        for (int t = 1; t < kLight; ++t) sum = row_add(sum, r[u][t]);
-        row_store(a.cnn.dXw, (int64_t)s * L + e, a.wd, wd4, q, sum);
+      for (int t = 1; t < kLight; ++t) sum = row_add(sum, r[u][t]);
+      if (un < ne) {
+        row_store(a.cnn.dXw, (int64_t)s * L + un, a.wd, wd4, q, sum);
+      } else {
+        float4* dst = reinterpret_cast<float4*>(sPart + (un - ne) * kTP);
+        dst[q] = sum.a;
+        dst[q + 16] = sum.b;
       }
     }
   }
-  const int nh = sNH;
-  for (int hi = 0; hi < nh; ++hi) {
-    const int e = sHeavy[hi], st = sStart[e], cn = sCnt[e];
-    Row sum = row_zero();
-    for (int t0 = grp; t0 < cn; t0 += 64) {  // this group's positions, 4 in flight
-      Row r[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r[u] = (t0 + 16 * u < cn) ? row_load(dXs, sPos[st + t0 + 16 * u], a.wd, wd4, q) : row_zero();
-#pragma unroll
-      for (int u = 0; u < 4; ++u) sum = row_add(sum, r[u]);
+  __syncthreads();
+  for (int hi = grp; hi < nh; hi += 16) {  // a heavy word's chunks, in chunk order
+    Row tot = row_zero();
+    for (int ch = sHBase[hi]; ch < sHBase[hi + 1]; ++ch) {
+      const float4* src = reinterpret_cast<const float4*>(sPart + ch * kTP);
+      tot.a = add4(tot.a, src[q]);
+      tot.b = add4(tot.b, src[q + 16]);
     }
-    __syncthreads();
-    reinterpret_cast<float4*>(sR + grp * kTP)[q] = sum.a;
-    reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = sum.b;
-    __syncthreads();
-    if (grp == 0) {
-      Row tot = row_zero();
-      for (int g = 0; g < 16; ++g) {
-        tot.a = add4(tot.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
-        tot.b = add4(tot.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
-      }
-      row_store(a.cnn.dXw, (int64_t)s * L + e, a.wd, wd4, q, tot);
-    }
+    row_store(a.cnn.dXw, (int64_t)s * L + sHeavy[hi], a.wd, wd4, q, tot);
   }
 }
 
