@@ -486,7 +486,12 @@ def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
     np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
     names = ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta") if model == "cnn_embedding" else ("W", "Wd", "gamma", "beta")
     for name in names:
-        np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=1e-5, err_msg=name)
+        # word rows: each is an fp32 sum over every (item, occurrence) of the word in the block -- up to
+        # 5,632 items x ~90 distinct words here -- taken in a different order by the oracle (np.add.at over
+        # tokens) and the kernels (per word, slots in order); 3e-5 absolute on entries of ~0.05 is that
+        # reordering, the loss and the user table above hold the 1e-5 budget
+        atol = 3e-5 if name == "W" else 1e-5
+        np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=atol, err_msg=name)
 
 
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
