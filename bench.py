@@ -223,9 +223,9 @@ def measured_traffic(args, conf, d):
 
 
 def main_data_parallel(args, rank, world, local_rank):
-    """N > 1, model_choice = basic_embedding: one process per GPU, users + their links partitioned
-    by user range, text tower replicated, ONE RCCL all-reduce of the tower gradients per global
-    step (nncf_amd/sharded.py: DataParallelTower).  Weak scaling: b positives per rank per step."""
+    """N > 1, model_choice = basic_embedding / cnn_embedding: one process per GPU, users + their links
+    partitioned by user range, text tower replicated, ONE RCCL all-reduce of the tower gradients per
+    global step (nncf_amd/sharded.py: DataParallelTower).  Weak scaling: b positives per rank per step."""
     import torch
     import torch.distributed as dist
     from nncf_amd import engine as nengine
@@ -237,7 +237,7 @@ def main_data_parallel(args, rank, world, local_rank):
     data = make_data(args)
     trace("data made")
     users = int(data["train"][:, 0].max()) + 1
-    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice="basic_embedding")
+    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice=args.model)
     b, d = pconf.batch_size_p, args.dim
     mine = partition_links_by_user(data["train"], users, world)[rank].copy()
     rs = np.random.RandomState(4224 + rank)
@@ -250,11 +250,11 @@ def main_data_parallel(args, rank, world, local_rank):
         have += len(mine)
     stream = np.concatenate(chunks, 0)[:need]
     helper = get_data(data, pconf, rand_seed=12345, device=local_rank)
-    md = get_model(pconf, helper, "basic_embedding", device=local_rank, seed=0)   # same seed: identical replicas
+    md = get_model(pconf, helper, args.model, device=local_rank, seed=0)   # same seed: identical replicas
     trace("model built")
     rep = HipTowerReplica(md, args.scheme)
-    if pconf.word_emb_dropout_rate > 0:
-        rep.tower.set_dropout(pconf.word_emb_dropout_rate, 29 + rank)            # each rank its own row masks
+    if pconf.word_emb_dropout_rate > 0 or args.model == "cnn_embedding":
+        rep.tower.set_dropout(pconf.word_emb_dropout_rate, 29 + rank)            # each rank its own masks
     tr = DataParallelTower(rep)
     eng = rep.engine
     uid, cid = eng.ids(stream[:, 0]), eng.ids(stream[:, 1])
@@ -287,31 +287,43 @@ def main_data_parallel(args, rank, world, local_rank):
     # roofline leg (all ranks step together; rank 0's brackets are reported)
     L = args.content_len if not args.small else min(args.content_len, 40)
     keep = 1.0 - args.dropout
-    name = args.roofline_kernel or "tower_word_kernel"
+    cnn = args.model == "cnn_embedding"
+    name = args.roofline_kernel or ("cnn_conv_bwd_kernel" if cnn else "tower_word_kernel")
     prof_n = min(K, args.profile_launches)
     nengine.profile_begin(name, prof_n)
     run(W, prof_n, False)
     raw_ms, launches, ov_ms = nengine.profile_end()
     kern_ms = max(raw_ms - ov_ms, 1e-9)
-    work = 4.0 * b * L * d * keep
-    ach = work / (kern_ms * 1e-3) / 1e9
+    if name.startswith("cnn_conv"):   # n_u = unique items of the bracketed steps (counted here from the id stream)
+        n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
+        mult = 2 if name == "cnn_conv_fwd_kernel" else 4
+        work = mult * n_u * L * args.filter_len * d * d
+        roof = {"bound": "mfma", "achieved": work / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "what": "%d*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % (mult, n_u)}
+    else:
+        work = 4.0 * b * L * d * keep
+        roof = {"bound": "hbm", "achieved": work / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)"}
+    tower_txt = ("cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %d)+BN+ReLU+"
+                 "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_len, args.conv_dropout)
+                 if cnn else "basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
+                 % (L, args.vocab, args.dropout))
     if rank == 0:
         line = {
             "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links, item text), random-init parameters",
-            "config": {"workload": "CiteULike-a-shaped, basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row "
-                                   "dropout %g, Dense+BN+ReLU) d=%d, train_scheme=%s, loss=%s, b=%d per GPU, sparse SGD"
-                                   % (L, args.vocab, args.dropout, d, args.scheme, pconf.loss, b),
+            "config": {"workload": "CiteULike-a-shaped, %s d=%d, train_scheme=%s, loss=%s, b=%d per GPU, sparse SGD"
+                                   % (tower_txt, d, args.scheme, pconf.loss, b),
                        "global_batch": b * world,
                        "parallelism": "1 process per GPU; users + their links partitioned by user range, text tower "
                                       "replicated; one RCCL all-reduce of the tower gradients (%.2f MB) per step"
                                       % (rep.grad.numel() * 4 / 1e6)},
             "mean_loss": mean_loss,
-            "roofline": {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_per_launch": work,
-                         "algorithmic_what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)",
+            "roofline": {"kernel": name, "bound": roof["bound"], "achieved": roof["achieved"], "peak": roof["peak"],
+                         "unit": roof["unit"], "frac": roof["achieved"] / roof["peak"], "traffic": None,
+                         "algorithmic_per_launch": work, "algorithmic_what": roof["what"],
                          "kernel_ms": kern_ms, "event_bracket_ms": raw_ms, "empty_bracket_ms": ov_ms, "launches": launches},
             "cpu_baseline": None,
         }
@@ -327,10 +339,10 @@ def main_sharded(args, conf, rank, world, local_rank):
     import torch.distributed as dist
     from nncf_amd.sharded import HipBackend, ShardedNegShared, partition_links_by_user, shard_size
     from nncf_amd.synthetic import make_citeulike_like
-    if args.model == "basic_embedding":
+    if args.model in ("basic_embedding", "cnn_embedding"):
         return main_data_parallel(args, rank, world, local_rank)
     if args.model != "mf":
-        raise SystemExit("--gpus > 1 is built for --model basic_embedding (data parallel) and --model mf (item-sharded)")
+        raise SystemExit("--gpus > 1 is built for the text-tower models (data parallel) and --model mf (item-sharded)")
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
     conf = conf_for(args)

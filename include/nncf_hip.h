@@ -333,8 +333,10 @@ int nncf_tower_conv_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d
 
 /* Data-parallel training (one process per GPU, tower replicated): while d_grad is non-NULL the
  * backward applies nothing and writes the step's gradients to d_grad -- nncf_tower_grad_floats()
- * floats: [words (word_count*word_dim) | dense_w (word_dim*item_dim) | dense_b, bn_gamma, bn_beta
- * (128 each)], every element written, zeros for words outside the batch.  After the all-reduce,
+ * floats: [words (word_count*word_dim) | dense_w (H*item_dim, H = conv_filters or word_dim) | dense_b,
+ * bn_gamma, bn_beta (128 each)] and, for the CNN tower, [conv_w (filter_len*word_dim*conv_filters) |
+ * conv_b, bn1_gamma, bn1_beta (128 each)]; every live element written, zeros for words outside the
+ * batch; the pads of the 128-float vectors are left alone (hand in a zeroed buffer).  After the all-reduce,
  * nncf_tower_apply_grads takes the optimiser step with scale * d_grad (step_t: 1-based Adam step,
  * 0 = the tower's own counter). */
 int64_t nncf_tower_grad_floats(const nncf_tower* t);

@@ -830,6 +830,10 @@ __global__ void __launch_bounds__(1024) cnn_update_kernel(TowerArgs a, int nblk)
       float gsum = 0.f;
 #pragma unroll
       for (int gg = 0; gg < 8; ++gg) gsum += sG[gg * 128 + c];
+      if (a.gexp) {  // data-parallel step: the gradient leaves, nothing is applied here
+        a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + el] = gsum;
+        return;
+      }
       const float nw = a.opt ? adam1(gsum, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * gsum;
       a.cnn.Wk[el] = nw;
       const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
@@ -846,7 +850,12 @@ __global__ void __launch_bounds__(1024) cnn_update_kernel(TowerArgs a, int nblk)
 #pragma unroll
   for (int gg = 0; gg < 8; ++gg) gb += sG[gg * 128 + c];
   const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
-  if (a.opt) {
+  if (a.gexp) {
+    float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + nel;
+    gd[c] = gb;
+    gd[128 + c] = d2;
+    gd[256 + c] = d1;
+  } else if (a.opt) {
     float *mm = a.cnn.mC + nel, *vv = a.cnn.vC + nel;
     a.cnn.bc[c] = adam1(gb, mm + c, vv + c, a.cnn.bc[c], a);
     a.cnn.g1[c] = adam1(d2, mm + 128 + c, vv + 128 + c, a.cnn.g1[c], a);

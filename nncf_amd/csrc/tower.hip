@@ -706,17 +706,35 @@ __global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const flo
     return;
   }
   const size_t j = i - nW;
-  if (j >= nel + 384) return;
-  float* p;
-  if (j < nel) {
-    p = a.Wd + j;
-  } else {
-    const size_t c = (j - nel) & 127, which = (j - nel) >> 7;
-    if ((int)c >= a.d) return;
-    p = (which == 0 ? a.bd : which == 1 ? a.gamma : a.beta) + c;
+  if (j < nel + 384) {
+    float* p;
+    if (j < nel) {
+      p = a.Wd + j;
+    } else {
+      const size_t c = (j - nel) & 127, which = (j - nel) >> 7;
+      if ((int)c >= a.d) return;
+      p = (which == 0 ? a.bd : which == 1 ? a.gamma : a.beta) + c;
+    }
+    const float gv = scale * g[i];
+    *p = a.opt ? adam1(gv, a.mD + j, a.vD + j, *p, a) : *p - a.lr * gv;
+    return;
   }
+  // CNN front: Wk (and its transposed copy), conv bias, BN1 scale / shift
+  const int F = a.cnn.F, fl = a.cnn.fl;
+  const size_t k = j - (nel + 384), nelC = (size_t)fl * a.wd * F;
+  if (F == 0 || k >= nelC + 384) return;
   const float gv = scale * g[i];
-  *p = a.opt ? adam1(gv, a.mD + j, a.vD + j, *p, a) : *p - a.lr * gv;
+  if (k < nelC) {
+    const float nw = a.opt ? adam1(gv, a.cnn.mC + k, a.cnn.vC + k, a.cnn.Wk[k], a) : a.cnn.Wk[k] - a.lr * gv;
+    a.cnn.Wk[k] = nw;
+    const int f = (int)(k % F), kw = (int)((k / F) % a.wd), tap = (int)(k / ((size_t)F * a.wd));
+    a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + kw] = nw;
+    return;
+  }
+  const size_t c = (k - nelC) & 127, which = (k - nelC) >> 7;
+  if ((int)c >= F) return;
+  float* p = (which == 0 ? a.cnn.bc : which == 1 ? a.cnn.g1 : a.cnn.b1) + c;
+  *p = a.opt ? adam1(gv, a.cnn.mC + k, a.cnn.vC + k, *p, a) : *p - a.lr * gv;
 }
 
 __global__ void tower_scale_kernel(TowerArgs a, float* __restrict__ out) {
@@ -1045,12 +1063,15 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
 }
 
 int64_t nncf_tower_grad_floats(const nncf_tower* t) {
-  return t ? (int64_t)t->cfg.word_count * t->cfg.word_dim + (int64_t)t->cfg.word_dim * t->cfg.item_dim + 384 : 0;
+  if (!t) return 0;
+  const int64_t F = t->cnn.F, hd = F > 0 ? F : t->cfg.word_dim;
+  int64_t n = (int64_t)t->cfg.word_count * t->cfg.word_dim + hd * t->cfg.item_dim + 384;
+  if (F > 0) n += (int64_t)t->cnn.fl * t->cfg.word_dim * F + 384;
+  return n;
 }
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
-  NNCF_REQUIRE(t->cnn.F == 0 || !d_grad, "gradient export is not built for the CNN tower");
   t->gexp = d_grad;
   return NNCF_OK;
 }
@@ -1065,6 +1086,7 @@ int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int6
     a.lr_t = (float)((double)a.lr * std::sqrt(1.0 - std::pow((double)t->beta2, tt)) / (1.0 - std::pow((double)t->beta1, tt)));
     a.step_no = (int)tt;
     a.aw = t->aw; a.mD = t->mD; a.vD = t->vD;
+    a.cnn.mC = t->cnn.mC; a.cnn.vC = t->cnn.vC;
     if (step_t <= 0) t->adam_t++;
   }
   const int64_t n = nncf_tower_grad_floats(t);

@@ -405,6 +405,23 @@ class CnnTowerOracle(TowerOracle):
         self.conv_mask = None
         assert self.Wc.shape[0] % 2 == 1, "odd filter lengths only"
 
+    def flat_grads(self):
+        """TowerOracle.flat_grads + [Wc | bc, g1, b1 at 128-float pitch] (nncf_tower_grad_floats)."""
+        g = self.grads
+        pad = lambda v: np.concatenate([v, np.zeros(128 - len(v), dtype=self.dt)])  # noqa: E731
+        return np.concatenate([TowerOracle.flat_grads(self), g["Wc"].reshape(-1), pad(g["bc"]), pad(g["g1"]),
+                               pad(g["b1"])]).astype(self.dt)
+
+    def apply_flat(self, flat, scale=1.0):
+        TowerOracle.apply_flat(self, flat, scale)
+        off = self.W.size + self.Wd.size + 384
+        nC, F = self.Wc.size, len(self.bc)
+        f = np.asarray(flat, dtype=self.dt) * self.dt.type(scale)
+        self.Wc -= self.lr * f[off:off + nC].reshape(self.Wc.shape)
+        self.bc -= self.lr * f[off + nC:off + nC + F]
+        self.g1 -= self.lr * f[off + nC + 128:off + nC + 128 + F]
+        self.b1 -= self.lr * f[off + nC + 256:off + nC + 256 + F]
+
     def _front_forward(self, toks, row_scale, train):
         fl, pad = self.Wc.shape[0], self.Wc.shape[0] // 2
         n, L = toks.shape

@@ -193,10 +193,19 @@ def _tower_setup(seed=3):
     return C, W, Wd, U
 
 
-def _tower_oracle(conf):
+TW_F, TW_FL = 5, 3   # the CNN variant: Convolution1D(5 filters, length 3) in front of the same tail
+
+
+def _tower_oracle(conf, cnn=False):
     C, W, Wd, U = _tower_setup()
-    to = so.TowerOracle(C, W, Wd, np.zeros(D, np.float32), np.ones(D, np.float32), np.zeros(D, np.float32), conf.learn_rate,
-                        dtype=np.float32)
+    z, o = (lambda n: np.zeros(n, np.float32)), (lambda n: np.ones(n, np.float32))
+    if cnn:
+        rs = np.random.RandomState(9)
+        Wc = rs.uniform(-.5, .5, (TW_FL, D, TW_F)).astype(np.float32)
+        Wd = rs.uniform(-.5, .5, (TW_F, D)).astype(np.float32)
+        to = so.CnnTowerOracle(C, W, Wc, z(TW_F), o(TW_F), z(TW_F), Wd, z(D), o(D), z(D), conf.learn_rate, dtype=np.float32)
+    else:
+        to = so.TowerOracle(C, W, Wd, z(D), o(D), z(D), conf.learn_rate, dtype=np.float32)
     to.export_only = True
     return so.StepOracle(U, None, conf, dtype=np.float32, tower=to), to
 
@@ -204,9 +213,9 @@ def _tower_oracle(conf):
 class NumpyTowerReplica(object):
     """Test double of HipTowerReplica: oracle arithmetic, gradients exported to a flat CPU tensor."""
 
-    def __init__(self, conf):
-        self.orc, self.to = _tower_oracle(conf)
-        self.grad = torch.zeros(self.to.W.size + self.to.Wd.size + 384)
+    def __init__(self, conf, cnn=False):
+        self.orc, self.to = _tower_oracle(conf, cnn)
+        self.grad = torch.zeros(self.to.W.size + self.to.Wd.size + 384 + ((self.to.Wc.size + 384) if cnn else 0))
 
     def step(self, uid, cid, loss_out=None):
         loss = self.orc.step_neg_shared(uid.numpy(), cid.numpy())
@@ -224,33 +233,35 @@ def _tower_batches(world, seed=4):
             for r in range(world)]
 
 
-def _dp_worker(rank, world, port, ret):
+def _dp_worker(rank, world, port, ret, cnn):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     conf = so.OracleConf(batch_size_p=B, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.1,
                          model_choice="basic_embedding")
-    rep = NumpyTowerReplica(conf)
+    rep = NumpyTowerReplica(conf, cnn)
     tr = DataParallelTower(rep)
     losses = []
     for uid, cid in _tower_batches(world)[rank]:
         losses.append(float(tr.step(torch.from_numpy(uid), torch.from_numpy(cid))[0]))
-    ret[rank] = (rep.orc.U.copy(), {k: getattr(rep.to, k).copy() for k in ("W", "Wd", "bd", "gamma", "beta")}, losses)
+    ret[rank] = (rep.orc.U.copy(), {k: getattr(rep.to, k).copy() for k in rep.to.PARAMS}, losses)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_tower_world2():
+@pytest.mark.parametrize("cnn", [False, True], ids=["mean_pool", "cnn"])
+def test_data_parallel_tower_world2(cnn):
     """Two ranks, one all-reduce per step: replicas stay identical and equal a single-process
     restatement (every rank's gradient from the same pre-step parameters, summed, applied once);
-    user rows are touched only by their owner."""
+    user rows are touched only by their owner.  Both text towers (the CNN tower's flat buffer also
+    carries the convolution and its BatchNorm)."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_dp_worker, args=(world, _free_port(), ret, cnn), nprocs=world, join=True)
     conf = so.OracleConf(batch_size_p=B, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.1,
                          model_choice="basic_embedding")
-    reps = [NumpyTowerReplica(conf) for _ in range(world)]
+    reps = [NumpyTowerReplica(conf, cnn) for _ in range(world)]
     batches = _tower_batches(world)
     losses = [[] for _ in range(world)]
     for t in range(STEPS):
