@@ -73,7 +73,9 @@ def _load(data_name, **synth_kw):
     if isinstance(data_name, dict):
         return data_name
     if data_name.startswith("synthetic"):
-        return synthetic.make_citeulike_like(**synth_kw)
+        kw = dict(content_len=200, vocab=8001)   # item text as citeulike_title_and_abstract carries it (mf ignores it)
+        kw.update(synth_kw)
+        return synthetic.make_citeulike_like(**kw)
     with open(data_name, "rb") as fp:
         return pickle.load(fp, encoding="latin1")
 

@@ -111,11 +111,12 @@ def make_citeulike_like(users=16000, items=17000, train_links=200000, test_frac=
         for i0 in range(0, items, 1000):
             i1 = min(items, i0 + 1000)
             logits = text_scale * (Q[i0:i1] @ W[1:].T)
-            g = logits[:, None, :] + rs.gumbel(size=(i1 - i0, 1, vocab - 1)) * 0  # shared per item
-            for r, it in enumerate(range(i0, i1)):
-                pr = np.exp(g[r, 0] - g[r, 0].max())
-                pr /= pr.sum()
-                toks = rs.choice(vocab - 1, size=lens[it], p=pr) + 1
+            pr = np.exp(logits - logits.max(axis=1, keepdims=True))
+            cdf = np.cumsum(pr, axis=1)
+            cdf /= cdf[:, -1:]
+            u = rs.random_sample((i1 - i0, content_len))
+            for r, it in enumerate(range(i0, i1)):                 # inverse-CDF draws, one item at a time
+                toks = np.minimum(np.searchsorted(cdf[r], u[r, :lens[it]], side="right"), vocab - 2) + 1
                 C[it, content_len - lens[it]:] = toks
     else:
         C = np.zeros((items, 1), dtype=np.int64)
