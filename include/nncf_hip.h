@@ -366,6 +366,16 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all,
                      const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss,
                      int32_t* d_n_u, void* stream);
+/* The same for row-wise batches above a text tower -- n = b(1+k) independent (user, item, label)
+ * rows in any order, what train_scheme = presample / group_sample / reverse feed to
+ * model.train_on_batch with model_choice = cnn_embedding / basic_embedding
+ * (models/train_presample.py:48-85, train_group_sample.py:75-88, train_reverse.py:59-68;
+ * scripts/demos/run_presample_random.sh, run_group_sample.sh): d_uid[n], d_cid[n], d_y[n] as
+ * nncf_step_rowwise takes them; pointwise losses only. */
+int nncf_tower_step_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid, const int32_t* d_cid,
+                            const int32_t* d_y, float* d_loss, int update, const float* d_row_scale, void* stream);
+int nncf_tower_epoch_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all,
+                             const int32_t* d_y_all, int64_t n_steps, float* d_loss, void* stream);
 
 /* Two-phase step for models whose item rows are produced per batch (text towers):
  *   nncf_plan_item_block: plans the batch (scheme 0 original: d_cid[b(1+k)]; 1 neg_shared,

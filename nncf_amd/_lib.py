@@ -127,6 +127,8 @@ def _declare(lib):
         "nncf_tower_backward": [vp, vp, vp],
         "nncf_tower_step": [vp, vp, i32, vp, vp, vp, i32, vp, vp],
         "nncf_tower_epoch": [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp],
+        "nncf_tower_step_rowwise": [vp, vp, vp, vp, vp, vp, i32, vp, vp],
+        "nncf_tower_epoch_rowwise": [vp, vp, vp, vp, vp, i64, vp, vp],
         "nncf_model_set_item_grad_export": [vp, vp],
         "nncf_plan_item_block": [vp, i32, vp, vp, vp, vp, vp],
         "nncf_step_planned": [vp, i32, vp, vp, i32, vp],

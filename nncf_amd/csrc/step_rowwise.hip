@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) rowwise_score_kernel(StepArgs a, const in
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = a.d >> 2;
   if (row >= n) return;
   Row u = row_load(a.U, uid[row], a.stride, d4, q);
-  Row v = row_load(a.V, cid[row], a.stride, d4, q);
+  Row v = item_row(a, cid[row], d4, q);   // table row, or BatchNorm + ReLU of the text tower's block
   const float uss = row16_sum(row_dot_partial(u, u));
   if (NU) u = row_scale(u, inv_norm(uss));
   if (NV) v = row_scale(v, inv_norm(row16_sum(row_dot_partial(v, v))));
@@ -84,10 +84,14 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
           apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
         });
   } else {
+    const int chunk = blockIdx.x - chunks;
+    BnTail bt;   // text tower above the item block: BatchNorm + ReLU on load, its backward sums per chunk
+    bn_tail_init(bt, a, q);
     chunk_reduce(
-        pv, blockIdx.x - chunks, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
+        pv, chunk, sR, [&](int c) { return row_load(bt.on ? a.bn_z : a.V, c, a.stride, d4, q); },
         [&](int pos, bool) { return row_scale(row_load(ws.Urow, pos, a.d, d4, q), ws.g[pos]); },
-        [&](int c, int, Row vraw, Row acc) {
+        [&](int c, int, Row loaded, Row acc) {
+          const Row vraw = bn_tail_row(bt, loaded);
           Row grad = acc;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));
@@ -96,7 +100,9 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
           }
           if (a.gV) row_store(a.gV, c, a.d, d4, q, grad);
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
+          bn_tail_acc(bt, a, vraw, grad, loaded);
         });
+    bn_tail_flush(bt, a, sR, chunk);
   }
 }
 

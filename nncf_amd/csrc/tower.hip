@@ -877,13 +877,14 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
 
 int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
   if (!t || !m) return fail(NNCF_ERR_INVALID, "tower / model is NULL");
-  NNCF_REQUIRE(scheme >= 0 && scheme <= 2, "scheme must be 0 (original), 1 (neg_shared) or 2 (group_neg_shared)");
+  NNCF_REQUIRE(scheme >= 0 && scheme <= 3, "scheme must be 0 (original), 1 (neg_shared), 2 (group_neg_shared) or 3 (row-wise)");
   NNCF_REQUIRE(m->cfg.dim == t->cfg.item_dim && m->cfg.row_stride == m->cfg.dim, "model dim / stride != tower item_dim");
   NNCF_REQUIRE(m->export_gV != nullptr, "the model must export item gradients (nncf_model_set_item_grad_export)");
-  const int64_t n = scheme == 0 ? (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives) : m->cfg.batch_size_p;
+  const bool rows = scheme == 0 || scheme == 3;   // b(1+k) (user, item) rows per step
+  const int64_t n = rows ? (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives) : m->cfg.batch_size_p;
   NNCF_REQUIRE(n <= t->cfg.max_rows && n <= m->cfg.item_count, "batch of %lld item slots exceeds max_rows / item block",
                (long long)n);
-  if (scheme == 0) NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
+  if (rows) NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original and row-wise batches need num_negatives > 0");
   else NNCF_REQUIRE(m->cfg.batch_size_p % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
   return NNCF_OK;
 }
@@ -891,7 +892,7 @@ int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
 // one planned step: plans pu / pv (localized), the block's global ids and count on device
 int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid, const PlanView& pu,
                     const PlanView& pv, const int32_t* uniq_g, const int32_t* n_u, int n, float* loss, int update,
-                    const float* scale, hipStream_t st) {
+                    const float* scale, hipStream_t st, const int32_t* y = nullptr) {
   // the normalised block is never written: the step kernels apply BatchNorm + ReLU when they
   // load an item row from z
   int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st);
@@ -904,13 +905,15 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   sa.item_gid = uniq_g;  // InteractionDot item bias is indexed by catalogue id, the block by tf.unique rank
   // shared schemes: the apply kernel's item chunks (b / 16 of them) emit the BN backward's sums
   const int chunks = (b + kChunkSlots - 1) / kChunkSlots;
-  const int nfused = (scheme != 0 && update && chunks <= kTowerWG) ? chunks : 0;
+  const int nfused = ((scheme == 1 || scheme == 2) && update && chunks <= kTowerWG) ? chunks : 0;
   if (nfused) sa.bn_part = t->ws + ws_bsum();
-  const bool big = scheme == 0 && update;   // thousands of rows: partials per item chunk, merged by one workgroup
+  const bool big = (scheme == 0 || scheme == 3) && update;   // thousands of rows: partials per item chunk, merged by one workgroup
   const int cv = (n + kChunkSlots - 1) / kChunkSlots;
   if (big) sa.bn_part = t->bpart;
   if (scheme == 0)
     rc = launch_original(sa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
+  else if (scheme == 3)
+    rc = launch_rowwise(sa, uid, cid_local, y, m->rws, pu, pv, n, loss, update, st);
   else
     rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
   if (rc || !update) return rc;
@@ -1149,6 +1152,7 @@ int nncf_tower_backward(nncf_tower* t, const float* d_dA, void* stream) {
 
 int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
                     float* d_loss, int update, const float* d_row_scale, void* stream) {
+  NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_step_rowwise");
   if (int rc = check_pair(t, m, scheme)) return rc;
   NNCF_REQUIRE(d_uid && d_cid && d_loss, "NULL argument");
   const int b = m->cfg.batch_size_p, n = scheme == 0 ? b * (1 + m->cfg.num_negatives) : b;
@@ -1162,8 +1166,51 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
   return rc;
 }
 
+int nncf_tower_step_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, const int32_t* d_y,
+                            float* d_loss, int update, const float* d_row_scale, void* stream) {
+  if (int rc = check_pair(t, m, 3)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid && d_y && d_loss, "NULL argument");
+  const int n = m->cfg.batch_size_p * (1 + m->cfg.num_negatives);
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan_pair(d_uid, n, m->plan_u, d_cid, n, m->plan_v, st);
+  if (rc) return rc;
+  rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st);
+  if (rc) return rc;
+  rc = tower_step_body(t, m, 3, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st, d_y);
+  t->fwd_cached = false;
+  return rc;
+}
+
+int nncf_tower_epoch_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid_all, const int32_t* d_cid_all,
+                             const int32_t* d_y_all, int64_t n_steps, float* d_loss, void* stream) {
+  if (int rc = check_pair(t, m, 3)) return rc;
+  if (n_steps == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_y_all && d_loss, "NULL argument");
+  NNCF_REQUIRE(n_steps >= 0, "negative step count");
+  const int64_t n = (int64_t)m->cfg.batch_size_p * (1 + m->cfg.num_negatives), cap = t->cfg.max_rows;
+  hipStream_t st = as_stream(stream);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc = launch_plan(d_uid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_u, cnt, st);
+    if (rc) return rc;
+    rc = launch_plan(d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v, cnt, st);
+    if (rc) return rc;
+    rc = launch_plan_localize(m->plan_v, (int)n, t->uniq_g, t->n_u, st, cnt, cap);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t s = t0 + i;
+      rc = tower_step_body(t, m, 3, d_uid_all + s * n, m->plan_u.at(i), m->plan_v.at(i), t->uniq_g + i * cap, t->n_u + i,
+                           (int)n, d_loss + s, 1, nullptr, st, d_y_all + s * n);
+      if (rc) return rc;
+    }
+  }
+  t->fwd_cached = false;
+  return NNCF_OK;
+}
+
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,
                      const int32_t* d_neg_all, int64_t n_steps, float* d_loss, int32_t* d_n_u, void* stream) {
+  NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_epoch_rowwise");
   if (int rc = check_pair(t, m, scheme)) return rc;
   if (n_steps == 0) return NNCF_OK;
   NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss, "NULL argument");

@@ -143,14 +143,6 @@ class SampledNegSharedModel(_Head):
         return e.epoch_original(uid_all, cid_all, neg, n_steps)
 
 
-class _Unbuilt(object):
-    def __init__(self, what):
-        self.what = what
-
-    def train_on_batch(self, x, y=None):
-        raise NotImplementedError("%s is not built yet" % self.what)
-
-
 class EmbeddingModel(_Head):
     """model_user_emb / model_item_emb (model_framework.py:173-174): the tower output for a list
     of ids.  Only the 'given' evaluation scheme uses these; rows are gathered with torch
@@ -254,6 +246,25 @@ class _TowerCore(object):
         tw.version += 1
         return losses
 
+    def step_rowwise(self, uid_dev, cid_dev, y_dev, update=True, loss_out=None):
+        """b(1+k) independent (user, item, label) rows in any order (nncf_tower_step_rowwise)."""
+        e, tw = self.engine, self.tower
+        out = loss_out if loss_out is not None else e._loss1
+        with torch.cuda.device(e.device):
+            _lib.check(e._L.nncf_tower_step_rowwise(tw.handle, e._h, _ptr(uid_dev), _ptr(cid_dev), _ptr(y_dev), _ptr(out),
+                                                    int(update), None, e._stream()))
+        if update:
+            tw.version += 1
+        return out
+
+    def epoch_rowwise(self, uid_all, cid_all, y_all, n_steps, losses):
+        e, tw = self.engine, self.tower
+        with torch.cuda.device(e.device):
+            _lib.check(e._L.nncf_tower_epoch_rowwise(tw.handle, e._h, _ptr(uid_all), _ptr(cid_all), _ptr(y_all),
+                                                     int(n_steps), _ptr(losses), e._stream()))
+        tw.version += 1
+        return losses
+
     def eval_engine(self):
         """Engine over (shared U, inference-mode embeddings of ALL items), refreshed when the
         tower changed (predict_on_batch runs in the Keras inference phase: BN running stats,
@@ -281,9 +292,15 @@ class TowerHead(_Head):
         uid, cid = _as_ids(x[0]), _as_ids(x[1])
         if self.kind == "original":
             b, k = e.b, e.k
-            if uid.size != b * (1 + k) or not np.array_equal(uid[b:], np.repeat(uid[:b], k)):
-                raise ValueError("[ERROR] model expects the trainer's layout: b positives then k negatives per "
-                                 "positive (train_original.py:49-56)")
+            if uid.size != b * (1 + k) or cid.size != b * (1 + k):
+                raise ValueError("[ERROR] model expects batch_size_p * (1 + num_negatives) = %d rows, got %d"
+                                 % (b * (1 + k), uid.size))
+            if not (np.array_equal(uid[b:], np.repeat(uid[:b], k)) and (y is None or _labels_positive_first(y, b))):
+                # any other row order (presample / group_sample / reverse): general row-wise kernels
+                if y is None:
+                    raise ValueError("[ERROR] row-wise batches need their labels")
+                yy = np.asarray(y[0] if isinstance(y, (list, tuple)) else y).reshape(-1)
+                return self._loss(self.core.step_rowwise(e.ids(uid), e.ids(cid), e.ids(yy), update=self.update))
             uid = uid[:b]
         elif uid.size != e.b:
             raise ValueError("[ERROR] %s needs exactly batch_size_p = %d rows" % (self.kind, e.b))
@@ -306,12 +323,62 @@ class TowerHead(_Head):
             self.core.step(self.kind, uid_all[t * b:(t + 1) * b], cid, update=self.update, loss_out=losses[t:t + 1])
         return losses[:n_steps]
 
+    def run_epoch_rowwise(self, uid_all, cid_all, y_all, n_steps):
+        """presample / group_sample / reverse above a text tower: n_steps batches of b(1+k) rows."""
+        e = self.engine
+        losses = torch.empty(max(n_steps, 1), dtype=torch.float32, device=e.device)
+        if n_steps == 0:
+            return losses[:0]
+        if self.update:
+            return self.core.epoch_rowwise(uid_all, cid_all, y_all, n_steps, losses)[:n_steps]
+        n = e.b * (1 + e.k)
+        for t in range(n_steps):
+            sl = slice(t * n, (t + 1) * n)
+            self.core.step_rowwise(uid_all[sl], cid_all[sl], y_all[sl], update=False, loss_out=losses[t:t + 1])
+        return losses[:n_steps]
+
     def predict_on_batch(self, x):
         ev = self.core.eval_engine()
         return ev.predict_scores(ev.ids(_as_ids(x[0])), ev.ids(_as_ids(x[1]))).cpu().numpy()
 
     def predict_on_batch_device(self, uid_dev, cid_dev, out=None):
         return self.core.eval_engine().predict_scores(uid_dev, cid_dev, out=out)
+
+
+class TowerSampledNegSharedHead(_Head):
+    """model_dict['model_sampled_neg_shared'] above a text tower: as SampledNegSharedModel -- the
+    per-positive step with the k shared negatives replicated per positive, on a core whose engine
+    leaves the user rows un-normalised (U_emb_front, model_framework.py:64-65)."""
+
+    def __init__(self, core, make_core):
+        super(TowerSampledNegSharedHead, self).__init__(core.engine)
+        self._make, self._core = make_core, None
+
+    @property
+    def core(self):
+        if self._core is None:
+            self._core = self._make()
+        return self._core
+
+    def train_on_batch(self, x, y=None):
+        core = self.core
+        e = core.engine
+        b, k = e.b, e.k
+        uid, cid = _as_ids(x[0]), _as_ids(x[1])
+        if uid.size != b + k or cid.size != b + k:
+            raise ValueError("[ERROR] model_sampled_neg_shared expects batch_size_p + num_negatives = %d rows" % (b + k))
+        full = np.concatenate([cid[:b], np.tile(cid[b:], b)])
+        return self._loss(core.step("original", e.ids(uid[:b]), e.ids(full)))
+
+    def run_epoch(self, uid_all, cid_all, n_steps, neg_shared_all=None):
+        core = self.core
+        e = core.engine
+        b, k = e.b, e.k
+        losses = torch.empty(max(n_steps, 1), dtype=torch.float32, device=e.device)
+        if n_steps == 0:
+            return losses[:0]
+        neg = neg_shared_all[:n_steps * k].view(n_steps, 1, k).expand(n_steps, b, k).reshape(-1).contiguous()
+        return core.epoch("original", uid_all, cid_all, neg, n_steps, losses)[:n_steps]
 
 
 def engine_kwargs(conf, data_spec, model_name):
@@ -378,11 +445,21 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
             return TowerHead(core2, kind, update=False)
         return make
 
+    def make_unnormalised_core():
+        if not kw["normalize_user"]:
+            return core
+        kw2 = dict(kw, normalize_user=False)
+        e2 = Engine(device=device, tables=(engine.U, engine.V), bias_state=engine.bias, **kw2)
+        core2 = _TowerCore(e2, tower, data_spec.item_count, kw2, device)
+        if opt != "sgd":
+            e2.set_optimizer(opt, state=engine.opt_state)   # one optimiser for all heads (model_framework.py:24)
+        return core2
+
     return {
         "model": TowerHead(core, "original"),
         "model_neg_shared": TowerHead(core, "neg_shared"),
         "model_group_neg_shared": TowerHead(core, "group_neg_shared"),
-        "model_sampled_neg_shared": _Unbuilt("model_sampled_neg_shared with a text tower"),
+        "model_sampled_neg_shared": TowerSampledNegSharedHead(core, make_unnormalised_core),
         "model_user_emb": EmbeddingModel(engine, "user"),
         "model_item_emb": EmbeddingModel(engine, "item"),
         "model_pred_pairs": PredPairsModel(engine),

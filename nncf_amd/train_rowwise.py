@@ -18,8 +18,6 @@ class RowwiseTrainer(TrainerBase):
         super(RowwiseTrainer, self).__init__(model_dict, conf, data_helper)
         self.model_train = model_dict["model"]
         self.neg_sign = -1 if conf.loss == "skip-gram" else 0
-        if not hasattr(self.model_train, "run_epoch_rowwise"):
-            raise NotImplementedError("row-wise training schemes are built for the id-table model (mf)")
 
     def build_epoch(self, epoch):
         """-> (rows (n_rows, 3) int64, per-epoch host cost excluded from the timing window)."""

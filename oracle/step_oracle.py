@@ -653,6 +653,7 @@ class StepOracle(object):
         # the head uses U_emb_front = Emb_U(uid[:b]) WITHOUT normalisation (:64-65) and C_emb
         # sliced front/back (:114-117); the regulariser node is the front call.
         ufront = uid[:b]
+        cid = self._tower_in(cid)
         raw_u = self.U[ufront]
         reg = self.dt.type(self.conf.u_reg) * np.sum(np.mean(raw_u * raw_u, axis=0))
         raw_v, hat_v, inv_v = self._item_side(cid)
@@ -665,6 +666,7 @@ class StepOracle(object):
             g_u = G[:, :1] * hat_v[:b] + G[:, 1:] @ hat_v[b:]
             g_v = np.concatenate([G[:, :1] * raw_u, G[:, 1:].T @ raw_u], axis=0)
             self._apply(ufront, cid, raw_u, raw_u, None, hat_v, inv_v, g_u, g_v)
+        self._tower_out(update)
         return float(loss + reg)
 
     # -- inference heads (model_framework.py:153,173-176) --------------------------------

@@ -225,17 +225,17 @@ def _conf_cnn(loss, scheme, b=64, k=3, d=24, F=20, fl=3, lr=0.1, wdrop=0.0, cdro
     return get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
 
 
-def _oracle_cnn(conf, md, data):
+def _oracle_cnn(conf, md, data, dtype=np.float32):
     core = md["model"].core
     tw, eng = core.tower, core.engine
     oc = so.OracleConf(batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
                        loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
                        learn_rate=conf.learn_rate, emb_normalization=conf.emb_normalization,
                        model_choice="basic_embedding", optimizer=conf.optimizer)
-    g = lambda t: t.cpu().numpy()  # noqa: E731
+    g = lambda t: t.cpu().numpy().astype(dtype)  # noqa: E731
     to = so.CnnTowerOracle(data["C"], g(tw.W), g(tw.Wc), g(tw.bc), g(tw.g1), g(tw.b1), g(tw.Wd), g(tw.bd), g(tw.gamma),
-                           g(tw.beta), conf.learn_rate, dtype=np.float32)
-    return so.StepOracle(g(eng.U), None, oc, dtype=np.float32, tower=to), to
+                           g(tw.beta), conf.learn_rate, dtype=dtype)
+    return so.StepOracle(g(eng.U), None, oc, dtype=dtype, tower=to), to
 
 
 CNN_PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta", "rm", "rv", "rm1", "rv1")
@@ -243,6 +243,7 @@ CNN_PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta", "rm", "r
 
 @pytest.mark.parametrize("scheme,loss,fl,drop", [("neg_shared", "skip-gram", 3, False), ("neg_shared", "log-loss", 3, True),
                                                  ("group_neg_shared", "log-loss", 5, False), ("original", "skip-gram", 1, True),
+                                                 ("original", "skip-gram", 3, False),
                                                  ("group_neg_shared", "max-margin", 3, True)])
 def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop):
     """cnn_embedding (conv + BN + relu + dropout + average pooling in front of Dense/BN/ReLU) against
@@ -519,3 +520,74 @@ def test_cnn_embedding_adam_matches_oracle(text_data, kind):
         for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4,
                                        err_msg="%s step %d" % (name, step))
+
+
+@pytest.mark.parametrize("model,loss", [("basic_embedding", "skip-gram"), ("basic_embedding", "mse"),
+                                        ("cnn_embedding", "skip-gram"), ("cnn_embedding", "mse")])
+def test_rowwise_batches_above_a_text_tower(text_data, model, loss):
+    """presample / group_sample / reverse feed model.train_on_batch b(1+k) (user, item, label) rows in an
+    arbitrary order (the demo scripts run them with cnn_embedding): the general row-wise kernels with the
+    item rows coming from the tower == the oracle's row-wise step; the epoch runner == step by step."""
+    conf = (_conf_cnn if model == "cnn_embedding" else _conf)(loss, "original")
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    mds = [get_model(conf, helper, model, seed=2) for _ in range(2)]
+    md = mds[0]
+    # CNN tower: float64 oracle.  With ~250 items x 24 positions behind the conv BatchNorm, the numpy fp32
+    # restatement of its backward (N da - sum da - xhat sum da xhat) loses 5e-4 on the word rows to
+    # cancellation; the kernels agree with the float64 evaluation to 1e-7.
+    orc, to = _oracle_cnn(conf, md, text_data, dtype=np.float64) if model == "cnn_embedding" else _oracle(conf, md, text_data)
+    head = md["model"]
+    b, k = conf.batch_size_p, conf.num_negatives
+    n = b * (1 + k)
+    rs = np.random.RandomState(17)
+    train = text_data["train"]
+    rows = []
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+        if step == 1:      # reverse: the negatives are sampled USERS of the positive's item
+            u = u.copy()
+            u[b:] = rs.randint(0, 300, b * k)
+            c = np.concatenate([c[:b], np.repeat(c[:b], k)])
+        perm = rs.permutation(n)
+        u, c, y = u[perm], c[perm], y[perm]
+        rows.append((u, c, y))
+        want = orc.step_original(u, c, y)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        names = CNN_PARAMS if model == "cnn_embedding" else ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
+        for name in names:
+            np.testing.assert_allclose(getattr(head.core.tower, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5,
+                                       err_msg="%s step %d" % (name, step))
+    # the epoch runner on a fresh model: same losses, same parameters (bitwise)
+    h1 = mds[1]["model"]
+    e = h1.engine
+    cat = lambda i: e.ids(np.concatenate([r[i] for r in rows]))  # noqa: E731
+    losses = h1.run_epoch_rowwise(cat(0), cat(1), cat(2), len(rows)).cpu().numpy()
+    assert torch.equal(h1.engine.U, head.engine.U) and torch.equal(h1.core.tower.W, head.core.tower.W)
+    assert losses.shape == (3,) and np.all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("model", ["basic_embedding", "cnn_embedding"])
+def test_sampled_neg_shared_above_a_text_tower(text_data, model):
+    """model_sampled_neg_shared with a text tower: b positives + k negatives shared by every positive."""
+    conf = (_conf_cnn if model == "cnn_embedding" else _conf)("skip-gram", "original")
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, model, seed=2)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, text_data)
+    head = md["model_sampled_neg_shared"]
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(23)
+    train = text_data["train"]
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        negs = rs.randint(0, 260, k)
+        u = np.concatenate([bt[:, 0], np.zeros(k, dtype=np.int64)])
+        c = np.concatenate([bt[:, 1], negs])
+        want = orc.step_sampled_neg_shared(u, c)
+        got = head.train_on_batch([u, c])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(head.core.tower.W.cpu().numpy(), to.W, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(head.core.tower.Wd.cpu().numpy(), to.Wd, rtol=2e-4, atol=2e-5)
