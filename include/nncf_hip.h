@@ -412,7 +412,7 @@ int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, int64_t n, in
  * (d_truth_ptr[n_users+1], d_truth_idx sorted ascending inside a user).  Per user with >= 1 true
  * item: d_metrics[3u..] = {map@k, recall@k, precision@k}, d_valid[u] = 1; others d_valid[u] = 0
  * (objectives.py:316).  Score ties go to the lower slot (the reference uses random noise).
- * Limits: n_cand <= 16384, topk <= 1024. */
+ * Limits: topk <= 1024; any n_cand (the row is read twice, only candidates of the top k are held on chip). */
 int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, int32_t n_cand,
                    const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
                    int32_t* d_valid, void* stream);

@@ -180,6 +180,57 @@ def test_topk_kernel_matches_reference_eval_multiple():
             np.testing.assert_allclose(met.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
+def _np_metrics(scores, truth_slots, topk):
+    """metrics_ranking.py:14-29 with ties going to the lower slot."""
+    n = len(scores)
+    order = np.lexsort((np.arange(n), -scores.astype(np.float64)))[:min(topk, n)]
+    hits = np.isin(order, truth_slots)
+    nh = np.cumsum(hits)
+    ap = float((nh / np.arange(1, len(order) + 1))[hits].sum()) / min(len(truth_slots), topk)
+    return np.array([ap, hits.sum() / len(truth_slots), hits.sum() / topk])
+
+
+def test_topk_selection_against_numpy():
+    """The select-then-sort evaluator: random rows of every size (below a wave, beyond the old 16,384
+    cap), heavy ties, rows arranged against the bucket stride (large collected sets) and one that
+    overflows the LDS buffer (exact fallback), k from 1 to 1024."""
+    import ctypes
+    from nncf_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    cases = []
+    for n, k in ((7, 50), (40, 50), (600, 50), (13600, 50), (40000, 50), (5000, 1), (5000, 1024), (3000, 700)):
+        cases.append((rs.normal(size=n).astype(np.float32), k))
+    cases.append((np.zeros(9000, dtype=np.float32), 50))                                  # all tied: slots 0..49
+    cases.append((rs.randint(0, 5, 20000).astype(np.float32), 50))                        # 5 distinct values
+    a = rs.normal(size=30000).astype(np.float32)
+    a[::1024] += 100.0                                                                   # the top 30 in ONE bucket
+    cases.append((a, 50))
+    n = 200 * 1024
+    b = rs.uniform(-1, 0, n).astype(np.float32)                                          # overflow of the LDS buffer:
+    idx = np.arange(n)
+    high = (idx % 1024) < 50                                                             # 50 buckets hold every large
+    b[high] = 10.0 + rs.uniform(0, 1, high.sum()).astype(np.float32)                     # value, one of them only the
+    b[(idx % 1024) == 49] = 5.0 + rs.uniform(0, 1, (idx % 1024 == 49).sum()).astype(np.float32)   # smallest of those
+    cases.append((b, 50))
+    for sc, topk in cases:
+        n = len(sc)
+        truth = np.sort(rs.choice(n, size=min(n, 25), replace=False)).astype(np.int32)
+        top = np.lexsort((np.arange(n), -sc.astype(np.float64)))[:3]
+        truth = np.unique(np.concatenate([truth, top])).astype(np.int32)                 # some hits for sure
+        scores = torch.as_tensor(sc).cuda().reshape(1, -1).contiguous()
+        ptr = torch.as_tensor(np.array([0, len(truth)], dtype=np.int32)).cuda()
+        idx_t = torch.as_tensor(truth).cuda()
+        met = torch.zeros(3, device="cuda")
+        val = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(L.nncf_eval_topk(ctypes.c_void_p(scores.data_ptr()), 1, n, n, ctypes.c_void_p(ptr.data_ptr()),
+                                    ctypes.c_void_p(idx_t.data_ptr()), topk, ctypes.c_void_p(met.data_ptr()),
+                                    ctypes.c_void_p(val.data_ptr()), _lib.stream_ptr()))
+        assert int(val.item()) == 1
+        np.testing.assert_allclose(met.cpu().numpy(), _np_metrics(sc, truth, topk), rtol=1e-6, atol=1e-7,
+                                   err_msg="n=%d k=%d" % (n, topk))
+
+
 def test_group_trainer_with_device_shuffle_learns():
     """conf.device_shuffle: the per-epoch stratified shuffle runs on the device (rocPRIM sorts);
     training still converges and batches are item-stratified (mean unique items per batch well
