@@ -246,8 +246,10 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
       afrag[kk] = isV ? sG[kidx * kGP + m] : sG[m * kGP + kidx];
     }
     const float* B = (isV ? sU : sV) + (lane >> 4) * DP + (lane & 15);
+    // the table rows are the MFMA's A operand and G its B operand: D[i = 4kq + r][j = x] is column
+    // 16nt + 4kq + r of slab row 16mt + x -- four consecutive floats per lane, one 16-byte store per tile
     float* slab = (isV ? ws.dV_part + ((int64_t)bi * b + bj * kTile) * d : ws.dU_part + ((int64_t)bj * b + bi * kTile) * d) +
-                  (int64_t)(mt * 16 + (lane >> 4) * 4) * d + (lane & 15);
+                  (int64_t)(mt * 16 + (lane & 15)) * d + (lane >> 4) * 4;
     const int ntiles = NP >> 4;
     for (int nt = par; nt < ntiles; nt += 4) {
       const bool two = nt + 2 < ntiles;
@@ -260,15 +262,12 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b0[kk], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[kk], b1[kk], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0[kk], afrag[kk], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[kk], afrag[kk], c1, 0, 0, 0);
       }
-      const int n0 = nt * 16 + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (n0 < d) slab[(int64_t)r * d + nt * 16] = c0[r];
-        if (two && n0 + 32 < d) slab[(int64_t)r * d + nt * 16 + 32] = c1[r];
-      }
+      const int n0 = nt * 16 + (lane >> 4) * 4;
+      if (n0 < d) *reinterpret_cast<float4*>(slab + nt * 16) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+      if (two && n0 + 32 < d) *reinterpret_cast<float4*>(slab + nt * 16 + 32) = make_float4(c1[0], c1[1], c1[2], c1[3]);
     }
   }
   NNCF_STAMP(6);
