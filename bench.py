@@ -261,8 +261,7 @@ def main_data_parallel(args, rank, world, local_rank):
     losses = torch.zeros(K, dtype=torch.float32, device=eng.device)
 
     def run(first, count, keep):
-        for t in range(first, first + count):
-            tr.step(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b], losses[t - first:t - first + 1] if keep else None)
+        tr.run_epoch(uid[first * b:(first + count) * b], cid[first * b:(first + count) * b], count, b, losses if keep else None)
 
     trace("warmup")
     run(0, W, False)

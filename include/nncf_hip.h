@@ -366,6 +366,14 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all,
                      const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss,
                      int32_t* d_n_u, void* stream);
+/* The epoch runner in two halves, for callers that put something between the steps (the
+ * data-parallel path: all-reduce + nncf_tower_apply_grads after every step): plan up to 64
+ * consecutive steps in one launch (d_uid[n_steps*b], d_cid[n_steps*b], d_neg[n_steps*b*k] for
+ * scheme 0), then run planned step `index` (d_uid = that step's b user ids). */
+int nncf_tower_plan_steps(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                          const int32_t* d_neg, int64_t n_steps, void* stream);
+int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t index, const int32_t* d_uid,
+                       float* d_loss, void* stream);
 /* The same for row-wise batches above a text tower -- n = b(1+k) independent (user, item, label)
  * rows in any order, what train_scheme = presample / group_sample / reverse feed to
  * model.train_on_batch with model_choice = cnn_embedding / basic_embedding

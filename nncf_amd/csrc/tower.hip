@@ -1208,6 +1208,38 @@ int nncf_tower_epoch_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid_
   return NNCF_OK;
 }
 
+int nncf_tower_plan_steps(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid, const int32_t* d_cid,
+                          const int32_t* d_neg, int64_t n_steps, void* stream) {
+  NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_epoch_rowwise");
+  if (int rc = check_pair(t, m, scheme)) return rc;
+  NNCF_REQUIRE(d_uid && d_cid, "NULL argument");
+  NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps can be planned at once", kPlanChunk);
+  NNCF_REQUIRE(scheme != 0 || d_neg, "train_scheme=original needs the presampled negatives");
+  const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
+  const int n = (int)(scheme == 0 ? b * (1 + k) : b);
+  hipStream_t st = as_stream(stream);
+  int rc = launch_plan(d_uid, b, (int)b, nullptr, 0, 0, m->plan_u, n_steps, st);
+  if (rc) return rc;
+  if (scheme == 0) rc = launch_plan(d_cid, b, (int)b, d_neg, b * k, (int)(b * k), m->plan_v, n_steps, st);
+  else rc = launch_plan(d_cid, b, (int)b, nullptr, 0, 0, m->plan_v, n_steps, st);
+  if (rc) return rc;
+  return launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, n_steps, t->cfg.max_rows);
+}
+
+int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t index, const int32_t* d_uid, float* d_loss,
+                       void* stream) {
+  NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_epoch_rowwise");
+  if (int rc = check_pair(t, m, scheme)) return rc;
+  NNCF_REQUIRE(d_uid && d_loss, "NULL argument");
+  NNCF_REQUIRE(index >= 0 && index < kPlanChunk, "plan slot %lld out of range", (long long)index);
+  const int64_t b = m->cfg.batch_size_p, cap = t->cfg.max_rows;
+  const int n = (int)(scheme == 0 ? b * (1 + m->cfg.num_negatives) : b);
+  const int rc = tower_step_body(t, m, scheme, d_uid, m->plan_u.at(index), m->plan_v.at(index), t->uniq_g + index * cap,
+                                 t->n_u + index, n, d_loss, 1, nullptr, as_stream(stream));
+  t->fwd_cached = false;
+  return rc;
+}
+
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,
                      const int32_t* d_neg_all, int64_t n_steps, float* d_loss, int32_t* d_n_u, void* stream) {
   NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_epoch_rowwise");

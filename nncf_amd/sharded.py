@@ -181,9 +181,29 @@ class HipTowerReplica(object):
         self.grad = torch.zeros(n, dtype=torch.float32, device=self.engine.device)
         _lib.check(L.nncf_tower_set_grad_export(self.tower.handle, ctypes.c_void_p(self.grad.data_ptr())))
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.engine.device)
+        self.PLAN_CHUNK = 64 if scheme in self._SCHEME else 0   # steps planned per launch (original: per step)
+
+    _SCHEME = {"neg_shared": 1, "group_neg_shared": 2}
 
     def step(self, uid, cid, loss_out=None):
         return self.core.step(self.scheme, uid, cid, update=True, loss_out=loss_out if loss_out is not None else self._loss)
+
+    def plan(self, uid_chunk, cid_chunk, n_steps):
+        """Duplicate plans + tf.unique of up to 64 consecutive steps in one launch (nncf_tower_plan_steps)."""
+        e, L = self.engine, self._lib.lib()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(e.device):
+            self._lib.check(L.nncf_tower_plan_steps(self.tower.handle, e._h, self._SCHEME[self.scheme], p(uid_chunk), p(cid_chunk),
+                                                    None, int(n_steps), e._stream()))
+
+    def step_at(self, index, uid, loss_out=None):
+        e, L = self.engine, self._lib.lib()
+        out = loss_out if loss_out is not None else self._loss
+        with torch.cuda.device(e.device):
+            self._lib.check(L.nncf_tower_step_at(self.tower.handle, e._h, self._SCHEME[self.scheme], int(index),
+                                                 ctypes.c_void_p(uid.data_ptr()), ctypes.c_void_p(out.data_ptr()), e._stream()))
+        self.tower.version += 1
+        return out
 
     def apply(self, scale=1.0):
         e = self.engine
@@ -219,3 +239,24 @@ class DataParallelTower(object):
             dist.all_reduce(self.be.grad, op=dist.ReduceOp.SUM, group=self.group)
         self.be.apply(1.0)
         return loss
+
+    def run_epoch(self, uid_all, cid_all, n_steps, b, losses=None):
+        """n_steps global steps over this rank's link stream (uid_all / cid_all: n_steps * b ids).  Replicas
+        that can plan ahead (HipTowerReplica) make the duplicate plans of 64 steps in one launch, as the
+        single-GPU epoch runner does; per step: planned step -> all-reduce -> apply."""
+        be = self.be
+        chunk = getattr(be, "PLAN_CHUNK", 0)
+        for t0 in range(0, n_steps, max(chunk, 1)):
+            cnt = min(max(chunk, 1), n_steps - t0)
+            if chunk:
+                be.plan(uid_all[t0 * b:(t0 + cnt) * b], cid_all[t0 * b:(t0 + cnt) * b], cnt)
+            for i in range(cnt):
+                t = t0 + i
+                lo = losses[t:t + 1] if losses is not None else None
+                if chunk:
+                    be.step_at(i, uid_all[t * b:(t + 1) * b], lo)
+                else:
+                    be.step(uid_all[t * b:(t + 1) * b], cid_all[t * b:(t + 1) * b], lo)
+                if self.world > 1:
+                    dist.all_reduce(be.grad, op=dist.ReduceOp.SUM, group=self.group)
+                be.apply(1.0)

@@ -107,3 +107,35 @@ def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
         np.testing.assert_allclose(getattr(t0, name).cpu().numpy(), getattr(t1, name).cpu().numpy(), rtol=1e-5, atol=1e-6,
                                    err_msg=name)
     np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_data_parallel_run_epoch_equals_plain_epoch():
+    """DataParallelTower.run_epoch (plans of 64 steps per launch, planned step -> apply) over 70 steps ==
+    the single-GPU epoch runner, bitwise on the user table and to rounding on the tower (the gradient
+    takes the export buffer's detour)."""
+    from nncf_amd import synthetic
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    from nncf_amd.sharded import DataParallelTower, HipTowerReplica
+    data = synthetic.make_citeulike_like(users=300, items=260, train_links=5000, seed=3, content_len=24, vocab=120)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
+          "user_dim": 24, "item_dim": 24, "word_dim": 24, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.}
+    conf = get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+    mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2) for _ in range(2)]
+    dp = DataParallelTower(HipTowerReplica(mds[0], "neg_shared"))
+    plain = mds[1]["model_neg_shared"]
+    e = plain.engine
+    rs = np.random.RandomState(2)
+    steps, b = 70, 64
+    bt = data["train"][rs.choice(len(data["train"]), steps * b, replace=True)]
+    u, c = e.ids(bt[:, 0]), e.ids(bt[:, 1])
+    losses = torch.zeros(steps, device="cuda")
+    dp.run_epoch(u, c, steps, b, losses)
+    want = plain.run_epoch(u, c, steps)
+    np.testing.assert_allclose(losses.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    for name in ("W", "Wd", "gamma", "beta"):
+        np.testing.assert_allclose(getattr(dp.be.tower, name).cpu().numpy(), getattr(plain.core.tower, name).cpu().numpy(),
+                                   rtol=1e-4, atol=2e-6, err_msg=name)
+    np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-5, atol=1e-6)
