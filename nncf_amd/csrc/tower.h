@@ -53,6 +53,8 @@ struct TowerArgs {
   const int32_t* item_ptr;   // CSR of the content matrix: item -> (word, count) pairs
   const int32_t* item_word;
   const uint8_t* item_cnt;
+  const int32_t* ent_word;   // the same pairs at a fixed stride of L per item (-1 / 0 past the item's last pair):
+  const uint8_t* ent_cnt;    // one dependent load less than through item_ptr (built at create, mean-pool tower)
   const float* scale;        // per-word row-dropout scale (Embedding(dropout=...), :56-59) or NULL
   // per call
   const int32_t* ids;        // [m] item ids of the block's rows
@@ -158,6 +160,8 @@ struct nncf_tower {
   void* arena = nullptr;
   float *h = nullptr, *z = nullptr, *dh = nullptr, *ws = nullptr;
   uint8_t* cnt_t = nullptr;
+  int32_t* ent_word = nullptr;  // fixed-stride copy of the item CSR (mean-pool tower)
+  uint8_t* ent_cnt = nullptr;
   float* bpart = nullptr;
   int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
   bool fwd_cached = false;

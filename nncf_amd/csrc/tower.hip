@@ -5,10 +5,10 @@
 // step kernels (the tower's output block is the step's item table, item gradients come back
 // through the export buffer).  Per training step, after the batched duplicate plans:
 //
-//   tower_pool_kernel   one workgroup per unique item: gather-mean of its L word rows
-//                       (4*L*word_dim bytes, the path's dominant traffic), z = h.Wd + bd from the
-//                       pooled row still in LDS, and the item's (word, count) pairs transposed into
-//                       the word-major count matrix the backward reads
+//   tower_pool_kernel   one workgroup per unique item: mean of its L word rows as sum over the item's
+//                       DISTINCT words of count * row (4*L*word_dim bytes token-wise, the path's dominant
+//                       traffic), z = h.Wd + bd from the pooled row still in LDS, and the item's (word,
+//                       count) pairs transposed into the word-major count matrix the backward reads
 //   tower_stats_kernel  per-workgroup Welford partials of every column of z
 //   tower_bn_kernel     merge (Chan) -> mu, var; E = relu(gamma (z-mu) rsqrt(var+eps) + beta);
 //                       running statistics
@@ -35,7 +35,8 @@ namespace nncf {
 
 // One workgroup per block row s: h[s] = (1/L) sum_l scale[c] W[c], c = content[ids[s]][l]
 // (AverageEmbeddings divides by L always: the mask compares ids with -1, mean_pool.py:30; the pad
-// id 0 contributes its row), then z[s] = h[s].Wd + bd.  Inference (train = 0) finishes the row:
+// id 0 contributes its row) -- evaluated as (1/L) sum_w count_w scale[w] W[w] over the item's distinct
+// words -- then z[s] = h[s].Wd + bd.  Inference (train = 0) finishes the row:
 // E[s] = relu(BN_running(z[s])).
 __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
@@ -57,34 +58,29 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
     const int k = kp * kper + i;
     w[i] = (i < kper && k < a.hd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
   }
-  // all L tokens (and their dropout scales) in one round trip, parked in LDS
-  const int32_t* toks = a.content + (int64_t)item * a.L;
-  if (tid < a.L) {
-    const int tk = toks[tid];
-    sTok[tid] = tk;
-    sSc[tid] = a.train ? word_scale(a, tk) : 1.f;
-  }
-  // backward preparation, loads first: this item's (word, count) pairs
-  int fp0 = 0, fp1 = 0, fw = 0;
+  // The item's distinct words with their counts (fixed-stride copy of the CSR: one round trip, no
+  // pointer hop): sum_l scale[c_l] W[c_l] = sum_w count_w scale_w W[w] needs one row load per DISTINCT
+  // kept word -- ~45 instead of ~100 kept tokens for a CiteULike abstract, one round of loads per item.
+  int fw = -1;
   unsigned fc = 0;
-  if (a.fill) {
-    fp0 = a.item_ptr[item];
-    fp1 = a.item_ptr[item + 1];
-    if (fp0 + tid < fp1) {
-      fw = a.item_word[fp0 + tid];
-      fc = a.item_cnt[fp0 + tid];
-    }
+  float fsc = 0.f;
+  if (tid < a.L) {
+    fw = a.ent_word[(int64_t)item * a.L + tid];
+    fc = a.ent_cnt[(int64_t)item * a.L + tid];
+    if (fw >= 0) fsc = (a.train ? word_scale(a, fw) : 1.f) * (float)fc;
+    sTok[tid] = fw;
+    sSc[tid] = fsc;
   }
-  __syncthreads();
+  const int ne = __syncthreads_count(fw >= 0);  // pairs of this item (they come first)
   Row acc = row_zero();
-  const int nper = (a.L + 15) >> 4;  // tokens per group
+  const int nper = (ne + 15) >> 4;  // pairs per group
   for (int i0 = 0; i0 < nper; i0 += 7) {  // 7 word rows of this group in flight
     float sc[7];
     Row r[7];
 #pragma unroll
     for (int e = 0; e < 7; ++e) {
       const int l = grp + 16 * (i0 + e);
-      const bool ok = (i0 + e < nper) && l < a.L;
+      const bool ok = (i0 + e < nper) && l < ne;
       sc[e] = ok ? sSc[l] : 0.f;
       r[e] = (sc[e] != 0.f) ? row_load(a.W, sTok[l], a.wd, wd4, q) : row_zero();
     }
@@ -133,13 +129,19 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   }
   // backward preparation: cnt_t[w * cap + s] = occurrences of word w in this item.  Every
   // (w, s) cell is written by exactly one thread: no atomics.  Dropped words get no gradient.
-  if (a.fill) {
-    if (fp0 + tid < fp1 && word_scale(a, fw) != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = (uint8_t)fc;
-    for (int p = fp0 + tid + 256; p < fp1; p += 256) {
-      const int wv = a.item_word[p];
-      if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = a.item_cnt[p];
-    }
-  }
+  if (a.fill && fsc != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = (uint8_t)fc;
+}
+
+// fixed-stride copy of the item CSR: ent[item][e] = e-th (word, count) pair of the item, (-1, 0) past the last
+__global__ void tower_entries_kernel(TowerArgs a, int64_t items, int32_t* __restrict__ ent_word,
+                                     uint8_t* __restrict__ ent_cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= items * a.L) return;
+  const int64_t item = i / a.L;
+  const int p = a.item_ptr[item] + (int)(i % a.L);
+  const bool ok = p < a.item_ptr[item + 1];
+  ent_word[i] = ok ? a.item_word[p] : -1;
+  ent_cnt[i] = ok ? a.item_cnt[p] : (uint8_t)0;
 }
 
 // Column sums over the real rows of a block, 1024 threads = 64 row groups per workgroup, eight
@@ -761,6 +763,10 @@ void carve_tower(nncf_tower* t, Carver& c) {
   t->ws = c.take<float>(ws_total((int)wide, (int)d, t->ks));
   if (t->cfg.conv_filters > 0) cnn_carve(t, c);
   t->cnt_t = c.take<uint8_t>((int64_t)t->cfg.word_count * cap);
+  if (t->cfg.conv_filters == 0) {
+    t->ent_word = c.take<int32_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
+    t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
+  }
   t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
@@ -773,6 +779,7 @@ TowerArgs base_args(const nncf_tower* t) {
   a.rm = p.bn_mean; a.rv = p.bn_var;
   a.content = p.content; a.item_ptr = p.item_ptr; a.item_word = p.item_word; a.item_cnt = p.item_cnt;
   a.h = t->h; a.z = t->z; a.dh = t->dh; a.ws = t->ws; a.cnt_t = t->cnt_t;
+  a.ent_word = t->ent_word; a.ent_cnt = t->ent_cnt;
   a.wd = t->cfg.word_dim; a.hd = t->cfg.word_dim; a.d = t->cfg.item_dim; a.L = t->cfg.content_len; a.cap = t->cfg.max_rows;
   a.n_words = t->cfg.word_count;
   a.eps = t->cfg.bn_eps; a.momentum = t->cfg.bn_momentum; a.lr = t->cfg.learn_rate;
@@ -997,6 +1004,14 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
     if (rc) {
       nncf_tower_destroy(t);
       return rc;
+    }
+  } else {
+    const int64_t n = (int64_t)cfg->item_count * cfg->content_len;
+    hipLaunchKernelGGL(tower_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, base_args(t),
+                       (int64_t)cfg->item_count, t->ent_word, t->ent_cnt);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      nncf_tower_destroy(t);
+      return fail(NNCF_ERR_HIP, "building the item entry table failed");
     }
   }
   *out = t;
