@@ -696,8 +696,13 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       else kloop(N{}, N{});
       auto put = [&](const f32x4& acc, int kt, int ft) {  // one 16-byte store per tile and lane
         const int k = kt * 16 + x, f = ft * 16 + 4 * kq;
-        if (k < a.wd && f < F)
-          *reinterpret_cast<float4*>(gw + ((int64_t)tap * a.wd + k) * F + f) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (k < a.wd && f < F) {  // streaming stores: 120 KB per workgroup, read once by cnn_update -- not worth L2 lines
+          float* dst = gw + ((int64_t)tap * a.wd + k) * F + f;
+          __builtin_nontemporal_store(acc[0], dst);
+          __builtin_nontemporal_store(acc[1], dst + 1);
+          __builtin_nontemporal_store(acc[2], dst + 2);
+          __builtin_nontemporal_store(acc[3], dst + 3);
+        }
       };
       put(acc00, kt0, ft0);
       if (f1) put(acc01, kt0, ft0 + 1);
