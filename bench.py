@@ -561,7 +561,7 @@ def main():
                   "after_steps": int(W + K + prof_n * len(names)),
                   "note": "whole@50 after the warm-up, timed and roofline passes of this run (a short run, not a converged model)"
                           + ("; learn_rate 0.01 is the demo scripts' ADAM step size -- plain SGD barely moves with it "
-                             "(--optimizer adam: train 0.55-0.60 / cold-item test 0.18 after the same steps)"
+                             "(--optimizer adam: train 0.68 / cold-item test 0.27 after the same steps)"
                              if args.optimizer == "sgd" else "")}
 
     if rank == 0:
