@@ -295,7 +295,10 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
 //   sum_p da = dh[s][c]/L * M1[s][c],  sum_p da*xhat = dh[s][c]/L * M2[s][c],
 // M1 = sum_p m, M2 = sum_p m*xhat: both are emitted per item by this pass over Y, and the backward
 // needs no pass of its own for them (cnn_merge_kernel weighs them with dh).
-__global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
+// 512 threads = 32 row groups: the item's L <= 224 positions are one round of loads (seven rows per group
+// in flight); the four groups of a wave are combined by shuffles, the 8 waves through LDS in wave order.
+constexpr int kPoolThreads = 512;
+__global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[3][16 * kTP];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
   __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
@@ -305,12 +308,12 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   const int s = blockIdx.x;
   if (s >= valid_rows(a)) return;
   const bool prep = a.train && a.fill;
-  const int c4 = tid & 31, kp = tid >> 5, kper = (F + 7) >> 3;
+  const int c4 = tid & 31, kp = (tid >> 5) & 7, kper = (F + 7) >> 3;   // dense part: the first 256 threads
   float4 w[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = kp * kper + i;
-    w[i] = (i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+    w[i] = (tid < 256 && i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
   }
   if (tid < 128) {
     float mul = 0.f, add = 0.f;
@@ -342,13 +345,14 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   rmu.b = reinterpret_cast<const float4*>(sMu)[q + 16];
   rinv.a = reinterpret_cast<const float4*>(sInv)[q];
   rinv.b = reinterpret_cast<const float4*>(sInv)[q + 16];
-  for (int p0 = grp; p0 < L; p0 += 112) {
-    Row y[7];
+  constexpr int NG = kPoolThreads / 16, NR = 7;
+  for (int p0 = grp; p0 < L; p0 += NG * NR) {
+    Row y[NR];
 #pragma unroll
-    for (int e = 0; e < 7; ++e) y[e] = (p0 + 16 * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + 16 * e, F, f4, q) : row_zero();
+    for (int e = 0; e < NR; ++e) y[e] = (p0 + NG * e < L) ? row_load(a.cnn.Y, (int64_t)s * L + p0 + NG * e, F, f4, q) : row_zero();
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
-      const int p = p0 + 16 * e;
+    for (int e = 0; e < NR; ++e) {
+      const int p = p0 + NG * e;
       if (p < L) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -366,18 +370,35 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
       }
     }
   }
-  reinterpret_cast<float4*>(sR[0] + grp * kTP)[q] = acc.a;
-  reinterpret_cast<float4*>(sR[0] + grp * kTP)[q + 16] = acc.b;
+  auto wave_fold = [&](Row& r) {   // the wave's four groups (lanes q, q+16, q+32, q+48) -> group 0 of the wave
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = relem(r, k);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      relem(r, k) = v;
+    }
+  };
+  wave_fold(acc);
   if (prep) {
-    reinterpret_cast<float4*>(sR[1] + grp * kTP)[q] = m1.a;
-    reinterpret_cast<float4*>(sR[1] + grp * kTP)[q + 16] = m1.b;
-    reinterpret_cast<float4*>(sR[2] + grp * kTP)[q] = m2.a;
-    reinterpret_cast<float4*>(sR[2] + grp * kTP)[q + 16] = m2.b;
+    wave_fold(m1);
+    wave_fold(m2);
+  }
+  const int wv = tid >> 6;
+  if ((tid & 63) < 16) {
+    reinterpret_cast<float4*>(sR[0] + wv * kTP)[q] = acc.a;
+    reinterpret_cast<float4*>(sR[0] + wv * kTP)[q + 16] = acc.b;
+    if (prep) {
+      reinterpret_cast<float4*>(sR[1] + wv * kTP)[q] = m1.a;
+      reinterpret_cast<float4*>(sR[1] + wv * kTP)[q + 16] = m1.b;
+      reinterpret_cast<float4*>(sR[2] + wv * kTP)[q] = m2.a;
+      reinterpret_cast<float4*>(sR[2] + wv * kTP)[q + 16] = m2.b;
+    }
   }
   __syncthreads();
   if (prep && (grp == 1 || grp == 2)) {  // M1 / M2 of this item, groups in order
     Row sum = row_zero();
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < kPoolThreads / 64; ++g) {
       sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR[grp] + g * kTP)[q]);
       sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[grp] + g * kTP)[q + 16]);
     }
@@ -387,7 +408,7 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
   }
   if (grp == 0) {
     Row sum = row_zero();
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < kPoolThreads / 64; ++g) {
       sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q]);
       sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q + 16]);
     }
@@ -397,13 +418,15 @@ __global__ void __launch_bounds__(256) cnn_pool_dense_kernel(TowerArgs a) {
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
   }
   __syncthreads();
-  float4 part = zero4();
+  if (tid < 256) {
+    float4 part = zero4();
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = kp * kper + i;
-    if (i < kper && k < F) part = fma4(sH[k], w[i], part);
+    for (int i = 0; i < 16; ++i) {
+      const int k = kp * kper + i;
+      if (i < kper && k < F) part = fma4(sH[k], w[i], part);
+    }
+    sP[kp * 32 + c4] = part;
   }
-  sP[kp * 32 + c4] = part;
   __syncthreads();
   if (tid < d4) {
     float4 z = reinterpret_cast<const float4*>(a.bd)[tid];
@@ -944,7 +967,7 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_pool_dense_kernel", st);
-    hipLaunchKernelGGL(cnn_pool_dense_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(cnn_pool_dense_kernel, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
