@@ -591,3 +591,28 @@ def test_sampled_neg_shared_above_a_text_tower(text_data, model):
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(head.core.tower.W.cpu().numpy(), to.W, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(head.core.tower.Wd.cpu().numpy(), to.Wd, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_rowwise_batches_above_the_cnn_tower_under_adam(text_data, kind):
+    """The demo scripts' presample / group_sample runs: cnn_embedding, row-wise batches, Adam."""
+    conf = _conf_cnn("skip-gram", "original", lr=0.01)
+    conf.optimizer = kind
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    head = md["model"]
+    tw = head.core.tower
+    orc, to = _oracle_cnn(conf, md, text_data, dtype=np.float64)
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(31)
+    for step in range(3):
+        bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
+        u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), "skip-gram")
+        perm = rs.permutation(b * (1 + k))
+        u, c, y = u[perm], c[perm], y[perm]
+        want = orc.step_original(u, c, y)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
+        for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):   # bc / bd: see test_cnn_embedding_adam_matches_oracle
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4,
+                                       err_msg="%s step %d" % (name, step))
