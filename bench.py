@@ -300,9 +300,10 @@ def main_data_parallel(args, rank, world, local_rank):
         roof = {"bound": "mfma", "achieved": work / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "what": "%d*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % (mult, n_u)}
     else:
-        work = 4.0 * b * L * d * keep
+        n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
+        work = 4.0 * n_u * L * d * keep
         roof = {"bound": "hbm", "achieved": work / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)"}
+                "what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % n_u}
     tower_txt = ("cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %d)+BN+ReLU+"
                  "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_len, args.conv_dropout)
                  if cnn else "basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
@@ -511,9 +512,10 @@ def main():
         "cnn_conv_bwd_kernel": ("mfma", 2 * conv_flop, "dX and dWk: 4*n_u*L*fl*word_dim*F flop, n_u = %.1f" % mean_n_u),
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
-        "tower_pool_kernel": ("hbm", 4.0 * b * L * d * keep, "4*L*word_dim*(1-dropout) B per unique item (n_u <= b rows)"),
-        "tower_word_kernel": ("hbm", 4.0 * b * L * d * keep,
-                              "4*L*word_dim*(1-dropout) B of gradient rows per unique item (n_u <= b)"),
+        "tower_pool_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
+                              "4*L*word_dim*(1-dropout) B per unique item, n_u = %.1f unique items per launch" % mean_n_u),
+        "tower_word_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
+                              "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % mean_n_u),
         "tower_bwd_kernel": ("mfma", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
     }
     default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
