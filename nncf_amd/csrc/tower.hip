@@ -522,6 +522,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 // Remaining blocks: Wd, bd, gamma, beta -= lr * gradient (K-parts / partials summed in order).
 constexpr int kWordsPerWG = 8;
 constexpr int kListCap = 256;
+constexpr int kRowsInFlight = 8;
 template <bool CNN>
 __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
@@ -596,18 +597,18 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       // a popular word through LDS latency).
       int curj = -1;
       float2 run = make_float2(0.f, 0.f);
-      for (int e0 = 0; e0 < cnt; e0 += 16) {  // 16 rows of dh in flight
-        int ent[16];
-        float2 r[16];
+      for (int e0 = 0; e0 < cnt; e0 += kRowsInFlight) {  // rows of dh in flight
+        int ent[kRowsInFlight];
+        float2 r[kRowsInFlight];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
+        for (int u = 0; u < kRowsInFlight; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < kRowsInFlight; ++u)
           r[u] = (ent[u] && lane < d2)
                      ? dh2[(cnn ? (int64_t)((ent[u] >> 8) & 0xFFFF) * a.L + ((ent[u] & 255) - 1) : (int64_t)((ent[u] >> 8) & 0xFFFF)) * d2 + lane]
                      : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < kRowsInFlight; ++u) {
           if (ent[u]) {  // uniform across the wave
             const int j = ent[u] >> 24;
             if (j != curj) {
