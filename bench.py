@@ -222,6 +222,19 @@ def measured_traffic(args, conf, d):
     return ent["bytes_per_launch"] if ent else None
 
 
+def rocprof_duration_ms(args, conf, d):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of
+    this workload (profiles/traffic.json carries it next to the PMC bytes), for comparison with the live
+    event-bracket figure; None when there is no committed profile of exactly this workload."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None
+    key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
+    us = (table.get(key) or {}).get("rocprof_avg_us")
+    return us * 1e-3 if us else None
+
+
 def main_data_parallel(args, rank, world, local_rank):
     """N > 1, model_choice = basic_embedding / cnn_embedding: one process per GPU, users + their links
     partitioned by user range, text tower replicated, ONE RCCL all-reduce of the tower gradients per
@@ -546,6 +559,9 @@ def main():
                       "empty_bracket_ms": ov_ms, "launches": launches})
     roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d)
+    # the profiler's duration of the same kernel (start to end of the dispatch, incl. what the event bracket's
+    # empty-bracket correction removes): committed summary under profiles/, None without one
+    roof["rocprof_kernel_ms"] = rocprof_duration_ms(args, conf, d)
 
     cpu = None
     if want_cpu:

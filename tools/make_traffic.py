@@ -30,6 +30,22 @@ def pmc_mean(path, kernel, counter):
     return None
 
 
+def trace_avg_us(path, kernel):
+    """average duration (us) of `kernel` in a tools/prof_summary.py kernel-trace summary"""
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith("# PMC counters"):
+            break
+        if kernel in line:
+            parts = line.split()
+            try:
+                return float(parts[-2])
+            except (ValueError, IndexError):
+                continue
+    return None
+
+
 def main():
     d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
     table = {}
@@ -41,6 +57,7 @@ def main():
         table[key] = {
             "kernel": kernel, "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
             "bytes_per_launch": int(round((2 * f + w) * 1024)),
+            "rocprof_avg_us": trace_avg_us(os.path.join(d, "%s_%s_kernel_trace.txt" % (tag, stem)), kernel),
             "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes "
                    "(profiles/%s_%s_pmc_*.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024" % (tag, stem),
             "round": int(tag.lstrip("r") or 0),
