@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-from .train_base import TrainerBase
+from .train_base import TrainerBase, shuffle_rows
 
 
 class Trainer(TrainerBase):
@@ -26,7 +26,7 @@ class Trainer(TrainerBase):
         self.train_time = []
         for epoch in range(conf.max_epoch + 1):
             cost, it = 0, 0
-            np.random.shuffle(train)
+            shuffle_rows(train)
             n_steps = len(train) // b if epoch > 0 else 0
             uid, cid = self._upload(train, n_steps)
             torch.cuda.synchronize(engine.device)

@@ -1,6 +1,6 @@
 """models/train_original.py:8-88 -- plain negative sampling.
 
-Per epoch: np.random.shuffle(train) on the host exactly as the reference (:36), then the whole
+Per epoch: np.random.shuffle(train) on the host exactly as the reference (:36; train_base.shuffle_rows), then the whole
 `while` loop (:43-68) runs on the device inside nncf_epoch_original: the epoch's negatives are
 drawn first (the same LCG stream consumed in the same order: step t uses draws
 [t*b*k, (t+1)*b*k) == the reference's per-step sample_batch(k*b) calls, :51), batches are
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-from .train_base import TrainerBase
+from .train_base import TrainerBase, shuffle_rows
 
 
 class Trainer(TrainerBase):
@@ -35,7 +35,7 @@ class Trainer(TrainerBase):
                   "model_dict['model_all_loss'][name].train_on_batch for spot checks")
         self.train_time = []
         for epoch in range(conf.max_epoch + 1):
-            np.random.shuffle(train)
+            shuffle_rows(train)
             cost, it = 0, 0
             n_steps = len(train) // b if epoch > 0 else 0  # ragged tail dropped (:46-48)
             uid, cid = self._upload(train, n_steps)

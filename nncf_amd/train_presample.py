@@ -3,6 +3,7 @@ grouped according to conf.shuffle_st (:44-85)."""
 import numpy as np
 
 from .data_utils import group_shuffle_train
+from .train_base import shuffle_rows
 from .train_rowwise import RowwiseTrainer
 
 
@@ -22,13 +23,13 @@ class Trainer(RowwiseTrainer):
         train_p = self.data_helper.data["train"]
         st = conf.shuffle_st
         if st == "original":  # :44-50
-            np.random.shuffle(train_p)
+            shuffle_rows(train_p)
             train = train_p.repeat(1 + k, axis=0)
             train[:, 1] = self.sample_batch(train.shape[0])
             train[:, 2] = neg_sign
             train[::1 + k] = train_p
         elif st == "reverse":  # :51-57
-            np.random.shuffle(train_p)
+            shuffle_rows(train_p)
             train = train_p.repeat(1 + k, axis=0)
             train[:, 0] = self.sample_batch_u(train.shape[0])
             train[:, 2] = neg_sign
@@ -39,7 +40,7 @@ class Trainer(RowwiseTrainer):
             train_n[:, 2] = neg_sign
             train = np.vstack((train_p, train_n))
             if st == "random":
-                np.random.shuffle(train)
+                shuffle_rows(train)
             elif st == "by_user":
                 train = group_shuffle_train(train, by="user", iidx=self._iidx["user"])
             elif st == "by_item":

@@ -3,6 +3,7 @@ import time
 
 import numpy as np
 
+from .train_base import shuffle_rows
 from .train_rowwise import RowwiseTrainer
 
 
@@ -16,7 +17,7 @@ class Trainer(RowwiseTrainer):
         conf = self.conf
         b, k = conf.batch_size_p, conf.num_negatives
         train = self.data_helper.data["train"]
-        np.random.shuffle(train)
+        shuffle_rows(train)
         n_steps = len(train) // b if epoch > 0 else 0   # nothing is drawn at epoch 0 (no training there)
         t0 = time.time()
         pos = train[:n_steps * b].reshape(n_steps, b, 3)
