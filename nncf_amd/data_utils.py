@@ -118,13 +118,15 @@ def group_shuffle_train(train, by="item", chop=0, iidx=None, rng=None):
     if iidx is None:
         iidx = np.arange(np.max(train[:, col]) + 1)
     rng.shuffle(iidx)
-    rng.shuffle(train)
+    # row / block shuffles as permuted copies: the same permutations and the same RNG consumption as
+    # rng.shuffle on the 2-D / 3-D arrays (which swaps rows one by one), several times faster
+    train[:] = train[rng.permutation(train.shape[0])]   # in place, as rng.shuffle(train): the caller's array moves too
     key = iidx[train[:, col]]
     train = train[np.argsort(key, kind="stable")]
     if chop > 0:
         bulk_len = (train.shape[0] // chop) * chop
         bulk = train[:bulk_len].reshape((-1, chop, train.shape[-1]))
-        rng.shuffle(bulk)
+        bulk = bulk[rng.permutation(bulk.shape[0])]
         train = np.vstack([bulk.reshape((-1, train.shape[-1])), train[bulk_len:]])
     return train
 
