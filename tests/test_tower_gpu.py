@@ -616,3 +616,41 @@ def test_rowwise_batches_above_the_cnn_tower_under_adam(text_data, kind):
         for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):   # bc / bd: see test_cnn_embedding_adam_matches_oracle
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4,
                                        err_msg="%s step %d" % (name, step))
+
+
+def test_rowwise_tower_with_normalisation_and_bias(text_data):
+    """Row-wise batches above the mean-pool tower with emb_normalization (both sides l2-normalised) and
+    interaction_bias = 'both' (item bias by catalogue id, block rows by tf.unique rank)."""
+    conf = _conf("skip-gram", "original")
+    conf.emb_normalization = True
+    conf.interaction_bias = "both"
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    orc.conf.interaction_bias = "both"
+    head = md["model"]
+    eng = head.engine
+    rs = np.random.RandomState(41)
+    eng.bias["ub"].copy_(torch.as_tensor(rs.randn(300).astype(np.float32) * 0.2))
+    eng.bias["cb"].copy_(torch.as_tensor(rs.randn(260).astype(np.float32) * 0.2))
+    orc.ub, orc._want_cb = eng.bias["ub"].cpu().numpy().copy(), True
+    orc.cb = eng.bias["cb"].cpu().numpy().copy()
+    b, k = conf.batch_size_p, conf.num_negatives
+    for step in range(3):
+        bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
+        u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), "skip-gram")
+        perm = rs.permutation(b * (1 + k))
+        u, c, y = u[perm], c[perm], y[perm]
+        want = orc.step_original(u, c, y)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=2e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-5, atol=5e-6)
+        for name in ("W", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(head.core.tower, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5,
+                                       err_msg="%s step %d" % (name, step))
+    # the loss monitor head (SGD(0.), model_all_loss) scores a row-wise batch without touching anything
+    mon = md["model_all_loss"]["skip-gram"]
+    U0 = eng.U.clone()
+    lm = mon.train_on_batch([u, c], [y])
+    assert np.isfinite(lm) and torch.equal(eng.U, U0)
