@@ -150,3 +150,18 @@ def test_group_sampler_matches_reference_golden():
     random.seed(998)
     assert np.array_equal(gs.sample(30), g["u_a"])
     assert np.array_equal(gs.sample_with_negs(30, 2), g["u_c"])
+
+
+def test_shuffle_rows_is_np_random_shuffle():
+    """train_base.shuffle_rows: the permutation np.random.shuffle would apply to the rows, the same RNG
+    consumption, in place."""
+    from nncf_amd.train_base import shuffle_rows
+    a = np.arange(3000).reshape(1000, 3).astype(np.int64)
+    b = a.copy()
+    np.random.seed(11)
+    np.random.shuffle(a)
+    after_a = np.random.randint(1 << 30)
+    np.random.seed(11)
+    shuffle_rows(b)
+    after_b = np.random.randint(1 << 30)
+    assert np.array_equal(a, b) and after_a == after_b
