@@ -321,6 +321,36 @@ def test_cnn_embedding_citeulike_tile_shape():
                                        err_msg="%s step %d" % (name, step))
 
 
+@pytest.mark.parametrize("L,wd,F,fl", [(250, 128, 128, 5), (130, 72, 88, 3)])
+def test_cnn_embedding_general_tile_shapes(L, wd, F, fl):
+    """Shapes outside the two fast specialisations: the masked <8, 8> forward tiles (L up to 256, word_dim up
+    to 128), an 8-group / 6-group K loop in the backward, three position blocks per item, filter length 5."""
+    data = synthetic.make_citeulike_like(users=120, items=90, train_links=1500, seed=13, content_len=L, vocab=300)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "log-loss", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 32,
+          "user_dim": 64, "item_dim": 64, "word_dim": wd, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.3,
+          "num_filters": [F], "filter_lengths": [fl], "conv_dropout_rate": 0.1}
+    conf = get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+    md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    orc, to = _oracle_cnn(conf, md, data, dtype=np.float64)
+    head = md["model_neg_shared"]
+    tw = head.core.tower
+    rs = np.random.RandomState(3)
+    for step in range(2):
+        bt = data["train"][rs.choice(len(data["train"]), 32, replace=False)]
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        to.conv_mask = tw.conv_mask(step, 32).cpu().numpy().astype(np.float64)
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        for name in CNN_PARAMS:
+            if name == "bc":
+                np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
+                continue
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=3e-4, atol=3e-5,
+                                       err_msg="%s step %d" % (name, step))
+
+
 @pytest.mark.parametrize("model", ["basic_embedding", "cnn_embedding"])
 def test_dims_not_multiple_of_4_are_padded_exactly(text_data, model):
     """The reference's default widths are 50: the wrappers zero-pad every width to a multiple of 4.
