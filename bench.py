@@ -351,7 +351,6 @@ def main_sharded(args, conf, rank, world, local_rank):
     import torch
     import torch.distributed as dist
     from nncf_amd.sharded import HipBackend, ShardedNegShared, partition_links_by_user, shard_size
-    from nncf_amd.synthetic import make_citeulike_like
     if args.model in ("basic_embedding", "cnn_embedding"):
         return main_data_parallel(args, rank, world, local_rank)
     if args.model != "mf":
@@ -359,7 +358,7 @@ def main_sharded(args, conf, rank, world, local_rank):
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
     conf = conf_for(args)
-    data = make_citeulike_like(users=2000, items=2000, train_links=20000, seed=7) if args.small else make_citeulike_like()
+    data = make_data(args)   # --large: BASELINE configs[3], 10M users x 1M items (only the links the run consumes)
     users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
     b, d = conf.batch_size_p, args.dim
     mine = partition_links_by_user(data["train"], users, world)[rank].copy()
@@ -410,10 +409,11 @@ def main_sharded(args, conf, rank, world, local_rank):
             "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables",
-            "config": {"workload": "CiteULike-a-shaped, id-table towers (model_choice=mf), item table sharded by id "
+            "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init tables" if args.large else
+                     "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables"),
+            "config": {"workload": "%s, id-table towers (model_choice=mf), item table sharded by id "
                                    "range, d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
-                                   % (d, conf.loss, b),
+                                   % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", d, conf.loss, b),
                        "global_batch": b * world,
                        "parallelism": "1 process per GPU; users + their links and item rows range-sharded; "
                                       "3 RCCL all-to-alls per step (ids, rows, gradients)"},
