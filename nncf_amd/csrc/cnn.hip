@@ -111,7 +111,9 @@ constexpr int kFwdMt = 8;  // row tiles of 16 positions per workgroup: L <= 2 * 
 // NMT / NKT: row tiles per workgroup and 16-column K groups of the word dimension as compile-time
 // loop bounds.  MASK = false: the shape matches exactly (the LDS tile is zero-padded past L and
 // past wd, so no per-fragment guards remain between the MFMAs); MASK = true: any smaller shape.
-template <int NMT, int NKT, bool MASK>
+// TAIL = 1: word_dim = 16 NKT + 4 -- the last four columns are ONE k-step (lane kq takes column
+// 16 NKT + kq of both operands as dwords) instead of a zero-padded 16-column group of four.
+template <int NMT, int NKT, bool MASK, int TAIL = 0>
 __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
@@ -144,6 +146,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
   // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
   // 16t+4kq serves k-step (t, e) on both operands)
   float4 bf[3][NKT];
+  float bt[3] = {0.f, 0.f, 0.f};
   auto load_b = [&](int nt, int tap0) {
     const int col = nt * 16 + x;
 #pragma unroll
@@ -155,6 +158,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
         const int c0 = 16 * t + 4 * kq;
         bf[tt][t] = (tap < fl && t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
       }
+      if (TAIL) bt[tt] = (tap < fl && col < F) ? a.cnn.Wt[(int64_t)col * KW + tap * a.wd + 16 * NKT + kq] : 0.f;
     }
   };
   // the wave's first strip is known now: its filter fragments travel while the rows are staged
@@ -191,6 +195,14 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
 #pragma unroll
               for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
             }
+          }
+          if (TAIL) {
+            const float* tbase = sX + (int64_t)(x + tap) * XP + 16 * NKT + kq;
+            float at[NMT];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) at[mt] = tbase[(int64_t)16 * mt * XP];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[tt], at[mt], acc[mt], 0, 0, 0);
           }
         }
       }
@@ -496,7 +508,8 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
 
 // One workgroup per (slot, block of kConvLB positions).  NFT: 16-column groups of the filter
 // dimension as a compile-time bound of (a)'s K loop (MASK = false: exactly ceil(F/16) == NFT).
-template <int NFT, bool MASK>
+// TAIL = 1: F = 16 NFT + 4 -- (a)'s last four filters are one k-step of dword operands (as in the forward).
+template <int NFT, bool MASK, int TAIL = 0>
 __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int sTok[256];
@@ -601,6 +614,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       for (int mt = 0; mt < nMb; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int tap0 = 0; tap0 < fl; tap0 += 3) {
         float4 bf[3][NFT];
+        float bt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
           const int tap = tap0 + tt;
@@ -608,8 +622,9 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 #pragma unroll
           for (int t = 0; t < NFT; ++t) {
             const int c0 = 16 * t + 4 * kq;
-            bf[tt][t] = (tap < fl && t < nFt && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
+            bf[tt][t] = (tap < fl && t < (TAIL ? NFT : nFt) && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
           }
+          if (TAIL) bt[tt] = (tap < fl && kcol < a.wd) ? a.cnn.Wk[((int64_t)tap * a.wd + kcol) * F + 16 * NFT + kq] : 0.f;
         }
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
@@ -631,6 +646,14 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 #pragma unroll
                 for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
               }
+            }
+            if (TAIL) {
+              const float* tbase = sD + (int64_t)(x + (fl - 1 - tap)) * FP + 16 * NFT + kq;
+              float at[kConvLB / 16];
+#pragma unroll
+              for (int mt = 0; mt < nMb; ++mt) at[mt] = tbase[(int64_t)16 * mt * FP];
+#pragma unroll
+              for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[tt], at[mt], acc[mt], 0, 0, 0);
             }
           }
         }
@@ -950,7 +973,10 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   {
     ProfScope _ps("cnn_conv_fwd_kernel", st);
     const dim3 grid((unsigned)a.m * kFwdSplit);
-    if (nMtH == 7 && nKt == 7) {  // L in (192, 224], word_dim in (96, 112]: the CiteULike shape
+    if (nMtH == 7 && a.wd == 100) {  // L in (192, 224], word_dim 100 = 6 K groups + a 4-column tail: the CiteULike shape
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 6, false, 1>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 6, false, 1>), grid, dim3(kConvThreads), lds, st, a);
+    } else if (nMtH == 7 && nKt == 7) {  // L in (192, 224], word_dim in (96, 112]
       if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 7, false>), lds)) return rc;
       hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 7, false>), grid, dim3(kConvThreads), lds, st, a);
     } else if (nMtH <= 4 && nKt <= 4) {
@@ -979,7 +1005,9 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch32(a.wd) + conv_pitch32(a.cnn.F)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tile of %zu bytes exceeds the LDS", lds);
   const int nFt = (a.cnn.F + 15) / 16;
-  const void* bwd_fn = nFt == 7 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<7, false>)
+  const bool tail = a.cnn.F == 100;   // 6 K groups + a 4-filter tail in (a)
+  const void* bwd_fn = tail ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<6, false, 1>)
+                       : nFt == 7 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<7, false>)
                        : nFt <= 4 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<4, true>)
                                   : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<8, true>);
   if (int rc = set_lds(bwd_fn, lds)) return rc;
@@ -990,7 +1018,8 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);
     const dim3 grid((unsigned)(a.m * nblk));
-    if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(kConvThreads), lds, st, a, nblk);
+    if (tail) hipLaunchKernelGGL((cnn_conv_bwd_kernel<6, false, 1>), grid, dim3(kConvThreads), lds, st, a, nblk);
+    else if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(kConvThreads), lds, st, a, nblk);
     else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
     else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
   }
