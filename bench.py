@@ -217,6 +217,8 @@ def measured_traffic(args, conf, d):
         table = json.load(open(path))
     except Exception:
         return None
+    if args.optimizer != "sgd" or args.large:
+        return None   # the committed PMC passes are of the sparse-SGD CiteULike-shaped runs
     key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
     ent = table.get(key)
     return ent["bytes_per_launch"] if ent else None
@@ -229,6 +231,8 @@ def rocprof_duration_ms(args, conf, d):
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
+        return None
+    if args.optimizer != "sgd" or args.large:
         return None
     key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
     us = (table.get(key) or {}).get("rocprof_avg_us")
