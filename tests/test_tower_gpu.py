@@ -684,3 +684,36 @@ def test_rowwise_tower_with_normalisation_and_bias(text_data):
     U0 = eng.U.clone()
     lm = mon.train_on_batch([u, c], [y])
     assert np.isfinite(lm) and torch.equal(eng.U, U0)
+
+
+@pytest.mark.parametrize("model", ["mf", "basic_embedding"])
+def test_row_order_does_not_matter_at_baseline_shape(citeulike_data, model):
+    """Size-independent property at BASELINE's full shape (b = 512, k = 10, d = 100, 16K x 17K): the b(1+k)
+    (user, item, label) rows of an `original` batch give the same loss and the same updated parameters
+    whether they arrive positives-first (per-positive kernels) or in any other order (row-wise kernels)."""
+    data = citeulike_data
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 10, "neg_loss_weight": 128,
+          "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 512,
+          "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6, "word_emb_dropout_rate": 0.,
+          "interaction_bias": None}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2) for _ in range(2)]
+    b, k = 512, 10
+    rs = np.random.RandomState(3)
+    n_items = data["C"].shape[0]
+    for step in range(2):
+        bt = data["train"][rs.choice(len(data["train"]), b, replace=False)]
+        u, c, y = so.assemble_original(bt, rs.randint(0, n_items, b * k), "skip-gram")
+        perm = rs.permutation(b * (1 + k))
+        l0 = mds[0]["model"].train_on_batch([u, c], [y])
+        l1 = mds[1]["model"].train_on_batch([u[perm], c[perm]], [y[perm]])
+        assert abs(l0 - l1) <= 1e-5 * max(1, abs(l0)), (step, l0, l1)
+    e0, e1 = mds[0]["model"].engine, mds[1]["model"].engine
+    np.testing.assert_allclose(e0.U.cpu().numpy(), e1.U.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    if model == "mf":
+        np.testing.assert_allclose(e0.V.cpu().numpy(), e1.V.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        t0, t1 = mds[0]["model"].core.tower, mds[1]["model"].core.tower
+        for name in ("W", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(t0, name).cpu().numpy(), getattr(t1, name).cpu().numpy(), rtol=1e-4, atol=2e-6,
+                                       err_msg=name)
