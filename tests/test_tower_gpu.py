@@ -717,3 +717,42 @@ def test_row_order_does_not_matter_at_baseline_shape(citeulike_data, model):
         for name in ("W", "Wd", "gamma", "beta"):
             np.testing.assert_allclose(getattr(t0, name).cpu().numpy(), getattr(t1, name).cpu().numpy(), rtol=1e-4, atol=2e-6,
                                        err_msg=name)
+
+
+@pytest.mark.parametrize("model,scheme", [("basic_embedding", "neg_shared"), ("cnn_embedding", "group_neg_shared"),
+                                          ("cnn_embedding", "original")])
+def test_steps_are_bitwise_reproducible_at_baseline_shape(citeulike_data, model, scheme):
+    """No float atomics, fixed summation orders, and a conv-backward piece queue whose pieces do not depend on
+    which wave computes them: two fresh models fed the same batches end up bit-identical (BASELINE shape)."""
+    data = citeulike_data
+    loss = "log-loss" if scheme == "group_neg_shared" else "skip-gram"
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": loss, "num_negatives": 10 if scheme == "original" else 0,
+          "neg_loss_weight": 128, "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
+          "batch_size_p": 512, "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6,
+          "word_emb_dropout_rate": 0.5, "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    key = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]
+    b, k = 512, conf.num_negatives
+    n_items = data["C"].shape[0]
+    outs = []
+    for run in range(2):
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
+        head = md[key]
+        rs = np.random.RandomState(11)
+        losses = []
+        for step in range(3):
+            bt = data["train"][rs.choice(len(data["train"]), b, replace=False)]
+            if scheme == "group_neg_shared":
+                bt[:, 1] = np.repeat(bt[::4, 1], 4)
+            if scheme == "original":
+                u, c, y = so.assemble_original(bt, rs.randint(0, n_items, b * k), loss)
+            else:
+                u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            losses.append(head.train_on_batch([u, c], [y]))
+        tw = head.core.tower
+        names = ("W", "Wd", "bd", "gamma", "beta", "rm", "rv") + (("Wc", "bc", "g1", "b1") if model == "cnn_embedding" else ())
+        outs.append((losses, head.engine.U.clone(), {n: getattr(tw, n).clone() for n in names}))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    for n, v in outs[0][2].items():
+        assert torch.equal(v, outs[1][2][n]), n
