@@ -18,6 +18,7 @@ python3 bench.py --scheme group_neg_shared --cpu-seconds 6 --steps 1170 2>/dev/n
 python3 bench.py --scheme original --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_original.json
 python3 bench.py --optimizer adam --cpu-seconds 0 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_adam.json
 python3 bench.py --model cnn_embedding --scheme group_neg_shared --cpu-seconds 8 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared.json
+python3 bench.py --model cnn_embedding --scheme group_neg_shared --optimizer adam --cpu-seconds 0 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared_adam.json
 python3 bench.py --model mf --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared.json
 python3 bench.py --model mf --scheme original --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_original.json
 python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_group_neg_shared.json
