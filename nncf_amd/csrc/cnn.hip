@@ -18,9 +18,10 @@
 //   cnn_conv_bwd    dY = BN backward of da -> LDS; dX = sum_tap dY(shifted).Wk[tap]^T (MFMA) -> HBM;
 //                   partial dWk[tap] = X(shifted)^T.dY (MFMA) per workgroup
 //   cnn_presum      per item: dX rows summed per distinct word (static sorted-position index)
-//   cnn_update      dWk partials summed in workgroup order; SGD / Adam on Wk (+ transposed copy),
-//                   conv bias, BN1 gamma / beta
-//   tower_word_kernel (tower.hip) then reduces the per-(item, word) rows per word as for MeanPool.
+//   tower_word_kernel (tower.hip) then reduces the per-(item, word) rows per word as for MeanPool; extra
+//                   workgroups of the same launch (cnn_update_block, tower.h) sum the dWk partials in
+//                   workgroup order and take the SGD / Adam step on Wk (+ transposed copy), conv bias,
+//                   BN1 gamma / beta -- disjoint parameters, one launch less
 // Everything has a fixed summation order (no float atomics); conv dropout is a counter-based hash.
 #include <type_traits>
 
@@ -854,70 +855,6 @@ __global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
   }
 }
 
-// Weight-gradient partials [nparts][nel] -> sums in partial order.  128 elements x 8 part-groups per
-// workgroup: part-group g adds parts g, g+8, ... (16 loads in flight), the groups are combined in
-// group order through LDS.  The last workgroup handles the conv bias and the BN1 scale / shift.
-__global__ void __launch_bounds__(1024) cnn_update_kernel(TowerArgs a, int nblk) {
-  __shared__ float sG[8 * 128];
-  const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
-  const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x blocks, contiguous
-  const int nb = (nel + 127) / 128;
-  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
-  if ((int)blockIdx.x < nb) {
-    const int el = blockIdx.x * 128 + c;
-    float acc = 0.f;
-    if (el < nel) {
-      for (int p0 = g; p0 < nparts; p0 += 8 * 16) {
-        float u[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[e] = (p0 + 8 * e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + 8 * e) * nel + el] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc += u[e];
-      }
-    }
-    sG[g * 128 + c] = acc;
-    __syncthreads();
-    if (g == 0 && el < nel) {
-      float gsum = 0.f;
-#pragma unroll
-      for (int gg = 0; gg < 8; ++gg) gsum += sG[gg * 128 + c];
-      if (a.gexp) {  // data-parallel step: the gradient leaves, nothing is applied here
-        a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + el] = gsum;
-        return;
-      }
-      const float nw = a.opt ? adam1(gsum, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * gsum;
-      a.cnn.Wk[el] = nw;
-      const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
-      a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + k] = nw;
-    }
-    return;
-  }
-  float acc = 0.f;
-  for (int p = g; p < nparts; p += 8) acc += a.cnn.gbpart[(int64_t)p * 128 + c];
-  sG[g * 128 + c] = acc;
-  __syncthreads();
-  if (g != 0 || c >= F) return;
-  float gb = 0.f;
-#pragma unroll
-  for (int gg = 0; gg < 8; ++gg) gb += sG[gg * 128 + c];
-  const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
-  if (a.gexp) {
-    float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + nel;
-    gd[c] = gb;
-    gd[128 + c] = d2;
-    gd[256 + c] = d1;
-  } else if (a.opt) {
-    float *mm = a.cnn.mC + nel, *vv = a.cnn.vC + nel;
-    a.cnn.bc[c] = adam1(gb, mm + c, vv + c, a.cnn.bc[c], a);
-    a.cnn.g1[c] = adam1(d2, mm + 128 + c, vv + 128 + c, a.cnn.g1[c], a);
-    a.cnn.b1[c] = adam1(d1, mm + 256 + c, vv + 256 + c, a.cnn.b1[c], a);
-  } else {
-    a.cnn.bc[c] -= a.lr * gb;
-    a.cnn.g1[c] -= a.lr * d2;
-    a.cnn.b1[c] -= a.lr * d1;
-  }
-}
-
 __global__ void cnn_transpose_kernel(CnnArgs c, int wd) {
   const int nel = c.fl * wd * c.F, el = blockIdx.x * blockDim.x + threadIdx.x;
   if (el < nel) {
@@ -1026,11 +963,6 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   {
     ProfScope _ps("cnn_presum_kernel", st);
     hipLaunchKernelGGL(cnn_presum_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
-  }
-  {
-    ProfScope _ps("cnn_update_kernel", st);
-    const int nel = fl * a.wd * a.cnn.F;
-    hipLaunchKernelGGL(cnn_update_kernel, dim3((nel + 127) / 128 + 1), dim3(1024), 0, st, a, nblk);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -152,6 +152,76 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* counter) {
 }  // namespace nncf
 
 // ---- the tower object --------------------------------------------------------------------------
+namespace nncf {
+// Conv weight update as workgroups of the word kernel's launch (512 threads = 4 part-groups x 128
+// elements): the dWk partials [nparts][nel] of the conv backward are summed in partial order --
+// part-group g adds parts g, g+4, ... (16 loads in flight), the groups are combined in group order
+// through LDS -- and the SGD / Adam step is taken on Wk (+ its transposed copy).  Block nb (the last)
+// handles the conv bias and the BN1 scale / shift.  sG: 4 x 128 floats of LDS.
+constexpr int kCnnUpdGroups = 4;
+__device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, float* sG) {
+  const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
+  const int nblk = (a.L + kConvLB - 1) / kConvLB;
+  const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x position blocks, contiguous
+  const int nb = (nel + 127) / 128;
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+  if (blk < nb) {
+    const int el = blk * 128 + c;
+    float acc = 0.f;
+    if (el < nel) {
+      for (int p0 = g; p0 < nparts; p0 += kCnnUpdGroups * 16) {
+        float u[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          u[e] = (p0 + kCnnUpdGroups * e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + kCnnUpdGroups * e) * nel + el] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += u[e];
+      }
+    }
+    sG[g * 128 + c] = acc;
+    __syncthreads();
+    if (g == 0 && el < nel) {
+      float gsum = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < kCnnUpdGroups; ++gg) gsum += sG[gg * 128 + c];
+      if (a.gexp) {  // data-parallel step: the gradient leaves, nothing is applied here
+        a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + el] = gsum;
+        return;
+      }
+      const float nw = a.opt ? adam1(gsum, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * gsum;
+      a.cnn.Wk[el] = nw;
+      const int f = el % F, k = (el / F) % a.wd, tap = el / (F * a.wd);
+      a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + k] = nw;
+    }
+    return;
+  }
+  float acc = 0.f;
+  for (int p = g; p < nparts; p += kCnnUpdGroups) acc += a.cnn.gbpart[(int64_t)p * 128 + c];
+  sG[g * 128 + c] = acc;
+  __syncthreads();
+  if (g != 0 || c >= F) return;
+  float gb = 0.f;
+#pragma unroll
+  for (int gg = 0; gg < kCnnUpdGroups; ++gg) gb += sG[gg * 128 + c];
+  const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
+  if (a.gexp) {
+    float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + nel;
+    gd[c] = gb;
+    gd[128 + c] = d2;
+    gd[256 + c] = d1;
+  } else if (a.opt) {
+    float *mm = a.cnn.mC + nel, *vv = a.cnn.vC + nel;
+    a.cnn.bc[c] = adam1(gb, mm + c, vv + c, a.cnn.bc[c], a);
+    a.cnn.g1[c] = adam1(d2, mm + 128 + c, vv + 128 + c, a.cnn.g1[c], a);
+    a.cnn.b1[c] = adam1(d1, mm + 256 + c, vv + 256 + c, a.cnn.b1[c], a);
+  } else {
+    a.cnn.bc[c] -= a.lr * gb;
+    a.cnn.g1[c] -= a.lr * d2;
+    a.cnn.b1[c] -= a.lr * d1;
+  }
+}
+}  // namespace nncf
+
 struct nncf_tower {
   nncf_tower_cfg cfg;
   nncf_tower_params prm;

@@ -530,15 +530,24 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
   __shared__ int sHit[kWordsPerWG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = (a.n_words + kWordsPerWG - 1) / kWordsPerWG;
-  if ((int)blockIdx.x >= G) {
-    const int el = ((int)blockIdx.x - G) * 512 + tid, nel = a.hd * a.d;
+  // CNN tower: the first workgroups of the grid sum the dWk partials and update the conv weights, conv
+  // bias and BN1 scale / shift (parameters nobody else in this launch touches).  First, because their
+  // chain of partial loads is the longest in the launch: they run under the word workgroups.
+  const int ncnn = CNN ? (a.cnn.fl * a.wd * a.cnn.F + 127) / 128 + 1 : 0;
+  if (CNN && (int)blockIdx.x < ncnn) {
+    cnn_update_block(a, (int)blockIdx.x, reinterpret_cast<float*>(sAccW));
+    return;
+  }
+  const int bid = (int)blockIdx.x - ncnn;
+  if (bid >= G) {
+    const int el = (bid - G) * 512 + tid, nel = a.hd * a.d;
     if (el < nel) {
       float g = 0.f;
       for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
       if (a.gexp) a.gexp[(size_t)a.n_words * a.wd + el] = g;
       else a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
     }
-    if ((int)blockIdx.x == G && tid < a.d) {
+    if (bid == G && tid < a.d) {
       float gb = 0.f;
       for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
       float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
@@ -563,7 +572,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
   }
   if (a.skip_words) return;
   const int n = valid_rows(a), d2 = a.wd >> 1;
-  const int my_w = blockIdx.x + wave * G;  // the word this wave finishes
+  const int my_w = bid + wave * G;  // the word this wave finishes
   float2 wold = make_float2(0.f, 0.f);
   if (my_w < a.n_words && lane < d2) wold = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
   if (tid < kWordsPerWG) sHit[tid] = 0;
@@ -582,7 +591,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     unsigned c[kWordsPerWG];
 #pragma unroll
     for (int j = 0; j < kWordsPerWG; ++j) {
-      const int w = blockIdx.x + j * G;
+      const int w = bid + j * G;
       c[j] = (w < a.n_words && slot < n) ? a.cnt_t[(int64_t)w * a.cap + slot] : 0u;
     }
     // list the non-zero cells word by word (ballot + prefix count); the list holds kListCap
@@ -644,7 +653,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       const int pc = __popcll(mask);
       if (cnt + pc > kListCap) drain();
       if (c[j]) {
-        a.cnt_t[(int64_t)(blockIdx.x + j * G) * a.cap + slot] = 0;
+        a.cnt_t[(int64_t)(bid + j * G) * a.cap + slot] = 0;
         list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (slot << 8) | (int)c[j];
       }
       if (mask && lane == 0) sHit[j] = 1;
@@ -875,7 +884,8 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   {
     ProfScope _ps("tower_word_kernel", st);
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
-    if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    const int ncnn = a.cnn.F > 0 ? (a.cnn.fl * a.wd * a.cnn.F + 127) / 128 + 1 : 0;   // cnn_update_block workgroups
+    if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
