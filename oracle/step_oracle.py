@@ -10,15 +10,20 @@ Follows (all paths under /root/reference):
   utils/utilities.py:74-83,122-135   K.diag via gather_nd; L1L2Act activity regulariser
   models/train_{original,neg_shared,group_neg_shared}.py   batch assembly conventions
 
-Parity status: UNPINNED by the reference.  The Keras-1.2.2 / TF-1.0 half of the reference can
-neither be imported nor installed here and ships no tests or golden
-vectors, so this restatement is pinned only against (a) torch-CPU autograd of the same
-formulas (tests/test_oracle_step.py) and (b) hand-computed toy cases.  Items taken from
-memory of the absent packages are marked [K-mem]:
+Parity status.  PINNED to the reference's own text: the loss factories, InteractionDot.call and the
+activity regulariser (objectives.py:15-220, interaction_dot.py:82-107, utilities.py:122-135) are
+exec'd from /root/reference by tools/gen_golden_losses.py over a primitive-op K / tf shim; their
+losses and autograd gradients (tests/golden/loss_golden.npz: 4 families x 4 losses x 7 shapes,
+float32 and float64) are what tests/test_loss_golden.py holds this file to (1e-9 in float64).
+NOT pinnable here (Keras 1.2.2 / TF 1.0 can neither be imported nor installed, SURVEY.md 8(c);
+the reference ships no tests or vectors) -- items taken from memory of the absent packages,
+marked [K-mem]:
   * tf.nn.l2_normalize(x, dim=-1) = x * rsqrt(max(sum(x^2), 1e-12))            [K-mem]
   * a custom-objective Keras model's train_on_batch returns mean(loss_tensor) + sum of
     activity-regulariser terms of the layers on the model's own graph             [K-mem]
-  * K.relu gradient at 0 is 0                                                      [K-mem]
+  * K.relu gradient at 0 is 0; K.repeat's (samples, n, dim) layout; tf.unique order [K-mem]
+  * BatchNormalization eps 1e-3 / momentum 0.99, Embedding / Dense initialisers, Embedding row
+    dropout, the Keras Adam formula (text towers and optimisers below)            [K-mem]
 The optimiser is the north-star's sparse SGD (BASELINE.json), not the reference's dense
 Adam (configs/basic_embedding_conf.py:59-60): table[row] -= lr * sum_of_row_gradients.
 -log(sigmoid(x)) is evaluated as softplus(-x) (identical wherever the reference's
@@ -68,6 +73,17 @@ def _softplus(x):
     return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
 
 
+def _f32_const(v, dt):
+    """gamma / lambda as the reference holds them: np.array(v, dtype=np.float32) (objectives.py:23,32).
+    Identity for the float32 oracle; keeps the float64 oracle on the reference's constants."""
+    return dt.type(np.float32(v))
+
+
+def _f32_ratio(v, n, dt):
+    """np.float32 array / python int stays float32 (objectives.py:60,66,100,107,143,151)."""
+    return dt.type(np.float32(v) / np.float32(n))
+
+
 def _sigmoid(x):
     # numerically stable logistic, same dtype as x
     e = np.exp(-np.abs(x))
@@ -105,7 +121,7 @@ def original_loss(s, y, conf):
     negative row j (0-based among negatives) belongs to positive j // k (K.repeat, :51-57)."""
     b, k = conf.batch_size_p, conf.num_negatives
     dt = s.dtype
-    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    lam, gamma = _f32_const(conf.neg_loss_weight, dt), _f32_const(conf.loss_gamma, dt)
     g = np.zeros_like(s)
     if conf.loss in ("max-margin", "log-loss"):
         pos, neg = s[:b], s[b:]
@@ -120,12 +136,12 @@ def original_loss(s, y, conf):
         g[b:] = -gd
         g[:b] = gd.reshape(b, k).sum(axis=1)
     elif conf.loss == "skip-gram":
-        wv = lam / dt.type(k)
+        wv = _f32_ratio(conf.neg_loss_weight, k, dt)
         w = 1 + (1 - y) / 2 * (wv - 1)                               # objectives.py:60-62
         loss = np.sum(w * _softplus(-y * s)) / dt.type(b)
         g = -w * y * _sigmoid(-y * s) / dt.type(b)
     else:  # mse
-        wv = lam / dt.type(k)
+        wv = _f32_ratio(conf.neg_loss_weight, k, dt)
         w = 1 + (1 - y) * (wv - 1)                                   # objectives.py:66-68
         loss = np.sum(w * (y - s) ** 2) / dt.type(b)
         g = 2 * w * (s - y) / dt.type(b)
@@ -138,7 +154,7 @@ def neg_shared_loss(S, conf):
     diff[i,j] = S[j,j] - S[i,j]  (objectives.py:92,97; utilities.py:74-83)."""
     b = S.shape[0]
     dt = S.dtype
-    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    lam, gamma = _f32_const(conf.neg_loss_weight, dt), _f32_const(conf.loss_gamma, dt)
     eye = np.eye(b, dtype=bool)
     if conf.loss in ("max-margin", "log-loss"):
         diff = np.diag(S)[None, :] - S
@@ -154,7 +170,7 @@ def neg_shared_loss(S, conf):
         G = -gd                                                       # through -S[i,j]
         G[np.arange(b), np.arange(b)] += gd.sum(axis=0)               # through S[j,j] (column j)
     else:
-        wv = lam / dt.type(b - 1)
+        wv = _f32_ratio(conf.neg_loss_weight, b - 1, dt)
         w = np.where(eye, dt.type(1), wv)                             # objectives.py:100-102
         if conf.loss == "skip-gram":
             label = np.where(eye, dt.type(1), dt.type(-1))            # :103
@@ -172,7 +188,7 @@ def group_neg_shared_loss(S, pos_col, conf):
     diff[i,j] = S[i,pos_i] - S[i,j]  (row-anchored, :175,196,200); num_negatives = n_u - 1 (:177)."""
     b, nu = S.shape
     dt = S.dtype
-    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    lam, gamma = _f32_const(conf.neg_loss_weight, dt), _f32_const(conf.loss_gamma, dt)
     rows = np.arange(b)
     posmask = np.zeros((b, nu), dtype=bool)
     posmask[rows, pos_col] = True
@@ -207,7 +223,7 @@ def sampled_neg_shared_loss(S, conf):
     b, k1 = S.shape
     k = k1 - 1
     dt = S.dtype
-    lam, gamma = dt.type(conf.neg_loss_weight), dt.type(conf.loss_gamma)
+    lam, gamma = _f32_const(conf.neg_loss_weight, dt), _f32_const(conf.loss_gamma, dt)
     if conf.loss in ("max-margin", "log-loss"):
         diff = S[:, :1] - S[:, 1:]
         m = dt.type(b * k)
@@ -219,7 +235,7 @@ def sampled_neg_shared_loss(S, conf):
             gd = -gamma * _sigmoid(-gamma * diff) / m
         G = np.concatenate([gd.sum(axis=1, keepdims=True), -gd], axis=1)
     else:
-        wv = lam / dt.type(k)
+        wv = _f32_ratio(conf.neg_loss_weight, k, dt)
         w = np.ones((b, k1), dtype=dt)
         w[:, 1:] = wv
         label = np.ones((b, k1), dtype=dt)
@@ -657,15 +673,17 @@ class StepOracle(object):
         raw_u = self.U[ufront]
         reg = self.dt.type(self.conf.u_reg) * np.sum(np.mean(raw_u * raw_u, axis=0))
         raw_v, hat_v, inv_v = self._item_side(cid)
-        pos = np.sum(raw_u * hat_v[:b], axis=1, keepdims=True)
-        neg = raw_u @ hat_v[b:].T
+        bu, bc = self._bias(ufront, cid)                                # interaction_dot.py:96-99,104-107
+        pos = np.sum(raw_u * hat_v[:b], axis=1, keepdims=True) + (bu + bc[:b])[:, None]
+        neg = raw_u @ hat_v[b:].T + bu[:, None] + bc[b:][None, :]
         S = np.concatenate([pos, neg], axis=1)
         loss, G = sampled_neg_shared_loss(S, self.conf)
         self.scores = S
         if update:
             g_u = G[:, :1] * hat_v[:b] + G[:, 1:] @ hat_v[b:]
             g_v = np.concatenate([G[:, :1] * raw_u, G[:, 1:].T @ raw_u], axis=0)
-            self._apply(ufront, cid, raw_u, raw_u, None, hat_v, inv_v, g_u, g_v)
+            self._apply(ufront, cid, raw_u, raw_u, None, hat_v, inv_v, g_u, g_v, G.sum(axis=1),
+                        np.concatenate([G[:, 0], G[:, 1:].sum(axis=0)]))
         self._tower_out(update)
         return float(loss + reg)
 
