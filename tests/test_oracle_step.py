@@ -31,7 +31,8 @@ def _torch_original(U, V, uid, cid, y, conf, ub=None, cb=None):
     if ub is not None:
         pred = pred + ub[uid].reshape(-1, 1) + cb[cid].reshape(-1, 1)     # interaction_dot.py:96-99
     y = y.reshape(-1, 1)
-    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    lam, gamma = float(np.float32(conf.neg_loss_weight)), float(np.float32(conf.loss_gamma))
+    lam_k = float(np.float32(conf.neg_loss_weight) / np.float32(k)) if k else 0.0   # objectives.py:60,66: float32 array / int
     pos, neg = pred[:b], pred[b:]
     if conf.loss == "max-margin":
         diff = pos.repeat(1, k).reshape(-1, 1) - neg
@@ -40,10 +41,10 @@ def _torch_original(U, V, uid, cid, y, conf, ub=None, cb=None):
         diff = pos.repeat(1, k).reshape(-1, 1) - neg
         task = (-torch.log(torch.sigmoid(gamma * diff))).mean()
     elif conf.loss == "skip-gram":
-        w = 1 + (1 - y) / 2.0 * (lam / k - 1)
+        w = 1 + (1 - y) / 2.0 * (lam_k - 1)
         task = (-w * torch.log(torch.sigmoid(y * pred))).sum() / b
     else:
-        w = 1 + (1 - y) * (lam / k - 1)
+        w = 1 + (1 - y) * (lam_k - 1)
         task = (w * (y - pred) ** 2).sum() / b
     return task + reg
 
@@ -58,7 +59,7 @@ def _torch_neg_shared(U, V, uid, cid, conf, ub=None, cb=None):
     pred = u @ v.t()
     if ub is not None:
         pred = pred + ub[uid].reshape(-1, 1) + cb[cid].reshape(1, -1)     # interaction_dot.py:104-107
-    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    lam, gamma = float(np.float32(conf.neg_loss_weight)), float(np.float32(conf.loss_gamma))
     eye = torch.eye(b, dtype=pred.dtype)
     if conf.loss == "max-margin":
         diff = torch.diagonal(pred) - pred  # (b,) - (b,b): broadcasts over rows
@@ -68,12 +69,12 @@ def _torch_neg_shared(U, V, uid, cid, conf, ub=None, cb=None):
         diff = torch.diagonal(pred) - pred
         task = (-torch.log(torch.sigmoid(gamma * diff))).mean()
     elif conf.loss == "skip-gram":
-        wv = lam / (b - 1)
+        wv = float(np.float32(conf.neg_loss_weight) / np.float32(b - 1))   # objectives.py:100,107
         w = eye * (1 - wv) + wv
         label = 2 * eye - 1
         task = (-w * torch.log(torch.sigmoid(label * pred))).sum() / b
     else:
-        wv = lam / (b - 1)
+        wv = float(np.float32(conf.neg_loss_weight) / np.float32(b - 1))   # objectives.py:100,107
         w = eye * (1 - wv) + wv
         task = (w * (pred - eye) ** 2).sum() / b
     return task + reg
@@ -90,7 +91,7 @@ def _torch_group(U, V, uid, cid_u, cid_x, conf, ub=None, cb=None):
     if ub is not None:
         pred = pred + ub[uid].reshape(-1, 1) + cb[cid_u].reshape(1, -1)
     nu = pred.shape[1]
-    lam, gamma = conf.neg_loss_weight, conf.loss_gamma
+    lam, gamma = float(np.float32(conf.neg_loss_weight)), float(np.float32(conf.loss_gamma))
     rows = torch.arange(b)
     pred_pos = pred[rows, cid_x].reshape(-1, 1)
     mask = torch.zeros_like(pred)
