@@ -41,7 +41,8 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node (default: WORLD_SIZE, else 1); > 1 without a "
+                    "torchrun environment: bench.py starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=3900)     # 10 epochs of 390 steps
     ap.add_argument("--warmup", type=int, default=390)
     ap.add_argument("--scheme", default="neg_shared", choices=["original", "neg_shared", "group_neg_shared"])
@@ -64,6 +65,9 @@ def parse():
                     help="sgd = the north-star's sparse SGD (headline); adam = Keras Adam, the reference's dense "
                          "default; sparse_adam = utils/optimizer.py")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--recall-epochs", type=int, default=30,
+                    help="epochs of the side run that reports Recall@50 of a TRAINED model (Keras Adam, the reference's "
+                         "optimiser; 30 = the demo scripts' max_epoch); 0 = skip")
     ap.add_argument("--profile-launches", type=int, default=1000)
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
@@ -85,12 +89,18 @@ def param_dict_for(args):
             "conv_dropout_rate": args.conv_dropout}
 
 
-def conf_for(args):
-    from oracle.step_oracle import OracleConf  # only for the cpu_baseline leg
+def oracle_conf_for(args):
+    """OracleConf of the run -- ONLY for the cpu_baseline leg (the product path takes nncf_amd.conf.get_conf)."""
+    from oracle.step_oracle import OracleConf
     pd = param_dict_for(args)
     return OracleConf(batch_size_p=pd["batch_size_p"], num_negatives=pd["num_negatives"], loss=pd["loss"],
                       loss_gamma=pd["loss_gamma"], neg_loss_weight=pd["neg_loss_weight"], u_reg=pd["u_reg"],
                       learn_rate=pd["learn_rate"], model_choice=args.model, optimizer=args.optimizer)
+
+
+def product_conf(args):
+    from nncf_amd.conf import get_conf
+    return get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice=args.model)
 
 
 def make_large(args):
@@ -143,47 +153,119 @@ def build_inputs(args, conf, rank, world):
     return dict(users=users, items=items, uid=stream[:, 0], cid=stream[:, 1], dist=dist, data=data)
 
 
-def cpu_baseline(args, conf, inp, U0, V0, tower_params):
-    """numpy oracle of the same step on the host cores, bounded sample."""
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, inp, U0, V0, tower_params):
+    """the CPU restatement of the same step on this box's host cores, bounded sample.
+    basic_embedding / mf: oracle/step_torch.py (torch-CPU graph + autograd, as the reference's Keras-CPU path
+    runs it) at all cores and at 1 thread; cnn_embedding: the numpy oracle.  Plus the C restatement of the
+    sampler (oracle/nodesampler_oracle.c) on one core -- the reference sampler is single-threaded."""
     from oracle import step_oracle as so
     from oracle.sampler_oracle import OracleSampler
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    tower = None
-    if tower_params is not None:
-        cls = so.CnnTowerOracle if args.model == "cnn_embedding" else so.TowerOracle
-        tower = cls(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
-    o = so.StepOracle(U0, V0, conf, dtype=np.float32, tower=tower)
+    import torch
+    conf = oracle_conf_for(args)
+    nproc = os.cpu_count() or 1
     b, k = conf.batch_size_p, conf.num_negatives
-    sampler = OracleSampler(inp["dist"], 1.0, 12345) if args.scheme == "original" else None
+    budget = args.cpu_seconds
+    max_steps = min(args.steps + args.warmup, len(inp["uid"]) // b)
+    drop = args.dropout if tower_params is not None else 0.0
+    sampler = OracleSampler(inp["dist"], 1.0, 12345)
     t0 = time.time()
-    steps = 0
-    max_steps = min(args.steps, len(inp["uid"]) // b)
-    drop = args.dropout if tower is not None else 0.0
-    mask_rs = np.random.RandomState(29)
-    while steps < max_steps and (time.time() - t0 < args.cpu_seconds or steps < 5):
-        if drop > 0:   # Embedding(dropout): a fresh row mask per batch (mean_pool.py:56-59)
-            o.row_scale = ((mask_rs.rand(tower.W.shape[0]) < 1 - drop) / (1 - drop)).astype(np.float32)
-        if args.model == "cnn_embedding" and args.conv_dropout > 0:   # Dropout(conv_dropout_rate), cnn_model.py:97
-            kc = 1 - args.conv_dropout
-            tower.conv_mask = ((mask_rs.rand(b * (1 + k), tower.C.shape[1], tower.Wc.shape[2]) < kc) / kc).astype(np.float32)
-        u = inp["uid"][steps * b:(steps + 1) * b]
-        c = inp["cid"][steps * b:(steps + 1) * b]
-        if args.scheme == "original":
-            negs = sampler.sample_batch(b * k)
-            uu, cc, yy = so.assemble_original(np.stack([u, c, np.ones(b, dtype=np.int64)], 1), negs, conf.loss)
-            o.step_original(uu, cc, yy)
-        elif args.scheme == "neg_shared":
-            o.step_neg_shared(u, c)
-        else:
-            o.step_group_neg_shared(u, c)
-        steps += 1
-    dt = time.time() - t0
-    return {"value": steps * b / dt, "unit": "positive-links/s", "cores": int(cores), "kind": "port",
-            "sample": "%d steps of the same %s/%s workload (numpy fp32 oracle, %.1f s)" % (steps, args.model, args.scheme, dt)}
+    draws = 0
+    while time.time() - t0 < min(2.0, budget / 6):
+        sampler.sample_batch(1 << 20)
+        draws += 1 << 20
+    sampler_rate = draws / (time.time() - t0)
+
+    def batches(stepper, seconds, mask_words):
+        mask_rs = np.random.RandomState(29)
+        t0 = time.time()
+        steps = 0
+        while steps < max_steps and (time.time() - t0 < seconds or steps < 3):
+            if drop > 0:   # Embedding(dropout): a fresh row mask per batch (mean_pool.py:56-59)
+                stepper.row_scale = ((mask_rs.rand(mask_words) < 1 - drop) / (1 - drop)).astype(np.float32)
+            u = inp["uid"][steps * b:(steps + 1) * b]
+            c = inp["cid"][steps * b:(steps + 1) * b]
+            if args.scheme == "original":
+                negs = sampler.sample_batch(b * k)
+                uu, cc, yy = so.assemble_original(np.stack([u, c, np.ones(b, dtype=np.int64)], 1), negs, conf.loss)
+                stepper.step_original(uu, cc, yy)
+            elif args.scheme == "neg_shared":
+                stepper.step_neg_shared(u, c)
+            else:
+                stepper.step_group_neg_shared(u, c)
+            steps += 1
+        return steps, time.time() - t0
+
+    if args.model == "cnn_embedding":
+        tower = so.CnnTowerOracle(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
+        o = so.StepOracle(U0, None, conf, dtype=np.float32, tower=tower)
+        kc = 1 - args.conv_dropout
+        if args.conv_dropout > 0:   # Dropout(conv_dropout_rate), cnn_model.py:97: one fixed mask (timing only)
+            tower.conv_mask = ((np.random.RandomState(3).rand(b * (1 + k), tower.C.shape[1], tower.Wc.shape[2]) < kc) / kc).astype(np.float32)
+        steps, dt = batches(o, budget, tower.W.shape[0])
+        return {"value": steps * b / dt, "unit": "positive-links/s", "cores": int(nproc), "kind": "port",
+                "cpu_model": cpu_model_name(), "sampler_samples_per_s_1core": sampler_rate,
+                "sample": "%d steps of the same %s/%s workload (numpy fp32 oracle, BLAS threads = all cores, %.1f s)"
+                          % (steps, args.model, args.scheme, dt)}
+    from oracle.step_torch import TorchStep
+    tower = None
+    words = 0
+    if tower_params is not None:
+        tower = dict(zip(("W", "Wd", "bd", "gamma", "beta"), tower_params), C=inp["data"]["C"])
+        words = tower["W"].shape[0]
+    res = {}
+    prev = torch.get_num_threads()
+    for label, threads in (("all", nproc), ("one", 1)):
+        st = TorchStep(U0, V0 if tower is None else None, conf, tower=tower, threads=threads)
+        res[label] = batches(st, budget / 2.0, words)
+    torch.set_num_threads(prev)
+    (sa, ta), (s1, t1) = res["all"], res["one"]
+    return {"value": sa * b / ta, "unit": "positive-links/s", "cores": int(nproc), "kind": "port",
+            "value_1thread": s1 * b / t1, "cpu_model": cpu_model_name(), "sampler_samples_per_s_1core": sampler_rate,
+            "sample": "CPU restatement of the reference path (Keras 1.2.2 / TF 1.0 not runnable): torch-CPU graph + autograd "
+                      "of the same %s/%s step (oracle/step_torch.py), %d steps at %d threads in %.1f s, %d steps at 1 thread "
+                      "in %.1f s; sampler = oracle/nodesampler_oracle.c on one core" % (args.model, args.scheme, sa, nproc, ta, s1, t1)}
+
+
+def trained_recall(args, data, device):
+    """Second half of BASELINE's metric on a TRAINED state: a fresh model of the same configuration, trained
+    through the product Trainer (models/train_*.py mirror) for --recall-epochs epochs with the reference's
+    optimiser (Keras Adam(learn_rate), basic_embedding_conf.py:59-60), then whole@50 on the GPU evaluator.
+    Outside every timed region."""
+    import contextlib
+    import importlib
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    pd = dict(param_dict_for(args), optimizer="adam", max_epoch=int(args.recall_epochs))
+    conf = get_conf("synthetic_citeulike", "best", pd, model_choice=args.model)
+    conf.eval_topk = 50
+    d2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in data.items()}
+    t0 = time.time()
+    with contextlib.redirect_stdout(sys.stderr if os.environ.get("NNCF_BENCH_TRACE") == "1" else open(os.devnull, "w")):
+        helper = get_data(d2, conf, rand_seed=12345, device=device)
+        md = get_model(conf, helper, args.model, device=device, seed=0)
+        Trainer = importlib.import_module("nncf_amd.train_" + args.scheme).Trainer
+        np.random.seed(4224)
+        tr = Trainer(md, conf, helper)
+        tr.train(None)
+        tr_res, te_res = tr.evaluater.run(md["model_neg_shared"], verbose=False, eval_scheme="whole")
+    return {"train": float(tr_res["recall@50"]), "test_cold_items": float(te_res["recall@50"]),
+            "optimizer": "adam (Keras Adam(%g), the reference's optimiser)" % conf.learn_rate,
+            "epochs": int(args.recall_epochs), "steps_per_epoch": len(d2["train"]) // conf.batch_size_p,
+            "train_scheme": args.scheme, "train_seconds_per_epoch": float(np.mean(tr.train_time)) if tr.train_time else None,
+            "wall_seconds": time.time() - t0,
+            "note": "whole@50 (objectives.py:296-370,395-421) of a model trained by nncf_amd.train_%s.Trainer on the same "
+                    "synthetic data; test items are cold (seen only through their text)" % args.scheme}
 
 
 _T0 = time.time()
@@ -208,34 +290,36 @@ def emit(line):
     print(json.dumps(line), flush=True)
 
 
-def measured_traffic(args, conf, d):
-    """Bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, KiB -> bytes),
-    when one exists for exactly this workload; else None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        table = json.load(open(path))
-    except Exception:
-        return None
-    if args.optimizer != "sgd" or args.large:
-        return None   # the committed PMC passes are of the sparse-SGD CiteULike-shaped runs
-    key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
-    ent = table.get(key)
-    return ent["bytes_per_launch"] if ent else None
-
-
-def rocprof_duration_ms(args, conf, d):
-    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of
-    this workload (profiles/traffic.json carries it next to the PMC bytes), for comparison with the live
-    event-bracket figure; None when there is no committed profile of exactly this workload."""
+def _profile_entry(args, conf, d, kernel):
+    """profiles/traffic.json (tools/make_traffic.py, from the committed rocprofv3 passes of the newest round):
+    entry of exactly this workload and kernel, or None."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
     if args.optimizer != "sgd" or args.large:
-        return None
+        return None   # the committed passes are of the sparse-SGD CiteULike-shaped runs
     key = "%s/%s/%s/b%d/d%d%s" % (args.model, args.scheme, conf.loss, conf.batch_size_p, d, "/small" if args.small else "")
-    us = (table.get(key) or {}).get("rocprof_avg_us")
+    ent = table.get(key) or {}
+    import __graft_entry__ as ge
+    if ent.get("csrc_hash") != ge._source_hash():
+        return None   # profiled before the kernel sources changed: stale, fall back to the live bracket
+    if ent.get("kernel", kernel) == kernel:
+        return ent
+    return (ent.get("kernels") or {}).get(kernel)
+
+
+def measured_traffic(args, conf, d, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE with the
+    gfx950 corrections of MI355X_MICROARCH.md), or None."""
+    ent = _profile_entry(args, conf, d, kernel)
+    return ent.get("bytes_per_launch") if ent else None
+
+
+def rocprof_duration_ms(args, conf, d, kernel):
+    """Average duration (ms) of `kernel` in the committed rocprofv3 --kernel-trace --stats summary, or None."""
+    ent = _profile_entry(args, conf, d, kernel)
+    us = ent.get("rocprof_avg_us") if ent else None
     return us * 1e-3 if us else None
 
 
@@ -246,7 +330,6 @@ def main_data_parallel(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
     from nncf_amd import engine as nengine
-    from nncf_amd.conf import get_conf
     from nncf_amd.data_utils import get_data
     from nncf_amd.model_framework import get_model
     from nncf_amd.sharded import DataParallelTower, HipTowerReplica, partition_links_by_user
@@ -254,7 +337,7 @@ def main_data_parallel(args, rank, world, local_rank):
     data = make_data(args)
     trace("data made")
     users = int(data["train"][:, 0].max()) + 1
-    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice=args.model)
+    pconf = product_conf(args)
     b, d = pconf.batch_size_p, args.dim
     mine = partition_links_by_user(data["train"], users, world)[rank].copy()
     rs = np.random.RandomState(4224 + rank)
@@ -309,7 +392,7 @@ def main_data_parallel(args, rank, world, local_rank):
     nengine.profile_begin(name, prof_n)
     run(W, prof_n, False)
     raw_ms, launches, ov_ms = nengine.profile_end()
-    kern_ms = max(raw_ms - ov_ms, 1e-9)
+    kern_ms = raw_ms   # raw event bracket (includes the marker packets' own cost: errs on the slow side)
     if name.startswith("cnn_conv"):   # n_u = unique items of the bracketed steps (counted here from the id stream)
         n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
         mult = 2 if name == "cnn_conv_fwd_kernel" else 4
@@ -361,7 +444,6 @@ def main_sharded(args, conf, rank, world, local_rank):
         raise SystemExit("--gpus > 1 is built for the text-tower models (data parallel) and --model mf (item-sharded)")
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
-    conf = conf_for(args)
     data = make_data(args)   # --large: BASELINE configs[3], 10M users x 1M items (only the links the run consumes)
     users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
     b, d = conf.batch_size_p, args.dim
@@ -374,9 +456,10 @@ def main_sharded(args, conf, rank, world, local_rank):
         chunks.append(mine.copy())
         have += len(mine)
     stream = np.concatenate(chunks, 0)[:need]
+    norm = bool(conf.emb_normalization)
     kw = dict(user_count=users, item_count=items, dim=d, batch_size_p=b, num_negatives=0, loss=conf.loss,
               loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
-              learn_rate=conf.learn_rate, normalize_user=conf.normalize_user, normalize_item=conf.normalize_item)
+              learn_rate=abs(conf.learn_rate), normalize_user=norm, normalize_item=False)   # mf: model_framework.py:85-88
     us, isz = shard_size(users, world), shard_size(items, world)
     be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank,
                     world=world, item_shard=isz, item_offset=rank * isz, seed=rank)
@@ -428,13 +511,133 @@ def main_sharded(args, conf, rank, world, local_rank):
     dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: this process never touches a GPU (no torch device
+    call, the build runs in a child) -- it starts N fresh rank processes with
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`,
+    lets their stderr through, relays rank 0's ONE JSON line and exits non-zero if any rank failed
+    or no line came back.  Never os.exec*: the ranks are children."""
+    import socket
+    import subprocess
+    n = int(args.gpus)
+    if os.environ.get("NNCF_BENCH_DRYRUN") != "1":
+        rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as g; g.build(quiet=True)"], cwd=ROOT)
+        if rc:
+            raise SystemExit("bench.py: building the HIP extension failed (exit %d)" % rc)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    trace("launching %d ranks: %s" % (n, " ".join(cmd)))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd(), universal_newlines=True)
+    line = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                line = json.loads(t)
+            except ValueError:
+                sys.stderr.write(ln)
+        else:
+            sys.stderr.write(ln)   # RCCL banners and the like: not the result line
+    rc = p.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: a rank failed (torch.distributed.run exit code %d)" % rc)
+    if line is None:
+        raise SystemExit("bench.py: the ranks finished but rank 0 printed no result line")
+    if line.get("n_gpus") != n:
+        raise SystemExit("bench.py: asked for %d GPUs, the ranks report n_gpus = %r" % (n, line.get("n_gpus")))
+    emit(line)
+
+
+class _NullBackend(object):
+    """NNCF_BENCH_DRYRUN=1 (no GPU: launcher / rendezvous / timing-contract check on a CPU box): the
+    backend interface of nncf_amd/sharded.py with no arithmetic at all -- CPU tensors of the real
+    shapes, so ShardedNegShared.step runs its three all-to-alls over gloo."""
+
+    def __init__(self, b, d, world):
+        import torch
+        self.b, self.cap, self.world = b, b, world
+        self.req = torch.full((world * b,), -1, dtype=torch.int32)
+        self.slot = torch.zeros(b, dtype=torch.int32)
+        self.rows_in = torch.zeros(world * b, d)
+        self.rows_out = torch.zeros(world * b, d)
+        self.g_out = torch.zeros(world * b, d)
+        self._loss = torch.zeros(1)
+
+    def route(self, cid):
+        return self.req, self.slot
+
+    def gather_rows(self, req_in):
+        return self.rows_out
+
+    def rows_landing(self):
+        return self.rows_in
+
+    def local_step(self, uid_local, slot):
+        return self._loss, self.g_out
+
+    def scatter_apply(self, req_in, g_in):
+        pass
+
+
+def main_dryrun(args, rank, world):
+    """The N-rank contract without a GPU: gloo process group, W untimed + K timed global steps of the
+    exchange pattern alone (no kernels -> "value" is null), barrier on both sides, MAX over ranks,
+    rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    from nncf_amd.sharded import ShardedNegShared
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("NNCF_BENCH_DRYRUN_FAIL") == str(rank):   # launcher test: a rank that dies
+        raise SystemExit(3)
+    b, d = args.batch, args.dim
+    tr = ShardedNegShared(_NullBackend(b, d, world), 16000, 17000, b, d)
+    ids = torch.zeros(b, dtype=torch.int32)
+    W, K = args.warmup, args.steps
+    for _ in range(W):
+        tr.step(ids, ids)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        tr.step(ids, ids)
+    t1 = time.perf_counter()
+    dist.barrier()
+    t = torch.tensor([t1 - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        emit({"metric": "positive-links/sec (train step)", "value": None, "unit": "positive-links/s", "n_gpus": world,
+              "steps": K, "warmup": W, "ms_per_step": float(t.item()) / max(K, 1) * 1e3, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True,
+              "config": {"workload": "NNCF_BENCH_DRYRUN: exchange pattern of the item-sharded step over gloo, no kernels",
+                         "global_batch": b * world, "parallelism": "1 process per rank (CPU, gloo)"},
+              "roofline": None, "cpu_baseline": None})
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.large:
         args.model, args.dim = "mf", 128
+    in_torchrun = "WORLD_SIZE" in os.environ
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if not in_torchrun and args.gpus > 1:
+        return launch_ranks(args)        # parent: starts the ranks, relays rank 0's line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
+    if os.environ.get("NNCF_BENCH_DRYRUN") == "1":
+        return main_dryrun(args, rank, world)
     # build (make: a child process) BEFORE anything initialises the GPU in this process
     import __graft_entry__ as ge
     if local_rank == 0:
@@ -457,16 +660,15 @@ def main():
         trace("process group up")
     from nncf_amd.sampler import MultinomialSampler
 
-    conf = conf_for(args)
+    pconf = product_conf(args)
+    conf = pconf
     if dist_on:
-        return main_sharded(args, conf, rank, world, local_rank)
-    inp = build_inputs(args, conf, rank, world)
-    b, k, d = conf.batch_size_p, conf.num_negatives, args.dim
-    from nncf_amd.conf import get_conf
+        return main_sharded(args, pconf, rank, world, local_rank)
+    inp = build_inputs(args, pconf, rank, world)
+    b, k, d = pconf.batch_size_p, pconf.num_negatives, args.dim
     from nncf_amd.data_utils import get_data
     from nncf_amd.model_framework import get_model
     from nncf_amd import engine as nengine
-    pconf = get_conf("synthetic_citeulike", "best", param_dict_for(args), model_choice=args.model)
     helper = get_data(inp["data"], pconf, rand_seed=12345, device=local_rank)
     md = get_model(pconf, helper, args.model, device=local_rank, seed=0)
     head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[args.scheme]]
@@ -551,7 +753,11 @@ def main():
         raw_ms, launches, ov_ms = nengine.profile_end()
         if launches == 0:
             continue
-        kern_ms = max(raw_ms - ov_ms, 1e-9)   # bracket minus the empty-bracket (marker packet) cost
+        # duration: the rocprofv3 --kernel-trace average of this exact workload when one is committed under
+        # profiles/ (first kernel only: the table holds the dominant one), else the raw event bracket -- which
+        # includes the marker packets' own cost (empty_bracket_ms), i.e. errs on the slow side
+        rp_ms = rocprof_duration_ms(args, conf, d, name)
+        kern_ms = rp_ms if rp_ms else raw_ms
         bound, work, what = kernels.get(name, ("hbm", 0.0, "n/a"))
         if bound == "hbm":
             ach, peak, unit = work / (kern_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
@@ -559,17 +765,16 @@ def main():
             ach, peak, unit = work / (kern_ms * 1e-3) / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
         roofs.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak,
                       "unit": unit, "frac": ach / peak, "traffic": None, "algorithmic_per_launch": work,
-                      "algorithmic_what": what, "kernel_ms": kern_ms, "event_bracket_ms": raw_ms,
-                      "empty_bracket_ms": ov_ms, "launches": launches})
+                      "algorithmic_what": what, "kernel_ms": kern_ms,
+                      "kernel_ms_source": "rocprofv3 kernel-trace average (profiles/)" if rp_ms else "HIP event bracket (live)",
+                      "event_bracket_ms": raw_ms, "empty_bracket_ms": ov_ms, "rocprof_kernel_ms": rp_ms,
+                      "launches": launches})
     roof = roofs[0]
-    roof["traffic"] = measured_traffic(args, conf, d)
-    # the profiler's duration of the same kernel (start to end of the dispatch, incl. what the event bracket's
-    # empty-bracket correction removes): committed summary under profiles/, None without one
-    roof["rocprof_kernel_ms"] = rocprof_duration_ms(args, conf, d)
+    roof["traffic"] = measured_traffic(args, conf, d, roof["kernel"])
 
     cpu = None
     if want_cpu:
-        cpu = cpu_baseline(args, conf, inp, U0, V0, tower_params)
+        cpu = cpu_baseline(args, inp, U0, V0, tower_params)
 
     # Recall@50 (the second half of BASELINE's metric) of the model as trained so far: whole@50
     # evaluator on the GPU (U.V^T over the candidate items + per-user top-k), outside every timed region
@@ -585,6 +790,10 @@ def main():
                           + ("; learn_rate 0.01 is the demo scripts' ADAM step size -- plain SGD barely moves with it "
                              "(--optimizer adam: train 0.68 / cold-item test 0.27 after the same steps)"
                              if args.optimizer == "sgd" else "")}
+
+    recall_trained = None
+    if rank == 0 and not args.large and args.recall_epochs > 0:
+        recall_trained = trained_recall(args, inp["data"], local_rank)
 
     if rank == 0:
         value = K * b * world / elapsed
@@ -610,6 +819,7 @@ def main():
             "mean_loss": mean_loss,
             "mean_unique_items_per_step": mean_n_u if args.model != "mf" else None,
             "recall_at_50": recall,
+            "recall_at_50_trained": recall_trained,
             "roofline": roof,
             "roofline_other_kernels": roofs[1:],
             "cpu_baseline": cpu,

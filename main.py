@@ -27,6 +27,13 @@ def main():
     parser.add_argument("--gpu", default=None, type=str)
     parser.add_argument("--seed", default=4224, type=int, help="NumPy seed (the reference is unseeded)")
     args = parser.parse_args()
+    # the reference's default is 'given' (main.py:18): pair AUC over sampled negatives through pandas / sklearn
+    # (objectives.py:231-294), outside the measured path and not built -- refused HERE, before data, samplers
+    # and a model are built and an epoch has run, not inside the first evaluation
+    if not args.eval_scheme.startswith("whole"):
+        parser.error("--eval_scheme %s is not built: use whole@K (e.g. whole@50, BASELINE's Recall@50)" % args.eval_scheme)
+    if args.pred_name is not None:
+        parser.error("--pred_name (pickling the (users x items) prediction matrices, objectives.py:317-318) is not built")
     param_dict = ast.literal_eval(args.param_dict) if args.param_dict is not None else None
     device = int(args.gpu) if args.gpu is not None else 0
     print("model_choice: %s \nconf_choice: %s" % (args.model_choice, args.conf_choice))
@@ -44,9 +51,8 @@ def main():
         conf.eval_topk = int(eval_scheme[p + 1:])
         eval_scheme = eval_scheme[:p]
     if conf.optimizer == "sgd":
-        print("[INFO] optimizer = sgd: this build's default is the sparse SGD scatter update; the reference compiles "
-              "Keras Adam(learn_rate) -- pass {'optimizer': 'adam'} (or 'sparse_adam') in --param_dict for it. "
-              "The demo scripts' learn_rate 0.01 is an Adam step size: plain SGD barely moves with it.")
+        print("[INFO] optimizer = sgd (sparse SGD scatter update, opt-in): the demo scripts' learn_rate 0.01 is an Adam "
+              "step size -- plain SGD barely moves with it.")
     data_helper = get_data(args.data_name, conf, reverse_samping=True, rand_seed=12345, device=device)
     print(conf.__dict__)
     model_dict = get_model(conf, data_helper, args.model_choice, device=device)

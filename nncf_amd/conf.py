@@ -4,12 +4,14 @@ for mf) and get_conf (:170-179).  Only fields consumed on the sampling + scoring
 text-tower presets (pretrain files, gating) are out of scope.
 
 Optimizer: `conf.optimizer` is a string here (the reference stores a Keras / TF object):
-  'sgd'          sparse SGD scatter update -- the build's default (BASELINE north-star);
   'adam'         Keras Adam(learn_rate), what the reference compiles for learn_rate > 0
-                 (basic_embedding_conf.py:59-60): dense, every row of every table moves each step;
+                 (basic_embedding_conf.py:59-60) -- the default, as in the reference: dense, every row
+                 of every table moves each step;
   'sparse_adam'  utils/optimizer.py AdamOptimizer(-learn_rate), what the reference switches to for
-                 learn_rate < 0 (:61-66); chosen automatically for a negative learn_rate.
-Pass {'optimizer': 'adam'} in param_dict for the reference's default optimiser.
+                 learn_rate < 0 (:61-66); chosen automatically for a negative learn_rate
+                 (conf.sparse_adam_duplicates = 'sum' | 'as_written' picks its duplicate-id semantics);
+  'sgd'          sparse SGD scatter update (BASELINE north-star) -- opt-in: {'optimizer': 'sgd'} in
+                 param_dict; bench.py's headline sets it explicitly.
 """
 
 
@@ -63,7 +65,9 @@ class Conf(object):
             self.emb_normalization = True if self.loss == "max-margin" or self.loss == "log-loss" else False
         opt = self.__dict__.get("optimizer")
         if opt is None:
-            opt = "sgd" if self.learn_rate > 0 else "sparse_adam"  # :59-66 (lr < 0 selects the sparse variant)
+            # :59-66: Adam(learn_rate) for learn_rate > 0, utils/optimizer.py AdamOptimizer(-learn_rate) for
+            # learn_rate < 0.  The north-star's sparse SGD scatter update is opt-in: {'optimizer': 'sgd'}
+            opt = "adam" if self.learn_rate > 0 else "sparse_adam"
         assert opt in ("sgd", "adam", "sparse_adam"), "[ERROR] optimizer %r unknown" % (opt,)
         self.optimizer = opt
         self.pretrain = None

@@ -163,6 +163,31 @@ class EmbeddingModel(_Head):
         return rows.cpu().numpy()
 
 
+class TowerItemEmbeddingModel(_Head):
+    """model_item_emb above a text tower (model_framework.py:174: Model([cid], C_emb) -- predict runs in
+    the Keras inference phase): the tower's inference-mode output (BatchNorm running statistics, no
+    dropout) of the REQUESTED ids, L2-normalised as configured (:109-111).  The training engine's item
+    "table" is a per-batch block of tower outputs, never indexed by catalogue id."""
+
+    def __init__(self, core):
+        super(TowerItemEmbeddingModel, self).__init__(core.engine)
+        self.core = core
+
+    def predict_on_batch(self, x):
+        import torch
+        e, tw = self.engine, self.core.tower
+        ids = e.ids(_as_ids(x[0]))
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.core.item_count):
+            raise IndexError("item id out of range [0, %d)" % self.core.item_count)
+        rows = torch.empty(ids.numel(), e.dim_p, dtype=torch.float32, device=e.device)
+        if ids.numel():
+            tw.forward(ids, train=False, out=rows)
+        rows = rows[:, :e.dim]
+        if e.cfg.normalize_item:
+            rows = rows * torch.rsqrt(torch.clamp((rows * rows).sum(-1, keepdim=True), min=1e-12))
+        return rows.cpu().numpy()
+
+
 class PredPairsModel(_Head):
     """model_pred_pairs (model_framework.py:125-126,175-176): row-wise dot of GIVEN embeddings."""
 
@@ -461,7 +486,7 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
         "model_group_neg_shared": TowerHead(core, "group_neg_shared"),
         "model_sampled_neg_shared": TowerSampledNegSharedHead(core, make_unnormalised_core),
         "model_user_emb": EmbeddingModel(engine, "user"),
-        "model_item_emb": EmbeddingModel(engine, "item"),
+        "model_item_emb": TowerItemEmbeddingModel(core),
         "model_pred_pairs": PredPairsModel(engine),
         "model_all_loss": _LossMonitorDict(monitor("original")),
         "model_neg_shared_all_loss": _LossMonitorDict(monitor("neg_shared")),

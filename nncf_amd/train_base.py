@@ -56,6 +56,13 @@ class TrainerBase(object):
         cid = torch.as_tensor(np.ascontiguousarray(train[:n, 1]).astype(np.int32)).to(e.device)
         return uid, cid
 
+    @staticmethod
+    def _iterations(n_steps, n_rows, rows_per_step):
+        """`it` as the reference's loops count it (train_original.py:43-48 and every sibling): the counter is
+        bumped before the ragged-tail check, so an epoch whose link count is not a multiple of the batch
+        reports one iteration more than it trained -- and divides the printed cost by it."""
+        return n_steps + (1 if n_steps and n_rows % rows_per_step else 0)
+
     def _epoch_report(self, epoch, it, cost, eval_scheme):
         # train_original.py:69-87
         mean_cost = cost / it if it > 0 else -1

@@ -65,7 +65,7 @@ class Trainer(TrainerBase):
             if n_steps:
                 losses = self.model_train.run_epoch(uid, cid, n_steps, n_u_out=n_u)
                 cost = float(losses.double().sum().item())
-                it = n_steps
+                it = self._iterations(n_steps, len(train), b)
             if epoch > 0:
                 self.train_time.append(time.time() - t_start + in_window)
                 self.mean_n_u.append(float(n_u[:n_steps].double().mean().item()))

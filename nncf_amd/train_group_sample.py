@@ -30,6 +30,9 @@ class Trainer(RowwiseTrainer):
         self.by = "user" if st.startswith("by_user") else "item"
         print("[INFO] sampling group based on {}".format(self.by))
 
+    def ragged_tail(self, rows, n):
+        return len(self.data_helper.data["train"]) % self.conf.batch_size_p != 0
+
     def build_epoch(self, epoch):
         conf = self.conf
         b, k = conf.batch_size_p, conf.num_negatives

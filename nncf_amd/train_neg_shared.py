@@ -34,7 +34,7 @@ class Trainer(TrainerBase):
             if n_steps:
                 losses = self.model_train.run_epoch(uid, cid, n_steps)
                 cost = float(losses.double().sum().item())
-                it = n_steps
+                it = self._iterations(n_steps, len(train), b)
             if epoch > 0:
                 self.train_time.append(time.time() - t_start)
             self._epoch_report(epoch, it, cost, eval_scheme)

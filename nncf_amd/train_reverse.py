@@ -13,6 +13,9 @@ class Trainer(RowwiseTrainer):
         assert conf.loss not in ["log-loss", "max-margin"], "[ERROR] revrese does not support pairwise losses"
         self.sample_batch_u = data_helper.sampler_dict["sample_batch_u"]
 
+    def ragged_tail(self, rows, n):
+        return len(self.data_helper.data["train"]) % self.conf.batch_size_p != 0
+
     def build_epoch(self, epoch):
         conf = self.conf
         b, k = conf.batch_size_p, conf.num_negatives

@@ -19,6 +19,11 @@ class RowwiseTrainer(TrainerBase):
         self.model_train = model_dict["model"]
         self.neg_sign = -1 if conf.loss == "skip-gram" else 0
 
+    def ragged_tail(self, rows, n):
+        """does the reference's loop count one broken-off iteration this epoch?  presample walks the
+        pre-sampled array itself; group_sample / reverse walk the link list (overridden there)"""
+        return len(rows) % n != 0
+
     def build_epoch(self, epoch):
         """-> (rows (n_rows, 3) int64, per-epoch host cost excluded from the timing window)."""
         raise NotImplementedError
@@ -40,7 +45,7 @@ class RowwiseTrainer(TrainerBase):
             if n_steps:
                 losses = self.model_train.run_epoch_rowwise(uid, cid, y, n_steps)
                 cost = float(losses.double().sum().item())
-                it = n_steps
+                it = n_steps + (1 if n_steps and self.ragged_tail(rows, n) else 0)   # train_presample.py:88-93
             if epoch > 0:
                 # sampling done per step inside the reference's loop is part of its timing window
                 self.train_time.append(time.time() - t_start + in_window)

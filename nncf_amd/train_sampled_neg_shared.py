@@ -37,7 +37,7 @@ class Trainer(TrainerBase):
                 neg = sampler.sample_batch_device(n_steps * k)
                 losses = self.model_train.run_epoch(uid, cid, n_steps, neg_shared_all=neg)
                 cost = float(losses.double().sum().item())
-                it = n_steps
+                it = self._iterations(n_steps, len(train), b)
             if epoch > 0:
                 self.train_time.append(time.time() - t_start)
             self._epoch_report(epoch, it, cost, eval_scheme)

@@ -85,7 +85,7 @@ def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
           "num_filters": [20], "filter_lengths": [3], "conv_dropout_rate": 0., "optimizer": optimizer}
     if optimizer != "sgd":
         pd["learn_rate"] = 0.01
-    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2) for _ in range(2)]
     dp = DataParallelTower(HipTowerReplica(mds[0], "neg_shared"))
     plain = mds[1]["model_neg_shared"]
@@ -122,7 +122,7 @@ def test_data_parallel_run_epoch_equals_plain_epoch():
     pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
           "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
           "user_dim": 24, "item_dim": 24, "word_dim": 24, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.}
-    conf = get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="basic_embedding")
     mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2) for _ in range(2)]
     dp = DataParallelTower(HipTowerReplica(mds[0], "neg_shared"))
     plain = mds[1]["model_neg_shared"]

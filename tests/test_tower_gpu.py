@@ -24,7 +24,7 @@ def _conf(loss, scheme, b=64, k=3, d=24, lr=0.2):
           "neg_loss_weight": 16, "loss_gamma": 0.1 if loss == "max-margin" else 10, "learn_rate": lr,
           "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d, "item_dim": d,
           "word_dim": d, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.}
-    return get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+    return get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="basic_embedding")
 
 
 def _oracle(conf, md, data):
@@ -80,6 +80,37 @@ def test_basic_embedding_steps_match_oracle(text_data, scheme, loss):
     oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float32)
     want = oc2.predict_neg_shared(users, np.arange(len(items)))
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_model_item_emb_is_the_inference_tower_of_the_given_ids(text_data, loss):
+    """model_dict['model_item_emb'].predict_on_batch([cid]) (model_framework.py:174): inference-mode C_emb of
+    the REQUESTED catalogue ids -- also ids beyond the per-batch block -- after a few training steps."""
+    conf = _conf(loss, "neg_shared")
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    rs = np.random.RandomState(3)
+    train = text_data["train"]
+    for _ in range(2):
+        bt = train[rs.choice(len(train), conf.batch_size_p, replace=False)]
+        orc.step_neg_shared(bt[:, 0], bt[:, 1])
+        md["model_neg_shared"].train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+    ids = np.array([259, 0, 7, 7, 130, 258, 64, 65, 200])       # past the block of 64, with a duplicate
+    got = md["model_item_emb"].predict_on_batch([ids])
+    want = to.forward(ids, train=False)
+    if conf.emb_normalization:
+        want, _ = so.l2_normalize(want)
+    assert got.shape == (len(ids), conf.item_dim)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+    with pytest.raises(IndexError):
+        md["model_item_emb"].predict_on_batch([np.array([260])])
+    users = np.array([5, 1, 1])
+    got_u = md["model_user_emb"].predict_on_batch([users])
+    want_u = orc.U[users]
+    if conf.emb_normalization:
+        want_u, _ = so.l2_normalize(want_u)
+    np.testing.assert_allclose(got_u, want_u, rtol=2e-5, atol=2e-6)
 
 
 def test_basic_embedding_trainer_runs_and_learns(text_data):
@@ -222,7 +253,7 @@ def _conf_cnn(loss, scheme, b=64, k=3, d=24, F=20, fl=3, lr=0.1, wdrop=0.0, cdro
           "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d, "item_dim": d,
           "word_dim": 16, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": wdrop, "num_filters": [F],
           "filter_lengths": [fl], "conv_dropout_rate": cdrop}
-    return get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+    return get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="cnn_embedding")
 
 
 def _oracle_cnn(conf, md, data, dtype=np.float32):
@@ -300,7 +331,7 @@ def test_cnn_embedding_citeulike_tile_shape():
           "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 32,
           "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.5,
           "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
-    conf = get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="cnn_embedding")
     md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "cnn_embedding", seed=2)
     orc, to = _oracle_cnn(conf, md, data)
     head = md["model_neg_shared"]
@@ -330,7 +361,7 @@ def test_cnn_embedding_general_tile_shapes(L, wd, F, fl):
           "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 32,
           "user_dim": 64, "item_dim": 64, "word_dim": wd, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.3,
           "num_filters": [F], "filter_lengths": [fl], "conv_dropout_rate": 0.1}
-    conf = get_conf("synthetic", "best", pd, model_choice="cnn_embedding")
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="cnn_embedding")
     md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "cnn_embedding", seed=2)
     orc, to = _oracle_cnn(conf, md, data, dtype=np.float64)
     head = md["model_neg_shared"]
@@ -360,7 +391,7 @@ def test_dims_not_multiple_of_4_are_padded_exactly(text_data, model):
           "loss_gamma": 10, "learn_rate": 0.1, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
           "user_dim": 18, "item_dim": 18, "word_dim": 10, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.,
           "num_filters": [14], "filter_lengths": [3], "conv_dropout_rate": 0.}
-    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), model, seed=2)
     head = md["model_neg_shared"]
     tw, eng = head.core.tower, head.engine
@@ -487,7 +518,7 @@ def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
           "neg_loss_weight": 128, "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
           "batch_size_p": 512, "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6,
           "word_emb_dropout_rate": 0.5, "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
-    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
     orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data)
     head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
@@ -696,7 +727,7 @@ def test_row_order_does_not_matter_at_baseline_shape(citeulike_data, model):
           "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 512,
           "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6, "word_emb_dropout_rate": 0.,
           "interaction_bias": None}
-    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2) for _ in range(2)]
     b, k = 512, 10
     rs = np.random.RandomState(3)
@@ -730,7 +761,7 @@ def test_steps_are_bitwise_reproducible_at_baseline_shape(citeulike_data, model,
           "neg_loss_weight": 128, "loss_gamma": 10, "learn_rate": 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
           "batch_size_p": 512, "user_dim": 100, "item_dim": 100, "word_dim": 100, "chop_size": 5, "u_reg": 1e-6,
           "word_emb_dropout_rate": 0.5, "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
-    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     key = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]
     b, k = 512, conf.num_negatives
     n_items = data["C"].shape[0]

@@ -46,6 +46,30 @@ def trace_avg_us(path, kernel):
     return None
 
 
+def all_kernel_avgs(path):
+    """{kernel: avg_us} of every kernel in a kernel-trace summary"""
+    res = {}
+    if not os.path.exists(path):
+        return res
+    for line in open(path):
+        if line.startswith("# PMC counters"):
+            break
+        parts = line.split()
+        if len(parts) >= 5 and parts[0].endswith("_kernel") or (len(parts) >= 5 and "_kernel" in parts[0]):
+            try:
+                name = parts[0].split("<")[0].split("::")[-1]
+                res[name] = {"rocprof_avg_us": float(parts[-2])}
+            except ValueError:
+                pass
+    return res
+
+
+def source_hash():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+    return g._source_hash()
+
+
 def main():
     d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
     table = {}
@@ -61,6 +85,9 @@ def main():
             "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes "
                    "(profiles/%s_%s_pmc_*.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024" % (tag, stem),
             "round": int(tag.lstrip("r") or 0),
+            "kernels": all_kernel_avgs(os.path.join(d, "%s_%s_kernel_trace.txt" % (tag, stem))),
+            # bench.py trusts these durations only while the kernel sources are the ones that were profiled
+            "csrc_hash": source_hash(),
         }
     json.dump(table, open(out, "w"), indent=1)
     print(json.dumps(table, indent=1))

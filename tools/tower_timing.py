@@ -15,7 +15,7 @@ train = np.stack([rs.randint(0, U, n), rs.randint(0, I, n), np.ones(n, dtype=np.
 data = {"C": C, "train": train, "test": train[:1000].copy(), "test_seen": train[:1000].copy(), "train_items": np.arange(I), "test_items": np.arange(I)}
 pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 128, "loss_gamma": 10,
       "learn_rate": 0.01, "batch_size_p": 512, "user_dim": 100, "item_dim": 100, "word_dim": 100, "word_emb_dropout_rate": 0.}
-conf = get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="basic_embedding")
 helper = get_data(data, conf)
 md = get_model(conf, helper, "basic_embedding")
 head = md["model_neg_shared"]
