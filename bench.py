@@ -736,6 +736,11 @@ def main():
         "cnn_conv_fwd_kernel": ("mfma", conv_flop, "2*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % mean_n_u),
         "cnn_conv_bwd_kernel": ("mfma", 2 * conv_flop, "dX and dWk: 4*n_u*L*fl*word_dim*F flop, n_u = %.1f" % mean_n_u),
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
+        # the one-launch step computes S in both passes (8 b N d flop issued); the ALGORITHMIC work of the step is 6 b N d
+        "fused_strip_kernel": ("mfma", 6.0 * b * (mean_n_u if args.scheme == "group_neg_shared" and args.model != "mf" else b) * d,
+                               "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item pass)"),
+        "tower_wordbwd_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
+                                 "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % mean_n_u),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
         "tower_pool_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
                               "4*L*word_dim*(1-dropout) B per unique item, n_u = %.1f unique items per launch" % mean_n_u),
@@ -747,8 +752,10 @@ def main():
         {"mf": "shared_tile_kernel", "cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, "tower_word_kernel")
     names = [args.roofline_kernel or default_kernel]
     if args.model == "basic_embedding":
-        names += [n for n in ("tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel", "shared_tile_kernel")
-                  if n not in names]
+        names += [n for n in ("tower_wordbwd_kernel", "tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel",
+                              "fused_strip_kernel", "shared_tile_kernel") if n not in names]
+    if args.model == "mf":
+        names += [n for n in ("fused_strip_kernel", "shared_tile_kernel", "shared_apply_kernel") if n not in names]
     if args.model == "cnn_embedding":
         names += [n for n in ("cnn_conv_fwd_kernel", "tower_word_kernel", "shared_tile_kernel") if n not in names]
     prof_n = min(K, args.profile_launches)
@@ -775,6 +782,9 @@ def main():
                       "kernel_ms_source": "rocprofv3 kernel-trace average (profiles/)" if rp_ms else "HIP event bracket (live)",
                       "event_bracket_ms": raw_ms, "empty_bracket_ms": ov_ms, "rocprof_kernel_ms": rp_ms,
                       "launches": launches})
+    if not roofs:
+        roofs = [{"kernel": names[0], "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                  "note": "kernel not launched by this configuration"}]
     roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d, roof["kernel"])
 

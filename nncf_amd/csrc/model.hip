@@ -4,10 +4,12 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <string>
 
 #include "common.h"
 #include "model.h"
 #include "step.h"
+#include "step_fused.h"
 
 using namespace nncf;
 
@@ -63,6 +65,44 @@ int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st) {
   m->adam_t++;
   return NNCF_OK;
 }
+
+bool shared_step_fuses(const nncf_model* m, const StepArgs& a) {
+  return m->use_fused && fused_eligible(a) && (!a.bn_z || fused_max_blocks(a.b) <= 64);
+}
+
+int flush_pending_loss(nncf_model* m, hipStream_t st) {
+  if (!m->pend_out) return NNCF_OK;
+  const int mb = fused_max_blocks(m->cfg.batch_size_p) * fused_split(m->cfg.batch_size_p);
+  const int rc = launch_fused_flush(m->fpart + (size_t)m->pend_parity * mb, m->pend_n, m->pend_out, st);
+  m->pend_out = nullptr;
+  return rc;
+}
+
+int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
+                const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower) {
+  if (!shared_step_fuses(m, a)) {
+    if (int rc = flush_pending_loss(m, st)) return rc;
+    return launch_shared(a, group, uid, cid, m->sws, pu, pv, loss_out, update, st);
+  }
+  const int mb = fused_max_blocks(a.b) * fused_split(a.b);
+  FusedArgs f = tower ? *tower : FusedArgs();
+  f.split = fused_split(a.b);
+  f.slab = m->fslab;
+  f.cnt = m->fcnt;
+  f.loss_part = m->fpart + (size_t)m->fparity * mb;
+  f.dbg = m->sws.dbg;   // NNCF_DEBUG_TIMING=1: [2 mb + 1][32] stamps fit the tile kernel's [nb*nb][8] buffer for b >= 128
+  if (m->pend_out) {
+    f.prev_part = m->fpart + (size_t)m->pend_parity * mb;
+    f.prev_n = m->pend_n;
+    f.prev_out = m->pend_out;
+  }
+  if (int rc = launch_fused(a, group, uid, cid, f, pu, pv, update, st)) return rc;
+  m->pend_out = loss_out;
+  m->pend_n = mb;
+  m->pend_parity = m->fparity;
+  m->fparity ^= 1;
+  return NNCF_OK;
+}
 }  // namespace nncf
 
 namespace {
@@ -94,7 +134,13 @@ void carve(nncf_model* m, Carver& c) {
   m->sws.reg_part = c.take<float>(b);
   m->sws.gr_part = c.take<float>(nb * b);
   m->sws.gc_part = c.take<float>(nb * b);
-  m->sws.dbg = getenv("NNCF_DEBUG_TIMING") ? c.take<long long>(nb * nb * 8) : nullptr;
+  m->sws.dbg = getenv("NNCF_DEBUG_TIMING") ? c.take<long long>(nb * nb * 8 + (2 * (fused_max_blocks((int)b) + 8) * kFusedMaxSplit + 1) * 32) : nullptr;
+  {
+    const size_t mb = (size_t)fused_max_blocks((int)b), sp = (size_t)fused_split((int)b);
+    m->fpart = c.take<float>(2 * mb * sp);
+    m->fslab = c.take<float>(sp > 1 ? 2 * mb * sp * 16 * 128 : 4);
+    m->fcnt = c.take<int>(2 * mb);
+  }
   m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
   auto plan = [&](PlanView& v, int64_t cap) {
@@ -167,6 +213,7 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   m->U = d_user_table;
   m->V = d_item_table;
   m->device = device;
+  if (const char* e = getenv("NNCF_SHARED_PATH")) m->use_fused = std::string(e) != "tile";
   Carver dry;
   carve(m, dry);
   {
@@ -354,7 +401,8 @@ int nncf_step_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_t* d_c
   if (rc) return rc;
   {
     const StepArgs sa = make_args(m);
-    if (int rc2 = launch_shared(sa, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    if (int rc2 = shared_step(m, sa, 0, d_uid, d_cid, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    if (int rc2 = flush_pending_loss(m, st)) return rc2;
     return update ? finish_update(m, sa, st) : NNCF_OK;
   }
 }
@@ -370,8 +418,9 @@ int nncf_step_neg_shared_export(nncf_model* m, const int32_t* d_uid, const int32
   if (rc) return rc;
   StepArgs a = make_args(m);
   a.gV = d_item_grad;
-  rc = launch_shared(a, 0, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, 1, st);
+  rc = shared_step(m, a, 0, d_uid, d_cid, m->plan_u, m->plan_v, d_loss, 1, st);
   if (rc) return rc;
+  if ((rc = flush_pending_loss(m, st))) return rc;
   if (m->opt == 2) {  // item rows belong to their owners: only the user table is stepped here
     if (int rc2 = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc2;
   }
@@ -409,7 +458,8 @@ int nncf_step_planned(nncf_model* m, int32_t scheme, const int32_t* d_uid, float
   if (int rc = check_shared(m)) return rc;
   {
     const StepArgs sa = make_args(m);
-    if (int rc2 = launch_shared(sa, scheme == 2, d_uid, cid_local, m->sws, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    if (int rc2 = shared_step(m, sa, scheme == 2, d_uid, cid_local, m->plan_u, m->plan_v, d_loss, update, st)) return rc2;
+    if (int rc2 = flush_pending_loss(m, st)) return rc2;
     return update ? finish_update(m, sa, st) : NNCF_OK;
   }
 }
@@ -424,8 +474,9 @@ int nncf_step_group_neg_shared(nncf_model* m, const int32_t* d_uid, const int32_
   int rc = launch_plan_pair(d_uid, b, m->plan_u, d_cid, b, m->plan_v, st);
   if (rc) return rc;
   const StepArgs sa = make_args(m);
-  rc = launch_shared(sa, 1, d_uid, d_cid, m->sws, m->plan_u, m->plan_v, d_loss, update, st);
+  rc = shared_step(m, sa, 1, d_uid, d_cid, m->plan_u, m->plan_v, d_loss, update, st);
   if (rc) return rc;
+  if ((rc = flush_pending_loss(m, st))) return rc;
   if (update) rc = finish_update(m, sa, st);
   if (rc) return rc;
   if (d_cid_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_cid_u, m->plan_v.uniq, sizeof(int32_t) * b, hipMemcpyDeviceToDevice, st));
@@ -475,11 +526,12 @@ static int epoch_shared(nncf_model* m, int group, const int32_t* d_uid_all, cons
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;
       const StepArgs a = make_args(m);
-      rc = launch_shared(a, group, d_uid_all + t * b, d_cid_all + t * b, m->sws, m->plan_u.at(i), m->plan_v.at(i),
-                         d_loss + t, 1, st);
+      rc = shared_step(m, a, group, d_uid_all + t * b, d_cid_all + t * b, m->plan_u.at(i), m->plan_v.at(i),
+                       d_loss + t, 1, st);
       if (rc) return rc;
       if ((rc = finish_update(m, a, st))) return rc;
     }
+    if (int rcf = flush_pending_loss(m, st)) return rcf;
     if (d_n_u) {
       // n_u of each planned step (counts[2*i]) -> d_n_u[t0 + i]
       NNCF_HIP_CHECK(hipMemcpy2DAsync(d_n_u + t0, sizeof(int32_t), m->plan_v.counts, 4 * sizeof(int32_t),

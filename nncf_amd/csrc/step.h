@@ -231,9 +231,27 @@ struct nncf_model {
   nncf::AdamTable abu, abc;
   int64_t bias_items = 0;     // length of cb (the catalogue, also when the item table is a per-batch block)
   int32_t* bias_stamps = nullptr;  // owned: user_count + bias_items ints (dense Adam)
+  // one-launch shared-negative step (step_fused.hip): loss partials of the current / previous step and the
+  // step whose loss is still to be summed (done by the next fused launch or by flush_pending_loss)
+  int use_fused = 1;          // NNCF_SHARED_PATH=tile forces the two-launch tile + apply path
+  float* fpart = nullptr;     // [2][fused_max_blocks(b) * fused_split(b)]
+  float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips
+  int* fcnt = nullptr;        // [2 strips per side] arrival tickets (zero between launches)
+  int fparity = 0;
+  float* pend_out = nullptr;
+  int pend_n = 0, pend_parity = 0;
 };
 
 namespace nncf {
+struct FusedArgs;
+// neg_shared / group_neg_shared step kernels of one batch: the one-launch path when eligible (pointwise loss,
+// no bias), else tile + apply.  `tower`: statistics-fusion arguments of a text tower, or NULL.
+// *fused_out (optional) tells which path ran.
+int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
+                const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower = nullptr);
+bool shared_step_fuses(const nncf_model* m, const StepArgs& a);
+// sums the loss partials the last fused launch left behind (every entry point calls it before it returns)
+int flush_pending_loss(nncf_model* m, hipStream_t st);
 StepArgs make_args(const nncf_model* m);
 // after the kernels of an update step: dense-Adam idle rows, optimiser step counter
 int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st);

@@ -1,0 +1,40 @@
+// One-launch shared-negative step (step_fused.hip): argument block and host entry points.
+#pragma once
+#include "model.h"
+#include "step.h"
+
+namespace nncf {
+
+struct FusedArgs {
+  float* loss_part = nullptr;        // this step's per-workgroup loss partials [fused_max_blocks(b)]
+  const float* prev_part = nullptr;  // the previous step's partials, summed into *prev_out by this launch
+  int prev_n = 0;
+  float* prev_out = nullptr;
+  // text towers: when `stats` is set every workgroup derives the BatchNorm statistics of the item block
+  // (StepArgs::bn_z, rows [0, n_u)) itself and workgroup 0 publishes mu, inv, var, mul, add (128-float
+  // pitch) there + the running statistics; NULL: StepArgs::bn_stats already holds them.
+  float* stats = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float* rm = nullptr;
+  float* rv = nullptr;
+  float eps = 1e-3f, momentum = 0.99f;
+  // opposite-range split: `split` workgroups share one strip of 16 own rows (stage st belongs to part st % split);
+  // each writes its partial output rows to slab[strip][part][16][128], the last to arrive (per-strip ticket in
+  // cnt[], agent-scope release / acquire) adds the parts in part order and finalises the rows
+  int split = 1;
+  float* slab = nullptr;
+  int* cnt = nullptr;
+  long long* dbg = nullptr;   // developer timing: [workgroup][32] s_memtime stamps (NNCF_DEBUG_TIMING=1)
+};
+
+// pointwise loss, no InteractionDot bias, b a multiple of 16
+bool fused_eligible(const StepArgs& a);
+int fused_max_blocks(int b);  // strips per side (= V-pass BatchNorm partials)
+int fused_split(int b);       // workgroups per strip chosen for batch size b
+constexpr int kFusedMaxSplit = 8;
+int launch_fused(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const FusedArgs& f,
+                 const PlanView& pu, const PlanView& pv, int update, hipStream_t stream);
+int launch_fused_flush(const float* part, int n, float* out, hipStream_t stream);
+
+}  // namespace nncf

@@ -1,0 +1,662 @@
+// train_scheme = neg_shared / group_neg_shared, pointwise losses: the whole step in ONE launch.
+//
+// Reference path: models/train_neg_shared.py:46-51 / train_group_neg_shared.py:53-61 ->
+// model_framework.py:45-48,59-63,85-88,128-136 -> InteractionDot 'matmul' (interaction_dot.py:100-103)
+// -> get_neg_shared_loss / get_group_neg_shared_loss, skip-gram and mse branches
+// (utils/objectives.py:99-112,202-217) -> optimiser step on the touched rows.
+//
+// The two-launch design (step_shared.hip: 32 x 32 tiles + slab reduction) exists because dL/dU of a
+// user needs every column of its score row and dL/dV of an item every row of its column.  Here each
+// side RECOMPUTES what it needs instead of exchanging partials through HBM:
+//   U-pass workgroup  owns 16 UNIQUE users (segments of the duplicate plan), streams all N item rows
+//                     through LDS in stages of 128: S = U.V^T (fp32 MFMA 16x16x4) -> dL/dS element-wise on
+//                     the accumulators -> dU += G.V (MFMA) with dU resident in registers across stages
+//                     -> normalisation backward + regulariser + optimiser step of its 16 rows;
+//   V-pass workgroup  owns 16 unique items, streams all b user rows, the same with S^T.
+// 8 b N d flop instead of 6 b N d (S is computed by both passes), no slabs, no second launch, no
+// float atomics; every table row is written by exactly one 16-lane group.  At b = 16K (config 4's
+// large-batch regime) the same kernel has 2 x 1024 workgroups and is fp32-MFMA bound.
+//
+// A user (item) that occurs c times in the batch is ONE row here: its c score rows are identical, so
+//   dL/dS summed over its positions = m g_pos(s) + (c - m) g_neg(s),   m = #positions whose positive
+// is this column (objectives.py:100-103,107-110: weight 1 / label +1 on the positive, lambda/(N-1) /
+// label -1|0 elsewhere).
+//
+// Text towers: item rows are relu(z * mul + add) applied on load; with `stats` set every workgroup
+// first derives the BatchNorm statistics of the block itself (same arithmetic in every workgroup,
+// workgroup 0 publishes them), which removes the one-workgroup statistics launch from the chain; the
+// V-pass emits the BatchNorm backward's column sums like the slab path's apply kernel.
+//
+// The loss of a step is the sum of per-workgroup partials; it is finalised by the NEXT launch of this
+// kernel (or by fused_loss_flush_kernel at the end of an entry point): nothing waits for it.
+#include "common.h"
+#include "devutil.h"
+#include "model.h"
+#include "step.h"
+#include "step_fused.h"
+
+namespace nncf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFM = 16;            // own rows per workgroup
+constexpr int kFNB = 128;          // opposite rows per stage
+constexpr int kFDP = 128 + 4;      // LDS row pitch (floats): 16-byte rows; 4 banks apart -> conflict-free ds_read_b128 fragments
+constexpr int kFGP = kFNB + 4;     // pitch of the gradient tile
+constexpr int kFOP = 132;          // pitch of the output rows (16-byte aligned)
+constexpr int kFKeys = 128;        // positive-column keys of a workgroup's own rows held in LDS
+
+__host__ __device__ constexpr size_t fused_lds_bytes() {
+  return sizeof(float) * (kFM * kFDP + kFNB * kFDP + kFM * kFGP + 16 + 16 + 8 + 5 * 128) +
+         sizeof(int) * (kFNB + kFKeys + 16 + 16 + 4);
+}
+
+__device__ __forceinline__ void lds_store_row_f(float* dst, int q, Row v) {
+  reinterpret_cast<float4*>(dst)[q] = v.a;
+  reinterpret_cast<float4*>(dst)[q + 16] = v.b;
+}
+
+#define NNCF_MFMA4(A, B, C0, C1)                                        \
+  C0 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, C0, 0, 0, 0); \
+  C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, C1, 0, 0, 0); \
+  C0 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, C0, 0, 0, 0); \
+  C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, C1, 0, 0, 0)
+
+__device__ __forceinline__ void store_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// NG groups of 16 columns of one S tile: 2 NG ds_read_b128, 4 NG MFMAs
+template <int NG>
+__device__ __forceinline__ void s_tile(const float4* pa4, const float4* pb4, f32x4& acc0, f32x4& acc1) {
+  float4 fa[NG], fb[NG];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    fa[t] = pa4[4 * t];
+    fb[t] = pb4[4 * t];
+  }
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    NNCF_MFMA4(fa[t], fb[t], acc0, acc1);
+  }
+}
+
+#define FSTAMP(k)                                                                                   \
+  do {                                                                                              \
+    if (f.dbg && threadIdx.x == 0) f.dbg[(int64_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
+  } while (0)
+
+template <int LOSS, bool GROUP, bool NU, bool NV, bool USIDE>
+__device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __restrict__ uid,
+                                           const int32_t* __restrict__ cid, const FusedArgs& f, const PlanView& pu,
+                                           const PlanView& pv, int blk, int part, int update, float* smem) {
+  float* sOwn = smem;                       // [16][kFDP]   own rows (normalised), MFMA A operand of S
+  float* sOpp = sOwn + kFM * kFDP;          // [128][kFDP]  opposite rows of the stage
+  float* sG = sOpp + kFNB * kFDP;           // [16][kFGP]   dL/dS of the stage; afterwards the output rows [16][kFOP]
+  float* sCnt = sG + kFM * kFGP;            // [16] multiplicity c of every own row
+  float* sRowReg = sCnt + 16;               // [16] c * |raw row|^2 (regulariser)
+  float* sRed = sRowReg + 16;               // [8]
+  float* sStat = sRed + 8;                  // [5][128] mu, inv, var, mul, add (stats fusion)
+  int* sOppKey = reinterpret_cast<int*>(sStat + 5 * 128);  // [128]
+  int* sKeys = sOppKey + kFNB;              // [kFKeys]
+  int* sKeyStart = sKeys + kFKeys;          // [16]
+  int* sKeyCnt = sKeyStart + 16;            // [16]  < 0: list did not fit, read it from the plan
+  int* sTop = sKeyCnt + 16;                 // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid >> 4, q = tid & 15;     // 32 row groups of 16 lanes
+  const int b = a.b, d = a.d, d4 = d >> 2;
+  const int NP = (d + 15) & ~15;
+  const int n_items = GROUP ? pv.counts[0] : b;     // columns of the score matrix
+  const int n_opp = USIDE ? n_items : b;
+  const PlanView& po = USIDE ? pu : pv;
+  const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
+  const bool bn_on = a.bn_z != nullptr;
+
+  FSTAMP(0);
+  if (tid == 0) sTop[0] = 0;
+  // opposite side: ids of stage 0 and 1 and this workgroup's own descriptors are requested first -- every
+  // later load depends on them
+  auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
+  auto opp_key = [&](int j) -> int { return USIDE ? (GROUP ? j : pu.inverse[j]) : pv.inverse[j]; };
+  const int nst = (n_opp + kFNB - 1) / kFNB;
+  int idA[4], keyA[4], idB[4], keyB[4];
+  auto load_ids = [&](int st, int* ids, int* keys) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = st * kFNB + g + 32 * e;
+      const bool ok = st < nst && j < n_opp;
+      ids[e] = ok ? opp_id(j) : -1;
+      keys[e] = ok ? opp_key(j) : -1;
+    }
+  };
+  const int P = f.split;               // stage st belongs to part st % P: this workgroup runs part, part + P, ...
+  load_ids(part, idA, keyA);
+  load_ids(part + P, idB, keyB);
+  const int s_own = blk * kFM + g;
+  const bool own_ok = g < kFM && s_own < n_own;
+  // descriptor {id, first position, start, count}: requested before the segment count is known (the plan arrays hold
+  // b entries; entries past the count are stale and masked by own_ok below)
+  int4 own_ds = make_int4(0, 0, 0, 1);
+  if (g < kFM && s_own < b && !(GROUP && !USIDE)) own_ds = reinterpret_cast<const int4*>(po.desc)[s_own];
+  __syncthreads();
+  FSTAMP(1);
+  // ---- BatchNorm statistics of the item block, by every workgroup alike (text towers) ----------
+  Row bmul = row_zero(), badd = row_zero(), bmu = row_zero(), binv = row_zero();
+  if (bn_on) {
+    if (f.stats) {
+      const int nv = pv.counts[0];  // the block's real rows = the batch's unique items (both schemes)
+      const Row x0 = row_load(a.bn_z, 0, a.stride, d4, q);
+      Row s1 = row_zero(), s2 = row_zero();
+      for (int r0 = g; r0 < nv; r0 += 32 * 8) {
+        Row z[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {  // shifted sums (shift = row 0): no cancellation
+          const float4 da = make_float4(z[e].a.x - x0.a.x, z[e].a.y - x0.a.y, z[e].a.z - x0.a.z, z[e].a.w - x0.a.w);
+          const float4 db = make_float4(z[e].b.x - x0.b.x, z[e].b.y - x0.b.y, z[e].b.z - x0.b.z, z[e].b.w - x0.b.w);
+          s1.a = add4(s1.a, da);
+          s1.b = add4(s1.b, db);
+          s2.a = fma4v(da, da, s2.a);
+          s2.b = fma4v(db, db, s2.b);
+        }
+      }
+      // 32 groups -> column totals, in group order, through the (still unused) stage buffer
+      float* red = sOpp;  // [32][2][128]
+      reinterpret_cast<float4*>(red + (g * 2 + 0) * 128)[q] = s1.a;
+      reinterpret_cast<float4*>(red + (g * 2 + 0) * 128)[q + 16] = s1.b;
+      reinterpret_cast<float4*>(red + (g * 2 + 1) * 128)[q] = s2.a;
+      reinterpret_cast<float4*>(red + (g * 2 + 1) * 128)[q + 16] = s2.b;
+      __syncthreads();
+      if (tid < 128) {
+        const int c = tid;
+        float t1 = 0.f, t2 = 0.f;
+        for (int gg = 0; gg < 32; ++gg) {
+          t1 += red[(gg * 2 + 0) * 128 + c];
+          t2 += red[(gg * 2 + 1) * 128 + c];
+        }
+        float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
+        if (c < d) {
+          const float rn = 1.f / (float)max(nv, 1);
+          const float m1 = t1 * rn;
+          // x0 column c: columns [4q, 4q+4) then [64+4q, ...) -> read it back from the table (L1 hit)
+          mu = a.bn_z[c] + m1;
+          var = fmaxf(t2 * rn - m1 * m1, 0.f);
+          inv = rsqrtf(var + f.eps);
+          mul = f.gamma[c] * inv;
+          add = f.beta[c] - mu * mul;
+          if (blk == 0 && USIDE) {  // published once: later launches (tower backward) and the running statistics
+            f.stats[c] = mu;
+            f.stats[128 + c] = inv;
+            f.stats[256 + c] = var;
+            f.stats[384 + c] = mul;
+            f.stats[512 + c] = add;
+            if (update) {
+              f.rm[c] = f.momentum * f.rm[c] + (1.f - f.momentum) * mu;
+              f.rv[c] = f.momentum * f.rv[c] + (1.f - f.momentum) * var;
+            }
+          }
+        } else if (blk == 0 && USIDE) {
+          f.stats[384 + c] = 0.f;
+          f.stats[512 + c] = 0.f;
+        }
+        sStat[c] = mu;
+        sStat[128 + c] = inv;
+        sStat[384 + c] = mul;
+        sStat[512 + c] = add;
+      }
+      __syncthreads();
+      bmu = row_load(sStat, 0, 128, 32, q);
+      binv = row_load(sStat + 128, 0, 128, 32, q);
+      bmul = row_load(sStat + 384, 0, 128, 32, q);
+      badd = row_load(sStat + 512, 0, 128, 32, q);
+      __syncthreads();  // sOpp is reused by the stages
+    } else {
+      bmu = row_load(a.bn_stats, 0, 128, 32, q);
+      binv = row_load(a.bn_stats + 128, 0, 128, 32, q);
+      bmul = row_load(a.bn_stats + 384, 0, 128, 32, q);
+      badd = row_load(a.bn_stats + 512, 0, 128, 32, q);
+    }
+  }
+  auto item_load = [&](int64_t id, Row& zrow) -> Row {  // raw item row (after BatchNorm + ReLU for a text tower)
+    if (!bn_on) return row_load(a.V, id, a.stride, d4, q);
+    zrow = row_load(a.bn_z, id, a.stride, d4, q);
+    Row r;
+    r.a = bn_relu4(zrow.a, bmul.a, badd.a);
+    r.b = bn_relu4(zrow.b, bmul.b, badd.b);
+    if (q >= d4) r.a = zero4();
+    if (q + 16 >= d4) r.b = zero4();
+    return r;
+  };
+
+  Row rcur[4], rnext[4];
+  int kcur[4];
+  auto load_rows = [&](const int* ids, Row* rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Row zz;
+      rows[e] = (ids[e] >= 0) ? (USIDE ? item_load(ids[e], zz) : row_load(a.U, ids[e], a.stride, d4, q)) : row_zero();
+    }
+  };
+  load_rows(idA, rcur);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    kcur[e] = keyA[e];
+    idA[e] = idB[e];
+    keyA[e] = keyB[e];
+  }
+  load_ids(part + 2 * P, idB, keyB);
+  FSTAMP(2);
+  // ---- own rows: 16 unique ids of this side ---------------------------------------------------
+  int own_id = -1;
+  float own_c = 0.f, own_ss = 0.f, own_inv = 1.f;
+  Row own_raw = row_zero(), own_hat = row_zero(), own_z = row_zero();
+  if (g < kFM) {
+    int kstart = 0, kcnt = 0;
+    if (own_ok) {
+      int key0 = 0, cnt = 1, start = 0;
+      if (GROUP && !USIDE) {
+        own_id = pv.uniq[s_own];
+        key0 = s_own;
+        own_c = 1.f;   // a unique item is one column however often it occurs in the batch
+      } else {
+        const int4 ds = own_ds;
+        own_id = ds.x;
+        own_c = (float)ds.w;
+        start = ds.z;
+        if (GROUP && USIDE) cnt = ds.w;                 // one key per position: the rank of that position's item
+        else key0 = po.inverse[ds.y];                   // the rank of this id: positions of the other side match it
+      }
+      own_raw = USIDE ? row_load(a.U, own_id, a.stride, d4, q) : item_load(own_id, own_z);
+      own_ss = row16_sum(row_dot_partial(own_raw, own_raw));
+      own_hat = own_raw;
+      if (USIDE ? NU : NV) {
+        own_inv = inv_norm(own_ss);
+        own_hat = row_scale(own_raw, own_inv);
+      }
+      kcnt = cnt;
+      if (q == 0) {
+        kstart = atomicAdd(&sTop[0], cnt);   // order of allocation is irrelevant: lists are only searched
+        if (kstart + cnt > kFKeys) kcnt = -cnt;
+      }
+      kstart = __shfl(kstart, lane & 48);
+      kcnt = __shfl(kcnt, lane & 48);
+      if (kcnt > 0) {
+        if (GROUP && USIDE) {
+          for (int t = q; t < cnt; t += 16) sKeys[kstart + t] = pv.inverse[pu.order[start + t]];
+        } else if (q == 0) {
+          sKeys[kstart] = key0;
+        }
+      } else {
+        kstart = start;  // overflow: the element-wise stage reads pv.inverse[pu.order[start + t]] itself
+      }
+    }
+    lds_store_row_f(sOwn + g * kFDP, q, own_hat);
+    if (q == 0) {
+      sCnt[g] = own_c;
+      sRowReg[g] = own_c * own_ss;
+      sKeyStart[g] = kstart;
+      sKeyCnt[g] = kcnt;
+    }
+  }
+
+  __syncthreads();
+  // this lane's four own rows (4 kq + r) never change: multiplicity and positive-column key(s) in registers
+  float cnt_r[4];
+  int ks_r[4], kc_r[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (lane >> 4) + r;
+    cnt_r[r] = sCnt[i];
+    ks_r[r] = sKeyStart[i];
+    kc_r[r] = sKeyCnt[i];
+    if (!(GROUP && USIDE)) ks_r[r] = (kc_r[r] > 0) ? sKeys[ks_r[r]] : -2;   // a single key: hold the key itself
+  }
+  FSTAMP(3);
+  // ---- stages over the opposite side: ids two stages ahead, rows one stage ahead -----------------------
+  FSTAMP(4);
+
+  const float inv_b = 1.f / (float)b;
+  const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;  // objectives.py:100,107,203,211
+  const int x = lane & 15, kq = lane >> 4;
+  f32x4 accD0 = {0.f, 0.f, 0.f, 0.f}, accD1 = {0.f, 0.f, 0.f, 0.f};
+  float lsum = 0.f;
+  const bool back_wave = wave * 16 < NP;
+
+  int stamp_i = 0;
+  for (int st = part; st < nst; st += P, ++stamp_i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Row r = rcur[e];
+      if (USIDE ? NV : NU) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
+      lds_store_row_f(sOpp + (g + 32 * e) * kFDP, q, r);
+      if (q == 0) sOppKey[g + 32 * e] = kcur[e];
+    }
+    __syncthreads();
+    if (stamp_i < 4) FSTAMP(5 + 4 * stamp_i);
+    // next stage's rows (their ids arrived a stage ago) and the ids of the stage after it travel under this
+    // stage's MFMAs
+    load_rows(idA, rnext);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kcur[e] = keyA[e];
+      idA[e] = idB[e];
+      keyA[e] = keyB[e];
+    }
+    load_ids(st + 3 * P, idB, keyB);
+
+    // S tile of this wave: own rows x opposite rows [16 wave, 16 wave + 16).  The MFMA's k index is permuted
+    // (the same way for both operands): in a group of 16 columns lane (x, kq) supplies columns 4kq .. 4kq+3,
+    // one per MFMA -- one ds_read_b128 per operand and four MFMAs; fragments are fetched two groups ahead.
+    f32x4 acc;
+    {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float4* pa4 = reinterpret_cast<const float4*>(sOwn + x * kFDP + 4 * kq);
+      const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kFDP + 4 * kq);
+      const int ng = NP >> 4;   // 7 (d = 100) or 8 (d = 128); columns past d are zero in LDS
+      if (ng == 7) s_tile<7>(pa4, pb4, acc0, acc1);        // straight-line: all fragments requested up front,
+      else if (ng == 8) s_tile<8>(pa4, pb4, acc0, acc1);   // the compiler waits with counted lgkmcnt per MFMA group
+      else
+        for (int t = 0; t < ng; ++t) s_tile<1>(pa4 + 4 * t, pb4 + 4 * t, acc0, acc1);
+      acc = acc0 + acc1;
+    }
+
+    if (stamp_i < 4) FSTAMP(6 + 4 * stamp_i);
+    // dL/dS, element-wise: lane holds rows 4 kq + r of column 16 wave + x
+    {
+      const int j = 16 * wave + x;
+      const int okey = sOppKey[j];
+      const bool cvalid = st * kFNB + j < n_opp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * kq + r;
+        const float s = acc[r];
+        const float c = cnt_r[r];
+        float m = 0.f;
+        if (!(GROUP && USIDE)) {
+          m = (ks_r[r] == okey) ? 1.f : 0.f;
+        } else {
+          const int ks = ks_r[r], kc = kc_r[r];
+          if (kc >= 0) {
+            for (int t = 0; t < kc; ++t) m += (sKeys[ks + t] == okey) ? 1.f : 0.f;
+          } else {
+            for (int t = 0; t < -kc; ++t) m += (pv.inverse[pu.order[ks + t]] == okey) ? 1.f : 0.f;
+          }
+        }
+        float l, h;
+        if (LOSS == NNCF_LOSS_SKIP_GRAM) {
+          float sp, sg;
+          softplus_sigmoid(s, sp, sg);               // negatives: label -1 -> -log sigmoid(-s) = softplus(s)
+          l = (c - m) * wneg * sp;
+          h = (c - m) * wneg * sg;
+          if (m > 0.f) {
+            softplus_sigmoid(-s, sp, sg);            // positives: -log sigmoid(s)
+            l += m * sp;
+            h -= m * sg;
+          }
+        } else {                                     // mse
+          l = (c - m) * wneg * s * s + m * (s - 1.f) * (s - 1.f);
+          h = 2.f * ((c - m) * wneg * s + m * (s - 1.f));
+        }
+        if (!cvalid || c == 0.f) {
+          l = 0.f;
+          h = 0.f;
+        }
+        sG[i * kFGP + j] = h * inv_b;
+        lsum += l;
+      }
+    }
+    __syncthreads();
+
+    if (stamp_i < 4) FSTAMP(7 + 4 * stamp_i);
+    // back-GEMM: dOwn[16][d] += G[16][128] . Opp[128][d]; wave = 16-column tile of the output.  Same k
+    // permutation: in a group of 16 opposite rows lane (x, kq) supplies rows 4kq .. 4kq+3 (G: one
+    // ds_read_b128; rows of one half-wave are 4 apart = 16 banks: conflict-free ds_read_b32).
+    if (back_wave) {
+      const float4* pg4 = reinterpret_cast<const float4*>(sG + x * kFGP + 4 * kq);
+      const float* pbv = sOpp + (4 * kq) * kFDP + 16 * wave + x;
+      float4 g0 = pg4[0];
+      float4 v0 = make_float4(pbv[0], pbv[kFDP], pbv[2 * kFDP], pbv[3 * kFDP]);
+      float4 g1 = pg4[4];
+      float4 v1 = make_float4(pbv[16 * kFDP], pbv[17 * kFDP], pbv[18 * kFDP], pbv[19 * kFDP]);
+#pragma unroll
+      for (int t = 0; t < kFNB / 16; ++t) {
+        float4 g2 = g1, v2 = v1;
+        if (t + 2 < kFNB / 16) {
+          g2 = pg4[4 * (t + 2)];
+          const float* pr = pbv + 16 * (t + 2) * kFDP;
+          v2 = make_float4(pr[0], pr[kFDP], pr[2 * kFDP], pr[3 * kFDP]);
+        }
+        NNCF_MFMA4(g0, v0, accD0, accD1);
+        g0 = g1;
+        v0 = v1;
+        g1 = g2;
+        v1 = v2;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rcur[e] = rnext[e];
+    __syncthreads();
+    if (stamp_i < 4) FSTAMP(8 + 4 * stamp_i);
+  }
+
+  // ---- output rows -> LDS, loss partial ---------------------------------------------------------
+  float* sOut = sOpp;  // [16][kFOP]; the stage buffer is free after the last back-GEMM's barrier
+  if (back_wave) {
+    const f32x4 accD = accD0 + accD1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sOut[(4 * kq + r) * kFOP + 16 * wave + x] = accD[r];
+  }
+  if (USIDE) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) sRed[wave] = lsum;
+  }
+  __syncthreads();
+  if (USIDE && tid == 0) {
+    float reg = 0.f;
+    for (int i = 0; i < kFM; ++i) reg += sRowReg[i];
+    const float l = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+    // utilities.py:122-135 over the b rows (the regulariser is counted once per strip: by part 0)
+    f.loss_part[blk * P + part] = l * inv_b + (part == 0 ? a.u_reg * reg * inv_b : 0.f);
+  }
+
+  FSTAMP(20);
+  // ---- split strips: publish this part's rows; the last part to arrive adds them up ---------------------------
+  const int parts = min(P, nst);   // parts that own at least one stage
+  if (parts > 1) {
+    const int strip = (USIDE ? 0 : (a.b + kFM - 1) / kFM) + blk;
+    float* slab = f.slab + ((int64_t)strip * P + part) * kFM * 128;
+    // payload: write-through (sc1) 16-byte stores -- no release fence (no whole-L2 write-back); every storing
+    // wave drains its stores, then ONE lane takes the ticket (cdna_hip_programming.md, Guideline 16, R1)
+    if (g < kFM) {
+      store_sc1(slab + g * 128 + 4 * q, reinterpret_cast<const f32x4*>(sOut + g * kFOP)[q]);
+      store_sc1(slab + g * 128 + 64 + 4 * q, reinterpret_cast<const f32x4*>(sOut + g * kFOP)[q + 16]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(f.cnt + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == parts - 1;
+      if (last) {
+        __hip_atomic_store(f.cnt + strip, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      sTop[1] = last;
+    }
+    __syncthreads();
+    FSTAMP(23);
+    if (!sTop[1]) return;
+    if (g < kFM) {   // parts in part order, whoever arrived last
+      Row acc = row_zero();
+      for (int pp = 0; pp < parts; ++pp) {
+        const float* src = f.slab + ((int64_t)strip * P + pp) * kFM * 128 + g * 128;
+        acc.a = add4(acc.a, reinterpret_cast<const float4*>(src)[q]);
+        acc.b = add4(acc.b, reinterpret_cast<const float4*>(src)[q + 16]);
+      }
+      reinterpret_cast<float4*>(sOut + g * kFOP)[q] = acc.a;
+      reinterpret_cast<float4*>(sOut + g * kFOP)[q + 16] = acc.b;
+    }
+  }
+
+  FSTAMP(21);
+  // ---- finalize: one 16-lane group per own row -----------------------------------------------------
+  Row t1 = row_zero(), t2 = row_zero();  // BatchNorm backward sums of this workgroup's item rows
+  if (update && own_ok) {
+    Row acc;
+    acc.a = reinterpret_cast<const float4*>(sOut + g * kFOP)[q];
+    acc.b = reinterpret_cast<const float4*>(sOut + g * kFOP)[q + 16];
+    if (q >= d4) acc.a = zero4();
+    if (q + 16 >= d4) acc.b = zero4();
+    Row grad = acc;
+    if (USIDE ? NU : NV) grad = norm_backward(own_hat, own_inv, own_ss, acc);
+    if (USIDE) {
+      grad = row_fma(2.f * a.u_reg * own_c * inv_b, own_raw, grad);
+      apply_update(a, a.au, a.U, own_id, own_raw, grad, d4, q);
+    } else {
+      if (a.gV) row_store(a.gV, own_id, d, d4, q, grad);
+      else apply_update(a, a.av, a.V, own_id, own_raw, grad, d4, q);
+      if (bn_on && a.bn_part) {
+        bn_tail_acc4(own_raw.a, grad.a, own_z.a, bmu.a, binv.a, t1.a, t2.a);
+        bn_tail_acc4(own_raw.b, grad.b, own_z.b, bmu.b, binv.b, t1.b, t2.b);
+      }
+    }
+  }
+  if (!USIDE && update && bn_on && a.bn_part) {  // per-workgroup partials of sum dy, sum dy*xhat, in group order
+    __syncthreads();
+    float* red = sOpp + kFM * kFOP;  // [16][2][128], past the output rows
+    if (g < kFM) {
+      reinterpret_cast<float4*>(red + (g * 2 + 0) * 128)[q] = t1.a;
+      reinterpret_cast<float4*>(red + (g * 2 + 0) * 128)[q + 16] = t1.b;
+      reinterpret_cast<float4*>(red + (g * 2 + 1) * 128)[q] = t2.a;
+      reinterpret_cast<float4*>(red + (g * 2 + 1) * 128)[q + 16] = t2.b;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int half = tid >> 7, c = tid & 127;
+      float v = 0.f;
+      for (int gg = 0; gg < kFM; ++gg) v += red[(gg * 2 + half) * 128 + c];
+      a.bn_part[(int64_t)blk * 256 + half * 128 + c] = v;
+    }
+  }
+  FSTAMP(22);
+}
+
+// grid = 8 * ceil(2 gu / 8) * split + 1 workgroups, gu strips per side.  All parts of a strip get
+// block ids of one residue mod 8 -- the same XCD under round-robin dispatch (a speed choice only: the hand-off
+// between the parts is agent-scope and correct for any placement).
+template <int LOSS, bool GROUP, bool NU, bool NV>
+__global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int32_t* __restrict__ uid,
+                                                          const int32_t* __restrict__ cid, FusedArgs f, PlanView pu,
+                                                          PlanView pv, int update, int gu, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float fused_smem[];
+  const int id = blockIdx.x;
+  const int P = f.split;
+  if (id == nblk) {  // the previous step's loss: partials of its U-pass workgroups, in workgroup order
+    if (threadIdx.x < 64 && f.prev_out) {
+      float l = 0.f;
+      for (int i = threadIdx.x; i < f.prev_n; i += 64) l += f.prev_part[i];
+      l = wave_sum(l);
+      if (threadIdx.x == 0) *f.prev_out = l;
+    }
+    return;
+  }
+  const int rest = id >> 3;
+  const int part = rest % P, strip = (rest / P) * 8 + (id & 7);
+  if (strip >= 2 * gu) return;
+  const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];   // segments (neg_shared) and unique ranks (group): same count
+  if (strip < gu) {
+    const int n_items = GROUP ? nseg_v : a.b;
+    const int nst = (n_items + kFNB - 1) / kFNB;
+    if (strip * kFM >= nseg_u || part >= nst) {
+      if (threadIdx.x == 0) f.loss_part[strip * P + part] = 0.f;
+      return;
+    }
+    fused_body<LOSS, GROUP, NU, NV, true>(a, uid, cid, f, pu, pv, strip, part, update, fused_smem);
+  } else {
+    const int vb = strip - gu;
+    const int nst = (a.b + kFNB - 1) / kFNB;
+    if (vb * kFM >= nseg_v) {
+      if (part == 0 && a.bn_part && threadIdx.x < 256) a.bn_part[(int64_t)vb * 256 + threadIdx.x] = 0.f;
+      return;
+    }
+    if (!update || part >= nst) return;  // loss-only: the U-pass alone
+    fused_body<LOSS, GROUP, NU, NV, false>(a, uid, cid, f, pu, pv, vb, part, update, fused_smem);
+  }
+}
+
+__global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  float l = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) l += part[i];
+  l = wave_sum(l);
+  if (threadIdx.x == 0) *out = l;
+}
+
+namespace {
+
+template <int LOSS, bool GROUP, bool NU, bool NV>
+int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
+             const PlanView& pv, int update, hipStream_t stream) {
+  const int gu = (a.b + kFM - 1) / kFM;
+  const int nblk = ((2 * gu + 7) / 8) * 8 * f.split;
+  auto kern = fused_strip_kernel<LOSS, GROUP, NU, NV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)fused_lds_bytes()));
+    attr_set = true;
+  }
+  {
+    ProfScope _ps("fused_strip_kernel", stream);
+    hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, f, pu, pv, update, gu, nblk);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+template <int LOSS, bool GROUP>
+int launch_fn(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
+              const PlanView& pv, int update, hipStream_t stream) {
+  if (a.norm_u) {
+    if (a.norm_v) return launch_f<LOSS, GROUP, true, true>(a, uid, cid, f, pu, pv, update, stream);
+    return launch_f<LOSS, GROUP, true, false>(a, uid, cid, f, pu, pv, update, stream);
+  }
+  if (a.norm_v) return launch_f<LOSS, GROUP, false, true>(a, uid, cid, f, pu, pv, update, stream);
+  return launch_f<LOSS, GROUP, false, false>(a, uid, cid, f, pu, pv, update, stream);
+}
+
+}  // namespace
+
+bool fused_eligible(const StepArgs& a) {
+  return (a.loss == NNCF_LOSS_SKIP_GRAM || a.loss == NNCF_LOSS_MSE) && !a.ub && !a.cb && a.b % kFM == 0;
+}
+
+int fused_max_blocks(int b) { return (b + kFM - 1) / kFM; }
+
+// workgroups per strip: enough to put ~one workgroup on every CU (b = 512: 64 strips x 4), never more than the
+// stages of the shorter side
+int fused_split(int b) {
+  const int strips = 2 * fused_max_blocks(b);
+  int p = 256 / strips;
+  const int nst = (b + kFNB - 1) / kFNB;
+  if (p > nst) p = nst;
+  if (p > kFusedMaxSplit) p = kFusedMaxSplit;
+  return p < 1 ? 1 : p;
+}
+
+int launch_fused(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const FusedArgs& f,
+                 const PlanView& pu, const PlanView& pv, int update, hipStream_t stream) {
+  if (a.loss == NNCF_LOSS_SKIP_GRAM)
+    return group ? launch_fn<NNCF_LOSS_SKIP_GRAM, true>(a, uid, cid, f, pu, pv, update, stream)
+                 : launch_fn<NNCF_LOSS_SKIP_GRAM, false>(a, uid, cid, f, pu, pv, update, stream);
+  return group ? launch_fn<NNCF_LOSS_MSE, true>(a, uid, cid, f, pu, pv, update, stream)
+               : launch_fn<NNCF_LOSS_MSE, false>(a, uid, cid, f, pu, pv, update, stream);
+}
+
+int launch_fused_flush(const float* part, int n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(fused_loss_flush_kernel, dim3(1), dim3(64), 0, stream, part, n, out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+}  // namespace nncf

@@ -26,8 +26,10 @@
 // [K-mem] Keras-1 BatchNormalization: eps 1e-3, momentum 0.99, biased variance.
 #include <cstdlib>
 #include <new>
+#include <string>
 
 #include "tower.h"
+#include "step_fused.h"
 
 namespace nncf {
 
@@ -185,26 +187,6 @@ __device__ __forceinline__ void column_sums(const TowerArgs& a, int nv, F&& elem
     for (int w = 0; w < 16; ++w) {
       t1 += sS[(w * 2 + 0) * kTP + tid];
       t2 += sS[(w * 2 + 1) * kTP + tid];
-    }
-  }
-}
-
-// partial column sums of every workgroup -> totals, in workgroup order (threads c < d)
-__device__ __forceinline__ void merge_partials(const float* part, int nparts, int c, float& t1, float& t2) {
-  t1 = 0.f;
-  t2 = 0.f;
-  for (int p0 = 0; p0 < nparts; p0 += 16) {
-    float u1[16], u2[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float* in = part + (size_t)(p0 + e) * 2 * 128;
-      u1[e] = (p0 + e < nparts) ? in[c] : 0.f;
-      u2[e] = (p0 + e < nparts) ? in[128 + c] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      t1 += u1[e];
-      t2 += u2[e];
     }
   }
 }
@@ -778,6 +760,7 @@ void carve_tower(nncf_tower* t, Carver& c) {
     t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
   }
   t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
+  t->Wd_alt = c.take<float>(hd * d);
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
 }
@@ -785,7 +768,9 @@ void carve_tower(nncf_tower* t, Carver& c) {
 TowerArgs base_args(const nncf_tower* t) {
   TowerArgs a{};
   const nncf_tower_params& p = t->prm;
-  a.W = p.words; a.Wd = p.dense_w; a.bd = p.dense_b; a.gamma = p.bn_gamma; a.beta = p.bn_beta;
+  a.W = p.words; a.bd = p.dense_b; a.gamma = p.bn_gamma; a.beta = p.bn_beta;
+  a.Wd = t->wd_in_alt ? t->Wd_alt : p.dense_w;
+  a.Wd_next = t->wd_in_alt ? p.dense_w : t->Wd_alt;
   a.rm = p.bn_mean; a.rv = p.bn_var;
   a.content = p.content; a.item_ptr = p.item_ptr; a.item_word = p.item_word; a.item_cnt = p.item_cnt;
   a.h = t->h; a.z = t->z; a.dh = t->dh; a.ws = t->ws; a.cnt_t = t->cnt_t;
@@ -808,7 +793,7 @@ inline int stat_grid(int m) { return (m + 1023) / 1024; }  // workgroups of the 
 
 // forward of a block: rows of ids -> E.  train: batch statistics, h / z kept, optional fill.
 int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_valid, int train, int fill,
-                  const float* scale, float* E, hipStream_t st) {
+                  const float* scale, float* E, hipStream_t st, bool stats_by_consumer = false) {
   TowerArgs a = base_args(t);
   a.ids = ids; a.m = m; a.n_valid = n_valid; a.train = train; a.fill = fill; a.scale = scale; a.E = E;
   if (train && t->drop_rate > 0.f) {
@@ -825,7 +810,10 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     ProfScope _ps("tower_pool_kernel", st);
     hipLaunchKernelGGL(tower_pool_kernel, dim3((unsigned)m), dim3(256), 0, st, a);
   }
-  if (train) {
+  if (train && stats_by_consumer) {  // the one-launch step derives the statistics itself (step_fused.hip)
+    t->last = a;
+    t->fwd_cached = true;
+  } else if (train) {
     {
       ProfScope _ps("tower_stats_kernel", st);
       hipLaunchKernelGGL(tower_stats_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
@@ -893,6 +881,82 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   return NNCF_OK;
 }
 
+// One-launch backward of the shared-negative schemes (tower_fused.hip): dz in registers, the word rows
+// accumulated in dz space and multiplied by Wd^T once, the dWd tiles stepping the other Wd buffer.
+int tower_backward_fused(nncf_tower* t, const float* dA, hipStream_t st, int nfused, int64_t step_t, const CellsView& cv) {
+  TowerArgs a = t->last;
+  a.dA = dA;
+  a.gexp = t->gexp;
+  a.opt = t->gexp ? 0 : t->opt;
+  if (a.opt) {
+    const double tt = (double)(step_t > 0 ? step_t : t->adam_t + 1);
+    a.beta1 = t->beta1;
+    a.beta2 = t->beta2;
+    a.aeps = t->aeps;
+    a.lr_t = (float)((double)a.lr * std::sqrt(1.0 - std::pow((double)t->beta2, tt)) / (1.0 - std::pow((double)t->beta1, tt)));
+    a.step_no = (int)tt;
+    a.aw = t->aw;
+    a.mD = t->mD;
+    a.vD = t->vD;
+  }
+  if (int rc = launch_wordbwd(a, cv, nfused, st)) return rc;
+  if (!a.gexp) t->wd_in_alt = !t->wd_in_alt;  // the stepped Dense weights are in the other buffer now
+  if (a.opt && step_t <= 0) t->adam_t++;
+  return NNCF_OK;
+}
+
+// The caller's dense_w array is the tower's interface: before an entry point returns the current Dense
+// weights are copied back into it if the last step left them in the second buffer.
+int tower_sync_wd(nncf_tower* t, hipStream_t st) {
+  if (!t->wd_in_alt) return NNCF_OK;
+  const size_t hd = t->cnn.F > 0 ? (size_t)t->cnn.F : (size_t)t->cfg.word_dim;
+  NNCF_HIP_CHECK(hipMemcpyAsync(t->prm.dense_w, t->Wd_alt, sizeof(float) * hd * t->cfg.item_dim, hipMemcpyDeviceToDevice, st));
+  t->wd_in_alt = false;
+  return NNCF_OK;
+}
+
+// word -> (slot, count) lists for `rows`-row blocks (allocated on first use, own allocation)
+int ensure_cells(nncf_tower* t, int rows) {
+  if (t->cells_mem && t->cells_rows >= rows) return NNCF_OK;
+  DeviceGuard guard(t->device);
+  if (t->cells_mem) (void)hipFree(t->cells_mem);
+  t->cells_mem = nullptr;
+  const int W = t->cfg.word_count, rw = (rows + 31) / 32;
+  const int64_t cap = (int64_t)rows * t->cfg.content_len;
+  Carver c;
+  auto lay = [&](Carver& cc, CellsView& v) {
+    v.bits = cc.take<uint32_t>((size_t)kPlanChunk * W * rw);
+    v.off = cc.take<int32_t>((size_t)kPlanChunk * (W + 1));
+    v.cells = cc.take<int32_t>((size_t)kPlanChunk * cap);
+    v.rw = rw;
+    v.cells_cap = cap;
+    v.n_words = W;
+  };
+  CellsView dry;
+  lay(c, dry);
+  if (hipMalloc(&t->cells_mem, c.off + 256) != hipSuccess) return fail(NNCF_ERR_NOMEM, "cell-list allocation (%zu bytes) failed", c.off);
+  Carver real;
+  real.base = static_cast<char*>(t->cells_mem);
+  lay(real, t->cells);
+  t->cells_rows = rows;
+  return NNCF_OK;
+}
+
+// does the one-launch backward apply to a step of this scheme?
+bool wordbwd_applies(const nncf_tower* t, const nncf_model* m, int scheme) {
+  const int b = m->cfg.batch_size_p;
+  return t->use_wordbwd && t->cnn.F == 0 && (scheme == 1 || scheme == 2) && b <= 1024 && (b + kChunkSlots - 1) / kChunkSlots <= kTowerWG;
+}
+
+int plan_cells(nncf_tower* t, const nncf_model* m, int scheme, const int32_t* uniq_g, const int32_t* n_u, int64_t uniq_stride,
+               int64_t n_steps, hipStream_t st) {
+  if (!wordbwd_applies(t, m, scheme)) return NNCF_OK;
+  const int b = m->cfg.batch_size_p;
+  if (int rc = ensure_cells(t, b)) return rc;
+  TowerArgs a = base_args(t);
+  return launch_cells(a, t->cells, uniq_g, n_u, uniq_stride, b, n_steps, st);
+}
+
 int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
   if (!t || !m) return fail(NNCF_ERR_INVALID, "tower / model is NULL");
   NNCF_REQUIRE(scheme >= 0 && scheme <= 3, "scheme must be 0 (original), 1 (neg_shared), 2 (group_neg_shared) or 3 (row-wise)");
@@ -910,19 +974,32 @@ int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
 // one planned step: plans pu / pv (localized), the block's global ids and count on device
 int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid, const PlanView& pu,
                     const PlanView& pv, const int32_t* uniq_g, const int32_t* n_u, int n, float* loss, int update,
-                    const float* scale, hipStream_t st, const int32_t* y = nullptr) {
+                    const float* scale, hipStream_t st, const int32_t* y = nullptr, const CellsView* cells = nullptr) {
   // the normalised block is never written: the step kernels apply BatchNorm + ReLU when they
   // load an item row from z
-  int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st);
-  if (rc) return rc;
   const int b = m->cfg.batch_size_p;
   const int32_t* cid_local = pv.inverse;  // batch position -> row of the item block
   StepArgs sa = make_args(m);
   sa.bn_z = t->z;
   sa.bn_stats = t->ws + ws_muinv();
   sa.item_gid = uniq_g;  // InteractionDot item bias is indexed by catalogue id, the block by tf.unique rank
-  // shared schemes: the apply kernel's item chunks (b / 16 of them) emit the BN backward's sums
-  const int chunks = (b + kChunkSlots - 1) / kChunkSlots;
+  // shared schemes with a pointwise loss: ONE launch does statistics + scores + loss + both updates
+  const bool one_launch = (scheme == 1 || scheme == 2) && shared_step_fuses(m, sa);
+  const bool wb = cells != nullptr && update && wordbwd_applies(t, m, scheme);   // one-launch backward: no count matrix
+  int rc = tower_forward(t, uniq_g, n, n_u, 1, update && !wb, scale, nullptr, st, one_launch);
+  if (rc) return rc;
+  FusedArgs fa;
+  if (one_launch) {
+    fa.stats = t->ws + ws_muinv();
+    fa.gamma = t->prm.bn_gamma;
+    fa.beta = t->prm.bn_beta;
+    fa.rm = t->prm.bn_mean;
+    fa.rv = t->prm.bn_var;
+    fa.eps = t->cfg.bn_eps;
+    fa.momentum = t->cfg.bn_momentum;
+  }
+  // shared schemes: the item-side workgroups (b / 16 of them) emit the BN backward's sums
+  const int chunks = one_launch ? fused_max_blocks(b) : (b + kChunkSlots - 1) / kChunkSlots;
   const int nfused = ((scheme == 1 || scheme == 2) && update && chunks <= kTowerWG) ? chunks : 0;
   if (nfused) sa.bn_part = t->ws + ws_bsum();
   const bool big = (scheme == 0 || scheme == 3) && update;   // thousands of rows: partials per item chunk, merged by one workgroup
@@ -933,14 +1010,15 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   else if (scheme == 3)
     rc = launch_rowwise(sa, uid, cid_local, y, m->rws, pu, pv, n, loss, update, st);
   else
-    rc = launch_shared(sa, scheme == 2, uid, cid_local, m->sws, pu, pv, loss, update, st);
+    rc = shared_step(m, sa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, one_launch ? &fa : nullptr);
   if (rc || !update) return rc;
   if (big) {
     TowerArgs ma = t->last;
     ProfScope _ps("tower_merge_kernel", st);
     hipLaunchKernelGGL(tower_merge_kernel, dim3(1), dim3(1024), 0, st, ma, t->bpart, cv);
   }
-  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
+  if (wb && nfused) rc = tower_backward_fused(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, *cells);
+  else rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
   if (rc) return rc;
   return finish_update(m, sa, st);
 }
@@ -984,6 +1062,7 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   t->prm = *prm;
   t->device = device;
   t->ks = (cfg->max_rows + kRowsPerK - 1) / kRowsPerK;
+  if (const char* e = getenv("NNCF_TOWER_BWD")) t->use_wordbwd = std::string(e) != "split";
   if (cfg->conv_filters > 0) {
     CnnArgs& c = t->cnn;
     c.F = cfg->conv_filters;
@@ -1033,6 +1112,7 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
   if (t->stamps) hipFree(t->stamps);
+  if (t->cells_mem) hipFree(t->cells_mem);
   delete t;
   return NNCF_OK;
 }
@@ -1187,9 +1267,14 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
   if (rc) return rc;
   rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st);
   if (rc) return rc;
-  rc = tower_step_body(t, m, scheme, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st);
+  const bool wb = update && wordbwd_applies(t, m, scheme);
+  if (wb && (rc = plan_cells(t, m, scheme, t->uniq_g, t->n_u, t->cfg.max_rows, 1, st))) return rc;
+  rc = tower_step_body(t, m, scheme, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st,
+                       nullptr, wb ? &t->cells : nullptr);
   t->fwd_cached = false;
-  return rc;
+  if (rc) return rc;
+  if ((rc = tower_sync_wd(t, st))) return rc;
+  return flush_pending_loss(m, st);
 }
 
 int nncf_tower_step_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid, const int32_t* d_cid, const int32_t* d_y,
@@ -1249,7 +1334,9 @@ int nncf_tower_plan_steps(nncf_tower* t, nncf_model* m, int32_t scheme, const in
   if (scheme == 0) rc = launch_plan(d_cid, b, (int)b, d_neg, b * k, (int)(b * k), m->plan_v, n_steps, st);
   else rc = launch_plan(d_cid, b, (int)b, nullptr, 0, 0, m->plan_v, n_steps, st);
   if (rc) return rc;
-  return launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, n_steps, t->cfg.max_rows);
+  rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, n_steps, t->cfg.max_rows);
+  if (rc) return rc;
+  return plan_cells(t, m, scheme, t->uniq_g, t->n_u, t->cfg.max_rows, n_steps, st);
 }
 
 int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t index, const int32_t* d_uid, float* d_loss,
@@ -1260,10 +1347,15 @@ int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t ind
   NNCF_REQUIRE(index >= 0 && index < kPlanChunk, "plan slot %lld out of range", (long long)index);
   const int64_t b = m->cfg.batch_size_p, cap = t->cfg.max_rows;
   const int n = (int)(scheme == 0 ? b * (1 + m->cfg.num_negatives) : b);
-  const int rc = tower_step_body(t, m, scheme, d_uid, m->plan_u.at(index), m->plan_v.at(index), t->uniq_g + index * cap,
-                                 t->n_u + index, n, d_loss, 1, nullptr, as_stream(stream));
+  const bool wb = wordbwd_applies(t, m, scheme) && t->cells_mem != nullptr;
+  CellsView cvi;
+  if (wb) cvi = t->cells.at(index);
+  int rc = tower_step_body(t, m, scheme, d_uid, m->plan_u.at(index), m->plan_v.at(index), t->uniq_g + index * cap,
+                           t->n_u + index, n, d_loss, 1, nullptr, as_stream(stream), nullptr, wb ? &cvi : nullptr);
   t->fwd_cached = false;
-  return rc;
+  if (rc) return rc;
+  if ((rc = tower_sync_wd(t, as_stream(stream)))) return rc;
+  return flush_pending_loss(m, as_stream(stream));
 }
 
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,
@@ -1289,16 +1381,21 @@ int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t
     if (rc) return rc;
     rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, cnt, cap);
     if (rc) return rc;
+    const bool wb = wordbwd_applies(t, m, scheme);
+    if (wb && (rc = plan_cells(t, m, scheme, t->uniq_g, t->n_u, cap, cnt, st))) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t s = t0 + i;
+      CellsView cvi;
+      if (wb) cvi = t->cells.at(i);
       rc = tower_step_body(t, m, scheme, d_uid_all + s * b, m->plan_u.at(i), m->plan_v.at(i), t->uniq_g + i * cap,
-                           t->n_u + i, n, d_loss + s, 1, nullptr, st);
+                           t->n_u + i, n, d_loss + s, 1, nullptr, st, nullptr, wb ? &cvi : nullptr);
       if (rc) return rc;
     }
     if (d_n_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_n_u + t0, t->n_u, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, st));
   }
   t->fwd_cached = false;
-  return NNCF_OK;
+  if (int rc = tower_sync_wd(t, st)) return rc;
+  return flush_pending_loss(m, st);
 }
 
 }  // extern "C"

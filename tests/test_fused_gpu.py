@@ -1,0 +1,123 @@
+"""GPU: the one-launch shared-negative step (csrc/step_fused.hip: U-pass + V-pass strips, pointwise
+losses) against the numpy oracle, and against the two-launch tile + apply path it replaces
+(NNCF_SHARED_PATH=tile) -- duplicates on both sides, ragged stage counts, loss-only mode, key-list
+overflow."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+from oracle import step_oracle as so  # noqa: E402
+from nncf_amd.engine import Engine  # noqa: E402
+
+
+def _mk(loss, b, d, nu, ni, model, path, seed=0, lr=0.05, u_reg=1e-3):
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, u_reg=u_reg, learn_rate=lr, model_choice=model,
+                         neg_loss_weight=8. if loss == "mse" else 128.)
+    old = os.environ.get("NNCF_SHARED_PATH")
+    os.environ["NNCF_SHARED_PATH"] = path
+    try:
+        eng = Engine(nu, ni, d, b, 0, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                     conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5)
+    finally:
+        if old is None:
+            del os.environ["NNCF_SHARED_PATH"]
+        else:
+            os.environ["NNCF_SHARED_PATH"] = old
+    # float64 oracle: with an item in ~40 of 512 positions a float32 reference is itself 5e-6 off
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    return conf, eng, orc
+
+
+def _batch(rs, b, nu, ni, group):
+    uid = rs.randint(0, nu, b)
+    uid[:6] = uid[0]                      # one user six times
+    if group:
+        cid = np.repeat(np.minimum((ni * rs.power(0.4, b // 4)).astype(np.int64), ni - 1), 4)
+    else:
+        cid = np.minimum((ni * rs.power(0.4, b)).astype(np.int64), ni - 1)   # popular items repeat
+    return uid, cid
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+@pytest.mark.parametrize("shape", [(64, 20, 50, 300), (512, 100, 700, 600), (256, 128, 3000, 90), (32, 4, 10, 12)])
+def test_fused_step_matches_oracle_and_tile_path(loss, scheme, shape):
+    b, d, nu, ni = shape
+    group = scheme == "group_neg_shared"
+    conf, eng, orc = _mk(loss, b, d, nu, ni, "mf", "fused", seed=2)
+    _, eng_t, _ = _mk(loss, b, d, nu, ni, "mf", "tile", seed=2)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        uid, cid = _batch(rs, b, nu, ni, group)
+        if group:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            ref = eng_t.step_group_neg_shared(eng_t.ids(uid), eng_t.ids(cid)).item()
+        else:
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            ref = eng_t.step_neg_shared(eng_t.ids(uid), eng_t.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (step, got, ref)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(eng_t.U.cpu().numpy(), orc.U, rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(eng_t.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+def test_fused_content_normalisation_and_loss_only(scheme):
+    """item-side L2 normalisation (content models) + update = 0 leaves the tables alone"""
+    b, d, nu, ni = 64, 24, 40, 80
+    group = scheme == "group_neg_shared"
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.05,
+                         model_choice="basic_embedding", emb_normalization=True)
+    eng = Engine(nu, ni, d, b, 0, "skip-gram", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate, True, True,
+                 seed=5, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(9)
+    uid, cid = _batch(rs, b, nu, ni, group)
+    U0, V0 = eng.U.clone(), eng.V.clone()
+    f = eng.step_group_neg_shared if group else eng.step_neg_shared
+    fo = orc.step_group_neg_shared if group else orc.step_neg_shared
+    l0 = f(eng.ids(uid), eng.ids(cid), update=False).item()
+    assert torch.equal(eng.U, U0) and torch.equal(eng.V, V0)
+    want = fo(uid, cid)
+    got = f(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)) and abs(l0 - want) <= 1e-5 * max(1.0, abs(want))
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+
+
+def test_fused_group_key_list_overflow():
+    """group_neg_shared, one user in 300 of 512 positions: its positive-column list does not fit the
+    workgroup's LDS key buffer and is read from the plan instead"""
+    b, d, nu, ni = 512, 20, 100, 400
+    conf, eng, orc = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=7)
+    rs = np.random.RandomState(1)
+    uid = rs.randint(0, nu, b)
+    uid[rs.choice(b, 300, replace=False)] = 17
+    cid = np.repeat(rs.choice(ni, b // 4, replace=False), 4)
+    want = orc.step_group_neg_shared(uid, cid)
+    got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=4e-6)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+
+
+def test_fused_epoch_runner_equals_step_by_step():
+    b, d, nu, ni, steps = 128, 40, 900, 800, 70     # 70 > one plan chunk of 64
+    _, e1, _ = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=4)
+    _, e2, _ = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=4)
+    rs = np.random.RandomState(8)
+    uid, cid = rs.randint(0, nu, steps * b), rs.randint(0, ni, steps * b)
+    ua, ca = e1.ids(uid), e1.ids(cid)
+    l1 = e1.epoch_neg_shared(ua, ca, steps).cpu().numpy()
+    l2 = np.array([e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)])
+    assert np.array_equal(l1, l2.astype(np.float32))
+    assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V)

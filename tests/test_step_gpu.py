@@ -380,3 +380,82 @@ def test_interaction_bias_adam_and_rowwise():
         assert abs(got - want) <= 2e-5 * max(1, abs(want))
         np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=1e-5, atol=2e-6)
+
+
+# ---- BASELINE configs[3]: 10M users x 1M items, d = 128, neg_shared (and original), id tables ---------------
+def _compact_oracle(eng, conf, uid_steps, cid_steps, V=None, item_offset=0):
+    """Oracle over ONLY the rows the steps touch (the step reads and writes nothing else): gathers those rows from
+    the device tables, remaps the ids; returns (oracle, user ids, item ids, remap functions)."""
+    users = np.unique(np.concatenate(uid_steps))
+    items = np.unique(np.concatenate(cid_steps))
+    Vt = eng.V if V is None else V
+    Us = eng.U[torch.as_tensor(users, device=eng.U.device)].cpu().numpy()
+    Vs = Vt[torch.as_tensor(items - item_offset, device=Vt.device)].cpu().numpy()
+    orc = so.StepOracle(Us, Vs, conf, dtype=np.float32)
+    return orc, users, items, (lambda u: np.searchsorted(users, u)), (lambda c: np.searchsorted(items, c))
+
+
+@pytest.mark.parametrize("scheme,loss", [("neg_shared", "skip-gram"), ("neg_shared", "log-loss"), ("original", "skip-gram")])
+def test_config4_shape_10m_x_1m_d128(scheme, loss):
+    """BASELINE configs[3] on one GPU: 10M x 128 user table (5.1 GB), 1M x 128 item table, b = 512, Zipf links;
+    3 steps, loss and every touched row against the oracle."""
+    users, items, b, d = 10000000, 1000000, 512, 128
+    k = 10 if scheme == "original" else 0
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, u_reg=1e-6, learn_rate=0.05, model_choice="mf")
+    eng = Engine(users, items, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=11)
+    assert eng.U.shape == (users, d) and eng.V.shape == (items, d)
+    rs = np.random.RandomState(5)
+    zipf = lambda n, cnt: np.minimum((cnt * rs.power(0.35, n)).astype(np.int64), cnt - 1)  # noqa: E731
+    steps = []
+    for _ in range(3):
+        u, c = zipf(b, users), zipf(b, items)
+        u[0], c[0] = users - 1, items - 1                 # the last rows of both tables
+        if scheme == "original":
+            uu, cc, yy = so.assemble_original(np.stack([u, c, np.ones(b, dtype=np.int64)], 1), zipf(b * k, items), loss)
+            steps.append((uu, cc, yy))
+        else:
+            steps.append((u, c, None))
+    orc, us, its, mu, mc = _compact_oracle(eng, conf, [s[0] for s in steps], [s[1] for s in steps])
+    for t, (u, c, y) in enumerate(steps):
+        if scheme == "original":
+            want = orc.step_original(mu(u), mc(c), y)
+            got = eng.step_original(eng.ids(u[:b]), eng.ids(c)).item()
+        else:
+            want = orc.step_neg_shared(mu(u), mc(c))
+            got = eng.step_neg_shared(eng.ids(u), eng.ids(c)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (t, got, want)
+        np.testing.assert_allclose(eng.U[torch.as_tensor(us, device=eng.U.device)].cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(eng.V[torch.as_tensor(its, device=eng.V.device)].cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+    # nothing else moved: spot-check untouched rows against a fresh engine of the same seed
+    del orc
+    ref = Engine(users, items, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=11)
+    probe = np.setdiff1d(rs.randint(0, users, 4096), us)
+    assert torch.equal(eng.U[torch.as_tensor(probe, device=eng.U.device)], ref.U[torch.as_tensor(probe, device=eng.U.device)])
+    probe = np.setdiff1d(rs.randint(0, items, 4096), its)
+    assert torch.equal(eng.V[torch.as_tensor(probe, device=eng.V.device)], ref.V[torch.as_tensor(probe, device=eng.V.device)])
+
+
+@pytest.mark.parametrize("loss", LOSSES)
+@pytest.mark.parametrize("scheme", ["original", "neg_shared", "group_neg_shared"])
+def test_d128_all_schemes_and_losses(scheme, loss):
+    """d = 128 (configs[3]'s row width: the full 16-lane x 2 x float4 row) in the scheme x loss matrix"""
+    b, k, d = 64, 3, 128
+    conf, eng, orc = _mk(loss, b, k if scheme == "original" else 0, d, 70, 90, "mf", seed=9)
+    rs = np.random.RandomState(13)
+    for step in range(2):
+        uid, cid = rs.randint(0, 70, b), rs.randint(0, 90, b)
+        if scheme == "original":
+            u, c, y = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=int)], 1), rs.randint(0, 90, b * k), loss)
+            want = orc.step_original(u, c, y)
+            got = eng.step_original(eng.ids(uid), eng.ids(c)).item()
+        elif scheme == "neg_shared":
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            cid = np.repeat(cid[:b // 4], 4)
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
+        _check_tables(eng, orc)
