@@ -474,11 +474,11 @@ def main_sharded(args, conf, rank, world, local_rank):
     W, K = args.warmup, args.steps
     losses = torch.zeros(K, dtype=torch.float32, device=be.device)
 
+    scratch = torch.zeros(max(W, 1), dtype=torch.float32, device=be.device)
+
     def run(first, count, keep):
-        for t in range(first, first + count):
-            l = tr.step(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
-            if keep:
-                losses[t - first].copy_(l[0])
+        # plans + the id all-to-all batched 64 steps at a time; per step: rows -> local step -> gradients -> apply
+        tr.run_epoch(uid[first * b:(first + count) * b], cid[first * b:(first + count) * b], count, losses if keep else scratch)
 
     run(0, W, False)
     torch.cuda.synchronize()
@@ -508,8 +508,8 @@ def main_sharded(args, conf, rank, world, local_rank):
                                    "range, d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
                                    % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", d, conf.loss, b),
                        "global_batch": b * world,
-                       "parallelism": "1 process per GPU; users + their links and item rows range-sharded; "
-                                      "3 RCCL all-to-alls per step (ids, rows, gradients)"},
+                       "parallelism": "1 process per GPU; users + their links and item rows range-sharded; RCCL "
+                                      "all-to-alls: ids once per 64 steps, rows and gradients per step"},
             "mean_loss": mean_loss,
             "roofline": None, "cpu_baseline": None,
         }

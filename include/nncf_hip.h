@@ -441,6 +441,34 @@ int nncf_scatter_apply(float* d_table, int32_t row_stride, int32_t dim, const in
                        int32_t id_offset, const float* d_rows, float lr, int32_t* d_plan_ws, void* stream);
 int64_t nncf_scatter_apply_ws_ints(int32_t n);
 
+/* Chunked item-sharded neg_shared trainer (no reference counterpart; SURVEY.md 8(e), BASELINE configs[3]): one
+ * object per rank around a model whose "item table" is the landing buffer of fetched rows (n_ranks * batch_size_p
+ * rows) and this rank's shard of the real item table (rows [item_offset, item_offset + shard rows), id / item_shard =
+ * owner).  Item ids do not depend on the training state, so for up to 64 steps at a time
+ *   nncf_shard_plan        routes (unique ids per owner, request slot of every batch position) and the duplicate
+ *                          plans of the local steps, batched; fills req_out [n_ranks][64][batch_size_p] (-1 padded)
+ *   (host: ONE all-to-all of req_out -> req_in for the whole chunk)
+ *   nncf_shard_plan_owner  owner-side scatter plans of every step; gathers the rows of step 0 into rows_out
+ * and per step i only
+ *   (host: all-to-all rows_out -> rows_in)
+ *   nncf_shard_step        the local step on (user shard, landed rows): loss, user rows updated, item gradients
+ *                          exported to g_out per request slot
+ *   (host: all-to-all g_out -> g_in)
+ *   nncf_shard_apply       table[id] -= lr * (gradients of id summed in (rank, slot) order), then gathers the rows of
+ *                          step i + 1 (after the update: synchronous SGD).
+ * With n_ranks == 1 req_in / g_in / rows_out alias req_out / g_out / the landing buffer: nothing is copied.
+ * nncf_shard_buffers returns the device pointers the host hands to its collectives. */
+typedef struct nncf_shard nncf_shard;
+int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t row_stride, int32_t item_shard, int32_t item_offset,
+                      int32_t n_ranks, int device, nncf_shard** out);
+int nncf_shard_destroy(nncf_shard* h);
+int nncf_shard_buffers(nncf_shard* h, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in, float** g_out,
+                       float** g_in);
+int nncf_shard_plan(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, int64_t n_steps, void* stream);
+int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, void* stream);
+int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d_loss, void* stream);
+int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, void* stream);
+
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
  * segment starts, and tf.unique-style first-occurrence outputs.
  *   d_order[n], d_seg_start[n+1], d_uniq[n], d_inverse[n],

@@ -81,6 +81,9 @@ int flush_pending_loss(nncf_model* m, hipStream_t st) {
 int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
                 const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower) {
   if (!shared_step_fuses(m, a)) {
+    if (!m->tile_ok)
+      return fail(NNCF_ERR_INVALID, "batch_size_p = %d: above %d only the one-launch step is built (skip-gram / mse, no "
+                  "interaction bias, NNCF_SHARED_PATH unset)", a.b, kTileMaxBatch);
     if (int rc = flush_pending_loss(m, st)) return rc;
     return launch_shared(a, group, uid, cid, m->sws, pu, pv, loss_out, update, st);
   }
@@ -124,8 +127,11 @@ void carve(nncf_model* m, Carver& c) {
   m->rws.Vrow = c.take<float>(n * d);
   m->rws.loss_part = c.take<float>(n);
   m->rws.reg_part = c.take<float>(n);
-  m->sws.dU_part = c.take<float>(nb * b * d);
-  m->sws.dV_part = c.take<float>(nb * b * d);
+  // the tile + apply path's slabs grow with b^2 d / 32 (1 GB each at b = 8192, d = 128): large batches run the
+  // one-launch step only (pointwise losses, no bias) -- see shared_step
+  m->tile_ok = b <= kTileMaxBatch;
+  m->sws.dU_part = c.take<float>(m->tile_ok ? nb * b * d : 4);
+  m->sws.dV_part = c.take<float>(m->tile_ok ? nb * b * d : 4);
   m->sws.c_part = c.take<float>(nb * b);
   m->sws.r_part = c.take<float>(nb * b);
   m->sws.Uhat = c.take<float>(b * d);

@@ -207,6 +207,8 @@ int launch_predict(const StepArgs& a, const int32_t* uid, int64_t p, const int32
 
 }  // namespace nncf
 
+constexpr int kTileMaxBatch = 2048;   // largest batch_size_p the slab-based tile + apply path allocates for
+
 // The model object behind the B2 entry points (include/nncf_hip.h).
 struct nncf_model {
   nncf_model_cfg cfg;
@@ -233,6 +235,7 @@ struct nncf_model {
   int32_t* bias_stamps = nullptr;  // owned: user_count + bias_items ints (dense Adam)
   // one-launch shared-negative step (step_fused.hip): loss partials of the current / previous step and the
   // step whose loss is still to be summed (done by the next fused launch or by flush_pending_loss)
+  bool tile_ok = true;        // the tile + apply workspace exists (batch_size_p <= kTileMaxBatch)
   int use_fused = 1;          // NNCF_SHARED_PATH=tile forces the two-launch tile + apply path
   float* fpart = nullptr;     // [2][fused_max_blocks(b) * fused_split(b)]
   float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips

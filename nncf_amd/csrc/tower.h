@@ -274,7 +274,7 @@ struct nncf_tower {
   float* bpart = nullptr;
   int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
   // one-launch backward of the shared-negative schemes (tower_fused.hip)
-  int use_wordbwd = 1;           // NNCF_TOWER_BWD=split forces tower_bwd_kernel + tower_word_kernel
+  int use_wordbwd = 0;           // NNCF_TOWER_BWD=fused selects the one-launch backward (tower_fused.hip)
   float* Wd_alt = nullptr;       // second buffer of the Dense weights (arena)
   bool wd_in_alt = false;        // the current weights live in Wd_alt (copied back before an entry point returns)
   nncf::CellsView cells;         // lazily allocated for `cells_rows` block rows (own allocation)

@@ -1062,7 +1062,11 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   t->prm = *prm;
   t->device = device;
   t->ks = (cfg->max_rows + kRowsPerK - 1) / kRowsPerK;
-  if (const char* e = getenv("NNCF_TOWER_BWD")) t->use_wordbwd = std::string(e) != "split";
+  // the one-launch backward (tower_fused.hip) is correct and tested but, at 2 workgroups of 8 waves per CU, its
+  // 1,050 workgroups take three rounds: 23 us against 8.5 + 11.4 us of the two-kernel chain (profiles/r02) --
+  // opt-in until it wins
+  t->use_wordbwd = 0;
+  if (const char* e = getenv("NNCF_TOWER_BWD")) t->use_wordbwd = std::string(e) == "fused";
   if (cfg->conv_filters > 0) {
     CnnArgs& c = t->cnn;
     c.F = cfg->conv_filters;

@@ -119,6 +119,79 @@ class HipBackend(object):
                                                            self.i0, p(g_in), self.lr, p(self._ws_apply),
                                                            self._stream()))
 
+    # -- chunked protocol (nncf_shard_*): plans and the id exchange of up to CHUNK steps batched ------------
+    CHUNK = 64
+
+    def _session(self):
+        if getattr(self, "_sh", None) is None:
+            L = self._lib.lib()
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                self._lib.check(L.nncf_shard_create(self.engine._h, ctypes.c_void_p(self.V.data_ptr()), self.dim, self.item_shard,
+                                                    self.i0, self.world, self.device.index, ctypes.byref(h)))
+            ptrs = [ctypes.c_void_p() for _ in range(6)]
+            self._lib.check(L.nncf_shard_buffers(h, *[ctypes.byref(x) for x in ptrs]))
+            n = self.world * self.cap
+
+            def view(ptr, count, dtype, shape):
+                # a torch view of library-owned device memory (the collectives read / write it in place)
+                t = _wrap_device_pointer(ptr.value, count, dtype, self.device)
+                return t.view(*shape)
+            self._sh = h
+            self._bufs = dict(
+                req_out=view(ptrs[0], n * self.CHUNK, torch.int32, (self.world, self.CHUNK * self.cap)),
+                req_in=view(ptrs[1], n * self.CHUNK, torch.int32, (self.world, self.CHUNK * self.cap)),
+                rows_out=view(ptrs[2], n * self.dim, torch.float32, (n, self.dim)),
+                rows_in=view(ptrs[3], n * self.dim, torch.float32, (n, self.dim)),
+                g_out=view(ptrs[4], n * self.dim, torch.float32, (n, self.dim)),
+                g_in=view(ptrs[5], n * self.dim, torch.float32, (n, self.dim)))
+        return self._sh
+
+    def chunk_buffers(self):
+        self._session()
+        return self._bufs
+
+    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+        h = self._session()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().nncf_shard_plan(h, p(uid_chunk), p(cid_chunk), int(n_steps), self._stream()))
+
+    def plan_owner(self, n_steps):
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().nncf_shard_plan_owner(self._session(), int(n_steps), self._stream()))
+
+    def local_step_at(self, index, uid_step, loss_out):
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().nncf_shard_step(self._session(), int(index), ctypes.c_void_p(uid_step.data_ptr()),
+                                                            ctypes.c_void_p(loss_out.data_ptr()), self._stream()))
+
+    def apply_at(self, index, n_steps):
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().nncf_shard_apply(self._session(), int(index), int(n_steps), self.lr, self._stream()))
+
+    def close(self):
+        h, self._sh = getattr(self, "_sh", None), None
+        if h:
+            self._lib.lib().nncf_shard_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _wrap_device_pointer(ptr, count, dtype, device):
+    """torch tensor over `count` elements of device memory owned by the native library (no copy, no ownership)."""
+    class _Holder(object):
+        pass
+    holder = _Holder()
+    holder.__cuda_array_interface__ = {
+        "shape": (int(count),), "typestr": {torch.int32: "<i4", torch.float32: "<f4"}[dtype], "data": (int(ptr), False),
+        "version": 3, "strides": None}
+    return torch.as_tensor(holder, device=device)
+
 
 class ShardedNegShared(object):
     """Collective neg_shared trainer state of one rank (see module docstring)."""
@@ -139,10 +212,39 @@ class ShardedNegShared(object):
         self._g_in = None
 
     def _a2a(self, out, inp):
+        if out.data_ptr() == inp.data_ptr():
+            return                      # one rank: the native session aliases the two ends
         if self.world == 1:
             out.copy_(inp)
         else:
             dist.all_to_all_single(out, inp, group=self.group)
+
+    def run_epoch(self, uid_local_all, cid_all, n_steps, losses=None):
+        """n_steps global steps over this rank's link stream (ids of n_steps * b links on the backend's device), with
+        the plans and the id all-to-all of up to CHUNK steps batched: per step only rows -> local step -> gradients ->
+        apply remain.  Backends without the chunk protocol fall back to step()."""
+        be, b = self.be, self.b
+        if not hasattr(be, "plan_chunk"):
+            for t in range(n_steps):
+                l = self.step(uid_local_all[t * b:(t + 1) * b], cid_all[t * b:(t + 1) * b])
+                if losses is not None:
+                    losses[t:t + 1].copy_(l.reshape(1))
+            return losses
+        bufs = be.chunk_buffers()
+        ch = be.CHUNK
+        for t0 in range(0, n_steps, ch):
+            cnt = min(ch, n_steps - t0)
+            be.plan_chunk(uid_local_all[t0 * b:(t0 + cnt) * b], cid_all[t0 * b:(t0 + cnt) * b], cnt)
+            self._a2a(bufs["req_in"], bufs["req_out"])                  # all-to-all #1: the chunk's ids -> owners
+            be.plan_owner(cnt)                                           # owner plans; rows of step 0 gathered
+            for i in range(cnt):
+                t = t0 + i
+                self._a2a(bufs["rows_in"], bufs["rows_out"])            # all-to-all #2: rows -> requesters
+                lo = losses[t:t + 1] if losses is not None else be._loss
+                be.local_step_at(i, uid_local_all[t * b:(t + 1) * b], lo)
+                self._a2a(bufs["g_in"], bufs["g_out"])                  # all-to-all #3: gradients -> owners
+                be.apply_at(i, cnt)                                      # apply; rows of step i + 1 gathered
+        return losses
 
     def step(self, uid_local, cid):
         """uid_local: int32 [b] user ids RELATIVE to this rank's user range; cid: int32 [b] global

@@ -121,3 +121,22 @@ def test_fused_epoch_runner_equals_step_by_step():
     l2 = np.array([e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)])
     assert np.array_equal(l1, l2.astype(np.float32))
     assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V)
+
+
+@pytest.mark.parametrize("b,d", [(4096, 128), (8192, 64)])
+def test_fused_large_batch(b, d):
+    """config 4's large-batch regime (b >= 8K per GPU): 2 x b/16 strip workgroups, no split, no
+    O(b^2) workspace; one step against the float64 oracle (the tile + apply path does not exist above b = 2048)."""
+    nu, ni = 3 * b, 2 * b
+    conf, eng, orc = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=6, lr=0.05)
+    rs = np.random.RandomState(2)
+    uid = rs.randint(0, nu, b)
+    cid = np.minimum((ni * rs.power(0.6, b)).astype(np.int64), ni - 1)
+    want = orc.step_neg_shared(uid, cid)
+    got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):     # pairwise losses need the slab path, which stops at b = 2048
+        e2 = Engine(nu, ni, d, b, 0, "log-loss", 10., 128., 1e-6, 0.05, True, False, seed=1)
+        e2.step_neg_shared(e2.ids(uid), e2.ids(cid))

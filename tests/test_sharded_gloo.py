@@ -83,6 +83,47 @@ class NumpyBackend(object):
             self.V[k - self.i0] -= self.lr * g
 
 
+class ChunkedNumpyBackend(NumpyBackend):
+    """NumpyBackend + the chunk protocol of HipBackend (nncf_shard_*): routes and the id exchange of a chunk of
+    steps batched, buffers exchanged in place."""
+    CHUNK = 2     # STEPS = 3: one full chunk and a partial one
+
+    def chunk_buffers(self):
+        if not hasattr(self, "_bufs"):
+            n, d = self.world * self.cap, self.V.shape[1]
+            self._bufs = dict(req_out=torch.full((self.world, self.CHUNK * self.cap), -1, dtype=torch.int32),
+                              req_in=torch.full((self.world, self.CHUNK * self.cap), -1, dtype=torch.int32),
+                              rows_out=torch.zeros(n, d), rows_in=self.rows_in, g_out=torch.zeros(n, d), g_in=torch.zeros(n, d))
+            self._loss = torch.zeros(1)
+        return self._bufs
+
+    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+        bufs = self.chunk_buffers()
+        bufs["req_out"].fill_(-1)
+        self._slots = []
+        b = self.cap
+        for s in range(n_steps):
+            req, slot = self.route(cid_chunk[s * b:(s + 1) * b])
+            self._slots.append(slot)
+            bufs["req_out"].view(self.world, self.CHUNK, self.cap)[:, s, :] = req.view(self.world, self.cap)
+
+    def _req_of_step(self, s):
+        return self._bufs["req_in"].view(self.world, self.CHUNK, self.cap)[:, s, :].reshape(-1).contiguous()
+
+    def plan_owner(self, n_steps):
+        self._bufs["rows_out"].copy_(self.gather_rows(self._req_of_step(0)))
+
+    def local_step_at(self, index, uid_step, loss_out):
+        loss, g = self.local_step(uid_step, self._slots[index])
+        self._bufs["g_out"].copy_(g)
+        loss_out.copy_(loss.reshape(loss_out.shape))
+
+    def apply_at(self, index, n_steps):
+        self.scatter_apply(self._req_of_step(index), self._bufs["g_in"])
+        if index + 1 < n_steps:
+            self._bufs["rows_out"].copy_(self.gather_rows(self._req_of_step(index + 1)))
+
+
 def simulate_global_steps(loss, world):
     """Single-process restatement: every rank's batch sees the pre-step tables; user rows are
     disjoint across ranks; item gradients are summed over ranks (rank order) and applied once."""
@@ -127,6 +168,27 @@ def _worker(rank, world, port, loss, ret):
     dist.destroy_process_group()
 
 
+def _worker_chunked(rank, world, port, loss, ret):
+    """the same global steps through ShardedNegShared.run_epoch (plans + id all-to-all batched per chunk)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conf = _conf(loss)
+    U, V = _tables()
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    be = ChunkedNumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, isz,
+                             rank * isz)
+    tr = ShardedNegShared(be, NU, NI, B, D)
+    bt = _batches(world)[rank]
+    uid = torch.from_numpy(np.concatenate([(u - rank * us) for u, _ in bt]).astype(np.int32))
+    cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
+    losses = torch.zeros(STEPS)
+    tr.run_epoch(uid, cid, STEPS, losses)
+    ret[rank] = (be.U.copy(), be.V.copy(), [float(x) for x in losses])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -141,6 +203,23 @@ def test_world2_matches_single_process_restatement(loss):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), loss, ret), nprocs=world, join=True)
+    U, V, losses = simulate_global_steps(loss, world)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_ = ret[r]
+        np.testing.assert_allclose(Ur, U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vr, V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+        for t in range(STEPS):
+            assert abs(lr_[t] - losses[t][r]) < 1e-5 * max(1, abs(losses[t][r]))
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_world2_chunked_epoch_matches_single_process_restatement(loss):
+    """run_epoch: one id all-to-all per chunk of steps, per step only rows / gradients -- same results"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_chunked, args=(world, _free_port(), loss, ret), nprocs=world, join=True)
     U, V, losses = simulate_global_steps(loss, world)
     us, isz = shard_size(NU, world), shard_size(NI, world)
     for r in range(world):

@@ -38,6 +38,68 @@ def test_sharded_world1_matches_plain_engine_and_oracle(loss):
         np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_sharded_world1_chunked_epoch_equals_step_by_step_and_oracle(loss):
+    """ShardedNegShared.run_epoch over HipBackend's native chunk session (nncf_shard_*: routes, plans and the id
+    exchange of 64 steps batched; one rank: exchange buffers aliased) == the per-step protocol == the oracle;
+    70 steps = one full chunk and a partial one."""
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    gamma = {"log-loss": 10.}.get(loss, 10.)
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=gamma,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=loss != "skip-gram", normalize_item=False)
+    be1 = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0)
+    be2 = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0)
+    assert torch.equal(be1.U, be2.U) and torch.equal(be1.V, be2.V)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=gamma, neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.1, model_choice="mf")
+    orc = so.StepOracle(be1.U.cpu().numpy(), be1.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr1, tr2 = ShardedNegShared(be1, nu, ni, b, d), ShardedNegShared(be2, nu, ni, b, d)
+    ua, ca = be1.ids(uid), be1.ids(cid)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be1.device)
+    tr1.run_epoch(ua, ca, steps, losses)
+    l1 = losses.cpu().numpy()
+    for t in range(steps):
+        l2 = tr2.step(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item()
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l1[t] - l2) <= 1e-6 * max(1, abs(l2)), (t, l1[t], l2)
+        assert abs(l1[t] - want) <= 2e-5 * max(1, abs(want)), (t, l1[t], want)
+    np.testing.assert_allclose(be1.U.cpu().numpy(), be2.U.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(be1.V.cpu().numpy(), be2.V.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(be1.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(be1.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+
+
+def test_sharded_world1_config4_shape():
+    """BASELINE configs[3] through the sharded path at world = 1: 10M users x 1M items, d = 128, b = 512, neg_shared;
+    3 steps, loss and every touched row of the user shard and of the item shard against the oracle."""
+    users, items, b, d = 10000000, 1000000, 512, 128
+    kw = dict(user_count=users, item_count=items, dim=d, batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=128., u_reg=1e-6, learn_rate=0.05, normalize_user=False, normalize_item=False)
+    be = HipBackend(kw, users, items, 0, world=1, item_shard=items, item_offset=0, seed=3)
+    assert be.U.shape == (users, d) and be.V.shape == (items, d)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-6, learn_rate=0.05, model_choice="mf")
+    rs = np.random.RandomState(5)
+    zipf = lambda n, cnt: np.minimum((cnt * rs.power(0.35, n)).astype(np.int64), cnt - 1)  # noqa: E731
+    steps = 3
+    uid, cid = zipf(steps * b, users), zipf(steps * b, items)
+    uid[0], cid[0] = users - 1, items - 1
+    us, its = np.unique(uid), np.unique(cid)
+    dev = be.device
+    orc = so.StepOracle(be.U[torch.as_tensor(us, device=dev)].cpu().numpy(), be.V[torch.as_tensor(its, device=dev)].cpu().numpy(),
+                        conf, dtype=np.float32)
+    tr = ShardedNegShared(be, users, items, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=dev)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    for t in range(steps):
+        want = orc.step_neg_shared(np.searchsorted(us, uid[t * b:(t + 1) * b]), np.searchsorted(its, cid[t * b:(t + 1) * b]))
+        assert abs(losses[t].item() - want) <= 1e-5 * max(1, abs(want)), (t, losses[t].item(), want)
+    np.testing.assert_allclose(be.U[torch.as_tensor(us, device=dev)].cpu().numpy(), orc.U, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(be.V[torch.as_tensor(its, device=dev)].cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+
+
 def test_gather_and_scatter_apply_rows():
     import ctypes
     from nncf_amd import _lib

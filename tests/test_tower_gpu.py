@@ -82,6 +82,44 @@ def test_basic_embedding_steps_match_oracle(text_data, scheme, loss):
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("shared_path", ["fused", "tile"])
+@pytest.mark.parametrize("bwd", ["split", "fused"])
+@pytest.mark.parametrize("scheme,loss,opt", [("neg_shared", "skip-gram", "sgd"), ("group_neg_shared", "mse", "sgd"),
+                                             ("neg_shared", "skip-gram", "adam")])
+def test_every_kernel_path_of_the_shared_schemes_matches_the_oracle(text_data, monkeypatch, shared_path, bwd, scheme, loss, opt):
+    """One-launch step (step_fused.hip) vs tile + apply, one-launch tower backward (tower_fused.hip: planned word ->
+    cell lists, double-buffered Dense weights) vs tower_bwd + tower_word: all four combinations, 5 steps (odd: the
+    Dense weights end in the second buffer and are copied back), every parameter against the oracle."""
+    monkeypatch.setenv("NNCF_SHARED_PATH", shared_path)
+    monkeypatch.setenv("NNCF_TOWER_BWD", bwd)
+    conf = _conf(loss, scheme, lr=0.02 if opt == "adam" else 0.2)
+    conf.optimizer = opt
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    orc.conf.optimizer = opt
+    head = md["model_neg_shared" if scheme == "neg_shared" else "model_group_neg_shared"]
+    core = head.core
+    b = conf.batch_size_p
+    rs = np.random.RandomState(11)
+    train = text_data["train"]
+    for step in range(5):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        want = orc.step_neg_shared(bt[:, 0], bt[:, 1]) if scheme == "neg_shared" else orc.step_group_neg_shared(bt[:, 0], bt[:, 1])
+        got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        tw = core.tower
+        rt, at = (5e-4, 5e-5) if opt == "adam" else (2e-5, 5e-6)     # Adam divides by sqrt(v): the existing Adam tests' budget
+        np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+            if opt == "adam" and name == "bd":
+                continue   # dL/dbd = sum dz is exactly 0 behind a BatchNorm: Adam turns its rounding noise into +-lr steps
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+
+
 @pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
 def test_model_item_emb_is_the_inference_tower_of_the_given_ids(text_data, loss):
     """model_dict['model_item_emb'].predict_on_batch([cid]) (model_framework.py:174): inference-mode C_emb of
