@@ -748,8 +748,12 @@ def main():
                               "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % mean_n_u),
         "tower_bwd_kernel": ("mfma", 4.0 * b * d * d, "2*m*wd*d (dh) + 2*m*wd*d (dWd) flop"),
     }
-    default_kernel = {"mf": {"original": "original_score_kernel"}}.get(args.model, {}).get(args.scheme) or \
-        {"mf": "shared_tile_kernel", "cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, "tower_word_kernel")
+    # dominant kernel of the step by time (profiles/): the one-launch step for the shared schemes with a pointwise loss,
+    # the tile kernel for their pairwise losses, the per-positive score kernel for `original`, the conv backward for cnn
+    pointwise = pconf.loss in ("skip-gram", "mse")
+    shared_kernel = "fused_strip_kernel" if (pointwise and os.environ.get("NNCF_SHARED_PATH") != "tile") else "shared_tile_kernel"
+    default_kernel = {"mf": {"original": "original_score_kernel"}, "basic_embedding": {"original": "tower_word_kernel"}}.get(
+        args.model, {}).get(args.scheme) or {"cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, shared_kernel)
     names = [args.roofline_kernel or default_kernel]
     if args.model == "basic_embedding":
         names += [n for n in ("tower_wordbwd_kernel", "tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel",

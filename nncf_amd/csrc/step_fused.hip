@@ -186,7 +186,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
           inv = rsqrtf(var + f.eps);
           mul = f.gamma[c] * inv;
           add = f.beta[c] - mu * mul;
-          if (blk == 0 && USIDE) {  // published once: later launches (tower backward) and the running statistics
+          if (blk == 0 && part == 0 && USIDE) {  // published once: later launches (tower backward) and the running statistics
             f.stats[c] = mu;
             f.stats[128 + c] = inv;
             f.stats[256 + c] = var;
@@ -197,7 +197,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
               f.rv[c] = f.momentum * f.rv[c] + (1.f - f.momentum) * var;
             }
           }
-        } else if (blk == 0 && USIDE) {
+        } else if (blk == 0 && part == 0 && USIDE) {
           f.stats[384 + c] = 0.f;
           f.stats[512 + c] = 0.f;
         }

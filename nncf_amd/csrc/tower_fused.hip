@@ -106,17 +106,17 @@ int launch_cells(const TowerArgs& a, const CellsView& cv, const int32_t* uniq_g,
 }
 
 // ---- one-launch backward ------------------------------------------------------------------------
-constexpr int kWBWords = 8;        // words per workgroup = waves per workgroup
+constexpr int kWBWords = 32;       // words per workgroup (8 waves, 4 words finished by each)
 constexpr int kWBAP = 132;         // LDS pitch of the accumulated / output rows
-constexpr int kWBCells = 4;        // cells (pairs of rows) in flight per wave
+constexpr int kWBCells = 4;        // cells (pairs of rows) in flight per wave (8: 154 VGPRs, or spills under a 128 cap)
 
 __host__ __device__ inline size_t wordbwd_lds_bytes(int, int) {
-  return sizeof(float) * ((size_t)2 * 8 * kWBWords * 64 + 16 * kWBAP + kWBWords * kWBAP);
+  return sizeof(float) * ((size_t)2 * kWBWords * kWBAP + 2 * 8 * 2 * 64);
 }
 
-// Blocks [0, G), G = ceil(n_words / 8): word workgroups (wave v finishes word bid + v G, as tower_word_kernel).
+// Blocks [0, G), G = ceil(n_words / 32): word workgroups (32 words each: bid + j G).
 // Blocks [G, G + ntile): one 16 x 16 tile of dWd = h^T.dz each, rows split over the 8 waves.
-__global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, CellsView cv, int nfused, float lr_over_L) {
+__global__ void __launch_bounds__(512) tower_wordbwd_kernel(TowerArgs a, CellsView cv, int nfused, float lr_over_L) {
   extern __shared__ __attribute__((aligned(16))) float wb_smem[];
   __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128], sA[128], sBq[128];
   __shared__ f32x4 sAcc[8 * 64];
@@ -234,19 +234,20 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
   }
 
   // ---- word workgroup -----------------------------------------------------------------------------
-  // The cells of the workgroup's 8 words form ONE list that is cut into 8 equal parts, one per wave (a
-  // frequent word -- the pad id occurs in every item -- would otherwise serialise on one wave): wave v
-  // accumulates count * dz[slot] per word in its LDS stripe, wave j then adds the 8 stripes of word j in
-  // wave order.  Fixed summation order, no float atomics.
-  float2* sStripe = reinterpret_cast<float2*>(wb_smem);                       // [8 waves][8 words][64 lanes]
-  float* sAccA = wb_smem + 2 * 8 * kWBWords * 64;                             // [16][kWBAP]  rows 8..15 stay zero
-  float* sOutW = sAccA + 16 * kWBAP;                                          // [8][kWBAP]
-  __shared__ int sC0[kWBWords], sPre[kWBWords + 1];
+  // 32 words per workgroup (word bid + j G, j < 32: frequent words have neighbouring ids, striding spreads them),
+  // ~300 workgroups: one round on the chip.  The cells of the 32 words form ONE list cut into 8 equal parts, one per
+  // wave (a frequent word -- the pad id occurs in every item -- would otherwise serialise on one wave).  A wave
+  // accumulates count * dz[slot] per word in registers; a word whose cells all lie inside the wave's part goes
+  // straight to its row of the MFMA operand, a word cut by a part boundary leaves a partial (at most two per wave)
+  // that the word's finishing wave adds in wave order.  Fixed summation order, no float atomics.
+  float* sAccA = wb_smem;                                   // [32][kWBAP]  accumulated dz-space rows (MFMA A operand)
+  float* sOutW = sAccA + kWBWords * kWBAP;                  // [32][kWBAP]  rows . Wd^T
+  float2* sPart = reinterpret_cast<float2*>(sOutW + kWBWords * kWBAP);   // [8 waves][2][64 lanes]
+  __shared__ int sC0[kWBWords], sPre[kWBWords + 1], sPartWord[16];
   __shared__ float sScale[kWBWords];
   const int bid = (int)blockIdx.x;
-  const int d2 = a.wd >> 1, dz2 = d >> 1, d4 = d >> 2;
-  const int my_w = bid + wave * G;  // the word this wave finishes
-  const bool wok = my_w < a.n_words;
+  const int d2 = a.wd >> 1, dz2 = d >> 1;
+  constexpr int kPerWave = kWBWords / 8;   // words a wave finishes
   // Wd^T fragments of this wave's 16 output columns (kw = 16 wave + x), k-permuted like the A operand: the
   // float4 at column 16t + 4kq serves four MFMAs.  Requested first: nothing depends on them until the end.
   const int ng = (d + 15) >> 4;
@@ -259,17 +260,19 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
       bw[t] = (t < ng && kw < hd && col < d) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)kw * d)[col >> 2] : zero4();
     }
   }
-  float2 wold = make_float2(0.f, 0.f);
-  if (wok && lane < d2) wold = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
+  float2 wold[kPerWave];
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int w = bid + (kPerWave * wave + i) * G;
+    wold[i] = (w < a.n_words && lane < d2) ? reinterpret_cast<const float2*>(a.W + (int64_t)w * a.wd)[lane] : make_float2(0.f, 0.f);
+  }
   if (tid >= 128 && tid < 128 + kWBWords) {
     sC0[tid - 128] = pre_c0;
     sScale[tid - 128] = pre_sc;
     sPre[tid - 128 + 1] = pre_c1 - pre_c0;
   }
-  for (int i = tid; i < 16 * kWBAP; i += 512) sAccA[i] = 0.f;
-  float2* accw = sStripe + wave * kWBWords * 64;
-#pragma unroll
-  for (int j = 0; j < kWBWords; ++j) accw[j * 64 + lane] = make_float2(0.f, 0.f);
+  if (tid < 16) sPartWord[tid] = -1;
+  for (int i = tid; i < kWBWords * kWBAP; i += 512) sAccA[i] = 0.f;
   __syncthreads();
   if (tid == 0) {
     int run = 0;
@@ -292,11 +295,13 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
   const float saA = lok ? sA[ca] : 0.f, saB = lok ? sA[cb] : 0.f, sqA = lok ? sBq[ca] : 0.f, sqB = lok ? sBq[cb] : 0.f;
   const float2* z2 = reinterpret_cast<const float2*>(a.z);
   const float2* g2 = reinterpret_cast<const float2*>(a.dA);
-  // flat index -> (word j, address): uniform across the wave
+  // flat index -> (word j, address): uniform across the wave (binary search in the 33 prefix sums)
   auto locate = [&](int fidx, int& j) -> int {
-    j = 0;
+    int lo = 0;
 #pragma unroll
-    for (int k = 1; k < kWBWords; ++k) j += (fidx >= sPre[k]) ? 1 : 0;
+    for (int step = kWBWords / 2; step >= 1; step >>= 1)
+      if (fidx >= sPre[lo + step]) lo += step;
+    j = lo;
     return sC0[j] + (fidx - sPre[j]);
   };
   int ent[kWBCells], wj[kWBCells];
@@ -310,8 +315,20 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
       j_out[u] = j;
     }
   };
+  // a finished run of word j over flat cells [r0, r1): whole word -> its operand row; cut -> a partial slot
+  auto flush = [&](int j, int r0, int r1, float2 run) {
+    if (j < 0) return;
+    const bool whole = r0 == sPre[j] && r1 == sPre[j + 1];
+    if (whole) {
+      if (lok) reinterpret_cast<float2*>(sAccA + j * kWBAP)[lane] = run;
+    } else {
+      const int k = (r0 != sPre[j]) ? 0 : 1;   // 0: the word began in an earlier wave's part; 1: it continues in a later one
+      sPart[(wave * 2 + k) * 64 + lane] = run;
+      if (lane == 0) sPartWord[wave * 2 + k] = j;
+    }
+  };
   load_ents(f_beg, ent, wj);
-  int curj = -1;
+  int curj = -1, run0 = f_beg;
   float2 run = make_float2(0.f, 0.f);
   for (int f0 = f_beg; f0 < f_end; f0 += kWBCells) {
     float2 zz[kWBCells], gg[kWBCells];
@@ -328,14 +345,9 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
     for (int u = 0; u < kWBCells; ++u) {
       if (ent[u] >= 0) {  // uniform across the wave
         if (wj[u] != curj) {
-          if (curj >= 0) {
-            float2* p = accw + curj * 64 + lane;
-            float2 t = *p;
-            t.x += run.x;
-            t.y += run.y;
-            *p = t;
-          }
+          flush(curj, run0, f0 + u, run);
           curj = wj[u];
+          run0 = f0 + u;
           run = make_float2(0.f, 0.f);
         }
         const float cf = (float)(ent[u] & 255);
@@ -353,86 +365,95 @@ __global__ void __launch_bounds__(512, 2) tower_wordbwd_kernel(TowerArgs a, Cell
       wj[u] = wjn[u];
     }
   }
-  if (curj >= 0) {
-    float2* p = accw + curj * 64 + lane;
-    float2 t = *p;
-    t.x += run.x;
-    t.y += run.y;
-    *p = t;
-  }
+  flush(curj, run0, f_end, run);
   __syncthreads();
-  const bool hit = sPre[wave + 1] > sPre[wave];
-  const float scale = sScale[wave];
-  if (lok) {
+  // words cut by part boundaries: their partials, in (wave, slot) order, by the word's finishing wave
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int j = kPerWave * wave + i;
     float2 sum = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const float2 t = sStripe[(v * kWBWords + wave) * 64 + lane];
-      sum.x += t.x;
-      sum.y += t.y;
-    }
-    reinterpret_cast<float2*>(sAccA + wave * kWBAP)[lane] = sum;
-  }
-  __syncthreads();
-  // out[word][kw] = sum_c acc[word][c] Wd[kw][c]: wave = 16-column tile of kw
-  if (wave * 16 < hd) {
-    const float4* pa4 = reinterpret_cast<const float4*>(sAccA + x * kWBAP + 4 * kq);
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < ng) {
-        const float4 af = pa4[4 * t];
-        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[t].x, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[t].y, o1, 0, 0, 0);
-        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[t].z, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[t].w, o1, 0, 0, 0);
+    bool any = false;
+    for (int p = 0; p < 16; ++p) {
+      if (sPartWord[p] == j) {   // uniform across the wave
+        const float2 t = sPart[p * 64 + lane];
+        sum.x += t.x;
+        sum.y += t.y;
+        any = true;
       }
     }
-    const f32x4 o = o0 + o1;
-    if (kq < 2 && 16 * wave + x < hd) {
+    if (any && lok) reinterpret_cast<float2*>(sAccA + j * kWBAP)[lane] = sum;
+  }
+  __syncthreads();
+  // out[word][kw] = sum_c acc[word][c] Wd[kw][c]: wave = 16-column tile of kw, both 16-row tiles of the 32 words
+  if (wave * 16 < hd) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sOutW[(4 * kq + r) * kWBAP + 16 * wave + x] = o[r];  // D[i = word 4kq + r][j = kw]
+    for (int mt = 0; mt < kWBWords / 16; ++mt) {
+      const float4* pa4 = reinterpret_cast<const float4*>(sAccA + (16 * mt + x) * kWBAP + 4 * kq);
+      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t < ng) {
+          const float4 af = pa4[4 * t];
+          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[t].x, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[t].y, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[t].z, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[t].w, o1, 0, 0, 0);
+        }
+      }
+      const f32x4 o = o0 + o1;
+      if (16 * wave + x < hd) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sOutW[(16 * mt + 4 * kq + r) * kWBAP + 16 * wave + x] = o[r];  // D[i = word][j = kw]
+      }
     }
   }
   __syncthreads();
-  (void)d4;
-  if (!wok || lane >= d2) return;
-  if (a.gexp) {
-    float2 gout = make_float2(0.f, 0.f);
-    if (hit) {
-      const float2 sum = reinterpret_cast<const float2*>(sOutW + wave * kWBAP)[lane];
-      const float gs = scale / (float)a.L;
-      gout = make_float2(gs * sum.x, gs * sum.y);
+  if (lane >= d2) return;
+#pragma unroll
+  for (int i = 0; i < kPerWave; ++i) {
+    const int j = kPerWave * wave + i;
+    const int my_w = bid + j * G;
+    if (my_w >= a.n_words) continue;
+    const bool hit = sPre[j + 1] > sPre[j];
+    const float scale = sScale[j];
+    float2 wv = wold[i];
+    if (a.gexp) {
+      float2 gout = make_float2(0.f, 0.f);
+      if (hit) {
+        const float2 sum = reinterpret_cast<const float2*>(sOutW + j * kWBAP)[lane];
+        const float gs = scale / (float)a.L;
+        gout = make_float2(gs * sum.x, gs * sum.y);
+      }
+      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = gout;
+      continue;
     }
-    reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = gout;
-    return;
-  }
-  if (hit) {
-    const float2 sum = reinterpret_cast<const float2*>(sOutW + wave * kWBAP)[lane];
-    if (a.opt) {
-      const float gs = scale / (float)a.L;
+    if (hit) {
+      const float2 sum = reinterpret_cast<const float2*>(sOutW + j * kWBAP)[lane];
+      if (a.opt) {
+        const float gs = scale / (float)a.L;
+        float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
+        float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
+        float2 mm = *mp, vv = *vp;
+        wv.x = adam1(gs * sum.x, &mm.x, &vv.x, wv.x, a);
+        wv.y = adam1(gs * sum.y, &mm.y, &vv.y, wv.y, a);
+        *mp = mm;
+        *vp = vv;
+      } else {
+        const float sc = lr_over_L * scale;
+        wv.x = fmaf(-sc, sum.x, wv.x);
+        wv.y = fmaf(-sc, sum.y, wv.y);
+      }
+      reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wv;
+    } else if (a.opt == 2) {  // dense Adam (Keras): a word without a gradient still takes the zero-gradient step
       float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
       float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
       float2 mm = *mp, vv = *vp;
-      wold.x = adam1(gs * sum.x, &mm.x, &vv.x, wold.x, a);
-      wold.y = adam1(gs * sum.y, &mm.y, &vv.y, wold.y, a);
+      wv.x = adam1(0.f, &mm.x, &vv.x, wv.x, a);
+      wv.y = adam1(0.f, &mm.y, &vv.y, wv.y, a);
       *mp = mm;
       *vp = vv;
-    } else {
-      const float sc = lr_over_L * scale;
-      wold.x = fmaf(-sc, sum.x, wold.x);
-      wold.y = fmaf(-sc, sum.y, wold.y);
+      reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wv;
     }
-    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
-  } else if (a.opt == 2) {  // dense Adam (Keras): a word without a gradient still takes the zero-gradient step
-    float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
-    float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
-    float2 mm = *mp, vv = *vp;
-    wold.x = adam1(0.f, &mm.x, &vv.x, wold.x, a);
-    wold.y = adam1(0.f, &mm.y, &vv.y, wold.y, a);
-    *mp = mm;
-    *vp = vv;
-    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
   }
 }
 

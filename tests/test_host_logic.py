@@ -41,6 +41,21 @@ def test_group_shuffle_matches_reference_up_to_within_group_order(gold):
             assert np.array_equal(a[np.lexsort(a.T)], b[np.lexsort(b.T)])
 
 
+def test_group_shuffle_equals_reference_with_stable_argsort_exactly(gold):
+    """chop in {0, 2, 5}, by item and by user, two consecutive epochs (iidx persists shuffled): the build's
+    group_shuffle_train == the reference's function text run here with `.argsort()` -> `.argsort(kind='stable')`
+    (tools/gen_golden_host.py), row for row: same NumPy stream, same permutations."""
+    for c in gold["gst_cases"].tolist():
+        train = gold["gst%d_train" % c]
+        seed, col, chop = [int(x) for x in gold["gst%d_cfg" % c]]
+        iidx = np.arange(train[:, col].max() + 1)
+        np.random.seed(seed)
+        got = group_shuffle_train(train.copy(), by="user" if col == 0 else "item", chop=chop, iidx=iidx)
+        assert np.array_equal(got, gold["gst%d_out" % c]), (c, chop)
+        got2 = group_shuffle_train(got.copy(), by="user" if col == 0 else "item", chop=chop, iidx=iidx)
+        assert np.array_equal(got2, gold["gst%d_out2" % c]), (c, chop)
+
+
 def test_group_shuffle_chop_properties():
     rs = np.random.RandomState(0)
     n, chop = 1003, 5

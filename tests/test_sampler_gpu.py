@@ -144,3 +144,24 @@ def test_device_group_shuffle_properties():
     pos = [int(np.flatnonzero(group_shuffle_train_device(du, dc, seed=s, want_perm=True)[2].cpu().numpy() == 0)[0])
            for s in range(40)]
     assert len(set(pos)) > 15
+
+
+def test_device_group_shuffle_equals_its_oracle_exactly():
+    """nncf_group_shuffle's permutation == the numpy restatement of the same counter-based keys and stable sorts
+    (oracle/shuffle_oracle.py), bit for bit: items and users, chop 0 / 2 / 5, ragged tails, tiny inputs."""
+    import torch
+    from nncf_amd.data_utils import group_shuffle_train_device
+    from oracle.shuffle_oracle import group_shuffle_perm
+    rs = np.random.RandomState(1)
+    for n, nu, ni in [(20003, 500, 300), (4096, 60, 4000), (7, 3, 2), (1, 1, 1)]:
+        u = rs.randint(0, nu, n).astype(np.int32)
+        c = (rs.zipf(1.3, n) % ni).astype(np.int32)
+        du, dc = torch.as_tensor(u).cuda(), torch.as_tensor(c).cuda()
+        for by in ("item", "user"):
+            for chop in (0, 2, 5):
+                for seed in (0, 7, 2 ** 63 + 11):
+                    uo, co, perm = [t.cpu().numpy() for t in
+                                    group_shuffle_train_device(du, dc, by=by, chop=chop, seed=seed, want_perm=True)]
+                    want = group_shuffle_perm(u, c, by == "user", chop, seed)
+                    assert np.array_equal(perm, want), (n, by, chop, seed)
+                    assert np.array_equal(uo, u[want]) and np.array_equal(co, c[want])

@@ -114,8 +114,9 @@ def test_every_kernel_path_of_the_shared_schemes_matches_the_oracle(text_data, m
         rt, at = (5e-4, 5e-5) if opt == "adam" else (2e-5, 5e-6)     # Adam divides by sqrt(v): the existing Adam tests' budget
         np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
         for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
-            if opt == "adam" and name == "bd":
+            if opt == "adam" and name in ("bd", "rm"):
                 continue   # dL/dbd = sum dz is exactly 0 behind a BatchNorm: Adam turns its rounding noise into +-lr steps
+                           # of bd, which shift the batch mean (and its running average) and nothing else
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
                                        err_msg="%s step %d" % (name, step))
 

@@ -35,6 +35,18 @@ def ref_group_shuffle():
     return ns["group_shuffle_train"]
 
 
+def ref_group_shuffle_stable():
+    """The same source lines with ONE token changed in memory: `.argsort()` (:234, an unstable quicksort whose
+    within-group order is NumPy-build specific) -> `.argsort(kind='stable')`, the documented deviation of the build.
+    With it the chop > 0 outputs are reproducible, and the build's function must equal them exactly."""
+    lines = open(os.path.join(REF, "configs", "data_utils.py")).read().split("\n")
+    src = "\n".join(lines[217:241])
+    assert src.count(".argsort()") == 1
+    ns = {"np": np}
+    exec(compile(src.replace(".argsort()", ".argsort(kind='stable')"), "ref_group_shuffle_train_stable", "exec"), ns)
+    return ns["group_shuffle_train"]
+
+
 def main():
     out = {}
     ev = ref_eval_multiple()
@@ -67,6 +79,24 @@ def main():
         out["gs%d_seed" % c] = np.array([1234 + c])
         out["gs%d_by" % c] = np.array([col])
     out["gs_cases"] = np.arange(3)
+    gss = ref_group_shuffle_stable()
+    k = 0
+    for (n, nu, ni, by) in [(2003, 300, 120, "item"), (777, 50, 40, "user")]:
+        for chop in (0, 2, 5):
+            rs = np.random.RandomState(200 + k)
+            train = np.stack([rs.randint(0, nu, n), rs.randint(0, ni, n), np.ones(n, dtype=np.int64)], 1).astype(np.int64)
+            col = 0 if by == "user" else 1
+            iidx = np.arange(train[:, col].max() + 1)
+            np.random.seed(4321 + k)
+            ii = iidx.copy()
+            res = gss(train.copy(), by=by, chop=chop, iidx=ii)
+            res2 = gss(res.copy(), by=by, chop=chop, iidx=ii)     # a second epoch: iidx persists shuffled (:231)
+            out["gst%d_train" % k] = train
+            out["gst%d_out" % k] = res
+            out["gst%d_out2" % k] = res2
+            out["gst%d_cfg" % k] = np.array([4321 + k, col, chop])
+            k += 1
+    out["gst_cases"] = np.arange(k)
     path = os.path.join(ROOT, "tests", "golden", "host_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KB")

@@ -12,8 +12,8 @@ import sys
 
 # bench key -> (profile name stem, kernel whose traffic bench.py reports)
 CASES = {
-    "basic_embedding/neg_shared/skip-gram/b512/d100": ("basic_embedding_neg_shared", "tower_word_kernel"),
-    "mf/neg_shared/skip-gram/b512/d100": ("mf_neg_shared", "shared_tile_kernel"),
+    "basic_embedding/neg_shared/skip-gram/b512/d100": ("basic_embedding_neg_shared", "fused_strip_kernel"),
+    "mf/neg_shared/skip-gram/b512/d100": ("mf_neg_shared", "fused_strip_kernel"),
 }
 
 

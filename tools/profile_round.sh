@@ -1,29 +1,20 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: bench JSON lines + rocprofv3 summaries.
-# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r01
+# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r02
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
+B="--recall-epochs 0"
 run_prof () {  # name, extra rocprof args, bench args...
   local name=$1; shift
   local extra=$1; shift
-  (cd /tmp && rocprofv3 --kernel-trace $extra -d $OUT/prof_$name -o p -- python3 $R/bench.py "$@" > $OUT/prof_$name.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace $extra -d $OUT/prof_$name -o p -- python3 $R/bench.py "$@" $B > $OUT/prof_$name.log 2>&1)
   python3 $R/tools/prof_summary.py $OUT/prof_$name/p_results.db $OUT/${TAG}_$name.txt
   rm -rf $OUT/prof_$name
 }
-python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared.json
-python3 bench.py --scheme group_neg_shared --cpu-seconds 6 --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared.json
-python3 bench.py --scheme original --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_original.json
-python3 bench.py --optimizer adam --cpu-seconds 0 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_adam.json
-python3 bench.py --model cnn_embedding --scheme group_neg_shared --cpu-seconds 8 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared.json
-python3 bench.py --model cnn_embedding --scheme group_neg_shared --optimizer adam --cpu-seconds 0 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared_adam.json
-python3 bench.py --model mf --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared.json
-python3 bench.py --model mf --scheme original --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_original.json
-python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_group_neg_shared.json
-python3 bench.py --model mf --large --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared.json
-python3 bench.py --model mf --large --scheme original --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_original.json
+# kernel traces + PMC passes first: make_traffic.py turns them into profiles/traffic.json, which the bench lines below read
 run_prof basic_embedding_neg_shared_kernel_trace "--stats" --steps 780 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof basic_embedding_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof basic_embedding_neg_shared_pmc_write "--pmc WRITE_SIZE" --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
@@ -33,8 +24,31 @@ run_prof cnn_embedding_group_neg_shared_kernel_trace "--stats" --model cnn_embed
 run_prof mf_neg_shared_kernel_trace "--stats" --model mf --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_write "--pmc WRITE_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
+run_prof mf_neg_shared_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_original_kernel_trace "--stats" --model mf --scheme original --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_group_neg_shared_kernel_trace "--stats" --model mf --scheme group_neg_shared --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
-bash tools/pmc_mfma.sh $TAG > /dev/null 2>&1
+run_prof large_mf_b8192_kernel_trace "--stats" --large --batch 8192 --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
+run_prof large_mf_b8192_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
+(cd /tmp && NNCF_FORCE_SHARDED=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_sh -o p -- python3 $R/bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 $B > $OUT/prof_sh.log 2>&1)
+python3 $R/tools/prof_summary.py $OUT/prof_sh/p_results.db $OUT/${TAG}_mf_sharded_world1_kernel_trace.txt; rm -rf $OUT/prof_sh
 python3 tools/make_traffic.py $OUT $TAG $OUT/${TAG}_traffic.json > /dev/null
+cp $OUT/${TAG}_traffic.json profiles/traffic.json
+# bench lines (the headline first: full default run incl. cpu_baseline and the trained-Recall side run)
+python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared.json
+python3 bench.py --scheme group_neg_shared --cpu-seconds 6 --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared.json
+python3 bench.py --scheme original --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_original.json
+python3 bench.py --optimizer adam --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_adam.json
+NNCF_TOWER_BWD=fused python3 bench.py --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_fusedbwd.json
+NNCF_SHARED_PATH=tile python3 bench.py --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_tilepath.json
+python3 bench.py --model cnn_embedding --scheme group_neg_shared --cpu-seconds 8 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared.json
+python3 bench.py --model mf --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared.json
+NNCF_SHARED_PATH=tile python3 bench.py --model mf --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared_tilepath.json
+python3 bench.py --model mf --scheme original --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_original.json
+python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_group_neg_shared.json
+python3 bench.py --large --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared.json
+python3 bench.py --large --scheme original --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_original.json
+python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1.json
+python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
 ls -la $OUT/${TAG}_*

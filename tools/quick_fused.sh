@@ -1,5 +1,3 @@
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/r02_gputest_c.log
-NNCF_FORCE_SHARDED=1 python bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 --recall-epochs 0 2>gpurun_out/r02_q_sharded.err | tail -1 > gpurun_out/r02_q_mf_sharded_w1.json
-NNCF_FORCE_SHARDED=1 python bench.py --large --steps 780 --warmup 390 --cpu-seconds 0 --recall-epochs 0 2>>gpurun_out/r02_q_sharded.err | tail -1 > gpurun_out/r02_q_large_sharded_w1.json
-python bench.py --large --steps 780 --warmup 390 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 > gpurun_out/r02_q_large_plain.json
+NNCF_TOWER_BWD=fused python -m pytest tests/test_tower_gpu.py -q -k "every_kernel_path or bitwise" 2>&1 | tail -5 > gpurun_out/r02_gputest_d.log
+NNCF_TOWER_BWD=fused python bench.py --steps 780 --warmup 390 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 > gpurun_out/r02_q_basic_embedding_fusedbwd.json
