@@ -161,6 +161,15 @@ int nncf_model_destroy(nncf_model* m);
  * item gradients are exported).  Resets the step counter t. */
 int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float beta2, float epsilon, float* d_m_user,
                              float* d_v_user, float* d_m_item, float* d_v_item);
+/* Mode 1 only -- what happens to an id that occurs several times in a batch (utils/optimizer.py:108-134).
+ * as_written == 0 (default): the occurrences' gradients are summed first and the row takes ONE Adam step (TF's
+ * Optimizer._apply_sparse_duplicate_indices wraps _apply_sparse that way).  as_written != 0: the file's own
+ * arithmetic for an IndexedSlices that still holds duplicates -- m and v are scatter_update'd from each occurrence
+ * (the last one in batch order wins: m = beta1 m_old + (1 - beta1) g_last, the same for v) and the step
+ * lr_t m / (sqrt(v) + eps) is scatter_sub'ed once PER OCCURRENCE.  Id tables under neg_shared / group_neg_shared /
+ * row-wise batches (a lookup per batch position); `original` batches go through nncf_step_rowwise; the one-launch
+ * step (which folds duplicates into one row) is bypassed; text-tower word tables keep the summed form. */
+int nncf_model_set_sparse_adam_duplicates(nncf_model* m, int32_t as_written);
 int nncf_model_get_step(nncf_model* m, int64_t* out);
 
 /* InteractionDot bias (modules/interaction/interaction_dot.py:62-71,96-107; conf.interaction_bias
@@ -413,6 +422,16 @@ int64_t nncf_group_shuffle_ws_bytes(int64_t n);
 int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, int64_t n, int32_t by_user, int32_t chop,
                        uint64_t seed, int32_t* d_uid_out, int32_t* d_cid_out, int32_t* d_perm_out, void* d_ws,
                        int64_t ws_bytes, void* stream);
+
+/* Device GroupSampler.sample (configs/data_utils.py:244-330; models/train_group_neg_shared.py:24-27,56 with
+ * conf.group_shuffling_trick = False): d_groups[n_groups] = groups drawn from the B1 sampler over the group column
+ * (nncf_sampler_sample_dev: the reference's stream), then `chop` members of each group uniformly with replacement --
+ * member_ptr[groups + 1] / members[] = CSR of the positive members of every group in train order (:300-303).
+ * Member picks: counter-based hash of (seed, output row) -- np.random.choice's distribution, not NumPy's stream.
+ * Output row i (i < n_groups * chop) = (member, group i / chop); by_user != 0 swaps the roles. */
+int nncf_group_sample(const int32_t* d_groups, int64_t n_groups, int32_t chop, const int32_t* d_member_ptr,
+                      const int32_t* d_members, uint64_t seed, int32_t by_user, int32_t* d_uid_out, int32_t* d_cid_out,
+                      void* stream);
 
 /* Evaluator whole@k for one candidate set (utils/objectives.py:296-370,395-421 +
  * utils/metrics_ranking.py:6-35 eval_multiple).  d_scores: n_users rows of n_cand scores

@@ -95,6 +95,7 @@ def _declare(lib):
         "nncf_model_set_hparams": [vp, f32, f32, f32, f32],
         "nncf_model_set_optimizer": [vp, i32, f32, f32, f32, vp, vp, vp, vp],
         "nncf_model_get_step": [vp, ctypes.POINTER(ctypes.c_int64)],
+        "nncf_model_set_sparse_adam_duplicates": [vp, i32],
         "nncf_model_set_bias": [vp, vp, vp, i64, vp, vp, vp, vp],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
         "nncf_profile_begin": [ctypes.c_char_p, i64],
@@ -142,6 +143,7 @@ def _declare(lib):
         "nncf_plan_item_block": [vp, i32, vp, vp, vp, vp, vp],
         "nncf_step_planned": [vp, i32, vp, vp, i32, vp],
         "nncf_group_shuffle": [vp, vp, i64, i32, i32, u64, vp, vp, vp, vp, i64, vp],
+        "nncf_group_sample": [vp, i64, i32, vp, vp, u64, i32, vp, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })

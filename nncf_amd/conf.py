@@ -70,6 +70,11 @@ class Conf(object):
             opt = "adam" if self.learn_rate > 0 else "sparse_adam"
         assert opt in ("sgd", "adam", "sparse_adam"), "[ERROR] optimizer %r unknown" % (opt,)
         self.optimizer = opt
+        # duplicate ids of a batch under 'sparse_adam': 'sum' (TF sums the IndexedSlices first) | 'as_written'
+        # (utils/optimizer.py:108-134 taken literally: last-writer-wins moments, one scatter_sub per occurrence)
+        dup = self.__dict__.get("sparse_adam_duplicates") or "sum"
+        assert dup in ("sum", "as_written"), "[ERROR] sparse_adam_duplicates %r unknown" % (dup,)
+        self.sparse_adam_duplicates = dup
         self.pretrain = None
         self.item_dense_transform = {"dense_hidden_dim": self.user_dim, "dense_hidden_dropout": 0.,
                                      "dense_hidden_actv": "relu"}  # :83-86

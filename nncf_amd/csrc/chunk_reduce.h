@@ -28,13 +28,15 @@ __device__ __forceinline__ Row lds_get_row(const float* sR, int r, int q) {
 // prefetch(id) -> Row           : the table row `id` (issued early so it overlaps `compute`)
 // compute(pos, is_head) -> Row : gradient contribution of batch position `pos` (is_head: pos is
 //                               the first position of its segment)
-// finalize(id, count, Row raw, Row acc) : write table row `id` (called by one 16-lane group)
+// finalize(id, count, Row raw, Row acc, Row last) : write table row `id` (called by one 16-lane group);
+//                               `last` = the contribution of the segment's last position (batch order), for
+//                               the as-written lazy-sparse Adam (utils/optimizer.py:108-134 on duplicate indices)
 template <class Prefetch, class Compute, class Finalize>
 __device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, float* sR, Prefetch prefetch,
                                              Compute compute, Finalize finalize) {
   const int gl = threadIdx.x >> 4, q = threadIdx.x & 15;
   const int c0 = pl.chunk_start[chunk], c1 = pl.chunk_start[chunk + 1];
-  Row open_acc = row_zero(), open_raw = row_zero();
+  Row open_acc = row_zero(), open_raw = row_zero(), open_last = row_zero();
   int open_id = -1, open_end = 0, open_cnt = 0;  // segment this group is accumulating
   for (int base = c0; base < c1; base += kChunkSlots) {
     const int slot = base + gl;
@@ -54,20 +56,27 @@ __device__ __forceinline__ void chunk_reduce(const PlanView& pl, int chunk, floa
     const int wend = min(base + kChunkSlots, c1);
     if (open_id >= 0) {  // continue a segment opened in an earlier round
       const int e = min(open_end, wend);
-      for (int s = base; s < e; ++s) open_acc = row_add(open_acc, lds_get_row(sR, s - base, q));
+      for (int s = base; s < e; ++s) {
+        open_last = lds_get_row(sR, s - base, q);
+        open_acc = row_add(open_acc, open_last);
+      }
       if (open_end <= wend) {
-        finalize(open_id, open_cnt, open_raw, open_acc);
+        finalize(open_id, open_cnt, open_raw, open_acc, open_last);
         open_id = -1;
       }
     }
     if (live && ds.z == slot) {  // this group's slot is a segment head
-      Row acc = r;
+      Row acc = r, last = r;
       const int send = slot + ds.w;
       const int e = min(send, wend);
-      for (int s = slot + 1; s < e; ++s) acc = row_add(acc, lds_get_row(sR, s - base, q));
+      for (int s = slot + 1; s < e; ++s) {
+        last = lds_get_row(sR, s - base, q);
+        acc = row_add(acc, last);
+      }
       if (send <= wend) {
-        finalize(ds.x, ds.w, raw, acc);
+        finalize(ds.x, ds.w, raw, acc, last);
       } else {
+        open_last = last;
         open_acc = acc;
         open_raw = raw;
         open_id = ds.x;

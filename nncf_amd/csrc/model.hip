@@ -33,6 +33,7 @@ StepArgs make_args(const nncf_model* m) {
   a.lr = c.learn_rate;
   a.gV = m->export_gV;
   a.opt = m->opt;
+  a.dup_as_written = m->dup_as_written;
   if (m->opt) {  // the step about to be taken is number adam_t + 1
     const double t = (double)(m->adam_t + 1);
     a.beta1 = m->beta1;
@@ -67,6 +68,9 @@ int finish_update(nncf_model* m, const StepArgs& a, hipStream_t st) {
 }
 
 bool shared_step_fuses(const nncf_model* m, const StepArgs& a) {
+  // the one-launch step merges the positions of a duplicated id into one row: the as-written lazy-sparse Adam
+  // needs the last position's gradient on its own -> tile + apply path
+  if (a.opt == 1 && a.dup_as_written) return false;
   return m->use_fused && fused_eligible(a) && (!a.bn_z || fused_max_blocks(a.b) <= 64);
 }
 
@@ -318,6 +322,12 @@ int nncf_model_set_bias(nncf_model* m, float* d_user_bias, float* d_item_bias, i
   return NNCF_OK;
 }
 
+int nncf_model_set_sparse_adam_duplicates(nncf_model* m, int32_t as_written) {
+  if (int rc = check_model(m)) return rc;
+  m->dup_as_written = as_written ? 1 : 0;
+  return NNCF_OK;
+}
+
 int nncf_model_get_step(nncf_model* m, int64_t* out) {
   if (int rc = check_model(m)) return rc;
   NNCF_REQUIRE(out != nullptr, "out is NULL");
@@ -341,6 +351,9 @@ int nncf_step_original(nncf_model* m, const int32_t* d_uid, const int32_t* d_cid
   NNCF_REQUIRE(m->cfg.num_negatives > 0, "train_scheme=original needs num_negatives > 0");
   const int b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
   hipStream_t st = as_stream(stream);
+  NNCF_REQUIRE(!(m->opt == 1 && m->dup_as_written),
+               "sparse_adam_duplicates = 'as_written' with train_scheme = original: feed the batch through nncf_step_rowwise "
+               "(every row a lookup position of its own; pointwise losses)");
   int rc = launch_plan(d_uid, 0, b, nullptr, 0, 0, m->plan_u, 1, st);
   if (rc) return rc;
   rc = launch_plan(d_cid, 0, b * (1 + k), nullptr, 0, 0, m->plan_v, 1, st);

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) scatter_apply_kernel(float* __restrict__ 
       pl, blockIdx.x, sR,
       [&](int id) { return id >= 0 ? row_load(table, id - id_offset, stride, d4, q) : row_zero(); },
       [&](int pos, bool) { return row_load(rows, pos, d, d4, q); },
-      [&](int id, int, Row raw, Row acc) {
+      [&](int id, int, Row raw, Row acc, Row) {
         if (id >= 0) row_store(table, id - id_offset, stride, d4, q, row_fma(-lr, acc, raw));
       });
 }

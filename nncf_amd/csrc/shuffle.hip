@@ -142,3 +142,37 @@ extern "C" int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, in
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
+
+// ---- device GroupSampler.sample (configs/data_utils.py:244-330, used by train_group_neg_shared.py:24-27,56 when
+// conf.group_shuffling_trick is False): first sample a group (item) from the B1 sampler, then `chop` of its positive
+// members (users) uniformly with replacement.  The group ids come from the caller's device sampler draw (the
+// reference's stream); the member picks are a counter-based hash of (seed, output position) -- np.random.choice's
+// distribution, not NumPy's stream.  Output row i = (member, group) of group i / chop.
+namespace nncf {
+__global__ void group_sample_kernel(const int32_t* __restrict__ groups, int64_t n_rows, int chop,
+                                    const int32_t* __restrict__ member_ptr, const int32_t* __restrict__ members,
+                                    uint64_t seed, int by_user, int32_t* __restrict__ uid_out, int32_t* __restrict__ cid_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int g = groups[i / chop];
+  const int p0 = member_ptr[g], len = member_ptr[g + 1] - p0;
+  const uint32_t r = hash32(seed, (uint64_t)i);
+  const int pick = (int)(((uint64_t)r * (uint64_t)len) >> 32);   // uniform in [0, len)
+  const int m = members[p0 + pick];
+  uid_out[i] = by_user ? g : m;
+  cid_out[i] = by_user ? m : g;
+}
+}  // namespace nncf
+
+extern "C" int nncf_group_sample(const int32_t* d_groups, int64_t n_groups, int32_t chop, const int32_t* d_member_ptr,
+                                 const int32_t* d_members, uint64_t seed, int32_t by_user, int32_t* d_uid_out,
+                                 int32_t* d_cid_out, void* stream) {
+  NNCF_REQUIRE(n_groups >= 0 && chop >= 1, "bad shape");
+  if (n_groups == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_groups && d_member_ptr && d_members && d_uid_out && d_cid_out, "NULL argument");
+  const int64_t n = n_groups * chop;
+  hipLaunchKernelGGL(group_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), d_groups, n, chop,
+                     d_member_ptr, d_members, mix64(seed), by_user, d_uid_out, d_cid_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}

@@ -37,6 +37,10 @@ struct StepArgs {
   // (utils/optimizer.py:108-134); 2 dense Adam = Keras Adam (basic_embedding_conf.py:59-60): the
   // touched rows here, every other row by adam_idle_kernel with a zero gradient.
   int opt = 0;
+  // opt == 1 only: 0 = duplicate ids of a batch summed first (TF's _apply_sparse_duplicate_indices; default),
+  // 1 = utils/optimizer.py:108-134 as written for an IndexedSlices with duplicates: moments from the LAST
+  // occurrence's gradient (scatter_update: last writer wins), the step subtracted once per occurrence (scatter_sub)
+  int dup_as_written = 0;
   float lr_t = 0.f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;  // lr_t = lr sqrt(1-b2^t)/(1-b1^t)
   int step_no = 0;
   AdamTable au, av;
@@ -129,15 +133,15 @@ __device__ __forceinline__ float4 adam4(float4 g, float4& m, float4& v, float4 p
                      p.z - lr_t * m.z / (sqrtf(v.z) + eps), p.w - lr_t * m.w / (sqrtf(v.w) + eps));
 }
 __device__ __forceinline__ void apply_update(const StepArgs& a, const AdamTable& st, float* table, int64_t id, Row raw,
-                                             Row grad, int d4, int q) {
+                                             Row grad, int d4, int q, float mult = 1.f) {
   if (a.opt == 0) {
     row_store(table, id, a.stride, d4, q, row_fma(-a.lr, grad, raw));
     return;
   }
   Row m = row_load(st.m, id, a.stride, d4, q), v = row_load(st.v, id, a.stride, d4, q);
   Row p;
-  p.a = adam4(grad.a, m.a, v.a, raw.a, a.beta1, a.beta2, a.lr_t, a.eps);
-  p.b = adam4(grad.b, m.b, v.b, raw.b, a.beta1, a.beta2, a.lr_t, a.eps);
+  p.a = adam4(grad.a, m.a, v.a, raw.a, a.beta1, a.beta2, mult * a.lr_t, a.eps);   // mult: occurrences (as-written mode)
+  p.b = adam4(grad.b, m.b, v.b, raw.b, a.beta1, a.beta2, mult * a.lr_t, a.eps);
   row_store(st.m, id, a.stride, d4, q, m);
   row_store(st.v, id, a.stride, d4, q, v);
   row_store(table, id, a.stride, d4, q, p);
@@ -236,6 +240,7 @@ struct nncf_model {
   // one-launch shared-negative step (step_fused.hip): loss partials of the current / previous step and the
   // step whose loss is still to be summed (done by the next fused launch or by flush_pending_loss)
   bool tile_ok = true;        // the tile + apply workspace exists (batch_size_p <= kTileMaxBatch)
+  int dup_as_written = 0;     // nncf_model_set_sparse_adam_duplicates
   int use_fused = 1;          // NNCF_SHARED_PATH=tile forces the two-launch tile + apply path
   float* fpart = nullptr;     // [2][fused_max_blocks(b) * fused_split(b)]
   float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips

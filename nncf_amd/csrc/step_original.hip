@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
     chunk_reduce(
         pu, blockIdx.x, sR, [&](int u) { return row_load(a.U, u, a.stride, d4, q); },
         [&](int p, bool) { return row_load(ws.dUp, p, a.d, d4, q); },
-        [&](int u, int cnt, Row uraw, Row acc) {
+        [&](int u, int cnt, Row uraw, Row acc, Row) {
           Row grad = acc;
           if (NU) {
             const float ss = row16_sum(row_dot_partial(uraw, uraw));
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
           const int p = (n < b) ? n : (n - b) / k;
           return row_scale(row_load(ws.Uhat, p, a.d, d4, q), ws.g[n]);
         },
-        [&](int c, int, Row loaded, Row acc) {
+        [&](int c, int, Row loaded, Row acc, Row) {
           const Row vraw = bn_tail_row(bt, loaded);
           Row grad = acc;
           if (NV) {

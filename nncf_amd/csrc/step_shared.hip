@@ -332,15 +332,17 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           }
           return row;
         },
-        [&](int u, int cnt, Row uraw, Row acc) {
-          Row grad = acc;
+        [&](int u, int cnt, Row uraw, Row acc, Row last) {
+          const bool aw = a.dup_as_written && a.opt == 1;   // moments from the last occurrence, cnt steps
+          const Row src = aw ? last : acc;
+          Row grad = src;
           if (NU) {
             const float ss = row16_sum(row_dot_partial(uraw, uraw));
             const float inv = inv_norm(ss);
-            grad = norm_backward(row_scale(uraw, inv), inv, ss, acc);
+            grad = norm_backward(row_scale(uraw, inv), inv, ss, src);
           }
-          grad = row_fma(2.f * a.u_reg * (float)cnt / (float)b, uraw, grad);
-          apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
+          grad = row_fma(2.f * a.u_reg * (aw ? 1.f : (float)cnt) / (float)b, uraw, grad);
+          apply_update(a, a.au, a.U, u, uraw, grad, d4, q, aw ? (float)cnt : 1.f);
         });
   } else {
     const int chunk = blockIdx.x - max_chunks;
@@ -362,16 +364,19 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
           }
           return colv;
         },
-        [&](int c, int, Row loaded, Row acc) {
+        [&](int c, int cnt, Row loaded, Row acc, Row last) {
           const Row vraw = bn_tail_row(bt, loaded);
-          Row grad = acc;
+          // neg_shared: one lookup per batch position; group: the compact block holds every item once (no duplicates)
+          const bool aw = a.dup_as_written && a.opt == 1 && !a.gV && !GROUP;
+          const Row src = aw ? last : acc;
+          Row grad = src;
           if (NV) {
             const float ss = row16_sum(row_dot_partial(vraw, vraw));
             const float inv = inv_norm(ss);
-            grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
+            grad = norm_backward(row_scale(vraw, inv), inv, ss, src);
           }
           if (a.gV) row_store(a.gV, c, d, d4, q, grad);
-          else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
+          else apply_update(a, a.av, a.V, c, vraw, grad, d4, q, aw ? (float)cnt : 1.f);
           bn_tail_acc(bt, a, vraw, grad, loaded);
         });
     bn_tail_flush(bt, a, sR, chunk);

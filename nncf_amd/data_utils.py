@@ -212,6 +212,43 @@ class GroupSampler(object):
             batch = batch[:, [1, 0, 2]]
         return batch[:batch_size_p] if strict_return_shape else batch
 
+    def sample_device(self, batch_size_p, n_steps, seed=0):
+        """n_steps batches of `sample(batch_size_p)` drawn on the device (nncf_group_sample, csrc/shuffle.hip): the
+        groups of all steps from the B1 device sampler in ONE draw (the same stream, in the same order, as n_steps
+        calls), the members by a counter-based hash of (seed, row) -- np.random.choice's distribution, not NumPy's
+        stream.  Returns int32 device tensors (uid, cid) of n_steps * batch_size_p links; per step ceil(b / chop)
+        groups are drawn and the first b rows kept (strict_return_shape, :317-330)."""
+        import ctypes
+        import torch
+        from . import _lib
+        smp = getattr(self.group_sampler, "__self__", None)
+        if smp is None or not hasattr(smp, "sample_batch_device"):
+            raise ValueError("sample_device needs the HIP group sampler (MultinomialSampler)")
+        dev = torch.device("cuda", int(getattr(smp, "device", 0)))
+        if getattr(self, "_dev_csr", None) is None:
+            gmax = max(self.group_members) + 1
+            ptr = np.zeros(gmax + 1, dtype=np.int64)
+            for g, m in self.group_members.items():
+                ptr[g + 1] = len(m)
+            ptr = np.cumsum(ptr)
+            mem = np.concatenate([self.group_members[g] for g in sorted(self.group_members)]) if self.group_members else np.zeros(0)
+            self._dev_csr = (torch.as_tensor(ptr.astype(np.int32)).to(dev), torch.as_tensor(mem.astype(np.int32)).to(dev))
+        b, chop = int(batch_size_p), self.chop
+        per = int(np.ceil(float(b) / chop))
+        groups = smp.sample_batch_device(n_steps * per)
+        rows = per * chop
+        uo = torch.empty(n_steps * rows, dtype=torch.int32, device=groups.device)
+        co = torch.empty_like(uo)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(groups.device):
+            _lib.check(_lib.lib().nncf_group_sample(p(groups), n_steps * per, chop, p(self._dev_csr[0]), p(self._dev_csr[1]),
+                                                    int(seed) & (2 ** 64 - 1), int(self.group_by == "user"), p(uo), p(co),
+                                                    _lib.stream_ptr(torch.cuda.current_stream(groups.device))))
+        if rows != b:   # keep the first b rows of every step
+            uo = uo.view(n_steps, rows)[:, :b].contiguous().view(-1)
+            co = co.view(n_steps, rows)[:, :b].contiguous().view(-1)
+        return uo, co
+
     def sample_with_negs(self, batch_size_p, k, strict_return_shape=True):
         """first ~batch_size_p rows positives (response 1), the rest negatives (response neg_sign)."""
         import random

@@ -73,6 +73,7 @@ class Engine(object):
         assert interaction_bias in (None, "user", "item", "both"), "ERROR! Unknown interation bias"
         self.interaction_bias = interaction_bias
         self.opt_state, self.optimizer = None, "sgd"
+        self.sparse_adam_duplicates = "sum"
         self.bias = None
         if interaction_bias:
             if bias_state is None and share is not None:
@@ -99,6 +100,13 @@ class Engine(object):
                                                    _ptr(b.get("v_cb"))))
 
     OPT_CODES = {"sgd": 0, "sparse_adam": 1, "adam": 2}
+
+    def set_sparse_adam_duplicates(self, mode):
+        """'sum' (default; TF's _apply_sparse_duplicate_indices) | 'as_written' (utils/optimizer.py:108-134 on an
+        IndexedSlices with duplicates: moments from the last occurrence, one step per occurrence)."""
+        assert mode in ("sum", "as_written"), "[ERROR] sparse_adam_duplicates %r unknown" % (mode,)
+        self.sparse_adam_duplicates = mode
+        _lib.check(self._L.nncf_model_set_sparse_adam_duplicates(self._h, int(mode == "as_written")))
 
     def set_optimizer(self, kind, beta1=0.9, beta2=0.999, epsilon=1e-8, state=None):
         """'sgd' | 'sparse_adam' (utils/optimizer.py:108-134) | 'adam' (Keras Adam,

@@ -52,7 +52,10 @@ class OriginalModel(_Head):
             raise ValueError("[ERROR] model expects batch_size_p * (1 + num_negatives) = %d rows, got %d"
                              % (b * (1 + k), uid.size))
         e = self.engine
-        if np.array_equal(uid[b:], np.repeat(uid[:b], k)) and (y is None or _labels_positive_first(y, b)):
+        as_written = e.optimizer == "sparse_adam" and getattr(e, "sparse_adam_duplicates", "sum") == "as_written"
+        if as_written and y is None:   # every row is a lookup position of its own: the row-wise kernels
+            y = np.concatenate([np.ones(b), np.full(b * k, -1 if e.cfg.loss == 0 else 0)])
+        if not as_written and np.array_equal(uid[b:], np.repeat(uid[:b], k)) and (y is None or _labels_positive_first(y, b)):
             # the trainer's layout (train_original.py:49-56): per-positive kernel
             return self._loss(e.step_original(e.ids(uid[:b]), e.ids(cid), update=self.update))
         # any other row order (presample / group_sample / reverse): general row-wise kernels
@@ -457,6 +460,9 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
     opt = getattr(conf, "optimizer", "sgd")
     if opt != "sgd":
+        if getattr(conf, "sparse_adam_duplicates", "sum") != "sum":
+            raise NotImplementedError("sparse_adam_duplicates = 'as_written' is built for the id tables (model_choice = mf); "
+                                      "text-tower word tables keep the summed form")
         engine.set_optimizer(opt)   # after the export buffer is set: no item-table moments
         tower.set_optimizer(opt)
 
@@ -510,13 +516,16 @@ def get_model(conf, data_helper, model_name, device=0, seed=0):
     kw = engine_kwargs(conf, data_spec, model_name)
     engine = Engine(device=device, seed=seed, **kw)
     opt = getattr(conf, "optimizer", "sgd")
+    dup = getattr(conf, "sparse_adam_duplicates", "sum")
     if opt != "sgd":
         engine.set_optimizer(opt)
+        engine.set_sparse_adam_duplicates(dup)
 
     def make_unnormalised():
         e2 = Engine(device=device, share=engine, **dict(kw, normalize_user=False))
         if opt != "sgd":
             e2.set_optimizer(opt, state=engine.opt_state)   # one optimiser for all heads (model_framework.py:24)
+            e2.set_sparse_adam_duplicates(dup)
         return e2
 
     def monitor(head_cls):

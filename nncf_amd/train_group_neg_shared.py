@@ -50,6 +50,16 @@ class Trainer(TrainerBase):
             elif self.group_shuffling_trick:
                 train = group_shuffle_train(train, by="item", chop=conf.chop_size, iidx=self._iidx["item"])
                 uid, cid = self._upload(train, n_steps)
+            elif getattr(conf, "device_shuffle", False):
+                # every batch from the GroupSampler (:56), drawn on the device: groups from the B1 device sampler's
+                # stream, members by counter-based hash (csrc/shuffle.hip: nncf_group_sample)
+                t0 = time.time()
+                if n_steps:
+                    uid, cid = self.group_sampler.sample_device(b, n_steps, seed=getattr(conf, "shuffle_seed", 0) * 1000003 + epoch)
+                    torch.cuda.synchronize(engine.device)
+                else:
+                    uid = cid = torch.zeros(0, dtype=torch.int32, device=engine.device)
+                in_window = time.time() - t0
             else:
                 # every batch is drawn from the GroupSampler (:56); the reference draws inside its
                 # timed loop, here the epoch's batches are drawn first (same RNG call order: nothing

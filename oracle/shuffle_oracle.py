@@ -45,3 +45,20 @@ def group_shuffle_perm(uid, cid, by_user, chop, seed):
         key = (hi << np.uint64(32)) | i.astype(np.uint64)
         rows = rows[np.argsort(key, kind="stable")]
     return rows.astype(np.int64)
+
+
+def group_sample_rows(groups, chop, member_ptr, members, seed, by_user=False):
+    """numpy restatement of nncf_group_sample (csrc/shuffle.hip): rows (uid, cid) of GroupSampler.sample
+    (/root/reference/configs/data_utils.py:312-330) for the given sampled groups."""
+    groups = np.asarray(groups, dtype=np.int64)
+    n = len(groups) * chop
+    i = np.arange(n)
+    g = groups[i // chop]
+    p0 = np.asarray(member_ptr)[g].astype(np.uint64)
+    ln = (np.asarray(member_ptr)[g + 1] - np.asarray(member_ptr)[g]).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        s = mix64(np.uint64(seed))
+    r = hash32(int(s), i)
+    pick = (r * ln) >> np.uint64(32)
+    m = np.asarray(members)[(p0 + pick).astype(np.int64)]
+    return (g, m) if by_user else (m, g)

@@ -57,6 +57,7 @@ class OracleConf(object):
         # | 'sparse_adam' (utils/optimizer.py:108-134; duplicate ids summed first)
         assert optimizer in ("sgd", "adam", "sparse_adam")
         self.optimizer, self.beta1, self.beta2, self.epsilon = optimizer, beta1, beta2, epsilon
+        self.sparse_adam_duplicates = "sum"     # | 'as_written' (AdamSlot.step_as_written)
         # InteractionDot bias (interaction_dot.py:48-49,62-71): None | 'user' | 'item' | 'both'; zero init
         assert interaction_bias in ("user", "item", "both", None), "ERROR! Unknown interation bias"
         self.interaction_bias = interaction_bias
@@ -280,6 +281,22 @@ class AdamSlot(object):
             self.m[rows] = b1 * self.m[rows] + (dt(1) - b1) * g[rows]
             self.v[rows] = b2 * self.v[rows] + (dt(1) - b2) * g[rows] * g[rows]
             p[rows] -= lr_t * self.m[rows] / (np.sqrt(self.v[rows]) + eps)
+
+    def step_as_written(self, p, idx, g_pos, lr_t, conf):
+        """utils/optimizer.py:108-134 literally, for an IndexedSlices (indices idx, one gradient row g_pos[j] per
+        lookup position) that still holds duplicate indices: m / v gathered (old values), scatter_update'd per
+        position -- the last position of an index wins [K-mem: TF's CPU scatter_update applies updates in order] --
+        and lr_t m / (sqrt(v) + eps), gathered AFTER the update, scatter_sub'ed once per position."""
+        dt = p.dtype.type
+        b1, b2, eps, lr_t = dt(conf.beta1), dt(conf.beta2), dt(conf.epsilon), dt(lr_t)
+        idx = np.asarray(idx)
+        m_new = b1 * self.m[idx] + (dt(1) - b1) * g_pos                 # m_scaled + m_scaled_g_values, per position
+        v_new = b2 * self.v[idx] + (dt(1) - b2) * g_pos * g_pos
+        for j in range(len(idx)):                                       # scatter_update, in position order
+            self.m[idx[j]] = m_new[j]
+            self.v[idx[j]] = v_new[j]
+        upd = lr_t * self.m[idx] / (np.sqrt(self.v[idx]) + eps)         # m_tp, v_tp: gathered from the updated slots
+        np.subtract.at(p, idx, upd.astype(p.dtype))                     # scatter_sub: once per occurrence
 
 
 class TowerOracle(object):
@@ -607,9 +624,14 @@ class StepOracle(object):
                 self.slot_u = AdamSlot(self.U)
                 self.slot_v = AdamSlot(self.V) if self.tower is None else None
             sparse = opt == "sparse_adam"
-            self.slot_u.step(self.U, dU, lr_t, self.conf, tu if sparse else None)
-            if self.tower is None:
-                self.slot_v.step(self.V, dV, lr_t, self.conf, tv if sparse else None)
+            if sparse and getattr(self.conf, "sparse_adam_duplicates", "sum") == "as_written":
+                self.slot_u.step_as_written(self.U, uid, g_u.astype(self.dt), lr_t, self.conf)
+                if self.tower is None:
+                    self.slot_v.step_as_written(self.V, cid, g_v.astype(self.dt), lr_t, self.conf)
+            else:
+                self.slot_u.step(self.U, dU, lr_t, self.conf, tu if sparse else None)
+                if self.tower is None:
+                    self.slot_v.step(self.V, dV, lr_t, self.conf, tv if sparse else None)
         if gb_u is not None:
             self._apply_bias(uid, cid, gb_u, gb_v, adam_lr_t(self.conf.learn_rate, self.conf.beta1, self.conf.beta2, max(self.t, 1)))
         self.last = dict(g_u=g_u, g_v=g_v, dU=dU, dV=dV)

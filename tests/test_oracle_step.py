@@ -415,3 +415,23 @@ def test_interaction_bias_vs_autograd(loss):
         np.testing.assert_allclose(o.ub, ub0 - 0.1 * tub.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=scheme)
         np.testing.assert_allclose(o.cb, cb0 - 0.1 * tcb.grad.numpy(), rtol=1e-9, atol=1e-12, err_msg=scheme)
         np.testing.assert_allclose(o.U, U - 0.1 * tU.grad.numpy(), rtol=1e-8, atol=1e-11, err_msg=scheme)
+
+
+def test_sparse_adam_as_written_by_hand():
+    """utils/optimizer.py:108-134 with a duplicated index, step 1 from zero moments: index 2 occurs twice (gradients
+    g_a then g_b): m = (1-b1) g_b, v = (1-b2) g_b^2, and the step lr_t m / (sqrt(v) + eps) is subtracted TWICE;
+    index 0 occurs once.  The summed form would use g_a + g_b and subtract once."""
+    conf = so.OracleConf(optimizer="sparse_adam", learn_rate=0.1)
+    p = np.zeros((3, 2), dtype=np.float64)
+    slot = so.AdamSlot(p)
+    g = np.array([[1.0, -2.0], [0.5, 4.0], [-3.0, 0.25]])
+    idx = np.array([2, 0, 2])
+    lr_t = so.adam_lr_t(0.1, conf.beta1, conf.beta2, 1)
+    slot.step_as_written(p, idx, g, lr_t, conf)
+    b1, b2, eps = conf.beta1, conf.beta2, conf.epsilon
+    for row, glast, cnt in ((2, g[2], 2), (0, g[1], 1)):
+        m, v = (1 - b1) * glast, (1 - b2) * glast ** 2
+        np.testing.assert_allclose(slot.m[row], m, rtol=1e-12)
+        np.testing.assert_allclose(slot.v[row], v, rtol=1e-12)
+        np.testing.assert_allclose(p[row], -cnt * lr_t * m / (np.sqrt(v) + eps), rtol=1e-12)
+    assert np.all(p[1] == 0) and np.all(slot.m[1] == 0)

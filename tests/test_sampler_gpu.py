@@ -165,3 +165,35 @@ def test_device_group_shuffle_equals_its_oracle_exactly():
                     want = group_shuffle_perm(u, c, by == "user", chop, seed)
                     assert np.array_equal(perm, want), (n, by, chop, seed)
                     assert np.array_equal(uo, u[want]) and np.array_equal(co, c[want])
+
+
+def test_device_group_sampler_equals_its_oracle_exactly():
+    """GroupSampler.sample_device (nncf_group_sample): the groups are the B1 sampler's stream (bit-exact vs the C
+    oracle of nodesampler.cpp), the member picks equal the numpy restatement of the same counter-based hash; every
+    sampled link is a training link."""
+    import torch
+    from nncf_amd.data_utils import GroupSampler, degree_dist
+    from oracle.sampler_oracle import OracleSampler
+    from oracle.shuffle_oracle import group_sample_rows
+    rs = np.random.RandomState(2)
+    n, nu, ni = 5000, 200, 90
+    train = np.unique(np.stack([rs.randint(0, nu, n), rs.zipf(1.4, n) % ni, np.ones(n, dtype=np.int64)], 1), axis=0)
+    links = set(map(tuple, train[:, :2].tolist()))
+    for by, chop, b in (("item", 4, 64), ("item", 5, 64), ("user", 3, 32)):
+        gs = GroupSampler(train, group_by=by, chop=chop, neg_dist="unigram", neg_sign=-1)
+        smp = gs.group_sampler.__self__
+        smp.state = 4242
+        steps = 7
+        uo, co = [t.cpu().numpy() for t in gs.sample_device(b, steps, seed=13)]
+        assert uo.shape == (steps * b,)
+        gc = 1 if by == "item" else 0
+        per = -(-b // chop)
+        want_groups = OracleSampler(degree_dist(train, gc, "unigram"), 1.0, 4242).sample_batch(steps * per)
+        ptr, mem = [t.cpu().numpy() for t in gs._dev_csr]
+        wu, wc = group_sample_rows(want_groups, chop, ptr, mem, 13, by_user=(by == "user"))
+        wu = wu.reshape(steps, per * chop)[:, :b].reshape(-1)
+        wc = wc.reshape(steps, per * chop)[:, :b].reshape(-1)
+        assert np.array_equal(uo, wu) and np.array_equal(co, wc), (by, chop)
+        assert all((int(u), int(c)) in links for u, c in zip(uo, co))
+        grp = co if by == "item" else uo
+        assert np.all(grp.reshape(steps, b)[:, :chop] == grp.reshape(steps, b)[:, :1])     # runs of one group

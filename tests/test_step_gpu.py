@@ -459,3 +459,48 @@ def test_d128_all_schemes_and_losses(scheme, loss):
             got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
         assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, got, want)
         _check_tables(eng, orc)
+
+
+@pytest.mark.parametrize("scheme", ["original", "neg_shared", "group_neg_shared"])
+def test_sparse_adam_as_written_matches_oracle(scheme):
+    """sparse_adam_duplicates = 'as_written' (utils/optimizer.py:108-134 on duplicate indices: moments from the last
+    occurrence, the step subtracted once per occurrence) vs the oracle, with heavily repeated users and items."""
+    b, k, d, nu, ni = 64, 3, 24, 30, 40
+    loss = "skip-gram"
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k if scheme == "original" else 0, loss=loss, u_reg=1e-3,
+                         learn_rate=0.01, model_choice="mf", optimizer="sparse_adam")
+    conf.sparse_adam_duplicates = "as_written"
+    eng = Engine(nu, ni, d, b, conf.num_negatives, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=3, init_scale=0.5)
+    eng.set_optimizer("sparse_adam")
+    eng.set_sparse_adam_duplicates("as_written")
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    sum_orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(),
+                            so.OracleConf(batch_size_p=b, num_negatives=conf.num_negatives, loss=loss, u_reg=1e-3, learn_rate=0.01,
+                                          model_choice="mf", optimizer="sparse_adam"), dtype=np.float32)
+    rs = np.random.RandomState(5)
+    for step in range(4):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        if scheme == "group_neg_shared":
+            cid = np.repeat(cid[::4], 4)
+        if scheme == "original":
+            u, c, y = so.assemble_original(np.stack([uid, cid, np.ones(b, dtype=np.int64)], 1), rs.randint(0, ni, b * k), loss)
+            want = orc.step_original(u, c, y)
+            sum_orc.step_original(u, c, y)
+            got = eng.step_rowwise(eng.ids(u), eng.ids(c), eng.ids(y)).item()   # every row its own lookup position
+            with pytest.raises(ValueError):
+                eng.step_original(eng.ids(uid), eng.ids(c))
+        elif scheme == "neg_shared":
+            want = orc.step_neg_shared(uid, cid)
+            sum_orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_group_neg_shared(uid, cid)
+            sum_orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(eng.opt_state["mU"].cpu().numpy(), orc.slot_u.m, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(eng.opt_state["vV"].cpu().numpy(), orc.slot_v.v, rtol=2e-4, atol=1e-9)
+    assert np.abs(orc.U - sum_orc.U).max() > 1e-3      # the two semantics really differ on this data
