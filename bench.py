@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--profile-launches", type=int, default=1000)
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
+    ap.add_argument("--device-links", type=float, default=0,
+                    help="--large only: generate this many (user, item) links ON THE DEVICE (Zipf-like over 10M users / 1M items, "
+                         "torch's Philox counter PRNG, int32 pairs: 8 GB at 1e9 = SURVEY.md 8(d) input B) and train on their "
+                         "first (warmup + steps) * batch; 0 = only the consumed links, generated on the host")
     ap.add_argument("--large", action="store_true",
                     help="BASELINE config-4 shape on one GPU: 10M users x 1M items, d=128, id tables (mf), random "
                          "Zipf links; tables 5.6 GB -- the HBM-bound regime")
@@ -692,6 +696,19 @@ def main():
     uid = eng.ids(inp["uid"])
     cid = eng.ids(inp["cid"])
     W, K = args.warmup, args.steps
+    device_links = None
+    if args.large and args.device_links > 0:
+        # SURVEY.md 8(d) input B: the link list lives in HBM and is generated there (counter-based PRNG), int32 SoA
+        n_links = max(int(args.device_links), (W + K) * b)
+        gen = torch.Generator(device=eng.device).manual_seed(20170813)
+        ul = torch.empty(n_links, dtype=torch.int32, device=eng.device)
+        cl = torch.empty(n_links, dtype=torch.int32, device=eng.device)
+        for o in range(0, n_links, 1 << 27):
+            m = min(1 << 27, n_links - o)
+            for out, count in ((ul, inp["users"]), (cl, inp["items"])):
+                r = torch.rand(m, generator=gen, device=eng.device).pow_(1.0 / 0.35).mul_(count)    # numpy's power(0.35)
+                out[o:o + m] = r.to(torch.int32).clamp_(max=count - 1)
+        uid, cid, device_links = ul, cl, n_links
     sampler = None
     neg = None
     if args.scheme == "original":
@@ -838,6 +855,7 @@ def main():
                        "global_batch": b * world, "parallelism": "1 process per GPU"},
             "mean_loss": mean_loss,
             "mean_unique_items_per_step": mean_n_u if args.model != "mf" else None,
+            "device_generated_links": device_links,
             "recall_at_50": recall,
             "recall_at_50_trained": recall_trained,
             "roofline": roof,
