@@ -96,6 +96,8 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
   f.split = fused_split(a.b);
   f.slab = m->fslab;
   f.cnt = m->fcnt;
+  f.done = m->fdone;
+  f.parity = m->fparity;
   f.loss_part = m->fpart + (size_t)m->fparity * mb;
   f.dbg = m->sws.dbg;   // NNCF_DEBUG_TIMING=1: [2 mb + 1][32] stamps fit the tile kernel's [nb*nb][8] buffer for b >= 128
   if (m->pend_out) {
@@ -105,7 +107,7 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
   }
   if (int rc = launch_fused(a, group, uid, cid, f, pu, pv, update, st)) return rc;
   m->pend_out = loss_out;
-  m->pend_n = mb;
+  m->pend_n = fused_loss_parts(a);
   m->pend_parity = m->fparity;
   m->fparity ^= 1;
   return NNCF_OK;
@@ -150,6 +152,7 @@ void carve(nncf_model* m, Carver& c) {
     m->fpart = c.take<float>(2 * mb * sp);
     m->fslab = c.take<float>(sp > 1 ? 2 * mb * sp * 16 * 128 : 4);
     m->fcnt = c.take<int>(2 * mb);
+    m->fdone = c.take<int>(2);
   }
   m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries

@@ -25,6 +25,14 @@ struct FusedArgs {
   int split = 1;
   float* slab = nullptr;
   int* cnt = nullptr;
+  // read-before-write across the launch: a strip's rows are stepped IN PLACE while the opposite pass of other
+  // workgroups streams the same table.  Every workgroup announces "my table reads are done" in done[parity] (one
+  // relaxed agent-scope add, when its last stage's rows are in LDS); a workgroup that steps a table another pass
+  // reads waits for all of them (the count follows from the plans' segment counts) before its first store.
+  // done[parity ^ 1] is zeroed by this launch for the next one.  All workgroups must be resident at once: the
+  // launcher checks the grid against the device's capacity.
+  int* done = nullptr;
+  int parity = 0;
   long long* dbg = nullptr;   // developer timing: [workgroup][32] s_memtime stamps (NNCF_DEBUG_TIMING=1)
 };
 
@@ -32,6 +40,8 @@ struct FusedArgs {
 bool fused_eligible(const StepArgs& a);
 int fused_max_blocks(int b);  // strips per side (= V-pass BatchNorm partials)
 int fused_split(int b);       // workgroups per strip chosen for batch size b
+int fused_row_tiles(const StepArgs& a);   // 16-row tiles per workgroup (1: strip kernel; 2, 4: wide kernel)
+int fused_loss_parts(const StepArgs& a);  // loss partials one launch writes
 constexpr int kFusedMaxSplit = 8;
 int launch_fused(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const FusedArgs& f,
                  const PlanView& pu, const PlanView& pv, int update, hipStream_t stream);

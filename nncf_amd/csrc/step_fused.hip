@@ -66,6 +66,21 @@ __device__ __forceinline__ void store_sc1(float* p, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// one lane: this workgroup has read every table row it will read
+__device__ __forceinline__ void readers_arrive(const FusedArgs& f) {
+  __hip_atomic_fetch_add(f.done + f.parity, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int readers_seen(const FusedArgs& f) {
+  return __hip_atomic_load(f.done + f.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane, followed by __syncthreads(): every reading workgroup of the launch has arrived (`seen`: an earlier poll)
+__device__ __forceinline__ void readers_wait(const FusedArgs& f, int seen, int target) {
+  while (seen < target) {
+    __builtin_amdgcn_s_sleep(2);
+    seen = readers_seen(f);
+  }
+}
+
 // NG groups of 16 columns of one S tile: 2 NG ds_read_b128, 4 NG MFMAs
 template <int NG>
 __device__ __forceinline__ void s_tile(const float4* pa4, const float4* pb4, f32x4& acc0, f32x4& acc1) {
@@ -324,8 +339,14 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   float lsum = 0.f;
   const bool back_wave = wave * 16 < NP;
 
+  // Rows are stepped in place at the end while other workgroups of this launch still stream the same tables: every
+  // workgroup announces its last table read (its final stage's rows are in LDS) and whoever stores waits for all
+  // of them.  The announcement leaves a whole stage before the stores and the first poll is issued under the last
+  // back-GEMM, so the hand-shake normally costs no time.
+  int seen = 0;
   int stamp_i = 0;
   for (int st = part; st < nst; st += P, ++stamp_i) {
+    const bool last_stage = update && st + P >= nst;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       Row r = rcur[e];
@@ -334,6 +355,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
       if (q == 0) sOppKey[g + 32 * e] = kcur[e];
     }
     __syncthreads();
+    if (last_stage && tid == 0) readers_arrive(f);
     if (stamp_i < 4) FSTAMP(5 + 4 * stamp_i);
     // next stage's rows (their ids arrived a stage ago) and the ids of the stage after it travel under this
     // stage's MFMAs
@@ -408,6 +430,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
       }
     }
     __syncthreads();
+    if (last_stage && tid == 0) seen = readers_seen(f);
 
     if (stamp_i < 4) FSTAMP(7 + 4 * stamp_i);
     // back-GEMM: dOwn[16][d] += G[16][128] . Opp[128][d]; wave = 16-column tile of the output.  Same k
@@ -502,16 +525,28 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   FSTAMP(21);
   // ---- finalize: one 16-lane group per own row -----------------------------------------------------
   Row t1 = row_zero(), t2 = row_zero();  // BatchNorm backward sums of this workgroup's item rows
+  Row grad = row_zero();
   if (update && own_ok) {
     Row acc;
     acc.a = reinterpret_cast<const float4*>(sOut + g * kFOP)[q];
     acc.b = reinterpret_cast<const float4*>(sOut + g * kFOP)[q + 16];
     if (q >= d4) acc.a = zero4();
     if (q + 16 >= d4) acc.b = zero4();
-    Row grad = acc;
+    grad = acc;
     if (USIDE ? NU : NV) grad = norm_backward(own_hat, own_inv, own_ss, acc);
+    if (USIDE) grad = row_fma(2.f * a.u_reg * own_c * inv_b, own_raw, grad);
+  }
+  if (update && (USIDE || !a.gV)) {   // the rows stepped below are streamed by the other pass of every strip
+    if (tid == 0) {
+      const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
+      const int nst_u = ((GROUP ? nseg_v : b) + kFNB - 1) / kFNB, nst_v = (b + kFNB - 1) / kFNB;
+      readers_wait(f, seen, ((nseg_u + kFM - 1) / kFM) * min(P, nst_u) + ((nseg_v + kFM - 1) / kFM) * min(P, nst_v));
+    }
+    __syncthreads();
+  }
+  FSTAMP(24);
+  if (update && own_ok) {
     if (USIDE) {
-      grad = row_fma(2.f * a.u_reg * own_c * inv_b, own_raw, grad);
       apply_update(a, a.au, a.U, own_id, own_raw, grad, d4, q);
     } else {
       if (a.gV) row_store(a.gV, own_id, d, d4, q, grad);
@@ -559,6 +594,7 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
       l = wave_sum(l);
       if (threadIdx.x == 0) *f.prev_out = l;
     }
+    if (threadIdx.x == 0) f.done[f.parity ^ 1] = 0;   // the next launch's arrival counter
     return;
   }
   const int rest = id >> 3;
@@ -585,6 +621,390 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
   }
 }
 
+// ---- large batches (b >= 4096): MT row tiles of 16 own rows per workgroup --------------------------------------
+// At b = 512 the step is latency-bound and 16-row strips split over several workgroups fill the chip; at b >= 4096
+// it is fp32-MFMA-bound and a 16-row strip pays the staging of every 128-row stage (global -> LDS, normalisation,
+// two barriers) for 2 x 32 MFMAs per wave.  Here a workgroup owns 16 MT unique rows: a stage is staged once and
+// used by MT score tiles and MT back-GEMM tiles per wave (the opposite-row fragments are read from LDS once per
+// stage), L2 traffic per step drops by MT, and the element-wise dL/dS of tile m is independent of the MFMAs of
+// tile m + 1 (VALU under the matrix pipe).  No BatchNorm fusion and no split: the text towers cap the batch at
+// 1024 and 2 b / (16 MT) >= 256 workgroups already.
+template <int MT>
+__host__ __device__ constexpr size_t wide_lds_bytes() {
+  return sizeof(float) * (16 * MT * kFDP + kFNB * kFDP + 16 * MT * kFGP + 16 * MT + 16 * MT + 8) +
+         sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4);
+}
+
+template <int NG, int MT>
+__device__ __forceinline__ void s_tiles(const float* sOwn, const float4* pb4, int x, int kq, f32x4* acc) {
+  float4 fb[NG];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) fb[t] = pb4[4 * t];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kFDP + 4 * kq);
+    float4 fa[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) fa[t] = pa4[4 * t];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      NNCF_MFMA4(fa[t], fb[t], acc0, acc1);
+    }
+    acc[mt] = acc0 + acc1;
+  }
+}
+
+template <int LOSS, bool GROUP, bool NU, bool NV, bool USIDE, int MT>
+__device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __restrict__ uid,
+                                          const int32_t* __restrict__ cid, const FusedArgs& f, const PlanView& pu,
+                                          const PlanView& pv, int blk, int update, float* smem) {
+  constexpr int OWN = 16 * MT;
+  constexpr int RPG = (OWN + 31) / 32;      // own rows per 16-lane group
+  float* sOwn = smem;                       // [OWN][kFDP]
+  float* sOpp = sOwn + OWN * kFDP;          // [128][kFDP]
+  float* sG = sOpp + kFNB * kFDP;           // [OWN][kFGP]
+  float* sCnt = sG + OWN * kFGP;            // [OWN]
+  float* sRowReg = sCnt + OWN;              // [OWN]
+  float* sRed = sRowReg + OWN;              // [8]
+  int* sOppKey = reinterpret_cast<int*>(sRed + 8);  // [128]
+  int* sKeys = sOppKey + kFNB;              // [kFKeys MT]
+  int* sKeyStart = sKeys + kFKeys * MT;     // [OWN]
+  int* sKeyCnt = sKeyStart + OWN;           // [OWN]
+  int* sTop = sKeyCnt + OWN;                // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid >> 4, q = tid & 15;
+  const int b = a.b, d = a.d, d4 = d >> 2;
+  const int NP = (d + 15) & ~15;
+  const int n_items = GROUP ? pv.counts[0] : b;
+  const int n_opp = USIDE ? n_items : b;
+  const PlanView& po = USIDE ? pu : pv;
+  const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
+
+  if (tid == 0) sTop[0] = 0;
+  auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
+  auto opp_key = [&](int j) -> int { return USIDE ? (GROUP ? j : pu.inverse[j]) : pv.inverse[j]; };
+  const int nst = (n_opp + kFNB - 1) / kFNB;
+  int idA[4], keyA[4], idB[4], keyB[4];
+  auto load_ids = [&](int st, int* ids, int* keys) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = st * kFNB + g + 32 * e;
+      const bool ok = st < nst && j < n_opp;
+      ids[e] = ok ? opp_id(j) : -1;
+      keys[e] = ok ? opp_key(j) : -1;
+    }
+  };
+  load_ids(0, idA, keyA);
+  load_ids(1, idB, keyB);
+  __syncthreads();
+
+  Row rcur[4], rnext[4];
+  int kcur[4];
+  auto load_rows = [&](const int* ids, Row* rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      rows[e] = (ids[e] >= 0) ? row_load(USIDE ? a.V : a.U, ids[e], a.stride, d4, q) : row_zero();
+  };
+  load_rows(idA, rcur);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    kcur[e] = keyA[e];
+    idA[e] = idB[e];
+    keyA[e] = keyB[e];
+  }
+  load_ids(2, idB, keyB);
+
+  // ---- own rows: 16 MT unique ids of this side; only LDS keeps them across the stages (the finalize re-reads
+  // the raw row: nobody else writes it) ------------------------------------------------------------------------
+  auto own_desc = [&](int o, int& id, float& c, int& key0, int& cnt, int& start) -> bool {
+    const int s_own = blk * OWN + o;
+    id = -1;
+    c = 0.f;
+    key0 = 0;
+    cnt = 1;
+    start = 0;
+    if (o >= OWN || s_own >= n_own) return false;
+    if (GROUP && !USIDE) {
+      id = pv.uniq[s_own];
+      key0 = s_own;
+      c = 1.f;
+    } else {
+      const int4 ds = reinterpret_cast<const int4*>(po.desc)[s_own];
+      id = ds.x;
+      c = (float)ds.w;
+      start = ds.z;
+      if (GROUP && USIDE) cnt = ds.w;
+      else key0 = po.inverse[ds.y];
+    }
+    return true;
+  };
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    const int o = g + 32 * rr;
+    if (o < OWN) {
+      int id, key0, cnt, start;
+      float c;
+      const bool ok = own_desc(o, id, c, key0, cnt, start);
+      Row hat = row_zero();
+      float ss = 0.f;
+      int kstart = 0, kcnt = 0;
+      if (ok) {
+        const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
+        ss = row16_sum(row_dot_partial(raw, raw));
+        hat = (USIDE ? NU : NV) ? row_scale(raw, inv_norm(ss)) : raw;
+        kcnt = cnt;
+        if (q == 0) {
+          kstart = atomicAdd(&sTop[0], cnt);
+          if (kstart + cnt > kFKeys * MT) kcnt = -cnt;
+        }
+        kstart = __shfl(kstart, lane & 48);
+        kcnt = __shfl(kcnt, lane & 48);
+        if (kcnt > 0) {
+          if (GROUP && USIDE) {
+            for (int t = q; t < cnt; t += 16) sKeys[kstart + t] = pv.inverse[pu.order[start + t]];
+          } else if (q == 0) {
+            sKeys[kstart] = key0;
+          }
+        } else {
+          kstart = start;
+        }
+      }
+      lds_store_row_f(sOwn + o * kFDP, q, hat);
+      if (q == 0) {
+        sCnt[o] = c;
+        sRowReg[o] = c * ss;
+        sKeyStart[o] = kstart;
+        sKeyCnt[o] = kcnt;
+      }
+    }
+  }
+  __syncthreads();
+  const int x = lane & 15, kq = lane >> 4;
+  float cnt_r[MT][4];
+  int ks_r[MT][4], kc_r[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * mt + 4 * kq + r;
+      cnt_r[mt][r] = sCnt[i];
+      ks_r[mt][r] = sKeyStart[i];
+      kc_r[mt][r] = sKeyCnt[i];
+      if (!(GROUP && USIDE)) ks_r[mt][r] = (kc_r[mt][r] > 0) ? sKeys[ks_r[mt][r]] : -2;
+    }
+
+  const float inv_b = 1.f / (float)b;
+  const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
+  f32x4 accD0[MT], accD1[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    accD0[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accD1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float lsum = 0.f;
+  const bool back_wave = wave * 16 < NP;
+
+  int seen = 0;   // read-before-write hand-shake: see fused_body
+  for (int st = 0; st < nst; ++st) {
+    const bool last_stage = update && st == nst - 1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Row r = rcur[e];
+      if (USIDE ? NV : NU) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
+      lds_store_row_f(sOpp + (g + 32 * e) * kFDP, q, r);
+      if (q == 0) sOppKey[g + 32 * e] = kcur[e];
+    }
+    __syncthreads();
+    if (last_stage && tid == 0) readers_arrive(f);
+    load_rows(idA, rnext);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kcur[e] = keyA[e];
+      idA[e] = idB[e];
+      keyA[e] = keyB[e];
+    }
+    load_ids(st + 3, idB, keyB);
+
+    f32x4 acc[MT];
+    {
+      const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kFDP + 4 * kq);
+      const int ng = NP >> 4;
+      if (ng == 8) s_tiles<8, MT>(sOwn, pb4, x, kq, acc);
+      else if (ng == 7) s_tiles<7, MT>(sOwn, pb4, x, kq, acc);
+      else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < ng; ++t) {
+          f32x4 part[MT];
+          s_tiles<1, MT>(sOwn + 16 * t, pb4 + 4 * t, x, kq, part);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt] += part[mt];
+        }
+      }
+    }
+    {
+      const int j = 16 * wave + x;
+      const int okey = sOppKey[j];
+      const bool cvalid = st * kFNB + j < n_opp;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * kq + r;
+          const float s = acc[mt][r];
+          const float c = cnt_r[mt][r];
+          float m = 0.f;
+          if (!(GROUP && USIDE)) {
+            m = (ks_r[mt][r] == okey) ? 1.f : 0.f;
+          } else {
+            const int ks = ks_r[mt][r], kc = kc_r[mt][r];
+            if (kc >= 0) {
+              for (int t = 0; t < kc; ++t) m += (sKeys[ks + t] == okey) ? 1.f : 0.f;
+            } else {
+              for (int t = 0; t < -kc; ++t) m += (pv.inverse[pu.order[ks + t]] == okey) ? 1.f : 0.f;
+            }
+          }
+          float l, h;
+          if (LOSS == NNCF_LOSS_SKIP_GRAM) {
+            float sp, sg;
+            softplus_sigmoid(s, sp, sg);
+            l = (c - m) * wneg * sp;
+            h = (c - m) * wneg * sg;
+            if (m > 0.f) {
+              softplus_sigmoid(-s, sp, sg);
+              l += m * sp;
+              h -= m * sg;
+            }
+          } else {
+            l = (c - m) * wneg * s * s + m * (s - 1.f) * (s - 1.f);
+            h = 2.f * ((c - m) * wneg * s + m * (s - 1.f));
+          }
+          if (!cvalid || c == 0.f) {
+            l = 0.f;
+            h = 0.f;
+          }
+          sG[i * kFGP + j] = h * inv_b;
+          lsum += l;
+        }
+      }
+    }
+    __syncthreads();
+    if (last_stage && tid == 0) seen = readers_seen(f);
+    if (back_wave) {
+      const float* pbv = sOpp + (4 * kq) * kFDP + 16 * wave + x;
+#pragma unroll
+      for (int t = 0; t < kFNB / 16; ++t) {
+        const float* pr = pbv + 16 * t * kFDP;
+        const float4 v = make_float4(pr[0], pr[kFDP], pr[2 * kFDP], pr[3 * kFDP]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4 gg = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kFGP + 4 * kq)[4 * t];
+          NNCF_MFMA4(gg, v, accD0[mt], accD1[mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rcur[e] = rnext[e];
+    __syncthreads();
+  }
+
+  float* sOut = sOpp;  // [OWN][kFOP]
+  if (back_wave) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 accD = accD0[mt] + accD1[mt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sOut[(16 * mt + 4 * kq + r) * kFOP + 16 * wave + x] = accD[r];
+    }
+  }
+  if (USIDE) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) sRed[wave] = lsum;
+  }
+  __syncthreads();
+  if (USIDE && tid == 0) {
+    float reg = 0.f;
+    for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
+    const float l = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+    f.loss_part[blk] = l * inv_b + a.u_reg * reg * inv_b;
+  }
+  if (!update) return;
+  Row raw_r[RPG], grad_r[RPG];
+  int id_r[RPG];
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    const int o = g + 32 * rr;
+    int id, key0, cnt, start;
+    float c;
+    id_r[rr] = -1;
+    if (!own_desc(o, id, c, key0, cnt, start)) continue;
+    id_r[rr] = id;
+    const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
+    raw_r[rr] = raw;
+    Row acc;
+    acc.a = reinterpret_cast<const float4*>(sOut + o * kFOP)[q];
+    acc.b = reinterpret_cast<const float4*>(sOut + o * kFOP)[q + 16];
+    if (q >= d4) acc.a = zero4();
+    if (q + 16 >= d4) acc.b = zero4();
+    Row grad = acc;
+    if (USIDE ? NU : NV) {
+      const float ss = row16_sum(row_dot_partial(raw, raw));
+      const float inv = inv_norm(ss);
+      grad = norm_backward(row_scale(raw, inv), inv, ss, acc);
+    }
+    if (USIDE) grad = row_fma(2.f * a.u_reg * c * inv_b, raw, grad);
+    grad_r[rr] = grad;
+  }
+  if (USIDE || !a.gV) {   // in-place stores: wait until every strip has streamed its last opposite row
+    if (tid == 0) readers_wait(f, seen, (pu.counts[0] + OWN - 1) / OWN + (pv.counts[0] + OWN - 1) / OWN);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    if (id_r[rr] < 0) continue;
+    if (USIDE) {
+      apply_update(a, a.au, a.U, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
+    } else {
+      if (a.gV) row_store(a.gV, id_r[rr], d, d4, q, grad_r[rr]);
+      else apply_update(a, a.av, a.V, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
+    }
+  }
+}
+
+// grid = 2 gu + 1 workgroups: gu U strips, gu V strips of 16 MT unique rows, the previous step's loss
+template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
+__global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32_t* __restrict__ uid,
+                                                         const int32_t* __restrict__ cid, FusedArgs f, PlanView pu,
+                                                         PlanView pv, int update, int gu) {
+  extern __shared__ __attribute__((aligned(16))) float fused_smem[];
+  const int id = blockIdx.x;
+  if (id == 2 * gu) {
+    if (threadIdx.x < 64 && f.prev_out) {
+      float l = 0.f;
+      for (int i = threadIdx.x; i < f.prev_n; i += 64) l += f.prev_part[i];
+      l = wave_sum(l);
+      if (threadIdx.x == 0) *f.prev_out = l;
+    }
+    if (threadIdx.x == 0) f.done[f.parity ^ 1] = 0;
+    return;
+  }
+  const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
+  // U and V strips alternate: both kinds spread over the XCDs alike
+  const int strip = id >> 1;
+  if (!(id & 1)) {
+    if (strip * 16 * MT >= nseg_u) {
+      if (threadIdx.x == 0) f.loss_part[strip] = 0.f;
+      return;
+    }
+    wide_body<LOSS, GROUP, NU, NV, true, MT>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+  } else {
+    if (!update || strip * 16 * MT >= nseg_v) return;
+    wide_body<LOSS, GROUP, NU, NV, false, MT>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+  }
+}
+
 __global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
   float l = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) l += part[i];
@@ -594,9 +1014,48 @@ __global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __res
 
 namespace {
 
+// workgroups of `kern` (512 threads, `lds` bytes) the device holds at once; cached by the caller
+int resident_capacity(const void* kern, size_t lds, int* cached) {
+  if (*cached >= 0) return NNCF_OK;
+  int per_cu = 0, dev = 0, cus = 0;
+  NNCF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));
+  NNCF_HIP_CHECK(hipGetDevice(&dev));
+  NNCF_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  *cached = per_cu * cus;
+  return NNCF_OK;
+}
+
+template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
+int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
+             const PlanView& pv, int update, hipStream_t stream) {
+  const int gu = (a.b + 16 * MT - 1) / (16 * MT);
+  auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)wide_lds_bytes<MT>()));
+    attr_set = true;
+  }
+  static int capacity = -1;
+  if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), &capacity)) return rc;
+  if (update && 2 * gu > capacity)
+    return fail(NNCF_ERR_INVALID, "one-launch step: %d workgroups must be resident at once, the device holds %d "
+                "(batch_size_p = %d, %d row tiles per workgroup)", 2 * gu, capacity, a.b, MT);
+  const FusedArgs& fa = f;
+  {
+    ProfScope _ps("fused_wide_kernel", stream);
+    hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), wide_lds_bytes<MT>(), stream, a, uid, cid, fa, pu, pv, update, gu);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
 template <int LOSS, bool GROUP, bool NU, bool NV>
 int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream) {
+  const int mt = fused_row_tiles(a);
+  if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2>(a, uid, cid, f, pu, pv, update, stream);
   const int gu = (a.b + kFM - 1) / kFM;
   const int nblk = ((2 * gu + 7) / 8) * 8 * f.split;
   auto kern = fused_strip_kernel<LOSS, GROUP, NU, NV>;
@@ -606,9 +1065,15 @@ int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
                                        (int)fused_lds_bytes()));
     attr_set = true;
   }
+  static int capacity = -1;
+  if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), fused_lds_bytes(), &capacity)) return rc;
+  if (update && nblk > capacity)
+    return fail(NNCF_ERR_INVALID, "one-launch step: %d workgroups must be resident at once, the device holds %d "
+                "(batch_size_p = %d)", nblk, capacity, a.b);
+  const FusedArgs& fa = f;
   {
     ProfScope _ps("fused_strip_kernel", stream);
-    hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, f, pu, pv, update, gu, nblk);
+    hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, fa, pu, pv, update, gu, nblk);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -632,6 +1097,23 @@ bool fused_eligible(const StepArgs& a) {
 }
 
 int fused_max_blocks(int b) { return (b + kFM - 1) / kFM; }
+
+// row tiles per workgroup: 1 (16-row strips, split over workgroups) below 4096; then as many as leave >= 256
+// workgroups (b = 4096: 2, b >= 8192: 4).  NNCF_FUSED_MT = 1 | 2 | 4 overrides (measurement).
+int fused_row_tiles(const StepArgs& a) {
+  if (a.bn_z) return 1;
+  const char* e = getenv("NNCF_FUSED_MT");   // read per launch: the tests switch it between engines
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return a.b >= 8192 ? 4 : a.b >= 4096 ? 2 : 1;
+}
+
+// loss partials one launch writes
+int fused_loss_parts(const StepArgs& a) {
+  const int mt = fused_row_tiles(a);
+  if (mt > 1) return (a.b + 16 * mt - 1) / (16 * mt);
+  return fused_max_blocks(a.b) * fused_split(a.b);
+}
 
 // workgroups per strip: enough to put ~one workgroup on every CU (b = 512: 64 strips x 4), never more than the
 // stages of the shorter side

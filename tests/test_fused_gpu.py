@@ -140,3 +140,94 @@ def test_fused_large_batch(b, d):
     with pytest.raises(ValueError):     # pairwise losses need the slab path, which stops at b = 2048
         e2 = Engine(nu, ni, d, b, 0, "log-loss", 10., 128., 1e-6, 0.05, True, False, seed=1)
         e2.step_neg_shared(e2.ids(uid), e2.ids(cid))
+
+
+@pytest.fixture
+def force_row_tiles():
+    """NNCF_FUSED_MT (read per launch by fused_row_tiles): run the large-batch kernel at test sizes"""
+    old = os.environ.get("NNCF_FUSED_MT")
+
+    def set_(mt):
+        os.environ["NNCF_FUSED_MT"] = str(mt)
+    yield set_
+    if old is None:
+        os.environ.pop("NNCF_FUSED_MT", None)
+    else:
+        os.environ["NNCF_FUSED_MT"] = old
+
+
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+@pytest.mark.parametrize("shape", [(64, 20, 50, 300), (512, 100, 700, 600), (288, 128, 3000, 90)])
+def test_wide_kernel_matches_oracle(force_row_tiles, mt, loss, scheme, shape):
+    """fused_wide_kernel (16 MT own rows per workgroup; the path of b >= 4096) forced at small sizes: ragged last
+    strips (288 = 4 x 64 + 32), ragged stages, d = 20 / 100 / 128 (generic, 7 and 8 column groups), duplicates."""
+    b, d, nu, ni = shape
+    group = scheme == "group_neg_shared"
+    force_row_tiles(mt)
+    conf, eng, orc = _mk(loss, b, d, nu, ni, "mf", "fused", seed=2)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        uid, cid = _batch(rs, b, nu, ni, group)
+        if group:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mt", [2, 4])
+def test_wide_kernel_normalised_and_key_overflow(force_row_tiles, mt):
+    """both sides L2-normalised; group scheme with one user in 300 of 512 positions (key list read from the plan
+    when it does not fit); loss-only launches leave the tables alone; epoch runner == step by step"""
+    force_row_tiles(mt)
+    b, d, nu, ni = 512, 24, 100, 400
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.05,
+                         model_choice="basic_embedding", emb_normalization=True)
+    eng = Engine(nu, ni, d, b, 0, "skip-gram", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate, True, True,
+                 seed=5, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(1)
+    uid = rs.randint(0, nu, b)
+    uid[rs.choice(b, 300, replace=False)] = 17
+    cid = np.repeat(rs.choice(ni, b // 4, replace=False), 4)
+    U0, V0 = eng.U.clone(), eng.V.clone()
+    l0 = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid), update=False).item()
+    assert torch.equal(eng.U, U0) and torch.equal(eng.V, V0)
+    want = orc.step_group_neg_shared(uid, cid)
+    got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)) and abs(l0 - want) <= 1e-5 * max(1.0, abs(want))
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=4e-6)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=2e-6)
+
+    steps = 70
+    _, e1, _ = _mk("skip-gram", 128, 40, 900, 800, "mf", "fused", seed=4)
+    _, e2, _ = _mk("skip-gram", 128, 40, 900, 800, "mf", "fused", seed=4)
+    u2, c2 = rs.randint(0, 900, steps * 128), rs.randint(0, 800, steps * 128)
+    ua, ca = e1.ids(u2), e1.ids(c2)
+    l1 = e1.epoch_neg_shared(ua, ca, steps).cpu().numpy()
+    l2 = np.array([e2.step_neg_shared(ua[t * 128:(t + 1) * 128], ca[t * 128:(t + 1) * 128]).item() for t in range(steps)])
+    assert np.array_equal(l1, l2.astype(np.float32))
+    assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V)
+
+
+@pytest.mark.parametrize("b,d", [(512, 64), (2048, 32), (4096, 32), (8192, 16)])
+def test_fused_rows_are_read_before_any_is_stepped(b, d):
+    """The one-launch step updates table rows IN PLACE while other workgroups of the same launch stream the same
+    tables; a strip may only store after every strip has finished reading (FusedArgs::done).  A large SGD rate makes
+    a row read after its update visible far above the tolerance; three steps so that launch parity alternates."""
+    nu, ni = b // 2, b // 2          # every row is read by many strips and owned by one
+    conf, eng, orc = _mk("mse", b, d, nu, ni, "mf", "fused", seed=11, lr=4.0, u_reg=0.)
+    rs = np.random.RandomState(5)
+    for step in range(3):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
