@@ -102,4 +102,16 @@ __device__ __forceinline__ void softplus_sigmoid(float z, float& sp, float& sg) 
   sg = z >= 0.f ? r : e * r;
 }
 
+// both signs from the same exponential: softplus(z), sigmoid(z), softplus(-z), sigmoid(-z)
+__device__ __forceinline__ void softplus_sigmoid_both(float z, float& sp, float& sg, float& spn, float& sgn) {
+  const float e = __expf(-fabsf(z));
+  const float u = 1.f + e;
+  const float r = __builtin_amdgcn_rcpf(u);
+  const float lg = __logf(u);
+  sp = fmaxf(z, 0.f) + lg;
+  spn = fmaxf(-z, 0.f) + lg;
+  sg = z >= 0.f ? r : e * r;
+  sgn = z >= 0.f ? e * r : r;
+}
+
 }  // namespace nncf

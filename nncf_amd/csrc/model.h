@@ -19,6 +19,7 @@ struct PlanView {
   int32_t* desc = nullptr;       // 4 ints per segment: {id, first position, start in order[], count}
   int32_t* slot_seg = nullptr;   // segment index of every sorted slot
   int32_t* chunk_start = nullptr;  // sorted-slot ranges of whole segments, ~kChunkSlots slots each
+  int32_t* aux = nullptr;        // lists above 8192 entries only: per-position scratch that no longer fits LDS
   int64_t list_stride = 0;
 
   __host__ __device__ int64_t chunk_stride() const { return list_stride / 16 + 2; }
@@ -33,6 +34,7 @@ struct PlanView {
     v.desc += L * list_stride * 4;
     v.slot_seg += L * list_stride;
     v.chunk_start += L * chunk_stride();
+    if (v.aux) v.aux += L * list_stride;
     return v;
   }
 };

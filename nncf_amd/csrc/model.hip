@@ -97,6 +97,7 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
   f.slab = m->fslab;
   f.cnt = m->fcnt;
   f.done = m->fdone;
+  f.stage = m->fstage;   // used only when the launcher finds the grid too large for the device
   f.parity = m->fparity;
   f.loss_part = m->fpart + (size_t)m->fparity * mb;
   f.dbg = m->sws.dbg;   // NNCF_DEBUG_TIMING=1: [2 mb + 1][32] stamps fit the tile kernel's [nb*nb][8] buffer for b >= 128
@@ -153,6 +154,7 @@ void carve(nncf_model* m, Carver& c) {
     m->fslab = c.take<float>(sp > 1 ? 2 * mb * sp * 16 * 128 : 4);
     m->fcnt = c.take<int>(2 * mb);
     m->fdone = c.take<int>(2);
+    m->fstage = c.take<float>(2 * (size_t)b * 128);
   }
   m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
@@ -166,6 +168,7 @@ void carve(nncf_model* m, Carver& c) {
     v.desc = c.take<int32_t>(kPlanChunk * cap * 4);
     v.slot_seg = c.take<int32_t>(kPlanChunk * cap);
     v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
+    v.aux = cap > 8192 ? c.take<int32_t>(kPlanChunk * cap) : nullptr;
   };
   plan(m->plan_u, m->cap_u);
   plan(m->plan_v, m->cap_v);
@@ -210,8 +213,8 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   NNCF_REQUIRE(cfg->row_stride >= cfg->dim && cfg->row_stride % 4 == 0, "row_stride = %d must be >= dim and a multiple of 4",
                cfg->row_stride);
   NNCF_REQUIRE(cfg->loss >= 0 && cfg->loss <= 3, "[ERROR!] loss %d not specified.", cfg->loss);
-  NNCF_REQUIRE((int64_t)cfg->batch_size_p * (1 + cfg->num_negatives) <= 8192,
-               "batch_size_p * (1 + num_negatives) = %lld exceeds the per-step plan capacity 8192",
+  NNCF_REQUIRE((int64_t)cfg->batch_size_p * (1 + cfg->num_negatives) <= 16384,
+               "batch_size_p * (1 + num_negatives) = %lld exceeds the per-step plan capacity 16384",
                (long long)cfg->batch_size_p * (1 + cfg->num_negatives));
   NNCF_REQUIRE(cfg->user_count > 0 && cfg->item_count > 0, "empty table");
   NNCF_REQUIRE(((uintptr_t)d_user_table & 15) == 0 && ((uintptr_t)d_item_table & 15) == 0, "tables must be 16-byte aligned");

@@ -32,10 +32,14 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
                                           const int32_t* __restrict__ ids_b, int64_t stride_b, int nb,
                                           const PlanView& out, int64_t L) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // up to 8192 entries everything lives in LDS (16 B per entry); above, only the sort keys do (8 B per entry,
+  // 128 KiB at 16384) and the two per-entry int arrays are global: `seg` IS the slot_seg output, `aux` is
+  // PlanView::aux.  A workgroup reads back its own global writes after a barrier (same CU, same L1).
+  constexpr bool BIG = CAP > 8192;
   unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);   // CAP
-  int* seg = reinterpret_cast<int*>(key + CAP);                           // CAP: segment of sorted slot
-  int* aux = seg + CAP;                                                   // CAP: first-occurrence flags / ranks
-  int* scratch = aux + CAP;                                               // NT
+  int* seg = BIG ? out.slot_seg + L * out.list_stride : reinterpret_cast<int*>(key + CAP);   // CAP: segment of sorted slot
+  int* aux = BIG ? out.aux + L * out.list_stride : seg + CAP;                                  // CAP: first-occurrence flags / ranks
+  int* scratch = BIG ? reinterpret_cast<int*>(key + CAP) : aux + CAP;                          // NT
   const int tid = threadIdx.x;
   const int n = na + nb;
   ids_a += L * stride_a;
@@ -258,8 +262,22 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
       hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
                        ids_b, stride_b, nb, out);
     }
+  } else if (n <= 16384 && out.aux) {
+    constexpr int CAP = 16384, NT = 1024;
+    const size_t lds = CAP * 8 + NT * 4;  // keys only: 132 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    {
+      ProfScope _ps("plan_kernel", stream);
+      hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+                       ids_b, stride_b, nb, out);
+    }
   } else {
-    return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the in-LDS plan capacity (8192)", n);
+    return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (16384 with a scratch array, 8192 without)", n);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

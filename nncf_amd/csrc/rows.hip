@@ -205,6 +205,7 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     v.desc = c.take<int32_t>(kPlanChunk * cap * 4);
     v.slot_seg = c.take<int32_t>(kPlanChunk * cap);
     v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
+    v.aux = cap > 8192 ? c.take<int32_t>(kPlanChunk * cap) : nullptr;
   };
   plan(h->plan_id, h->b);
   plan(h->plan_own, n);
@@ -220,7 +221,7 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t row_stride, in
   NNCF_REQUIRE(n_ranks >= 1 && item_shard > 0 && item_offset >= 0, "bad shard shape");
   NNCF_REQUIRE(row_stride >= m->cfg.dim && row_stride % 4 == 0, "bad row stride");
   NNCF_REQUIRE(m->cfg.batch_size_p % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
-  NNCF_REQUIRE((int64_t)n_ranks * m->cfg.batch_size_p <= 8192, "n_ranks * batch_size_p = %lld exceeds the scatter plan capacity 8192",
+  NNCF_REQUIRE((int64_t)n_ranks * m->cfg.batch_size_p <= 16384, "n_ranks * batch_size_p = %lld exceeds the scatter plan capacity 16384",
                (long long)n_ranks * m->cfg.batch_size_p);
   NNCF_REQUIRE(m->cfg.item_count >= (int64_t)n_ranks * m->cfg.batch_size_p, "the model's item table must hold n_ranks * batch_size_p landing rows");
   nncf_shard* h = new (std::nothrow) nncf_shard();

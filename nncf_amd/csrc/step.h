@@ -245,6 +245,7 @@ struct nncf_model {
   float* fpart = nullptr;     // [2][fused_max_blocks(b) * fused_split(b)]
   float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips
   int* fcnt = nullptr;        // [2 strips per side] arrival tickets (zero between launches)
+  float* fstage = nullptr;    // [2][b][128] staged gradient rows of a deferred step (FusedArgs::stage)
   int* fdone = nullptr;       // [2] strips that finished reading, by launch parity (FusedArgs::done)
   int fparity = 0;
   float* pend_out = nullptr;

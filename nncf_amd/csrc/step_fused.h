@@ -33,6 +33,10 @@ struct FusedArgs {
   // launcher checks the grid against the device's capacity.
   int* done = nullptr;
   int parity = 0;
+  // set by the launcher when the grid does NOT fit the device at once: no hand-shake -- the gradient rows
+  // (normalisation backward and regulariser included) go to stage[side][own slot][128] and
+  // fused_commit_kernel, a second launch, steps the tables
+  float* stage = nullptr;
   long long* dbg = nullptr;   // developer timing: [workgroup][32] s_memtime stamps (NNCF_DEBUG_TIMING=1)
 };
 

@@ -536,7 +536,8 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
     if (USIDE ? NU : NV) grad = norm_backward(own_hat, own_inv, own_ss, acc);
     if (USIDE) grad = row_fma(2.f * a.u_reg * own_c * inv_b, own_raw, grad);
   }
-  if (update && (USIDE || !a.gV)) {   // the rows stepped below are streamed by the other pass of every strip
+  const bool deferred = f.stage != nullptr;
+  if (update && (USIDE || !a.gV) && !deferred) {   // the rows stepped below are streamed by the other pass of every strip
     if (tid == 0) {
       const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
       const int nst_u = ((GROUP ? nseg_v : b) + kFNB - 1) / kFNB, nst_v = (b + kFNB - 1) / kFNB;
@@ -547,9 +548,11 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   FSTAMP(24);
   if (update && own_ok) {
     if (USIDE) {
-      apply_update(a, a.au, a.U, own_id, own_raw, grad, d4, q);
+      if (deferred) row_store(f.stage, s_own, 128, d4, q, grad);
+      else apply_update(a, a.au, a.U, own_id, own_raw, grad, d4, q);
     } else {
       if (a.gV) row_store(a.gV, own_id, d, d4, q, grad);
+      else if (deferred) row_store(f.stage + (int64_t)a.b * 128, s_own, 128, d4, q, grad);
       else apply_update(a, a.av, a.V, own_id, own_raw, grad, d4, q);
       if (bn_on && a.bn_part) {
         bn_tail_acc4(own_raw.a, grad.a, own_z.a, bmu.a, binv.a, t1.a, t2.a);
@@ -682,6 +685,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   const PlanView& po = USIDE ? pu : pv;
   const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
 
+  FSTAMP(0);
   if (tid == 0) sTop[0] = 0;
   auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
   auto opp_key = [&](int j) -> int { return USIDE ? (GROUP ? j : pu.inverse[j]) : pv.inverse[j]; };
@@ -795,6 +799,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
       if (!(GROUP && USIDE)) ks_r[mt][r] = (kc_r[mt][r] > 0) ? sKeys[ks_r[mt][r]] : -2;
     }
 
+  FSTAMP(3);
   const float inv_b = 1.f / (float)b;
   const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
   f32x4 accD0[MT], accD1[MT];
@@ -818,6 +823,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
     __syncthreads();
     if (last_stage && tid == 0) readers_arrive(f);
+    if (st < 4) FSTAMP(5 + 4 * st);
     load_rows(idA, rnext);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -827,33 +833,38 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
     load_ids(st + 3, idB, keyB);
 
-    f32x4 acc[MT];
+    // S tiles and dL/dS, software-pipelined: the MFMAs of tile m + 1 are issued before the element-wise work of
+    // tile m (VALU / transcendental under the matrix pipe; one basic block for the pointwise non-group case).
+    // Always 8 column groups: columns past d are zero in LDS (d = 100 issues 1/8 idle MFMAs).
     {
       const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kFDP + 4 * kq);
-      const int ng = NP >> 4;
-      if (ng == 8) s_tiles<8, MT>(sOwn, pb4, x, kq, acc);
-      else if (ng == 7) s_tiles<7, MT>(sOwn, pb4, x, kq, acc);
-      else {
+      float4 fb[8];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ng; ++t) {
-          f32x4 part[MT];
-          s_tiles<1, MT>(sOwn + 16 * t, pb4 + 4 * t, x, kq, part);
+      for (int t = 0; t < 8; ++t) fb[t] = pb4[4 * t];
+      auto s_one = [&](int mt) -> f32x4 {
+        const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kFDP + 4 * kq);
+        float4 fa[8];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] += part[mt];
+        for (int t = 0; t < 8; ++t) fa[t] = pa4[4 * t];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          NNCF_MFMA4(fa[t], fb[t], acc0, acc1);
         }
-      }
-    }
-    {
+        return acc0 + acc1;
+      };
       const int j = 16 * wave + x;
       const int okey = sOppKey[j];
       const bool cvalid = st * kFNB + j < n_opp;
+      f32x4 acc = s_one(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        f32x4 nxt = acc;
+        if (mt + 1 < MT) nxt = s_one(mt + 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * mt + 4 * kq + r;
-          const float s = acc[mt][r];
+          const float sc = acc[r];
           const float c = cnt_r[mt][r];
           float m = 0.f;
           if (!(GROUP && USIDE)) {
@@ -868,18 +879,15 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           }
           float l, h;
           if (LOSS == NNCF_LOSS_SKIP_GRAM) {
-            float sp, sg;
-            softplus_sigmoid(s, sp, sg);
-            l = (c - m) * wneg * sp;
-            h = (c - m) * wneg * sg;
-            if (m > 0.f) {
-              softplus_sigmoid(-s, sp, sg);
-              l += m * sp;
-              h -= m * sg;
-            }
+            // label -1 off the positive: softplus(s); label +1: softplus(-s); one exponential for both, no branch
+            // (objectives.py:99-112)
+            float sp, sg, spn, sgn;
+            softplus_sigmoid_both(sc, sp, sg, spn, sgn);
+            l = (c - m) * wneg * sp + m * spn;
+            h = (c - m) * wneg * sg - m * sgn;
           } else {
-            l = (c - m) * wneg * s * s + m * (s - 1.f) * (s - 1.f);
-            h = 2.f * ((c - m) * wneg * s + m * (s - 1.f));
+            l = (c - m) * wneg * sc * sc + m * (sc - 1.f) * (sc - 1.f);
+            h = 2.f * ((c - m) * wneg * sc + m * (sc - 1.f));
           }
           if (!cvalid || c == 0.f) {
             l = 0.f;
@@ -888,10 +896,20 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           sG[i * kFGP + j] = h * inv_b;
           lsum += l;
         }
+        if (mt + 1 < MT && !(GROUP && USIDE)) {
+#pragma unroll
+          for (int t = 0; t < 32; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the previous tile's dL/dS
+          }
+        }
+        acc = nxt;
       }
     }
+    if (st < 4) FSTAMP(6 + 4 * st);
     __syncthreads();
     if (last_stage && tid == 0) seen = readers_seen(f);
+    if (st < 4) FSTAMP(7 + 4 * st);
     if (back_wave) {
       const float* pbv = sOpp + (4 * kq) * kFDP + 16 * wave + x;
 #pragma unroll
@@ -907,8 +925,11 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) rcur[e] = rnext[e];
+    if (st < 4) FSTAMP(19);
     __syncthreads();
+    if (st < 4) FSTAMP(8 + 4 * st);
   }
+  FSTAMP(20);
 
   float* sOut = sOpp;  // [OWN][kFOP]
   if (back_wave) {
@@ -957,17 +978,21 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     if (USIDE) grad = row_fma(2.f * a.u_reg * c * inv_b, raw, grad);
     grad_r[rr] = grad;
   }
-  if (USIDE || !a.gV) {   // in-place stores: wait until every strip has streamed its last opposite row
+  const bool deferred = f.stage != nullptr;
+  if ((USIDE || !a.gV) && !deferred) {   // in-place stores: wait until every strip has streamed its last opposite row
     if (tid == 0) readers_wait(f, seen, (pu.counts[0] + OWN - 1) / OWN + (pv.counts[0] + OWN - 1) / OWN);
     __syncthreads();
   }
 #pragma unroll
   for (int rr = 0; rr < RPG; ++rr) {
     if (id_r[rr] < 0) continue;
+    const int s_own = blk * OWN + g + 32 * rr;
     if (USIDE) {
-      apply_update(a, a.au, a.U, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
+      if (deferred) row_store(f.stage, s_own, 128, d4, q, grad_r[rr]);
+      else apply_update(a, a.au, a.U, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
     } else {
       if (a.gV) row_store(a.gV, id_r[rr], d, d4, q, grad_r[rr]);
+      else if (deferred) row_store(f.stage + (int64_t)a.b * 128, s_own, 128, d4, q, grad_r[rr]);
       else apply_update(a, a.av, a.V, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
     }
   }
@@ -1005,6 +1030,23 @@ __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32
   }
 }
 
+// second launch of a deferred step (grid beyond the device's resident capacity): one 16-lane group per unique
+// row steps the table from the staged gradient row.  y = 0: users, y = 1: items.
+template <bool GROUP>
+__global__ void __launch_bounds__(256) fused_commit_kernel(StepArgs a, FusedArgs f, PlanView pu, PlanView pv) {
+  const int side = blockIdx.y;
+  const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int s_own = blockIdx.x * 16 + g;
+  const int d4 = a.d >> 2;
+  const PlanView& po = side ? pv : pu;
+  if (s_own >= po.counts[0]) return;
+  const int id = (GROUP && side) ? pv.uniq[s_own] : reinterpret_cast<const int4*>(po.desc)[s_own].x;
+  float* table = side ? a.V : a.U;
+  const Row grad = row_load(f.stage + (int64_t)side * a.b * 128, s_own, 128, d4, q);
+  const Row raw = row_load(table, id, a.stride, d4, q);
+  apply_update(a, side ? a.av : a.au, table, id, raw, grad, d4, q);
+}
+
 __global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
   float l = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) l += part[i];
@@ -1025,6 +1067,22 @@ int resident_capacity(const void* kern, size_t lds, int* cached) {
   return NNCF_OK;
 }
 
+// NNCF_FUSED_DEFER=1: stage + commit even when the grid fits (tests of the two-launch form at small sizes)
+bool force_deferred() {
+  const char* e = getenv("NNCF_FUSED_DEFER");
+  return e && e[0] == '1';
+}
+
+template <bool GROUP>
+int launch_commit(const StepArgs& a, const FusedArgs& f, const PlanView& pu, const PlanView& pv, hipStream_t stream) {
+  {
+    ProfScope _ps("fused_commit_kernel", stream);
+    hipLaunchKernelGGL(fused_commit_kernel<GROUP>, dim3((a.b + 15) / 16, a.gV ? 1 : 2), dim3(256), 0, stream, a, f, pu, pv);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
 template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
 int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream) {
@@ -1038,16 +1096,14 @@ int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   }
   static int capacity = -1;
   if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), &capacity)) return rc;
-  if (update && 2 * gu > capacity)
-    return fail(NNCF_ERR_INVALID, "one-launch step: %d workgroups must be resident at once, the device holds %d "
-                "(batch_size_p = %d, %d row tiles per workgroup)", 2 * gu, capacity, a.b, MT);
-  const FusedArgs& fa = f;
+  FusedArgs fa = f;
+  if (!(update && (2 * gu > capacity || force_deferred()))) fa.stage = nullptr;   // fits: in place, with the hand-shake
   {
     ProfScope _ps("fused_wide_kernel", stream);
     hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), wide_lds_bytes<MT>(), stream, a, uid, cid, fa, pu, pv, update, gu);
   }
   NNCF_HIP_CHECK(hipGetLastError());
-  return NNCF_OK;
+  return fa.stage ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;
 }
 
 template <int LOSS, bool GROUP, bool NU, bool NV>
@@ -1067,16 +1123,14 @@ int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   }
   static int capacity = -1;
   if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), fused_lds_bytes(), &capacity)) return rc;
-  if (update && nblk > capacity)
-    return fail(NNCF_ERR_INVALID, "one-launch step: %d workgroups must be resident at once, the device holds %d "
-                "(batch_size_p = %d)", nblk, capacity, a.b);
-  const FusedArgs& fa = f;
+  FusedArgs fa = f;
+  if (!(update && (nblk > capacity || force_deferred()))) fa.stage = nullptr;   // fits: in place, with the hand-shake
   {
     ProfScope _ps("fused_strip_kernel", stream);
     hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, fa, pu, pv, update, gu, nblk);
   }
   NNCF_HIP_CHECK(hipGetLastError());
-  return NNCF_OK;
+  return fa.stage ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;
 }
 
 template <int LOSS, bool GROUP>

@@ -72,8 +72,8 @@ class HipBackend(object):
         self.V = V.to(self.device).contiguous()
         self.lr = float(kw["learn_rate"])
         n = self.world * self.cap
-        if n > 8192:
-            raise ValueError("world * batch_size_p = %d exceeds the scatter plan capacity 8192" % n)
+        if n > 16384:
+            raise ValueError("world * batch_size_p = %d exceeds the scatter plan capacity 16384" % n)
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=self.device)  # noqa: E731
         self.req = i32(n)
         self.slot = i32(self.b)

@@ -231,3 +231,76 @@ def test_fused_rows_are_read_before_any_is_stepped(b, d):
         assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture
+def force_deferred():
+    old = os.environ.get("NNCF_FUSED_DEFER")
+    os.environ["NNCF_FUSED_DEFER"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("NNCF_FUSED_DEFER", None)
+    else:
+        os.environ["NNCF_FUSED_DEFER"] = old
+
+
+@pytest.mark.parametrize("mt", [1, 4])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+@pytest.mark.parametrize("optimizer", ["sgd", "sparse_adam"])
+def test_deferred_step_stage_and_commit(force_deferred, force_row_tiles, mt, scheme, optimizer):
+    """The two-launch form a grid beyond the device's resident capacity takes (b = 16384): gradient rows staged by
+    the strip / wide kernel, tables stepped by fused_commit_kernel -- forced here at b = 512 and compared with the
+    oracle and, bitwise, with the in-place one-launch form."""
+    force_row_tiles(mt)
+    b, d, nu, ni = 512, 36, 300, 500
+    group = scheme == "group_neg_shared"
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.05, model_choice="mf",
+                         optimizer=optimizer)
+
+    def mk():
+        e = Engine(nu, ni, d, b, 0, "skip-gram", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                   False, False, seed=3, init_scale=0.5)
+        if optimizer != "sgd":
+            e.set_optimizer(optimizer)
+        return e
+    eng = mk()
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    ref = mk()
+    rs = np.random.RandomState(3)
+    name = "step_group_neg_shared" if group else "step_neg_shared"
+    for step in range(3):
+        uid, cid = _batch(rs, b, nu, ni, group)
+        want = getattr(orc, name)(uid, cid)
+        got = getattr(eng, name)(eng.ids(uid), eng.ids(cid)).item()
+        os.environ["NNCF_FUSED_DEFER"] = "0"
+        same = getattr(ref, name)(ref.ids(uid), ref.ids(cid)).item()
+        os.environ["NNCF_FUSED_DEFER"] = "1"
+        assert got == same
+        assert torch.equal(eng.U, ref.U) and torch.equal(eng.V, ref.V)
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        # Adam divides by sqrt(v): a tiny gradient difference is amplified where v ~ g^2 (test_step_gpu.py)
+        tol = dict(rtol=2e-5, atol=1e-5) if optimizer == "sgd" else dict(rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, **tol)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, **tol)
+
+
+def test_fused_batch_16384():
+    """b = 16384 (config 4's upper per-GPU batch): the 16384-entry plan (sort keys in LDS, per-entry
+    arrays in global memory), 2 x 256 wide workgroups -- more than the device holds at once, so the step stages
+    its gradient rows and a commit launch steps the tables.  float32 oracle (a float64 one would hold 2 GB per b x b
+    temporary), large SGD rate: rows read after an update would show."""
+    b, d = 16384, 16
+    nu, ni = b // 2, b // 2
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="mse", u_reg=0., learn_rate=4.0, model_choice="mf",
+                         neg_loss_weight=8.)
+    eng = Engine(nu, ni, d, b, 0, "mse", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate, False, False,
+                 seed=11, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(5)
+    for step in range(2):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)

@@ -26,11 +26,13 @@ for s in range(4):
     names[6 + 4 * s] = "st%d S mfma" % s
     names[7 + 4 * s] = "st%d elementwise+barrier" % s
     names[8 + 4 * s] = "st%d back mfma+barrier" % s
+names[19] = "(wide) last back mfma issued"
 names[20] = "out->LDS, loss partial"
 names[23] = "slab store + release + ticket"
 names[21] = "reducer: acquire + slab sum"
 names[22] = "finalize"
-order = [0, 1, 2, 3, 4] + list(range(5, 21)) + [20, 23, 21, 22]
+names[24] = "wait for all readers"
+order = [0, 1, 2, 3, 4] + list(range(5, 21)) + [20, 23, 21, 24, 22]
 order = [k for i, k in enumerate(order) if k not in order[:i]]
 live = [i for i in range(nblk) if st[i, 0] > 0 and st[i, 20] > 0]
 t0 = min(st[i, 0] for i in live)
