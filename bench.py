@@ -69,6 +69,8 @@ def parse():
                     help="epochs of the side run that reports Recall@50 of a TRAINED model (Keras Adam, the reference's "
                          "optimiser; 30 = the demo scripts' max_epoch); 0 = skip")
     ap.add_argument("--profile-launches", type=int, default=1000)
+    ap.add_argument("--dump-stamps", default=None, help="developer: with NNCF_DEBUG_TIMING=1, save the step kernel's in-kernel "
+                                                        "cycle stamps of the last launch to this .npy (tools/fused_timing.py)")
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
     ap.add_argument("--device-links", type=float, default=0,
@@ -740,6 +742,13 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    if args.dump_stamps:
+        import ctypes
+        from nncf_amd import _lib
+        nblk = 2 * (b // 16 + 8) * 8 + 1
+        stamps = np.zeros(nblk * 32, dtype=np.int64)
+        _lib.check(eng._L.nncf_model_debug_stamps(eng._h, stamps.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), stamps.size))
+        np.save(args.dump_stamps, stamps.reshape(nblk, 32))
     mean_loss = float(losses.double().mean().item())
     if not np.isfinite(mean_loss):
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)  # utilities.py:33-35

@@ -246,7 +246,7 @@ struct nncf_model {
   float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips
   int* fcnt = nullptr;        // [2 strips per side] arrival tickets (zero between launches)
   float* fstage = nullptr;    // [2][b][128] staged gradient rows of a deferred step (FusedArgs::stage)
-  int* fdone = nullptr;       // [2] strips that finished reading, by launch parity (FusedArgs::done)
+  int* fdone = nullptr;       // [2] workgroups that finished reading, by launch parity (FusedArgs::done)
   int fparity = 0;
   float* pend_out = nullptr;
   int pend_n = 0, pend_parity = 0;

@@ -156,19 +156,61 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   if (g < kFM && s_own < b && !(GROUP && !USIDE)) own_ds = reinterpret_cast<const int4*>(po.desc)[s_own];
   __syncthreads();
   FSTAMP(1);
-  // ---- BatchNorm statistics of the item block, by every workgroup alike (text towers) ----------
+  // ---- raw rows first: stage 0 of the opposite side and this workgroup's own rows are requested before the
+  // BatchNorm statistics are known (text towers: z rows; the transform is applied once the statistics are here)
+  const float* opp_tab = USIDE ? (bn_on ? a.bn_z : a.V) : a.U;
+  const float* own_tab = USIDE ? a.U : (bn_on ? a.bn_z : a.V);
+  Row rcur[4], rnext[4];
+  int kcur[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rcur[e] = (idA[e] >= 0) ? row_load(opp_tab, idA[e], a.stride, d4, q) : row_zero();
+  int own_id = -1, own_key0 = 0, own_cnt = 1, own_start = 0;
+  float own_c = 0.f;
+  Row own_z = row_zero();   // the raw own row (an item's z row under a text tower)
+  if (own_ok) {
+    if (GROUP && !USIDE) {
+      own_id = pv.uniq[s_own];
+      own_key0 = s_own;
+      own_c = 1.f;   // a unique item is one column however often it occurs in the batch
+    } else {
+      const int4 ds = own_ds;
+      own_id = ds.x;
+      own_c = (float)ds.w;
+      own_start = ds.z;
+      if (GROUP && USIDE) own_cnt = ds.w;             // one key per position: the rank of that position's item
+      else own_key0 = po.inverse[ds.y];               // the rank of this id: positions of the other side match it
+    }
+    own_z = row_load(own_tab, own_id, a.stride, d4, q);
+  }
+  // ---- BatchNorm statistics of the item block, by every workgroup alike (text towers) ---------------------------
+  // The z rows were written by the previous launch (other XCDs' L2s): a read costs a trip to memory, ~3 k cycles --
+  // all rows of a lane are requested in ONE batch (16 per 16-lane group: up to 512 rows per pass), gamma / beta /
+  // the shift row under them.  (A single publishing workgroup + flag was tried: the publisher is no faster alone --
+  // the sum is latency-bound -- and the others then wait for its result plus ~4 k cycles of propagation: 16 k
+  // cycles against 8.7 k for everybody computing, 6 k with the batched loads.)
   Row bmul = row_zero(), badd = row_zero(), bmu = row_zero(), binv = row_zero();
   if (bn_on) {
     if (f.stats) {
       const int nv = pv.counts[0];  // the block's real rows = the batch's unique items (both schemes)
+      const bool publish = blk == 0 && part == 0 && USIDE;
+      float x0c = 0.f, gam = 0.f, bet = 0.f, rm0 = 0.f, rv0 = 0.f;
+      if (tid < 128 && tid < d) {
+        x0c = a.bn_z[tid];
+        gam = f.gamma[tid];
+        bet = f.beta[tid];
+        if (publish && update) {
+          rm0 = f.rm[tid];
+          rv0 = f.rv[tid];
+        }
+      }
       const Row x0 = row_load(a.bn_z, 0, a.stride, d4, q);
       Row s1 = row_zero(), s2 = row_zero();
-      for (int r0 = g; r0 < nv; r0 += 32 * 8) {
-        Row z[8];
+      for (int r0 = g; r0 < nv; r0 += 32 * 16) {
+        Row z[16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
+        for (int e = 0; e < 16; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {  // shifted sums (shift = row 0): no cancellation
+        for (int e = 0; e < 16; ++e) {  // shifted sums (shift = row 0): no cancellation
           const float4 da = make_float4(z[e].a.x - x0.a.x, z[e].a.y - x0.a.y, z[e].a.z - x0.a.z, z[e].a.w - x0.a.w);
           const float4 db = make_float4(z[e].b.x - x0.b.x, z[e].b.y - x0.b.y, z[e].b.z - x0.b.z, z[e].b.w - x0.b.w);
           s1.a = add4(s1.a, da);
@@ -177,6 +219,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
           s2.b = fma4v(db, db, s2.b);
         }
       }
+      FSTAMP(25);
       // 32 groups -> column totals, in group order, through the (still unused) stage buffer
       float* red = sOpp;  // [32][2][128]
       reinterpret_cast<float4*>(red + (g * 2 + 0) * 128)[q] = s1.a;
@@ -187,6 +230,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
       if (tid < 128) {
         const int c = tid;
         float t1 = 0.f, t2 = 0.f;
+#pragma unroll
         for (int gg = 0; gg < 32; ++gg) {
           t1 += red[(gg * 2 + 0) * 128 + c];
           t2 += red[(gg * 2 + 1) * 128 + c];
@@ -195,26 +239,22 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
         if (c < d) {
           const float rn = 1.f / (float)max(nv, 1);
           const float m1 = t1 * rn;
-          // x0 column c: columns [4q, 4q+4) then [64+4q, ...) -> read it back from the table (L1 hit)
-          mu = a.bn_z[c] + m1;
+          mu = x0c + m1;
           var = fmaxf(t2 * rn - m1 * m1, 0.f);
           inv = rsqrtf(var + f.eps);
-          mul = f.gamma[c] * inv;
-          add = f.beta[c] - mu * mul;
-          if (blk == 0 && part == 0 && USIDE) {  // published once: later launches (tower backward) and the running statistics
-            f.stats[c] = mu;
-            f.stats[128 + c] = inv;
-            f.stats[256 + c] = var;
-            f.stats[384 + c] = mul;
-            f.stats[512 + c] = add;
-            if (update) {
-              f.rm[c] = f.momentum * f.rm[c] + (1.f - f.momentum) * mu;
-              f.rv[c] = f.momentum * f.rv[c] + (1.f - f.momentum) * var;
-            }
+          mul = gam * inv;
+          add = bet - mu * mul;
+        }
+        if (publish) {  // once: for later launches (tower backward) and the running statistics
+          f.stats[c] = mu;
+          f.stats[128 + c] = inv;
+          f.stats[256 + c] = var;
+          f.stats[384 + c] = mul;
+          f.stats[512 + c] = add;
+          if (update && c < d) {
+            f.rm[c] = f.momentum * rm0 + (1.f - f.momentum) * mu;
+            f.rv[c] = f.momentum * rv0 + (1.f - f.momentum) * var;
           }
-        } else if (blk == 0 && part == 0 && USIDE) {
-          f.stats[384 + c] = 0.f;
-          f.stats[512 + c] = 0.f;
         }
         sStat[c] = mu;
         sStat[128 + c] = inv;
@@ -222,6 +262,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
         sStat[512 + c] = add;
       }
       __syncthreads();
+      FSTAMP(26);
       bmu = row_load(sStat, 0, 128, 32, q);
       binv = row_load(sStat + 128, 0, 128, 32, q);
       bmul = row_load(sStat + 384, 0, 128, 32, q);
@@ -234,27 +275,30 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
       badd = row_load(a.bn_stats + 512, 0, 128, 32, q);
     }
   }
-  auto item_load = [&](int64_t id, Row& zrow) -> Row {  // raw item row (after BatchNorm + ReLU for a text tower)
-    if (!bn_on) return row_load(a.V, id, a.stride, d4, q);
-    zrow = row_load(a.bn_z, id, a.stride, d4, q);
+  auto bn_apply = [&](const Row& z) -> Row {   // item row of a text tower: relu(z mul + add), zero past d
     Row r;
-    r.a = bn_relu4(zrow.a, bmul.a, badd.a);
-    r.b = bn_relu4(zrow.b, bmul.b, badd.b);
+    r.a = bn_relu4(z.a, bmul.a, badd.a);
+    r.b = bn_relu4(z.b, bmul.b, badd.b);
     if (q >= d4) r.a = zero4();
     if (q + 16 >= d4) r.b = zero4();
     return r;
   };
-
-  Row rcur[4], rnext[4];
-  int kcur[4];
   auto load_rows = [&](const int* ids, Row* rows) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      Row zz;
-      rows[e] = (ids[e] >= 0) ? (USIDE ? item_load(ids[e], zz) : row_load(a.U, ids[e], a.stride, d4, q)) : row_zero();
+      Row r = row_zero();
+      if (ids[e] >= 0) {
+        r = row_load(opp_tab, ids[e], a.stride, d4, q);
+        if (USIDE && bn_on) r = bn_apply(r);
+      }
+      rows[e] = r;
     }
   };
-  load_rows(idA, rcur);
+  if (USIDE && bn_on) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (idA[e] >= 0) rcur[e] = bn_apply(rcur[e]);
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     kcur[e] = keyA[e];
@@ -264,26 +308,13 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   load_ids(part + 2 * P, idB, keyB);
   FSTAMP(2);
   // ---- own rows: 16 unique ids of this side ---------------------------------------------------
-  int own_id = -1;
-  float own_c = 0.f, own_ss = 0.f, own_inv = 1.f;
-  Row own_raw = row_zero(), own_hat = row_zero(), own_z = row_zero();
+  float own_ss = 0.f, own_inv = 1.f;
+  Row own_raw = row_zero(), own_hat = row_zero();
   if (g < kFM) {
     int kstart = 0, kcnt = 0;
     if (own_ok) {
-      int key0 = 0, cnt = 1, start = 0;
-      if (GROUP && !USIDE) {
-        own_id = pv.uniq[s_own];
-        key0 = s_own;
-        own_c = 1.f;   // a unique item is one column however often it occurs in the batch
-      } else {
-        const int4 ds = own_ds;
-        own_id = ds.x;
-        own_c = (float)ds.w;
-        start = ds.z;
-        if (GROUP && USIDE) cnt = ds.w;                 // one key per position: the rank of that position's item
-        else key0 = po.inverse[ds.y];                   // the rank of this id: positions of the other side match it
-      }
-      own_raw = USIDE ? row_load(a.U, own_id, a.stride, d4, q) : item_load(own_id, own_z);
+      const int key0 = own_key0, cnt = own_cnt, start = own_start;
+      own_raw = (!USIDE && bn_on) ? bn_apply(own_z) : own_z;
       own_ss = row16_sum(row_dot_partial(own_raw, own_raw));
       own_hat = own_raw;
       if (USIDE ? NU : NV) {
