@@ -42,6 +42,11 @@ struct PlanView {
 int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb,
                 const PlanView& out, int64_t n_lists, hipStream_t stream);
 
+// both lists of `n_lists` steps in one launch; uniq_global != NULL: the item plan is localised (text towers)
+int launch_plan_steps(const int32_t* uid, int64_t stride_u, int nu, const PlanView& pu, const int32_t* ids_a, int64_t stride_a,
+                      int na, const int32_t* ids_b, int64_t stride_b, int nb, const PlanView& pv, int32_t* uniq_global,
+                      int64_t uniq_stride, int32_t* n_u_out, int64_t n_lists, hipStream_t stream, int32_t* n_u_copy = nullptr);
+
 int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,
                      const PlanView& out1, hipStream_t stream);
 // n_lists plans at pl.at(0..): uniq_global + L*uniq_stride, n_u_out[L]

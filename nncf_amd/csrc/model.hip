@@ -190,11 +190,11 @@ int check_shared(const nncf_model* m) {
 int plan_chunk(nncf_model* m, int scheme, const int32_t* uid_all, const int32_t* cid_all, const int32_t* neg,
                int64_t t0, int64_t cnt, hipStream_t stream) {
   const int b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
-  int rc = launch_plan(uid_all + t0 * b, b, b, nullptr, 0, 0, m->plan_u, cnt, stream);
-  if (rc) return rc;
-  PlanView pv = m->plan_v;
-  if (scheme == 0) return launch_plan(cid_all + t0 * b, b, b, neg + t0 * b * k, (int64_t)b * k, b * k, pv, cnt, stream);
-  return launch_plan(cid_all + t0 * b, b, b, nullptr, 0, 0, pv, cnt, stream);
+  if (scheme == 0)
+    return launch_plan_steps(uid_all + t0 * b, b, b, m->plan_u, cid_all + t0 * b, b, b, neg + t0 * b * k, (int64_t)b * k, b * k,
+                             m->plan_v, nullptr, 0, nullptr, cnt, stream);
+  return launch_plan_steps(uid_all + t0 * b, b, b, m->plan_u, cid_all + t0 * b, b, b, nullptr, 0, 0, m->plan_v, nullptr, 0, nullptr,
+                           cnt, stream);
 }
 
 }  // namespace
@@ -399,9 +399,8 @@ int nncf_epoch_rowwise(nncf_model* m, const int32_t* d_uid_all, const int32_t* d
   hipStream_t st = as_stream(stream);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
-    int rc = launch_plan(d_uid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_u, cnt, st);
-    if (rc) return rc;
-    rc = launch_plan(d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v, cnt, st);
+    int rc = launch_plan_steps(d_uid_all + t0 * n, n, (int)n, m->plan_u, d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v,
+                               nullptr, 0, nullptr, cnt, st);
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t t = t0 + i;

@@ -192,19 +192,45 @@ __global__ void __launch_bounds__(NT) plan_pair_kernel(const int32_t* __restrict
 // Re-express a plan of GLOBAL ids in LOCAL ids = tf.unique ranks (the item block of a text tower
 // or of fetched rows is indexed by rank): desc[s].id = rank, uniq[j] = j; the global ids of the
 // ranks are copied out first.  One workgroup.
-__global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl0, int n, int32_t* __restrict__ uniq_global,
-                                                            int64_t uniq_stride, int32_t* __restrict__ n_u_out) {
-  const PlanView pl = pl0.at(blockIdx.x);
-  uniq_global += blockIdx.x * uniq_stride;
+__device__ __forceinline__ void plan_localize_body(const PlanView& pl, int n, int32_t* __restrict__ uniq_global,
+                                                   int32_t* __restrict__ n_u_out) {
   const int nseg = pl.counts[0];
   int4* desc = reinterpret_cast<int4*>(pl.desc);
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     uniq_global[j] = (j < nseg) ? pl.uniq[j] : 0;  // padding ranks point at row 0 (masked by the caller)
   }
   for (int s = threadIdx.x; s < nseg; s += blockDim.x) desc[s].x = pl.inverse[desc[s].y];
-  if (threadIdx.x == 0 && n_u_out) n_u_out[blockIdx.x] = nseg;
+  if (threadIdx.x == 0 && n_u_out) *n_u_out = nseg;
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += blockDim.x) pl.uniq[j] = j;
+}
+
+__global__ void __launch_bounds__(256) plan_localize_kernel(PlanView pl0, int n, int32_t* __restrict__ uniq_global,
+                                                            int64_t uniq_stride, int32_t* __restrict__ n_u_out) {
+  plan_localize_body(pl0.at(blockIdx.x), n, uniq_global + blockIdx.x * uniq_stride, n_u_out ? n_u_out + blockIdx.x : nullptr);
+}
+
+// A chunk of steps in ONE launch: grid (steps, 2) -- y = 0 plans the step's user list, y = 1 its item list
+// (+ negatives) and, for a text tower, re-expresses it in tf.unique ranks straight away (the same workgroup reads
+// back what it wrote).  Three dependent ~17 us launches per chunk become one: 1 us per step at the driver's 20-step
+// bench call.
+template <int CAP, int NT>
+__global__ void __launch_bounds__(NT) plan_steps_kernel(const int32_t* __restrict__ uid, int64_t stride_u, int nu, PlanView pu,
+                                                        const int32_t* __restrict__ ids_a, int64_t stride_a, int na,
+                                                        const int32_t* __restrict__ ids_b, int64_t stride_b, int nb, PlanView pv,
+                                                        int32_t* __restrict__ uniq_global, int64_t uniq_stride,
+                                                        int32_t* __restrict__ n_u_out, int32_t* __restrict__ n_u_copy) {
+  const int64_t L = blockIdx.x;
+  if (blockIdx.y == 0) {
+    plan_body<CAP, NT>(uid, stride_u, nu, nullptr, 0, 0, pu, L);
+    return;
+  }
+  plan_body<CAP, NT>(ids_a, stride_a, na, ids_b, stride_b, nb, pv, L);
+  if (uniq_global) {
+    __syncthreads();
+    plan_localize_body(pv.at(L), na + nb, uniq_global + L * uniq_stride, n_u_out ? n_u_out + L : nullptr);
+    if (threadIdx.x == 0 && n_u_copy) n_u_copy[L] = pv.at(L).counts[0];   // the caller's per-step unique-item counts
+  }
 }
 
 int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_t* n_u_out, hipStream_t stream,
@@ -217,6 +243,43 @@ int launch_plan_localize(const PlanView& pl, int n, int32_t* uniq_global, int32_
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
+}
+
+template <int CAP, int NT>
+static int launch_plan_steps_t(size_t lds, const int32_t* uid, int64_t stride_u, int nu, const PlanView& pu, const int32_t* ids_a,
+                               int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb, const PlanView& pv,
+                               int32_t* uniq_global, int64_t uniq_stride, int32_t* n_u_out, int32_t* n_u_copy, int64_t n_lists,
+                               hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_steps_kernel<CAP, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  {
+    ProfScope _ps("plan_kernel", stream);
+    hipLaunchKernelGGL((plan_steps_kernel<CAP, NT>), dim3((unsigned)n_lists, 2), dim3(NT), lds, stream, uid, stride_u, nu, pu,
+                       ids_a, stride_a, na, ids_b, stride_b, nb, pv, uniq_global, uniq_stride, n_u_out, n_u_copy);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int launch_plan_steps(const int32_t* uid, int64_t stride_u, int nu, const PlanView& pu, const int32_t* ids_a, int64_t stride_a,
+                      int na, const int32_t* ids_b, int64_t stride_b, int nb, const PlanView& pv, int32_t* uniq_global,
+                      int64_t uniq_stride, int32_t* n_u_out, int64_t n_lists, hipStream_t stream, int32_t* n_u_copy) {
+  const int n = nu > na + nb ? nu : na + nb;
+  if (n_lists <= 0 || n <= 0) return NNCF_OK;
+  if (n <= 1024)
+    return launch_plan_steps_t<1024, 256>(1024 * 8 + 1024 * 4 * 2 + 256 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
+                                          stride_b, nb, pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
+  if (n <= 8192)
+    return launch_plan_steps_t<8192, 1024>(8192 * 8 + 8192 * 4 * 2 + 1024 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
+                                           stride_b, nb, pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
+  if (n <= 16384 && pu.aux && pv.aux)
+    return launch_plan_steps_t<16384, 1024>(16384 * 8 + 1024 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b, stride_b, nb,
+                                            pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
+  return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (16384 with a scratch array, 8192 without)", n);
 }
 
 int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,

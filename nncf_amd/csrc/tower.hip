@@ -1306,11 +1306,8 @@ int nncf_tower_epoch_rowwise(nncf_tower* t, nncf_model* m, const int32_t* d_uid_
   hipStream_t st = as_stream(stream);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
-    int rc = launch_plan(d_uid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_u, cnt, st);
-    if (rc) return rc;
-    rc = launch_plan(d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v, cnt, st);
-    if (rc) return rc;
-    rc = launch_plan_localize(m->plan_v, (int)n, t->uniq_g, t->n_u, st, cnt, cap);
+    int rc = launch_plan_steps(d_uid_all + t0 * n, n, (int)n, m->plan_u, d_cid_all + t0 * n, n, (int)n, nullptr, 0, 0, m->plan_v,
+                               t->uniq_g, cap, t->n_u, cnt, st);
     if (rc) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t s = t0 + i;
@@ -1331,14 +1328,14 @@ int nncf_tower_plan_steps(nncf_tower* t, nncf_model* m, int32_t scheme, const in
   NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps can be planned at once", kPlanChunk);
   NNCF_REQUIRE(scheme != 0 || d_neg, "train_scheme=original needs the presampled negatives");
   const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives;
-  const int n = (int)(scheme == 0 ? b * (1 + k) : b);
   hipStream_t st = as_stream(stream);
-  int rc = launch_plan(d_uid, b, (int)b, nullptr, 0, 0, m->plan_u, n_steps, st);
-  if (rc) return rc;
-  if (scheme == 0) rc = launch_plan(d_cid, b, (int)b, d_neg, b * k, (int)(b * k), m->plan_v, n_steps, st);
-  else rc = launch_plan(d_cid, b, (int)b, nullptr, 0, 0, m->plan_v, n_steps, st);
-  if (rc) return rc;
-  rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, n_steps, t->cfg.max_rows);
+  int rc;
+  if (scheme == 0)
+    rc = launch_plan_steps(d_uid, b, (int)b, m->plan_u, d_cid, b, (int)b, d_neg, b * k, (int)(b * k), m->plan_v, t->uniq_g,
+                           t->cfg.max_rows, t->n_u, n_steps, st);
+  else
+    rc = launch_plan_steps(d_uid, b, (int)b, m->plan_u, d_cid, b, (int)b, nullptr, 0, 0, m->plan_v, t->uniq_g, t->cfg.max_rows,
+                           t->n_u, n_steps, st);
   if (rc) return rc;
   return plan_cells(t, m, scheme, t->uniq_g, t->n_u, t->cfg.max_rows, n_steps, st);
 }
@@ -1376,14 +1373,13 @@ int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t
   hipStream_t st = as_stream(stream);
   for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
     const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
-    int rc = launch_plan(d_uid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_u, cnt, st);
-    if (rc) return rc;
+    int rc;
     if (scheme == 0)
-      rc = launch_plan(d_cid_all + t0 * b, b, (int)b, d_neg_all + t0 * b * k, b * k, (int)(b * k), m->plan_v, cnt, st);
+      rc = launch_plan_steps(d_uid_all + t0 * b, b, (int)b, m->plan_u, d_cid_all + t0 * b, b, (int)b, d_neg_all + t0 * b * k, b * k,
+                             (int)(b * k), m->plan_v, t->uniq_g, cap, t->n_u, cnt, st, d_n_u ? d_n_u + t0 : nullptr);
     else
-      rc = launch_plan(d_cid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_v, cnt, st);
-    if (rc) return rc;
-    rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st, cnt, cap);
+      rc = launch_plan_steps(d_uid_all + t0 * b, b, (int)b, m->plan_u, d_cid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_v,
+                             t->uniq_g, cap, t->n_u, cnt, st, d_n_u ? d_n_u + t0 : nullptr);
     if (rc) return rc;
     const bool wb = wordbwd_applies(t, m, scheme);
     if (wb && (rc = plan_cells(t, m, scheme, t->uniq_g, t->n_u, cap, cnt, st))) return rc;
@@ -1395,7 +1391,6 @@ int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t
                            t->n_u + i, n, d_loss + s, 1, nullptr, st, nullptr, wb ? &cvi : nullptr);
       if (rc) return rc;
     }
-    if (d_n_u) NNCF_HIP_CHECK(hipMemcpyAsync(d_n_u + t0, t->n_u, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, st));
   }
   t->fwd_cached = false;
   if (int rc = tower_sync_wd(t, st)) return rc;
