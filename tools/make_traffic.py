@@ -55,9 +55,10 @@ def all_kernel_avgs(path):
         if line.startswith("# PMC counters"):
             break
         parts = line.split()
-        if len(parts) >= 5 and parts[0].endswith("_kernel") or (len(parts) >= 5 and "_kernel" in parts[0]):
+        tok = [x for x in parts[:2] if "_kernel" in x]     # "nncf::x_kernel ..." or "void nncf::x_kernel<...> ..."
+        if len(parts) >= 5 and tok:
             try:
-                name = parts[0].split("<")[0].split("::")[-1]
+                name = tok[0].split("<")[0].split("::")[-1]
                 res[name] = {"rocprof_avg_us": float(parts[-2])}
             except ValueError:
                 pass

@@ -28,6 +28,7 @@ run_prof mf_neg_shared_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
 run_prof mf_original_kernel_trace "--stats" --model mf --scheme original --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_group_neg_shared_kernel_trace "--stats" --model mf --scheme group_neg_shared --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b8192_kernel_trace "--stats" --large --batch 8192 --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
+run_prof large_mf_b16384_kernel_trace "--stats" --large --batch 16384 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 5
 run_prof large_mf_b8192_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
 (cd /tmp && NNCF_FORCE_SHARDED=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_sh -o p -- python3 $R/bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 $B > $OUT/prof_sh.log 2>&1)
 python3 $R/tools/prof_summary.py $OUT/prof_sh/p_results.db $OUT/${TAG}_mf_sharded_world1_kernel_trace.txt; rm -rf $OUT/prof_sh
@@ -48,6 +49,9 @@ python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 $B 2>/dev/
 python3 bench.py --large --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared.json
 python3 bench.py --large --scheme original --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_original.json
 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192.json
+python3 bench.py --large --batch 4096 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b4096.json
+python3 bench.py --large --batch 16384 --steps 50 --warmup 5 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b16384.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_style_steps20.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1.json
 python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
