@@ -52,6 +52,8 @@ def parse():
                          "(configs[4]: use --scheme group_neg_shared); mf = id-table towers only")
     ap.add_argument("--conv-dropout", type=float, default=0.1, help="cnn_embedding: Dropout after the conv ('best' preset)")
     ap.add_argument("--filter-len", type=int, default=3, help="cnn_embedding: Convolution1D filter length ('best' preset)")
+    ap.add_argument("--filter-lens", default=None, help="cnn_embedding: a filter BANK, e.g. 1,3,5 with --dim 50 --conv-dropout 0.3 "
+                                                        "--dropout 0 = the reference's 'default' preset (cnn_embedding_conf.py:30-50)")
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--negatives", type=int, default=10)
@@ -91,8 +93,13 @@ def param_dict_for(args):
             "learn_rate": 0.001 if loss == "mse" else 0.01, "neg_dist": "unigram", "neg_sampling_power": 1,
             "batch_size_p": args.batch, "user_dim": args.dim, "item_dim": args.dim, "word_dim": args.dim,
             "chop_size": args.chop, "u_reg": 1e-6, "word_emb_dropout_rate": args.dropout, "interaction_bias": None,
-            "optimizer": args.optimizer, "num_filters": [args.dim], "filter_lengths": [args.filter_len],
+            "optimizer": args.optimizer, "num_filters": [args.dim],
+            "filter_lengths": [bank_lens(args)] if args.filter_lens else [args.filter_len],
             "conv_dropout_rate": args.conv_dropout}
+
+
+def bank_lens(args):
+    return [int(v) for v in args.filter_lens.split(",")] if args.filter_lens else [args.filter_len]
 
 
 def oracle_conf_for(args):
@@ -212,11 +219,17 @@ def cpu_baseline(args, inp, U0, V0, tower_params):
         return steps, time.time() - t0
 
     if args.model == "cnn_embedding":
-        tower = so.CnnTowerOracle(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
-        o = so.StepOracle(U0, None, conf, dtype=np.float32, tower=tower)
         kc = 1 - args.conv_dropout
-        if args.conv_dropout > 0:   # Dropout(conv_dropout_rate), cnn_model.py:97: one fixed mask (timing only)
-            tower.conv_mask = ((np.random.RandomState(3).rand(b * (1 + k), tower.C.shape[1], tower.Wc.shape[2]) < kc) / kc).astype(np.float32)
+        mk_mask = lambda F: ((np.random.RandomState(3).rand(b * (1 + k), inp["data"]["C"].shape[1], F) < kc) / kc).astype(np.float32)  # noqa: E731
+        if isinstance(tower_params, dict):   # a filter bank (--filter-lens): parameters at the configured widths
+            tower = so.CnnBankTowerOracle(inp["data"]["C"], lr=conf.learn_rate, dtype=np.float32, **tower_params)
+            if args.conv_dropout > 0:
+                tower.conv_mask = [mk_mask(w.shape[2]) for w in tower.Wc]
+        else:
+            tower = so.CnnTowerOracle(inp["data"]["C"], *tower_params, lr=conf.learn_rate, dtype=np.float32)
+            if args.conv_dropout > 0:   # Dropout(conv_dropout_rate), cnn_model.py:97: one fixed mask (timing only)
+                tower.conv_mask = mk_mask(tower.Wc.shape[2])
+        o = so.StepOracle(U0, None, conf, dtype=np.float32, tower=tower)
         steps, dt = batches(o, budget, tower.W.shape[0])
         return {"value": steps * b / dt, "unit": "positive-links/s", "cores": int(nproc), "kind": "port",
                 "cpu_model": cpu_model_name(), "sampler_samples_per_s_1core": sampler_rate,
@@ -695,6 +708,15 @@ def main():
         names_p = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta") if args.model == "cnn_embedding" else \
             ("W", "Wd", "bd", "gamma", "beta")
         tower_params = [getattr(tw, n).cpu().numpy().copy() for n in names_p]
+        if getattr(tw, "nb", 0) > 1:   # filter bank: per-bank lists, pad rows / columns cut away
+            g = lambda t: t.cpu().numpy().copy()  # noqa: E731
+            wd_l, F_l, d_l, rows = tw.wd_l, tw.F_l, tw.d_l, tw.dense_rows().numpy()
+            tower_params = dict(W=g(tw.W)[:, :wd_l], Wc=[g(tw.bank_Wc(i))[:, :wd_l, :F_l] for i in range(tw.nb)],
+                                bc=[g(tw.bc)[i, :F_l] for i in range(tw.nb)], g1=[g(tw.g1)[i, :F_l] for i in range(tw.nb)],
+                                b1=[g(tw.b1)[i, :F_l] for i in range(tw.nb)], Wd=g(tw.Wd)[rows][:, :d_l], bd=g(tw.bd)[:d_l],
+                                gamma=g(tw.gamma)[:d_l], beta=g(tw.beta)[:d_l])
+            if U0 is not None:
+                U0 = U0[:, :eng.dim]
     uid = eng.ids(inp["uid"])
     cid = eng.ids(inp["cid"])
     W, K = args.warmup, args.steps
@@ -757,9 +779,10 @@ def main():
     L = args.content_len if not args.small else min(args.content_len, 40)
     keep = 1.0 - (args.dropout if args.model != "mf" else 0.0)
     mean_n_u = float(n_u_buf[W:W + K].double().mean().item()) if n_u_buf is not None else float(b)
-    conv_flop = 2.0 * mean_n_u * L * args.filter_len * d * d   # per launch, n_u = mean unique items of the timed steps
+    # per LAUNCH: a filter bank launches the conv kernels once per length -- the mean over the banks
+    conv_flop = 2.0 * mean_n_u * L * (sum(bank_lens(args)) / float(len(bank_lens(args)))) * d * d
     kernels = {
-        "cnn_conv_fwd_kernel": ("mfma", conv_flop, "2*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % mean_n_u),
+        "cnn_conv_fwd_kernel": ("mfma", conv_flop, "2*n_u*L*fl*word_dim*F flop (fl: mean over the bank's lengths), n_u = %.1f unique items per launch" % mean_n_u),
         "cnn_conv_bwd_kernel": ("mfma", 2 * conv_flop, "dX and dWk: 4*n_u*L*fl*word_dim*F flop, n_u = %.1f" % mean_n_u),
         "shared_tile_kernel": ("mfma", 6.0 * b * b * d, "6*b*N*d flop (S, G.V, G^T.U; N = b upper bound)"),
         # the one-launch step computes S in both passes (8 b N d flop issued); the ALGORITHMIC work of the step is 6 b N d
@@ -850,8 +873,8 @@ def main():
         tower_txt = ("basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
                      % (L, args.vocab, args.dropout)
                      if args.model == "basic_embedding" else
-                     "cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %d)+BN+ReLU+"
-                     "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_len, args.conv_dropout)
+                     "cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %s)+BN+ReLU+"
+                     "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_lens or str(args.filter_len), args.conv_dropout)
                      if args.model == "cnn_embedding" else "id-table towers (model_choice=mf)")
         line = {
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",

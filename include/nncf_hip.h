@@ -288,6 +288,13 @@ typedef struct nncf_tower_cfg {
   int32_t conv_filters;
   int32_t filter_len;
   float conv_dropout;
+  /* filter bank (cnn_model.py:63-81; the `default` preset's filter_lengths [[1, 3, 5]], cnn_embedding_conf.py:42-45):
+   * n_filter_lens > 1 runs a Convolution1D of every listed odd length, conv_filters filters each, over the same
+   * word rows and concatenates them along the filter axis (each with its own BatchNorm scale / shift); the Dense layer
+   * then has n_filter_lens * conv_filters inputs.  conv_w holds the banks one after the other ([sum fl][word_dim][F]),
+   * conv_b / bn1_* one 128-float pitched row per bank.  0 / 1: the single filter_len above. */
+  int32_t n_filter_lens;
+  int32_t filter_lens[4];
 } nncf_tower_cfg;
 
 typedef struct nncf_tower_params {

@@ -55,6 +55,8 @@ class TowerCfg(ctypes.Structure):
         ("conv_filters", ctypes.c_int32),
         ("filter_len", ctypes.c_int32),
         ("conv_dropout", ctypes.c_float),
+        ("n_filter_lens", ctypes.c_int32),
+        ("filter_lens", ctypes.c_int32 * 4),
     ]
 
 

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
   float* sX = smem;
   stage_tokens(a, item, sTok, sSc);
   // backward preparation: cnt_t[w][s] = 1 + ordinal of word w among the item's distinct words
-  if (a.fill && half == 0) {
+  if (a.fill && half == 0 && a.cnn.c_off == 0) {   // once per item: by the first bank
     const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
     for (int e = e0 + tid; e < e1; e += kConvThreads) {
       const int wv = a.item_word[e];
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = kp * kper + i;
-    w[i] = (tid < 256 && i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+    w[i] = (tid < 256 && i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)(a.cnn.c_off + k) * a.d)[c4] : zero4();
   }
   if (tid < 128) {
     float mul = 0.f, add = 0.f;
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
       sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q + 16]);
     }
     sum = row_scale(sum, 1.f / (float)L);
-    if (a.train) row_store(a.h, s, F, f4, q, sum);
+    if (a.train) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, sum);   // this bank's columns of the pooled block
     reinterpret_cast<float4*>(sH)[q] = sum.a;
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
   }
@@ -442,10 +442,11 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
   }
   __syncthreads();
   if (tid < d4) {
-    float4 z = reinterpret_cast<const float4*>(a.bd)[tid];
+    // a filter bank: the banks add their h.Wd one after the other (launch order = bank order)
+    float4 z = a.cnn.z_acc ? reinterpret_cast<const float4*>(a.z + (int64_t)s * a.d)[tid] : reinterpret_cast<const float4*>(a.bd)[tid];
 #pragma unroll
     for (int p = 0; p < 8; ++p) z = add4(z, sP[p * 32 + tid]);
-    if (a.train) {
+    if (a.train || !a.cnn.last) {
       reinterpret_cast<float4*>(a.z + (int64_t)s * a.d)[tid] = z;
     } else {
       const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
         const int s = s0 + 8 * e;
         u1[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + c] : 0.f;
         u2[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + 128 + c] : 0.f;
-        dv[e] = s < n ? a.dh[(int64_t)s * F + c] * rL : 0.f;
+        dv[e] = s < n ? a.dh[(int64_t)s * a.hd + a.cnn.c_off + c] * rL : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
     sS1[tid] = a.cnn.st1[640 + tid];
     sS2[tid] = a.cnn.st1[768 + tid];
   }
-  const Row dhr = row_scale(row_load(a.dh, s, F, f4, q), 1.f / (float)L);
+  const Row dhr = row_scale(row_load(a.dh + a.cnn.c_off, s, a.hd, f4, q), 1.f / (float)L);
   __syncthreads();
   stage_rows(a, sTok, sSc, sX, XP, p0 - pad, rows);
   // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
@@ -667,8 +668,10 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
         const int p = p0 + 16 * mt + x;
         if (p < L && k0 < a.wd) {
           const float sc = sSc[p];
-          *reinterpret_cast<float4*>(a.cnn.dX + ((int64_t)s * L + p) * a.wd + k0) =
-              make_float4(acc[mt][0] * sc, acc[mt][1] * sc, acc[mt][2] * sc, acc[mt][3] * sc);
+          float4* dst = reinterpret_cast<float4*>(a.cnn.dX + ((int64_t)s * L + p) * a.wd + k0);
+          float4 v = make_float4(acc[mt][0] * sc, acc[mt][1] * sc, acc[mt][2] * sc, acc[mt][3] * sc);
+          if (a.cnn.dx_acc) v = add4(*dst, v);   // a filter bank: dL/dX is the sum over the banks, in bank order
+          *dst = v;
         }
       }
     } else {
@@ -874,23 +877,31 @@ static int conv_blocks(int L) { return (L + kConvLB - 1) / kConvLB; }
 
 size_t cnn_carve(nncf_tower* t, Carver& c) {
   const int64_t cap = t->cfg.max_rows, L = t->cfg.content_len, wd = t->cfg.word_dim, F = t->cfg.conv_filters;
-  const int64_t fl = t->cfg.filter_len, nblk = conv_blocks((int)L);
-  CnnArgs& a = t->cnn;
-  a.Wt = c.take<float>(F * fl * wd);
-  a.Y = c.take<float>(cap * L * F);
-  a.dX = c.take<float>(cap * L * wd);
-  a.dXw = c.take<float>(cap * L * wd);
-  a.part1 = c.take<float>(cap * kFwdSplit * 256);
-  a.st1 = c.take<float>(7 * 128);
-  a.bpart = c.take<float>(cap * 256);
-  a.gWpart = c.take<float>(cap * nblk * fl * wd * F);
-  a.gbpart = c.take<float>(cap * nblk * 128);
+  const int64_t nblk = conv_blocks((int)L);
+  float* dX = c.take<float>(cap * L * wd);     // shared by the banks (the backward accumulates into it)
+  float* dXw = c.take<float>(cap * L * wd);
+  for (int g = 0; g < t->nb; ++g) {
+    CnnArgs& a = t->bank_at(g);
+    const int64_t fl = a.fl;
+    a.dX = dX;
+    a.dXw = dXw;
+    a.Wt = c.take<float>(F * fl * wd);
+    a.Y = c.take<float>(cap * L * F);
+    a.part1 = c.take<float>(cap * kFwdSplit * 256);
+    a.st1 = c.take<float>(7 * 128);
+    a.bpart = c.take<float>(cap * 256);
+    a.gWpart = c.take<float>(cap * nblk * fl * wd * F);
+    a.gbpart = c.take<float>(cap * nblk * 128);
+  }
   return c.off;
 }
 
 int cnn_sync_weights(nncf_tower* t, hipStream_t st) {
-  const int nel = t->cnn.fl * t->cfg.word_dim * t->cnn.F;
-  hipLaunchKernelGGL(cnn_transpose_kernel, dim3((nel + 255) / 256), dim3(256), 0, st, t->cnn, t->cfg.word_dim);
+  for (int g = 0; g < t->nb; ++g) {
+    const CnnArgs& c = t->bank_at(g);
+    const int nel = c.fl * t->cfg.word_dim * c.F;
+    hipLaunchKernelGGL(cnn_transpose_kernel, dim3((nel + 255) / 256), dim3(256), 0, st, c, t->cfg.word_dim);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -900,7 +911,34 @@ static int set_lds(const void* fn, size_t bytes) {
   return NNCF_OK;
 }
 
+// this call's arguments for bank g: the bank's buffers, the caller's dropout state (an own mask seed per bank)
+static TowerArgs bank_args(const nncf_tower* t, const TowerArgs& a, int g) {
+  TowerArgs b = a;
+  if (g > 0) {
+    b.cnn = t->bank_at(g);
+    b.cnn.keep = a.cnn.keep;
+    b.cnn.seed = splitmix64(a.cnn.seed + 0x9E3779B97F4A7C15ull * (uint64_t)g);
+    b.cnn.dbg = a.cnn.dbg;
+  }
+  b.cnn.c_off = g * a.cnn.F;
+  b.cnn.z_acc = g > 0;
+  b.cnn.dx_acc = g > 0;
+  b.cnn.last = g == t->nb - 1;
+  return b;
+}
+
+static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st);
+static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st);
+
 int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  for (int g = 0; g < t->nb; ++g) {
+    TowerArgs b = bank_args(t, a, g);
+    if (int rc = cnn_forward_bank(t, b, st)) return rc;
+  }
+  return NNCF_OK;
+}
+
+static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int L = a.L, fl = a.cnn.fl;
   const int nMtH = (((L + 15) / 16) + kFwdSplit - 1) / kFwdSplit;
   const size_t lds = (size_t)(16 * nMtH + fl - 1) * conv_pitch(a.wd) * sizeof(float);
@@ -936,8 +974,36 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   return NNCF_OK;
 }
 
-// after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) rows
+__global__ void __launch_bounds__(512) cnn_update_kernel(TowerArgs a) {
+  __shared__ float sG[kCnnUpdGroups * 128];
+  cnn_update_block(a, (int)blockIdx.x, sG);
+}
+
+// after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) rows.  Banks 1 .. take their
+// parameter step here (bank 0's rides in the word kernel's launch, tower.hip).
 int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  for (int g = 0; g < t->nb; ++g) {
+    TowerArgs b = bank_args(t, a, g);
+    if (g > 0) {
+      b.cnn.mC = t->bank_at(g).mC;
+      b.cnn.vC = t->bank_at(g).vC;
+    }
+    if (int rc = cnn_backward_bank(t, b, st)) return rc;
+    if (g > 0) {
+      ProfScope _ps("cnn_update_kernel", st);
+      const int ncnn = (b.cnn.fl * b.wd * b.cnn.F + 127) / 128 + 1;
+      hipLaunchKernelGGL(cnn_update_kernel, dim3(ncnn), dim3(512), 0, st, b);
+    }
+  }
+  {
+    ProfScope _ps("cnn_presum_kernel", st);
+    hipLaunchKernelGGL(cnn_presum_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int nblk = conv_blocks(a.L), fl = a.cnn.fl;
   const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch32(a.wd) + conv_pitch32(a.cnn.F)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tile of %zu bytes exceeds the LDS", lds);
@@ -960,17 +1026,16 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
     else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
     else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
   }
-  {
-    ProfScope _ps("cnn_presum_kernel", st);
-    hipLaunchKernelGGL(cnn_presum_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
-  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
 
 int cnn_mask(nncf_tower* t, TowerArgs& a, int64_t m, float* out, hipStream_t st) {
-  const int64_t n = m * a.L * a.cnn.F;
-  hipLaunchKernelGGL(cnn_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n, out);
+  const int64_t n = m * a.L * a.cnn.F;   // one [m][L][F] block per bank, bank after bank
+  for (int g = 0; g < t->nb; ++g) {
+    TowerArgs b = bank_args(t, a, g);
+    hipLaunchKernelGGL(cnn_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, n, out + g * n);
+  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

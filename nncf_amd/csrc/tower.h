@@ -37,6 +37,13 @@ struct CnnArgs {
   const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
   float *mC, *vC;            // Adam moments of [Wk | bc, g1, b1 (128 each)]
   int dbg;                   // NNCF_CNN_DBG (timing experiments only): 1 skip MFMA loops, 2 skip the gather
+  // filter bank (cnn_model.py:63-81: Convolution1D of several lengths over the same input, concatenated along the
+  // filter axis): every length is one CnnArgs whose F filters are columns [c_off, c_off + F) of the pooled block h /
+  // dh (pitch TowerArgs::hd) and rows [c_off, ...) of the Dense weights.  Banks run one after the other:
+  int c_off;                 // first column of this bank in h / dh / Wd
+  int z_acc;                 // pooling pass: add this bank's h.Wd to the z the earlier banks left (0: start from bd)
+  int last;                  // pooling pass, inference: this bank completes z -> BatchNorm -> ReLU -> E
+  int dx_acc;                // conv backward: add to the dX of the earlier banks (0: store)
 };
 constexpr int kConvLB = 112;  // positions per workgroup of the conv backward
 
@@ -293,7 +300,12 @@ struct nncf_tower {
   int32_t* stamps = nullptr;
   float* gexp = nullptr;
   // convolutional front (cfg.conv_filters > 0)
-  nncf::CnnArgs cnn{};
+  nncf::CnnArgs cnn{};           // bank 0 (the only one unless cfg.n_filter_lens > 1)
+  int nb = 0;                    // filter banks (0: mean-pool tower)
+  nncf::CnnArgs bank[3]{};       // banks 1 .. nb - 1
+  const nncf::CnnArgs& bank_at(int g) const { return g == 0 ? cnn : bank[g - 1]; }
+  nncf::CnnArgs& bank_at(int g) { return g == 0 ? cnn : bank[g - 1]; }
+  int hd() const { return nb > 0 ? nb * cnn.F : cfg.word_dim; }   // width of the pooled block = Dense input width
   float conv_drop = 0.f;
   uint64_t conv_step = 0;  // train-mode forwards since nncf_tower_set_dropout (conv mask index)
 };

@@ -747,7 +747,7 @@ namespace {
 
 void carve_tower(nncf_tower* t, Carver& c) {
   const int64_t cap = t->cfg.max_rows, wd = t->cfg.word_dim, d = t->cfg.item_dim;
-  const int64_t hd = t->cfg.conv_filters > 0 ? (int64_t)t->cfg.conv_filters : wd;  // Dense input width
+  const int64_t hd = t->hd();  // Dense input width: word_dim, or the conv filters of all banks
   const int64_t wide = hd > wd ? hd : wd;
   t->h = c.take<float>(cap * wide);
   t->z = c.take<float>(cap * d);
@@ -781,7 +781,7 @@ TowerArgs base_args(const nncf_tower* t) {
   a.keep = 1.f;
   a.cnn = t->cnn;
   a.cnn.keep = 1.f;
-  if (t->cnn.F > 0) a.hd = t->cnn.F;
+  a.hd = t->hd();
   return a;
 }
 
@@ -909,7 +909,7 @@ int tower_backward_fused(nncf_tower* t, const float* dA, hipStream_t st, int nfu
 // weights are copied back into it if the last step left them in the second buffer.
 int tower_sync_wd(nncf_tower* t, hipStream_t st) {
   if (!t->wd_in_alt) return NNCF_OK;
-  const size_t hd = t->cnn.F > 0 ? (size_t)t->cnn.F : (size_t)t->cfg.word_dim;
+  const size_t hd = (size_t)t->hd();
   NNCF_HIP_CHECK(hipMemcpyAsync(t->prm.dense_w, t->Wd_alt, sizeof(float) * hd * t->cfg.item_dim, hipMemcpyDeviceToDevice, st));
   t->wd_in_alt = false;
   return NNCF_OK;
@@ -1046,6 +1046,10 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
     NNCF_REQUIRE(prm->conv_w && prm->conv_b && prm->bn1_gamma && prm->bn1_beta && prm->bn1_mean && prm->bn1_var &&
                      prm->item_spos && prm->item_start, "NULL CNN parameter pointer");
     NNCF_REQUIRE(((uintptr_t)prm->conv_w & 15) == 0, "conv_w must be 16-byte aligned");
+    NNCF_REQUIRE(cfg->n_filter_lens >= 0 && cfg->n_filter_lens <= 4, "n_filter_lens = %d: at most 4 filter lengths per bank", cfg->n_filter_lens);
+    for (int g = 0; g < cfg->n_filter_lens; ++g)
+      NNCF_REQUIRE(cfg->filter_lens[g] >= 1 && cfg->filter_lens[g] % 2 == 1 && cfg->filter_lens[g] <= 7,
+                   "filter_lens[%d] = %d must be odd, 1..7", g, cfg->filter_lens[g]);
   } else {
     NNCF_REQUIRE(cfg->conv_filters == 0, "negative conv_filters");
   }
@@ -1068,14 +1072,22 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   t->use_wordbwd = 0;
   if (const char* e = getenv("NNCF_TOWER_BWD")) t->use_wordbwd = std::string(e) == "fused";
   if (cfg->conv_filters > 0) {
-    CnnArgs& c = t->cnn;
-    c.F = cfg->conv_filters;
-    c.fl = cfg->filter_len;
-    c.keep = 1.f;
-    c.Wk = prm->conv_w; c.bc = prm->conv_b; c.g1 = prm->bn1_gamma; c.b1 = prm->bn1_beta; c.rm1 = prm->bn1_mean;
-    c.rv1 = prm->bn1_var; c.item_spos = prm->item_spos; c.item_start = prm->item_start;
+    t->nb = cfg->n_filter_lens > 1 ? cfg->n_filter_lens : 1;
+    int64_t taps = 0;   // conv_w: the banks' [fl][word_dim][F] blocks one after the other
+    for (int g = 0; g < t->nb; ++g) {
+      CnnArgs& c = t->bank_at(g);
+      c.F = cfg->conv_filters;
+      c.fl = cfg->n_filter_lens > 0 ? cfg->filter_lens[g] : cfg->filter_len;
+      c.keep = 1.f;
+      c.Wk = prm->conv_w + taps * cfg->word_dim * c.F;
+      c.bc = prm->conv_b + 128 * g; c.g1 = prm->bn1_gamma + 128 * g; c.b1 = prm->bn1_beta + 128 * g;
+      c.rm1 = prm->bn1_mean + 128 * g; c.rv1 = prm->bn1_var + 128 * g;
+      c.item_spos = prm->item_spos; c.item_start = prm->item_start;
+      c.c_off = g * c.F;
+      if (const char* e = getenv("NNCF_CNN_DBG")) c.dbg = atoi(e);
+      taps += c.fl;
+    }
     t->conv_drop = cfg->conv_dropout;
-    if (const char* e = getenv("NNCF_CNN_DBG")) c.dbg = atoi(e);
   }
   Carver dry;
   carve_tower(t, dry);
@@ -1160,10 +1172,14 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
   t->aw = AdamTable{d_m_words, d_v_words, nullptr};
   t->mD = d_m_dense;
   t->vD = d_v_dense;
-  if (t->cnn.F > 0 && mode) {  // conv / BN1 moments follow the Dense / BN2 block
-    const int64_t off = (int64_t)t->cnn.F * t->cfg.item_dim + 384;
-    t->cnn.mC = d_m_dense + off;
-    t->cnn.vC = d_v_dense + off;
+  if (t->cnn.F > 0 && mode) {  // conv / BN1 moments follow the Dense / BN2 block, bank after bank
+    int64_t off = (int64_t)t->hd() * t->cfg.item_dim + 384;
+    for (int g = 0; g < t->nb; ++g) {
+      CnnArgs& c = t->bank_at(g);
+      c.mC = d_m_dense + off;
+      c.vC = d_v_dense + off;
+      off += (int64_t)c.fl * t->cfg.word_dim * c.F + 384;
+    }
   }
   if (mode == 2) {
     DeviceGuard guard(t->device);
@@ -1177,20 +1193,22 @@ int nncf_tower_set_optimizer(nncf_tower* t, int32_t mode, float beta1, float bet
 
 int64_t nncf_tower_grad_floats(const nncf_tower* t) {
   if (!t) return 0;
-  const int64_t F = t->cnn.F, hd = F > 0 ? F : t->cfg.word_dim;
+  const int64_t F = t->cnn.F, hd = t->hd();
   int64_t n = (int64_t)t->cfg.word_count * t->cfg.word_dim + hd * t->cfg.item_dim + 384;
-  if (F > 0) n += (int64_t)t->cnn.fl * t->cfg.word_dim * F + 384;
+  for (int g = 0; g < t->nb; ++g) n += (int64_t)t->bank_at(g).fl * t->cfg.word_dim * F + 384;
   return n;
 }
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(t->nb <= 1 || !d_grad, "gradient export (data-parallel training) with a filter bank is not built");
   t->gexp = d_grad;
   return NNCF_OK;
 }
 
 int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream) {
   NNCF_REQUIRE(t && d_grad, "NULL argument");
+  NNCF_REQUIRE(t->nb <= 1, "applying exported gradients (data-parallel training) with a filter bank is not built");
   TowerArgs a = base_args(t);
   a.opt = t->opt;
   if (t->opt) {

@@ -65,11 +65,18 @@ class MeanPoolTower(object):
         W[:, :self.wd_l] = (torch.rand(self.word_count, self.wd_l, generator=gen) * 2 - 1) * 0.05
         self.W = W.to(dev).contiguous()
         self.conv = dict(conv) if conv else None
-        self.hd_l = int(self.conv["filters"]) if self.conv else self.wd_l     # Dense input width
-        self.hd = pad4(self.hd_l)
+        # filter bank (cnn_model.py:63-81): filter_lens = [1, 3, 5] -> three Convolution1D of `filters` filters each,
+        # concatenated along the filter axis; bank g owns columns [g F, g F + F_l) of the padded pooled block
+        self.filter_lens = [int(v) for v in (self.conv.get("filter_lens") or [self.conv["filter_len"]])] if self.conv else []
+        self.nb = len(self.filter_lens)
+        self.F_l = int(self.conv["filters"]) if self.conv else 0
+        self.F = pad4(self.F_l)
+        self.hd_l = self.nb * self.F_l if self.conv else self.wd_l     # Dense input width
+        self.hd = self.nb * self.F if self.conv else pad4(self.hd_l)
         lim = float(np.sqrt(6.0 / (self.hd_l + self.d_l)))  # glorot_uniform
         Wd = torch.zeros(self.hd, self.d)
-        Wd[:self.hd_l, :self.d_l] = (torch.rand(self.hd_l, self.d_l, generator=gen) * 2 - 1) * lim
+        Wd0 = (torch.rand(self.hd_l, self.d_l, generator=gen) * 2 - 1) * lim
+        Wd[self.dense_rows(), :self.d_l] = Wd0
         self.Wd = Wd.to(dev).contiguous()
         # one allocation for the five small vectors, each 512-byte aligned
         vec = torch.zeros(5, 128, device=dev)
@@ -87,14 +94,22 @@ class MeanPoolTower(object):
         F = fl = 0
         cdrop = 0.0
         if self.conv:
-            F, fl, cdrop = self.hd, int(self.conv["filter_len"]), float(self.conv.get("dropout", 0.0))
-            assert F <= 128 and fl % 2 == 1, "conv filters above 128 / even filter lengths are not built"
+            F, fl, cdrop = self.F, self.filter_lens[0], float(self.conv.get("dropout", 0.0))
+            assert F <= 128 and all(v % 2 == 1 for v in self.filter_lens) and 1 <= self.nb <= 4, \
+                "more than 128 filters per length / even filter lengths / more than 4 lengths are not built"
             # Convolution1D init='he_normal' (cnn_model.py:88): std = sqrt(2 / fan_in), fan_in = fl * word_dim [K-mem]
-            Wc = torch.zeros(fl, self.wd, F)
-            Wc[:, :self.wd_l, :self.hd_l] = torch.randn(fl, self.wd_l, self.hd_l, generator=gen) * float(np.sqrt(2.0 / (fl * self.wd_l)))
+            # one tensor for all banks: [sum fl][wd][F], bank g = taps [tap_off[g], tap_off[g] + fl_g)
+            self.tap_off = [int(v) for v in np.concatenate([[0], np.cumsum(self.filter_lens)])]
+            Wc = torch.zeros(self.tap_off[-1], self.wd, F)
+            for g, flg in enumerate(self.filter_lens):
+                Wc[self.tap_off[g]:self.tap_off[g + 1], :self.wd_l, :self.F_l] = \
+                    torch.randn(flg, self.wd_l, self.F_l, generator=gen) * float(np.sqrt(2.0 / (flg * self.wd_l)))
             self.Wc = Wc.to(dev).contiguous()
-            vec1 = torch.zeros(5, 128, device=dev)
-            self.bc, self.g1, self.b1, self.rm1, self.rv1 = (vec1[i, :F] for i in range(5))
+            vec1 = torch.zeros(5, self.nb, 128, device=dev)
+            if self.nb == 1:
+                self.bc, self.g1, self.b1, self.rm1, self.rv1 = (vec1[i, 0, :F] for i in range(5))
+            else:   # one row per bank
+                self.bc, self.g1, self.b1, self.rm1, self.rv1 = (vec1[i, :, :F] for i in range(5))
             self.g1.fill_(1.0)
             self.rv1.fill_(1.0)
             self._vec1 = vec1
@@ -109,6 +124,10 @@ class MeanPoolTower(object):
             extra = [self.Wc, self.bc, self.g1, self.b1, self.rm1, self.rv1, self.item_spos, self.item_start]
         cfg = _lib.TowerCfg(self.word_count, self.wd, self.d, self.Lc, self.cap, self.item_count, self.eps, self.mom,
                             self.lr, F, fl, cdrop)
+        if self.nb > 1:
+            cfg.n_filter_lens = self.nb
+            for g, flg in enumerate(self.filter_lens):
+                cfg.filter_lens[g] = flg
         prm = _lib.TowerParams(*([t.data_ptr() for t in (self.W, self.Wd, self.bd, self.gamma, self.beta, self.rm,
                                                          self.rv, self.C, self.item_ptr, self.item_word, self.item_cnt)] +
                                  [(t.data_ptr() if t is not None else None) for t in extra]))
@@ -127,6 +146,16 @@ class MeanPoolTower(object):
     def _stream(self):
         return _lib.stream_ptr(torch.cuda.current_stream(self.device))
 
+    def dense_rows(self):
+        """rows of the padded Dense weight matrix that are real inputs, in the configured order (bank after bank)"""
+        if not self.conv:
+            return torch.arange(self.hd_l)
+        return torch.cat([torch.arange(g * self.F, g * self.F + self.F_l) for g in range(self.nb)])
+
+    def bank_Wc(self, g):
+        """view of bank g's filters [fl_g][wd][F] (padded widths)"""
+        return self.Wc[self.tap_off[g]:self.tap_off[g + 1]]
+
     def set_params(self, **kw):
         """W, Wd, bd, gamma, beta (+ Wc, bc, g1, b1 for the CNN tower) from host arrays."""
         for name, v in kw.items():
@@ -138,11 +167,11 @@ class MeanPoolTower(object):
 
     def conv_mask(self, step_index, m):
         """Dropout(conv_dropout) mask of the step_index-th train-mode forward, first m rows (checkers)."""
-        out = torch.empty(m, self.Lc, self.hd, dtype=torch.float32, device=self.device)
+        out = torch.empty(self.nb, m, self.Lc, self.F, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._L.nncf_tower_conv_mask(self.handle, int(step_index), m, ctypes.c_void_p(out.data_ptr()),
                                                     self._stream()))
-        return out
+        return out[0] if self.nb == 1 else out   # a filter bank: one (m, L, F) mask per bank
 
     def set_optimizer(self, kind, beta1=0.9, beta2=0.999, epsilon=1e-8):
         """'sgd' | 'sparse_adam' | 'adam' for the tower's parameters (see Engine.set_optimizer)."""
@@ -152,7 +181,7 @@ class MeanPoolTower(object):
         if mode:
             nd = self.hd * self.d + 384
             if self.conv:
-                nd += self.Wc.numel() + 384
+                nd += self.Wc.numel() + 384 * self.nb   # per bank: [fl][wd][F] filters | bias, BN scale, BN shift at 128-float pitch
             z = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=self.device)  # noqa: E731
             self.opt_state = {"mW": z(self.word_count, self.wd), "vW": z(self.word_count, self.wd), "mD": z(nd), "vD": z(nd)}
         st = self.opt_state or {}

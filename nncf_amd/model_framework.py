@@ -423,21 +423,26 @@ def engine_kwargs(conf, data_spec, model_name):
 
 
 def _conv_spec(conf):
-    """The convolutional front of cnn_embedding as this build runs it (cnn_model.py:61-111): one
-    Convolution1D layer, a single odd filter length, BatchNorm, relu, whole-length average pooling."""
+    """The convolutional front of cnn_embedding as this build runs it (cnn_model.py:61-111): one convolution layer --
+    a single odd filter length (the 'best' preset, filter_lengths [3]) or a bank of up to four odd lengths whose
+    outputs are concatenated (the 'default' preset, filter_lengths [[1, 3, 5]]; :63-81) -- BatchNorm, relu,
+    whole-length average pooling."""
     fls, nfs = list(conf.filter_lengths), list(conf.num_filters)
-    ok = (len(fls) == 1 and not isinstance(fls[0], (list, tuple)) and int(fls[0]) % 2 == 1 and len(nfs) == 1 and
+    bank = None
+    if len(fls) == 1:
+        bank = [int(v) for v in fls[0]] if isinstance(fls[0], (list, tuple)) else [int(fls[0])]
+    ok = (bank is not None and 1 <= len(bank) <= 4 and all(v % 2 == 1 and 1 <= v <= 7 for v in bank) and len(nfs) == 1 and
           list(conf.poolings) == ["average"] and list(conf.pool_lengths)[0] <= 0 and conf.conv_activation == "relu" and
           conf.conv_batch_normalization and not getattr(conf, "no_BN", False) and
           not getattr(conf, "contextual_spatial_gated_input", None) and
           not getattr(conf, "contextual_temporal_gated_input", None))
     if not ok:
         raise NotImplementedError(
-            "cnn_embedding is built for ONE Convolution1D layer with a single odd filter length (e.g. "
-            "filter_lengths=[3], the 'best' preset), conv BatchNorm + relu, poolings=['average'] over the whole "
-            "length, no gating; got filter_lengths=%r num_filters=%r poolings=%r pool_lengths=%r"
-            % (fls, nfs, conf.poolings, conf.pool_lengths))
-    return dict(filters=int(nfs[0]), filter_len=int(fls[0]), dropout=float(conf.conv_dropout_rate))
+            "cnn_embedding is built for ONE convolution layer (filter_lengths=[3], the 'best' preset, or a bank of up "
+            "to four odd lengths <= 7 such as [[1, 3, 5]], the 'default' preset), conv BatchNorm + relu, "
+            "poolings=['average'] over the whole length, no gating; got filter_lengths=%r num_filters=%r poolings=%r "
+            "pool_lengths=%r" % (fls, nfs, conf.poolings, conf.pool_lengths))
+    return dict(filters=int(nfs[0]), filter_len=bank[0], filter_lens=bank, dropout=float(conf.conv_dropout_rate))
 
 
 def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):

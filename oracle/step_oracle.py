@@ -512,6 +512,115 @@ class CnnTowerOracle(TowerOracle):
         return dict(W=dW, Wc=dWc, bc=dY.sum(axis=(0, 1)), g1=dg1, b1=db1)
 
 
+class CnnBankTowerOracle(TowerOracle):
+    """CNN item tower with a FILTER BANK (modules/content/cnn_model.py:63-81, the `default` preset's
+    filter_lengths [[1, 3, 5]], cnn_embedding_conf.py:42-45): one Convolution1D('same', linear) per listed length
+    over the same word rows, outputs merged with mode 'concat' along the filter axis (:80), then ONE
+    BatchNormalization over (items, positions) per channel of the concatenation (:89-95) -- per-channel statistics, so
+    it factors per bank --, relu, Dropout, AveragePooling1D over the whole length, Flatten, Dense, BatchNorm, ReLU.
+    Wc / bc / g1 / b1: lists with one entry per filter length ((fl, wd, F), (F,), (F,), (F,)); conv_mask: list of
+    (n, L, F) masks including their 1/keep scale, or None.  With one bank this is CnnTowerOracle
+    (tests/test_oracle_step.py checks that, and the bank against one zero-padded convolution of the longest length)."""
+
+    def __init__(self, C, W, Wc, bc, g1, b1, Wd, bd, gamma, beta, lr, dtype=np.float32, eps=1e-3, momentum=0.99):
+        TowerOracle.__init__(self, C, W, Wd, bd, gamma, beta, lr, dtype=dtype, eps=eps, momentum=momentum)
+        self.Wc = [np.array(v, dtype=self.dt) for v in Wc]
+        self.bc = [np.array(v, dtype=self.dt) for v in bc]
+        self.g1 = [np.array(v, dtype=self.dt) for v in g1]
+        self.b1 = [np.array(v, dtype=self.dt) for v in b1]
+        self.rm1 = [np.zeros_like(v) for v in self.b1]
+        self.rv1 = [np.ones_like(v) for v in self.b1]
+        self.conv_mask = None
+        self.nb = len(self.Wc)
+        assert all(w.shape[0] % 2 == 1 for w in self.Wc), "odd filter lengths only"
+        assert self.Wd.shape[0] == sum(w.shape[2] for w in self.Wc), "Dense input = all banks' filters"
+
+    PARAMS = ("W", "Wd", "bd", "gamma", "beta")      # + the per-bank lists, stepped in backward_update below
+
+    def _front_forward(self, toks, row_scale, train):
+        n, L = toks.shape
+        X = self.W[toks]
+        if row_scale is not None:
+            X = X * row_scale[toks][..., None]
+        hs, banks = [], []
+        for g in range(self.nb):
+            Wc = self.Wc[g]
+            fl, pad = Wc.shape[0], Wc.shape[0] // 2
+            Xp = np.zeros((n, L + 2 * pad, X.shape[2]), dtype=self.dt)
+            Xp[:, pad:pad + L] = X
+            Y = np.zeros((n, L, Wc.shape[2]), dtype=self.dt) + self.bc[g]
+            for tap in range(fl):
+                Y += Xp[:, tap:tap + L] @ Wc[tap]
+            if train:
+                mu = Y.mean(axis=(0, 1))
+                var = ((Y - mu) ** 2).mean(axis=(0, 1))
+            else:
+                mu, var = self.rm1[g], self.rv1[g]
+            inv = 1.0 / np.sqrt(var + self.eps)
+            xh = (Y - mu) * inv
+            y1 = self.g1[g] * xh + self.b1[g]
+            a = np.maximum(y1, 0)
+            mask = self.conv_mask[g][:n] if (train and self.conv_mask is not None) else None
+            if mask is not None:
+                a = a * mask
+            banks.append(dict(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var))
+            hs.append(a.sum(axis=1) / self.dt.type(L))
+        if train:
+            self.cache["banks"] = banks
+        return np.concatenate(hs, axis=1).astype(self.dt)       # Merge(mode='concat', concat_axis=-1)
+
+    def _front_backward(self, dh):
+        c = self.cache
+        toks = c["toks"]
+        n, L = toks.shape
+        dX = np.zeros((n, L, self.W.shape[1]), dtype=self.dt)
+        self.bank_grads = []
+        off = 0
+        for g in range(self.nb):
+            b, Wc = c["banks"][g], self.Wc[g]
+            fl, pad, F = Wc.shape[0], Wc.shape[0] // 2, Wc.shape[2]
+            da = np.repeat(dh[:, None, off:off + F], L, axis=1) / self.dt.type(L)
+            off += F
+            if b["mask"] is not None:
+                da = da * b["mask"]
+            dy1 = da * (b["y1"] > 0)
+            N = self.dt.type(n * L)
+            dg1 = (dy1 * b["xh1"]).sum(axis=(0, 1))
+            db1 = dy1.sum(axis=(0, 1))
+            dxh = dy1 * self.g1[g]
+            dY = b["inv1"] / N * (N * dxh - dxh.sum(axis=(0, 1)) - b["xh1"] * (dxh * b["xh1"]).sum(axis=(0, 1)))
+            dY = dY.astype(self.dt)
+            dWc = np.zeros_like(Wc)
+            dXp = np.zeros_like(b["Xp"])
+            for tap in range(fl):
+                dWc[tap] = np.einsum("nlk,nlf->kf", b["Xp"][:, tap:tap + L], dY)
+                dXp[:, tap:tap + L] += dY @ Wc[tap].T
+            dX += dXp[:, pad:pad + L]
+            self.bank_grads.append(dict(Wc=dWc, bc=dY.sum(axis=(0, 1)), g1=dg1, b1=db1))
+            self.rm1[g] = self.mom * self.rm1[g] + (1 - self.mom) * b["mu1"]
+            self.rv1[g] = self.mom * self.rv1[g] + (1 - self.mom) * b["var1"]
+        if c["row_scale"] is not None:
+            dX = dX * c["row_scale"][toks][..., None]
+        dW = np.zeros_like(self.W)
+        np.add.at(dW, toks, dX.astype(self.dt))
+        return dict(W=dW)
+
+    def backward_update(self, dA, conf=None, t=None):
+        TowerOracle.backward_update(self, dA, conf, t)
+        if getattr(self, "export_only", False):
+            return
+        for g in range(self.nb):
+            for k in ("Wc", "bc", "g1", "b1"):
+                p, grad = getattr(self, k)[g], self.bank_grads[g][k].astype(self.dt)
+                if conf is None or conf.optimizer == "sgd":
+                    p -= self.lr * grad
+                else:
+                    key = "%s%d" % (k, g)
+                    if key not in self.slots:
+                        self.slots[key] = AdamSlot(p)
+                    self.slots[key].step(p, grad, adam_lr_t(self.lr, conf.beta1, conf.beta2, t), conf)
+
+
 # ----------------------------------------------------------------------------------------
 # the model: id-table towers ('mf', model_framework.py:59-63,85-88) + sparse SGD
 # ----------------------------------------------------------------------------------------

@@ -826,3 +826,108 @@ def test_steps_are_bitwise_reproducible_at_baseline_shape(citeulike_data, model,
     assert torch.equal(outs[0][1], outs[1][1])
     for n, v in outs[0][2].items():
         assert torch.equal(v, outs[1][2][n]), n
+
+
+def _bank_oracle(conf, md, data, dtype=np.float32):
+    """CnnBankTowerOracle at the CONFIGURED widths from the (zero-padded) device parameters"""
+    core = md["model"].core
+    tw, eng = core.tower, core.engine
+    oc = so.OracleConf(batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
+                       loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
+                       learn_rate=conf.learn_rate, emb_normalization=conf.emb_normalization,
+                       model_choice="basic_embedding", optimizer=conf.optimizer)
+    g = lambda t: t.cpu().numpy().astype(dtype)  # noqa: E731
+    wd, F, d = tw.wd_l, tw.F_l, tw.d_l
+    rows = tw.dense_rows().numpy()
+    to = so.CnnBankTowerOracle(
+        data["C"], g(tw.W)[:, :wd], [g(tw.bank_Wc(b))[:, :wd, :F] for b in range(tw.nb)], [g(tw.bc)[b, :F] for b in range(tw.nb)],
+        [g(tw.g1)[b, :F] for b in range(tw.nb)], [g(tw.b1)[b, :F] for b in range(tw.nb)], g(tw.Wd)[rows][:, :d], g(tw.bd)[:d],
+        g(tw.gamma)[:d], g(tw.beta)[:d], conf.learn_rate, dtype=dtype)
+    return so.StepOracle(g(eng.U)[:, :eng.dim], None, oc, dtype=dtype, tower=to), to
+
+
+def _check_bank(tw, to, step):
+    g = lambda t: t.cpu().numpy()  # noqa: E731
+    wd, F, d = tw.wd_l, tw.F_l, tw.d_l
+    rows = tw.dense_rows().numpy()
+    tol = dict(rtol=3e-4, atol=3e-5)
+    # the pad word's row sums three banks x ~15 positions x every item of the block: float32 summation order shows
+    np.testing.assert_allclose(g(tw.W)[:, :wd], to.W, err_msg="W step %d" % step, rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(g(tw.Wd)[rows][:, :d], to.Wd, err_msg="Wd step %d" % step, **tol)
+    for name in ("bd", "gamma", "beta", "rm", "rv"):
+        np.testing.assert_allclose(g(getattr(tw, name))[:d], getattr(to, name), err_msg=name, **tol)
+    for b in range(tw.nb):
+        np.testing.assert_allclose(g(tw.bank_Wc(b))[:, :wd, :F], to.Wc[b], err_msg="Wc[%d] step %d" % (b, step), **tol)
+        np.testing.assert_allclose(g(tw.bc)[b, :F], to.bc[b], atol=1e-5, err_msg="bc[%d]" % b)   # rounding noise around zero
+        for name in ("g1", "b1", "rm1", "rv1"):
+            np.testing.assert_allclose(g(getattr(tw, name))[b, :F], getattr(to, name)[b], err_msg="%s[%d] step %d" % (name, b, step), **tol)
+    # pad rows / columns stay exactly zero: the padded model IS the configured one
+    pad_rows = np.setdiff1d(np.arange(tw.hd), rows)
+    assert np.all(g(tw.Wd)[pad_rows] == 0) and np.all(g(tw.Wd)[:, d:] == 0) and np.all(g(tw.W)[:, wd:] == 0)
+    assert np.all(g(tw.Wc)[:, wd:, :] == 0) and np.all(g(tw.Wc)[:, :, F:] == 0)
+
+
+@pytest.mark.parametrize("scheme,loss,drop,opt", [("neg_shared", "skip-gram", False, "sgd"), ("group_neg_shared", "log-loss", True, "sgd"),
+                                                  ("original", "skip-gram", True, "sgd"), ("neg_shared", "log-loss", True, "adam")])
+def test_cnn_embedding_default_preset_filter_bank(text_data, scheme, loss, drop, opt):
+    """cnn_embedding with the reference's `default` preset front (cnn_embedding_conf.py:30-50): widths 50 (zero-padded
+    to 52 on the device), filter_lengths [[1, 3, 5]] x 50 filters merged by concatenation (cnn_model.py:63-81), one
+    BatchNorm over the 150 channels, relu, Dropout, average pooling, Dense(150 -> 50).  Every step against
+    CnnBankTowerOracle at the configured widths: loss, all parameters of the three banks, running statistics, the pad
+    rows / columns exactly zero, and the inference-mode scores."""
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": loss, "num_negatives": 3 if scheme == "original" else 0,
+          "neg_loss_weight": 16, "loss_gamma": 10, "learn_rate": 0.1 if opt == "sgd" else 0.01, "neg_dist": "unigram",
+          "neg_sampling_power": 1, "batch_size_p": 64, "user_dim": 50, "item_dim": 50, "word_dim": 50, "chop_size": 4,
+          "u_reg": 1e-4, "word_emb_dropout_rate": 0.3 if drop else 0., "num_filters": [50], "filter_lengths": [[1, 3, 5]],
+          "conv_dropout_rate": 0.3 if drop else 0.}
+    conf = get_conf("synthetic", "best", dict({"optimizer": opt}, **pd), model_choice="cnn_embedding")
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    orc, to = _bank_oracle(conf, md, text_data, dtype=np.float64)   # float64: three banks' rounding would otherwise be the oracle's too
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    assert (tw.nb, tw.filter_lens, tw.F_l, tw.F, tw.hd_l, tw.hd, tw.wd, tw.d) == (3, [1, 3, 5], 50, 52, 150, 156, 52, 52)
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        if drop:
+            orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+            m = tw.conv_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+            to.conv_mask = [m[g][:, :, :tw.F_l] for g in range(tw.nb)]
+        if scheme == "original":
+            negs = rs.randint(0, 260, b * k)
+            u, c, y = so.assemble_original(bt, negs, loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        if opt == "sgd":
+            np.testing.assert_allclose(head.engine.U.cpu().numpy()[:, :50], orc.U, rtol=1e-4, atol=2e-5)
+            _check_bank(tw, to, step)
+        else:
+            # conv / dense biases sit in front of a BatchNorm: their gradients are rounding noise that Adam normalises
+            # to +-lr_t (test_cnn_embedding_adam_matches_oracle) -- everything else, per bank
+            g = lambda t: t.cpu().numpy()  # noqa: E731
+            tol = dict(rtol=1e-3, atol=1e-3)    # lr_t = 0.01: an element whose tiny gradient differs moves by a fraction of it
+            np.testing.assert_allclose(g(head.engine.U)[:, :50], orc.U, rtol=5e-4, atol=5e-5)
+            np.testing.assert_allclose(g(tw.W)[:, :50], to.W, err_msg="W step %d" % step, **tol)
+            np.testing.assert_allclose(g(tw.Wd)[tw.dense_rows().numpy()][:, :50], to.Wd, err_msg="Wd step %d" % step, **tol)
+            for bk in range(tw.nb):
+                np.testing.assert_allclose(g(tw.bank_Wc(bk))[:, :50, :50], to.Wc[bk], err_msg="Wc[%d] step %d" % (bk, step), **tol)
+                for name in ("g1", "b1"):
+                    np.testing.assert_allclose(g(getattr(tw, name))[bk, :50], getattr(to, name)[bk], err_msg=name, **tol)
+    if opt != "sgd":
+        return    # inference uses the running statistics: the noise-driven bias steps are not normalised away there
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)

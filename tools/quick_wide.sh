@@ -1,4 +1,6 @@
-set -x
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
-for i in 1 2 3; do timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('driver-style', j['ms_per_step'], j['value'])"; done
-timeout 300 python3 bench.py --steps 1170 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('headline', j['ms_per_step'], j['value'])"
+for scheme in group_neg_shared neg_shared original; do
+echo "== cnn_embedding default preset, $scheme"
+timeout 600 python main.py --data_name synthetic_citeulike --model_choice cnn_embedding --conf_choice default --train_scheme $scheme \
+     --eval_scheme whole@50 --param_dict "{'max_epoch': 3}" 2>&1 | grep -E "epoch 3|epoch 1|Training time|Error|error|Traceback" | cut -c1-260
+done
+timeout 600 python3 bench.py --model cnn_embedding --scheme group_neg_shared --dim 50 --filter-lens 1,3,5 --conv-dropout 0.3 --dropout 0 --steps 390 --warmup 39 --cpu-seconds 6 2>&1 | tail -1 | cut -c1-1800
