@@ -1,6 +1,5 @@
-for scheme in group_neg_shared neg_shared original; do
-echo "== cnn_embedding default preset, $scheme"
-timeout 600 python main.py --data_name synthetic_citeulike --model_choice cnn_embedding --conf_choice default --train_scheme $scheme \
-     --eval_scheme whole@50 --param_dict "{'max_epoch': 3}" 2>&1 | grep -E "epoch 3|epoch 1|Training time|Error|error|Traceback" | cut -c1-260
-done
-timeout 600 python3 bench.py --model cnn_embedding --scheme group_neg_shared --dim 50 --filter-lens 1,3,5 --conv-dropout 0.3 --dropout 0 --steps 390 --warmup 39 --cpu-seconds 6 2>&1 | tail -1 | cut -c1-1800
+set -x
+timeout 1200 python -m pytest tests/test_tower_gpu.py tests/test_fused_gpu.py -x -q 2>&1 | tail -8
+timeout 300 python3 bench.py --steps 1170 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('headline', j['ms_per_step'], [(o['kernel'], round(o['kernel_ms']*1e3,2)) for o in [j['roofline']]+j.get('roofline_other_kernels',[])])"
+NNCF_TOWER_ROLEA=bwd timeout 300 python3 bench.py --steps 1170 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('headline rolea=bwd', j['ms_per_step'])"
+timeout 300 python3 bench.py --scheme group_neg_shared --loss skip-gram --steps 1170 --cpu-seconds 0 --recall-epochs 0 2>/dev/null | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('group skip-gram', j['ms_per_step'])"
