@@ -89,7 +89,17 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
       return fail(NNCF_ERR_INVALID, "batch_size_p = %d: above %d only the one-launch step is built (skip-gram / mse, no "
                   "interaction bias, NNCF_SHARED_PATH unset)", a.b, kTileMaxBatch);
     if (int rc = flush_pending_loss(m, st)) return rc;
-    return launch_shared(a, group, uid, cid, m->sws, pu, pv, loss_out, update, st);
+    SharedWs w = m->sws;
+    if (tower && tower->stats) {   // text tower: the tile workgroups derive the BatchNorm statistics (no statistics launch)
+      w.st_out = tower->stats;
+      w.st_gamma = tower->gamma;
+      w.st_beta = tower->beta;
+      w.st_rm = tower->rm;
+      w.st_rv = tower->rv;
+      w.st_eps = tower->eps;
+      w.st_mom = tower->momentum;
+    }
+    return launch_shared(a, group, uid, cid, w, pu, pv, loss_out, update, st);
   }
   const int mb = fused_max_blocks(a.b) * fused_split(a.b);
   FusedArgs f = tower ? *tower : FusedArgs();

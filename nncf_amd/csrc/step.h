@@ -183,6 +183,16 @@ struct SharedWs {
   float* gr_part;    // [NBJ][b]        bias: partial row sums of h (dL/dS off the pairwise corrections)
   float* gc_part;    // [NBI][Npad]     bias: partial column sums of h
   long long* dbg;    // optional [tiles][8] s_memtime stamps of the tile kernel (NNCF_DEBUG_TIMING=1)
+  // text towers: with st_out set every tile workgroup derives the BatchNorm statistics of the item block itself
+  // (StepArgs::bn_z, rows [0, n unique items)) and tile (0, 0) publishes mu, inv, var, mul, add there (the apply kernel and
+  // the tower backward read them) + the running statistics -- no tower_stats launch in front of the tile kernel
+  float* st_out = nullptr;
+  const float* st_gamma = nullptr;
+  const float* st_beta = nullptr;
+  float* st_rm = nullptr;
+  float* st_rv = nullptr;
+  float st_eps = 1e-3f, st_mom = 0.99f;
+  int st_update = 0;
 };
 
 int launch_original(const StepArgs& a, const int32_t* uid, const int32_t* cid_pos, const int32_t* cid_neg,

@@ -82,6 +82,93 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
   const int DP = NP + 2;          // LDS row pitch: DP mod 4 == 2 => conflict-free fragment reads
   const int nbj_max = b / kTile;
   NNCF_STAMP(0);
+  // ---- text towers: BatchNorm statistics of the item block, by every tile workgroup alike -------------------------
+  __shared__ __attribute__((aligned(16))) float sStat[5 * 128];
+  const float* stat = a.bn_stats;    // mu, inv, var, mul, add at a 128-float pitch
+  if (a.bn_z && ws.st_out) {
+    const int grp = tid >> 4, q = tid & 15;
+    const int nv = pv.counts[0];     // rows of the block = unique items of the batch
+    const bool publish = bi == 0 && bj == 0;
+    float x0c = 0.f, gam = 0.f, bet = 0.f, rm0 = 0.f, rv0 = 0.f;
+    if (tid < 128 && tid < d) {
+      x0c = a.bn_z[tid];
+      gam = ws.st_gamma[tid];
+      bet = ws.st_beta[tid];
+      if (publish && ws.st_update) {
+        rm0 = ws.st_rm[tid];
+        rv0 = ws.st_rv[tid];
+      }
+    }
+    const Row x0 = row_load(a.bn_z, 0, a.stride, d4, q);
+    Row s1 = row_zero(), s2 = row_zero();
+    for (int r0 = grp; r0 < nv; r0 += 32 * 16) {
+      Row z[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {  // shifted sums (shift = row 0): no cancellation
+        const float4 da = make_float4(z[e].a.x - x0.a.x, z[e].a.y - x0.a.y, z[e].a.z - x0.a.z, z[e].a.w - x0.a.w);
+        const float4 db = make_float4(z[e].b.x - x0.b.x, z[e].b.y - x0.b.y, z[e].b.z - x0.b.z, z[e].b.w - x0.b.w);
+        s1.a = add4(s1.a, da);
+        s1.b = add4(s1.b, db);
+        s2.a = fma4v(da, da, s2.a);
+        s2.b = fma4v(db, db, s2.b);
+      }
+    }
+    // the wave's four 16-lane groups by shuffles, the eight waves through sP in wave order
+    auto fold = [&](float4& v) {
+      v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+      v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+    };
+    fold(s1.a); fold(s1.b); fold(s2.a); fold(s2.b);
+    if (lane < 16) {
+      reinterpret_cast<float4*>(sP + (wave * 2 + 0) * 128)[q] = s1.a;
+      reinterpret_cast<float4*>(sP + (wave * 2 + 0) * 128)[q + 16] = s1.b;
+      reinterpret_cast<float4*>(sP + (wave * 2 + 1) * 128)[q] = s2.a;
+      reinterpret_cast<float4*>(sP + (wave * 2 + 1) * 128)[q + 16] = s2.b;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        t1 += sP[(w * 2 + 0) * 128 + c];
+        t2 += sP[(w * 2 + 1) * 128 + c];
+      }
+      float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
+      if (c < d) {
+        const float rn = 1.f / (float)max(nv, 1);
+        const float m1 = t1 * rn;
+        mu = x0c + m1;
+        var = fmaxf(t2 * rn - m1 * m1, 0.f);
+        inv = rsqrtf(var + ws.st_eps);
+        mul = gam * inv;
+        add = bet - mu * mul;
+      }
+      if (publish) {
+        ws.st_out[c] = mu;
+        ws.st_out[128 + c] = inv;
+        ws.st_out[256 + c] = var;
+        ws.st_out[384 + c] = mul;
+        ws.st_out[512 + c] = add;
+        if (ws.st_update && c < d) {
+          ws.st_rm[c] = ws.st_mom * rm0 + (1.f - ws.st_mom) * mu;
+          ws.st_rv[c] = ws.st_mom * rv0 + (1.f - ws.st_mom) * var;
+        }
+      }
+      sStat[c] = mu;
+      sStat[128 + c] = inv;
+      sStat[256 + c] = var;
+      sStat[384 + c] = mul;
+      sStat[512 + c] = add;
+    }
+    __syncthreads();   // sStat ready; sP free again
+    stat = sStat;
+  }
+  auto item_row_s = [&](int64_t id, int d4_, int q_) -> Row {   // item_row with this workgroup's statistics
+    return a.bn_z ? row_load_bn(a.bn_z, stat + 384, id, a.stride, d4_, q_) : row_load(a.V, id, a.stride, d4_, q_);
+  };
 
   // ---- gather: 16-lane group `grp` owns user row grp, item row grp (and the anchor row) --
   {
@@ -96,9 +183,9 @@ __global__ void __launch_bounds__(512) shared_tile_kernel(StepArgs a, const int3
     if (tid < kTile) sPos[tid] = GROUP ? pv.inverse[bi * kTile + tid] : bi * kTile + tid;
     NNCF_STAMP(1);
     Row r0 = row_load(a.U, id0, a.stride, d4, q);
-    Row r1 = (id1 >= 0) ? item_row(a, id1, d4, q) : row_zero();
+    Row r1 = (id1 >= 0) ? item_row_s(id1, d4, q) : row_zero();
     Row r2 = row_zero();
-    if (PAIR) r2 = GROUP ? item_row(a, id2, d4, q) : row_load(a.U, id2, a.stride, d4, q);
+    if (PAIR) r2 = GROUP ? item_row_s(id2, d4, q) : row_load(a.U, id2, a.stride, d4, q);
     if (NU || bj == 0) {
       const float ss = row16_sum(row_dot_partial(r0, r0));
       if (bj == 0 && q == 0) ws.reg_part[gi] = ss;
@@ -434,7 +521,9 @@ void launch_pair(const StepArgs& a, const int32_t* uid, const int32_t* cid, cons
   const int nb = a.b / kTile;
   {
     ProfScope _ps("shared_tile_kernel", stream);
-    hipLaunchKernelGGL((shared_tile_kernel<LOSS, GROUP, NU, NV>), dim3(nb, nb), dim3(512), 0, stream, a, uid, cid, ws, pv);
+    SharedWs w = ws;
+    w.st_update = update;
+    hipLaunchKernelGGL((shared_tile_kernel<LOSS, GROUP, NU, NV>), dim3(nb, nb), dim3(512), 0, stream, a, uid, cid, w, pv);
   }
   const int max_chunks = (a.b + kChunkSlots - 1) / kChunkSlots;  // per id list; + the loss workgroup
   {

@@ -986,10 +986,14 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   // shared schemes with a pointwise loss: ONE launch does statistics + scores + loss + both updates
   const bool one_launch = (scheme == 1 || scheme == 2) && shared_step_fuses(m, sa);
   const bool wb = cells != nullptr && update && wordbwd_applies(t, m, scheme);   // one-launch backward: no count matrix
-  int rc = tower_forward(t, uniq_g, n, n_u, 1, update && !wb, scale, nullptr, st, one_launch);
+  // shared schemes on the tile + apply pair (pairwise losses, bias): the tile workgroups derive the statistics too
+  // (NNCF_TILE_STATS=launch keeps the tower_stats launch: measurement / tests)
+  static const bool tile_stats_launch = getenv("NNCF_TILE_STATS") != nullptr;
+  const bool tile_stats = (scheme == 1 || scheme == 2) && !one_launch && m->tile_ok && !tile_stats_launch;
+  int rc = tower_forward(t, uniq_g, n, n_u, 1, update && !wb, scale, nullptr, st, one_launch || tile_stats);
   if (rc) return rc;
   FusedArgs fa;
-  if (one_launch) {
+  if (one_launch || tile_stats) {
     fa.stats = t->ws + ws_muinv();
     fa.gamma = t->prm.bn_gamma;
     fa.beta = t->prm.bn_beta;
@@ -1010,7 +1014,7 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   else if (scheme == 3)
     rc = launch_rowwise(sa, uid, cid_local, y, m->rws, pu, pv, n, loss, update, st);
   else
-    rc = shared_step(m, sa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, one_launch ? &fa : nullptr);
+    rc = shared_step(m, sa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, (one_launch || tile_stats) ? &fa : nullptr);
   if (rc || !update) return rc;
   if (big) {
     TowerArgs ma = t->last;
