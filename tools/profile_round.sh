@@ -52,6 +52,9 @@ python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | t
 python3 bench.py --large --batch 4096 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b4096.json
 python3 bench.py --large --batch 16384 --steps 50 --warmup 5 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b16384.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_style_steps20.json
+python3 bench.py --model cnn_embedding --scheme group_neg_shared --dim 50 --filter-lens 1,3,5 --conv-dropout 0.3 --dropout 0 --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_default_preset_group_neg_shared.json
+NNCF_TILE_STATS=launch python3 bench.py --scheme group_neg_shared --cpu-seconds 0 --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared_statslaunch.json
+(cd /tmp && rocprofv3 --kernel-trace -d $OUT/prof_tl -o p -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 $B --profile-launches 0 > /dev/null 2>&1); python3 tools/prof_timeline.py $OUT/prof_tl/p_results.db 130 > $OUT/${TAG}_timeline_steps20.txt; rm -rf $OUT/prof_tl
 NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1.json
 python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
