@@ -1,0 +1,45 @@
+"""GPU: bench.py end to end at the quick functional size (--small): the ONE JSON line the driver parses carries the
+contract's fields, the roofline object and the cpu_baseline object, for the headline model and for the id-table
+model; the step count is honoured exactly."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--gpus", "1", "--steps", "8", "--warmup", "3",
+           "--cpu-seconds", "1", "--recall-epochs", "1"] + list(extra)
+    out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [(), ("--model", "mf"), ("--scheme", "group_neg_shared")])
+def test_bench_line_contract(extra):
+    j = _run(*extra)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["metric"].startswith("positive-links/sec") and j["unit"] == "positive-links/s"
+    assert (j["n_gpus"], j["steps"], j["warmup"]) == (1, 8, 3) and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and "synthetic" in j["data"]
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 0 and abs(j["value"] - 512 * 1e3 / j["ms_per_step"]) <= 1e-6 * j["value"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0 < r["frac"] < 1
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
