@@ -201,3 +201,30 @@ def test_data_parallel_run_epoch_equals_plain_epoch():
         np.testing.assert_allclose(getattr(dp.be.tower, name).cpu().numpy(), getattr(plain.core.tower, name).cpu().numpy(),
                                    rtol=1e-4, atol=2e-6, err_msg=name)
     np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_sharded_large_batch_world1():
+    """The large-batch regime of config 4 through the sharded path at world 1: b = 4,096 links per step -- the
+    4,096-entry request plan, the wide one-launch step exporting the item gradients, gather / scatter of 4,096 landing
+    rows -- three chunked steps == the serial oracle; rows nobody touched stay bit-identical."""
+    users, items, b, d, steps = 6000, 5000, 4096, 32, 3
+    kw = dict(user_count=users, item_count=items, dim=d, batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=128., u_reg=1e-6, learn_rate=0.05, normalize_user=False, normalize_item=False)
+    be = HipBackend(kw, users, items, 0, world=1, item_shard=items, item_offset=0, seed=3)
+    U0, V0 = be.U.cpu().numpy().copy(), be.V.cpu().numpy().copy()
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-6, learn_rate=0.05, model_choice="mf")
+    orc = so.StepOracle(U0, V0, conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, users, steps * b)
+    cid = np.minimum((items * rs.power(0.5, steps * b)).astype(np.int64), items - 1)
+    tr = ShardedNegShared(be, users, items, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(losses[t].item() - want) <= 1e-5 * max(1, abs(want)), (t, losses[t].item(), want)
+    U1, V1 = be.U.cpu().numpy(), be.V.cpu().numpy()
+    np.testing.assert_allclose(U1, orc.U, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(V1, orc.V, rtol=1e-5, atol=1e-5)
+    idle_u, idle_v = np.setdiff1d(np.arange(users), uid), np.setdiff1d(np.arange(items), cid)
+    assert np.array_equal(U1[idle_u], U0[idle_u]) and np.array_equal(V1[idle_v], V0[idle_v])

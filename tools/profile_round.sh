@@ -57,5 +57,6 @@ NNCF_TILE_STATS=launch python3 bench.py --scheme group_neg_shared --cpu-seconds 
 (cd /tmp && rocprofv3 --kernel-trace -d $OUT/prof_tl -o p -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 $B --profile-launches 0 > /dev/null 2>&1); python3 tools/prof_timeline.py $OUT/prof_tl/p_results.db 130 > $OUT/${TAG}_timeline_steps20.txt; rm -rf $OUT/prof_tl
 NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1_b8192.json
 python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
 ls -la $OUT/${TAG}_*
