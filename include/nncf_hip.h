@@ -466,6 +466,11 @@ int nncf_gather_rows(const float* d_table, int32_t row_stride, int32_t dim, cons
 int nncf_scatter_apply(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_ids, int32_t n,
                        int32_t id_offset, const float* d_rows, float lr, int32_t* d_plan_ws, void* stream);
 int64_t nncf_scatter_apply_ws_ints(int32_t n);
+/* nncf_scatter_merge: the same update for request blocks d_req[n_ranks][cap] (each block ascending in id, -1 padded at
+ *   its tail, an id at most once per block) and their gradient rows d_rows[n_ranks * cap][dim]: rows of the same id are
+ *   summed in rank order and the table row is stepped once -- no plan, no scratch, any n_ranks * cap. */
+int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_req, int32_t n_ranks, int32_t cap,
+                       int32_t id_offset, const float* d_rows, float lr, void* stream);
 
 /* Chunked item-sharded neg_shared trainer (no reference counterpart; SURVEY.md 8(e), BASELINE configs[3]): one
  * object per rank around a model whose "item table" is the landing buffer of fetched rows (n_ranks * batch_size_p
@@ -474,7 +479,7 @@ int64_t nncf_scatter_apply_ws_ints(int32_t n);
  *   nncf_shard_plan        routes (unique ids per owner, request slot of every batch position) and the duplicate
  *                          plans of the local steps, batched; fills req_out [n_ranks][64][batch_size_p] (-1 padded)
  *   (host: ONE all-to-all of req_out -> req_in for the whole chunk)
- *   nncf_shard_plan_owner  owner-side scatter plans of every step; gathers the rows of step 0 into rows_out
+ *   nncf_shard_plan_owner  regroups the received ids per step; gathers the rows of step 0 into rows_out
  * and per step i only
  *   (host: all-to-all rows_out -> rows_in)
  *   nncf_shard_step        the local step on (user shard, landed rows): loss, user rows updated, item gradients

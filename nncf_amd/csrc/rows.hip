@@ -59,9 +59,58 @@ __global__ void __launch_bounds__(256) scatter_apply_kernel(float* __restrict__ 
       });
 }
 
+// Owner side of a sharded step WITHOUT a sort: every rank's request block is ascending in id (route kernels; the
+// -1 padding at the tail compares as the largest unsigned value), and a rank asks for an id at most once -- so
+// the gradients of an id are at most one row per rank.  The 16-lane group of (rank r, slot k) looks its id up in
+// the blocks of the other ranks by binary search: if a lower rank asked for it too, that rank's group owns the
+// sum; otherwise this group adds the higher ranks' rows in rank order (fixed order, no atomics, no plan, any
+// number of requests) and steps the row.
+__global__ void __launch_bounds__(256) scatter_merge_kernel(float* __restrict__ table, int stride, int d, float lr,
+                                                            const float* __restrict__ rows, int id_offset,
+                                                            const int32_t* __restrict__ req, int ranks, int cap) {
+  const int64_t idx = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int q = threadIdx.x & 15, d4 = d >> 2;
+  if (idx >= (int64_t)ranks * cap) return;
+  const int id = req[idx];
+  if (id < 0) return;
+  const int r = (int)(idx / cap);
+  auto find = [&](int rr) -> int {   // slot of `id` in rank rr's block, or -1
+    const int32_t* blk = req + (int64_t)rr * cap;
+    int lo = 0, hi = cap;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)blk[mid] < (uint32_t)id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < cap && blk[lo] == id) ? lo : -1;
+  };
+  for (int rr = 0; rr < r; ++rr)
+    if (find(rr) >= 0) return;
+  Row acc = row_load(rows, idx, d, d4, q);
+  for (int rr = r + 1; rr < ranks; ++rr) {
+    const int s = find(rr);
+    if (s >= 0) acc = row_add(acc, row_load(rows, (int64_t)rr * cap + s, d, d4, q));
+  }
+  const Row raw = row_load(table, id - id_offset, stride, d4, q);
+  row_store(table, id - id_offset, stride, d4, q, row_fma(-lr, acc, raw));
+}
+
 }  // namespace nncf
 
 using namespace nncf;
+
+extern "C" int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_req, int32_t n_ranks,
+                                  int32_t cap, int32_t id_offset, const float* d_rows, float lr, void* stream) {
+  NNCF_REQUIRE(d_table && d_req && d_rows, "NULL argument");
+  NNCF_REQUIRE(n_ranks >= 1 && cap >= 1 && dim > 0 && dim % 4 == 0 && dim <= 128 && row_stride >= dim, "bad shape");
+  const int64_t n = (int64_t)n_ranks * cap;
+  {
+    ProfScope _ps("scatter_merge_kernel", as_stream(stream));
+    hipLaunchKernelGGL(scatter_merge_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, as_stream(stream), d_table, row_stride, dim,
+                       lr, d_rows, id_offset, d_req, n_ranks, cap);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
 
 static void carve_plan(PlanView& v, int32_t* p, int n) {
   v.list_stride = n;
@@ -147,7 +196,6 @@ struct nncf_shard {
   int32_t* slot = nullptr;                         // [kPlanChunk][b]  request slot of every batch position
   float *rows_out = nullptr, *g_out = nullptr, *g_in = nullptr;   // [ranks*cap][d]; rows land in the model's item table
   nncf::PlanView plan_id;                          // by item id (routing), kPlanChunk lists of b
-  nncf::PlanView plan_own;                         // owner side, kPlanChunk lists of ranks*cap
 };
 
 namespace nncf {
@@ -208,7 +256,6 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     v.aux = cap > 8192 ? c.take<int32_t>(kPlanChunk * cap) : nullptr;
   };
   plan(h->plan_id, h->b);
-  plan(h->plan_own, n);
 }
 
 extern "C" {
@@ -221,8 +268,6 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t row_stride, in
   NNCF_REQUIRE(n_ranks >= 1 && item_shard > 0 && item_offset >= 0, "bad shard shape");
   NNCF_REQUIRE(row_stride >= m->cfg.dim && row_stride % 4 == 0, "bad row stride");
   NNCF_REQUIRE(m->cfg.batch_size_p % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
-  NNCF_REQUIRE((int64_t)n_ranks * m->cfg.batch_size_p <= 16384, "n_ranks * batch_size_p = %lld exceeds the scatter plan capacity 16384",
-               (long long)n_ranks * m->cfg.batch_size_p);
   NNCF_REQUIRE(m->cfg.item_count >= (int64_t)n_ranks * m->cfg.batch_size_p, "the model's item table must hold n_ranks * batch_size_p landing rows");
   nncf_shard* h = new (std::nothrow) nncf_shard();
   if (!h) return fail(NNCF_ERR_NOMEM, "out of host memory");
@@ -291,8 +336,6 @@ int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, void* stream) {
   hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)((n * n_steps + 255) / 256)), dim3(256), 0, st, h->req_in, h->req_step,
                      h->ranks, h->cap, (int)n_steps);
   NNCF_HIP_CHECK(hipGetLastError());
-  int rc = launch_plan(h->req_step, n, (int)n, nullptr, 0, 0, h->plan_own, n_steps, st);
-  if (rc) return rc;
   float* rows_out = h->rows_out ? h->rows_out : h->m->V;
   return nncf_gather_rows(h->V, h->stride, h->d, h->req_step, n, h->i0, rows_out, stream);   // rows of step 0
 }
@@ -318,11 +361,10 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
   NNCF_REQUIRE(index >= 0 && index < n_steps && n_steps <= kPlanChunk, "plan slot out of range");
   hipStream_t st = as_stream(stream);
   const int64_t n = (int64_t)h->ranks * h->cap;
-  const int chunks = (int)((n + kChunkSlots - 1) / kChunkSlots);
   {
-    ProfScope _ps("scatter_apply_kernel", st);
-    hipLaunchKernelGGL(scatter_apply_kernel, dim3(chunks), dim3(256), 0, st, h->V, h->stride, h->d, lr, h->g_in, h->i0,
-                       h->plan_own.at(index));
+    ProfScope _ps("scatter_merge_kernel", st);
+    hipLaunchKernelGGL(scatter_merge_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, h->V, h->stride, h->d, lr, h->g_in,
+                       h->i0, h->req_step + index * n, h->ranks, h->cap);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   if (index + 1 < n_steps) {   // rows of the next step, after this step's update (synchronous SGD)

@@ -131,6 +131,42 @@ def test_gather_and_scatter_apply_rows():
     assert torch.equal(table, table2)
 
 
+@pytest.mark.parametrize("ranks,cap,n_rows", [(8, 512, 3000), (3, 100, 40), (8, 8192, 200000), (1, 64, 500)])
+def test_scatter_merge_of_sorted_request_blocks(ranks, cap, n_rows):
+    """Owner side of a sharded step (nncf_scatter_merge, what nncf_shard_apply runs): `ranks` request blocks, each
+    ascending in id with -1 padding at its tail, ids shared between ranks; the rows of an id are added in rank order
+    and the table row is stepped once -- against numpy, bitwise run to run, for 8 x 8,192 requests too (no plan)."""
+    import ctypes
+    from nncf_amd import _lib
+    L = _lib.lib()
+    d = 24
+    rs = np.random.RandomState(ranks * 1000 + cap)
+    req = np.full((ranks, cap), -1, dtype=np.int32)
+    for r in range(ranks):
+        k = min(rs.randint(cap // 2, cap + 1), n_rows)    # few table rows: most ids are shared by several ranks
+        req[r, :k] = np.sort(rs.choice(n_rows, k, replace=False))
+    rows = rs.rand(ranks * cap, d).astype(np.float32)
+    table0 = rs.rand(n_rows, d).astype(np.float32)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    req_t, rows_t = torch.as_tensor(req).cuda(), torch.as_tensor(rows).cuda()
+    outs = []
+    for _ in range(2):
+        table = torch.as_tensor(table0).cuda()
+        _lib.check(L.nncf_scatter_merge(p(table), d, d, p(req_t), ranks, cap, 0, p(rows_t), 0.5, _lib.stream_ptr()))
+        outs.append(table)
+    assert torch.equal(outs[0], outs[1])
+    acc = np.zeros_like(table0)
+    flat = req.reshape(-1)
+    for r in range(ranks):        # rank order, float32 like the kernel
+        sl = slice(r * cap, (r + 1) * cap)
+        ok = flat[sl] >= 0
+        acc[flat[sl][ok]] += rows[sl][ok]
+    ref = table0 - np.float32(0.5) * acc
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    untouched = np.setdiff1d(np.arange(n_rows), flat[flat >= 0])
+    assert np.array_equal(outs[0].cpu().numpy()[untouched], table0[untouched])
+
+
 @pytest.mark.parametrize("model,optimizer", [("basic_embedding", "sgd"), ("cnn_embedding", "sgd"), ("cnn_embedding", "adam")])
 def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
     """HipTowerReplica + DataParallelTower without a process group (gradients exported to the flat
