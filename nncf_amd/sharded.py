@@ -80,7 +80,6 @@ class HipBackend(object):
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         L = _lib.lib()
         self._ws_route = i32(int(L.nncf_scatter_apply_ws_ints(self.b)))
-        self._ws_apply = i32(int(L.nncf_scatter_apply_ws_ints(n)))
 
     def ids(self, x):
         return self.engine.ids(x)
@@ -112,10 +111,11 @@ class HipBackend(object):
         return self._loss, self.g_out
 
     def scatter_apply(self, req_in, g_in):
+        """owner side: req_in [world][cap] as the all-to-all delivered it (every rank's block ascending in id, -1 padded),
+        g_in the matching gradient rows: rows of an id summed in rank order, the shard row stepped once"""
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        self._lib.check(self._lib.lib().nncf_scatter_apply(p(self.V), self.dim, self.dim, p(req_in), req_in.numel(),
-                                                           self.i0, p(g_in), self.lr, p(self._ws_apply),
-                                                           self._stream()))
+        self._lib.check(self._lib.lib().nncf_scatter_merge(p(self.V), self.dim, self.dim, p(req_in), self.world, self.cap,
+                                                           self.i0, p(g_in), self.lr, self._stream()))
 
     # -- chunked protocol (nncf_shard_*): plans and the id exchange of up to CHUNK steps batched ------------
     CHUNK = 64
