@@ -44,8 +44,13 @@ struct CnnArgs {
   int z_acc;                 // pooling pass: add this bank's h.Wd to the z the earlier banks left (0: start from bd)
   int last;                  // pooling pass, inference: this bank completes z -> BatchNorm -> ReLU -> E
   int dx_acc;                // conv backward: add to the dX of the earlier banks (0: store)
+  long long gexp_off;        // this bank's [Wk | bc, g1, b1 (128 each)] block in the flat gradient, from the start of the conv section
 };
 constexpr int kConvLB = 112;  // positions per workgroup of the conv backward
+struct CnnBanks {             // all banks of a tower (kernels that walk the whole flat gradient)
+  int nb;
+  CnnArgs b[4];
+};
 
 struct TowerArgs {
   // parameters
@@ -231,7 +236,7 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
 #pragma unroll
       for (int gg = 0; gg < kCnnUpdGroups; ++gg) gsum += sG[gg * 128 + c];
       if (a.gexp) {  // data-parallel step: the gradient leaves, nothing is applied here
-        a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + el] = gsum;
+        a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + (size_t)a.cnn.gexp_off + el] = gsum;
         return;
       }
       const float nw = a.opt ? adam1(gsum, a.cnn.mC + el, a.cnn.vC + el, a.cnn.Wk[el], a) : a.cnn.Wk[el] - a.lr * gsum;
@@ -251,7 +256,7 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
   for (int gg = 0; gg < kCnnUpdGroups; ++gg) gb += sG[gg * 128 + c];
   const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
   if (a.gexp) {
-    float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + nel;
+    float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + (size_t)a.cnn.gexp_off + nel;
     gd[c] = gb;
     gd[128 + c] = d2;
     gd[256 + c] = d1;

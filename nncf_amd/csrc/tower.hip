@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
 
 // Data-parallel training: parameters -= step(scale * g) from an exported (and all-reduced)
 // gradient buffer.  Lazy-sparse Adam skips exactly-zero gradient elements of the word table.
-__global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const float* __restrict__ g, float scale) {
+__global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const float* __restrict__ g, float scale, CnnBanks bs) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t nW = (size_t)a.n_words * a.wd, nel = (size_t)a.hd * a.d;
   if (i < nW) {
@@ -713,22 +713,30 @@ __global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const flo
     *p = a.opt ? adam1(gv, a.mD + j, a.vD + j, *p, a) : *p - a.lr * gv;
     return;
   }
-  // CNN front: Wk (and its transposed copy), conv bias, BN1 scale / shift
-  const int F = a.cnn.F, fl = a.cnn.fl;
-  const size_t k = j - (nel + 384), nelC = (size_t)fl * a.wd * F;
-  if (F == 0 || k >= nelC + 384) return;
-  const float gv = scale * g[i];
-  if (k < nelC) {
-    const float nw = a.opt ? adam1(gv, a.cnn.mC + k, a.cnn.vC + k, a.cnn.Wk[k], a) : a.cnn.Wk[k] - a.lr * gv;
-    a.cnn.Wk[k] = nw;
-    const int f = (int)(k % F), kw = (int)((k / F) % a.wd), tap = (int)(k / ((size_t)F * a.wd));
-    a.cnn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + kw] = nw;
+  // CNN front, bank after bank: Wk (and its transposed copy), conv bias, BN1 scale / shift
+  size_t k = j - (nel + 384);
+  for (int gb = 0; gb < bs.nb; ++gb) {
+    const CnnArgs& cn = bs.b[gb];
+    const int F = cn.F, fl = cn.fl;
+    const size_t nelC = (size_t)fl * a.wd * F;
+    if (k >= nelC + 384) {
+      k -= nelC + 384;
+      continue;
+    }
+    const float gv = scale * g[i];
+    if (k < nelC) {
+      const float nw = a.opt ? adam1(gv, cn.mC + k, cn.vC + k, cn.Wk[k], a) : cn.Wk[k] - a.lr * gv;
+      cn.Wk[k] = nw;
+      const int f = (int)(k % F), kw = (int)((k / F) % a.wd), tap = (int)(k / ((size_t)F * a.wd));
+      cn.Wt[(int64_t)f * fl * a.wd + tap * a.wd + kw] = nw;
+      return;
+    }
+    const size_t c = (k - nelC) & 127, which = (k - nelC) >> 7;
+    if ((int)c >= F) return;
+    float* p = (which == 0 ? cn.bc : which == 1 ? cn.g1 : cn.b1) + c;
+    *p = a.opt ? adam1(gv, cn.mC + k, cn.vC + k, *p, a) : *p - a.lr * gv;
     return;
   }
-  const size_t c = (k - nelC) & 127, which = (k - nelC) >> 7;
-  if ((int)c >= F) return;
-  float* p = (which == 0 ? a.cnn.bc : which == 1 ? a.cnn.g1 : a.cnn.b1) + c;
-  *p = a.opt ? adam1(gv, a.cnn.mC + k, a.cnn.vC + k, *p, a) : *p - a.lr * gv;
 }
 
 __global__ void tower_scale_kernel(TowerArgs a, float* __restrict__ out) {
@@ -1088,6 +1096,7 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
       c.rm1 = prm->bn1_mean + 128 * g; c.rv1 = prm->bn1_var + 128 * g;
       c.item_spos = prm->item_spos; c.item_start = prm->item_start;
       c.c_off = g * c.F;
+      c.gexp_off = taps * cfg->word_dim * c.F + 384 * g;
       if (const char* e = getenv("NNCF_CNN_DBG")) c.dbg = atoi(e);
       taps += c.fl;
     }
@@ -1205,14 +1214,12 @@ int64_t nncf_tower_grad_floats(const nncf_tower* t) {
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
-  NNCF_REQUIRE(t->nb <= 1 || !d_grad, "gradient export (data-parallel training) with a filter bank is not built");
   t->gexp = d_grad;
   return NNCF_OK;
 }
 
 int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream) {
   NNCF_REQUIRE(t && d_grad, "NULL argument");
-  NNCF_REQUIRE(t->nb <= 1, "applying exported gradients (data-parallel training) with a filter bank is not built");
   TowerArgs a = base_args(t);
   a.opt = t->opt;
   if (t->opt) {
@@ -1225,9 +1232,12 @@ int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int6
     if (step_t <= 0) t->adam_t++;
   }
   const int64_t n = nncf_tower_grad_floats(t);
+  CnnBanks bs{};
+  bs.nb = t->nb;
+  for (int g = 0; g < t->nb; ++g) bs.b[g] = t->bank_at(g);
   {
     ProfScope _ps("tower_apply_kernel", as_stream(stream));
-    hipLaunchKernelGGL(tower_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, d_grad, scale);
+    hipLaunchKernelGGL(tower_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, d_grad, scale, bs);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -167,7 +167,8 @@ def test_scatter_merge_of_sorted_request_blocks(ranks, cap, n_rows):
     assert np.array_equal(outs[0].cpu().numpy()[untouched], table0[untouched])
 
 
-@pytest.mark.parametrize("model,optimizer", [("basic_embedding", "sgd"), ("cnn_embedding", "sgd"), ("cnn_embedding", "adam")])
+@pytest.mark.parametrize("model,optimizer", [("basic_embedding", "sgd"), ("cnn_embedding", "sgd"), ("cnn_embedding", "adam"),
+                                             ("cnn_bank", "sgd"), ("cnn_bank", "adam")])
 def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
     """HipTowerReplica + DataParallelTower without a process group (gradients exported to the flat
     buffer, then applied by nncf_tower_apply_grads) == the plain in-place step of the text-tower models."""
@@ -183,6 +184,9 @@ def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
           "num_filters": [20], "filter_lengths": [3], "conv_dropout_rate": 0., "optimizer": optimizer}
     if optimizer != "sgd":
         pd["learn_rate"] = 0.01
+    if model == "cnn_bank":    # the `default` preset's filter bank: the flat gradient carries one conv block per length
+        model = "cnn_embedding"
+        pd["filter_lengths"] = [[1, 3, 5]]
     conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2) for _ in range(2)]
     dp = DataParallelTower(HipTowerReplica(mds[0], "neg_shared"))
