@@ -8,20 +8,25 @@ CiteULike-a-shaped data set (16K users x 17K items x 200K links, item text L = 2
 BASELINE configs[1]: basic_embedding, train_scheme = neg_shared, as the demo scripts run it
 (--conf_choice best: word-row dropout 0.5) --
     duplicate plan + tf.unique -> text tower forward of the batch's unique items (word-row gather +
-    mean, Dense, BatchNorm statistics; BN + ReLU applied when the step kernels load an item row)
-    -> U.V^T shared-negative tile -> loss gradient -> back-GEMMs -> sparse SGD on the user rows
-    -> tower backward (BN / Dense by MFMA, sparse SGD on the word table)
+    mean, Dense; BatchNorm statistics derived by the step kernel, BN + ReLU applied when it loads an
+    item row) -> ONE launch: U.V^T shared-negative scores -> loss gradient -> back-GEMMs -> sparse SGD
+    on the user rows, item gradients exported -> tower backward (BN / Dense by MFMA, sparse SGD on the
+    word table)
 with all inputs (link list, content matrix, parameters) resident in HBM before the timed region
 and no host synchronisation between steps: the trainer loop (models/train_neg_shared.py:46-59)
 runs inside one native call (nncf_tower_epoch / nncf_epoch_*).  --model mf runs the id-table
-towers alone; --gpus N > 1 runs the item-sharded id-table path.  Prints ONE JSON line (rank 0).
+towers alone.  --gpus N > 1 (the parent starts its own N ranks unless it already runs under torchrun):
+data-parallel text tower for the default model, the item-sharded id-table path for --model mf.
+Prints ONE JSON line (rank 0).
 
 The line also carries
   roofline     -- the dominant kernel of the step by time: algorithmic bytes / flops per launch
-                  (stated in `algorithmic_what`) / its mean duration measured with
-                  HIP events on the launch stream in a second pass over the same steps
-                  (roofline_other_kernels: the same for the other heavy kernels);
-  cpu_baseline -- the numpy oracle of the same step (oracle/step_oracle.py, kind "port")
+                  (stated in `algorithmic_what`) / its mean duration: the rocprofv3
+                  kernel-trace average committed under profiles/ while its source hash matches the
+                  current kernels, else HIP events on the launch stream in a second pass over the same
+                  steps (`kernel_ms_source` says which; roofline_other_kernels: the other heavy kernels);
+  cpu_baseline -- the CPU restatement of the same step (oracle/step_torch.py: torch-CPU autograd at 1 / 8 /
+                  32 threads; cnn_embedding: the numpy oracle; kind "port") and the C sampler on one core,
                   timed on this box's host cores on a bounded sample of the same workload.
 """
 import argparse
