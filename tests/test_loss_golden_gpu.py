@@ -23,6 +23,21 @@ RUNNABLE = [i for i, c in enumerate(CASES) if not (c["family"] in SHARED and c["
 IDS = ["%d-%s-%s-%s" % (i, CASES[i]["family"], CASES[i]["loss"], CASES[i]["tag"]) for i in RUNNABLE]
 
 
+def _wide_cases():
+    """pointwise shared-negative cases without bias: the ones the one-launch step runs -- again through its large-batch
+    kernel (fused_wide_kernel, 2 and 4 row tiles per workgroup), forced at the goldens' sizes"""
+    return [i for i in RUNNABLE if CASES[i]["family"] in SHARED and CASES[i]["loss"] in ("skip-gram", "mse")
+            and not CASES[i]["bias"] and CASES[i]["b"] % 16 == 0]
+
+
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("i", _wide_cases(), ids=["%d-%s-%s-%s" % (i, CASES[i]["family"], CASES[i]["loss"], CASES[i]["tag"])
+                                                  for i in _wide_cases()])
+def test_wide_kernel_matches_reference_text(i, mt, monkeypatch):
+    monkeypatch.setenv("NNCF_FUSED_MT", str(mt))
+    test_hip_step_matches_reference_text(i)
+
+
 @pytest.mark.parametrize("i", RUNNABLE, ids=IDS)
 def test_hip_step_matches_reference_text(i):
     c, p = CASES[i], "c%d_" % i
