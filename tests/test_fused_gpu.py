@@ -304,3 +304,35 @@ def test_fused_batch_16384():
         assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_random_shapes_terminate_and_match(force_row_tiles, seed):
+    """Random small shapes -- tiny catalogues (few unique rows: most strips empty), one-item / one-user batches, both
+    schemes, 1 / 2 / 4 row tiles -- through two steps each: the in-launch hand-shakes count arrivals from the plans'
+    segment counts, and a miscount would hang the launch; every case must finish and match the oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    b = int(rs.choice([32, 64, 96, 128, 160, 256, 512]))
+    d = int(rs.choice([4, 20, 64, 100, 128]))
+    nu = int(rs.choice([1, 2, 7, 40, 400, 3000]))
+    ni = int(rs.choice([1, 2, 5, 33, 300, 2000]))
+    group = bool(rs.randint(2))
+    loss = str(rs.choice(["skip-gram", "mse"]))
+    force_row_tiles(int(rs.choice([1, 2, 4])))
+    conf, eng, orc = _mk(loss, b, d, nu, ni, "mf", "fused", seed=seed)
+    for step in range(2):
+        uid = rs.randint(0, nu, b)
+        if group:
+            cid = np.repeat(rs.randint(0, ni, b // 4), 4)
+            if len(np.unique(cid)) < 2:      # the reference's group loss divides by (n_u - 1): needs two unique items
+                continue
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            cid = rs.randint(0, ni, b)
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (step, got, want)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=2e-5)
