@@ -937,3 +937,39 @@ def test_cnn_embedding_default_preset_filter_bank(text_data, scheme, loss, drop,
     E = to.forward(items, train=False)
     oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(10))
+def test_text_tower_random_small_batches_terminate_and_match(text_data, seed):
+    """basic_embedding through the one-launch step with very few unique items (1 ... 40 of a 64-row batch: most item
+    strips empty, BatchNorm over a handful of rows) and with users repeated: every case finishes (the in-launch
+    hand-shakes count arrivals from the plans) and matches the oracle."""
+    rs = np.random.RandomState(500 + seed)
+    scheme = ["neg_shared", "group_neg_shared"][seed % 2]
+    loss = ["skip-gram", "mse"][(seed // 2) % 2]
+    conf = _conf(loss, scheme)
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data)
+    head = md["model_neg_shared" if scheme == "neg_shared" else "model_group_neg_shared"]
+    b = conf.batch_size_p
+    n_items = int(rs.choice([2, 3, 5, 17, 40]))
+    n_users = int(rs.choice([1, 3, 50, 300]))
+    pool_items = rs.choice(260, n_items, replace=False)
+    for step in range(2):
+        u = rs.randint(0, n_users, b)
+        c = pool_items[rs.randint(0, n_items, b)]
+        if scheme == "group_neg_shared":
+            c = np.repeat(c[::4], 4)
+            if len(np.unique(c)) < 2:
+                continue
+            want = orc.step_group_neg_shared(u, c)
+        else:
+            want = orc.step_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [np.ones(b)])
+        assert abs(got - want) <= 5e-5 * max(1, abs(want)), (step, got, want)
+        tw = head.core.tower
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+        for name in ("W", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4, err_msg=name)
