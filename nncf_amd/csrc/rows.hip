@@ -183,7 +183,7 @@ extern "C" int64_t nncf_scatter_apply_ws_ints(int32_t n) { return 9 * (int64_t)n
 
 // ---- chunked sharded trainer: plans and exchanges of up to kPlanChunk steps batched ------------------------------
 // (no reference counterpart).  Item ids do not depend on the training state, so for a chunk of
-// steps the routes, the duplicate plans of both sides and the owner-side scatter plans are made by a handful of
+// steps the routes and the duplicate plans of both sides are made by a handful of
 // batched launches, and ONE all-to-all carries the requested ids of the whole chunk.  Per step the host only
 // alternates two native calls with the two collectives that move rows and gradients.
 struct nncf_shard {

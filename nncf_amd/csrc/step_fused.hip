@@ -14,8 +14,12 @@
 //                     -> normalisation backward + regulariser + optimiser step of its 16 rows;
 //   V-pass workgroup  owns 16 unique items, streams all b user rows, the same with S^T.
 // 8 b N d flop instead of 6 b N d (S is computed by both passes), no slabs, no second launch, no
-// float atomics; every table row is written by exactly one 16-lane group.  At b = 16K (config 4's
-// large-batch regime) the same kernel has 2 x 1024 workgroups and is fp32-MFMA bound.
+// float atomics; every table row is written by exactly one 16-lane group.  From b = 4,096 (config 4's
+// large-batch regime) fused_wide_kernel below gives a workgroup 32 / 64 own rows: fp32-MFMA bound.
+//
+// Rows are stepped IN PLACE while other workgroups of the launch stream the same tables: every workgroup
+// announces its last table read and the stores wait for all announcements (FusedArgs::done); a grid
+// that does not fit the device at once stages the gradient rows and a commit launch steps the tables.
 //
 // A user (item) that occurs c times in the batch is ONE row here: its c score rows are identical, so
 //   dL/dS summed over its positions = m g_pos(s) + (c - m) g_neg(s),   m = #positions whose positive

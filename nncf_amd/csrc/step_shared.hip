@@ -16,6 +16,8 @@
 //   loss     d(loss)/dS element-wise on the accumulator registers, parked in LDS;
 //   back     dU += G.V and dV += G^T.U (fp32 MFMA again) against the rows already in LDS;
 //            partial results go to per-block slabs -- no float atomics anywhere.
+//   text towers: every tile workgroup first derives the BatchNorm statistics of the item block (as the
+//            one-launch step does) and applies them on load; tile (0, 0) publishes them (SharedWs::st_out).
 // Kernel B (apply): one 16-lane group per touched table row: sums the slabs (and duplicates
 //   of that row) in a fixed order, adds the pairwise rank-one terms, goes back through the
 //   normalisation, adds the regulariser gradient and writes the row once (sparse SGD).

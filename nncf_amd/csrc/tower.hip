@@ -9,11 +9,13 @@
 //                       DISTINCT words of count * row (4*L*word_dim bytes token-wise, the path's dominant
 //                       traffic), z = h.Wd + bd from the pooled row still in LDS, and the item's (word,
 //                       count) pairs transposed into the word-major count matrix the backward reads
-//   tower_stats_kernel  per-workgroup Welford partials of every column of z
-//   tower_bn_kernel     merge (Chan) -> mu, var; E = relu(gamma (z-mu) rsqrt(var+eps) + beta);
-//                       running statistics
-//   (step kernels: shared tile + apply, or original score + apply)
-//   tower_sums_kernel   dy = dA * [E > 0]; partial column sums of dy and dy*xhat
+//   tower_stats_kernel  shifted column sums of z -> mu, inv, var, fused scale / shift, running statistics
+//                       (`original` and row-wise batches, standalone forwards; the shared-negative step
+//                       kernels derive the statistics themselves: step_fused.hip, step_shared.hip)
+//   tower_bn_kernel     E = relu(z mul + add) for standalone forwards (the step kernels apply it on load)
+//   (step kernels: the one-launch shared-negative step, shared tile + apply, or original score + apply;
+//    their item-side workgroups emit the partial column sums of dy and dy*xhat)
+//   tower_sums_kernel   the same sums for a standalone backward
 //   tower_bwd_kernel    role A: dz rows -> LDS, dh = dz.Wd^T   (fp32 MFMA 16x16x4, 16 rows per WG)
 //                       role B: dWd = h^T.dz, dbd = sum dz     (fp32 MFMA, one 16x16 tile of the
 //                               gradient per workgroup, rows split over its 4 waves)

@@ -234,7 +234,7 @@ class ShardedNegShared(object):
             cnt = min(ch, n_steps - t0)
             be.plan_chunk(uid_local_all[t0 * b:(t0 + cnt) * b], cid_all[t0 * b:(t0 + cnt) * b], cnt)
             self._a2a(bufs["req_in"], bufs["req_out"])                  # all-to-all #1: the chunk's ids -> owners
-            be.plan_owner(cnt)                                           # owner plans; rows of step 0 gathered
+            be.plan_owner(cnt)                                           # received ids regrouped per step; rows of step 0 gathered
             for i in range(cnt):
                 t = t0 + i
                 self._a2a(bufs["rows_in"], bufs["rows_out"])            # all-to-all #2: rows -> requesters
