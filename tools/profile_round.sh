@@ -47,6 +47,7 @@ NNCF_SHARED_PATH=tile python3 bench.py --model mf --cpu-seconds 0 $B 2>/dev/null
 python3 bench.py --model mf --scheme original --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_original.json
 python3 bench.py --model mf --scheme group_neg_shared --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_group_neg_shared.json
 python3 bench.py --large --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared.json
+python3 bench.py --large --device-links 1e9 --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_devicelinks1e9.json
 python3 bench.py --large --scheme original --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_original.json
 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192.json
 python3 bench.py --large --batch 4096 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b4096.json
