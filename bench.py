@@ -249,14 +249,14 @@ def cpu_baseline(args, inp, U0, V0, tower_params):
     res = {}
     prev = torch.get_num_threads()
     # a b = 512 step is too small for hundreds of threads (256 threads: 10 s per step on a 2 x 64-core box);
-    # a few intra-op thread counts are tried and the best one is the multi-thread figure
+    # 1 thread and a few intra-op thread counts are tried; `value` is the best of them, all are in by_threads
     cand = sorted({t for t in (8, 32, nproc) if t <= nproc and (t <= 64 or t == nproc and nproc <= 64)})
     for threads in [1] + cand:
         st = TorchStep(U0, V0 if tower is None else None, conf, tower=tower, threads=threads)
         res[threads] = batches(st, budget / (2.0 if threads == 1 else 2.0 * len(cand)), words)
     torch.set_num_threads(prev)
     rate = {t: s * b / dt for t, (s, dt) in res.items()}
-    best = max(cand, key=lambda t: rate[t]) if cand else 1
+    best = max(rate, key=lambda t: rate[t])     # the CPU at its best, whichever thread count that is (cores = that count)
     return {"value": rate[best], "unit": "positive-links/s", "cores": int(best), "kind": "port",
             "value_1thread": rate[1], "by_threads": {str(t): rate[t] for t in sorted(rate)}, "host_cores": int(nproc),
             "cpu_model": cpu_model_name(), "sampler_samples_per_s_1core": sampler_rate,
