@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTP = 128;       // LDS pitch of pooled rows
 constexpr int kZP = 132;       // LDS pitch of dz rows (16-byte aligned, 4 banks apart)
 constexpr int kTowerWG = 64;   // at most this many workgroups emit statistics partials
-constexpr int kRowsPerK = 1024;  // rows per K-part of the weight-gradient tiles
+constexpr int kRowsPerK = 256;   // rows per K-part of the weight-gradient tiles
 
 // Convolutional front of the cnn_embedding tower (cnn.hip); F == 0: mean-pool tower.
 struct CnnArgs {
