@@ -171,6 +171,16 @@ int nncf_model_set_optimizer(nncf_model* m, int32_t mode, float beta1, float bet
  * step (which folds duplicates into one row) is bypassed; text-tower word tables keep the summed form. */
 int nncf_model_set_sparse_adam_duplicates(nncf_model* m, int32_t as_written);
 int nncf_model_get_step(nncf_model* m, int64_t* out);
+/* The one-launch shared-negative step (no reference counterpart: the reference runs one TF session.run per step,
+ * models/train_neg_shared.py:46-51) steps table rows in place behind an in-launch hand-shake that needs the whole grid
+ * resident at once.  shared != 0: this model does NOT have the device to itself (a second process or rank on the GPU,
+ * an evaluator on a side stream) -> every step takes the stage + commit form, which waits for nothing inside a launch
+ * (same results bit for bit).  Environment default: NNCF_SHARED_DEVICE=1. */
+int nncf_model_set_shared_device(nncf_model* m, int32_t shared);
+/* Synchronises `stream` and reports whether an in-launch wait ever timed out (the wait is bounded: NNCF_FUSED_SPIN_MS,
+ * default 250 ms; a workgroup that times out stores nothing and every later loss of the model reads NaN):
+ * NNCF_OK, or NNCF_ERR_HIP with the explanation in nncf_last_error(). */
+int nncf_model_check(nncf_model* m, void* stream);
 
 /* InteractionDot bias (modules/interaction/interaction_dot.py:62-71,96-107; conf.interaction_bias
  * 'user' | 'item' | 'both'): every score becomes U.V + d_user_bias[uid] + d_item_bias[cid] (training

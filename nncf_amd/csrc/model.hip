@@ -77,7 +77,7 @@ bool shared_step_fuses(const nncf_model* m, const StepArgs& a) {
 int flush_pending_loss(nncf_model* m, hipStream_t st) {
   if (!m->pend_out) return NNCF_OK;
   const int mb = fused_max_blocks(m->cfg.batch_size_p) * fused_split(m->cfg.batch_size_p);
-  const int rc = launch_fused_flush(m->fpart + (size_t)m->pend_parity * mb, m->pend_n, m->pend_out, st);
+  const int rc = launch_fused_flush(m->fpart + (size_t)m->pend_parity * mb, m->pend_n, m->pend_out, m->ferr, st);
   m->pend_out = nullptr;
   return rc;
 }
@@ -107,6 +107,9 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
   f.slab = m->fslab;
   f.cnt = m->fcnt;
   f.done = m->fdone;
+  f.err = m->ferr;
+  f.spin_ticks = m->spin_ticks;
+  f.shared_device = m->shared_device;
   f.stage = m->fstage;   // used only when the launcher finds the grid too large for the device
   f.parity = m->fparity;
   f.loss_part = m->fpart + (size_t)m->fparity * mb;
@@ -164,6 +167,7 @@ void carve(nncf_model* m, Carver& c) {
     m->fslab = c.take<float>(sp > 1 ? 2 * mb * sp * 16 * 128 : 4);
     m->fcnt = c.take<int>(2 * mb);
     m->fdone = c.take<int>(2);
+    m->ferr = c.take<int>(2);
     m->fstage = c.take<float>(2 * (size_t)b * 128);
   }
   m->cap_u = n;  // row-wise batches list a user per row
@@ -240,6 +244,11 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   m->V = d_item_table;
   m->device = device;
   if (const char* e = getenv("NNCF_SHARED_PATH")) m->use_fused = std::string(e) != "tile";
+  if (const char* e = getenv("NNCF_FUSED_SPIN_MS")) {
+    const double ms = atof(e);
+    if (ms > 0) m->spin_ticks = (long long)(ms * 1e5);   // 100 MHz wall clock
+  }
+  if (const char* e = getenv("NNCF_SHARED_DEVICE")) m->shared_device = e[0] == '1';
   Carver dry;
   carve(m, dry);
   {
@@ -341,6 +350,25 @@ int nncf_model_set_bias(nncf_model* m, float* d_user_bias, float* d_item_bias, i
 int nncf_model_set_sparse_adam_duplicates(nncf_model* m, int32_t as_written) {
   if (int rc = check_model(m)) return rc;
   m->dup_as_written = as_written ? 1 : 0;
+  return NNCF_OK;
+}
+
+int nncf_model_set_shared_device(nncf_model* m, int32_t shared) {
+  if (int rc = check_model(m)) return rc;
+  m->shared_device = shared ? 1 : 0;
+  return NNCF_OK;
+}
+
+int nncf_model_check(nncf_model* m, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  int flag = 0;
+  DeviceGuard guard(m->device);
+  NNCF_HIP_CHECK(hipMemcpyAsync(&flag, m->ferr, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
+  NNCF_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  if (flag)
+    return fail(NNCF_ERR_HIP, "a one-launch step timed out waiting for the other workgroups of its launch (they were not "
+                "resident: another process or stream is using this GPU); the tables hold a partial step.  Create the model "
+                "with nncf_model_set_shared_device(m, 1) / NNCF_SHARED_DEVICE=1 on a shared GPU");
   return NNCF_OK;
 }
 

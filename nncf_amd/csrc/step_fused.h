@@ -33,6 +33,13 @@ struct FusedArgs {
   // launcher checks the grid against the device's capacity.
   int* done = nullptr;
   int parity = 0;
+  // the hand-shake's wait is bounded: after spin_ticks of the 100 MHz wall clock a waiting workgroup raises *err,
+  // stores nothing and every later loss of the model is NaN (nncf_model_check reports it).  shared_device (host side
+  // only): the model does not have the device to itself (another process, an evaluator on a side stream) -> the
+  // launcher always takes the stage + commit form, which waits for nothing.
+  int* err = nullptr;
+  long long spin_ticks = 25000000;   // 250 ms
+  int shared_device = 0;
   // set by the launcher when the grid does NOT fit the device at once: no hand-shake -- the gradient rows
   // (normalisation backward and regulariser included) go to stage[side][own slot][128] and
   // fused_commit_kernel, a second launch, steps the tables
@@ -49,6 +56,6 @@ int fused_loss_parts(const StepArgs& a);  // loss partials one launch writes
 constexpr int kFusedMaxSplit = 8;
 int launch_fused(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const FusedArgs& f,
                  const PlanView& pu, const PlanView& pv, int update, hipStream_t stream);
-int launch_fused_flush(const float* part, int n, float* out, hipStream_t stream);
+int launch_fused_flush(const float* part, int n, float* out, const int* err, hipStream_t stream);
 
 }  // namespace nncf

@@ -77,11 +77,22 @@ __device__ __forceinline__ void readers_arrive(const FusedArgs& f) {
 __device__ __forceinline__ int readers_seen(const FusedArgs& f) {
   return __hip_atomic_load(f.done + f.parity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane, followed by __syncthreads(): every reading workgroup of the launch has arrived (`seen`: an earlier poll)
-__device__ __forceinline__ void readers_wait(const FusedArgs& f, int seen, int target) {
-  while (seen < target) {
+// one lane, followed by __syncthreads(): every reading workgroup of the launch has arrived (`seen`: an earlier poll).
+// The wait is BOUNDED (FusedArgs::spin_ticks of the 100 MHz wall clock; a legitimate wait is a few microseconds):
+// if the other workgroups of the launch are not resident -- a co-tenant process or stream holds the compute units the
+// launcher counted on -- the lane raises FusedArgs::err and returns false, the workgroup stores NOTHING, every later
+// loss of the model reads NaN and nncf_model_check() reports the launch.  A loud failure instead of a hung GPU.
+__device__ __forceinline__ bool readers_wait(const FusedArgs& f, int seen, int target) {
+  if (seen >= target) return true;
+  const unsigned long long t0 = wall_clock64();
+  while (true) {
     __builtin_amdgcn_s_sleep(2);
     seen = readers_seen(f);
+    if (seen >= target) return true;
+    if (wall_clock64() - t0 > (unsigned long long)f.spin_ticks) {
+      __hip_atomic_store(f.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
   }
 }
 
@@ -576,9 +587,10 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
     if (tid == 0) {
       const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
       const int nst_u = ((GROUP ? nseg_v : b) + kFNB - 1) / kFNB, nst_v = (b + kFNB - 1) / kFNB;
-      readers_wait(f, seen, ((nseg_u + kFM - 1) / kFM) * min(P, nst_u) + ((nseg_v + kFM - 1) / kFM) * min(P, nst_v));
+      sTop[2] = readers_wait(f, seen, ((nseg_u + kFM - 1) / kFM) * min(P, nst_u) + ((nseg_v + kFM - 1) / kFM) * min(P, nst_v));
     }
     __syncthreads();
+    if (!sTop[2]) return;   // timed out (error raised): no row of this strip is stepped
   }
   FSTAMP(24);
   if (update && own_ok) {
@@ -630,7 +642,7 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
       float l = 0.f;
       for (int i = threadIdx.x; i < f.prev_n; i += 64) l += f.prev_part[i];
       l = wave_sum(l);
-      if (threadIdx.x == 0) *f.prev_out = l;
+      if (threadIdx.x == 0) *f.prev_out = f.err[0] ? __builtin_nanf("") : l;
     }
     if (threadIdx.x == 0) f.done[f.parity ^ 1] = 0;   // the next launch's arrival counter
     return;
@@ -1015,8 +1027,9 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   }
   const bool deferred = f.stage != nullptr;
   if ((USIDE || !a.gV) && !deferred) {   // in-place stores: wait until every strip has streamed its last opposite row
-    if (tid == 0) readers_wait(f, seen, (pu.counts[0] + OWN - 1) / OWN + (pv.counts[0] + OWN - 1) / OWN);
+    if (tid == 0) sTop[2] = readers_wait(f, seen, (pu.counts[0] + OWN - 1) / OWN + (pv.counts[0] + OWN - 1) / OWN);
     __syncthreads();
+    if (!sTop[2]) return;   // timed out (error raised): nothing is stepped
   }
 #pragma unroll
   for (int rr = 0; rr < RPG; ++rr) {
@@ -1045,7 +1058,7 @@ __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32
       float l = 0.f;
       for (int i = threadIdx.x; i < f.prev_n; i += 64) l += f.prev_part[i];
       l = wave_sum(l);
-      if (threadIdx.x == 0) *f.prev_out = l;
+      if (threadIdx.x == 0) *f.prev_out = f.err[0] ? __builtin_nanf("") : l;
     }
     if (threadIdx.x == 0) f.done[f.parity ^ 1] = 0;
     return;
@@ -1082,23 +1095,41 @@ __global__ void __launch_bounds__(256) fused_commit_kernel(StepArgs a, FusedArgs
   apply_update(a, side ? a.av : a.au, table, id, raw, grad, d4, q);
 }
 
-__global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+__global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
+                                                              const int* __restrict__ err) {
   float l = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) l += part[i];
   l = wave_sum(l);
-  if (threadIdx.x == 0) *out = l;
+  if (threadIdx.x == 0) *out = (err && err[0]) ? __builtin_nanf("") : l;   // a timed-out hand-shake poisons the loss
 }
 
 namespace {
 
-// workgroups of `kern` (512 threads, `lds` bytes) the device holds at once; cached by the caller
-int resident_capacity(const void* kern, size_t lds, int* cached) {
-  if (*cached >= 0) return NNCF_OK;
-  int per_cu = 0, dev = 0, cus = 0;
-  NNCF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));
+// Per kernel instantiation AND per device (both hipFuncSetAttribute and the occupancy are per device): the dynamic-LDS
+// opt-in is made and the resident capacity (workgroups of 512 threads / `lds` bytes the device holds at once) looked up
+// the first time a device launches the kernel.
+constexpr int kMaxDevices = 64;
+struct KernelDeviceState {
+  bool attr_set[kMaxDevices] = {};
+  int capacity[kMaxDevices];
+  KernelDeviceState() { for (int i = 0; i < kMaxDevices; ++i) capacity[i] = -1; }
+};
+
+int prepare_kernel(const void* kern, size_t lds, KernelDeviceState& st, int* capacity) {
+  int dev = 0;
   NNCF_HIP_CHECK(hipGetDevice(&dev));
-  NNCF_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  *cached = per_cu * cus;
+  NNCF_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d beyond %d", dev, kMaxDevices);
+  if (!st.attr_set[dev]) {
+    NNCF_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    st.attr_set[dev] = true;
+  }
+  if (st.capacity[dev] < 0) {
+    int per_cu = 0, cus = 0;
+    NNCF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));
+    NNCF_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    st.capacity[dev] = per_cu * cus;
+  }
+  *capacity = st.capacity[dev];
   return NNCF_OK;
 }
 
@@ -1123,16 +1154,12 @@ int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
              const PlanView& pv, int update, hipStream_t stream) {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
   auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)wide_lds_bytes<MT>()));
-    attr_set = true;
-  }
-  static int capacity = -1;
-  if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), &capacity)) return rc;
+  static KernelDeviceState kds;
+  int capacity = 0;
+  if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), kds, &capacity)) return rc;
   FusedArgs fa = f;
-  if (!(update && (2 * gu > capacity || force_deferred()))) fa.stage = nullptr;   // fits: in place, with the hand-shake
+  // in place (with the hand-shake) only when the whole grid is resident at once on a device this model has to itself
+  if (!(update && (2 * gu > capacity || f.shared_device || force_deferred()))) fa.stage = nullptr;
   {
     ProfScope _ps("fused_wide_kernel", stream);
     hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), wide_lds_bytes<MT>(), stream, a, uid, cid, fa, pu, pv, update, gu);
@@ -1150,16 +1177,12 @@ int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   const int gu = (a.b + kFM - 1) / kFM;
   const int nblk = ((2 * gu + 7) / 8) * 8 * f.split;
   auto kern = fused_strip_kernel<LOSS, GROUP, NU, NV>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)fused_lds_bytes()));
-    attr_set = true;
-  }
-  static int capacity = -1;
-  if (int rc = resident_capacity(reinterpret_cast<const void*>(kern), fused_lds_bytes(), &capacity)) return rc;
+  static KernelDeviceState kds;
+  int capacity = 0;
+  if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), fused_lds_bytes(), kds, &capacity)) return rc;
   FusedArgs fa = f;
-  if (!(update && (nblk > capacity || force_deferred()))) fa.stage = nullptr;   // fits: in place, with the hand-shake
+  // in place (with the hand-shake) only when the whole grid is resident at once on a device this model has to itself
+  if (!(update && (nblk > capacity || f.shared_device || force_deferred()))) fa.stage = nullptr;
   {
     ProfScope _ps("fused_strip_kernel", stream);
     hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, fa, pu, pv, update, gu, nblk);
@@ -1224,8 +1247,8 @@ int launch_fused(const StepArgs& a, int group, const int32_t* uid, const int32_t
                : launch_fn<NNCF_LOSS_MSE, false>(a, uid, cid, f, pu, pv, update, stream);
 }
 
-int launch_fused_flush(const float* part, int n, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(fused_loss_flush_kernel, dim3(1), dim3(64), 0, stream, part, n, out);
+int launch_fused_flush(const float* part, int n, float* out, const int* err, hipStream_t stream) {
+  hipLaunchKernelGGL(fused_loss_flush_kernel, dim3(1), dim3(64), 0, stream, part, n, out, err);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

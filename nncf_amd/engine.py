@@ -155,6 +155,16 @@ class Engine(object):
     def _stream(self):
         return _lib.stream_ptr(torch.cuda.current_stream(self.device))
 
+    def set_shared_device(self, shared=True):
+        """The GPU is shared with another process / rank / stream: the one-launch step never waits inside a launch
+        (stage + commit form; same results bit for bit).  See nncf_model_set_shared_device."""
+        _lib.check(self._L.nncf_model_set_shared_device(self._h, int(bool(shared))))
+
+    def check(self):
+        """Synchronises the stream; raises RuntimeError if an in-launch wait of the one-launch step ever timed out."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_model_check(self._h, self._stream()))
+
     def set_item_grad_export(self, buf):
         """While `buf` ([rows][dim] fp32) is set, steps leave item rows untouched and write
         dL/d(item row) there instead (text towers above the item block, sharded rows)."""

@@ -336,3 +336,38 @@ def test_fused_random_shapes_terminate_and_match(force_row_tiles, seed):
         assert abs(got - want) <= 2e-5 * max(1.0, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=2e-5)
+
+
+def test_in_launch_wait_is_bounded_and_fails_loudly(monkeypatch):
+    """The read-before-write hand-shake of the in-place step spins on other workgroups of the same launch.  The spin is
+    bounded: with the bound set to ~nothing (NNCF_FUSED_SPIN_MS) a waiting workgroup gives up, stores nothing, raises the
+    model's error flag -- nncf_model_check reports it and every later loss reads NaN -- instead of hanging the GPU
+    (a co-tenant process / stream can keep part of the grid from becoming resident)."""
+    monkeypatch.setenv("NNCF_FUSED_SPIN_MS", "0.00001")     # one tick of the 100 MHz clock
+    b, d, nu, ni = 512, 100, 700, 600
+    conf, eng, orc = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=2)
+    rs = np.random.RandomState(3)
+    losses = []
+    for _ in range(8):
+        # group scheme, 16 unique items: a user strip has ONE stage of columns, an item strip four stages of rows -- the
+        # user strips reach their stores long before the item strips announce their last read: they must wait
+        uid, cid = rs.randint(0, nu, b), np.repeat(rs.choice(ni, 16, replace=False), b // 16)
+        losses.append(eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item())
+    with pytest.raises(RuntimeError, match="timed out"):
+        eng.check()
+    assert np.isnan(losses[-1])
+    # the same workload with the default bound never trips it; and a shared device takes the stage + commit form,
+    # which has no in-launch wait at all: bitwise the same tables
+    monkeypatch.delenv("NNCF_FUSED_SPIN_MS")
+    _, eng_a, _ = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=2)
+    _, eng_b, _ = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=2)
+    eng_b.set_shared_device(True)
+    rs = np.random.RandomState(3)
+    for _ in range(4):
+        uid, cid = _batch(rs, b, nu, ni, False)
+        la = eng_a.step_neg_shared(eng_a.ids(uid), eng_a.ids(cid)).item()
+        lb = eng_b.step_neg_shared(eng_b.ids(uid), eng_b.ids(cid)).item()
+        assert la == lb and np.isfinite(la)
+    eng_a.check()
+    eng_b.check()
+    assert torch.equal(eng_a.U, eng_b.U) and torch.equal(eng_a.V, eng_b.V)
