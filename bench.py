@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--dump-stamps", default=None, help="developer: with NNCF_DEBUG_TIMING=1, save the step kernel's in-kernel "
                                                         "cycle stamps of the last launch to this .npy (tools/fused_timing.py)")
     ap.add_argument("--roofline-kernel", default=None, help="HIP kernel to bracket (default: per workload)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--gpus N > 1, --model mf: weak = b links per GPU and step (default); strong = ONE global batch of b "
+                         "links per step split by rows over the GPUs (the one-device step's result; SURVEY.md 8(e))")
     ap.add_argument("--small", action="store_true", help="2K x 2K x 20K data (quick functional run)")
     ap.add_argument("--device-links", type=float, default=0,
                     help="--large only: generate this many (user, item) links ON THE DEVICE (Zipf-like over 10M users / 1M items, "
@@ -395,6 +398,32 @@ def rocprof_duration_ms(args, conf, d, kernel):
     return us * 1e-3 if us else None
 
 
+def rank_windows(run_window, K, device):
+    """N > 1: the timed windows of every rank -- barrier + synchronise on both sides of EXACTLY K steps, the window's
+    time = MAX over ranks (so all ranks take the same repeat decisions); returns (median seconds, stats)."""
+    import torch
+    import torch.distributed as dist
+
+    def window():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_window()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dist.barrier()
+        return t1 - t0
+
+    def reduce_max(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    times = timed_windows(window, reduce_max)
+    return window_stats(times, K)
+
+
 def main_data_parallel(args, rank, world, local_rank):
     """N > 1, model_choice = basic_embedding / cnn_embedding: one process per GPU, users + their links
     partitioned by user range, text tower replicated, ONE RCCL all-reduce of the tower gradients per
@@ -431,51 +460,60 @@ def main_data_parallel(args, rank, world, local_rank):
     eng = rep.engine
     uid, cid = eng.ids(stream[:, 0]), eng.ids(stream[:, 1])
     losses = torch.zeros(K, dtype=torch.float32, device=eng.device)
+    want_cpu = rank == 0 and args.cpu_seconds > 0
+    U0 = eng.U.cpu().numpy().copy() if want_cpu else None
+    tower_params = None
+    if want_cpu:
+        tw = rep.tower
+        names_p = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta") if args.model == "cnn_embedding" else \
+            ("W", "Wd", "bd", "gamma", "beta")
+        if getattr(tw, "nb", 0) > 1:
+            want_cpu = False      # filter banks: the N = 1 line carries their CPU figure
+        else:
+            tower_params = [getattr(tw, n).cpu().numpy().copy() for n in names_p]
 
     def run(first, count, keep):
         tr.run_epoch(uid[first * b:(first + count) * b], cid[first * b:(first + count) * b], count, b, losses if keep else None)
 
     trace("warmup")
     run(0, W, False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    trace("timed region")
-    t0 = time.perf_counter()
-    run(W, K, True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    trace("timed region done")
-    dist.barrier()
-    t = torch.tensor([t1 - t0], dtype=torch.float64, device=eng.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    trace("timed windows")
+    elapsed, win_stats = rank_windows(lambda: run(W, K, True), K, eng.device)
+    trace("timed windows done")
     ml = losses.double().mean()
     dist.all_reduce(ml)
     mean_loss = float(ml.item()) / world
     if not np.isfinite(mean_loss):
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)
-    # roofline leg (all ranks step together; rank 0's brackets are reported)
+    # roofline leg (all ranks step together; rank 0's brackets are reported): the SAME kernel as the N = 1 line
     L = args.content_len if not args.small else min(args.content_len, 40)
-    keep = 1.0 - args.dropout
     cnn = args.model == "cnn_embedding"
-    name = args.roofline_kernel or ("cnn_conv_bwd_kernel" if cnn else "tower_word_kernel")
+    pointwise = pconf.loss in ("skip-gram", "mse")
+    name = args.roofline_kernel or ("cnn_conv_bwd_kernel" if cnn else ("tower_word_kernel" if args.scheme == "original" else
+                                    ("fused_strip_kernel" if pointwise else "shared_tile_kernel")))
     prof_n = min(K, args.profile_launches)
     nengine.profile_begin(name, prof_n)
     run(W, prof_n, False)
     raw_ms, launches, ov_ms = nengine.profile_end()
-    kern_ms = raw_ms   # raw event bracket (includes the marker packets' own cost: errs on the slow side)
+    n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
+    keep = 1.0 - args.dropout
     if name.startswith("cnn_conv"):   # n_u = unique items of the bracketed steps (counted here from the id stream)
-        n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
         mult = 2 if name == "cnn_conv_fwd_kernel" else 4
-        work = mult * n_u * L * args.filter_len * d * d
-        roof = {"bound": "mfma", "achieved": work / (kern_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "what": "%d*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % (mult, n_u)}
+        bound, work = "mfma", mult * n_u * L * args.filter_len * d * d
+        what = "%d*n_u*L*fl*word_dim*F flop, n_u = %.1f unique items per launch" % (mult, n_u)
+    elif name in ("fused_strip_kernel", "shared_tile_kernel"):
+        bound, work = "mfma", 6.0 * b * (n_u if args.scheme == "group_neg_shared" else b) * d
+        what = "6*b*N*d flop (S, G.V, G^T.U); the one-launch kernel issues 8*b*N*d (S recomputed by the item pass)"
     else:
-        n_u = float(np.mean([len(np.unique(stream[t * b:(t + 1) * b, 1])) for t in range(W, W + prof_n)]))
-        work = 4.0 * n_u * L * d * keep
-        roof = {"bound": "hbm", "achieved": work / (kern_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "what": "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % n_u}
+        bound, work = "hbm", 4.0 * n_u * L * d * keep
+        what = "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % n_u
+    roof = roof_entry(name, bound, work, what, raw_ms, ov_ms, launches) if launches else None
+    cpu = None
+    if want_cpu:
+        inp = dict(uid=stream[:, 0], cid=stream[:, 1], data=data,
+                   dist=__import__("nncf_amd.data_utils", fromlist=["degree_dist"]).degree_dist(data["train"], column=1, neg_dist="unigram"))
+        cpu = cpu_baseline(args, inp, U0, None, tower_params)
+    dist.barrier()      # the other ranks wait for rank 0's CPU leg
     tower_txt = ("cnn_embedding (CNN text tower L=%d, vocab=%d, word-row dropout %g, Conv1D(%d filters, length %d)+BN+ReLU+"
                  "Dropout(%g)+avg-pool, Dense+BN+ReLU)" % (L, args.vocab, args.dropout, d, args.filter_len, args.conv_dropout)
                  if cnn else "basic_embedding (mean-pool text tower L=%d, vocab=%d, word-row dropout %g, Dense+BN+ReLU)"
@@ -484,7 +522,7 @@ def main_data_parallel(args, rank, world, local_rank):
         line = {
             "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "windows": win_stats,
             "data": "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links, item text), random-init parameters",
             "config": {"workload": "CiteULike-a-shaped, %s d=%d, train_scheme=%s, loss=%s, b=%d per GPU, sparse SGD"
                                    % (tower_txt, d, args.scheme, pconf.loss, b),
@@ -493,35 +531,42 @@ def main_data_parallel(args, rank, world, local_rank):
                                       "replicated; one RCCL all-reduce of the tower gradients (%.2f MB) per step"
                                       % (rep.grad.numel() * 4 / 1e6)},
             "mean_loss": mean_loss,
-            "roofline": {"kernel": name, "bound": roof["bound"], "achieved": roof["achieved"], "peak": roof["peak"],
-                         "unit": roof["unit"], "frac": roof["achieved"] / roof["peak"], "traffic": None,
-                         "algorithmic_per_launch": work, "algorithmic_what": roof["what"],
-                         "kernel_ms": kern_ms, "event_bracket_ms": raw_ms, "empty_bracket_ms": ov_ms, "launches": launches},
-            "cpu_baseline": None,
+            "roofline": roof,
+            "cpu_baseline": cpu,
         }
         emit(line)
     dist.destroy_process_group()
 
 
 def main_sharded(args, conf, rank, world, local_rank):
-    """N > 1, --model mf: one process per GPU, user/item tables range-sharded, three RCCL all-to-alls
-    per global step (nncf_amd/sharded.py: ShardedNegShared; the north-star's config-4 path).
-    Weak scaling: b positives per rank per step."""
+    """N > 1, --model mf: one process per GPU, user/item tables range-sharded, RCCL all-to-alls of ids (once per 64
+    steps), rows and gradients (per step) with compact variable splits (nncf_amd/sharded.py; the north-star's config-4
+    path).  --scaling weak (default): b positives per rank per step (ShardedNegShared); --scaling strong: ONE global
+    batch of b positives per step split by rows over the ranks (ShardedGlobalBatch: the one-device step's result)."""
     import torch
     import torch.distributed as dist
-    from nncf_amd.sharded import HipBackend, ShardedNegShared, partition_links_by_user, shard_size
+    from nncf_amd import engine as nengine
+    from nncf_amd.sharded import HipBackend, ShardedGlobalBatch, ShardedNegShared, partition_links_by_user, shard_size
     if args.model in ("basic_embedding", "cnn_embedding"):
+        if args.scaling == "strong":
+            raise SystemExit("--scaling strong is built for --model mf (id tables); the text-tower models run data parallel")
         return main_data_parallel(args, rank, world, local_rank)
     if args.model != "mf":
         raise SystemExit("--gpus > 1 is built for the text-tower models (data parallel) and --model mf (item-sharded)")
     if args.scheme != "neg_shared":
         raise SystemExit("--gpus > 1 is built for train_scheme=neg_shared (north-star config 4 path)")
+    strong = args.scaling == "strong"
     data = make_data(args)   # --large: BASELINE configs[3], 10M users x 1M items (only the links the run consumes)
     users, items = int(data["train"][:, 0].max()) + 1, int(data["C"].shape[0])
     b, d = conf.batch_size_p, args.dim
-    mine = partition_links_by_user(data["train"], users, world)[rank].copy()
-    rs = np.random.RandomState(4224 + rank)
-    need = (args.warmup + args.steps) * b
+    W, K = args.warmup, args.steps
+    need = (W + K) * b
+    if strong:
+        mine = data["train"].copy()                 # the global link stream, the same on every rank
+        rs = np.random.RandomState(4224)
+    else:
+        mine = partition_links_by_user(data["train"], users, world)[rank].copy()
+        rs = np.random.RandomState(4224 + rank)
     chunks, have = [], 0
     while have < need:
         rs.shuffle(mine)
@@ -534,50 +579,70 @@ def main_sharded(args, conf, rank, world, local_rank):
               learn_rate=abs(conf.learn_rate), normalize_user=norm, normalize_item=False)   # mf: model_framework.py:85-88
     us, isz = shard_size(users, world), shard_size(items, world)
     be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank,
-                    world=world, item_shard=isz, item_offset=rank * isz, seed=rank)
-    tr = ShardedNegShared(be, users, items, b, d)
-    uid, cid = be.ids(stream[:, 0] - rank * us), be.ids(stream[:, 1])   # user ids relative to my range
-    W, K = args.warmup, args.steps
+                    world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
+                    mode="strong" if strong else "weak", user_shard=us, user_offset=rank * us)
+    if strong:
+        tr = ShardedGlobalBatch(be, users, items, b, d)
+        uid, cid = be.ids(stream[:, 0]), be.ids(stream[:, 1])
+    else:
+        tr = ShardedNegShared(be, users, items, b, d)
+        uid, cid = be.ids(stream[:, 0] - rank * us), be.ids(stream[:, 1])   # user ids relative to my range
     losses = torch.zeros(K, dtype=torch.float32, device=be.device)
-
-    scratch = torch.zeros(max(W, 1), dtype=torch.float32, device=be.device)
+    scratch = torch.zeros(max(W, K, 1), dtype=torch.float32, device=be.device)
 
     def run(first, count, keep):
         # plans + the id all-to-all batched 64 steps at a time; per step: rows -> local step -> gradients -> apply
         tr.run_epoch(uid[first * b:(first + count) * b], cid[first * b:(first + count) * b], count, losses if keep else scratch)
 
     run(0, W, False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(W, K, True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    dist.barrier()
-    t = torch.tensor([t1 - t0], dtype=torch.float64, device=be.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    tr.wire_bytes = 0
+    elapsed, win_stats = rank_windows(lambda: run(W, K, True), K, be.device)
+    wire_per_step = tr.wire_bytes / float(K * win_stats["count"])
+    be.engine.check()
     ml = losses.double().mean()
     dist.all_reduce(ml)
-    mean_loss = float(ml.item()) / world
+    mean_loss = float(ml.item()) / (1 if strong else world)     # strong: a step's loss is the SUM of the ranks' shares
     if not np.isfinite(mean_loss):
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)
+    # roofline leg: the same kernel as the N = 1 line of this model (the one-launch step), rank 0's brackets
+    name = args.roofline_kernel or ("fused_strip_kernel" if (b < 4096 or strong) else "fused_wide_kernel")
+    prof_n = min(K, args.profile_launches)
+    nengine.profile_begin(name, prof_n)
+    run(W, prof_n, False)
+    raw_ms, launches, ov_ms = nengine.profile_end()
+    rows = b // world if strong else b
+    work = 6.0 * rows * b * d
+    roof = roof_entry(name, "mfma", work, "6*rows*b*d flop (S, G.V, G^T.U) of this rank's %d x %d block of the score matrix; the kernel "
+                      "issues 8*rows*b*d (S recomputed by the item pass)" % (rows, b), raw_ms, ov_ms, launches) if launches else None
+    cpu = None
+    if rank == 0 and args.cpu_seconds > 0 and not args.large:
+        rs2 = np.random.RandomState(5)     # timing only: tables of the global shape, rank 0's batches
+        inp = dict(uid=stream[:, 0], cid=stream[:, 1], data=data,
+                   dist=__import__("nncf_amd.data_utils", fromlist=["degree_dist"]).degree_dist(data["train"], column=1, neg_dist="unigram"))
+        cpu = cpu_baseline(args, inp, rs2.uniform(-.05, .05, (users, d)).astype(np.float32),
+                           rs2.uniform(-.05, .05, (items, d)).astype(np.float32), None)
+    dist.barrier()
     if rank == 0:
+        gb = b if strong else b * world
         line = {
-            "metric": "positive-links/sec (train step)", "value": K * b * world / elapsed, "unit": "positive-links/s",
+            "metric": "positive-links/sec (train step)", "value": K * gb / elapsed, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "windows": win_stats,
             "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init tables" if args.large else
                      "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables"),
-            "config": {"workload": "%s, id-table towers (model_choice=mf), item table sharded by id "
-                                   "range, d=%d, train_scheme=neg_shared, loss=%s, b=%d per GPU, sparse SGD"
-                                   % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", d, conf.loss, b),
-                       "global_batch": b * world,
-                       "parallelism": "1 process per GPU; users + their links and item rows range-sharded; RCCL "
-                                      "all-to-alls: ids once per 64 steps, rows and gradients per step"},
+            "config": {"workload": "%s, id-table towers (model_choice=mf), tables sharded by id "
+                                   "range, d=%d, train_scheme=neg_shared, loss=%s, %s, sparse SGD"
+                                   % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", d, conf.loss,
+                                      ("ONE global batch b=%d per step, rows split over the GPUs" % b) if strong else ("b=%d per GPU" % b)),
+                       "global_batch": gb,
+                       "parallelism": ("1 process per GPU; user AND item rows range-sharded and fetched per step (users of the local "
+                                       "rows, items of all columns), both gradients returned to the owners" if strong else
+                                       "1 process per GPU; users + their links and item rows range-sharded") +
+                                      "; RCCL all-to-alls with compact variable splits: ids + counts once per 64 steps, rows and "
+                                      "gradients per step",
+                       "wire_bytes_per_rank_per_step": wire_per_step},
             "mean_loss": mean_loss,
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof, "cpu_baseline": cpu,
         }
         emit(line)
     dist.destroy_process_group()
@@ -589,19 +654,15 @@ def launch_ranks(args):
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`,
     lets their stderr through, relays rank 0's ONE JSON line and exits non-zero if any rank failed
     or no line came back.  Never os.exec*: the ranks are children."""
-    import socket
     import subprocess
     n = int(args.gpus)
     if os.environ.get("NNCF_BENCH_DRYRUN") != "1":
         rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as g; g.build(quiet=True)"], cwd=ROOT)
         if rc:
             raise SystemExit("bench.py: building the HIP extension failed (exit %d)" % rc)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own rendezvous binds port 0 itself (no pick-then-reuse race between concurrent launches)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=%d" % n, os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
     env.setdefault("OMP_NUM_THREADS", "1")

@@ -482,31 +482,48 @@ int64_t nncf_scatter_apply_ws_ints(int32_t n);
 int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_req, int32_t n_ranks, int32_t cap,
                        int32_t id_offset, const float* d_rows, float lr, void* stream);
 
-/* Chunked item-sharded neg_shared trainer (no reference counterpart; SURVEY.md 8(e), BASELINE configs[3]): one
- * object per rank around a model whose "item table" is the landing buffer of fetched rows (n_ranks * batch_size_p
- * rows) and this rank's shard of the real item table (rows [item_offset, item_offset + shard rows), id / item_shard =
- * owner).  Item ids do not depend on the training state, so for up to 64 steps at a time
- *   nncf_shard_plan        routes (unique ids per owner, request slot of every batch position) and the duplicate
- *                          plans of the local steps, batched; fills req_out [n_ranks][64][batch_size_p] (-1 padded)
- *   (host: ONE all-to-all of req_out -> req_in for the whole chunk)
- *   nncf_shard_plan_owner  regroups the received ids per step; gathers the rows of step 0 into rows_out
+/* Chunked sharded neg_shared trainer (no reference counterpart: /root/reference/main.py:34-35 selects ONE device;
+ * SURVEY.md 8(e), BASELINE configs[3]).  One object per rank around a model whose "item table" is the landing buffer of
+ * fetched item rows (batch_size_p rows) and this rank's shard of the real item table (rows [item_offset, item_offset +
+ * shard rows), owner of an id = id / item_shard).  Two forms:
+ *   weak   (d_user_shard == NULL): every rank trains its own batch of batch_size_p links per step -- users and their
+ *          links live with their owner, the model's user table IS this rank's user shard, only item rows travel;
+ *   strong (d_user_shard != NULL): ONE global batch of batch_size_p links per step over all ranks (the result of the
+ *          one-device step on the same batch, models/train_neg_shared.py:46-51): rank g holds rows g, g + n_ranks, ... of
+ *          the b x b score matrix; the model's user table is a landing buffer too (batch_size_p / n_ranks rows); the
+ *          item rows of all b columns and the user rows of the local positions are fetched, both gradients go back to
+ *          the owners, which add the ranks' partial rows in rank order.  Pointwise losses, sparse SGD.
+ * Ids do not depend on the training state, so for up to 64 steps at a time
+ *   nncf_shard_plan        routes and duplicate plans of the chunk, batched: landing slot of every position (= rank of its
+ *                          id among the step's unique ids, ascending), the COMPACT request lists req_out (per owner, per
+ *                          step: exactly the unique ids that live there) and their sizes cnt_out[owner][exchange][64].
+ *                          d_uid: weak [n_steps][b] ids relative to this rank's user range; strong [n_steps][b / n_ranks]
+ *                          global user ids of this rank's positions.  d_cid: [n_steps][b] global item ids (strong: of
+ *                          ALL positions).
+ *   (host: static all-to-all cnt_out -> cnt_in; read both; variable-split all-to-all req_out -> req_in per exchange)
+ *   nncf_shard_plan_owner  offsets of the received lists; gathers the rows of step 0 into rows_out.  rows_per_step
+ *                          [n_exchanges][n_steps] (host): rows this rank's shard is asked for per step = sum over
+ *                          requesters of cnt_in (may be NULL with one rank).
  * and per step i only
- *   (host: all-to-all rows_out -> rows_in)
- *   nncf_shard_step        the local step on (user shard, landed rows): loss, user rows updated, item gradients
- *                          exported to g_out per request slot
+ *   (host: all-to-all rows_out -> rows_in, splits = the step's counts)
+ *   nncf_shard_step        the local step on the landed rows: loss (strong: this rank's share -- the step's loss is the
+ *                          sum over ranks), gradients exported per landing slot to g_out (weak: user rows stepped in place)
  *   (host: all-to-all g_out -> g_in)
- *   nncf_shard_apply       table[id] -= lr * (gradients of id summed in (rank, slot) order), then gathers the rows of
+ *   nncf_shard_apply       table[id] -= lr * (gradient rows of id summed in rank order), then gathers the rows of
  *                          step i + 1 (after the update: synchronous SGD).
- * With n_ranks == 1 req_in / g_in / rows_out alias req_out / g_out / the landing buffer: nothing is copied.
- * nncf_shard_buffers returns the device pointers the host hands to its collectives. */
+ * With n_ranks == 1 both ends of every exchange are the same memory: nothing is copied.
+ * nncf_shard_counts / nncf_shard_buffers return the device pointers the host hands to its collectives (exchange 0:
+ * items, 1: users in the strong form). */
 typedef struct nncf_shard nncf_shard;
-int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t row_stride, int32_t item_shard, int32_t item_offset,
-                      int32_t n_ranks, int device, nncf_shard** out);
+int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, int32_t item_shard, int32_t item_offset,
+                      float* d_user_shard, int32_t user_stride, int32_t user_shard, int32_t user_offset, int32_t n_ranks,
+                      int32_t rank, int device, nncf_shard** out);
 int nncf_shard_destroy(nncf_shard* h);
-int nncf_shard_buffers(nncf_shard* h, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in, float** g_out,
-                       float** g_in);
+int nncf_shard_counts(nncf_shard* h, int32_t** cnt_out, int32_t** cnt_in, int32_t* n_exchanges);
+int nncf_shard_buffers(nncf_shard* h, int32_t exchange, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in,
+                       float** g_out, float** g_in, int32_t* ids_per_step);
 int nncf_shard_plan(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, int64_t n_steps, void* stream);
-int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, void* stream);
+int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, const int64_t* rows_per_step, void* stream);
 int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d_loss, void* stream);
 int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, void* stream);
 

@@ -117,11 +117,12 @@ def _declare(lib):
         "nncf_step_neg_shared_export": [vp, vp, vp, vp, vp, vp],
         "nncf_shard_route": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
         "nncf_gather_rows": [vp, i32, i32, vp, i64, i32, vp, vp],
-        "nncf_shard_create": [vp, vp, i32, i32, i32, i32, i32, ctypes.POINTER(vp)],
+        "nncf_shard_create": [vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, ctypes.POINTER(vp)],
         "nncf_shard_destroy": [vp],
-        "nncf_shard_buffers": [vp] + [ctypes.POINTER(vp)] * 6,
+        "nncf_shard_counts": [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int32)],
+        "nncf_shard_buffers": [vp, i32] + [ctypes.POINTER(vp)] * 6 + [ctypes.POINTER(ctypes.c_int32)],
         "nncf_shard_plan": [vp, vp, vp, i64, vp],
-        "nncf_shard_plan_owner": [vp, i64, vp],
+        "nncf_shard_plan_owner": [vp, i64, vp, vp],
         "nncf_shard_step": [vp, i64, vp, vp, vp],
         "nncf_shard_apply": [vp, i64, i64, f32, vp],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],

@@ -101,9 +101,9 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
     }
     return launch_shared(a, group, uid, cid, w, pu, pv, loss_out, update, st);
   }
-  const int mb = fused_max_blocks(a.b) * fused_split(a.b);
+  const int mb = fused_max_blocks(m->cfg.batch_size_p) * fused_split(m->cfg.batch_size_p);   // as carved
   FusedArgs f = tower ? *tower : FusedArgs();
-  f.split = fused_split(a.b);
+  f.split = a.bc ? fused_split_rect(a.b, a.bc) : fused_split(a.b);
   f.slab = m->fslab;
   f.cnt = m->fcnt;
   f.done = m->fdone;

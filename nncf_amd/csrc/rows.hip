@@ -182,97 +182,244 @@ extern "C" int64_t nncf_scatter_apply_ws_ints(int32_t n) { return 9 * (int64_t)n
 
 
 // ---- chunked sharded trainer: plans and exchanges of up to kPlanChunk steps batched ------------------------------
-// (no reference counterpart).  Item ids do not depend on the training state, so for a chunk of
-// steps the routes and the duplicate plans of both sides are made by a handful of
-// batched launches, and ONE all-to-all carries the requested ids of the whole chunk.  Per step the host only
-// alternates two native calls with the two collectives that move rows and gradients.
+// (no reference counterpart -- /root/reference/main.py:34-35 is single-device).  Ids do not depend on
+// the training state, so for a chunk of steps the routes and the duplicate plans of both sides are made by a handful
+// of batched launches and ONE all-to-all carries the requested ids of the whole chunk.  The wire format is COMPACT:
+// a rank asks an owner for exactly the unique ids of a step that live there, the owner answers with exactly those
+// rows, the gradients travel back the same way -- the per-(owner, step) counts are exchanged with the plan (one small
+// static all-to-all per chunk) so that the host can size the variable-split all-to-alls.  Landing slot of a unique id =
+// its rank among the step's unique ids in ascending id order (owners are id ranges, so the rows of owner 0, 1, ...
+// land back to back in exactly that order).
+//
+// Two forms share the machinery (one `Exch` per exchanged table):
+//   weak   (G independent b x b batches; users and their links live with their owner): items exchanged, user rows local
+//   strong (ONE b x b batch over G ranks, rank g holds rows g, g + G, ...: SURVEY.md 8(e) as written): the items of all b
+//          columns AND the users of the b / G local rows are fetched from their owners, the step (rectangular form of the
+//          one-launch kernel) exports both gradients, owners sum the ranks' partial rows in rank order and step.
+constexpr int kMaxRanks = 64;
+
+struct Exch {
+  float* shard = nullptr;        // this rank's rows [shard_rows][stride] of the table; id / shard_rows = owner
+  int stride = 0, shard_rows = 0, i0 = 0;
+  int n = 0;                     // ids per step in a request list
+  nncf::PlanView plan;           // by id: kPlanChunk lists of n
+  int32_t* slot = nullptr;       // [kPlanChunk][n]  landing slot of every list position
+  int32_t* send_off = nullptr;   // [ranks * kPlanChunk + 1]  (owner, step) -> offset in req_out
+  int32_t* recv_off = nullptr;   // [ranks * kPlanChunk + 1]  (requester, step) -> offset in req_in
+  int32_t* step_off = nullptr;   // [kPlanChunk][ranks + 1]   owner side: the rows of step s for rank r start here
+  int32_t *req_out = nullptr, *req_in = nullptr;
+  float *rows_out = nullptr, *land = nullptr, *g_out = nullptr, *g_in = nullptr;
+};
+
 struct nncf_shard {
   nncf_model* m = nullptr;
-  float* V = nullptr;          // local item shard [shard rows][stride]
-  int stride = 0, d = 0, b = 0, cap = 0, ranks = 1, shard = 0, i0 = 0, device = 0;
+  int d = 0, b = 0, ranks = 1, rank = 0, device = 0, nx = 1, strong = 0;
   void* arena = nullptr;
-  int32_t *req_out = nullptr, *req_in = nullptr;   // [ranks][kPlanChunk][cap]
-  int32_t* req_step = nullptr;                     // [kPlanChunk][ranks*cap]  req_in regrouped per step
-  int32_t* slot = nullptr;                         // [kPlanChunk][b]  request slot of every batch position
-  float *rows_out = nullptr, *g_out = nullptr, *g_in = nullptr;   // [ranks*cap][d]; rows land in the model's item table
-  nncf::PlanView plan_id;                          // by item id (routing), kPlanChunk lists of b
+  Exch x[2];                       // 0: items, 1: users (strong form only)
+  int32_t *cnt_out = nullptr, *cnt_in = nullptr;   // [ranks][nx][kPlanChunk]: unique ids of step s asked of / by rank r
+  int64_t bound[2][nncf::kPlanChunk];              // host: rows the owner side handles per step (grid sizes)
+  bool have_bound = false;
 };
 
 namespace nncf {
 
-__global__ void __launch_bounds__(256) route_chunk_kernel(PlanView pl0, int n, int shard, int cap, int ranks,
-                                                          int32_t* __restrict__ req, int32_t* __restrict__ slot_of_pos) {
+__device__ __forceinline__ int seg_lower_bound(const int4* desc, int nseg, int id) {
+  int lo = 0, hi = nseg;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (desc[mid].x < id) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// cnt[(o * nx + x) * kPlanChunk + s] = unique ids of step s owned by rank o; grid = steps, one thread per owner
+__global__ void __launch_bounds__(64) shard_count_kernel(PlanView pl0, int shard, int ranks, int nx, int xi, int32_t* __restrict__ cnt) {
+  const int s = blockIdx.x;
+  const PlanView pl = pl0.at(s);
+  const int4* desc = reinterpret_cast<const int4*>(pl.desc);
+  const int nseg = pl.counts[0];
+  for (int o = threadIdx.x; o < ranks; o += 64) {
+    const int lo = seg_lower_bound(desc, nseg, o * shard);
+    const int hi = (o + 1 == ranks) ? nseg : seg_lower_bound(desc, nseg, (o + 1) * shard);
+    cnt[((int64_t)o * nx + xi) * kPlanChunk + s] = hi - lo;
+  }
+}
+
+// off[(r, s)] = exclusive prefix of cnt over (rank-major, step) order, off[ranks * kPlanChunk] = total; and, when
+// step_off != NULL, step_off[s][r] = prefix over ranks inside step s.  One wave.
+__global__ void __launch_bounds__(64) shard_offsets_kernel(const int32_t* __restrict__ cnt, int ranks, int nx, int xi,
+                                                           int32_t* __restrict__ off, int32_t* __restrict__ step_off) {
+  const int lane = threadIdx.x;
+  const int total = ranks * kPlanChunk;
+  const int per = (total + 63) / 64;
+  const int lo = lane * per, hi = min(total, lo + per);
+  auto at = [&](int i) { return cnt[((int64_t)(i / kPlanChunk) * nx + xi) * kPlanChunk + (i % kPlanChunk)]; };
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += at(i);
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  int run = incl - sum;
+  for (int i = lo; i < hi; ++i) {
+    off[i] = run;
+    run += at(i);
+  }
+  if (lane == 63) off[total] = incl;
+  if (step_off) {
+    for (int s = lane; s < kPlanChunk; s += 64) {
+      int acc = 0;
+      for (int r = 0; r < ranks; ++r) {
+        step_off[s * (ranks + 1) + r] = acc;
+        acc += cnt[((int64_t)r * nx + xi) * kPlanChunk + s];
+      }
+      step_off[s * (ranks + 1) + ranks] = acc;
+    }
+  }
+}
+
+// landing slot of every list position (= the segment index of its id: ascending-id rank) and the compact request lists
+__global__ void __launch_bounds__(256) route_compact_kernel(PlanView pl0, int n, int shard, int ranks, const int32_t* __restrict__ send_off,
+                                                            int32_t* __restrict__ req, int32_t* __restrict__ slot_of_pos) {
   const int step = blockIdx.y;
   const PlanView pl = pl0.at(step);
   const int4* desc = reinterpret_cast<const int4*>(pl.desc);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int s = pl.slot_seg[i];
     const int4 ds = desc[s];
-    const int owner = ds.x / shard;
-    int lo = 0, hi = s;
-    const int base = owner * shard;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (desc[mid].x < base) lo = mid + 1; else hi = mid;
+    slot_of_pos[(int64_t)step * n + pl.order[i]] = s;
+    if (ds.z == i) {   // the segment's head sends the request
+      const int owner = min(ds.x / shard, ranks - 1);
+      const int first = seg_lower_bound(desc, s, owner * shard);
+      req[send_off[owner * kPlanChunk + step] + (s - first)] = ds.x;
     }
-    const int k = s - lo;
-    slot_of_pos[(int64_t)step * n + pl.order[i]] = owner * cap + k;
-    if (ds.z == i) req[((int64_t)owner * kPlanChunk + step) * cap + k] = ds.x;   // [owner][step][cap]
   }
-  (void)ranks;
 }
 
-// req_in [ranks][kPlanChunk][cap] (as the all-to-all delivers it) -> req_step [steps][ranks*cap]
-__global__ void __launch_bounds__(256) regroup_kernel(const int32_t* __restrict__ req_in, int32_t* __restrict__ req_step,
-                                                      int ranks, int cap, int steps) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t per = (int64_t)ranks * cap;
-  if (i >= per * steps) return;
-  const int s = (int)(i / per), j = (int)(i % per), r = j / cap, k = j % cap;
-  req_step[i] = req_in[((int64_t)r * kPlanChunk + s) * cap + k];
+// (rank r, k) of the t-th row the owner handles at step s
+__device__ __forceinline__ bool owner_row(const int32_t* __restrict__ step_off, int ranks, int s, int64_t t, int& r, int& k) {
+  const int32_t* so = step_off + s * (ranks + 1);
+  if (t >= so[ranks]) return false;
+  r = 0;
+  while (r + 1 < ranks && so[r + 1] <= t) ++r;
+  k = (int)(t - so[r]);
+  return true;
+}
+
+__global__ void __launch_bounds__(256) gather_step_kernel(const float* __restrict__ table, int stride, int d, int id_offset,
+                                                          const int32_t* __restrict__ req_in, const int32_t* __restrict__ recv_off,
+                                                          const int32_t* __restrict__ step_off, int ranks, int s,
+                                                          float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int q = threadIdx.x & 15, d4 = d >> 2;
+  int r, k;
+  if (!owner_row(step_off, ranks, s, t, r, k)) return;
+  const int id = req_in[recv_off[r * kPlanChunk + s] + k];
+  row_store(out, t, d, d4, q, row_load(table, id - id_offset, stride, d4, q));
+}
+
+// owner side of a step: the ranks' request blocks of the step are ascending in id and hold an id at most once, so the
+// gradient rows of an id are at most one per rank: the group of (rank r, k) looks the id up in the other ranks' blocks
+// by binary search -- a lower rank that asked for it too owns the sum; otherwise this group adds the higher ranks' rows
+// in rank order (fixed order, no atomics) and steps the row.
+__global__ void __launch_bounds__(256) merge_step_kernel(float* __restrict__ table, int stride, int d, float lr, int id_offset,
+                                                         const float* __restrict__ rows, const int32_t* __restrict__ req_in,
+                                                         const int32_t* __restrict__ recv_off, const int32_t* __restrict__ step_off,
+                                                         int ranks, int s) {
+  const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int q = threadIdx.x & 15, d4 = d >> 2;
+  int r, k;
+  if (!owner_row(step_off, ranks, s, t, r, k)) return;
+  const int32_t* so = step_off + s * (ranks + 1);
+  const int id = req_in[recv_off[r * kPlanChunk + s] + k];
+  auto find = [&](int rr) -> int {   // position of `id` in rank rr's block of this step, or -1
+    const int32_t* blk = req_in + recv_off[rr * kPlanChunk + s];
+    const int len = so[rr + 1] - so[rr];
+    int lo = 0, hi = len;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (blk[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < len && blk[lo] == id) ? lo : -1;
+  };
+  for (int rr = 0; rr < r; ++rr)
+    if (find(rr) >= 0) return;
+  Row acc = row_load(rows, t, d, d4, q);
+  for (int rr = r + 1; rr < ranks; ++rr) {
+    const int p = find(rr);
+    if (p >= 0) acc = row_add(acc, row_load(rows, (int64_t)so[rr] + p, d, d4, q));
+  }
+  const Row raw = row_load(table, id - id_offset, stride, d4, q);
+  row_store(table, id - id_offset, stride, d4, q, row_fma(-lr, acc, raw));
 }
 
 }  // namespace nncf
 
 static void carve_shard(nncf_shard* h, Carver& c) {
-  const int64_t n = (int64_t)h->ranks * h->cap;
-  h->req_out = c.take<int32_t>(n * kPlanChunk);
-  h->req_in = h->ranks > 1 ? c.take<int32_t>(n * kPlanChunk) : h->req_out;
-  h->req_step = c.take<int32_t>(n * kPlanChunk);
-  h->slot = c.take<int32_t>((int64_t)kPlanChunk * h->b);
-  h->g_out = c.take<float>(n * h->d);
-  h->g_in = h->ranks > 1 ? c.take<float>(n * h->d) : h->g_out;
-  h->rows_out = h->ranks > 1 ? c.take<float>(n * h->d) : nullptr;   // one rank: rows are gathered straight into the landing buffer
-  auto plan = [&](PlanView& v, int64_t cap) {
-    v.list_stride = cap;
-    v.order = c.take<int32_t>(kPlanChunk * cap);
-    v.seg_start = c.take<int32_t>(kPlanChunk * (cap + 1));
-    v.uniq = c.take<int32_t>(kPlanChunk * cap);
-    v.inverse = c.take<int32_t>(kPlanChunk * cap);
+  const int R = h->ranks;
+  const bool alias = R == 1;   // one rank: both ends of every exchange are the same memory
+  h->cnt_out = c.take<int32_t>((size_t)R * h->nx * kPlanChunk);
+  h->cnt_in = alias ? h->cnt_out : c.take<int32_t>((size_t)R * h->nx * kPlanChunk);
+  for (int xi = 0; xi < h->nx; ++xi) {
+    Exch& e = h->x[xi];
+    const int64_t n = e.n;
+    e.slot = c.take<int32_t>((size_t)kPlanChunk * n);
+    e.send_off = c.take<int32_t>((size_t)R * kPlanChunk + 1);
+    e.recv_off = alias ? e.send_off : c.take<int32_t>((size_t)R * kPlanChunk + 1);
+    e.step_off = c.take<int32_t>((size_t)kPlanChunk * (R + 1));
+    e.req_out = c.take<int32_t>((size_t)kPlanChunk * n);
+    e.req_in = alias ? e.req_out : c.take<int32_t>((size_t)R * kPlanChunk * n);
+    e.g_out = c.take<float>((size_t)n * h->d);
+    e.g_in = alias ? e.g_out : c.take<float>((size_t)R * n * h->d);
+    e.rows_out = alias ? nullptr : c.take<float>((size_t)R * n * h->d);   // one rank: gathered straight into the landing buffer
+    PlanView& v = e.plan;
+    v.list_stride = n;
+    v.order = c.take<int32_t>(kPlanChunk * n);
+    v.seg_start = c.take<int32_t>(kPlanChunk * (n + 1));
+    v.uniq = c.take<int32_t>(kPlanChunk * n);
+    v.inverse = c.take<int32_t>(kPlanChunk * n);
     v.counts = c.take<int32_t>(kPlanChunk * 4);
-    v.desc = c.take<int32_t>(kPlanChunk * cap * 4);
-    v.slot_seg = c.take<int32_t>(kPlanChunk * cap);
+    v.desc = c.take<int32_t>(kPlanChunk * n * 4);
+    v.slot_seg = c.take<int32_t>(kPlanChunk * n);
     v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
-    v.aux = cap > 8192 ? c.take<int32_t>(kPlanChunk * cap) : nullptr;
-  };
-  plan(h->plan_id, h->b);
+    v.aux = n > 8192 ? c.take<int32_t>(kPlanChunk * n) : nullptr;
+  }
 }
 
 extern "C" {
 
-int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t row_stride, int32_t item_shard, int32_t item_offset,
-                      int32_t n_ranks, int device, nncf_shard** out) {
+int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, int32_t item_shard, int32_t item_offset,
+                      float* d_user_shard, int32_t user_stride, int32_t user_shard, int32_t user_offset, int32_t n_ranks,
+                      int32_t rank, int device, nncf_shard** out) {
   NNCF_REQUIRE(out != nullptr, "out is NULL");
   *out = nullptr;
   NNCF_REQUIRE(m && d_item_shard, "NULL argument");
-  NNCF_REQUIRE(n_ranks >= 1 && item_shard > 0 && item_offset >= 0, "bad shard shape");
-  NNCF_REQUIRE(row_stride >= m->cfg.dim && row_stride % 4 == 0, "bad row stride");
-  NNCF_REQUIRE(m->cfg.batch_size_p % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
-  NNCF_REQUIRE(m->cfg.item_count >= (int64_t)n_ranks * m->cfg.batch_size_p, "the model's item table must hold n_ranks * batch_size_p landing rows");
+  NNCF_REQUIRE(n_ranks >= 1 && n_ranks <= kMaxRanks && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
+  NNCF_REQUIRE(item_shard > 0 && item_offset >= 0, "bad shard shape");
+  NNCF_REQUIRE(item_stride >= m->cfg.dim && item_stride % 4 == 0, "bad row stride");
+  const int b = m->cfg.batch_size_p;
+  const bool strong = d_user_shard != nullptr;
+  NNCF_REQUIRE(b % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
+  NNCF_REQUIRE(m->cfg.item_count >= b, "the model's item table is the landing buffer: it must hold batch_size_p rows");
+  if (strong) {
+    NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
+    NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
+    NNCF_REQUIRE(m->cfg.user_count >= b / n_ranks, "the model's user table is the landing buffer: it must hold batch_size_p / n_ranks rows");
+    NNCF_REQUIRE(m->opt == 0, "same-global-batch form: the owners take sparse SGD steps only");
+  }
   nncf_shard* h = new (std::nothrow) nncf_shard();
   if (!h) return fail(NNCF_ERR_NOMEM, "out of host memory");
-  h->m = m; h->V = d_item_shard; h->stride = row_stride; h->d = m->cfg.dim; h->b = m->cfg.batch_size_p; h->cap = h->b;
-  h->ranks = n_ranks; h->shard = item_shard; h->i0 = item_offset; h->device = device;
+  h->m = m; h->d = m->cfg.dim; h->b = b; h->ranks = n_ranks; h->rank = rank; h->device = device;
+  h->strong = strong ? 1 : 0;
+  h->nx = strong ? 2 : 1;
+  h->x[0].shard = d_item_shard; h->x[0].stride = item_stride; h->x[0].shard_rows = item_shard; h->x[0].i0 = item_offset;
+  h->x[0].n = b; h->x[0].land = m->V;
+  if (strong) {
+    h->x[1].shard = d_user_shard; h->x[1].stride = user_stride; h->x[1].shard_rows = user_shard; h->x[1].i0 = user_offset;
+    h->x[1].n = b / n_ranks; h->x[1].land = m->U;
+  }
   Carver dry;
   carve_shard(h, dry);
   DeviceGuard guard(device);
@@ -295,15 +442,26 @@ int nncf_shard_destroy(nncf_shard* h) {
   return NNCF_OK;
 }
 
-int nncf_shard_buffers(nncf_shard* h, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in, float** g_out,
-                       float** g_in) {
+int nncf_shard_counts(nncf_shard* h, int32_t** cnt_out, int32_t** cnt_in, int32_t* n_exchanges) {
   NNCF_REQUIRE(h != nullptr, "shard is NULL");
-  if (req_out) *req_out = h->req_out;
-  if (req_in) *req_in = h->req_in;
-  if (rows_out) *rows_out = h->rows_out ? h->rows_out : h->m->V;
-  if (rows_in) *rows_in = h->m->V;
-  if (g_out) *g_out = h->g_out;
-  if (g_in) *g_in = h->g_in;
+  if (cnt_out) *cnt_out = h->cnt_out;
+  if (cnt_in) *cnt_in = h->cnt_in;
+  if (n_exchanges) *n_exchanges = h->nx;
+  return NNCF_OK;
+}
+
+int nncf_shard_buffers(nncf_shard* h, int32_t exchange, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in,
+                       float** g_out, float** g_in, int32_t* ids_per_step) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
+  const Exch& e = h->x[exchange];
+  if (req_out) *req_out = e.req_out;
+  if (req_in) *req_in = e.req_in;
+  if (rows_out) *rows_out = e.rows_out ? e.rows_out : e.land;
+  if (rows_in) *rows_in = e.land;
+  if (g_out) *g_out = e.g_out;
+  if (g_in) *g_in = e.g_in;
+  if (ids_per_step) *ids_per_step = e.n;
   return NNCF_OK;
 }
 
@@ -312,42 +470,83 @@ int nncf_shard_plan(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, i
   NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps per chunk", kPlanChunk);
   hipStream_t st = as_stream(stream);
   nncf_model* m = h->m;
-  const int b = h->b;
-  const int64_t n = (int64_t)h->ranks * h->cap;
-  NNCF_HIP_CHECK(hipMemsetAsync(h->req_out, 0xFF, sizeof(int32_t) * (size_t)n * kPlanChunk, st));  // -1 everywhere
-  int rc = launch_plan(d_cid, b, b, nullptr, 0, 0, h->plan_id, n_steps, st);   // by item id: routing
-  if (rc) return rc;
-  {
+  h->have_bound = false;
+  NNCF_HIP_CHECK(hipMemsetAsync(h->cnt_out, 0, sizeof(int32_t) * (size_t)h->ranks * h->nx * kPlanChunk, st));
+  for (int xi = 0; xi < h->nx; ++xi) {
+    Exch& e = h->x[xi];
+    const int32_t* ids = xi == 0 ? d_cid : d_uid;
+    int rc = launch_plan(ids, e.n, e.n, nullptr, 0, 0, e.plan, n_steps, st);   // by id: routing
+    if (rc) return rc;
     ProfScope _ps("route_kernel", st);
-    hipLaunchKernelGGL(route_chunk_kernel, dim3((b + 255) / 256, (unsigned)n_steps), dim3(256), 0, st, h->plan_id, b, h->shard,
-                       h->cap, h->ranks, h->req_out, h->slot);
+    hipLaunchKernelGGL(shard_count_kernel, dim3((unsigned)n_steps), dim3(64), 0, st, e.plan, e.shard_rows, h->ranks, h->nx, xi, h->cnt_out);
+    hipLaunchKernelGGL(shard_offsets_kernel, dim3(1), dim3(64), 0, st, h->cnt_out, h->ranks, h->nx, xi, e.send_off,
+                       h->ranks == 1 ? e.step_off : (int32_t*)nullptr);
+    hipLaunchKernelGGL(route_compact_kernel, dim3((e.n + 255) / 256, (unsigned)n_steps), dim3(256), 0, st, e.plan, e.n, e.shard_rows,
+                       h->ranks, e.send_off, e.req_out, e.slot);
+    NNCF_HIP_CHECK(hipGetLastError());
   }
-  NNCF_HIP_CHECK(hipGetLastError());
-  rc = launch_plan(d_uid, b, b, nullptr, 0, 0, m->plan_u, n_steps, st);        // the local step's plans
+  // the local step's duplicate plans: users by local id (weak) / by landing slot (strong); items by landing slot
+  const int nu = h->strong ? h->x[1].n : h->b;
+  int rc = launch_plan(h->strong ? h->x[1].slot : d_uid, nu, nu, nullptr, 0, 0, m->plan_u, n_steps, st);
   if (rc) return rc;
-  return launch_plan(h->slot, b, b, nullptr, 0, 0, m->plan_v, n_steps, st);    // items of the step = landing slots
+  return launch_plan(h->x[0].slot, h->b, h->b, nullptr, 0, 0, m->plan_v, n_steps, st);
 }
 
-int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, void* stream) {
+static int gather_step(nncf_shard* h, int xi, int64_t s, hipStream_t st) {
+  Exch& e = h->x[xi];
+  const int64_t rows = h->have_bound ? h->bound[xi][s] : (int64_t)h->ranks * e.n;
+  if (rows <= 0) return NNCF_OK;
+  float* out = e.rows_out ? e.rows_out : e.land;
+  ProfScope _ps("gather_rows_kernel", st);
+  hipLaunchKernelGGL(gather_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.req_in,
+                     e.recv_off, e.step_off, h->ranks, (int)s, out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, const int64_t* rows_per_step, void* stream) {
   NNCF_REQUIRE(h != nullptr, "shard is NULL");
   NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps per chunk", kPlanChunk);
+  NNCF_REQUIRE(h->ranks == 1 || rows_per_step, "with several ranks the host passes the rows every step handles (from the exchanged counts)");
   hipStream_t st = as_stream(stream);
-  const int64_t n = (int64_t)h->ranks * h->cap;
-  hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)((n * n_steps + 255) / 256)), dim3(256), 0, st, h->req_in, h->req_step,
-                     h->ranks, h->cap, (int)n_steps);
-  NNCF_HIP_CHECK(hipGetLastError());
-  float* rows_out = h->rows_out ? h->rows_out : h->m->V;
-  return nncf_gather_rows(h->V, h->stride, h->d, h->req_step, n, h->i0, rows_out, stream);   // rows of step 0
+  if (rows_per_step) {   // [n_exchanges][n_steps]: what this rank's shard is asked for, per step
+    for (int xi = 0; xi < h->nx; ++xi)
+      for (int64_t s = 0; s < n_steps; ++s) {
+        const int64_t v = rows_per_step[xi * n_steps + s];
+        NNCF_REQUIRE(v >= 0 && v <= (int64_t)h->ranks * h->x[xi].n, "rows_per_step out of range");
+        h->bound[xi][s] = v;
+      }
+    h->have_bound = true;
+  }
+  for (int xi = 0; xi < h->nx; ++xi) {
+    Exch& e = h->x[xi];
+    if (h->ranks > 1) {
+      hipLaunchKernelGGL(shard_offsets_kernel, dim3(1), dim3(64), 0, st, h->cnt_in, h->ranks, h->nx, xi, e.recv_off, e.step_off);
+      NNCF_HIP_CHECK(hipGetLastError());
+    }
+    if (int rc = gather_step(h, xi, 0, st)) return rc;   // rows of step 0
+  }
+  return NNCF_OK;
 }
 
 int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d_loss, void* stream) {
-  NNCF_REQUIRE(h && d_uid && d_loss, "NULL argument");
+  NNCF_REQUIRE(h && d_loss, "NULL argument");
   NNCF_REQUIRE(index >= 0 && index < kPlanChunk, "plan slot out of range");
   nncf_model* m = h->m;
   hipStream_t st = as_stream(stream);
   StepArgs a = make_args(m);
-  a.gV = h->g_out;
-  int rc = shared_step(m, a, 0, d_uid, h->slot + index * h->b, m->plan_u.at(index), m->plan_v.at(index), d_loss, 1, st);
+  a.gV = h->x[0].g_out;
+  const int32_t* uid = d_uid;
+  if (h->strong) {   // rows rank, rank + ranks, ... of the b x b score matrix; both tables are landing buffers
+    a.gU = h->x[1].g_out;
+    a.bc = h->b;
+    a.b = h->b / h->ranks;
+    a.row0 = h->rank;
+    a.row_step = h->ranks;
+    uid = h->x[1].slot + index * h->x[1].n;
+  }
+  NNCF_REQUIRE(uid != nullptr, "NULL argument");
+  int rc = shared_step(m, a, 0, uid, h->x[0].slot + index * h->b, m->plan_u.at(index), m->plan_v.at(index), d_loss, 1, st);
   if (rc) return rc;
   if (m->opt == 2) {  // item rows belong to their owners: only the user table is stepped here
     if (int rc2 = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc2;
@@ -360,17 +559,19 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
   NNCF_REQUIRE(h != nullptr, "shard is NULL");
   NNCF_REQUIRE(index >= 0 && index < n_steps && n_steps <= kPlanChunk, "plan slot out of range");
   hipStream_t st = as_stream(stream);
-  const int64_t n = (int64_t)h->ranks * h->cap;
-  {
-    ProfScope _ps("scatter_merge_kernel", st);
-    hipLaunchKernelGGL(scatter_merge_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, h->V, h->stride, h->d, lr, h->g_in,
-                       h->i0, h->req_step + index * n, h->ranks, h->cap);
+  for (int xi = 0; xi < h->nx; ++xi) {
+    Exch& e = h->x[xi];
+    const int64_t rows = h->have_bound ? h->bound[xi][index] : (int64_t)h->ranks * e.n;
+    if (rows > 0) {
+      ProfScope _ps("scatter_merge_kernel", st);
+      hipLaunchKernelGGL(merge_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, lr, e.i0, e.g_in,
+                         e.req_in, e.recv_off, e.step_off, h->ranks, (int)index);
+      NNCF_HIP_CHECK(hipGetLastError());
+    }
+    if (index + 1 < n_steps)   // rows of the next step, after this step's update (synchronous SGD)
+      if (int rc = gather_step(h, xi, index + 1, st)) return rc;
   }
-  NNCF_HIP_CHECK(hipGetLastError());
-  if (index + 1 < n_steps) {   // rows of the next step, after this step's update (synchronous SGD)
-    float* rows_out = h->rows_out ? h->rows_out : h->m->V;
-    return nncf_gather_rows(h->V, h->stride, h->d, h->req_step + (index + 1) * n, n, h->i0, rows_out, stream);
-  }
+  if (index + 1 < n_steps) return NNCF_OK;
   return flush_pending_loss(h->m, st);
 }
 

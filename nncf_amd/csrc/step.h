@@ -25,6 +25,12 @@ struct StepArgs {
   float gamma, lambda, u_reg, lr;
   float* gV;  // if non-NULL the item rows are NOT updated: dL/dV rows are written to gV[row id][d]
               // (sharded mode: V is a buffer of fetched rows, gradients go back to their owners)
+  float* gU = nullptr;   // the same for the user rows (same-global-batch multi-GPU step: both tables are landing buffers)
+  // Rectangular neg_shared step (one-launch path only; no reference counterpart -- models/train_neg_shared.py:46-51 is one
+  // b x b matrix on one device): bc != 0 -> this launch owns the b rows row0, row0 + row_step, ... of a bc x bc score
+  // matrix.  uid[b] lists its positions' users, cid[bc] and the item plan all bc columns; the positive of local row i is
+  // column row0 + i row_step; the loss is normalised by bc, negatives weigh lambda / (bc - 1).
+  int bc = 0, row0 = 0, row_step = 1;
   // text tower: item row = relu(bn_z[row] * mul[c] + add[c]) -- BatchNorm + ReLU applied on load
   // from the pre-activation block, the normalised block is never materialised.  NULL = V.
   // bn_stats: five 128-float vectors mu, inv, var, mul, add.

@@ -51,6 +51,7 @@ struct FusedArgs {
 bool fused_eligible(const StepArgs& a);
 int fused_max_blocks(int b);  // strips per side (= V-pass BatchNorm partials)
 int fused_split(int b);       // workgroups per strip chosen for batch size b
+int fused_split_rect(int b, int bc);   // the same for b rows x bc columns (StepArgs::bc)
 int fused_row_tiles(const StepArgs& a);   // 16-row tiles per workgroup (1: strip kernel; 2, 4: wide kernel)
 int fused_loss_parts(const StepArgs& a);  // loss partials one launch writes
 constexpr int kFusedMaxSplit = 8;

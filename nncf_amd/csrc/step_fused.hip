@@ -135,12 +135,17 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tid >> 4, q = tid & 15;     // 32 row groups of 16 lanes
-  const int b = a.b, d = a.d, d4 = d >> 2;
+  const int b = a.b, d = a.d, d4 = d >> 2;       // b: the rows of the score matrix = this launch's batch positions
   const int NP = (d + 15) & ~15;
-  const int n_items = GROUP ? pv.counts[0] : b;     // columns of the score matrix
+  // Rectangular form (same-global-batch multi-GPU step, neg_shared only): this rank holds rows row0, row0 + row_step, ...
+  // of a bc x bc score matrix; uid lists its b positions, cid and the item plan all bc columns
+  const bool rect = !GROUP && a.bc != 0;
+  const int bc = rect ? a.bc : b;
+  const int n_items = GROUP ? pv.counts[0] : bc;     // columns of the score matrix
   const int n_opp = USIDE ? n_items : b;
   const PlanView& po = USIDE ? pu : pv;
   const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
+  const int own_cap = USIDE ? b : bc;             // entries the own side's plan arrays hold
   const bool bn_on = a.bn_z != nullptr;
 
   FSTAMP(0);
@@ -148,7 +153,15 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   // opposite side: ids of stage 0 and 1 and this workgroup's own descriptors are requested first -- every
   // later load depends on them
   auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
-  auto opp_key = [&](int j) -> int { return USIDE ? (GROUP ? j : pu.inverse[j]) : pv.inverse[j]; };
+  auto opp_key = [&](int j) -> int {
+    if (USIDE) {
+      if (GROUP) return j;
+      if (!rect) return pu.inverse[j];
+      const int t = j - a.row0;           // column j is the positive of local row t / row_step, if that is one of ours
+      return (t >= 0 && t % a.row_step == 0 && t / a.row_step < b) ? pu.inverse[t / a.row_step] : -1;
+    }
+    return pv.inverse[rect ? a.row0 + j * a.row_step : j];
+  };
   const int nst = (n_opp + kFNB - 1) / kFNB;
   int idA[4], keyA[4], idB[4], keyB[4];
   auto load_ids = [&](int st, int* ids, int* keys) {
@@ -168,7 +181,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   // descriptor {id, first position, start, count}: requested before the segment count is known (the plan arrays hold
   // b entries; entries past the count are stale and masked by own_ok below)
   int4 own_ds = make_int4(0, 0, 0, 1);
-  if (g < kFM && s_own < b && !(GROUP && !USIDE)) own_ds = reinterpret_cast<const int4*>(po.desc)[s_own];
+  if (g < kFM && s_own < own_cap && !(GROUP && !USIDE)) own_ds = reinterpret_cast<const int4*>(po.desc)[s_own];
   __syncthreads();
   FSTAMP(1);
   // ---- raw rows first: stage 0 of the opposite side and this workgroup's own rows are requested before the
@@ -378,7 +391,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   // ---- stages over the opposite side: ids two stages ahead, rows one stage ahead -----------------------
   FSTAMP(4);
 
-  const float inv_b = 1.f / (float)b;
+  const float inv_b = 1.f / (float)bc;   // the loss is a mean over the GLOBAL batch (objectives.py:104,111)
   const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;  // objectives.py:100,107,203,211
   const int x = lane & 15, kq = lane >> 4;
   f32x4 accD0 = {0.f, 0.f, 0.f, 0.f}, accD1 = {0.f, 0.f, 0.f, 0.f};
@@ -583,10 +596,10 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
     if (USIDE) grad = row_fma(2.f * a.u_reg * own_c * inv_b, own_raw, grad);
   }
   const bool deferred = f.stage != nullptr;
-  if (update && (USIDE || !a.gV) && !deferred) {   // the rows stepped below are streamed by the other pass of every strip
+  if (update && (USIDE ? !a.gU : !a.gV) && !deferred) {   // the rows stepped below are streamed by the other pass of every strip
     if (tid == 0) {
       const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
-      const int nst_u = ((GROUP ? nseg_v : b) + kFNB - 1) / kFNB, nst_v = (b + kFNB - 1) / kFNB;
+      const int nst_u = ((GROUP ? nseg_v : bc) + kFNB - 1) / kFNB, nst_v = (b + kFNB - 1) / kFNB;
       sTop[2] = readers_wait(f, seen, ((nseg_u + kFM - 1) / kFM) * min(P, nst_u) + ((nseg_v + kFM - 1) / kFM) * min(P, nst_v));
     }
     __syncthreads();
@@ -595,7 +608,8 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
   FSTAMP(24);
   if (update && own_ok) {
     if (USIDE) {
-      if (deferred) row_store(f.stage, s_own, 128, d4, q, grad);
+      if (a.gU) row_store(a.gU, own_id, d, d4, q, grad);
+      else if (deferred) row_store(f.stage, s_own, 128, d4, q, grad);
       else apply_update(a, a.au, a.U, own_id, own_raw, grad, d4, q);
     } else {
       if (a.gV) row_store(a.gV, own_id, d, d4, q, grad);
@@ -633,7 +647,7 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
 template <int LOSS, bool GROUP, bool NU, bool NV>
 __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int32_t* __restrict__ uid,
                                                           const int32_t* __restrict__ cid, FusedArgs f, PlanView pu,
-                                                          PlanView pv, int update, int gu, int nblk) {
+                                                          PlanView pv, int update, int gu, int gv, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float fused_smem[];
   const int id = blockIdx.x;
   const int P = f.split;
@@ -649,10 +663,10 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
   }
   const int rest = id >> 3;
   const int part = rest % P, strip = (rest / P) * 8 + (id & 7);
-  if (strip >= 2 * gu) return;
+  if (strip >= gu + gv) return;
   const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];   // segments (neg_shared) and unique ranks (group): same count
   if (strip < gu) {
-    const int n_items = GROUP ? nseg_v : a.b;
+    const int n_items = GROUP ? nseg_v : (a.bc ? a.bc : a.b);
     const int nst = (n_items + kFNB - 1) / kFNB;
     if (strip * kFM >= nseg_u || part >= nst) {
       if (threadIdx.x == 0) f.loss_part[strip * P + part] = 0.f;
@@ -1174,18 +1188,19 @@ int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   const int mt = fused_row_tiles(a);
   if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4>(a, uid, cid, f, pu, pv, update, stream);
   if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2>(a, uid, cid, f, pu, pv, update, stream);
-  const int gu = (a.b + kFM - 1) / kFM;
-  const int nblk = ((2 * gu + 7) / 8) * 8 * f.split;
+  const int gu = (a.b + kFM - 1) / kFM;                       // user strips: this launch's rows
+  const int gv = ((a.bc ? a.bc : a.b) + kFM - 1) / kFM;       // item strips: all columns
+  const int nblk = ((gu + gv + 7) / 8) * 8 * f.split;
   auto kern = fused_strip_kernel<LOSS, GROUP, NU, NV>;
   static KernelDeviceState kds;
   int capacity = 0;
   if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), fused_lds_bytes(), kds, &capacity)) return rc;
   FusedArgs fa = f;
   // in place (with the hand-shake) only when the whole grid is resident at once on a device this model has to itself
-  if (!(update && (nblk > capacity || f.shared_device || force_deferred()))) fa.stage = nullptr;
+  if (!(update && (nblk > capacity || f.shared_device || force_deferred())) || (a.gU && a.gV)) fa.stage = nullptr;   // both exported: nothing is stepped
   {
     ProfScope _ps("fused_strip_kernel", stream);
-    hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, fa, pu, pv, update, gu, nblk);
+    hipLaunchKernelGGL(kern, dim3(nblk + 1, 1), dim3(512), fused_lds_bytes(), stream, a, uid, cid, fa, pu, pv, update, gu, gv, nblk);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return fa.stage ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;
@@ -1213,7 +1228,7 @@ int fused_max_blocks(int b) { return (b + kFM - 1) / kFM; }
 // row tiles per workgroup: 1 (16-row strips, split over workgroups) below 4096; then as many as leave >= 256
 // workgroups (b = 4096: 2, b >= 8192: 4).  NNCF_FUSED_MT = 1 | 2 | 4 overrides (measurement).
 int fused_row_tiles(const StepArgs& a) {
-  if (a.bn_z) return 1;
+  if (a.bn_z || a.bc) return 1;   // text towers and the rectangular form: strip kernel
   const char* e = getenv("NNCF_FUSED_MT");   // read per launch: the tests switch it between engines
   const int forced = e ? atoi(e) : 0;
   if (forced == 1 || forced == 2 || forced == 4) return forced;
@@ -1224,7 +1239,7 @@ int fused_row_tiles(const StepArgs& a) {
 int fused_loss_parts(const StepArgs& a) {
   const int mt = fused_row_tiles(a);
   if (mt > 1) return (a.b + 16 * mt - 1) / (16 * mt);
-  return fused_max_blocks(a.b) * fused_split(a.b);
+  return fused_max_blocks(a.b) * (a.bc ? fused_split_rect(a.b, a.bc) : fused_split(a.b));
 }
 
 // workgroups per strip: enough to put ~one workgroup on every CU (b = 512: 64 strips x 4), never more than the
@@ -1235,6 +1250,17 @@ int fused_split(int b) {
   const int nst = (b + kFNB - 1) / kFNB;
   if (p > nst) p = nst;
   if (p > kFusedMaxSplit) p = kFusedMaxSplit;
+  return p < 1 ? 1 : p;
+}
+
+// rectangular form: b rows x bc columns; never more parts than the square form of bc x bc allocates workspace for
+int fused_split_rect(int b, int bc) {
+  const int strips = fused_max_blocks(b) + fused_max_blocks(bc);
+  int p = 256 / strips;
+  const int nst = (bc + kFNB - 1) / kFNB;
+  if (p > nst) p = nst;
+  const int cap = fused_split(bc);
+  if (p > cap) p = cap;
   return p < 1 ? 1 : p;
 }
 

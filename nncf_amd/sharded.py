@@ -1,30 +1,39 @@
 """Multi-GPU neg_shared training: one process per GPU, tables range-sharded, RCCL all-to-all
 over xGMI for the cross-shard row exchange (no reference counterpart --
-the reference is single-process).
+the reference is single-process, main.py:34-35).
 
-Partitioning
-  * users: contiguous id ranges; rank r owns users [r*Us, (r+1)*Us) AND every training link of
-    those users, so user rows are always local.
+Partitioning (both forms)
+  * users: contiguous id ranges; rank r owns user rows [r*Us, (r+1)*Us)
   * items: contiguous id ranges; rank r owns item rows [r*Is, (r+1)*Is) (north-star: "the
     embedding table shards by item-id range").
-One global step (all ranks call `step` together, weak scaling: b positives per rank)
-  1. each rank de-duplicates its batch's items and lays the unique ids out per owner
-     (nncf_shard_route: request slot = owner * b + rank among the owner's ids);
-  2. all-to-all #1: requested item ids -> owners      (fixed capacity b per peer, -1 padded)
-  3. owners gather the rows (HIP), all-to-all #2: rows -> requesters, landing directly in the
-     buffer the step kernels read as their "item table" (batch positions index request slots)
-  4. local neg_shared step (tile + apply kernels) on [local user shard, fetched item rows];
-     user rows are updated in place, item gradients are exported per request slot
-  5. all-to-all #3: item gradients -> owners, which sum them in (rank, slot) order and apply the
-     sparse SGD update (deterministic scatter, no atomics).
-This is synchronous data-parallel SGD: all ranks' batches see the same pre-step item rows and
-the owners apply the sum of the per-rank gradients.  `simulate_global_step` in
-tests/test_sharded_gloo.py restates exactly that on one process with the oracle.
 
-All collectives have equal, static split sizes (no host synchronisation to size them); xGMI is
-a full mesh, so all-to-all drives every link at once, unlike a ring all-reduce.
-The exchange logic is backend-agnostic: `HipBackend` runs the kernels, tests inject a numpy
-backend and run the same code over gloo on CPU.
+WEAK form (`ShardedNegShared`; weak scaling: b positives per rank and step).  Rank r also owns every training
+link of its users, so user rows are always local.  One global step (all ranks together):
+  1. each rank de-duplicates its batch's items; landing slot of a unique id = its rank among the
+     batch's unique ids (ascending); owners are id ranges, so the ids of owner 0, 1, ... are contiguous runs;
+  2. requested ids -> owners                      (all-to-all; batched for 64 steps at a time)
+  3. owners gather the rows (HIP), rows -> requesters, landing directly in the buffer the step
+     kernel reads as its "item table"            (all-to-all)
+  4. local neg_shared step on [local user shard, fetched item rows]: user rows are updated in
+     place, item gradients are exported per landing slot
+  5. item gradients -> owners                     (all-to-all), which add the ranks' rows of an id in rank order and
+     apply the sparse SGD update (deterministic, no atomics).
+This is synchronous data-parallel SGD: all ranks' batches see the same pre-step item rows and
+the owners apply the sum of the per-rank gradients (`simulate_global_steps` in tests/test_sharded_gloo.py restates it).
+
+STRONG form (`ShardedGlobalBatch`; strong scaling: ONE batch of b positives per step over all ranks --
+SURVEY.md 8(e) as written, and the only form whose result can be compared with the one-device step on identical
+inputs, models/train_neg_shared.py:46-51).  Rank g holds rows g, g + G, ... of the b x b score matrix: it fetches the
+user rows of its b / G positions AND the item rows of all b columns from their owners, runs the rectangular form of
+the one-launch step (StepArgs::bc), and returns both gradients; the owners add the ranks' partial rows in rank order.
+The step's loss is the sum of the ranks' shares.
+
+The wire format is compact: every all-to-all carries exactly the rows that are needed (variable splits; the
+per-(peer, step) counts are exchanged once per 64 steps together with the ids, which costs one host read of
+2 x world x 64 integers per chunk).  xGMI is a full mesh, so all-to-all drives every link at once, unlike a ring
+all-reduce.  The exchange logic is backend-agnostic: `HipBackend` runs the kernels, tests inject a numpy
+backend and run the same code over gloo on CPU; with a gloo process group and CUDA tensors the payloads are staged
+through host memory (two ranks sharing one GPU in the tests).
 """
 import ctypes
 
@@ -45,41 +54,63 @@ def partition_links_by_user(train, user_count, world):
 
 
 class HipBackend(object):
-    """Compute on this rank's GPU through libnncf_hip.so."""
+    """Compute on this rank's GPU through libnncf_hip.so.
 
-    def __init__(self, engine_kwargs, local_users, local_items, device, world, item_shard, item_offset, seed=0):
+    mode = "weak": the engine's user table is this rank's user shard, its item table the landing buffer.
+    mode = "strong": both engine tables are landing buffers (b / world user rows, b item rows); the shards are
+    `self.U` (local_users rows) and `self.V` (local_items rows)."""
+
+    def __init__(self, engine_kwargs, local_users, local_items, device, world, item_shard, item_offset, seed=0, rank=0,
+                 mode="weak", user_shard=None, user_offset=0, shared_device=False):
         from . import _lib
         from .engine import Engine
+        assert mode in ("weak", "strong")
         self._lib = _lib
         self.device = torch.device("cuda", device)
+        self.mode, self.rank = mode, int(rank)
         kw = dict(engine_kwargs)
         if kw.get("interaction_bias"):
             raise NotImplementedError("interaction_bias is not built for the item-sharded path")
         kw.pop("bias_item_count", None)
-        kw["user_count"] = local_users
         self.b = kw["batch_size_p"]
         self.dim = (int(kw["dim"]) + 3) // 4 * 4   # physical row width (Engine pads to a multiple of 4)
         self.world, self.cap = int(world), self.b
         self.item_shard, self.i0 = int(item_shard), int(item_offset)
-        # the model's "item table" is the landing buffer of fetched rows: world * cap request slots
-        kw["item_count"] = self.world * self.cap
+        self.user_shard, self.u0 = int(user_shard or local_users), int(user_offset)
+        if mode == "strong":
+            if kw["loss"] not in ("skip-gram", "mse"):
+                raise NotImplementedError("the same-global-batch form runs the one-launch step: pointwise losses (skip-gram, mse)")
+            assert self.b % (16 * self.world) == 0, "batch_size_p must be a multiple of 16 * world"
+            kw["user_count"] = self.b // self.world          # landing rows of this rank's positions
+            kw["item_count"] = self.b                        # landing rows of all columns
+        else:
+            kw["user_count"] = local_users
+            # the model's "item table" is the landing buffer of fetched rows; world * cap slots for the per-step protocol
+            # (step(): static capacity b per peer), of which the chunked protocol uses the first b
+            kw["item_count"] = self.world * self.cap
         self.engine = Engine(device=device, seed=seed, **kw)
-        self.U = self.engine.U                      # local user shard
-        self.rows_in = self.engine.V                # [world*cap][d], filled by all-to-all #2
-        gen = torch.Generator().manual_seed(int(seed) + 1)
-        V = torch.zeros(local_items, self.dim)
-        V[:, :int(kw["dim"])] = (torch.rand(local_items, int(kw["dim"]), generator=gen) * 2 - 1) * 0.05
-        self.V = V.to(self.device).contiguous()
+        if shared_device:
+            self.engine.set_shared_device(True)
+        self.rows_in = self.engine.V                # landing buffer of item rows
+        dim_l = int(kw["dim"])
+
+        def table(rows, s):
+            gen = torch.Generator().manual_seed(int(s))
+            t = torch.zeros(rows, self.dim)
+            t[:, :dim_l] = (torch.rand(rows, dim_l, generator=gen) * 2 - 1) * 0.05
+            return t.to(self.device).contiguous()
+        self.V = table(local_items, int(seed) + 1)   # this rank's item shard
+        self.U = table(local_users, int(seed) + 2) if mode == "strong" else self.engine.U   # this rank's user shard
         self.lr = float(kw["learn_rate"])
-        n = self.world * self.cap     # the owner side merges the ranks' sorted request blocks (nncf_scatter_merge): no plan, no cap on n
+        n = self.world * self.cap     # per-step protocol: the owner side merges the ranks' sorted request blocks (nncf_scatter_merge)
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=self.device)  # noqa: E731
-        self.req = i32(n)
-        self.slot = i32(self.b)
-        self.rows_out = torch.empty(n, self.dim, dtype=torch.float32, device=self.device)
-        self.g_out = torch.zeros(n, self.dim, dtype=torch.float32, device=self.device)
+        if mode == "weak":
+            self.req = i32(n)
+            self.slot = i32(self.b)
+            self.rows_out = torch.empty(n, self.dim, dtype=torch.float32, device=self.device)
+            self.g_out = torch.zeros(n, self.dim, dtype=torch.float32, device=self.device)
+            self._ws_route = i32(int(_lib.lib().nncf_scatter_apply_ws_ints(self.b)))
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        L = _lib.lib()
-        self._ws_route = i32(int(L.nncf_scatter_apply_ws_ints(self.b)))
 
     def ids(self, x):
         return self.engine.ids(x)
@@ -87,6 +118,7 @@ class HipBackend(object):
     def _stream(self):
         return self._lib.stream_ptr(torch.cuda.current_stream(self.device))
 
+    # -- per-step protocol (weak form; static capacity b per peer, -1 padded) ------------------------------
     def route(self, cid):
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self._lib.check(self._lib.lib().nncf_shard_route(p(cid), cid.numel(), self.item_shard, self.world, self.cap,
@@ -117,32 +149,49 @@ class HipBackend(object):
         self._lib.check(self._lib.lib().nncf_scatter_merge(p(self.V), self.dim, self.dim, p(req_in), self.world, self.cap,
                                                            self.i0, p(g_in), self.lr, self._stream()))
 
-    # -- chunked protocol (nncf_shard_*): plans and the id exchange of up to CHUNK steps batched ------------
+    # -- chunked protocol (nncf_shard_*): plans and the id exchange of up to CHUNK steps batched, compact payloads ------
     CHUNK = 64
+
+    @property
+    def nx(self):
+        return 2 if self.mode == "strong" else 1
 
     def _session(self):
         if getattr(self, "_sh", None) is None:
             L = self._lib.lib()
             h = ctypes.c_void_p()
+            strong = self.mode == "strong"
             with torch.cuda.device(self.device):
-                self._lib.check(L.nncf_shard_create(self.engine._h, ctypes.c_void_p(self.V.data_ptr()), self.dim, self.item_shard,
-                                                    self.i0, self.world, self.device.index, ctypes.byref(h)))
-            ptrs = [ctypes.c_void_p() for _ in range(6)]
-            self._lib.check(L.nncf_shard_buffers(h, *[ctypes.byref(x) for x in ptrs]))
-            n = self.world * self.cap
+                self._lib.check(L.nncf_shard_create(
+                    self.engine._h, ctypes.c_void_p(self.V.data_ptr()), self.dim, self.item_shard, self.i0,
+                    ctypes.c_void_p(self.U.data_ptr()) if strong else ctypes.c_void_p(), self.dim, self.user_shard, self.u0,
+                    self.world, self.rank, self.device.index, ctypes.byref(h)))
+            self._sh = h
+            W, CH = self.world, self.CHUNK
+            co, ci, nx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32()
+            self._lib.check(L.nncf_shard_counts(h, ctypes.byref(co), ctypes.byref(ci), ctypes.byref(nx)))
+            assert nx.value == self.nx
 
             def view(ptr, count, dtype, shape):
                 # a torch view of library-owned device memory (the collectives read / write it in place)
-                t = _wrap_device_pointer(ptr.value, count, dtype, self.device)
-                return t.view(*shape)
-            self._sh = h
-            self._bufs = dict(
-                req_out=view(ptrs[0], n * self.CHUNK, torch.int32, (self.world, self.CHUNK * self.cap)),
-                req_in=view(ptrs[1], n * self.CHUNK, torch.int32, (self.world, self.CHUNK * self.cap)),
-                rows_out=view(ptrs[2], n * self.dim, torch.float32, (n, self.dim)),
-                rows_in=view(ptrs[3], n * self.dim, torch.float32, (n, self.dim)),
-                g_out=view(ptrs[4], n * self.dim, torch.float32, (n, self.dim)),
-                g_in=view(ptrs[5], n * self.dim, torch.float32, (n, self.dim)))
+                return _wrap_device_pointer(ptr.value, count, dtype, self.device).view(*shape)
+            bufs = dict(cnt_out=view(co, W * self.nx * CH, torch.int32, (W, self.nx * CH)),
+                        cnt_in=view(ci, W * self.nx * CH, torch.int32, (W, self.nx * CH)), x=[])
+            for xi in range(self.nx):
+                ptrs = [ctypes.c_void_p() for _ in range(6)]
+                n = ctypes.c_int32()
+                self._lib.check(L.nncf_shard_buffers(h, xi, *([ctypes.byref(q) for q in ptrs] + [ctypes.byref(n)])))
+                n = n.value
+                own = W * n if W > 1 else n      # owner-side capacity (one rank: the two ends are the same memory)
+                bufs["x"].append(dict(
+                    n=n,
+                    req_out=view(ptrs[0], CH * n, torch.int32, (CH * n,)),
+                    req_in=view(ptrs[1], CH * own, torch.int32, (CH * own,)),
+                    rows_out=view(ptrs[2], own * self.dim, torch.float32, (own, self.dim)),
+                    rows_in=view(ptrs[3], n * self.dim, torch.float32, (n, self.dim)),
+                    g_out=view(ptrs[4], n * self.dim, torch.float32, (n, self.dim)),
+                    g_in=view(ptrs[5], own * self.dim, torch.float32, (own, self.dim))))
+            self._bufs = bufs
         return self._sh
 
     def chunk_buffers(self):
@@ -155,13 +204,19 @@ class HipBackend(object):
         with torch.cuda.device(self.device):
             self._lib.check(self._lib.lib().nncf_shard_plan(h, p(uid_chunk), p(cid_chunk), int(n_steps), self._stream()))
 
-    def plan_owner(self, n_steps):
+    def plan_owner(self, n_steps, rows_per_step=None):
+        """rows_per_step: int64 [nx][n_steps] host array (rows this shard is asked for per step), None with one rank."""
+        ptr = ctypes.c_void_p()
+        if rows_per_step is not None:
+            self._rps = np.ascontiguousarray(rows_per_step, dtype=np.int64)
+            ptr = ctypes.c_void_p(self._rps.ctypes.data)
         with torch.cuda.device(self.device):
-            self._lib.check(self._lib.lib().nncf_shard_plan_owner(self._session(), int(n_steps), self._stream()))
+            self._lib.check(self._lib.lib().nncf_shard_plan_owner(self._session(), int(n_steps), ptr, self._stream()))
 
     def local_step_at(self, index, uid_step, loss_out):
         with torch.cuda.device(self.device):
-            self._lib.check(self._lib.lib().nncf_shard_step(self._session(), int(index), ctypes.c_void_p(uid_step.data_ptr()),
+            self._lib.check(self._lib.lib().nncf_shard_step(self._session(), int(index),
+                                                            ctypes.c_void_p(uid_step.data_ptr()) if uid_step is not None else ctypes.c_void_p(),
                                                             ctypes.c_void_p(loss_out.data_ptr()), self._stream()))
 
     def apply_at(self, index, n_steps):
@@ -191,31 +246,89 @@ def _wrap_device_pointer(ptr, count, dtype, device):
     return torch.as_tensor(holder, device=device)
 
 
-class ShardedNegShared(object):
-    """Collective neg_shared trainer state of one rank (see module docstring)."""
+class _Exchanger(object):
+    """all-to-alls of one rank's trainer: static and variable splits; aliasing (one rank), host staging (gloo process
+    group with device tensors: the CPU-box and two-ranks-on-one-GPU tests) or the process group's own transport (RCCL)."""
 
-    def __init__(self, backend, user_count, item_count, batch_size_p, dim, group=None):
-        self.be = backend
+    def _init_group(self, group):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stage_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+        self.wire_bytes = 0       # payload bytes this rank handed to all_to_all_single (incl. its own share), for the record
+
+    def _a2a(self, out, inp, out_splits=None, in_splits=None):
+        if out.data_ptr() == inp.data_ptr():
+            return                      # one rank: the native session aliases the two ends
+        if out_splits is not None:
+            out, inp = out[:int(sum(out_splits))], inp[:int(sum(in_splits))]
+            out_splits, in_splits = [int(v) for v in out_splits], [int(v) for v in in_splits]
+        if self.world == 1:
+            out.copy_(inp)
+            return
+        self.wire_bytes += inp.numel() * inp.element_size()
+        if self.stage_host and inp.is_cuda:
+            oc = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(oc, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(oc)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def _run_chunks(self, uid_all, cid_all, n_steps, nu, nc, losses, uid_per_step):
+        """n_steps global steps; uid_all / cid_all hold nu / nc ids per step.  Per chunk of up to CHUNK steps: plan ->
+        counts -> ids; per step: rows -> local step -> gradients -> apply."""
+        be = self.be
+        bufs = be.chunk_buffers()
+        ch, nx, W = be.CHUNK, be.nx, self.world
+        for t0 in range(0, n_steps, ch):
+            cnt = min(ch, n_steps - t0)
+            be.plan_chunk(uid_all[t0 * nu:(t0 + cnt) * nu], cid_all[t0 * nc:(t0 + cnt) * nc], cnt)
+            send = recv = None
+            if W > 1:
+                self._a2a(bufs["cnt_in"], bufs["cnt_out"])              # static: nx * CHUNK counts per peer
+                both = torch.stack([bufs["cnt_out"], bufs["cnt_in"]]).cpu().numpy().reshape(2, W, nx, ch)   # the chunk's one host read
+                send, recv = both[0], both[1]                            # [peer][exchange][step]
+                for xi in range(nx):                                     # the chunk's requested ids -> owners
+                    xb = bufs["x"][xi]
+                    self._a2a(xb["req_in"], xb["req_out"], recv[:, xi, :cnt].sum(1), send[:, xi, :cnt].sum(1))
+                be.plan_owner(cnt, recv[:, :, :cnt].sum(0))
+            else:
+                be.plan_owner(cnt)                                       # rows of step 0 gathered
+            for i in range(cnt):
+                t = t0 + i
+                for xi in range(nx):                                     # rows -> requesters
+                    xb = bufs["x"][xi]
+                    if W > 1:
+                        self._a2a(xb["rows_in"], xb["rows_out"], send[:, xi, i], recv[:, xi, i])
+                    else:
+                        self._a2a(xb["rows_in"], xb["rows_out"])
+                lo = losses[t:t + 1] if losses is not None else be._loss
+                be.local_step_at(i, uid_all[t * nu:(t + 1) * nu] if uid_per_step else None, lo)
+                for xi in range(nx):                                     # gradients -> owners
+                    xb = bufs["x"][xi]
+                    if W > 1:
+                        self._a2a(xb["g_in"], xb["g_out"], recv[:, xi, i], send[:, xi, i])
+                    else:
+                        self._a2a(xb["g_in"], xb["g_out"])
+                be.apply_at(i, cnt)                                      # apply; rows of step i + 1 gathered
+        return losses
+
+
+class ShardedNegShared(_Exchanger):
+    """Collective neg_shared trainer state of one rank, weak form (see module docstring)."""
+
+    def __init__(self, backend, user_count, item_count, batch_size_p, dim, group=None):
+        self.be = backend
+        self._init_group(group)
         self.us = shard_size(user_count, self.world)
         self.isz = shard_size(item_count, self.world)
         self.u0 = self.rank * self.us
         self.i0 = self.rank * self.isz
         self.b = int(batch_size_p)
         self.dim = int(dim)
-        self.cap = self.b  # ids requested from one peer per step: at most b (all uniques on one shard)
+        self.cap = self.b  # per-step protocol: ids requested from one peer per step: at most b (all uniques on one shard)
         self._req_in = None
         self._g_in = None
-
-    def _a2a(self, out, inp):
-        if out.data_ptr() == inp.data_ptr():
-            return                      # one rank: the native session aliases the two ends
-        if self.world == 1:
-            out.copy_(inp)
-        else:
-            dist.all_to_all_single(out, inp, group=self.group)
 
     def run_epoch(self, uid_local_all, cid_all, n_steps, losses=None):
         """n_steps global steps over this rank's link stream (ids of n_steps * b links on the backend's device), with
@@ -228,25 +341,12 @@ class ShardedNegShared(object):
                 if losses is not None:
                     losses[t:t + 1].copy_(l.reshape(1))
             return losses
-        bufs = be.chunk_buffers()
-        ch = be.CHUNK
-        for t0 in range(0, n_steps, ch):
-            cnt = min(ch, n_steps - t0)
-            be.plan_chunk(uid_local_all[t0 * b:(t0 + cnt) * b], cid_all[t0 * b:(t0 + cnt) * b], cnt)
-            self._a2a(bufs["req_in"], bufs["req_out"])                  # all-to-all #1: the chunk's ids -> owners
-            be.plan_owner(cnt)                                           # received ids regrouped per step; rows of step 0 gathered
-            for i in range(cnt):
-                t = t0 + i
-                self._a2a(bufs["rows_in"], bufs["rows_out"])            # all-to-all #2: rows -> requesters
-                lo = losses[t:t + 1] if losses is not None else be._loss
-                be.local_step_at(i, uid_local_all[t * b:(t + 1) * b], lo)
-                self._a2a(bufs["g_in"], bufs["g_out"])                  # all-to-all #3: gradients -> owners
-                be.apply_at(i, cnt)                                      # apply; rows of step i + 1 gathered
-        return losses
+        return self._run_chunks(uid_local_all, cid_all, n_steps, b, b, losses, True)
 
     def step(self, uid_local, cid):
         """uid_local: int32 [b] user ids RELATIVE to this rank's user range; cid: int32 [b] global
-        item ids; both on the backend's device.  Returns the local loss tensor [1] (no host sync)."""
+        item ids; both on the backend's device.  Returns the local loss tensor [1] (no host sync).
+        Per-step protocol with static splits (capacity b per peer, -1 padded)."""
         be = self.be
         req, slot = be.route(cid)                                  # request slots, slot of every batch position
         if self._req_in is None:
@@ -260,6 +360,31 @@ class ShardedNegShared(object):
         self._a2a(self._g_in, g_out)                               # all-to-all #3: gradients -> owners
         be.scatter_apply(self._req_in, self._g_in)                 # deterministic (rank, slot) order
         return loss
+
+
+class ShardedGlobalBatch(_Exchanger):
+    """Strong form: ONE global batch of b links per step, rank g holds positions g, g + G, ... (module docstring).
+    Every rank is handed the same global link stream."""
+
+    def __init__(self, backend, user_count, item_count, batch_size_p, dim, group=None):
+        self.be = backend
+        self._init_group(group)
+        self.us = shard_size(user_count, self.world)
+        self.isz = shard_size(item_count, self.world)
+        self.b = int(batch_size_p)
+        self.dim = int(dim)
+        assert self.b % self.world == 0
+        self.bl = self.b // self.world
+
+    def local_positions(self, uid_global_all, n_steps):
+        """uid of this rank's positions (g, g + G, ...) of every step: [n_steps * b / G]"""
+        return uid_global_all[:n_steps * self.b].view(n_steps, self.b)[:, self.rank::self.world].contiguous().view(-1)
+
+    def run_epoch(self, uid_global_all, cid_global_all, n_steps, losses=None):
+        """uid / cid: the GLOBAL link stream (n_steps * b ids each, the same on every rank).  losses[t] receives this
+        rank's share of step t's loss; the step's loss is the sum over ranks (all-reduce it when you need it)."""
+        uid_mine = self.local_positions(uid_global_all, n_steps)
+        return self._run_chunks(uid_mine, cid_global_all, n_steps, self.bl, self.b, losses, False)
 
 
 # ------------------------------------------------------------------------------------------

@@ -252,6 +252,43 @@ def sampled_neg_shared_loss(S, conf):
 
 
 
+def neg_shared_row_block(raw_u, raw_v, rows, conf, dtype=np.float32):
+    """Rows `rows` of the b x b neg_shared step (pointwise losses) -- the share of one rank in the build's
+    same-global-batch multi-GPU form (no reference counterpart; the whole matrix is get_neg_shared_loss,
+    objectives.py:99-112, on InteractionDot 'matmul', interaction_dot.py:100-103).
+    raw_u: (len(rows), d) raw user rows of the global positions `rows`; raw_v: (b, d) raw item rows of ALL positions.
+    Returns (loss share incl. this block's part of the activity regulariser, dL/d raw_u (len(rows), d), the block's
+    PARTIAL dL/d raw_v (b, d)); summed over a partition of the rows they are the one-device step's loss / gradients."""
+    dt = np.dtype(dtype)
+    raw_u, raw_v = np.asarray(raw_u, dtype=dt), np.asarray(raw_v, dtype=dt)
+    rows = np.asarray(rows, dtype=np.int64)
+    b = raw_v.shape[0]
+    assert conf.loss in ("skip-gram", "mse") and b == conf.batch_size_p
+    hat_u, inv_u = l2_normalize(raw_u) if conf.normalize_user else (raw_u, None)
+    hat_v, inv_v = l2_normalize(raw_v) if conf.normalize_item else (raw_v, None)
+    S = hat_u @ hat_v.T
+    pos = np.zeros(S.shape, dtype=bool)
+    pos[np.arange(len(rows)), rows] = True
+    wv = _f32_ratio(conf.neg_loss_weight, b - 1, dt)
+    w = np.where(pos, dt.type(1), wv)
+    if conf.loss == "skip-gram":
+        label = np.where(pos, dt.type(1), dt.type(-1))
+        loss = np.sum(w * _softplus(-label * S)) / dt.type(b)
+        G = -w * label * _sigmoid(-label * S) / dt.type(b)
+    else:
+        label = np.where(pos, dt.type(1), dt.type(0))
+        loss = np.sum(w * (S - label) ** 2) / dt.type(b)
+        G = 2 * w * (S - label) / dt.type(b)
+    G = G.astype(dt)
+    reg = dt.type(conf.u_reg) * np.sum(raw_u * raw_u) / dt.type(b)       # utilities.py:122-135: mean over the b rows
+    g_u = G @ hat_v
+    g_u = l2_normalize_backward(hat_u, inv_u, g_u) if inv_u is not None else g_u
+    g_u = g_u + 2 * dt.type(conf.u_reg) * raw_u / dt.type(b)
+    g_v = G.T @ hat_u
+    g_v = l2_normalize_backward(hat_v, inv_v, g_v) if inv_v is not None else g_v
+    return float(loss + reg), g_u.astype(dt), g_v.astype(dt)
+
+
 # ----------------------------------------------------------------------------------------
 # item text tower of model_choice = basic_embedding
 # ----------------------------------------------------------------------------------------

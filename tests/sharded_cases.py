@@ -1,0 +1,101 @@
+"""Shared by tests/test_sharded_two_ranks_gpu.py and its rank processes (tests/sharded_rank_worker.py): the seeded inputs
+of the multi-rank cases and their single-process restatements on the oracle.  Test infrastructure only."""
+import numpy as np
+
+from oracle import step_oracle as so
+
+B, D, NU, NI, STEPS = 64, 20, 300, 500, 70        # 70 steps = one full chunk of 64 and a partial one
+LR, UREG, LAMBDA = 0.1, 1e-3, 16.0
+
+
+def shard_size(count, world):
+    return (int(count) + world - 1) // world
+
+
+def conf(loss="skip-gram", model="mf"):
+    return so.OracleConf(batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=LAMBDA, u_reg=UREG,
+                         learn_rate=LR, model_choice=model)
+
+
+def engine_kwargs(loss="skip-gram"):
+    return dict(user_count=NU, item_count=NI, dim=D, batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10.,
+                neg_loss_weight=LAMBDA, u_reg=UREG, learn_rate=LR, normalize_user=False, normalize_item=False)
+
+
+def tables(seed=0):
+    rs = np.random.RandomState(seed)
+    return (rs.uniform(-.5, .5, (NU, D)).astype(np.float32), rs.uniform(-.5, .5, (NI, D)).astype(np.float32))
+
+
+def weak_batches(world, seed=1):
+    """per rank: STEPS batches of B links whose users lie in the rank's range; odd steps repeat few items"""
+    rs = np.random.RandomState(seed)
+    us = shard_size(NU, world)
+    out = []
+    for r in range(world):
+        lo, hi = r * us, min(NU, (r + 1) * us)
+        out.append([(rs.randint(lo, hi, B), rs.randint(0, 40 if t % 2 else NI, B)) for t in range(STEPS)])
+    return out
+
+
+def global_batches(seed=7):
+    rs = np.random.RandomState(seed)
+    out = []
+    for t in range(STEPS):
+        uid = rs.randint(0, NU, B)
+        uid[:5] = uid[0]                       # one user on several ranks' rows
+        out.append((uid, rs.randint(0, 12 if t % 3 == 1 else NI, B)))
+    return out
+
+
+def simulate_weak(loss, world):
+    """every rank's batch sees the pre-step tables; user rows are disjoint across ranks; item gradients are summed over
+    ranks (rank order) and applied once"""
+    c = conf(loss)
+    U, V = tables()
+    bt = weak_batches(world)
+    lr = np.float32(c.learn_rate)
+    losses = []
+    for t in range(STEPS):
+        dV = np.zeros_like(V)
+        newU = U.copy()
+        row = []
+        for r in range(world):
+            uid, cid = bt[r][t]
+            o = so.StepOracle(U, V, c, dtype=np.float32)
+            row.append(o.step_neg_shared(uid, cid))
+            touched = np.unique(uid)
+            newU[touched] = o.U[touched]
+            dV += o.last["dV"]
+        U, V = newU, V - lr * dV
+        losses.append(row)
+    return U, V, np.asarray(losses)
+
+
+def simulate_strong(loss):
+    """the one-device step (models/train_neg_shared.py:46-51 semantics) on the global batches, float64"""
+    c = conf(loss)
+    U, V = tables()
+    o = so.StepOracle(U, V, c, dtype=np.float64)
+    losses = [o.step_neg_shared(u, cc) for u, cc in global_batches()]
+    return o.U, o.V, np.asarray(losses)
+
+
+# ---- data-parallel text tower --------------------------------------------------------------------------
+TW = dict(users=300, items=260, train_links=5000, seed=3, content_len=24, vocab=120)
+TW_PD = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+         "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
+         "user_dim": 24, "item_dim": 24, "word_dim": 24, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.,
+         "optimizer": "sgd"}
+
+
+def tower_streams(train, users, world, seed=2):
+    """per rank: STEPS * 64 links of its user range (with replacement)"""
+    rs = np.random.RandomState(seed)
+    us = shard_size(users, world)
+    owner = train[:, 0] // us
+    out = []
+    for r in range(world):
+        mine = train[owner == r]
+        out.append(mine[rs.choice(len(mine), STEPS * 64, replace=True)])
+    return out

@@ -1,0 +1,77 @@
+"""One rank of tests/test_sharded_two_ranks_gpu.py: `python sharded_rank_worker.py CASE RANK WORLD PORT OUTDIR [LOSS]`.
+All ranks share GPU 0 (the one-GPU box), collectives over gloo with the payloads staged through host memory
+(nncf_amd/sharded.py: _Exchanger.stage_host); the HIP kernels are the product's."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from tests import sharded_cases as sc  # noqa: E402
+
+
+def main():
+    case, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    loss = sys.argv[6] if len(sys.argv) > 6 else "skip-gram"
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nncf_amd.sharded import HipBackend, ShardedGlobalBatch, ShardedNegShared
+    out = {}
+    if case in ("weak", "strong"):
+        U, V = sc.tables()
+        us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+        ul, il = min(us, sc.NU - rank * us), min(isz, sc.NI - rank * isz)
+        be = HipBackend(sc.engine_kwargs(loss), ul, il, 0, world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
+                        mode=case, user_shard=us, user_offset=rank * us, shared_device=True)
+        be.U[:, :sc.D].copy_(torch.from_numpy(U[rank * us:rank * us + ul]))
+        be.V[:, :sc.D].copy_(torch.from_numpy(V[rank * isz:rank * isz + il]))
+        losses = torch.zeros(sc.STEPS, dtype=torch.float32, device=be.device)
+        if case == "weak":
+            tr = ShardedNegShared(be, sc.NU, sc.NI, sc.B, sc.D)
+            bt = sc.weak_batches(world)[rank]
+            uid = be.ids(np.concatenate([u for u, _ in bt]) - rank * us)
+            cid = be.ids(np.concatenate([c for _, c in bt]))
+        else:
+            tr = ShardedGlobalBatch(be, sc.NU, sc.NI, sc.B, sc.D)
+            bt = sc.global_batches()
+            uid = be.ids(np.concatenate([u for u, _ in bt]))
+            cid = be.ids(np.concatenate([c for _, c in bt]))
+        tr.run_epoch(uid, cid, sc.STEPS, losses)
+        be.engine.check()
+        lc = losses.cpu()
+        if case == "strong":
+            dist.all_reduce(lc)               # a step's loss = the sum of the ranks' shares
+        out = dict(U=be.U[:, :sc.D].cpu().numpy(), V=be.V[:, :sc.D].cpu().numpy(), losses=lc.numpy(), wire=np.int64(tr.wire_bytes))
+    elif case == "tower":
+        from nncf_amd import synthetic
+        from nncf_amd.conf import get_conf
+        from nncf_amd.data_utils import get_data
+        from nncf_amd.model_framework import get_model
+        from nncf_amd.sharded import DataParallelTower, HipTowerReplica
+        data = synthetic.make_citeulike_like(**sc.TW)
+        conf = get_conf("synthetic", "best", dict(sc.TW_PD), model_choice="basic_embedding")
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)
+        md["model_neg_shared"].engine.set_shared_device(True)
+        rep = HipTowerReplica(md, "neg_shared")
+        dp = DataParallelTower(rep)
+        stream = sc.tower_streams(data["train"], sc.TW["users"], world)[rank]
+        e = rep.engine
+        losses = torch.zeros(sc.STEPS, dtype=torch.float32, device=e.device)
+        dp.run_epoch(e.ids(stream[:, 0]), e.ids(stream[:, 1]), sc.STEPS, 64, losses)
+        e.check()
+        tw = rep.tower
+        out = dict(U=e.U.cpu().numpy(), losses=losses.cpu().numpy(),
+                   **{k: getattr(tw, k).cpu().numpy() for k in ("W", "Wd", "bd", "gamma", "beta")})
+    else:
+        raise SystemExit("unknown case %r" % case)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,45 +83,144 @@ class NumpyBackend(object):
             self.V[k - self.i0] -= self.lr * g
 
 
-class ChunkedNumpyBackend(NumpyBackend):
-    """NumpyBackend + the chunk protocol of HipBackend (nncf_shard_*): routes and the id exchange of a chunk of
-    steps batched, buffers exchanged in place."""
+class _CompactChunks(object):
+    """The compact chunk protocol of HipBackend (nncf_shard_*) in numpy: per (peer, step) counts, request lists per owner
+    and step holding exactly the unique ids that live there, rows / gradients packed requester-major.  `_tables` lists the
+    exchanged tables: (shard array, shard rows per rank, first id, ids per step)."""
     CHUNK = 2     # STEPS = 3: one full chunk and a partial one
 
     def chunk_buffers(self):
         if not hasattr(self, "_bufs"):
-            n, d = self.world * self.cap, self.V.shape[1]
-            self._bufs = dict(req_out=torch.full((self.world, self.CHUNK * self.cap), -1, dtype=torch.int32),
-                              req_in=torch.full((self.world, self.CHUNK * self.cap), -1, dtype=torch.int32),
-                              rows_out=torch.zeros(n, d), rows_in=self.rows_in, g_out=torch.zeros(n, d), g_in=torch.zeros(n, d))
+            W, CH, nx = self.world, self.CHUNK, self.nx
+            x = []
+            for (shard, rows_per_rank, i0, n) in self._tables():
+                d = shard.shape[1]
+                x.append(dict(n=n, req_out=torch.zeros(CH * n, dtype=torch.int32), req_in=torch.zeros(CH * W * n, dtype=torch.int32),
+                              rows_out=torch.zeros(W * n, d), rows_in=torch.zeros(n, d), g_out=torch.zeros(n, d),
+                              g_in=torch.zeros(W * n, d)))
+            self._bufs = dict(cnt_out=torch.zeros(W, nx * CH, dtype=torch.int32), cnt_in=torch.zeros(W, nx * CH, dtype=torch.int32), x=x)
             self._loss = torch.zeros(1)
         return self._bufs
 
-    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+    def _plan_lists(self, lists, n_steps):
+        """lists[xi]: flat ids of the chunk, n ids per step"""
         bufs = self.chunk_buffers()
-        bufs["req_out"].fill_(-1)
-        self._slots = []
-        b = self.cap
-        for s in range(n_steps):
-            req, slot = self.route(cid_chunk[s * b:(s + 1) * b])
-            self._slots.append(slot)
-            bufs["req_out"].view(self.world, self.CHUNK, self.cap)[:, s, :] = req.view(self.world, self.cap)
+        W, CH = self.world, self.CHUNK
+        bufs["cnt_out"].zero_()
+        self._slots, self._nuniq = [], []
+        for xi, (shard, rpr, i0, n) in enumerate(self._tables()):
+            ids = lists[xi].numpy().reshape(n_steps, n)
+            per = [[None] * n_steps for _ in range(W)]
+            slots, nun = [], []
+            for s in range(n_steps):
+                uq = np.unique(ids[s])
+                slots.append(np.searchsorted(uq, ids[s]).astype(np.int32))
+                nun.append(len(uq))
+                own = np.minimum(uq // rpr, W - 1)
+                for o in range(W):
+                    per[o][s] = uq[own == o]
+                    bufs["cnt_out"][o, xi * CH + s] = len(per[o][s])
+            flat = np.concatenate([per[o][s] for o in range(W) for s in range(n_steps)]).astype(np.int32)
+            bufs["x"][xi]["req_out"][:len(flat)] = torch.from_numpy(flat)
+            self._slots.append(slots)
+            self._nuniq.append(nun)
 
-    def _req_of_step(self, s):
-        return self._bufs["req_in"].view(self.world, self.CHUNK, self.cap)[:, s, :].reshape(-1).contiguous()
+    def _blocks(self, xi, s):
+        """ids this shard is asked for at step s, per requester (from cnt_in / req_in)"""
+        bufs, W, CH = self._bufs, self.world, self.CHUNK
+        cnt = bufs["cnt_in"].numpy().reshape(W, self.nx, CH)[:, xi, :]
+        off = np.concatenate([[0], np.cumsum(cnt.reshape(-1))])
+        req = bufs["x"][xi]["req_in"].numpy()
+        return [req[off[r * CH + s]:off[r * CH + s] + cnt[r, s]] for r in range(W)]
 
-    def plan_owner(self, n_steps):
-        self._bufs["rows_out"].copy_(self.gather_rows(self._req_of_step(0)))
+    def _gather(self, s):
+        for xi, (shard, rpr, i0, n) in enumerate(self._tables()):
+            ids = np.concatenate(self._blocks(xi, s))
+            self._bufs["x"][xi]["rows_out"][:len(ids)] = torch.from_numpy(shard[ids - i0])
 
-    def local_step_at(self, index, uid_step, loss_out):
-        loss, g = self.local_step(uid_step, self._slots[index])
-        self._bufs["g_out"].copy_(g)
-        loss_out.copy_(loss.reshape(loss_out.shape))
+    def plan_owner(self, n_steps, rows_per_step=None):
+        if self.world == 1:     # one rank: the native session aliases the two ends; the test double copies
+            self._bufs["cnt_in"].copy_(self._bufs["cnt_out"])
+            for xb in self._bufs["x"]:
+                xb["req_in"][:xb["req_out"].numel()] = xb["req_out"]
+        elif rows_per_step is not None:
+            for xi in range(self.nx):
+                for s in range(n_steps):
+                    assert rows_per_step[xi][s] == sum(len(blk) for blk in self._blocks(xi, s))
+        self._gather(0)
 
     def apply_at(self, index, n_steps):
-        self.scatter_apply(self._req_of_step(index), self._bufs["g_in"])
+        for xi, (shard, rpr, i0, n) in enumerate(self._tables()):
+            g = self._bufs["x"][xi]["g_in"].numpy()
+            acc, k = {}, 0
+            for blk in self._blocks(xi, index):          # requester order: deterministic
+                for it in blk:
+                    acc[it] = acc.get(it, np.zeros(g.shape[1], dtype=np.float32)) + g[k]
+                    k += 1
+            for it, gr in acc.items():
+                shard[it - i0] -= self.lr * gr
         if index + 1 < n_steps:
-            self._bufs["rows_out"].copy_(self.gather_rows(self._req_of_step(index + 1)))
+            self._gather(index + 1)
+
+
+class ChunkedNumpyBackend(_CompactChunks, NumpyBackend):
+    """weak form: items exchanged, user rows local"""
+    nx = 1
+
+    def _tables(self):
+        return [(self.V, self.isz, self.i0, self.cap)]
+
+    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+        self._plan_lists([cid_chunk], n_steps)
+
+    def local_step_at(self, index, uid_step, loss_out):
+        xb = self._bufs["x"][0]
+        if self.world == 1:
+            xb["rows_in"].copy_(xb["rows_out"][:self.cap])
+        o = so.StepOracle(self.U, xb["rows_in"].numpy(), self.conf, dtype=np.float32)
+        loss = o.step_neg_shared(uid_step.numpy(), self._slots[0][index])
+        self.U[...] = o.U
+        xb["g_out"].copy_(torch.from_numpy(o.last["dV"].astype(np.float32)))
+        if self.world == 1:
+            xb["g_in"][:self.cap] = xb["g_out"]
+        loss_out.copy_(torch.tensor([loss]).reshape(loss_out.shape))
+
+
+class StrongNumpyBackend(_CompactChunks):
+    """strong form (one global batch, rank g holds rows g, g + G, ...): users AND items exchanged; the local share
+    is oracle/step_oracle.py: neg_shared_row_block"""
+    nx = 2
+
+    def __init__(self, conf, Ushard, Vshard, world, rank, user_shard, item_shard):
+        self.conf, self.U, self.V, self.world, self.rank = conf, Ushard, Vshard, world, rank
+        self.lr = np.float32(conf.learn_rate)
+        self.b, self.usz, self.isz = conf.batch_size_p, user_shard, item_shard
+        self.bl = self.b // world
+
+    def _tables(self):
+        return [(self.V, self.isz, self.rank * self.isz, self.b), (self.U, self.usz, self.rank * self.usz, self.bl)]
+
+    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+        self._plan_lists([cid_chunk, uid_chunk], n_steps)
+
+    def local_step_at(self, index, uid_step, loss_out):
+        xv, xu = self._bufs["x"]
+        if self.world == 1:
+            xv["rows_in"].copy_(xv["rows_out"][:self.b])
+            xu["rows_in"].copy_(xu["rows_out"][:self.bl])
+        sv, su = self._slots[0][index], self._slots[1][index]
+        rows = self.rank + self.world * np.arange(self.bl)
+        loss, g_u, g_v = so.neg_shared_row_block(xu["rows_in"].numpy()[su], xv["rows_in"].numpy()[sv], rows, self.conf)
+        gu = np.zeros((self.bl, g_u.shape[1]), dtype=np.float32)
+        gv = np.zeros((self.b, g_v.shape[1]), dtype=np.float32)
+        np.add.at(gu, su, g_u)                      # per landing slot: positions of one id summed
+        np.add.at(gv, sv, g_v)
+        xu["g_out"].copy_(torch.from_numpy(gu))
+        xv["g_out"].copy_(torch.from_numpy(gv))
+        if self.world == 1:
+            xu["g_in"][:self.bl] = xu["g_out"]
+            xv["g_in"][:self.b] = xv["g_out"]
+        loss_out.copy_(torch.tensor([loss]).reshape(loss_out.shape))
 
 
 def simulate_global_steps(loss, world):
@@ -241,6 +340,95 @@ def test_world1_equals_plain_step():
         l = tr.step(torch.from_numpy(uid.astype(np.int32)), torch.from_numpy(cid.astype(np.int32)))
         want = o.step_neg_shared(uid, cid)
         assert abs(float(l[0]) - want) < 1e-5 * max(1, abs(want))
+    np.testing.assert_allclose(be.U, o.U, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(be.V, o.V, rtol=1e-5, atol=1e-6)
+
+
+def _global_batches(seed=7):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(STEPS):
+        uid = rs.randint(0, NU, B)
+        uid[:5] = uid[0]                       # one user on several ranks' rows
+        cid = rs.randint(0, 12 if _ == 1 else NI, B)   # step 1: heavy item duplication
+        out.append((uid, cid))
+    return out
+
+
+def _worker_strong(rank, world, port, loss, ret):
+    from nncf_amd.sharded import ShardedGlobalBatch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    conf = _conf(loss)
+    U, V = _tables()
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    be = StrongNumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, rank, us, isz)
+    tr = ShardedGlobalBatch(be, NU, NI, B, D)
+    bt = _global_batches()
+    uid = torch.from_numpy(np.concatenate([u for u, _ in bt]).astype(np.int32))
+    cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
+    losses = torch.zeros(STEPS)
+    tr.run_epoch(uid, cid, STEPS, losses)
+    dist.all_reduce(losses)                    # a step's loss = the sum of the ranks' shares
+    ret[rank] = (be.U.copy(), be.V.copy(), [float(x) for x in losses], tr.wire_bytes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_batch_over_ranks_equals_the_single_device_step(loss, world):
+    """Strong form (SURVEY.md 8(e) as written): ONE batch of b links per step, rank g holds rows g, g + G, ... of the
+    b x b matrix, users and items fetched from their owners, both gradients returned -- loss and both tables equal the
+    one-device step (oracle, models/train_neg_shared.py:46-51 semantics) on the SAME batches to 1e-5."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_strong, args=(world, _free_port(), loss, ret), nprocs=world, join=True)
+    conf = _conf(loss)
+    U, V = _tables()
+    orc = so.StepOracle(U, V, conf, dtype=np.float32)
+    want = [orc.step_neg_shared(u, c) for u, c in _global_batches()]
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_, wire = ret[r]
+        np.testing.assert_allclose(lr_, want, rtol=1e-5)
+        np.testing.assert_allclose(Ur, orc.U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vr, orc.V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+        assert wire > 0
+
+
+def test_global_batch_world1_equals_plain_step():
+    from nncf_amd.sharded import ShardedGlobalBatch
+    conf = _conf("skip-gram")
+    U, V = _tables()
+    be = StrongNumpyBackend(conf, U.copy(), V.copy(), 1, 0, NU, NI)
+    tr = ShardedGlobalBatch(be, NU, NI, B, D)
+    bt = _global_batches()
+    uid = torch.from_numpy(np.concatenate([u for u, _ in bt]).astype(np.int32))
+    cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
+    losses = torch.zeros(STEPS)
+    tr.run_epoch(uid, cid, STEPS, losses)
+    orc = so.StepOracle(U, V, conf, dtype=np.float32)
+    want = [orc.step_neg_shared(u, c) for u, c in bt]
+    np.testing.assert_allclose(losses.numpy(), want, rtol=1e-5)
+    np.testing.assert_allclose(be.U, orc.U, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(be.V, orc.V, rtol=1e-5, atol=1e-6)
+
+
+def test_chunked_world1_numpy_equals_plain_step():
+    conf = _conf("skip-gram")
+    U, V = _tables()
+    be = ChunkedNumpyBackend(conf, U.copy(), V.copy(), 1, NI, 0)
+    tr = ShardedNegShared(be, NU, NI, B, D)
+    bt = _batches(1)[0]
+    uid = torch.from_numpy(np.concatenate([u for u, _ in bt]).astype(np.int32))
+    cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
+    losses = torch.zeros(STEPS)
+    tr.run_epoch(uid, cid, STEPS, losses)
+    o = so.StepOracle(U, V, conf, dtype=np.float32)
+    want = [o.step_neg_shared(u, c) for u, c in bt]
+    np.testing.assert_allclose(losses.numpy(), want, rtol=1e-5)
     np.testing.assert_allclose(be.U, o.U, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(be.V, o.V, rtol=1e-5, atol=1e-6)
 

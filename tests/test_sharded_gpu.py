@@ -268,3 +268,89 @@ def test_sharded_large_batch_world1():
     np.testing.assert_allclose(V1, orc.V, rtol=1e-5, atol=1e-5)
     idle_u, idle_v = np.setdiff1d(np.arange(users), uid), np.setdiff1d(np.arange(items), cid)
     assert np.array_equal(U1[idle_u], U0[idle_u]) and np.array_equal(V1[idle_v], V0[idle_v])
+
+
+@pytest.mark.parametrize("loss,norm", [("skip-gram", False), ("mse", False), ("skip-gram", True)])
+def test_strong_form_world1_equals_plain_step_and_oracle(loss, norm):
+    """ShardedGlobalBatch at world 1: both engine tables are landing buffers, the rectangular form of the one-launch step
+    (all rows) exports both gradients, the owner-side merge steps the shards -- 70 steps (a full chunk + a partial one)
+    == the oracle's one-device step on the same batches; duplicates on both sides."""
+    from nncf_amd.sharded import ShardedGlobalBatch
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=norm, normalize_item=False)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode="strong", user_shard=nu)
+    assert be.engine.U.shape[0] == b and be.engine.V.shape[0] == b and be.U.shape[0] == nu and be.V.shape[0] == ni
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.1, model_choice="mf", emb_normalization=norm)
+    orc = so.StepOracle(be.U.cpu().numpy(), be.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    uid[:6] = uid[0]
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr = ShardedGlobalBatch(be, nu, ni, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    be.engine.check()
+    l = losses.cpu().numpy()
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l[t] - want) <= 1e-5 * max(1, abs(want)), (t, l[t], want)
+    np.testing.assert_allclose(be.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
+
+
+def test_rectangular_step_shares_add_up_to_the_square_step():
+    """The rectangular form of the one-launch step (StepArgs::bc; rows g, g + G, ... of the b x b matrix) run for
+    g = 0 .. G-1 on the SAME landed rows: the loss shares and the exported gradient rows add up to the square step's
+    (nncf_shard_step at world 1 in the strong form == all rows).  b = 512, d = 100, G = 4: split strips on both sides,
+    user strips of 128 rows against 512 columns."""
+    import ctypes
+    from nncf_amd import _lib
+    from nncf_amd.sharded import ShardedGlobalBatch
+    b, d, nu, ni, G = 512, 100, 700, 600, 4
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=128., u_reg=1e-3, learn_rate=0.05, normalize_user=True, normalize_item=False)
+    rs = np.random.RandomState(5)
+    uid = rs.randint(0, nu, b)
+    uid[:9] = uid[0]
+    cid = np.minimum((ni * rs.power(0.4, b)).astype(np.int64), ni - 1)
+    U0 = rs.uniform(-.5, .5, (nu, d)).astype(np.float32)
+    V0 = rs.uniform(-.5, .5, (ni, d)).astype(np.float32)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", neg_loss_weight=128., u_reg=1e-3, learn_rate=0.05,
+                         model_choice="mf", emb_normalization=True)
+    want_loss, gu_want, gv_want = 0.0, np.zeros((nu, d)), np.zeros((ni, d))
+    for g in range(G):
+        rows = g + G * np.arange(b // G)
+        l, gu, gv = so.neg_shared_row_block(U0[uid[rows]], V0[cid], rows, conf, dtype=np.float64)
+        want_loss += l
+        np.add.at(gu_want, uid[rows], gu)
+        np.add.at(gv_want, cid, gv)
+    orc = so.StepOracle(U0, V0, conf, dtype=np.float64)
+    sq = orc.step_neg_shared(uid, cid)
+    assert abs(want_loss - sq) < 1e-9 * abs(sq)          # the oracle's row blocks add up to its square step
+    # each "rank" g as its own world-G backend on this one GPU; the exchanges are emulated by hand from the global tables
+    gu_got, gv_got = np.zeros((nu, d)), np.zeros((ni, d))   # (the loss shares are checked by the two-rank tests)
+    us, isz = (nu + G - 1) // G, (ni + G - 1) // G
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    L = _lib.lib()
+    for g in range(G):
+        be = HipBackend(kw, min(us, nu - g * us), min(isz, ni - g * isz), 0, world=G, item_shard=isz, item_offset=g * isz, seed=0,
+                        rank=g, mode="strong", user_shard=us, user_offset=g * us, shared_device=True)
+        mine = be.ids(uid[g::G])          # (no process group here: ShardedGlobalBatch would take rank 0 of 1)
+        bufs = be.chunk_buffers()
+        be.plan_chunk(mine, be.ids(cid), 1)
+        torch.cuda.synchronize()
+        uq_v, uq_u = np.unique(cid), np.unique(uid[g::G])
+        xv, xu = bufs["x"]
+        xv["rows_in"][:len(uq_v), :d] = torch.from_numpy(V0[uq_v]).cuda()       # what the owners would have sent
+        xu["rows_in"][:len(uq_u), :d] = torch.from_numpy(U0[uq_u]).cuda()
+        loss = torch.zeros(1, device="cuda")
+        _lib.check(L.nncf_shard_step(be._session(), 0, None, p(loss), _lib.stream_ptr()))
+        _lib.check(L.nncf_model_check(be.engine._h, _lib.stream_ptr()))   # synchronises; no in-launch wait timed out
+        gu_got[uq_u] += xu["g_out"][:len(uq_u), :d].cpu().numpy()
+        gv_got[uq_v] += xv["g_out"][:len(uq_v), :d].cpu().numpy()
+        be.close()
+    scale = max(np.abs(gu_want).max(), np.abs(gv_want).max())
+    np.testing.assert_allclose(gu_got, gu_want, rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(gv_got, gv_want, rtol=0, atol=2e-5 * scale)
