@@ -43,3 +43,27 @@ def test_bench_line_contract(extra):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    w = j["windows"]
+    assert w["count"] >= 5 and w["timed_seconds_total"] >= 0.2 and w["steps_each"] == 8     # several windows, the median reported
+    assert abs(j["ms_per_step"] - w["ms_per_step_median"]) <= 1e-9
+    assert r["kernel_ms_source"].startswith("HIP event bracket of this run")                 # frac is what THIS run measured
+    assert abs(r["kernel_ms"] - (r["event_bracket_ms"] - r["empty_bracket_ms"])) <= 1e-9
+
+
+@pytest.mark.parametrize("extra", [("--model", "mf"), ("--model", "mf", "--scaling", "strong"), ()])
+def test_multi_rank_lines_carry_roofline_and_cpu_baseline(extra, monkeypatch):
+    """The N > 1 code paths (item-sharded weak / strong, data-parallel tower) run here as ONE rank over a real process group
+    (NNCF_FORCE_SHARDED=1): their line has the same objects as the N = 1 line -- roofline of the same kernel, rank 0's
+    cpu_baseline, the timed windows."""
+    monkeypatch.setenv("NNCF_FORCE_SHARDED", "1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    j = _run(*extra)
+    assert j["n_gpus"] == 1 and j["scaling"] == ("strong" if "strong" in extra else "weak")
+    r, c, w = j["roofline"], j["cpu_baseline"], j["windows"]
+    assert r["kernel"] == "fused_strip_kernel" and r["bound"] == "mfma" and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+    assert w["count"] >= 5 and w["timed_seconds_total"] >= 0.2
+    assert j["value"] > 0 and abs(j["value"] - 512 * 1e3 / j["ms_per_step"]) <= 1e-6 * j["value"]
+    if "mf" in extra:
+        assert j["config"]["wire_bytes_per_rank_per_step"] == 0        # one rank: nothing travels
