@@ -304,7 +304,7 @@ def trained_recall(args, data, device):
 _T0 = time.time()
 
 
-def timed_windows(window, reduce_max=None, min_total=0.2, min_windows=5, max_windows=512):
+def timed_windows(window, reduce_max=None, min_total=0.2, min_windows=5, max_windows=4096):
     """SURVEY.md 8(d) "several timed windows, report the median": `window()` runs EXACTLY K steps between a
     synchronise (+ barrier for N > 1) on both sides and returns its wall seconds (already the MAX over ranks when
     `reduce_max` is given, so every rank takes the same decisions); repeated until at least `min_windows` windows and

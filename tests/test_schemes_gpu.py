@@ -158,7 +158,7 @@ def test_scheme_trainers_match_oracle_loops(small_data, scheme):
         costs.append(cost / it if it else -1)
     got = [h[2] for h in tr.history]
     for g, w in zip(got, costs):
-        assert abs(g - w) <= 2e-5 * max(1, abs(w)), (scheme, got, costs)
+        assert abs(g - w) <= 1e-5 * max(1, abs(w)), (scheme, got, costs)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
 
@@ -212,6 +212,6 @@ def test_group_sampler_trainers_match_oracle_loops(small_data, scheme):
                 cost += orc.step_original(rows[:, 0], rows[:, 1], rows[:, 2])
         got = tr.history[epoch][2]
         it = n_steps + (1 if len(small_data["train"]) % b else 0)   # the reference counts the broken-off tail iteration
-        assert abs(got - cost / it) <= 2e-5 * max(1, abs(cost / it)), (epoch, got, cost / it)
+        assert abs(got - cost / it) <= 1e-5 * max(1, abs(cost / it)), (epoch, got, cost / it)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)

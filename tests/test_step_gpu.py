@@ -221,7 +221,7 @@ def test_adam_steps_match_oracle(kind, scheme):
         else:
             want = orc.step_group_neg_shared(uid, cid)
             got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         # Adam divides by sqrt(v): a tiny gradient difference is amplified where v ~ g^2
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
@@ -266,7 +266,7 @@ def test_dim_50_is_padded_exactly():
             uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
             want = orc.step_neg_shared(uid, cid)
             got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
-            assert abs(got - want) <= 2e-5 * max(1, abs(want)), (kind, step, got, want)
+            assert abs(got - want) <= 1e-5 * max(1, abs(want)), (kind, step, got, want)
         tol = dict(rtol=2e-4, atol=2e-5) if kind == "adam" else dict(rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(eng.U.cpu().numpy()[:, :50], orc.U, **tol)
         np.testing.assert_allclose(eng.V.cpu().numpy()[:, :50], orc.V, **tol)
@@ -280,18 +280,18 @@ def test_edge_cases_degenerate_batches():
     for loss in ("skip-gram", "log-loss"):
         conf, eng, orc = _mk(loss, b, k, d, nu, ni, "mf", seed=2)
         uid, cid = np.full(b, 7), np.full(b, 11)                          # every row the same pair
-        assert abs(eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item() - orc.step_neg_shared(uid, cid)) < 2e-5 * 10
+        assert abs(eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item() - orc.step_neg_shared(uid, cid)) < 1e-5 * 10
         _check_tables(eng, orc)
         want = orc.step_group_neg_shared(uid, cid)                        # n_u = 1: a single shared item
         got, cu, cx, n_u = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid), want_unique=True)
-        assert int(n_u.item()) == 1 and abs(got.item() - want) <= 2e-5 * max(1, abs(want))
+        assert int(n_u.item()) == 1 and abs(got.item() - want) <= 1e-5 * max(1, abs(want))
         _check_tables(eng, orc)
         uid2, cid2 = np.full(b, 3), np.arange(b)                          # one user, b different items
         negs = np.full(b * k, 5)                                          # one negative for everybody
         u, c, y = so.assemble_original(np.stack([uid2, cid2, np.ones(b, dtype=np.int64)], 1), negs, loss)
         want = orc.step_original(u, c, y)
         got = eng.step_original(eng.ids(uid2), eng.ids(c)).item()
-        assert abs(got - want) <= 2e-5 * max(1, abs(want))
+        assert abs(got - want) <= 1e-5 * max(1, abs(want))
         _check_tables(eng, orc)
     U0, V0 = eng.U.clone(), eng.V.clone()
     empty = torch.zeros(0, dtype=torch.int32, device=eng.device)
@@ -338,7 +338,7 @@ def test_interaction_bias_matches_oracle(scheme, loss):
         else:
             want = orc.step_group_neg_shared(uid, cid)
             got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         _check_tables(eng, orc)
         np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=1e-5, atol=2e-6)
@@ -362,7 +362,7 @@ def test_interaction_bias_adam_and_rowwise():
             uid, cid = rs.randint(0, nu, b), rs.randint(0, ni // 2, b)
             want = orc.step_neg_shared(uid, cid)
             got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
-            assert abs(got - want) <= 2e-5 * max(1, abs(want)), (kind, step, got, want)
+            assert abs(got - want) <= 1e-5 * max(1, abs(want)), (kind, step, got, want)
             np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-4, atol=2e-5)
         assert eng.bias["ub"] is None
     conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss="mse", u_reg=1e-3, learn_rate=0.05, model_choice="mf",
@@ -377,7 +377,7 @@ def test_interaction_bias_adam_and_rowwise():
         y = np.where(rs.rand(n) < 0.3, 1, 0)
         want = orc.step_original(uid, cid, y)
         got = eng.step_rowwise(eng.ids(uid), eng.ids(cid), eng.ids(y)).item()
-        assert abs(got - want) <= 2e-5 * max(1, abs(want))
+        assert abs(got - want) <= 1e-5 * max(1, abs(want))
         np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=1e-5, atol=2e-6)
 
@@ -498,7 +498,7 @@ def test_sparse_adam_as_written_matches_oracle(scheme):
             want = orc.step_group_neg_shared(uid, cid)
             sum_orc.step_group_neg_shared(uid, cid)
             got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(eng.opt_state["mU"].cpu().numpy(), orc.slot_u.m, rtol=2e-4, atol=1e-7)

@@ -27,7 +27,7 @@ def _conf(loss, scheme, b=64, k=3, d=24, lr=0.2):
     return get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="basic_embedding")
 
 
-def _oracle(conf, md, data):
+def _oracle(conf, md, data, dtype=np.float32):
     core = md["model"].core
     tw, eng = core.tower, core.engine
     oc = so.OracleConf(batch_size_p=conf.batch_size_p, num_negatives=conf.num_negatives, loss=conf.loss,
@@ -35,8 +35,8 @@ def _oracle(conf, md, data):
                        learn_rate=conf.learn_rate, emb_normalization=conf.emb_normalization,
                        model_choice="basic_embedding")
     to = so.TowerOracle(data["C"], tw.W.cpu().numpy(), tw.Wd.cpu().numpy(), tw.bd.cpu().numpy(),
-                        tw.gamma.cpu().numpy(), tw.beta.cpu().numpy(), conf.learn_rate, dtype=np.float32)
-    return so.StepOracle(eng.U.cpu().numpy(), None, oc, dtype=np.float32, tower=to), to
+                        tw.gamma.cpu().numpy(), tw.beta.cpu().numpy(), conf.learn_rate, dtype=dtype)
+    return so.StepOracle(eng.U.cpu().numpy(), None, oc, dtype=dtype, tower=to), to
 
 
 @pytest.mark.parametrize("scheme,loss", [("neg_shared", "skip-gram"), ("neg_shared", "log-loss"),
@@ -67,7 +67,7 @@ def test_basic_embedding_steps_match_oracle(text_data, scheme, loss):
             u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
             want = orc.step_group_neg_shared(u, c)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         tw = core.tower
         np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
@@ -109,7 +109,7 @@ def test_every_kernel_path_of_the_shared_schemes_matches_the_oracle(text_data, m
             bt[:, 1] = np.repeat(bt[::4, 1], 4)
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1]) if scheme == "neg_shared" else orc.step_group_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         tw = core.tower
         rt, at = (5e-4, 5e-5) if opt == "adam" else (2e-5, 5e-6)     # Adam divides by sqrt(v): the existing Adam tests' budget
         np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
@@ -219,7 +219,7 @@ def test_large_block_original_matches_oracle():
         assert len(np.unique(c)) > 1024
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         tw = head.core.tower
         np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
@@ -250,7 +250,7 @@ def test_row_dropout_matches_oracle_with_same_mask(text_data):
     for t in range(steps):
         orc.row_scale = masks[t]
         want = orc.step_neg_shared(bt[t * b:(t + 1) * b, 0], bt[t * b:(t + 1) * b, 1])
-        assert abs(got[t] - want) <= 2e-5 * max(1, abs(want)), (t, got[t], want)
+        assert abs(got[t] - want) <= 1e-5 * max(1, abs(want)), (t, got[t], want)
     for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
         np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-4, atol=2e-5, err_msg=name)
     # inference ignores the mask
@@ -274,7 +274,7 @@ def test_basic_embedding_adam_matches_oracle(text_data, kind):
         bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
         # dense_b is left out: its gradient through BatchNorm is exactly zero in real arithmetic, so
         # what Adam normalises to +-lr_t is rounding noise (in the reference as well); BatchNorm
@@ -346,7 +346,7 @@ def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop):
             u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
             want = orc.step_group_neg_shared(u, c)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         for name in CNN_PARAMS:
             if name == "bc":   # gradient through BatchNorm is rounding noise around zero
@@ -382,7 +382,7 @@ def test_cnn_embedding_citeulike_tile_shape():
         to.conv_mask = tw.conv_mask(step, 32).cpu().numpy()
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         for name in CNN_PARAMS:
             if name == "bc":
                 np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
@@ -412,7 +412,7 @@ def test_cnn_embedding_general_tile_shapes(L, wd, F, fl):
         to.conv_mask = tw.conv_mask(step, 32).cpu().numpy().astype(np.float64)
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         for name in CNN_PARAMS:
             if name == "bc":
                 np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
@@ -454,7 +454,7 @@ def test_dims_not_multiple_of_4_are_padded_exactly(text_data, model):
         bt = text_data["train"][rs.choice(len(text_data["train"]), 64, replace=False)]
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
     np.testing.assert_allclose(g(eng.U)[:, :d], orc.U, rtol=2e-5, atol=5e-6)
     assert np.all(g(eng.U)[:, d:] == 0)
     for name, sl in names.items():
@@ -529,7 +529,7 @@ def test_interaction_bias_with_text_tower(text_data, scheme, loss):
             u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
             want = orc.step_group_neg_shared(u, c)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(head.core.tower.W.cpu().numpy(), to.W, rtol=2e-4, atol=2e-5)
@@ -559,7 +559,9 @@ def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
           "word_emb_dropout_rate": 0.5, "num_filters": [100], "filter_lengths": [3], "conv_dropout_rate": 0.1}
     conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice=model)
     md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
-    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data)
+    # float64 oracle: at this shape a float32 restatement is the noisier side (the pad word's row is a sum over ~75
+    # occurrences in each of up to 5,632 items)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data, dtype=np.float64)
     head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
     tw = head.core.tower
     b, k = 512, conf.num_negatives
@@ -593,10 +595,7 @@ def test_text_towers_at_baseline_shape(citeulike_data, model, scheme):
         # reordering, the loss and the user table above hold the 1e-5 budget
         atol = 3e-5 if name == "W" else 2e-5   # Dense / BatchNorm gradients: fp32 sums over up to 5,632 rows
         got_p, want_p = getattr(tw, name).cpu().numpy(), getattr(to, name)
-        if name == "W":   # row 0 is the pad word: ~75 occurrences in EVERY item of the block, the longest sum by far
-            np.testing.assert_allclose(got_p[0], want_p[0], rtol=2e-3, atol=2e-4, err_msg="W[pad]")
-            got_p, want_p = got_p[1:], want_p[1:]
-        np.testing.assert_allclose(got_p, want_p, rtol=2e-4, atol=atol, err_msg=name)
+        np.testing.assert_allclose(got_p, want_p, rtol=2e-4, atol=atol, err_msg=name)     # incl. W[pad], the longest sum
 
 
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
@@ -613,7 +612,7 @@ def test_cnn_embedding_adam_matches_oracle(text_data, kind):
         bt = text_data["train"][rs.choice(len(text_data["train"]), b, replace=False)]
         want = orc.step_neg_shared(bt[:, 0], bt[:, 1])
         got = head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
         # conv / dense biases sit in front of a BatchNorm: their gradients are rounding noise that Adam
         # normalises to +-lr_t (see test_basic_embedding_adam_matches_oracle)
@@ -654,7 +653,7 @@ def test_rowwise_batches_above_a_text_tower(text_data, model, loss):
         rows.append((u, c, y))
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         names = CNN_PARAMS if model == "cnn_embedding" else ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
         for name in names:
@@ -687,7 +686,7 @@ def test_sampled_neg_shared_above_a_text_tower(text_data, model):
         c = np.concatenate([bt[:, 1], negs])
         want = orc.step_sampled_neg_shared(u, c)
         got = head.train_on_batch([u, c])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(head.core.tower.W.cpu().numpy(), to.W, rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(head.core.tower.Wd.cpu().numpy(), to.Wd, rtol=2e-4, atol=2e-5)
@@ -711,7 +710,7 @@ def test_rowwise_batches_above_the_cnn_tower_under_adam(text_data, kind):
         u, c, y = u[perm], c[perm], y[perm]
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=5e-4, atol=5e-5)
         for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):   # bc / bd: see test_cnn_embedding_adam_matches_oracle
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4,
@@ -742,7 +741,7 @@ def test_rowwise_tower_with_normalisation_and_bias(text_data):
         u, c, y = u[perm], c[perm], y[perm]
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), orc.ub, rtol=2e-5, atol=5e-6)
         np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), orc.cb, rtol=2e-5, atol=5e-6)
@@ -908,7 +907,7 @@ def test_cnn_embedding_default_preset_filter_bank(text_data, scheme, loss, drop,
             u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
             want = orc.step_group_neg_shared(u, c)
         got = head.train_on_batch([u, c], [y])
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (step, got, want)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
         if opt == "sgd":
             np.testing.assert_allclose(head.engine.U.cpu().numpy()[:, :50], orc.U, rtol=1e-4, atol=2e-5)
             _check_bank(tw, to, step)
