@@ -337,6 +337,18 @@ int nncf_tower_destroy(nncf_tower* t);
 int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate);
 /* cnn_embedding: call after the host changed conv_w (the tower keeps a transposed copy). */
 int nncf_tower_sync_params(nncf_tower* t, void* stream);
+/* conf.pooling (modules/content/mean_pool.py:68-76): 0 = 'average' (AverageEmbeddings: sum of the word rows / L, :27-33;
+ * default), != 0 = 'max' (MaxPooling1D over the whole length, :70-72: per column the largest scale[w] W[w][c] of the item's
+ * tokens -- rows dropped by Embedding(dropout) are zeros and take part; the gradient of a column goes to the word that
+ * supplied its maximum).  Mean-pool tower only. */
+int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling);
+/* conf.use_content_id (mean_pool.py:102-108): the tower's output becomes relu(BN(Dense(pool))) + Emb_Cid[item id] with
+ * d_id_table [item_count][item_dim] (borrowed; NULL switches it off) and activity_l2(v_reg) on the Embedding's output
+ * (v_reg * sum_d mean over the block's rows of row^2 added to the loss).  Steps of a tower with an id table materialise the
+ * item block (statistics launch + BatchNorm / ReLU + the id rows), run the step kernels on it as on an id table and
+ * step the id rows of the batch's unique items with the model's optimiser (d_m / d_v: zero-initialised moment arrays
+ * shaped like the table for the Adam modes, d_stamp [item_count] int32 zeros for dense Adam; NULL for sparse SGD). */
+int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, float* d_m, float* d_v, int32_t* d_stamp);
 /* Embedding(dropout=rate) of Keras 1 (mean_pool.py:56-59; 0.5 in the 'best' preset,
  * basic_embedding_conf.py:112): per train-mode forward a fresh mask drops whole word rows
  * (survivors scaled by 1/(1-rate)).  The mask is a counter-based hash of (seed, forward index,

@@ -131,6 +131,8 @@ def _declare(lib):
         "nncf_tower_destroy": [vp],
         "nncf_tower_set_learn_rate": [vp, f32],
         "nncf_tower_set_dropout": [vp, f32, u64],
+        "nncf_tower_set_pooling": [vp, i32],
+        "nncf_tower_set_content_id": [vp, vp, f32, vp, vp, vp],
         "nncf_tower_sync_params": [vp, vp],
         "nncf_tower_conv_mask": [vp, u64, i64, vp, vp],
         "nncf_tower_set_grad_export": [vp, vp],

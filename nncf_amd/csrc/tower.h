@@ -95,6 +95,10 @@ struct TowerArgs {
   // data-parallel training: if non-NULL the backward applies nothing and writes the gradients
   // [words (n_words*wd) | dense_w (wd*d) | dense_b, bn_gamma, bn_beta (128 each)] here
   float* gexp;
+  // conf.pooling == 'max' (mean_pool.py:70-72: MaxPooling1D over the whole length): h[s][c] = max over the item's
+  // tokens of scale[w] W[w][c]; amax[s][c] = the word that supplied it (the backward routes dh[s][c] to that word's row)
+  int pool_max;
+  int32_t* amax;             // [cap][wd]
   CnnArgs cnn;
 };
 
@@ -313,6 +317,14 @@ struct nncf_tower {
   int hd() const { return nb > 0 ? nb * cnn.F : cfg.word_dim; }   // width of the pooled block = Dense input width
   float conv_drop = 0.f;
   uint64_t conv_step = 0;  // train-mode forwards since nncf_tower_set_dropout (conv mask index)
+  // conf.pooling = 'max' (nncf_tower_set_pooling)
+  int pool_max = 0;
+  int32_t* amax = nullptr;       // own allocation [max_rows][word_dim]
+  // conf.use_content_id (mean_pool.py:102-108; nncf_tower_set_content_id): tower output + Emb_Cid[item id]
+  float* cid_tab = nullptr;      // [item_count][item_dim], borrowed
+  float v_reg = 0.f;             // activity_l2(v_reg) on the Emb_Cid output
+  nncf::AdamTable acid;          // its Adam state (borrowed; stamp for dense Adam)
+  float* cid_reg = nullptr;      // own allocation [max_rows] |Emb_Cid row|^2 of the block's rows
 };
 
 namespace nncf {

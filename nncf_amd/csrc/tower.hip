@@ -42,8 +42,13 @@ namespace nncf {
 // id 0 contributes its row) -- evaluated as (1/L) sum_w count_w scale[w] W[w] over the item's distinct
 // words -- then z[s] = h[s].Wd + bd.  Inference (train = 0) finishes the row:
 // E[s] = relu(BN_running(z[s])).
+// MAXP (conf.pooling == 'max', mean_pool.py:70-72): h[s][c] = max over the item's tokens of scale[w] W[w][c] (a dropped
+// row is a row of zeros and still takes part, as Keras' Embedding(dropout) leaves it); the word that supplied each
+// column's maximum is kept in amax[s][c] for the backward.  Equal values from different words: the pair listed first wins.
+template <bool MAXP>
 __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
+  __shared__ int sArg[MAXP ? 16 * kTP : 1];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
   __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
   __shared__ int sTok[256];
@@ -71,36 +76,86 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   if (tid < a.L) {
     fw = a.ent_word[(int64_t)item * a.L + tid];
     fc = a.ent_cnt[(int64_t)item * a.L + tid];
-    if (fw >= 0) fsc = (a.train ? word_scale(a, fw) : 1.f) * (float)fc;
+    if (fw >= 0) fsc = (a.train ? word_scale(a, fw) : 1.f) * (MAXP ? 1.f : (float)fc);
     sTok[tid] = fw;
     sSc[tid] = fsc;
   }
   const int ne = __syncthreads_count(fw >= 0);  // pairs of this item (they come first)
   Row acc = row_zero();
+  int arg[8];
+  if (MAXP) {
+    acc.a = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    acc.b = acc.a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) arg[e] = -1;
+  }
   const int nper = (ne + 15) >> 4;  // pairs per group
   for (int i0 = 0; i0 < nper; i0 += 7) {  // 7 word rows of this group in flight
     float sc[7];
     Row r[7];
+    bool live[7];
 #pragma unroll
     for (int e = 0; e < 7; ++e) {
       const int l = grp + 16 * (i0 + e);
       const bool ok = (i0 + e < nper) && l < ne;
+      live[e] = ok;
       sc[e] = ok ? sSc[l] : 0.f;
       r[e] = (sc[e] != 0.f) ? row_load(a.W, sTok[l], a.wd, wd4, q) : row_zero();
     }
 #pragma unroll
-    for (int e = 0; e < 7; ++e) acc = row_fma(sc[e], r[e], acc);
+    for (int e = 0; e < 7; ++e) {
+      if (!MAXP) {
+        acc = row_fma(sc[e], r[e], acc);
+      } else if (live[e]) {     // a dropped word (scale 0) is a row of zeros
+        const int w = sTok[grp + 16 * (i0 + e)];
+        Row v = row_scale(r[e], sc[e]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float x = relem(v, c);
+          if (x > relem(acc, c)) {
+            relem(acc, c) = x;
+            arg[c] = w;
+          }
+        }
+      }
+    }
   }
   reinterpret_cast<float4*>(sR + grp * kTP)[q] = acc.a;
   reinterpret_cast<float4*>(sR + grp * kTP)[q + 16] = acc.b;
+  if (MAXP) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sArg[grp * kTP + col_of(q, c)] = arg[c];
+  }
   __syncthreads();
   if (grp == 0) {
     Row sum = row_zero();
-    for (int g = 0; g < 16; ++g) {
-      sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
-      sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+    if (!MAXP) {
+      for (int g = 0; g < 16; ++g) {
+        sum.a = add4(sum.a, reinterpret_cast<const float4*>(sR + g * kTP)[q]);
+        sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR + g * kTP)[q + 16]);
+      }
+      sum = row_scale(sum, 1.f / (float)a.L);
+    } else {
+      // groups hold pairs grp, grp + 16, ...: the pair listed first wins a tie -> compare (value, pair order) is not
+      // tracked per column; group order is the tie rule between groups (exact ties between DIFFERENT words do not
+      // occur with real-valued rows; the same word never sits in two pairs)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = col_of(q, c);
+        float best = -INFINITY;
+        int bw = -1;
+        for (int g = 0; g < 16; ++g) {
+          const float x = sR[g * kTP + col];
+          if (x > best) {
+            best = x;
+            bw = sArg[g * kTP + col];
+          }
+        }
+        const bool real = col < a.wd;
+        relem(sum, c) = real ? best : 0.f;
+        if (a.train && real) a.amax[(int64_t)s * a.wd + col] = bw;
+      }
     }
-    sum = row_scale(sum, 1.f / (float)a.L);
     if (a.train) row_store(a.h, s, a.wd, wd4, q, sum);
     reinterpret_cast<float4*>(sH)[q] = sum.a;  // chunks past wd are the zeros row_load produced
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
@@ -133,7 +188,7 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   }
   // backward preparation: cnt_t[w * cap + s] = occurrences of word w in this item.  Every
   // (w, s) cell is written by exactly one thread: no atomics.  Dropped words get no gradient.
-  if (a.fill && fsc != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = (uint8_t)fc;
+  if (a.fill && fsc != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = MAXP ? (uint8_t)1 : (uint8_t)fc;
 }
 
 // fixed-stride copy of the item CSR: ent[item][e] = e-th (word, count) pair of the item, (-1, 0) past the last
@@ -507,7 +562,9 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 constexpr int kWordsPerWG = 8;
 constexpr int kListCap = 256;
 constexpr int kRowsInFlight = 8;
-template <bool CNN>
+// MAXP: max pooling -- a listed (word, slot) cell contributes dh[slot][c] only in the columns whose maximum the word
+// supplied (amax[slot][c] == word); no 1/L.
+template <bool CNN, bool MAXP = false>
 __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
@@ -600,6 +657,17 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
           r[u] = (ent[u] && lane < d2)
                      ? dh2[(cnn ? (int64_t)((ent[u] >> 8) & 0xFFFF) * a.L + ((ent[u] & 255) - 1) : (int64_t)((ent[u] >> 8) & 0xFFFF)) * d2 + lane]
                      : make_float2(0.f, 0.f);
+        if (MAXP) {
+#pragma unroll
+          for (int u = 0; u < kRowsInFlight; ++u) {
+            if (ent[u] && lane < d2) {
+              const int2 am = reinterpret_cast<const int2*>(a.amax)[(int64_t)((ent[u] >> 8) & 0xFFFF) * d2 + lane];
+              const int w = bid + (ent[u] >> 24) * G;
+              if (am.x != w) r[u].x = 0.f;
+              if (am.y != w) r[u].y = 0.f;
+            }
+          }
+        }
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u) {
           if (ent[u]) {  // uniform across the wave
@@ -657,7 +725,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       sum.y += t.y;
     }
     // gradient = scale[w] / L * sum (mean-pool); the CNN rows already carry scale and 1/L
-    const float gs = cnn ? 1.f : word_scale(a, my_w) / (float)a.L;
+    const float gs = cnn ? 1.f : (MAXP ? word_scale(a, my_w) : word_scale(a, my_w) / (float)a.L);
     if (a.gexp) {
       reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(gs * sum.x, gs * sum.y);
       return;
@@ -671,7 +739,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       *mp = mm;
       *vp = vv;
     } else {
-      const float sc = cnn ? a.lr : lr_over_L * word_scale(a, my_w);
+      const float sc = cnn ? a.lr : (MAXP ? a.lr : lr_over_L) * word_scale(a, my_w);
       wold.x = fmaf(-sc, sum.x, wold.x);
       wold.y = fmaf(-sc, sum.y, wold.y);
     }
@@ -741,6 +809,42 @@ __global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const flo
   }
 }
 
+// conf.use_content_id (mean_pool.py:102-108): E[s] += Emb_Cid[ids[s]] for the block's real rows; reg[s] = |Emb_Cid row|^2
+// (activity_l2(v_reg) on the Embedding's output, utilities.py:122-135).  One 16-lane group per row.
+__global__ void __launch_bounds__(256) cid_add_kernel(float* __restrict__ E, int d, const float* __restrict__ tab,
+                                                      const int32_t* __restrict__ ids, const int32_t* __restrict__ n_valid, int m,
+                                                      float* __restrict__ reg) {
+  const int s = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = d >> 2;
+  const int nv = n_valid ? min(*n_valid, m) : m;
+  if (s >= nv) return;
+  const Row c = row_load(tab, ids[s], d, d4, q);
+  row_store(E, s, d, d4, q, row_add(row_load(E, s, d, d4, q), c));
+  if (reg) {
+    const float ss = row16_sum(row_dot_partial(c, c));
+    if (q == 0) reg[s] = ss;
+  }
+}
+
+// after the step: Emb_Cid[ids[s]] takes the optimiser step with dL/dE[s] + 2 v_reg / n * row (every id of the block is
+// unique: one row, one writer); workgroup 0 also adds the regulariser v_reg / n * sum_s |row_s|^2 to *loss (rows in order)
+__global__ void __launch_bounds__(256) cid_update_kernel(StepArgs a, AdamTable st, float* __restrict__ tab,
+                                                         const int32_t* __restrict__ ids, const int32_t* __restrict__ n_valid, int m,
+                                                         const float* __restrict__ dE, float v_reg, const float* __restrict__ reg,
+                                                         float* __restrict__ loss) {
+  const int s = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = a.d >> 2;
+  const int nv = n_valid ? min(*n_valid, m) : m;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && loss && v_reg != 0.f) {
+    float t = 0.f;
+    for (int i = 0; i < nv; ++i) t += reg[i];
+    *loss += v_reg * t / (float)max(nv, 1);
+  }
+  if (s >= nv) return;
+  const int id = ids[s];
+  const Row raw = row_load(tab, id, a.d, d4, q);
+  const Row g = row_fma(2.f * v_reg / (float)max(nv, 1), raw, row_load(dE, s, a.d, d4, q));
+  apply_update(a, st, tab, id, raw, g, d4, q);
+}
+
 __global__ void tower_scale_kernel(TowerArgs a, float* __restrict__ out) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < a.n_words) out[w] = word_scale(a, w);
@@ -792,6 +896,8 @@ TowerArgs base_args(const nncf_tower* t) {
   a.cnn = t->cnn;
   a.cnn.keep = 1.f;
   a.hd = t->hd();
+  a.pool_max = t->pool_max;
+  a.amax = t->amax;
   return a;
 }
 
@@ -818,7 +924,8 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     if (int rc = cnn_forward(t, a, st)) return rc;
   } else {
     ProfScope _ps("tower_pool_kernel", st);
-    hipLaunchKernelGGL(tower_pool_kernel, dim3((unsigned)m), dim3(256), 0, st, a);
+    if (a.pool_max) hipLaunchKernelGGL(tower_pool_kernel<true>, dim3((unsigned)m), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tower_pool_kernel<false>, dim3((unsigned)m), dim3(256), 0, st, a);
   }
   if (train && stats_by_consumer) {  // the one-launch step derives the statistics itself (step_fused.hip)
     t->last = a;
@@ -884,6 +991,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
     const int ncnn = a.cnn.F > 0 ? (a.cnn.fl * a.wd * a.cnn.F + 127) / 128 + 1 : 0;   // cnn_update_block workgroups
     if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    else if (a.pool_max) hipLaunchKernelGGL((tower_word_kernel<false, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
@@ -955,7 +1063,8 @@ int ensure_cells(nncf_tower* t, int rows) {
 // does the one-launch backward apply to a step of this scheme?
 bool wordbwd_applies(const nncf_tower* t, const nncf_model* m, int scheme) {
   const int b = m->cfg.batch_size_p;
-  return t->use_wordbwd && t->cnn.F == 0 && (scheme == 1 || scheme == 2) && b <= 1024 && (b + kChunkSlots - 1) / kChunkSlots <= kTowerWG;
+  return t->use_wordbwd && t->cnn.F == 0 && !t->pool_max && !t->cid_tab && (scheme == 1 || scheme == 2) && b <= 1024 &&
+         (b + kChunkSlots - 1) / kChunkSlots <= kTowerWG;
 }
 
 int plan_cells(nncf_tower* t, const nncf_model* m, int scheme, const int32_t* uniq_g, const int32_t* n_u, int64_t uniq_stride,
@@ -994,6 +1103,46 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   sa.bn_stats = t->ws + ws_muinv();
   sa.item_gid = uniq_g;  // InteractionDot item bias is indexed by catalogue id, the block by tf.unique rank
   // shared schemes with a pointwise loss: ONE launch does statistics + scores + loss + both updates
+  if (t->cid_tab) {
+    // conf.use_content_id: the item row is relu(BN(z)) + Emb_Cid[id] -- the block is MATERIALISED into the model's item
+    // table (statistics launch, BatchNorm + ReLU, + the id rows), the step kernels run on it as on an id table and
+    // export dL/dE, which is both the id rows' gradient and the tower backward's input (its BatchNorm sums by their
+    // own launch).  Not the fused fast path: the option is off in every shipped configuration.
+    NNCF_REQUIRE(!t->gexp, "use_content_id is not built for the data-parallel gradient export");
+    int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, m->V, st, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cid_add_kernel, dim3((n + 15) / 16), dim3(256), 0, st, m->V, t->cfg.item_dim, t->cid_tab, uniq_g, n_u, n,
+                       t->cid_reg);
+    NNCF_HIP_CHECK(hipGetLastError());
+    StepArgs pa = make_args(m);       // plain table mode: no BatchNorm on load, no fused sums
+    pa.item_gid = uniq_g;
+    if (scheme == 0)
+      rc = launch_original(pa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
+    else if (scheme == 3)
+      rc = launch_rowwise(pa, uid, cid_local, y, m->rws, pu, pv, n, loss, update, st);
+    else
+      rc = shared_step(m, pa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, nullptr);
+    if (rc) return rc;
+    if ((rc = flush_pending_loss(m, st))) return rc;
+    StepArgs ca = pa;                 // the id table's own row width / optimiser state
+    ca.stride = t->cfg.item_dim;
+    ca.lr = t->cfg.learn_rate;
+    if (update) {
+      hipLaunchKernelGGL(cid_update_kernel, dim3((n + 15) / 16), dim3(256), 0, st, ca, t->acid, t->cid_tab, uniq_g, n_u, n, m->export_gV,
+                         t->v_reg, t->cid_reg, loss);
+      NNCF_HIP_CHECK(hipGetLastError());
+      if (pa.opt == 2)
+        if (int rc2 = launch_adam_idle(ca, t->cid_tab, t->acid, t->cfg.item_count, st)) return rc2;
+      if ((rc = tower_backward(t, m->export_gV, st, 0, m->opt ? m->adam_t + 1 : 0, false))) return rc;
+      return finish_update(m, pa, st);
+    }
+    if (t->v_reg != 0.f) {   // loss only: the regulariser still belongs to the loss
+      hipLaunchKernelGGL(cid_update_kernel, dim3(1), dim3(256), 0, st, ca, t->acid, t->cid_tab, uniq_g, n_u, 0, m->export_gV, t->v_reg,
+                         t->cid_reg, loss);
+      NNCF_HIP_CHECK(hipGetLastError());
+    }
+    return NNCF_OK;
+  }
   const bool one_launch = (scheme == 1 || scheme == 2) && shared_step_fuses(m, sa);
   const bool wb = cells != nullptr && update && wordbwd_applies(t, m, scheme);   // one-launch backward: no count matrix
   // shared schemes on the tile + apply pair (pairwise losses, bias): the tile workgroups derive the statistics too
@@ -1140,6 +1289,8 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
 }
 
 int nncf_tower_destroy(nncf_tower* t) {
+  if (t && t->amax) (void)hipFree(t->amax);
+  if (t && t->cid_reg) (void)hipFree(t->cid_reg);
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
   if (t->stamps) hipFree(t->stamps);
@@ -1275,12 +1426,49 @@ int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, cons
   NNCF_REQUIRE(d_item_ids && d_out, "NULL argument");
   NNCF_REQUIRE(!train || m <= t->cfg.max_rows, "train-mode block of %lld rows exceeds max_rows = %d", (long long)m, t->cfg.max_rows);
   hipStream_t st = as_stream(stream);
-  if (train) return tower_forward(t, d_item_ids, (int)m, d_n_valid, 1, prepare_backward != 0, d_row_scale, d_out, st);
+  auto add_ids = [&]() -> int {   // conf.use_content_id: + Emb_Cid[id] (mean_pool.py:102-108)
+    if (!t->cid_tab) return NNCF_OK;
+    hipLaunchKernelGGL(cid_add_kernel, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, st, d_out, t->cfg.item_dim, t->cid_tab, d_item_ids,
+                       d_n_valid, (int)m, (float*)nullptr);
+    NNCF_HIP_CHECK(hipGetLastError());
+    return NNCF_OK;
+  };
+  if (train) {
+    if (int rc = tower_forward(t, d_item_ids, (int)m, d_n_valid, 1, prepare_backward != 0, d_row_scale, d_out, st)) return rc;
+    return add_ids();
+  }
   const int64_t chunk = t->cnn.F > 0 ? t->cfg.max_rows : (1 << 20);  // the CNN keeps a block's conv output
   for (int64_t i0 = 0; i0 < m; i0 += chunk) {  // inference rows are independent: any m
     const int64_t cnt = m - i0 < chunk ? m - i0 : chunk;
     if (int rc = tower_forward(t, d_item_ids + i0, (int)cnt, nullptr, 0, 0, nullptr, d_out + i0 * t->cfg.item_dim, st)) return rc;
   }
+  return add_ids();
+}
+
+int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(!max_pooling || t->cfg.conv_filters == 0, "pooling = 'max' belongs to the mean-pool tower (cnn_embedding pools its conv output)");
+  if (max_pooling && !t->amax) {
+    DeviceGuard guard(t->device);
+    if (hipMalloc(&t->amax, sizeof(int32_t) * (size_t)t->cfg.max_rows * t->cfg.word_dim) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "argmax buffer allocation failed");
+  }
+  t->pool_max = max_pooling ? 1 : 0;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, float* d_m, float* d_v, int32_t* d_stamp) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(!d_id_table || ((uintptr_t)d_id_table & 15) == 0, "the id table must be 16-byte aligned");
+  NNCF_REQUIRE(v_reg >= 0.f, "v_reg must be >= 0");
+  if (d_id_table && !t->cid_reg) {
+    DeviceGuard guard(t->device);
+    if (hipMalloc(&t->cid_reg, sizeof(float) * (size_t)t->cfg.max_rows) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "regulariser buffer allocation failed");
+  }
+  t->cid_tab = d_id_table;
+  t->v_reg = v_reg;
+  t->acid = AdamTable{d_m, d_v, d_stamp};
   return NNCF_OK;
 }
 

@@ -189,6 +189,40 @@ class MeanPoolTower(object):
             _lib.check(self._L.nncf_tower_set_optimizer(self.handle, mode, beta1, beta2, epsilon, p(st.get("mW")),
                                                         p(st.get("vW")), p(st.get("mD")), p(st.get("vD"))))
         self.optimizer = kind
+        if getattr(self, "Cid", None) is not None:
+            self._bind_content_id(kind)
+
+    def set_pooling(self, pooling):
+        """conf.pooling (mean_pool.py:68-76): 'average' (default) | 'max' (MaxPooling1D over the whole length)."""
+        assert pooling in ("average", "max"), "[ERROR] unknown pooling: %s" % pooling
+        assert not (self.conv and pooling == "max"), "pooling = 'max' belongs to the mean-pool tower"
+        self.pooling = pooling
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_pooling(self.handle, int(pooling == "max")))
+        self.version += 1
+
+    def set_content_id(self, v_reg=0.0, seed=0, optimizer="sgd"):
+        """conf.use_content_id (mean_pool.py:102-108): the tower's output + Emb_Cid[item id]; Embedding(item_count,
+        item_dim) init uniform(+-0.05) [K-mem], activity_l2(v_reg) on its output."""
+        gen = torch.Generator().manual_seed(int(seed) + 41)
+        Cid = torch.zeros(self.item_count, self.d)
+        Cid[:, :self.d_l] = (torch.rand(self.item_count, self.d_l, generator=gen) * 2 - 1) * 0.05
+        self.Cid = Cid.to(self.device).contiguous()
+        self.v_reg = float(v_reg)
+        self._bind_content_id(optimizer)
+        self.version += 1
+
+    def _bind_content_id(self, optimizer):
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+        st = {}
+        if optimizer != "sgd":
+            st = dict(m=torch.zeros_like(self.Cid), v=torch.zeros_like(self.Cid))
+            if optimizer == "adam":
+                st["stamp"] = torch.zeros(self.item_count, dtype=torch.int32, device=self.device)
+        self.cid_state = st
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_content_id(self.handle, p(self.Cid), self.v_reg, p(st.get("m")), p(st.get("v")),
+                                                         p(st.get("stamp"))))
 
     def set_dropout(self, rate, seed=0):
         """Embedding(dropout=rate) row dropout (mean_pool.py:56-59), mask generated inside the

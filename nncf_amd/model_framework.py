@@ -448,10 +448,11 @@ def _conv_spec(conf):
 def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     from .mean_pool import MeanPoolTower
     data_spec = data_helper.data_spec
-    if getattr(conf, "pretrain", None) or getattr(conf, "use_content_id", False) or \
-            (conv is None and conf.pooling != "average"):
-        raise NotImplementedError("the text towers are built for pretrain=None, use_content_id=False, "
-                                  "pooling='average' (what the demo scripts run)")
+    if getattr(conf, "pretrain", None):
+        raise NotImplementedError("the text towers are built for pretrain=None (what the demo scripts run: the pretrained "
+                                  "sentence vectors are not in the repo)")
+    pooling = getattr(conf, "pooling", "average")
+    assert conv is not None or pooling in ("average", "max"), "[ERROR] unknown pooling: %s" % pooling   # mean_pool.py:76
     idt = conf.item_dense_transform
     assert idt["dense_hidden_dim"] == conf.item_dim and idt["dense_hidden_actv"] == "relu" and \
         idt["dense_hidden_dropout"] == 0., "item_dense_transform other than Dense(item_dim)+relu is not built"
@@ -462,6 +463,10 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     tower = MeanPoolTower(data_helper.data["C"], data_spec.word_count, conf.word_dim, conf.item_dim,
                           abs(conf.learn_rate), engine.device, seed=seed,
                           dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap, conv=conv)
+    if conv is None and pooling == "max":
+        tower.set_pooling("max")                                        # mean_pool.py:70-72
+    if getattr(conf, "use_content_id", False):                          # mean_pool.py:102-108
+        tower.set_content_id(getattr(conf, "v_reg", 0.0), seed=seed)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
     opt = getattr(conf, "optimizer", "sgd")
     if opt != "sgd":

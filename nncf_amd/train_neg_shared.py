@@ -26,16 +26,19 @@ class Trainer(TrainerBase):
         self.train_time = []
         for epoch in range(conf.max_epoch + 1):
             cost, it = 0, 0
+            monitor = (dict((n, 0.0) for n in self.model_all_loss.keys()), 0)
             shuffle_rows(train)
             n_steps = len(train) // b if epoch > 0 else 0
             uid, cid = self._upload(train, n_steps)
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
             if n_steps:
-                losses = self.model_train.run_epoch(uid, cid, n_steps)
+                losses, mon_costs, mon_it = self._run_epoch_monitored(self.model_train, self.model_all_loss, "neg_shared", uid, cid,
+                                                                      n_steps)   # :52-58
+                monitor = (mon_costs, mon_it)
                 cost = float(losses.double().sum().item())
                 it = self._iterations(n_steps, len(train), b)
             if epoch > 0:
                 self.train_time.append(time.time() - t_start)
-            self._epoch_report(epoch, it, cost, eval_scheme)
+            self._epoch_report(epoch, it, cost, eval_scheme, monitor)
         self._finish()

@@ -22,7 +22,7 @@ class Trainer(TrainerBase):
         self.model_all_loss = model_dict["model_all_loss"]
         self.neg_sign = np.array([-1], dtype="int32") if conf.loss == "skip-gram" else 0  # :13-14
         self.sample_batch = data_helper.sampler_dict["sample_batch"]
-        self.monitor_rate = getattr(conf, "monitor_rate_all_loss", 0)
+        self.monitor_rate = getattr(conf, "monitor_rate_all_loss", 0)   # :16-19: > 0 to monitor the other losses
 
     def train(self, eval_scheme=None, use_async_eval=True):
         conf = self.conf
@@ -30,23 +30,23 @@ class Trainer(TrainerBase):
         train = self.data_helper.data["train"]
         engine = self.model_train.engine
         sampler = self.sample_batch.__self__
-        if self.monitor_rate:
-            print("[WARNING] monitor_rate_all_loss is ignored by the device epoch loop; use "
-                  "model_dict['model_all_loss'][name].train_on_batch for spot checks")
         self.train_time = []
         for epoch in range(conf.max_epoch + 1):
             shuffle_rows(train)
             cost, it = 0, 0
+            monitor = (dict((n, 0.0) for n in self.model_all_loss.keys()), 0)
             n_steps = len(train) // b if epoch > 0 else 0  # ragged tail dropped (:46-48)
             uid, cid = self._upload(train, n_steps)
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
             if n_steps:
                 neg = sampler.sample_batch_device(n_steps * b * k)
-                losses = self.model_train.run_epoch(uid, cid, n_steps, neg_all=neg)
+                losses, mon_costs, mon_it = self._run_epoch_monitored(self.model_train, self.model_all_loss, "original", uid, cid,
+                                                                      n_steps, neg=neg)   # :59-67
+                monitor = (mon_costs, mon_it)
                 cost = float(losses.double().sum().item())  # one host sync per epoch
                 it = self._iterations(n_steps, len(train), b)
             if epoch > 0:
                 self.train_time.append(time.time() - t_start)
-            self._epoch_report(epoch, it, cost, eval_scheme)
+            self._epoch_report(epoch, it, cost, eval_scheme, monitor)
         self._finish()

@@ -357,6 +357,10 @@ class TowerOracle(object):
         self.rv = np.ones_like(self.beta)
         self.lr = self.dt.type(lr)
         self.eps, self.mom = self.dt.type(eps), self.dt.type(momentum)
+        self.pooling = "average"   # conf.pooling (mean_pool.py:68-76): 'average' | 'max'
+        self.Cid = None            # conf.use_content_id (mean_pool.py:102-108): Emb_Cid table (item_count, d), or None
+        self.v_reg = self.dt.type(0)   # activity_l2(v_reg) on the Emb_Cid output
+        self.extra_loss = 0.0
 
     PARAMS = ("W", "Wd", "bd", "gamma", "beta")
 
@@ -365,6 +369,11 @@ class TowerOracle(object):
         E = self.W[toks]                                       # (n_u, L, wd)
         if row_scale is not None:
             E = E * row_scale[toks][..., None]
+        if self.pooling == "max":                              # mean_pool.py:70-72: MaxPooling1D(max_content_len)
+            am = E.argmax(axis=1)                              # (n, wd) position of each column's maximum
+            if train:
+                self.cache["argmax"] = am
+            return np.take_along_axis(E, am[:, None, :], axis=1)[:, 0, :]
         return E.sum(axis=1) / self.dt.type(toks.shape[1])     # mean_pool.py:30: divide by L always
 
     def _front_backward(self, dh):
@@ -372,11 +381,47 @@ class TowerOracle(object):
         c = self.cache
         L = self.dt.type(c["toks"].shape[1])
         dW = np.zeros_like(self.W)
+        if self.pooling == "max":      # the gradient of column c goes to the word at the argmax position [K-mem: first maximum]
+            am = c["argmax"]
+            words = np.take_along_axis(c["toks"], am, axis=1)  # (n, wd) word that supplied each column's maximum
+            g = dh if c["row_scale"] is None else dh * c["row_scale"][words]
+            cols = np.broadcast_to(np.arange(dh.shape[1])[None, :], dh.shape)
+            np.add.at(dW, (words, cols), g.astype(self.dt))
+            return dict(W=dW)
         contrib = np.repeat(dh[:, None, :], c["toks"].shape[1], axis=1) / L
         if c["row_scale"] is not None:
             contrib = contrib * c["row_scale"][c["toks"]][..., None]
         np.add.at(dW, c["toks"], contrib.astype(self.dt))
         return dict(W=dW)
+
+    def _plus_content_id(self, out, cid_u, train):
+        """mean_pool.py:102-108: h + Emb_Cid[cid]; activity_l2(v_reg): v_reg * sum_d mean_n(row^2) joins the loss."""
+        self.extra_loss = 0.0
+        if self.Cid is None:
+            return out
+        rows = self.Cid[np.asarray(cid_u)]
+        if train:
+            self.cache["cid_u"] = np.asarray(cid_u)
+            self.extra_loss = float(self.v_reg * np.sum(np.mean(rows * rows, axis=0)))
+        return (out + rows).astype(self.dt)
+
+    def _content_id_update(self, dA, conf, t):
+        if self.Cid is None:
+            return
+        ids = self.cache["cid_u"]                              # unique ids of the block: one gradient row each
+        n = self.dt.type(len(ids))
+        g = (dA + 2 * self.v_reg * self.Cid[ids] / n).astype(self.dt)
+        if getattr(self, "export_only", False):
+            raise NotImplementedError("use_content_id with the data-parallel export")
+        if conf is None or conf.optimizer == "sgd":
+            self.Cid[ids] -= self.lr * g
+        else:
+            if not hasattr(self, "slot_cid"):
+                self.slot_cid = AdamSlot(self.Cid)
+            full = np.zeros_like(self.Cid)
+            full[ids] = g
+            self.slot_cid.step(self.Cid, full, adam_lr_t(self.lr, conf.beta1, conf.beta2, t), conf,
+                               ids if conf.optimizer == "sparse_adam" else None)
 
     def forward(self, cid_u, train=True, row_scale=None):
         toks = self.C[np.asarray(cid_u)]                       # (n_u, L)
@@ -394,11 +439,12 @@ class TowerOracle(object):
         y = self.gamma * xhat + self.beta
         if train:
             self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
-        return np.maximum(y, 0).astype(self.dt)
+        return self._plus_content_id(np.maximum(y, 0).astype(self.dt), cid_u, train)
 
     def backward_update(self, dA, conf=None, t=None):
         """conf / t: OracleConf with optimizer != 'sgd' and the 1-based optimiser step."""
         c = self.cache
+        self._content_id_update(dA, conf, t)
         n = self.dt.type(dA.shape[0])
         dy = dA * (c["y"] > 0)
         dgamma = (dy * c["xhat"]).sum(axis=0)
@@ -796,7 +842,7 @@ class StepOracle(object):
         if update:
             self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, g[:, None] * hat_v, g[:, None] * hat_u, g, g)
         self._tower_out(update)
-        return float(loss + reg)
+        return float(loss + reg) + float(getattr(self.tower, 'extra_loss', 0.0) or 0.0)   # + activity_l2(v_reg) of Emb_Cid
 
     # -- train_scheme = neg_shared (train_neg_shared.py:46-51; :128-129,153-155) ----------
     def step_neg_shared(self, uid, cid, update=True):
@@ -811,7 +857,7 @@ class StepOracle(object):
         if update:
             self._apply(uid, cid, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u, G.sum(axis=1), G.sum(axis=0))
         self._tower_out(update)
-        return float(loss + reg)
+        return float(loss + reg) + float(getattr(self.tower, 'extra_loss', 0.0) or 0.0)   # + activity_l2(v_reg) of Emb_Cid
 
     # -- train_scheme = group_neg_shared (train_group_neg_shared.py:53-61; :131-136,158-161)
     def step_group_neg_shared(self, uid, cid, update=True):
@@ -828,7 +874,7 @@ class StepOracle(object):
         if update:
             self._apply(uid, cid_u, raw_u, hat_u, inv_u, hat_v, inv_v, G @ hat_v, G.T @ hat_u, G.sum(axis=1), G.sum(axis=0))
         self._tower_out(update)
-        return float(loss + reg)
+        return float(loss + reg) + float(getattr(self.tower, 'extra_loss', 0.0) or 0.0)   # + activity_l2(v_reg) of Emb_Cid
 
     # -- train_scheme = sampled_neg_shared (train_sampled_neg_shared.py:46-52; :138-143,166-170)
     def step_sampled_neg_shared(self, uid, cid, update=True):
@@ -853,7 +899,7 @@ class StepOracle(object):
             self._apply(ufront, cid, raw_u, raw_u, None, hat_v, inv_v, g_u, g_v, G.sum(axis=1),
                         np.concatenate([G[:, 0], G[:, 1:].sum(axis=0)]))
         self._tower_out(update)
-        return float(loss + reg)
+        return float(loss + reg) + float(getattr(self.tower, 'extra_loss', 0.0) or 0.0)   # + activity_l2(v_reg) of Emb_Cid
 
     # -- inference heads (model_framework.py:153,173-176) --------------------------------
     def predict_neg_shared(self, uid, cid):

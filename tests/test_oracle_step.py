@@ -285,6 +285,55 @@ def test_tower_oracle_vs_autograd_full_chain():
         np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
 
 
+@pytest.mark.parametrize("pooling,content_id", [("max", False), ("average", True), ("max", True)])
+def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id):
+    """conf.pooling = 'max' (mean_pool.py:70-72: MaxPooling1D over the whole length) and conf.use_content_id
+    (mean_pool.py:102-108: tower output + Emb_Cid[cid], activity_l2(v_reg) on the Embedding output): loss and every
+    gradient of the oracle against torch autograd of the formulas; word-row dropout on (dropped rows are zeros that
+    still take part in the maximum)."""
+    rs = np.random.RandomState(1)
+    I, L, Wc, wd, d, nu, b = 30, 7, 20, 8, 8, 10, 8
+    C = rs.randint(0, Wc, (I, L))
+    C[:, :2] = 0
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = rs.uniform(-.1, .1, d), rs.uniform(.5, 1.5, d), rs.uniform(-.1, .1, d)
+    U, Cid = rs.uniform(-.5, .5, (nu, d)), rs.uniform(-.5, .5, (I, d))
+    scale = ((rs.rand(Wc) < 0.7) / 0.7)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-3, learn_rate=0.1,
+                         model_choice="basic_embedding")
+    tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.1, dtype=np.float64)
+    tw.pooling = pooling
+    if content_id:
+        tw.Cid, tw.v_reg = Cid.copy(), 0.05
+    o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
+    o.row_scale = scale
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+    cid[3] = cid[0]
+    l_o = o.step_neg_shared(uid, cid)
+    tU = torch.tensor(U, requires_grad=True)
+    tp = [torch.tensor(x, requires_grad=True) for x in (W, Wd, bd, ga, be, Cid)]
+    cu, cx = so.tf_unique(cid)
+    rows = tp[0][torch.tensor(C[cu])] * torch.tensor(scale)[torch.tensor(C[cu])][..., None]
+    h = rows.max(dim=1).values if pooling == "max" else rows.sum(1) / L
+    z = h @ tp[1] + tp[2]
+    mu = z.mean(0)
+    var = ((z - mu) ** 2).mean(0)
+    E = torch.relu(tp[3] * (z - mu) / torch.sqrt(var + 1e-3) + tp[4])
+    extra = 0.
+    if content_id:
+        ce = tp[5][torch.tensor(cu, dtype=torch.long)]
+        E = E + ce
+        extra = 0.05 * (ce * ce).mean(0).sum()
+    l_t = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf) + extra
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    for name, t in zip(("W", "Wd", "bd", "gamma", "beta"), tp):
+        np.testing.assert_allclose(tw.grads[name], t.grad.numpy(), atol=1e-10, err_msg=name)
+    np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
+    if content_id:    # the SGD step the oracle took on the id rows = lr * autograd's gradient
+        np.testing.assert_allclose(Cid - tw.Cid, 0.1 * tp[5].grad.numpy(), atol=1e-10)
+
+
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
 def test_adam_slot_against_torch_adam(kind):
     """AdamSlot (Keras / TF formula lr_t m / (sqrt v + eps)) against torch.optim.Adam /

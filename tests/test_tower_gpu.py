@@ -972,3 +972,65 @@ def test_text_tower_random_small_batches_terminate_and_match(text_data, seed):
         np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
         for name in ("W", "Wd", "gamma", "beta"):
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4, err_msg=name)
+
+
+@pytest.mark.parametrize("pooling,content_id", [("max", False), ("average", True), ("max", True)])
+@pytest.mark.parametrize("scheme,loss,opt", [("neg_shared", "skip-gram", "sgd"), ("original", "skip-gram", "sgd"),
+                                             ("group_neg_shared", "log-loss", "sgd"), ("neg_shared", "skip-gram", "adam")])
+def test_pooling_max_and_use_content_id_match_oracle(text_data, pooling, content_id, scheme, loss, opt):
+    """conf.pooling = 'max' (mean_pool.py:70-72) and conf.use_content_id with v_reg > 0 (mean_pool.py:102-108): three
+    steps with word-row dropout (masks materialised for the oracle) -- loss, user table, every tower parameter, the
+    Emb_Cid table -- then inference-mode scores and model_item_emb."""
+    conf = _conf(loss, scheme, lr=0.02 if opt == "adam" else 0.2)
+    conf.optimizer = opt
+    conf.pooling = pooling
+    conf.use_content_id = content_id
+    conf.v_reg = 0.05 if content_id else 0.0
+    conf.word_emb_dropout_rate = 0.3
+    helper = get_data(dict(text_data), conf, rand_seed=5)
+    md = get_model(conf, helper, "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data, dtype=np.float64)
+    orc.conf.optimizer = opt
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    core = head.core
+    tw = core.tower
+    to.pooling = pooling
+    if content_id:
+        to.Cid, to.v_reg = tw.Cid.cpu().numpy().astype(np.float64), 0.05
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    rt, at = (5e-4, 5e-5) if opt == "adam" else (2e-5, 5e-6)
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv") + (("Cid",) if content_id else ()):
+            if opt == "adam" and name in ("bd", "rm"):
+                continue
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+    if opt == "adam":
+        return    # bd (and with it the running mean) carries Adam's +-lr rounding steps: inference is checked under SGD
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=2e-4, atol=2e-5)
+    emb = md["model_item_emb"].predict_on_batch([items])
+    if conf.emb_normalization:
+        E = E / np.sqrt(np.maximum((E * E).sum(-1, keepdims=True), 1e-12))
+    np.testing.assert_allclose(emb, E, rtol=2e-4, atol=2e-5)

@@ -265,3 +265,69 @@ def test_group_trainer_with_device_shuffle_learns():
     costs = [h[2] for h in tr.history[1:]]
     assert all(np.isfinite(costs)) and costs[-1] < costs[0]
     assert max(tr.mean_n_u) < 40          # ~ b / chop distinct items per batch, not ~ b
+
+
+@pytest.mark.parametrize("scheme", ["original", "neg_shared"])
+def test_monitor_rate_all_loss_inside_the_device_epoch_loop(small_data, scheme):
+    """conf.monitor_rate_all_loss (train_original.py:16-19,38-40,59-67,74-79; train_neg_shared.py:52-58): after a step, with
+    probability `rate` (random.random(), one draw per step), the four loss-monitor models evaluate that step's batch
+    against the parameters the step left, touching nothing.  Rate 0.3 over one epoch: the monitored steps are the
+    reference's draws, the summed costs equal the oracle's, and training itself is unchanged by the cuts in the loop."""
+    import random
+    conf = _conf("skip-gram", scheme, epochs=1)
+    conf.monitor_rate_all_loss = 0.3
+    runs = []
+    for monitored in (True, False):
+        data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in small_data.items()}
+        c2 = _conf("skip-gram", scheme, epochs=1)
+        if monitored:
+            c2.monitor_rate_all_loss = 0.3
+        helper = get_data(data, c2, rand_seed=777)
+        md = get_model(c2, helper, "mf", seed=1)
+        eng = md["model"].engine
+        U0, V0 = eng.U.cpu().numpy().copy(), eng.V.cpu().numpy().copy()
+        mod = __import__("nncf_amd.train_%s" % scheme, fromlist=["Trainer"])
+        np.random.seed(99)
+        random.seed(5)
+        tr = mod.Trainer(md, c2, helper)
+        tr.train(None)
+        runs.append((tr, eng.U.cpu().numpy().copy(), eng.V.cpu().numpy().copy()))
+    (tr, U1, V1), (tr0, U2, V2) = runs
+    assert np.array_equal(U1, U2) and np.array_equal(V1, V2) and tr.history[-1][2] == tr0.history[-1][2]
+    # the reference loop with its monitoring, on the oracle
+    from oracle.sampler_oracle import OracleSampler
+    from nncf_amd.data_utils import degree_dist
+    ocf = _oracle_conf(conf)
+    orc = so.StepOracle(U0, V0, ocf, dtype=np.float32)
+    train = small_data["train"].copy()
+    b, k = conf.batch_size_p, conf.num_negatives
+    smp = OracleSampler(degree_dist(train, 1, "unigram"), 1.0, 777) if scheme == "original" else None
+    np.random.seed(99)
+    random.seed(5)
+    names = ("skip-gram", "mse", "log-loss", "max-margin")
+    want = dict((n, 0.0) for n in names)
+    mon_it = 0
+    for epoch in range(2):
+        train[:] = train[np.random.permutation(len(train))]
+        for t in range(len(train) // b if epoch else 0):
+            bt = train[t * b:(t + 1) * b]
+            if scheme == "original":
+                u, c, y = so.assemble_original(bt, smp.sample_batch(k * b), conf.loss)
+                orc.step_original(u, c, y)
+            else:
+                u, c = bt[:, 0], bt[:, 1]
+                orc.step_neg_shared(u, c)
+            if random.random() < 0.3:
+                mon_it += 1
+                for n in names:
+                    oc = _oracle_conf(conf)
+                    oc.loss = n
+                    o2 = so.StepOracle(orc.U, orc.V, oc, dtype=np.float32)
+                    if scheme == "original":
+                        want[n] += o2.step_original(u, c, np.where(np.arange(len(u)) < b, 1, -1 if n == "skip-gram" else 0), update=False)
+                    else:
+                        want[n] += o2.step_neg_shared(u, c, update=False)
+    epoch, got_it, got = tr.monitor_history[-1]
+    assert got_it == mon_it and mon_it > 10
+    for n in names:
+        assert abs(got[n] - want[n]) <= 1e-5 * max(1, abs(want[n])), (n, got[n], want[n])
