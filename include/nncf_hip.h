@@ -461,6 +461,20 @@ int nncf_group_shuffle(const int32_t* d_uid, const int32_t* d_cid, int64_t n, in
 int nncf_group_sample(const int32_t* d_groups, int64_t n_groups, int32_t chop, const int32_t* d_member_ptr,
                       const int32_t* d_members, uint64_t seed, int32_t by_user, int32_t* d_uid_out, int32_t* d_cid_out,
                       void* stream);
+/* Device GroupSampler.sample_with_negs (configs/data_utils.py:335-408, used by models/train_group_sample.py:86-88 when
+ * conf.group_shuffling_trick is False), n_steps batches per call: per batch ceil(b / chop) groups (more, in the reference's
+ * rounds :376-390, while the batch is short), `chop` positive members per group, random_rounding(k * chop * p_n/p_d[group])
+ * negative members per group, rows = [positives ; negatives] cut to b * (1 + k), labels 1 / neg_sign.
+ * d_groups [n_steps][gcap]: the group sampler's draws (its stream, gcap per batch); d_neg_members [n_steps][ncap]: the
+ * member sampler's draws, consumed in batch row order; member picks and the rounding uniforms are counter-based hashes of
+ * (seed, position) -- np.random.choice's / random.random()'s distributions, not their streams.  d_p_n_div_p_d: per group
+ * id (double; NULL = 1, neg_dist 'unigram').  d_used_out[t] = groups batch t consumed, -1 if gcap / ncap did not suffice
+ * (the reference asserts after 10 rounds).  gcap <= 4096. */
+int nncf_group_sample_with_negs(const int32_t* d_groups, const int32_t* d_neg_members, int64_t n_steps, int32_t gcap,
+                                int32_t ncap, int32_t batch_size_p, int32_t k, int32_t chop, const int32_t* d_member_ptr,
+                                const int32_t* d_members, const double* d_p_n_div_p_d, uint64_t seed, int32_t by_user,
+                                int32_t neg_sign, int32_t* d_uid_out, int32_t* d_cid_out, int32_t* d_y_out,
+                                int32_t* d_used_out, void* stream);
 
 /* Evaluator whole@k for one candidate set (utils/objectives.py:296-370,395-421 +
  * utils/metrics_ranking.py:6-35 eval_multiple).  d_scores: n_users rows of n_cand scores

@@ -176,3 +176,102 @@ extern "C" int nncf_group_sample(const int32_t* d_groups, int64_t n_groups, int3
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
+
+
+// ---- device GroupSampler.sample_with_negs (configs/data_utils.py:335-408; models/train_group_sample.py:86-88 when
+// conf.group_shuffling_trick is False): a batch = groups from the group sampler, `chop` positive members each, and per
+// group num_negatives = random_rounding(k chop p_n/p_d[group]) negative members from the member sampler; strict return
+// shape: groups are added in rounds (:376-390) until the batch holds b (1 + k) rows, then [positives ; negatives] is cut
+// to that size.  One workgroup per batch, static shapes, nothing syncs:
+//   groups of batch t       = d_groups[t][0 .. gcap)        (the group sampler's stream, gcap draws per batch)
+//   its negative members    = d_neg_members[t][0 .. ncap)   (the member sampler's stream, in batch row order)
+//   positive member picks   = hash32(seed0, t * gcap * chop + row)      (np.random.choice's distribution)
+//   random rounding uniform = hash32(seed1, t * gcap + group index) / 2^32   (random.random()'s distribution)
+// d_used[t] = groups the batch consumed, or -1 when gcap / ncap did not suffice (the reference asserts after 10 rounds).
+namespace nncf {
+constexpr int kGroupCap = 4096;
+
+__global__ void __launch_bounds__(256) group_negs_kernel(const int32_t* __restrict__ groups, const int32_t* __restrict__ neg_members,
+                                                         int gcap, int ncap, int b, int k, int chop,
+                                                         const int32_t* __restrict__ member_ptr, const int32_t* __restrict__ members,
+                                                         const double* __restrict__ pnd, uint64_t seed0, uint64_t seed1, int by_user,
+                                                         int neg_sign, int32_t* __restrict__ uid_out, int32_t* __restrict__ cid_out,
+                                                         int32_t* __restrict__ y_out, int32_t* __restrict__ used_out) {
+  __shared__ int sP[kGroupCap];   // inclusive prefix of the groups' negative counts
+  __shared__ int sUsed, sOk;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int32_t* g = groups + (int64_t)t * gcap;
+  for (int i = tid; i < gcap; i += 256) {
+    const double x = (double)k * (double)chop * (pnd ? pnd[g[i]] : 1.0);
+    const int fl = (int)x;
+    const double u = (double)hash32(seed1, (uint64_t)t * gcap + i) * (1.0 / 4294967296.0);
+    sP[i] = fl + ((u < x - (double)fl) ? 1 : 0);      // int(x) + (random.random() < x - int(x)), :345
+  }
+  __syncthreads();
+  if (tid == 0) {   // gcap <= 4096: a serial prefix is ~2 us and has one order
+    int acc = 0;
+    for (int i = 0; i < gcap; ++i) {
+      acc += sP[i];
+      sP[i] = acc;
+    }
+    const int whole = b * (1 + k);
+    int used = (b + chop - 1) / chop, ok = 1;       // strict_return_shape, :353-354
+    for (int round = 0;; ++round) {
+      if (used > gcap) { ok = 0; used = gcap; break; }
+      const int have = used * chop + sP[used - 1];
+      const int diff = whole - have;
+      if (diff <= 0) break;
+      if (round >= 10) { ok = 0; break; }            // the reference's assert, :379-380
+      used += diff <= 100 ? diff : diff / (chop * (1 + k)) + 100;   // :386-389
+    }
+    sUsed = used;
+    sOk = ok;
+  }
+  __syncthreads();
+  const int used = sUsed, whole = b * (1 + k), npos = used * chop;
+  int ok = sOk;
+  for (int r = tid; r < whole; r += 256) {
+    int grp, mem, y;
+    if (r < npos) {
+      grp = g[r / chop];
+      const int p0 = member_ptr[grp], len = member_ptr[grp + 1] - p0;
+      const uint32_t h = hash32(seed0, (uint64_t)t * gcap * chop + r);
+      mem = members[p0 + (int)(((uint64_t)h * (uint64_t)len) >> 32)];
+      y = 1;
+    } else {
+      const int q = r - npos;       // q-th negative of the batch: group with P[i-1] <= q < P[i]
+      int lo = 0, hi = used - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sP[mid] <= q) lo = mid + 1; else hi = mid;
+      }
+      grp = g[lo];
+      if (q >= ncap) { ok = 0; mem = 0; } else mem = neg_members[(int64_t)t * ncap + q];
+      y = neg_sign;
+    }
+    const int64_t o = (int64_t)t * whole + r;
+    uid_out[o] = by_user ? grp : mem;
+    cid_out[o] = by_user ? mem : grp;
+    y_out[o] = y;
+  }
+  const int all_ok = __syncthreads_and(ok);
+  if (tid == 0) used_out[t] = all_ok ? used : -1;
+}
+}  // namespace nncf
+
+extern "C" int nncf_group_sample_with_negs(const int32_t* d_groups, const int32_t* d_neg_members, int64_t n_steps, int32_t gcap,
+                                           int32_t ncap, int32_t batch_size_p, int32_t k, int32_t chop, const int32_t* d_member_ptr,
+                                           const int32_t* d_members, const double* d_p_n_div_p_d, uint64_t seed, int32_t by_user,
+                                           int32_t neg_sign, int32_t* d_uid_out, int32_t* d_cid_out, int32_t* d_y_out,
+                                           int32_t* d_used_out, void* stream) {
+  NNCF_REQUIRE(n_steps >= 0 && batch_size_p >= 1 && k >= 1 && chop >= 1, "bad shape");
+  if (n_steps == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_groups && d_neg_members && d_member_ptr && d_members && d_uid_out && d_cid_out && d_y_out && d_used_out, "NULL argument");
+  NNCF_REQUIRE(gcap >= (batch_size_p + chop - 1) / chop && gcap <= kGroupCap, "gcap = %d out of range [ceil(b / chop), %d]", gcap, kGroupCap);
+  NNCF_REQUIRE(ncap >= 1, "ncap must be positive");
+  hipLaunchKernelGGL(group_negs_kernel, dim3((unsigned)n_steps), dim3(256), 0, as_stream(stream), d_groups, d_neg_members, gcap, ncap,
+                     batch_size_p, k, chop, d_member_ptr, d_members, d_p_n_div_p_d, mix64(seed), mix64(seed + 1), by_user, neg_sign,
+                     d_uid_out, d_cid_out, d_y_out, d_used_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}

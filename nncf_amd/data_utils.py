@@ -225,14 +225,7 @@ class GroupSampler(object):
         if smp is None or not hasattr(smp, "sample_batch_device"):
             raise ValueError("sample_device needs the HIP group sampler (MultinomialSampler)")
         dev = torch.device("cuda", int(getattr(smp, "device", 0)))
-        if getattr(self, "_dev_csr", None) is None:
-            gmax = max(self.group_members) + 1
-            ptr = np.zeros(gmax + 1, dtype=np.int64)
-            for g, m in self.group_members.items():
-                ptr[g + 1] = len(m)
-            ptr = np.cumsum(ptr)
-            mem = np.concatenate([self.group_members[g] for g in sorted(self.group_members)]) if self.group_members else np.zeros(0)
-            self._dev_csr = (torch.as_tensor(ptr.astype(np.int32)).to(dev), torch.as_tensor(mem.astype(np.int32)).to(dev))
+        self._device_csr(dev)
         b, chop = int(batch_size_p), self.chop
         per = int(np.ceil(float(b) / chop))
         groups = smp.sample_batch_device(n_steps * per)
@@ -248,6 +241,66 @@ class GroupSampler(object):
             uo = uo.view(n_steps, rows)[:, :b].contiguous().view(-1)
             co = co.view(n_steps, rows)[:, :b].contiguous().view(-1)
         return uo, co
+
+    def _device_csr(self, dev):
+        import torch
+        if getattr(self, "_dev_csr", None) is None:
+            gmax = max(self.group_members) + 1
+            ptr = np.zeros(gmax + 1, dtype=np.int64)
+            for g, m in self.group_members.items():
+                ptr[g + 1] = len(m)
+            ptr = np.cumsum(ptr)
+            mem = np.concatenate([self.group_members[g] for g in sorted(self.group_members)]) if self.group_members else np.zeros(0)
+            self._dev_csr = (torch.as_tensor(ptr.astype(np.int32)).to(dev), torch.as_tensor(mem.astype(np.int32)).to(dev))
+        return self._dev_csr
+
+    def negs_caps(self, batch_size_p, k):
+        """(groups, negative-member draws) one device batch of sample_with_negs consumes from the two samplers' streams"""
+        per = int(np.ceil(float(batch_size_p) / self.chop))
+        exact = all(v == 1.0 for v in self.p_n_div_p_d.values())     # 'unigram' / no correction: k * chop negatives per group
+        return (per if exact else min(2 * per + 200, 4096)), batch_size_p * (1 + k)
+
+    def sample_with_negs_device(self, batch_size_p, k, n_steps, seed=0):
+        """n_steps batches of `sample_with_negs(batch_size_p, k)` drawn on the device (nncf_group_sample_with_negs,
+        csrc/shuffle.hip): groups and negative members from the two B1 device samplers (one draw each for the whole
+        epoch, a fixed number per batch: negs_caps), positive members and the random rounding of the negatives' count
+        by counter-based hashes.  Returns int32 device tensors (uid, cid, y) of n_steps * b * (1 + k) rows."""
+        import ctypes
+        import torch
+        from . import _lib
+        gs, ms = getattr(self.group_sampler, "__self__", None), getattr(self.member_neg_sampler, "__self__", None)
+        if gs is None or ms is None or not hasattr(gs, "sample_batch_device") or not hasattr(ms, "sample_batch_device"):
+            raise ValueError("sample_with_negs_device needs the HIP samplers (MultinomialSampler)")
+        dev = torch.device("cuda", int(getattr(gs, "device", 0)))
+        ptr, mem = self._device_csr(dev)
+        b, k, chop = int(batch_size_p), int(k), self.chop
+        gcap, ncap = self.negs_caps(b, k)
+        whole = b * (1 + k)
+        if n_steps <= 0:
+            e = torch.empty(0, dtype=torch.int32, device=dev)
+            return e, e.clone(), e.clone()
+        groups = gs.sample_batch_device(n_steps * gcap)
+        negs = ms.sample_batch_device(n_steps * ncap)
+        pnd = None
+        if gcap != int(np.ceil(float(b) / chop)):
+            if getattr(self, "_dev_pnd", None) is None:
+                arr = np.ones(max(self.group_members) + 1, dtype=np.float64)
+                for g, v in self.p_n_div_p_d.items():
+                    arr[g] = v
+                self._dev_pnd = torch.as_tensor(arr).to(dev)
+            pnd = self._dev_pnd
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+        uo, co, yo, used = i32(n_steps * whole), i32(n_steps * whole), i32(n_steps * whole), i32(max(n_steps, 1))
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nncf_group_sample_with_negs(
+                p(groups), p(negs), n_steps, gcap, ncap, b, k, chop, p(ptr), p(mem), p(pnd), int(seed) & (2 ** 64 - 1),
+                int(self.group_by == "user"), int(np.asarray(self.neg_sign).reshape(-1)[0]), p(uo), p(co), p(yo), p(used),
+                _lib.stream_ptr(torch.cuda.current_stream(dev))))
+        if n_steps and int(used[:n_steps].min().item()) < 0:     # the epoch's one host read
+            raise AssertionError("[WARNING] the code here should be optimized if this is shown.")   # data_utils.py:379-380
+        self.last_groups_used = used[:n_steps]
+        return uo, co, yo
 
     def sample_with_negs(self, batch_size_p, k, strict_return_shape=True):
         """first ~batch_size_p rows positives (response 1), the rest negatives (response neg_sign)."""

@@ -39,6 +39,13 @@ class Trainer(RowwiseTrainer):
         if not self.group_shuffling_trick:   # :86-88: every batch straight from the GroupSampler
             n_steps = len(self.data_helper.data["train"]) // b if epoch > 0 else 0
             t0 = time.time()
+            if getattr(conf, "device_shuffle", False):
+                # the epoch's batches drawn on the device (nncf_group_sample_with_negs): no host loop, no upload
+                import torch
+                self._epoch_seed = getattr(self, "_epoch_seed", 0) + 1
+                uid, cid, y = self.group_sampler.sample_with_negs_device(b, k, n_steps, seed=self._epoch_seed)
+                torch.cuda.synchronize(uid.device)
+                return (uid, cid, y), time.time() - t0
             rows = [self.group_sampler.sample_with_negs(b, k) for _ in range(n_steps)]
             rows = np.concatenate(rows, 0) if rows else np.zeros((0, 3), dtype=np.int64)
             return rows, time.time() - t0

@@ -36,10 +36,15 @@ class RowwiseTrainer(TrainerBase):
         for epoch in range(conf.max_epoch + 1):
             rows, in_window = self.build_epoch(epoch)
             cost, it = 0, 0
-            n_steps = len(rows) // n if epoch > 0 else 0   # ragged tail dropped
-            m = n_steps * n
-            to = lambda col: torch.as_tensor(np.ascontiguousarray(rows[:m, col]).astype(np.int32)).to(engine.device)  # noqa: E731
-            uid, cid, y = to(0), to(1), to(2)
+            if isinstance(rows, tuple):      # (uid, cid, y) int32 device tensors: the epoch was assembled on the device
+                uid, cid, y = rows
+                n_steps = uid.numel() // n if epoch > 0 else 0
+                rows = np.zeros((uid.numel(), 0))
+            else:
+                n_steps = len(rows) // n if epoch > 0 else 0   # ragged tail dropped
+                m = n_steps * n
+                to = lambda col: torch.as_tensor(np.ascontiguousarray(rows[:m, col]).astype(np.int32)).to(engine.device)  # noqa: E731
+                uid, cid, y = to(0), to(1), to(2)
             torch.cuda.synchronize(engine.device)
             t_start = time.time()
             if n_steps:

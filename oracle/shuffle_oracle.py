@@ -62,3 +62,55 @@ def group_sample_rows(groups, chop, member_ptr, members, seed, by_user=False):
     pick = (r * ln) >> np.uint64(32)
     m = np.asarray(members)[(p0 + pick).astype(np.int64)]
     return (g, m) if by_user else (m, g)
+
+
+def group_sample_with_negs_rows(groups, neg_members, gcap, ncap, b, k, chop, member_ptr, members, pnd, seed, by_user=False, neg_sign=0):
+    """numpy restatement of nncf_group_sample_with_negs (csrc/shuffle.hip): the batches of GroupSampler.sample_with_negs
+    (/root/reference/configs/data_utils.py:335-408, strict_return_shape=True) for the given sampler draws
+    (groups [n_steps * gcap], neg_members [n_steps * ncap]).  Returns (uid, cid, y, groups_used) like the kernel."""
+    groups = np.asarray(groups, dtype=np.int64).reshape(-1, gcap)
+    negm = np.asarray(neg_members, dtype=np.int64).reshape(-1, ncap)
+    ptr, mem = np.asarray(member_ptr, dtype=np.int64), np.asarray(members, dtype=np.int64)
+    with np.errstate(over="ignore"):
+        s0, s1 = int(mix64(np.uint64(seed))), int(mix64(np.uint64(seed) + np.uint64(1)))
+    whole = b * (1 + k)
+    U, C, Y, used_out = [], [], [], []
+    for t in range(groups.shape[0]):
+        g = groups[t]
+        x = float(k) * float(chop) * (np.ones(gcap) if pnd is None else np.asarray(pnd, dtype=np.float64)[g])
+        fl = x.astype(np.int64)
+        u = hash32(s1, np.uint64(t) * np.uint64(gcap) + np.arange(gcap, dtype=np.uint64)).astype(np.float64) / 4294967296.0
+        P = np.cumsum(fl + (u < x - fl))
+        used, ok = -(-b // chop), True
+        for rnd in range(12):
+            if used > gcap:
+                ok, used = False, gcap
+                break
+            diff = whole - (used * chop + P[used - 1])
+            if diff <= 0:
+                break
+            if rnd >= 10:
+                ok = False
+                break
+            used += diff if diff <= 100 else diff // (chop * (1 + k)) + 100
+        npos = used * chop
+        r = np.arange(whole)
+        pos = r < npos
+        grp = np.empty(whole, dtype=np.int64)
+        mm = np.zeros(whole, dtype=np.int64)
+        rp = r[pos]
+        grp[pos] = g[rp // chop]
+        p0 = ptr[grp[pos]].astype(np.uint64)
+        ln = (ptr[grp[pos] + 1] - ptr[grp[pos]]).astype(np.uint64)
+        h = hash32(s0, np.uint64(t) * np.uint64(gcap) * np.uint64(chop) + rp.astype(np.uint64))
+        mm[pos] = mem[(p0 + ((h * ln) >> np.uint64(32))).astype(np.int64)]
+        q = r[~pos] - npos
+        grp[~pos] = g[np.searchsorted(P[:used], q, side="right").clip(max=used - 1)]
+        if q.size and q.max() >= ncap:
+            ok = False
+        mm[~pos] = negm[t][np.minimum(q, ncap - 1)]
+        U.append(grp if by_user else mm)
+        C.append(mm if by_user else grp)
+        Y.append(np.where(pos, 1, neg_sign))
+        used_out.append(used if ok else -1)
+    return np.concatenate(U), np.concatenate(C), np.concatenate(Y), np.asarray(used_out)

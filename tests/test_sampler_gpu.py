@@ -197,3 +197,64 @@ def test_device_group_sampler_equals_its_oracle_exactly():
         assert all((int(u), int(c)) in links for u, c in zip(uo, co))
         grp = co if by == "item" else uo
         assert np.all(grp.reshape(steps, b)[:, :chop] == grp.reshape(steps, b)[:, :1])     # runs of one group
+
+
+@pytest.mark.parametrize("neg_dist", ["unigram", "uniform"])
+def test_device_sample_with_negs_equals_its_oracle_and_the_reference_semantics(neg_dist):
+    """GroupSampler.sample_with_negs_device (nncf_group_sample_with_negs; configs/data_utils.py:335-408): groups and
+    negative members are the two B1 samplers' streams (bit-exact vs the C oracle of nodesampler.cpp), everything else
+    equals the numpy restatement of the same counter-based hashes; and the reference's semantics hold: positives first
+    with label 1, every positive a training link, runs of `chop` positives per group, the negatives of a group follow
+    its positives' group order, every batch exactly b (1 + k) rows, E[#negatives per group] = k chop p_n / p_d."""
+    import torch
+    from nncf_amd.data_utils import GroupSampler, degree_dist
+    from oracle.sampler_oracle import OracleSampler
+    from oracle.shuffle_oracle import group_sample_with_negs_rows
+    rs = np.random.RandomState(2)
+    n, nu, ni = 5000, 200, 90
+    train = np.unique(np.stack([rs.randint(0, nu, n), rs.zipf(1.4, n) % ni, np.ones(n, dtype=np.int64)], 1), axis=0)
+    links = set(map(tuple, train[:, :2].tolist()))
+    for by, chop, b, k in (("item", 4, 64, 3), ("item", 5, 64, 2), ("user", 3, 32, 4)):
+        gs = GroupSampler(train, group_by=by, chop=chop, neg_dist=neg_dist, neg_sign=-1)
+        g_smp, m_smp = gs.group_sampler.__self__, gs.member_neg_sampler.__self__
+        g_smp.state, m_smp.state = 4242, 777
+        steps = 9
+        uo, co, yo = [t.cpu().numpy() for t in gs.sample_with_negs_device(b, k, steps, seed=13)]
+        whole = b * (1 + k)
+        assert uo.shape == (steps * whole,)
+        gc, mc = (1, 0) if by == "item" else (0, 1)
+        gcap, ncap = gs.negs_caps(b, k)
+        assert (gcap == -(-b // chop)) == (neg_dist == "unigram")
+        want_groups = OracleSampler(degree_dist(train, gc, "unigram"), 1.0, 4242).sample_batch(steps * gcap)
+        want_negs = OracleSampler(degree_dist(train, mc, neg_dist), 0.75, 777).sample_batch(steps * ncap)
+        ptr, mem = [t.cpu().numpy() for t in gs._dev_csr]
+        pnd = None
+        if neg_dist == "uniform":
+            pnd = np.ones(len(ptr) - 1)
+            for g, v in gs.p_n_div_p_d.items():
+                pnd[g] = v
+        wu, wc, wy, used = group_sample_with_negs_rows(want_groups, want_negs, gcap, ncap, b, k, chop, ptr, mem, pnd, 13,
+                                                       by_user=(by == "user"), neg_sign=-1)
+        assert np.array_equal(uo, wu) and np.array_equal(co, wc) and np.array_equal(yo, wy), (by, chop)
+        assert np.array_equal(gs.last_groups_used.cpu().numpy(), used) and used.min() > 0
+        for t in range(steps):
+            sl = slice(t * whole, (t + 1) * whole)
+            y, u, c = yo[sl], uo[sl], co[sl]
+            npos = int((y == 1).sum())
+            # positives first; under 'uniform' popular groups get few negatives, the rounds add groups and the positives alone
+            # can fill the batch (the reference cuts [positives ; negatives] the same way, :404-406)
+            assert npos == min(used[t] * chop, whole) and np.all(y[:npos] == 1) and np.all(y[npos:] == -1)
+            npos -= npos % chop
+            assert all((int(a), int(bb)) in links for a, bb in zip(u[:npos], c[:npos]))
+            grp = (c if by == "item" else u)
+            assert np.all(grp[:npos].reshape(-1, chop) == grp[:npos].reshape(-1, chop)[:, :1])       # runs of one group
+            order = grp[:npos:chop]
+            neg_groups = grp[npos:]
+            first = [int(np.flatnonzero(order == g)[0]) for g in neg_groups]
+            assert first == sorted(first) or len(set(order)) < len(order)     # negatives in the groups' order
+        if neg_dist == "unigram":
+            assert np.all(used == -(-b // chop))
+    # the negatives' count per group is k chop p_n / p_d in expectation (random rounding, :345)
+    gs = GroupSampler(train, group_by="item", chop=2, neg_dist="uniform", neg_sign=0)
+    x = np.array([3 * 2 * gs.p_n_div_p_d[g] for g in sorted(gs.p_n_div_p_d)])
+    assert np.any(np.abs(x - np.round(x)) > 0.05)

@@ -215,3 +215,42 @@ def test_group_sampler_trainers_match_oracle_loops(small_data, scheme):
         assert abs(got - cost / it) <= 1e-5 * max(1, abs(cost / it)), (epoch, got, cost / it)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+
+
+def test_group_sample_trainer_with_device_sample_with_negs(small_data):
+    """train_scheme = group_sample, group_shuffling_trick = False, conf.device_shuffle = True: every epoch's batches come
+    from GroupSampler.sample_with_negs_device (no host loop, no upload) -- the trainer against the oracle loop fed with the
+    device sampler's restatement (oracle/shuffle_oracle.py) on the checker samplers' streams."""
+    import importlib
+    from oracle.shuffle_oracle import group_sample_with_negs_rows
+    conf = _conf("skip-gram", epochs=2)
+    conf.group_shuffling_trick = False
+    conf.device_shuffle = True
+    data = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in small_data.items()}
+    helper = get_data(data, conf, reverse_samping=True, rand_seed=3)
+    md = get_model(conf, helper, "mf", seed=4)
+    eng = md["model"].engine
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), _oconf(conf), dtype=np.float32)
+    tr = importlib.import_module("nncf_amd.train_group_sample").Trainer(md, conf, helper)
+    gs = tr.group_sampler
+    gs.group_sampler.__self__.state = 0
+    gs.member_neg_sampler.__self__.state = 0
+    tr.train(None)
+    b, k, chop = conf.batch_size_p, conf.num_negatives, conf.chop_size
+    train = small_data["train"]
+    n_steps = len(train) // b
+    gcap, ncap = gs.negs_caps(b, k)
+    g_or = OracleSampler(degree_dist(train, 1, "unigram"), 1.0, 0)
+    m_or = OracleSampler(degree_dist(train, 0, conf.neg_dist), 0.75, 0)
+    ptr, mem = [t.cpu().numpy() for t in gs._dev_csr]
+    n = b * (1 + k)
+    for epoch in (1, 2):
+        u, c, y, used = group_sample_with_negs_rows(g_or.sample_batch(n_steps * gcap), m_or.sample_batch(n_steps * ncap), gcap, ncap,
+                                                    b, k, chop, ptr, mem, None, epoch + 1, neg_sign=-1)
+        assert used.min() > 0
+        cost = sum(orc.step_original(u[t * n:(t + 1) * n], c[t * n:(t + 1) * n], y[t * n:(t + 1) * n]) for t in range(n_steps))
+        it = n_steps + (1 if len(train) % b else 0)
+        got = tr.history[epoch][2]
+        assert abs(got - cost / it) <= 1e-5 * max(1, abs(cost / it)), (epoch, got, cost / it)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
