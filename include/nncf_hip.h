@@ -342,6 +342,11 @@ int nncf_tower_sync_params(nncf_tower* t, void* stream);
  * tokens -- rows dropped by Embedding(dropout) are zeros and take part; the gradient of a column goes to the word that
  * supplied its maximum).  Mean-pool tower only. */
 int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling);
+/* Speed only (mean-pool tower, average pooling; no reference counterpart): up to 16 word ids that occur in most items of
+ * any batch (the pad id, the corpus's most frequent words).  Their word-row gradient sum_s count[w][s] dL/dh[s] is
+ * accumulated by the Dense backward's workgroups, which hold dL/dh, instead of by one wave of the word kernel gathering a
+ * row per (word, item) cell; same sums up to fp32 association.  host_words: host array. */
+int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n);
 /* conf.use_content_id (mean_pool.py:102-108): the tower's output becomes relu(BN(Dense(pool))) + Emb_Cid[item id] with
  * d_id_table [item_count][item_dim] (borrowed; NULL switches it off) and activity_l2(v_reg) on the Embedding's output
  * (v_reg * sum_d mean over the block's rows of row^2 added to the loss).  Steps of a tower with an id table materialise the

@@ -28,6 +28,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // Sum over all 64 lanes (result in every lane).
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
   v += __shfl_xor(v, 16);

@@ -99,8 +99,18 @@ struct TowerArgs {
   // tokens of scale[w] W[w][c]; amax[s][c] = the word that supplied it (the backward routes dh[s][c] to that word's row)
   int pool_max;
   int32_t* amax;             // [cap][wd]
+  // Hot words (mean-pool tower, average pooling): the few words that sit in most items of ANY batch (the pad id in all of
+  // them) made the workgroup that owns them the word kernel's long pole -- one wave gathering a dh row per (word, slot)
+  // cell, thousands of them.  Their gradient sum_s count[w][s] dh[s] is taken where dh is made instead: every role-A
+  // workgroup of tower_bwd_kernel (16 block rows, dh in its accumulators) writes count-weighted partial rows
+  // hot_part[workgroup][h][.] and clears the cells; the word kernel adds a hot word's partials in workgroup order.
+  const int32_t* hot;        // [n_hot] word ids
+  int n_hot;                 // <= kHotWords
+  float* hot_part;           // [cap / 16][kHotWords][128]
+  int32_t* hot_cnt;          // [cap / 16][kHotWords] cells (count sum) behind each partial: does the word take a step?
   CnnArgs cnn;
 };
+constexpr int kHotWords = 16;
 
 __device__ __forceinline__ float adam1(float g, float* m, float* v, float p, const TowerArgs& a) {
   const float mm = fmaf(a.beta1, *m, (1.f - a.beta1) * g), vv = fmaf(a.beta2, *v, (1.f - a.beta2) * g * g);
@@ -325,6 +335,11 @@ struct nncf_tower {
   float v_reg = 0.f;             // activity_l2(v_reg) on the Emb_Cid output
   nncf::AdamTable acid;          // its Adam state (borrowed; stamp for dense Adam)
   float* cid_reg = nullptr;      // own allocation [max_rows] |Emb_Cid row|^2 of the block's rows
+  // hot words (nncf_tower_set_hot_words; TowerArgs::hot)
+  int32_t* hot = nullptr;        // own allocation [kHotWords]
+  int n_hot = 0;
+  float* hot_part = nullptr;     // own allocation
+  int32_t* hot_cnt = nullptr;
 };
 
 namespace nncf {

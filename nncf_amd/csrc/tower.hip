@@ -415,10 +415,21 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
   __shared__ __attribute__((aligned(16))) float sZ[16 * kZP];
   __shared__ f32x4 sAcc[4 * 64];
   __shared__ float sCol[4 * 16];
+  __shared__ float sHotC[kHotWords * 16];   // role A: count of hot word h in block row i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = valid_rows(a);
   const int d4 = a.d >> 2;
   if (blockIdx.x < nA && blockIdx.x * 16 >= nv) return;
+  if (blockIdx.x < nA && a.n_hot > 0) {   // the hot words' cells of this workgroup's 16 rows: read, cleared (nobody else reads them)
+    const int h = tid >> 4, i = tid & 15, row = blockIdx.x * 16 + i;
+    float c = 0.f;
+    if (h < a.n_hot && row < nv) {
+      uint8_t* cell = a.cnt_t + (int64_t)a.hot[h] * a.cap + row;
+      c = (float)*cell;
+      if (c != 0.f) *cell = 0;
+    }
+    sHotC[h * 16 + i] = c;
+  }
   if (tid < 128) {
     float mu = 0.f, inv = 0.f, g = 0.f, mul = 0.f, add = 0.f, t1 = 0.f, t2 = 0.f;
     if (tid < a.d) {
@@ -494,6 +505,19 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
         const int rr = r0 + 4 * kq + r;
         if (rr < nv && kw < a.hd) a.dh[(int64_t)rr * a.hd + kw] = acc[r];
       }
+      // hot words: sum_i count[h][i] dh[r0 + i][kw] over this workgroup's rows (rows past nv have count 0)
+      for (int h = 0; h < a.n_hot; ++h) {
+        const float4 cw = *reinterpret_cast<const float4*>(sHotC + h * 16 + 4 * kq);
+        float pv = (cw.x * acc[0] + cw.y * acc[1]) + (cw.z * acc[2] + cw.w * acc[3]);
+        pv += __shfl_xor(pv, 16);
+        pv += __shfl_xor(pv, 32);
+        if (kq == 0 && kw < 128) a.hot_part[((int64_t)blockIdx.x * kHotWords + h) * 128 + kw] = pv;
+      }
+    }
+    if (tid < a.n_hot) {
+      float c = 0.f;
+      for (int i = 0; i < 16; ++i) c += sHotC[tid * 16 + i];
+      a.hot_cnt[(int64_t)blockIdx.x * kHotWords + tid] = (int)c;
     }
     return;
   }
@@ -564,7 +588,9 @@ constexpr int kListCap = 256;
 constexpr int kRowsInFlight = 8;
 // MAXP: max pooling -- a listed (word, slot) cell contributes dh[slot][c] only in the columns whose maximum the word
 // supplied (amax[slot][c] == word); no 1/L.
-template <bool CNN, bool MAXP = false>
+// NB: passes of 512 block rows whose count cells are requested together.  Measured at `original`'s 2,700 rows, same box:
+// NB = 1 / 2 / 3: 105.9 / 104.4 / 105.0 us per step -- no effect; NB = 4 spills (launch bound 512 threads); 1 is used.
+template <bool CNN, bool MAXP = false, int NB = 1>
 __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
@@ -584,13 +610,25 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     const int el = (bid - G) * 512 + tid, nel = a.hd * a.d;
     if (el < nel) {
       float g = 0.f;
-      for (int p = 0; p < ks; ++p) g += a.ws[ws_gw(ks) + (size_t)p * nel + el];
+      for (int p0 = 0; p0 < ks; p0 += 8) {   // K-part partials in part order, eight loads in flight (`original`: 22 parts)
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (p0 + e < ks) ? a.ws[ws_gw(ks) + (size_t)(p0 + e) * nel + el] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g += u[e];
+      }
       if (a.gexp) a.gexp[(size_t)a.n_words * a.wd + el] = g;
       else a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
     }
     if (bid == G && tid < a.d) {
       float gb = 0.f;
-      for (int p = 0; p < ks; ++p) gb += a.ws[ws_gb(0) + (size_t)p * 128 + tid];
+      for (int p0 = 0; p0 < ks; p0 += 8) {
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (p0 + e < ks) ? a.ws[ws_gb(0) + (size_t)(p0 + e) * 128 + tid] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gb += u[e];
+      }
       float t1 = a.ws[ws_bfin() + tid], t2 = a.ws[ws_bfin() + 128 + tid];
       if (nfused) merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
       if (a.gexp) {
@@ -611,7 +649,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     }
     return;
   }
-  if (a.skip_words) return;
+  if (a.skip_words & 1) return;
   const int n = valid_rows(a), d2 = a.wd >> 1;
   const int my_w = bid + wave * G;  // the word this wave finishes
   float2 wold = make_float2(0.f, 0.f);
@@ -627,21 +665,24 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
   constexpr bool cnn = CNN;
   const float2* dh2 = reinterpret_cast<const float2*>(cnn ? a.cnn.dXw : a.dh);
   __syncthreads();
-  for (int base = 0; base < n; base += 512) {
-    const int slot = base + 64 * wave + lane;
-    unsigned c[kWordsPerWG];
+  unsigned long long hit_bits[2] = {0ull, 0ull};   // (pass, word) pairs in which this lane found a cell: up to 16 passes
+  for (int base = 0; base < n; base += 512 * NB) {
+    unsigned c[NB][kWordsPerWG];
 #pragma unroll
-    for (int j = 0; j < kWordsPerWG; ++j) {
-      const int w = bid + j * G;
-      c[j] = (w < a.n_words && slot < n) ? a.cnt_t[(int64_t)w * a.cap + slot] : 0u;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int slot = base + 512 * nb + 64 * wave + lane;
+#pragma unroll
+      for (int j = 0; j < kWordsPerWG; ++j) {
+        const int w = bid + j * G;
+        c[nb][j] = (w < a.n_words && slot < n && !(a.skip_words & 4)) ? a.cnt_t[(int64_t)w * a.cap + slot] : 0u;
+      }
     }
     // list the non-zero cells word by word (ballot + prefix count); the list holds kListCap
     // entries: it is drained whenever the next word might not fit (rare: > 256 hits per 64 slots)
     int cnt = 0;
     auto drain = [&]() {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the list lives in LDS and is this wave's own: LDS operations of a
+      __builtin_amdgcn_wave_barrier();                       // wave complete in order -- nothing here waits for global memory
       // The list is word-major: consecutive entries of one word accumulate in registers and reach
       // the word's LDS stripe once per run (a read-modify-write per entry would chain every hit of
       // a popular word through LDS latency).
@@ -654,7 +695,7 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
         for (int u = 0; u < kRowsInFlight; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
 #pragma unroll
         for (int u = 0; u < kRowsInFlight; ++u)
-          r[u] = (ent[u] && lane < d2)
+          r[u] = (ent[u] && lane < d2 && !(a.skip_words & 2))
                      ? dh2[(cnn ? (int64_t)((ent[u] >> 8) & 0xFFFF) * a.L + ((ent[u] & 255) - 1) : (int64_t)((ent[u] >> 8) & 0xFFFF)) * d2 + lane]
                      : make_float2(0.f, 0.f);
         if (MAXP) {
@@ -701,22 +742,48 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
     };
 #pragma unroll
     for (int j = 0; j < kWordsPerWG; ++j) {
-      const unsigned long long mask = __ballot(c[j] != 0);
-      const int pc = __popcll(mask);
-      if (cnt + pc > kListCap) drain();
-      if (c[j]) {
-        a.cnt_t[(int64_t)(bid + j * G) * a.cap + slot] = 0;
-        list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (slot << 8) | (int)c[j];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int slot = base + 512 * nb + 64 * wave + lane;
+        const unsigned cb = c[nb][j];
+        const unsigned long long mask = __ballot(cb != 0);
+        const int pc = __popcll(mask);
+        if (cnt + pc > kListCap) drain();
+        if (cb) {
+          // the cell is cleared AFTER the scan loop (below): a store in flight here would turn the next pass's wait for its
+          // count cells into a wait for every outstanding store's acknowledgement (loads and stores share vmcnt)
+          hit_bits[((base >> 9) + nb) >> 3] |= 1ull << (((((base >> 9) + nb) & 7) << 3) | j);
+          list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (slot << 8) | (int)cb;
+        }
+        if (mask && lane == 0) sHit[j] = 1;
+        cnt += pc;
       }
-      if (mask && lane == 0) sHit[j] = 1;
-      cnt += pc;
     }
     drain();
   }
+  // cleared cells leave the matrix all-zero for the next step
+  for (int pass = 0; pass * 512 < n; ++pass) {
+    const unsigned bits = (unsigned)(hit_bits[pass >> 3] >> ((pass & 7) << 3)) & 255u;
+    const int slot = pass * 512 + 64 * wave + lane;
+#pragma unroll
+    for (int j = 0; j < kWordsPerWG; ++j)
+      if (bits & (1u << j)) a.cnt_t[(int64_t)(bid + j * G) * a.cap + slot] = 0;
+  }
   __syncthreads();
-  if (a.gexp && my_w < a.n_words && lane < d2 && !sHit[wave])
+  // hot word: its cells were consumed by tower_bwd_kernel's role-A workgroups, which left one partial row each
+  int hot_h = -1, hot_cells = 0;
+  if (!CNN && !MAXP && a.n_hot > 0 && my_w < a.n_words) {
+    for (int h = 0; h < a.n_hot; ++h)
+      if (a.hot[h] == my_w) hot_h = h;
+    if (hot_h >= 0) {
+      const int np = (n + 15) >> 4;
+      for (int p = lane; p < np; p += 64) hot_cells += a.hot_cnt[(int64_t)p * kHotWords + hot_h];
+      hot_cells = wave_sum_i(hot_cells);
+    }
+  }
+  if (a.gexp && my_w < a.n_words && lane < d2 && !sHit[wave] && hot_cells == 0)
     reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(0.f, 0.f);
-  if (my_w < a.n_words && sHit[wave] && lane < d2) {
+  if (my_w < a.n_words && (sHit[wave] || hot_cells > 0) && lane < d2) {
     float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
@@ -724,6 +791,21 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       sum.x += t.x;
       sum.y += t.y;
     }
+    if (hot_cells > 0 && !(a.skip_words & 8)) {   // partials in workgroup order; written on other compute units: every load is a trip to memory, 32 in flight
+      const int np = (n + 15) >> 4;
+      const float2* hp = reinterpret_cast<const float2*>(a.hot_part + (int64_t)hot_h * 128) + lane;
+      for (int p0 = 0; p0 < np; p0 += 32) {
+        float2 u[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) u[e] = (p0 + e < np) ? hp[(int64_t)(p0 + e) * kHotWords * 64] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          sum.x += u[e].x;
+          sum.y += u[e].y;
+        }
+      }
+    }
+
     // gradient = scale[w] / L * sum (mean-pool); the CNN rows already carry scale and 1/L
     const float gs = cnn ? 1.f : (MAXP ? word_scale(a, my_w) : word_scale(a, my_w) / (float)a.L);
     if (a.gexp) {
@@ -898,6 +980,11 @@ TowerArgs base_args(const nncf_tower* t) {
   a.hd = t->hd();
   a.pool_max = t->pool_max;
   a.amax = t->amax;
+  const bool hot_ok = t->n_hot > 0 && t->cnn.F == 0 && !t->pool_max;
+  a.hot = t->hot;
+  a.n_hot = hot_ok ? t->n_hot : 0;
+  a.hot_part = t->hot_part;
+  a.hot_cnt = t->hot_cnt;
   return a;
 }
 
@@ -986,6 +1073,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     a.cnn.vC = t->cnn.vC;
     if (int rc = cnn_backward(t, a, st)) return rc;
   }
+  if (const char* e = getenv("NNCF_WORD_DBG")) a.skip_words |= atoi(e);   // developer timing: 2 no row gathers, 4 no cell scan, 8 no hot partials
   {
     ProfScope _ps("tower_word_kernel", st);
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
@@ -1290,6 +1378,9 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
 
 int nncf_tower_destroy(nncf_tower* t) {
   if (t && t->amax) (void)hipFree(t->amax);
+  if (t && t->hot) (void)hipFree(t->hot);
+  if (t && t->hot_part) (void)hipFree(t->hot_part);
+  if (t && t->hot_cnt) (void)hipFree(t->hot_cnt);
   if (t && t->cid_reg) (void)hipFree(t->cid_reg);
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
@@ -1443,6 +1534,23 @@ int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, cons
     if (int rc = tower_forward(t, d_item_ids + i0, (int)cnt, nullptr, 0, 0, nullptr, d_out + i0 * t->cfg.item_dim, st)) return rc;
   }
   return add_ids();
+}
+
+int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(n >= 0 && n <= kHotWords && (n == 0 || host_words), "0..%d hot words", kHotWords);
+  for (int i = 0; i < n; ++i) NNCF_REQUIRE(host_words[i] >= 0 && host_words[i] < t->cfg.word_count, "hot word id out of range");
+  DeviceGuard guard(t->device);
+  if (n > 0 && !t->hot) {
+    const size_t np = (size_t)t->cfg.max_rows / 16 + 1;
+    if (hipMalloc(&t->hot, sizeof(int32_t) * kHotWords) != hipSuccess ||
+        hipMalloc(&t->hot_part, sizeof(float) * np * kHotWords * 128) != hipSuccess ||
+        hipMalloc(&t->hot_cnt, sizeof(int32_t) * np * kHotWords) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "hot-word buffers allocation failed");
+  }
+  if (n > 0) NNCF_HIP_CHECK(hipMemcpy(t->hot, host_words, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  t->n_hot = n;
+  return NNCF_OK;
 }
 
 int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling) {

@@ -11,6 +11,7 @@ bias, BatchNormalization eps 1e-3, momentum 0.99, biased batch variance, running
 holds the variance.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -135,6 +136,15 @@ class MeanPoolTower(object):
         idx = torch.device(dev).index or 0
         _lib.check(self._L.nncf_tower_create(ctypes.byref(cfg), ctypes.byref(prm), idx, ctypes.byref(h)))
         self.handle = h
+        if not self.conv and os.environ.get("NNCF_HOT_WORDS", "1") != "0":
+            # the words that sit in most items (the pad id in all of them): their gradient rows are summed by the Dense
+            # backward's workgroups instead of one wave of the word kernel (nncf_tower_set_hot_words); speed only
+            df = np.bincount(words, minlength=self.word_count)          # document frequency: one CSR entry per (item, word)
+            top = np.argsort(-df, kind="stable")[:16]
+            top = np.ascontiguousarray(top[df[top] * 8 >= self.item_count].astype(np.int32))   # in >= 1/8 of the items
+            self.hot_words = top
+            if top.size:
+                _lib.check(self._L.nncf_tower_set_hot_words(self.handle, top.ctypes.data_as(_lib.c_i32p), int(top.size)))
         if self.dropout > 0 or cdrop > 0:
             self.set_dropout(self.dropout, int(seed) + 29)
 
