@@ -905,8 +905,6 @@ def main():
                                "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item pass)"),
         "fused_wide_kernel": ("mfma", 6.0 * b * b * d,
                               "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item pass)"),
-        "tower_wordbwd_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
-                                 "4*L*word_dim*(1-dropout) B of gradient rows per unique item, n_u = %.1f" % mean_n_u),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
         "tower_pool_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
                               "4*L*word_dim*(1-dropout) B per unique item, n_u = %.1f unique items per launch" % mean_n_u),
@@ -924,7 +922,7 @@ def main():
         args.model, {}).get(args.scheme) or {"cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, shared_kernel)
     names = [args.roofline_kernel or default_kernel]
     if args.model == "basic_embedding":
-        names += [n for n in ("tower_wordbwd_kernel", "tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel",
+        names += [n for n in ("tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel",
                               "fused_strip_kernel", "shared_tile_kernel") if n not in names]
     if args.model == "mf":
         names += [n for n in ("fused_strip_kernel", "fused_wide_kernel", "shared_tile_kernel", "shared_apply_kernel") if n not in names]

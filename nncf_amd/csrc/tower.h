@@ -55,8 +55,7 @@ struct CnnBanks {             // all banks of a tower (kernels that walk the who
 struct TowerArgs {
   // parameters
   float* W;      // [n_words][wd]
-  float* Wd;     // [wd][d]  the CURRENT buffer of the double-buffered Dense weights
-  float* Wd_next;  // the other buffer: tower_wordbwd_kernel writes the stepped weights there (tower_fused.hip)
+  float* Wd;     // [wd][d]
   float* bd;
   float* gamma;
   float* beta;
@@ -196,24 +195,6 @@ __device__ __forceinline__ void merge_partials(const float* part, int nparts, in
   }
 }
 
-// Per-step word -> (slot, count) lists of the shared-negative schemes (tower_fused.hip), planned for up to
-// kPlanChunk steps at a time: cells of word w of step i are cells[i][off[i][w] .. off[i][w+1]), slots ascending.
-struct CellsView {
-  uint32_t* bits = nullptr;   // [steps][n_words][rw]  bitmap word x slot
-  int32_t* off = nullptr;     // [steps][n_words + 1]
-  int32_t* cells = nullptr;   // [steps][cells_cap]    slot << 8 | count
-  int rw = 0;                 // uint32 per bitmap row = ceil(rows / 32)
-  int64_t cells_cap = 0;      // rows * L
-  int n_words = 0;
-  CellsView at(int64_t i) const {
-    CellsView v = *this;
-    v.bits += i * (int64_t)n_words * rw;
-    v.off += i * (int64_t)(n_words + 1);
-    v.cells += i * cells_cap;
-    return v;
-  }
-};
-
 }  // namespace nncf
 
 // ---- the tower object --------------------------------------------------------------------------
@@ -299,13 +280,6 @@ struct nncf_tower {
   uint8_t* ent_cnt = nullptr;
   float* bpart = nullptr;
   int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
-  // one-launch backward of the shared-negative schemes (tower_fused.hip)
-  int use_wordbwd = 0;           // NNCF_TOWER_BWD=fused selects the one-launch backward (tower_fused.hip)
-  float* Wd_alt = nullptr;       // second buffer of the Dense weights (arena)
-  bool wd_in_alt = false;        // the current weights live in Wd_alt (copied back before an entry point returns)
-  nncf::CellsView cells;         // lazily allocated for `cells_rows` block rows (own allocation)
-  void* cells_mem = nullptr;
-  int cells_rows = 0;
   bool fwd_cached = false;
   nncf::TowerArgs last{};
   float drop_rate = 0.f;
@@ -343,10 +317,6 @@ struct nncf_tower {
 };
 
 namespace nncf {
-// tower_fused.hip
-int launch_cells(const TowerArgs& a, const CellsView& cv, const int32_t* uniq_g, const int32_t* n_u, int64_t uniq_stride,
-                 int rows, int64_t n_steps, hipStream_t st);
-int launch_wordbwd(const TowerArgs& a, const CellsView& cv, int nfused, hipStream_t st);
 // cnn.hip
 size_t cnn_carve(nncf_tower* t, Carver& c);
 int cnn_sync_weights(nncf_tower* t, hipStream_t st);

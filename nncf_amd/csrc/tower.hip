@@ -956,7 +956,6 @@ void carve_tower(nncf_tower* t, Carver& c) {
     t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
   }
   t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
-  t->Wd_alt = c.take<float>(hd * d);
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
 }
@@ -965,8 +964,7 @@ TowerArgs base_args(const nncf_tower* t) {
   TowerArgs a{};
   const nncf_tower_params& p = t->prm;
   a.W = p.words; a.bd = p.dense_b; a.gamma = p.bn_gamma; a.beta = p.bn_beta;
-  a.Wd = t->wd_in_alt ? t->Wd_alt : p.dense_w;
-  a.Wd_next = t->wd_in_alt ? p.dense_w : t->Wd_alt;
+  a.Wd = p.dense_w;
   a.rm = p.bn_mean; a.rv = p.bn_var;
   a.content = p.content; a.item_ptr = p.item_ptr; a.item_word = p.item_word; a.item_cnt = p.item_cnt;
   a.h = t->h; a.z = t->z; a.dh = t->dh; a.ws = t->ws; a.cnt_t = t->cnt_t;
@@ -1087,83 +1085,6 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   return NNCF_OK;
 }
 
-// One-launch backward of the shared-negative schemes (tower_fused.hip): dz in registers, the word rows
-// accumulated in dz space and multiplied by Wd^T once, the dWd tiles stepping the other Wd buffer.
-int tower_backward_fused(nncf_tower* t, const float* dA, hipStream_t st, int nfused, int64_t step_t, const CellsView& cv) {
-  TowerArgs a = t->last;
-  a.dA = dA;
-  a.gexp = t->gexp;
-  a.opt = t->gexp ? 0 : t->opt;
-  if (a.opt) {
-    const double tt = (double)(step_t > 0 ? step_t : t->adam_t + 1);
-    a.beta1 = t->beta1;
-    a.beta2 = t->beta2;
-    a.aeps = t->aeps;
-    a.lr_t = (float)((double)a.lr * std::sqrt(1.0 - std::pow((double)t->beta2, tt)) / (1.0 - std::pow((double)t->beta1, tt)));
-    a.step_no = (int)tt;
-    a.aw = t->aw;
-    a.mD = t->mD;
-    a.vD = t->vD;
-  }
-  if (int rc = launch_wordbwd(a, cv, nfused, st)) return rc;
-  if (!a.gexp) t->wd_in_alt = !t->wd_in_alt;  // the stepped Dense weights are in the other buffer now
-  if (a.opt && step_t <= 0) t->adam_t++;
-  return NNCF_OK;
-}
-
-// The caller's dense_w array is the tower's interface: before an entry point returns the current Dense
-// weights are copied back into it if the last step left them in the second buffer.
-int tower_sync_wd(nncf_tower* t, hipStream_t st) {
-  if (!t->wd_in_alt) return NNCF_OK;
-  const size_t hd = (size_t)t->hd();
-  NNCF_HIP_CHECK(hipMemcpyAsync(t->prm.dense_w, t->Wd_alt, sizeof(float) * hd * t->cfg.item_dim, hipMemcpyDeviceToDevice, st));
-  t->wd_in_alt = false;
-  return NNCF_OK;
-}
-
-// word -> (slot, count) lists for `rows`-row blocks (allocated on first use, own allocation)
-int ensure_cells(nncf_tower* t, int rows) {
-  if (t->cells_mem && t->cells_rows >= rows) return NNCF_OK;
-  DeviceGuard guard(t->device);
-  if (t->cells_mem) (void)hipFree(t->cells_mem);
-  t->cells_mem = nullptr;
-  const int W = t->cfg.word_count, rw = (rows + 31) / 32;
-  const int64_t cap = (int64_t)rows * t->cfg.content_len;
-  Carver c;
-  auto lay = [&](Carver& cc, CellsView& v) {
-    v.bits = cc.take<uint32_t>((size_t)kPlanChunk * W * rw);
-    v.off = cc.take<int32_t>((size_t)kPlanChunk * (W + 1));
-    v.cells = cc.take<int32_t>((size_t)kPlanChunk * cap);
-    v.rw = rw;
-    v.cells_cap = cap;
-    v.n_words = W;
-  };
-  CellsView dry;
-  lay(c, dry);
-  if (hipMalloc(&t->cells_mem, c.off + 256) != hipSuccess) return fail(NNCF_ERR_NOMEM, "cell-list allocation (%zu bytes) failed", c.off);
-  Carver real;
-  real.base = static_cast<char*>(t->cells_mem);
-  lay(real, t->cells);
-  t->cells_rows = rows;
-  return NNCF_OK;
-}
-
-// does the one-launch backward apply to a step of this scheme?
-bool wordbwd_applies(const nncf_tower* t, const nncf_model* m, int scheme) {
-  const int b = m->cfg.batch_size_p;
-  return t->use_wordbwd && t->cnn.F == 0 && !t->pool_max && !t->cid_tab && (scheme == 1 || scheme == 2) && b <= 1024 &&
-         (b + kChunkSlots - 1) / kChunkSlots <= kTowerWG;
-}
-
-int plan_cells(nncf_tower* t, const nncf_model* m, int scheme, const int32_t* uniq_g, const int32_t* n_u, int64_t uniq_stride,
-               int64_t n_steps, hipStream_t st) {
-  if (!wordbwd_applies(t, m, scheme)) return NNCF_OK;
-  const int b = m->cfg.batch_size_p;
-  if (int rc = ensure_cells(t, b)) return rc;
-  TowerArgs a = base_args(t);
-  return launch_cells(a, t->cells, uniq_g, n_u, uniq_stride, b, n_steps, st);
-}
-
 int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
   if (!t || !m) return fail(NNCF_ERR_INVALID, "tower / model is NULL");
   NNCF_REQUIRE(scheme >= 0 && scheme <= 3, "scheme must be 0 (original), 1 (neg_shared), 2 (group_neg_shared) or 3 (row-wise)");
@@ -1181,7 +1102,7 @@ int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
 // one planned step: plans pu / pv (localized), the block's global ids and count on device
 int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid, const PlanView& pu,
                     const PlanView& pv, const int32_t* uniq_g, const int32_t* n_u, int n, float* loss, int update,
-                    const float* scale, hipStream_t st, const int32_t* y = nullptr, const CellsView* cells = nullptr) {
+                    const float* scale, hipStream_t st, const int32_t* y = nullptr) {
   // the normalised block is never written: the step kernels apply BatchNorm + ReLU when they
   // load an item row from z
   const int b = m->cfg.batch_size_p;
@@ -1232,12 +1153,11 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
     return NNCF_OK;
   }
   const bool one_launch = (scheme == 1 || scheme == 2) && shared_step_fuses(m, sa);
-  const bool wb = cells != nullptr && update && wordbwd_applies(t, m, scheme);   // one-launch backward: no count matrix
   // shared schemes on the tile + apply pair (pairwise losses, bias): the tile workgroups derive the statistics too
   // (NNCF_TILE_STATS=launch keeps the tower_stats launch: measurement / tests)
   static const bool tile_stats_launch = getenv("NNCF_TILE_STATS") != nullptr;
   const bool tile_stats = (scheme == 1 || scheme == 2) && !one_launch && m->tile_ok && !tile_stats_launch;
-  int rc = tower_forward(t, uniq_g, n, n_u, 1, update && !wb, scale, nullptr, st, one_launch || tile_stats);
+  int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st, one_launch || tile_stats);
   if (rc) return rc;
   FusedArgs fa;
   if (one_launch || tile_stats) {
@@ -1268,8 +1188,7 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
     ProfScope _ps("tower_merge_kernel", st);
     hipLaunchKernelGGL(tower_merge_kernel, dim3(1), dim3(1024), 0, st, ma, t->bpart, cv);
   }
-  if (wb && nfused) rc = tower_backward_fused(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, *cells);
-  else rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
+  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
   if (rc) return rc;
   return finish_update(m, sa, st);
 }
@@ -1320,8 +1239,6 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   // the one-launch backward (tower_fused.hip) is correct and tested but, at 2 workgroups of 8 waves per CU, its
   // 1,050 workgroups take three rounds: 23 us against 8.5 + 11.4 us of the two-kernel chain (profiles/r02) --
   // opt-in until it wins
-  t->use_wordbwd = 0;
-  if (const char* e = getenv("NNCF_TOWER_BWD")) t->use_wordbwd = std::string(e) == "fused";
   if (cfg->conv_filters > 0) {
     t->nb = cfg->n_filter_lens > 1 ? cfg->n_filter_lens : 1;
     int64_t taps = 0;   // conv_w: the banks' [fl][word_dim][F] blocks one after the other
@@ -1385,7 +1302,6 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
   if (t->stamps) hipFree(t->stamps);
-  if (t->cells_mem) hipFree(t->cells_mem);
   delete t;
   return NNCF_OK;
 }
@@ -1601,13 +1517,9 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
   if (rc) return rc;
   rc = launch_plan_localize(m->plan_v, n, t->uniq_g, t->n_u, st);
   if (rc) return rc;
-  const bool wb = update && wordbwd_applies(t, m, scheme);
-  if (wb && (rc = plan_cells(t, m, scheme, t->uniq_g, t->n_u, t->cfg.max_rows, 1, st))) return rc;
-  rc = tower_step_body(t, m, scheme, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st,
-                       nullptr, wb ? &t->cells : nullptr);
+  rc = tower_step_body(t, m, scheme, d_uid, m->plan_u, m->plan_v, t->uniq_g, t->n_u, n, d_loss, update, d_row_scale, st);
   t->fwd_cached = false;
   if (rc) return rc;
-  if ((rc = tower_sync_wd(t, st))) return rc;
   return flush_pending_loss(m, st);
 }
 
@@ -1666,8 +1578,7 @@ int nncf_tower_plan_steps(nncf_tower* t, nncf_model* m, int32_t scheme, const in
   else
     rc = launch_plan_steps(d_uid, b, (int)b, m->plan_u, d_cid, b, (int)b, nullptr, 0, 0, m->plan_v, t->uniq_g, t->cfg.max_rows,
                            t->n_u, n_steps, st);
-  if (rc) return rc;
-  return plan_cells(t, m, scheme, t->uniq_g, t->n_u, t->cfg.max_rows, n_steps, st);
+  return rc;
 }
 
 int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t index, const int32_t* d_uid, float* d_loss,
@@ -1678,14 +1589,10 @@ int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t ind
   NNCF_REQUIRE(index >= 0 && index < kPlanChunk, "plan slot %lld out of range", (long long)index);
   const int64_t b = m->cfg.batch_size_p, cap = t->cfg.max_rows;
   const int n = (int)(scheme == 0 ? b * (1 + m->cfg.num_negatives) : b);
-  const bool wb = wordbwd_applies(t, m, scheme) && t->cells_mem != nullptr;
-  CellsView cvi;
-  if (wb) cvi = t->cells.at(index);
   int rc = tower_step_body(t, m, scheme, d_uid, m->plan_u.at(index), m->plan_v.at(index), t->uniq_g + index * cap,
-                           t->n_u + index, n, d_loss, 1, nullptr, as_stream(stream), nullptr, wb ? &cvi : nullptr);
+                           t->n_u + index, n, d_loss, 1, nullptr, as_stream(stream));
   t->fwd_cached = false;
   if (rc) return rc;
-  if ((rc = tower_sync_wd(t, as_stream(stream)))) return rc;
   return flush_pending_loss(m, as_stream(stream));
 }
 
@@ -1711,19 +1618,14 @@ int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t
       rc = launch_plan_steps(d_uid_all + t0 * b, b, (int)b, m->plan_u, d_cid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_v,
                              t->uniq_g, cap, t->n_u, cnt, st, d_n_u ? d_n_u + t0 : nullptr);
     if (rc) return rc;
-    const bool wb = wordbwd_applies(t, m, scheme);
-    if (wb && (rc = plan_cells(t, m, scheme, t->uniq_g, t->n_u, cap, cnt, st))) return rc;
     for (int64_t i = 0; i < cnt; ++i) {
       const int64_t s = t0 + i;
-      CellsView cvi;
-      if (wb) cvi = t->cells.at(i);
       rc = tower_step_body(t, m, scheme, d_uid_all + s * b, m->plan_u.at(i), m->plan_v.at(i), t->uniq_g + i * cap,
-                           t->n_u + i, n, d_loss + s, 1, nullptr, st, nullptr, wb ? &cvi : nullptr);
+                           t->n_u + i, n, d_loss + s, 1, nullptr, st);
       if (rc) return rc;
     }
   }
   t->fwd_cached = false;
-  if (int rc = tower_sync_wd(t, st)) return rc;
   return flush_pending_loss(m, st);
 }
 

@@ -83,15 +83,15 @@ def test_basic_embedding_steps_match_oracle(text_data, scheme, loss):
 
 
 @pytest.mark.parametrize("shared_path", ["fused", "tile"])
-@pytest.mark.parametrize("bwd", ["split", "fused"])
+@pytest.mark.parametrize("hot_words", ["1", "0"])
 @pytest.mark.parametrize("scheme,loss,opt", [("neg_shared", "skip-gram", "sgd"), ("group_neg_shared", "mse", "sgd"),
                                              ("neg_shared", "skip-gram", "adam")])
-def test_every_kernel_path_of_the_shared_schemes_matches_the_oracle(text_data, monkeypatch, shared_path, bwd, scheme, loss, opt):
-    """One-launch step (step_fused.hip) vs tile + apply, one-launch tower backward (tower_fused.hip: planned word ->
-    cell lists, double-buffered Dense weights) vs tower_bwd + tower_word: all four combinations, 5 steps (odd: the
-    Dense weights end in the second buffer and are copied back), every parameter against the oracle."""
+def test_every_kernel_path_of_the_shared_schemes_matches_the_oracle(text_data, monkeypatch, shared_path, hot_words, scheme, loss, opt):
+    """One-launch step (step_fused.hip) vs tile + apply, frequent words' gradient rows by the Dense backward's workgroups
+    (nncf_tower_set_hot_words) vs by the word kernel alone: all four combinations, 5 steps, every parameter against the
+    oracle."""
     monkeypatch.setenv("NNCF_SHARED_PATH", shared_path)
-    monkeypatch.setenv("NNCF_TOWER_BWD", bwd)
+    monkeypatch.setenv("NNCF_HOT_WORDS", hot_words)
     conf = _conf(loss, scheme, lr=0.02 if opt == "adam" else 0.2)
     conf.optimizer = opt
     helper = get_data(dict(text_data), conf, rand_seed=5)

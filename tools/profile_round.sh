@@ -39,7 +39,6 @@ python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_s
 python3 bench.py --scheme group_neg_shared --cpu-seconds 6 --steps 1170 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared.json
 python3 bench.py --scheme original --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_original.json
 python3 bench.py --optimizer adam --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_adam.json
-NNCF_TOWER_BWD=fused python3 bench.py --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_fusedbwd.json
 NNCF_SHARED_PATH=tile python3 bench.py --cpu-seconds 0 --steps 780 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared_tilepath.json
 python3 bench.py --model cnn_embedding --scheme group_neg_shared --cpu-seconds 8 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_group_neg_shared.json
 python3 bench.py --model mf --cpu-seconds 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_neg_shared.json
