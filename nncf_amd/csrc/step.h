@@ -39,6 +39,18 @@ struct StepArgs {
   // if non-NULL the apply kernel of the shared schemes also emits, per item chunk, the column sums
   // of dy = dL/dE * [E > 0] and dy * xhat (the BatchNorm backward's reductions): [chunk][2][128]
   float* bn_part = nullptr;
+  // text tower, blocks of more than 1,024 rows (`original`): the statistics launch leaves bn_nparts partial rows
+  // (shifted sums, shift = block row 0); every workgroup of the score kernel merges them itself and workgroup 0 publishes
+  // mu / inv / var / mul / add (bn_stats) + the running statistics -- no one-workgroup merge launch in between
+  const float* bn_parts = nullptr;   // [bn_nparts][2][128]
+  int bn_nparts = 0;
+  float* bn_pub = nullptr;           // = bn_stats, writable
+  const float* bn_gamma = nullptr;
+  const float* bn_beta = nullptr;
+  float* bn_rm = nullptr;
+  float* bn_rv = nullptr;
+  float bn_eps = 1e-3f, bn_mom = 0.99f;
+  const int32_t* bn_nv = nullptr;    // rows of the block (device scalar)
   // optimiser: 0 sparse SGD (north-star); 1 lazy-sparse Adam on the touched rows
   // (utils/optimizer.py:108-134); 2 dense Adam = Keras Adam (basic_embedding_conf.py:59-60): the
   // touched rows here, every other row by adam_idle_kernel with a zero gradient.

@@ -37,10 +37,70 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, q = lane & 15;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= a.b) return;
   const int k = a.k, d4 = a.d >> 2;
+  // text tower: BatchNorm scale / shift of the item block.  Large blocks: merged here from the statistics launch's
+  // partials (same arithmetic in every workgroup; workgroup 0 publishes for the kernels that follow)
+  __shared__ __attribute__((aligned(16))) float sBn[2 * 128];
+  Row bmul = row_zero(), badd = row_zero();
+  // the positive's user row and first item ids are requested BEFORE the merge below: their latency covers it
+  const bool live_p = p < a.b;
+  Row uhat = live_p ? row_load(a.U, uid[p], a.stride, d4, q) : row_zero();
+  int ids0[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int slot = 4 * e + grp;
+    ids0[e] = -1;
+    if (live_p && slot < 1 + k) ids0[e] = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
+  }
+  if (a.bn_z) {
+    if (a.bn_parts) {
+      if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        float mul = 0.f, add = 0.f;
+        if (c < a.d) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int pp = 0; pp < a.bn_nparts; ++pp) {   // <= 8 partials, in order
+            t1 += a.bn_parts[pp * 256 + c];
+            t2 += a.bn_parts[pp * 256 + 128 + c];
+          }
+          const int nv = *a.bn_nv;
+          const float rn = 1.f / (float)max(nv, 1);
+          const float m1 = t1 * rn;
+          const float mu = a.bn_z[c] + m1, var = fmaxf(t2 * rn - m1 * m1, 0.f), inv = rsqrtf(var + a.bn_eps);
+          mul = a.bn_gamma[c] * inv;
+          add = a.bn_beta[c] - mu * mul;
+          if (blockIdx.x == 0) {
+            a.bn_pub[c] = mu;
+            a.bn_pub[128 + c] = inv;
+            a.bn_pub[256 + c] = var;
+            a.bn_rm[c] = a.bn_mom * a.bn_rm[c] + (1.f - a.bn_mom) * mu;
+            a.bn_rv[c] = a.bn_mom * a.bn_rv[c] + (1.f - a.bn_mom) * var;
+          }
+        }
+        if (blockIdx.x == 0) {   // pad columns of the fused scale / shift are zero
+          a.bn_pub[384 + c] = mul;
+          a.bn_pub[512 + c] = add;
+        }
+        sBn[c] = mul;
+        sBn[128 + c] = add;
+      }
+      __syncthreads();
+      bmul = row_load(sBn, 0, 128, 32, q);
+      badd = row_load(sBn + 128, 0, 128, 32, q);
+    } else {
+      bmul = row_load(a.bn_stats + 384, 0, 128, 32, q);
+      badd = row_load(a.bn_stats + 512, 0, 128, 32, q);
+    }
+  }
+  auto item = [&](int id) -> Row {   // row `id` of the step's item table (plain table, or BatchNorm + ReLU of the tower's block)
+    if (!a.bn_z) return row_load(a.V, id, a.stride, d4, q);
+    Row r = row_load(a.bn_z, id, a.stride, d4, q);
+    if (q < d4) r.a = bn_relu4(r.a, bmul.a, badd.a);
+    if (q + 16 < d4) r.b = bn_relu4(r.b, bmul.b, badd.b);
+    return r;
+  };
+  if (p >= a.b) return;
   const int nslots = 1 + k;
-  Row uhat = row_load(a.U, uid[p], a.stride, d4, q);
   const float uss = row16_sum(row_dot_partial(uhat, uhat));
   if (NU) uhat = row_scale(uhat, inv_norm(uss));
 
@@ -58,10 +118,11 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
     for (int e = 0; e < 4; ++e) {
       const int slot = t0 + 4 * e + grp;
       ids[e] = -1;
-      if (slot < nslots) ids[e] = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
+      if (t0 == 0) ids[e] = ids0[e];
+      else if (slot < nslots) ids[e] = (slot == 0) ? cid_pos[p] : cid_neg[(int64_t)p * k + (slot - 1)];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (ids[e] >= 0) ? item_row(a, ids[e], d4, q) : row_zero();
+    for (int e = 0; e < 4; ++e) v[e] = (ids[e] >= 0) ? item(ids[e]) : row_zero();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int slot = t0 + 4 * e + grp;

@@ -45,8 +45,13 @@ namespace nncf {
 // MAXP (conf.pooling == 'max', mean_pool.py:70-72): h[s][c] = max over the item's tokens of scale[w] W[w][c] (a dropped
 // row is a row of zeros and still takes part, as Keras' Embedding(dropout) leaves it); the word that supplied each
 // column's maximum is kept in amax[s][c] for the backward.  Equal values from different words: the pair listed first wins.
-template <bool MAXP>
-__global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
+// BIG: blocks of thousands of rows (`original`: ~2,700 unique items) -- the kernel is then bound by how many workgroups
+// a compute unit holds (154 VGPRs: three of 4 waves; 2,700 workgroups = four rounds), not by one workgroup's latency:
+// the Dense weights are requested AFTER the pooling, in two halves of eight rows (32 registers instead of 64 held across
+// the gather), four word rows in flight instead of seven: 66 VGPRs, seven workgroups per compute unit, two rounds.
+// Measured (`original`, b = 512, k = 10): 21.4 -> 14.4 us.
+template <bool MAXP, bool BIG = false>
+__global__ void __launch_bounds__(256, BIG ? 6 : 1) tower_pool_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[16 * kTP];
   __shared__ int sArg[MAXP ? 16 * kTP : 1];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
@@ -62,10 +67,12 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   // Issued first: independent of the pooling below, so the two latencies overlap.
   const int c4 = tid & 31, kp = tid >> 5, kper = (a.hd + 7) >> 3;
   float4 w[16];
+  if (!BIG) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = kp * kper + i;
-    w[i] = (i < kper && k < a.hd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+    for (int i = 0; i < 16; ++i) {
+      const int k = kp * kper + i;
+      w[i] = (i < kper && k < a.hd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+    }
   }
   // The item's distinct words with their counts (fixed-stride copy of the CSR: one round trip, no
   // pointer hop): sum_l scale[c_l] W[c_l] = sum_w count_w scale_w W[w] needs one row load per DISTINCT
@@ -90,12 +97,13 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
     for (int e = 0; e < 8; ++e) arg[e] = -1;
   }
   const int nper = (ne + 15) >> 4;  // pairs per group
-  for (int i0 = 0; i0 < nper; i0 += 7) {  // 7 word rows of this group in flight
-    float sc[7];
-    Row r[7];
-    bool live[7];
+  constexpr int NR = BIG ? 4 : 7;   // word rows of this group in flight
+  for (int i0 = 0; i0 < nper; i0 += NR) {
+    float sc[NR];
+    Row r[NR];
+    bool live[NR];
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
+    for (int e = 0; e < NR; ++e) {
       const int l = grp + 16 * (i0 + e);
       const bool ok = (i0 + e < nper) && l < ne;
       live[e] = ok;
@@ -103,7 +111,7 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
       r[e] = (sc[e] != 0.f) ? row_load(a.W, sTok[l], a.wd, wd4, q) : row_zero();
     }
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
+    for (int e = 0; e < NR; ++e) {
       if (!MAXP) {
         acc = row_fma(sc[e], r[e], acc);
       } else if (live[e]) {     // a dropped word (scale 0) is a row of zeros
@@ -162,10 +170,27 @@ __global__ void __launch_bounds__(256) tower_pool_kernel(TowerArgs a) {
   }
   __syncthreads();
   float4 part = zero4();
+  if (BIG) {   // the Dense slice in two halves of eight rows
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = kp * kper + i;
-    if (i < kper && k < a.hd) part = fma4(sH[k], w[i], part);
+    for (int h0 = 0; h0 < 16; h0 += 8) {
+      float4 w8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = kp * kper + h0 + i;
+        w8[i] = (h0 + i < kper && k < a.hd && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)k * a.d)[c4] : zero4();
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = kp * kper + h0 + i;
+        if (h0 + i < kper && k < a.hd) part = fma4(sH[k], w8[i], part);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = kp * kper + i;
+      if (i < kper && k < a.hd) part = fma4(sH[k], w[i], part);
+    }
   }
   sP[kp * 32 + c4] = part;
   __syncthreads();
@@ -584,14 +609,18 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
 // cnt_t is all-zero again afterwards.
 // Remaining blocks: Wd, bd, gamma, beta -= lr * gradient (K-parts / partials summed in order).
 constexpr int kWordsPerWG = 8;
-constexpr int kListCap = 256;
+constexpr int kListCap = 240;   // with the stripes: 40.5 KB of LDS -> FOUR workgroups per compute unit (160 KB)
 constexpr int kRowsInFlight = 8;
 // MAXP: max pooling -- a listed (word, slot) cell contributes dh[slot][c] only in the columns whose maximum the word
 // supplied (amax[slot][c] == word); no 1/L.
 // NB: passes of 512 block rows whose count cells are requested together.  Measured at `original`'s 2,700 rows, same box:
 // NB = 1 / 2 / 3: 105.9 / 104.4 / 105.0 us per step -- no effect; NB = 4 spills (launch bound 512 threads); 1 is used.
+// Occupancy: ~1,000 workgroups of 8 waves; at 74 VGPRs / 41.0 KB of LDS three fit a compute unit -- 768 at once, the rest in
+// a second round.  <= 64 VGPRs (8 waves per SIMD) and <= 40 KB: four fit, 1,024 at once.  (Measured: no change in the step
+// time -- the kernel is bound by the instructions of its count-cell scan, 8,001 words x 2,700 rows / 64 ballot rounds
+// that are empty 3 times out of 4, not by residency.)
 template <bool CNN, bool MAXP = false, int NB = 1>
-__global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
+__global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
   __shared__ int sHit[kWordsPerWG];
@@ -791,15 +820,15 @@ __global__ void __launch_bounds__(512) tower_word_kernel(TowerArgs a, int ks, in
       sum.x += t.x;
       sum.y += t.y;
     }
-    if (hot_cells > 0 && !(a.skip_words & 8)) {   // partials in workgroup order; written on other compute units: every load is a trip to memory, 32 in flight
+    if (hot_cells > 0 && !(a.skip_words & 8)) {   // partials in workgroup order; written on other compute units: every load is a trip to memory, 16 in flight
       const int np = (n + 15) >> 4;
       const float2* hp = reinterpret_cast<const float2*>(a.hot_part + (int64_t)hot_h * 128) + lane;
-      for (int p0 = 0; p0 < np; p0 += 32) {
-        float2 u[32];
+      for (int p0 = 0; p0 < np; p0 += 16) {
+        float2 u[16];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) u[e] = (p0 + e < np) ? hp[(int64_t)(p0 + e) * kHotWords * 64] : make_float2(0.f, 0.f);
+        for (int e = 0; e < 16; ++e) u[e] = (p0 + e < np) ? hp[(int64_t)(p0 + e) * kHotWords * 64] : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
+        for (int e = 0; e < 16; ++e) {
           sum.x += u[e].x;
           sum.y += u[e].y;
         }
@@ -994,7 +1023,7 @@ inline int stat_grid(int m) { return (m + 1023) / 1024; }  // workgroups of the 
 
 // forward of a block: rows of ids -> E.  train: batch statistics, h / z kept, optional fill.
 int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_valid, int train, int fill,
-                  const float* scale, float* E, hipStream_t st, bool stats_by_consumer = false) {
+                  const float* scale, float* E, hipStream_t st, bool stats_by_consumer = false, bool merge_by_consumer = false) {
   TowerArgs a = base_args(t);
   a.ids = ids; a.m = m; a.n_valid = n_valid; a.train = train; a.fill = fill; a.scale = scale; a.E = E;
   if (train && t->drop_rate > 0.f) {
@@ -1010,6 +1039,7 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
   } else {
     ProfScope _ps("tower_pool_kernel", st);
     if (a.pool_max) hipLaunchKernelGGL(tower_pool_kernel<true>, dim3((unsigned)m), dim3(256), 0, st, a);
+    else if (m > 1024) hipLaunchKernelGGL((tower_pool_kernel<false, true>), dim3((unsigned)m), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(tower_pool_kernel<false>, dim3((unsigned)m), dim3(256), 0, st, a);
   }
   if (train && stats_by_consumer) {  // the one-launch step derives the statistics itself (step_fused.hip)
@@ -1019,7 +1049,8 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     {
       ProfScope _ps("tower_stats_kernel", st);
       hipLaunchKernelGGL(tower_stats_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
-      if (stat_grid(m) > 1) hipLaunchKernelGGL(tower_stats_merge_kernel, dim3(1), dim3(128), 0, st, a, stat_grid(m));
+      // several partial rows: merged by one workgroup, or (merge_by_consumer: `original`) by the score kernel's own
+      if (stat_grid(m) > 1 && !merge_by_consumer) hipLaunchKernelGGL(tower_stats_merge_kernel, dim3(1), dim3(128), 0, st, a, stat_grid(m));
     }
     if (E) {
       ProfScope _ps("tower_bn_kernel", st);
@@ -1157,8 +1188,21 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   // (NNCF_TILE_STATS=launch keeps the tower_stats launch: measurement / tests)
   static const bool tile_stats_launch = getenv("NNCF_TILE_STATS") != nullptr;
   const bool tile_stats = (scheme == 1 || scheme == 2) && !one_launch && m->tile_ok && !tile_stats_launch;
-  int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st, one_launch || tile_stats);
+  const bool score_merges = scheme == 0 && stat_grid(n) > 1;   // `original`: the score kernel merges the statistics partials
+  int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st, one_launch || tile_stats, score_merges);
   if (rc) return rc;
+  if (score_merges) {
+    sa.bn_parts = t->ws + ws_stats();
+    sa.bn_nparts = stat_grid(n);
+    sa.bn_pub = t->ws + ws_muinv();
+    sa.bn_gamma = t->prm.bn_gamma;
+    sa.bn_beta = t->prm.bn_beta;
+    sa.bn_rm = t->prm.bn_mean;
+    sa.bn_rv = t->prm.bn_var;
+    sa.bn_eps = t->cfg.bn_eps;
+    sa.bn_mom = t->cfg.bn_momentum;
+    sa.bn_nv = n_u;
+  }
   FusedArgs fa;
   if (one_launch || tile_stats) {
     fa.stats = t->ws + ws_muinv();
