@@ -592,7 +592,10 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
   const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1, nKf = nKw >> 1, nFf = nFt >> 1;
   const int nblock = fl * nKp * nFp;
   const int nA = (a.cnn.dbg & 4) ? 0 : nKw, nB = (a.cnn.dbg & 8) ? 0 : nblock;
-  float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * fl * a.wd * F;
+  // dWk partials, element-group major: gWpart[element / 64][part = this workgroup][64] -- the update workgroup of an element
+  // group then reads ONE contiguous run of (parts x 256 B) instead of 256-byte pieces 120 KB apart
+  const int64_t gw_parts = (int64_t)a.cap * nblk;
+  float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * kCnnUpdElems;
   if (tid >= kConvThreads - 128) {  // column sums of dY over the block's own positions (conv bias
     const int c = tid - (kConvThreads - 128);  // gradient): the last two waves, before they join the queue
     float t = 0.f;
@@ -747,7 +750,8 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       auto put = [&](const f32x4& acc, int kt, int ft) {  // one 16-byte store per tile and lane
         const int k = kt * 16 + x, f = ft * 16 + 4 * kq;
         if (k < a.wd && f < F) {  // streaming stores: 120 KB per workgroup, read once by cnn_update -- not worth L2 lines
-          float* dst = gw + ((int64_t)tap * a.wd + k) * F + f;
+          const int64_t el = ((int64_t)tap * a.wd + k) * F + f;   // a multiple of 4: the four floats stay in one group of 64
+          float* dst = gw + (el / kCnnUpdElems) * gw_parts * kCnnUpdElems + (el % kCnnUpdElems);
           __builtin_nontemporal_store(acc[0], dst);
           __builtin_nontemporal_store(acc[1], dst + 1);
           __builtin_nontemporal_store(acc[2], dst + 2);
@@ -890,7 +894,7 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
     a.part1 = c.take<float>(cap * kFwdSplit * 256);
     a.st1 = c.take<float>(7 * 128);
     a.bpart = c.take<float>(cap * 256);
-    a.gWpart = c.take<float>(cap * nblk * fl * wd * F);
+    a.gWpart = c.take<float>(cap * nblk * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
     a.gbpart = c.take<float>(cap * nblk * 128);
   }
   return c.off;
@@ -975,7 +979,7 @@ static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
 }
 
 __global__ void __launch_bounds__(512) cnn_update_kernel(TowerArgs a) {
-  __shared__ float sG[kCnnUpdGroups * 128];
+  __shared__ float sG[512];
   cnn_update_block(a, (int)blockIdx.x, sG);
 }
 
@@ -991,7 +995,7 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
     if (int rc = cnn_backward_bank(t, b, st)) return rc;
     if (g > 0) {
       ProfScope _ps("cnn_update_kernel", st);
-      const int ncnn = (b.cnn.fl * b.wd * b.cnn.F + 127) / 128 + 1;
+      const int ncnn = cnn_update_blocks(b.cnn.fl * b.wd * b.cnn.F);
       hipLaunchKernelGGL(cnn_update_kernel, dim3(ncnn), dim3(512), 0, st, b);
     }
   }

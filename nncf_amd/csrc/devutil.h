@@ -28,6 +28,27 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // Sum over all 64 lanes (result in every lane).
+// per-lane partial sums of two arrays over i = lane, lane + 64, ... < n, eight pairs of loads in flight (a load per
+// iteration turns a one-wave reduction into n / 64 dependent trips to memory: the launch's long pole); fixed order
+__device__ __forceinline__ void lane_sums2(const float* __restrict__ x, const float* __restrict__ y, int n, int lane, float& sx,
+                                           float& sy) {
+  sx = 0.f;
+  sy = 0.f;
+  for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+    float u[8], v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = i0 + 64 * e;
+      u[e] = i < n ? x[i] : 0.f;
+      v[e] = i < n ? y[i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sx += u[e];
+      sy += v[e];
+    }
+  }
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

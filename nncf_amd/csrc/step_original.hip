@@ -58,10 +58,16 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
         const int c = threadIdx.x;
         float mul = 0.f, add = 0.f;
         if (c < a.d) {
-          float t1 = 0.f, t2 = 0.f;
-          for (int pp = 0; pp < a.bn_nparts; ++pp) {   // <= 8 partials, in order
-            t1 += a.bn_parts[pp * 256 + c];
-            t2 += a.bn_parts[pp * 256 + 128 + c];
+          float t1 = 0.f, t2 = 0.f, u1[8], u2[8];   // <= 8 partials, all requested at once, added in order
+#pragma unroll
+          for (int pp = 0; pp < 8; ++pp) {
+            u1[pp] = pp < a.bn_nparts ? a.bn_parts[pp * 256 + c] : 0.f;
+            u2[pp] = pp < a.bn_nparts ? a.bn_parts[pp * 256 + 128 + c] : 0.f;
+          }
+#pragma unroll
+          for (int pp = 0; pp < 8; ++pp) {
+            t1 += u1[pp];
+            t2 += u2[pp];
           }
           const int nv = *a.bn_nv;
           const float rn = 1.f / (float)max(nv, 1);
@@ -205,11 +211,8 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
   if (blockIdx.x == gridDim.x - 1) {
     if (tid >= 64) return;
     // loss = sum of per-positive partials + regulariser, fixed order.
-    float l = 0.f, r = 0.f;
-    for (int i = lane; i < b; i += 64) {
-      l += ws.loss_part[i];
-      r += ws.reg_part[i];
-    }
+    float l, r;
+    lane_sums2(ws.loss_part, ws.reg_part, b, lane, l, r);
     l = wave_sum(l);
     r = wave_sum(r);
     // utilities.py:122-135: u_reg * sum_d mean_n(E^2) over the n = b(1+k) rows

@@ -58,11 +58,8 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
   const int tid = threadIdx.x, lane = tid & 63, q = tid & 15, d4 = a.d >> 2;
   if (blockIdx.x == gridDim.x - 1) {
     if (tid >= 64) return;
-    float l = 0.f, r = 0.f;
-    for (int i = lane; i < n; i += 64) {
-      l += ws.loss_part[i];
-      r += ws.reg_part[i];
-    }
+    float l, r;
+    lane_sums2(ws.loss_part, ws.reg_part, n, lane, l, r);
     l = wave_sum(l);
     r = wave_sum(r);
     if (lane == 0) *loss_out = l + a.u_reg * r / (float)n;  // utilities.py:122-135 over the n rows

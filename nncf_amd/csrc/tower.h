@@ -31,7 +31,7 @@ struct CnnArgs {
   float* part1;              // [m][2][128]   per-slot sums of (y-b), (y-b)^2
   float* st1;                // 7 x 128: mu, inv, var, mul, add, sum da, sum da*xhat
   float* bpart;              // [m][2][128]
-  float* gWpart;             // [m*nblk][fl*wd*F]
+  float* gWpart;             // [ceil(fl*wd*F / 64)][cap*nblk][64]: dWk partials, element-group major
   float* gbpart;             // [m*nblk][128]
   const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)
   const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
@@ -204,32 +204,35 @@ namespace nncf {
 // part-group g adds parts g, g+4, ... (16 loads in flight), the groups are combined in group order
 // through LDS -- and the SGD / Adam step is taken on Wk (+ its transposed copy).  Block nb (the last)
 // handles the conv bias and the BN1 scale / shift.  sG: 4 x 128 floats of LDS.
-constexpr int kCnnUpdGroups = 4;
+constexpr int kCnnUpdElems = 64;                      // elements of dWk per workgroup
+constexpr int kCnnUpdGroups = 512 / kCnnUpdElems;     // part-groups (one wave each): 250 partials = 2 rounds of 16 loads per wave
+__host__ __device__ inline int cnn_update_blocks(int nel) { return (nel + kCnnUpdElems - 1) / kCnnUpdElems + 1; }
 __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, float* sG) {
   const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
   const int nblk = (a.L + kConvLB - 1) / kConvLB;
   const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x position blocks, contiguous
-  const int nb = (nel + 127) / 128;
-  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+  const int nb = (nel + kCnnUpdElems - 1) / kCnnUpdElems;
   if (blk < nb) {
-    const int el = blk * 128 + c;
+    const int c = threadIdx.x & (kCnnUpdElems - 1), g = threadIdx.x / kCnnUpdElems;
+    const int el = blk * kCnnUpdElems + c;
     float acc = 0.f;
     if (el < nel) {
       for (int p0 = g; p0 < nparts; p0 += kCnnUpdGroups * 16) {
         float u[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-          u[e] = (p0 + kCnnUpdGroups * e < nparts) ? a.cnn.gWpart[(int64_t)(p0 + kCnnUpdGroups * e) * nel + el] : 0.f;
+          u[e] = (p0 + kCnnUpdGroups * e < nparts)
+                     ? a.cnn.gWpart[((int64_t)blk * a.cap * nblk + (p0 + kCnnUpdGroups * e)) * kCnnUpdElems + c] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc += u[e];
       }
     }
-    sG[g * 128 + c] = acc;
+    sG[g * kCnnUpdElems + c] = acc;
     __syncthreads();
     if (g == 0 && el < nel) {
       float gsum = 0.f;
 #pragma unroll
-      for (int gg = 0; gg < kCnnUpdGroups; ++gg) gsum += sG[gg * 128 + c];
+      for (int gg = 0; gg < kCnnUpdGroups; ++gg) gsum += sG[gg * kCnnUpdElems + c];
       if (a.gexp) {  // data-parallel step: the gradient leaves, nothing is applied here
         a.gexp[(size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + (size_t)a.cnn.gexp_off + el] = gsum;
         return;
@@ -241,14 +244,22 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
     }
     return;
   }
+  // the last block: conv bias and BN1 scale / shift (<= 128 columns): four part-groups of 128 lanes
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float acc = 0.f;
-  for (int p = g; p < nparts; p += kCnnUpdGroups) acc += a.cnn.gbpart[(int64_t)p * 128 + c];
+  for (int p0 = g; p0 < nparts; p0 += 4 * 16) {   // 16 loads in flight: a load per iteration made this ONE workgroup the
+    float u[16];                                    // launch's long pole (62 dependent trips to memory, ~19 us)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] = (p0 + 4 * e < nparts) ? a.cnn.gbpart[(int64_t)(p0 + 4 * e) * 128 + c] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc += u[e];
+  }
   sG[g * 128 + c] = acc;
   __syncthreads();
   if (g != 0 || c >= F) return;
   float gb = 0.f;
 #pragma unroll
-  for (int gg = 0; gg < kCnnUpdGroups; ++gg) gb += sG[gg * 128 + c];
+  for (int gg = 0; gg < 4; ++gg) gb += sG[gg * 128 + c];
   const float d1 = a.cnn.st1[640 + c], d2 = a.cnn.st1[768 + c];
   if (a.gexp) {
     float* gd = a.gexp + (size_t)a.n_words * a.wd + (size_t)a.hd * a.d + 384 + (size_t)a.cnn.gexp_off + nel;

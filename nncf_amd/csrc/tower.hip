@@ -405,16 +405,16 @@ __global__ void __launch_bounds__(1024) tower_merge_kernel(TowerArgs a, const fl
   __shared__ float sRed[8 * 2 * 128];
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float a1 = 0.f, a2 = 0.f;
-  for (int s0 = g; s0 < n; s0 += 64) {
-    float u1[8], u2[8];
+  for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 pairs of loads in flight: `original`'s 352 partials in three rounds
+    float u1[16], u2[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 16; ++e) {
       const int s = s0 + 8 * e;
       u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
       u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 16; ++e) {
       a1 += u1[e];
       a2 += u2[e];
     }
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
   // CNN tower: the first workgroups of the grid sum the dWk partials and update the conv weights, conv
   // bias and BN1 scale / shift (parameters nobody else in this launch touches).  First, because their
   // chain of partial loads is the longest in the launch: they run under the word workgroups.
-  const int ncnn = CNN ? (a.cnn.fl * a.wd * a.cnn.F + 127) / 128 + 1 : 0;
+  const int ncnn = CNN ? cnn_update_blocks(a.cnn.fl * a.wd * a.cnn.F) : 0;
   if (CNN && (int)blockIdx.x < ncnn) {
     cnn_update_block(a, (int)blockIdx.x, reinterpret_cast<float*>(sAccW));
     return;
@@ -1106,7 +1106,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   {
     ProfScope _ps("tower_word_kernel", st);
     const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
-    const int ncnn = a.cnn.F > 0 ? (a.cnn.fl * a.wd * a.cnn.F + 127) / 128 + 1 : 0;   // cnn_update_block workgroups
+    const int ncnn = a.cnn.F > 0 ? cnn_update_blocks(a.cnn.fl * a.wd * a.cnn.F) : 0;   // cnn_update_block workgroups
     if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else if (a.pool_max) hipLaunchKernelGGL((tower_word_kernel<false, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
