@@ -248,16 +248,16 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a)
 __device__ __forceinline__ void merge_slot_partials(const float* part, int n, float* sRed, float& t1, float& t2) {
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float a1 = 0.f, a2 = 0.f;
-  for (int s0 = g; s0 < n; s0 += 8 * 8) {
-    float u1[8], u2[8];
+  for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 pairs of loads in flight: 250 partials in two rounds
+    float u1[16], u2[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 16; ++e) {
       const int s = s0 + 8 * e;
       u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
       u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < 16; ++e) {
       a1 += u1[e];
       a2 += u2[e];
     }
@@ -478,17 +478,17 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   const float rL = 1.f / (float)a.L;
   float a1 = 0.f, a2 = 0.f;
   if (c < F) {
-    for (int s0 = g; s0 < n; s0 += 8 * 8) {
-      float u1[8], u2[8], dv[8];
+    for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 triples of loads in flight
+      float u1[16], u2[16], dv[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 16; ++e) {
         const int s = s0 + 8 * e;
         u1[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + c] : 0.f;
         u2[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + 128 + c] : 0.f;
         dv[e] = s < n ? a.dh[(int64_t)s * a.hd + a.cnn.c_off + c] * rL : 0.f;
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < 16; ++e) {
         a1 = fmaf(dv[e], u1[e], a1);
         a2 = fmaf(dv[e], u2[e], a2);
       }

@@ -399,9 +399,22 @@ __global__ void __launch_bounds__(256) shared_apply_kernel(StepArgs a, SharedWs 
 
   if (blockIdx.x == gridDim.x - 1) {
     if (tid >= 64) return;
+    // eight loads of each array in flight (a load per iteration: 12 dependent trips to memory in the launch's last workgroup)
     float l = 0.f, r = 0.f;
-    for (int t = lane; t < nbi * nbj; t += 64) l += ws.loss_part[(t / nbj) * nbj_max + (t % nbj)];
-    for (int i = lane; i < b; i += 64) r += ws.reg_part[i];
+    for (int t0 = lane; t0 < max(nbi * nbj, b); t0 += 64 * 8) {
+      float u[8], v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t = t0 + 64 * e;
+        u[e] = t < nbi * nbj ? ws.loss_part[(t / nbj) * nbj_max + (t % nbj)] : 0.f;
+        v[e] = t < b ? ws.reg_part[t] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        l += u[e];
+        r += v[e];
+      }
+    }
     l = wave_sum(l);
     r = wave_sum(r);
     if (lane == 0) *loss_out = l + a.u_reg * r / (float)b;  // utilities.py:122-135 over the b rows
