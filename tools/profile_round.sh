@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: bench JSON lines + rocprofv3 summaries.
-# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r02
+# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
@@ -58,5 +58,7 @@ NNCF_TILE_STATS=launch python3 bench.py --scheme group_neg_shared --cpu-seconds 
 NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1_b8192.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --scaling strong --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_strong_world1.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --steps 1170 --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_data_parallel_world1.json
 python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
 ls -la $OUT/${TAG}_*
