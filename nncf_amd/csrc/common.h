@@ -79,4 +79,23 @@ struct DeviceGuard {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a flag per process would leave a second device of the
+// same process without the opt-in.  One of these per kernel instantiation (function-static at the launch site).
+constexpr int kMaxDevices = 64;
+struct KernelDeviceState {
+  bool attr_set[kMaxDevices] = {};
+  int capacity[kMaxDevices];
+  KernelDeviceState() { for (int i = 0; i < kMaxDevices; ++i) capacity[i] = -1; }
+};
+inline int ensure_dynamic_lds(const void* kern, size_t lds, KernelDeviceState& st) {
+  int dev = 0;
+  NNCF_HIP_CHECK(hipGetDevice(&dev));
+  NNCF_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d beyond %d", dev, kMaxDevices);
+  if (!st.attr_set[dev]) {
+    NNCF_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    st.attr_set[dev] = true;
+  }
+  return NNCF_OK;
+}
+
 }  // namespace nncf

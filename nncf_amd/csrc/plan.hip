@@ -250,12 +250,9 @@ static int launch_plan_steps_t(size_t lds, const int32_t* uid, int64_t stride_u,
                                int64_t stride_a, int na, const int32_t* ids_b, int64_t stride_b, int nb, const PlanView& pv,
                                int32_t* uniq_global, int64_t uniq_stride, int32_t* n_u_out, int32_t* n_u_copy, int64_t n_lists,
                                hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_steps_kernel<CAP, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static KernelDeviceState kds;
+  if (lds > 64 * 1024)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_steps_kernel<CAP, NT>), lds, kds)) return rc;
   {
     ProfScope _ps("plan_kernel", stream);
     hipLaunchKernelGGL((plan_steps_kernel<CAP, NT>), dim3((unsigned)n_lists, 2), dim3(NT), lds, stream, uid, stride_u, nu, pu,
@@ -314,12 +311,8 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
   } else if (n <= 8192) {
     constexpr int CAP = 8192, NT = 1024;
     const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;  // 132 KiB of the CU's 160 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
+    static KernelDeviceState kds;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>), lds, kds)) return rc;
     {
       ProfScope _ps("plan_kernel", stream);
       hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
@@ -328,12 +321,8 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
   } else if (n <= 16384 && out.aux) {
     constexpr int CAP = 16384, NT = 1024;
     const size_t lds = CAP * 8 + NT * 4;  // keys only: 132 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      NNCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
+    static KernelDeviceState kds;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>), lds, kds)) return rc;
     {
       ProfScope _ps("plan_kernel", stream);
       hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,

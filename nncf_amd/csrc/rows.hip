@@ -403,11 +403,11 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   const bool strong = d_user_shard != nullptr;
   NNCF_REQUIRE(b % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
   NNCF_REQUIRE(m->cfg.item_count >= b, "the model's item table is the landing buffer: it must hold batch_size_p rows");
+  NNCF_REQUIRE(m->opt == 0, "the sharded trainers step the owners' rows with sparse SGD (scatter-merge): create the model without an Adam optimiser");
   if (strong) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
     NNCF_REQUIRE(m->cfg.user_count >= b / n_ranks, "the model's user table is the landing buffer: it must hold batch_size_p / n_ranks rows");
-    NNCF_REQUIRE(m->opt == 0, "same-global-batch form: the owners take sparse SGD steps only");
   }
   nncf_shard* h = new (std::nothrow) nncf_shard();
   if (!h) return fail(NNCF_ERR_NOMEM, "out of host memory");
@@ -547,12 +547,7 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
   }
   NNCF_REQUIRE(uid != nullptr, "NULL argument");
   int rc = shared_step(m, a, 0, uid, h->x[0].slot + index * h->b, m->plan_u.at(index), m->plan_v.at(index), d_loss, 1, st);
-  if (rc) return rc;
-  if (m->opt == 2) {  // item rows belong to their owners: only the user table is stepped here
-    if (int rc2 = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st)) return rc2;
-  }
-  if (m->opt) m->adam_t++;
-  return NNCF_OK;
+  return rc;
 }
 
 int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, void* stream) {

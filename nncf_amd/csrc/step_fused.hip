@@ -1119,24 +1119,13 @@ __global__ void __launch_bounds__(64) fused_loss_flush_kernel(const float* __res
 
 namespace {
 
-// Per kernel instantiation AND per device (both hipFuncSetAttribute and the occupancy are per device): the dynamic-LDS
-// opt-in is made and the resident capacity (workgroups of 512 threads / `lds` bytes the device holds at once) looked up
-// the first time a device launches the kernel.
-constexpr int kMaxDevices = 64;
-struct KernelDeviceState {
-  bool attr_set[kMaxDevices] = {};
-  int capacity[kMaxDevices];
-  KernelDeviceState() { for (int i = 0; i < kMaxDevices; ++i) capacity[i] = -1; }
-};
-
+// Per kernel instantiation AND per device (common.h: KernelDeviceState): the dynamic-LDS opt-in is made and the resident
+// capacity (workgroups of 512 threads / `lds` bytes the device holds at once) looked up the first time a device launches
+// the kernel.
 int prepare_kernel(const void* kern, size_t lds, KernelDeviceState& st, int* capacity) {
+  if (int rc = ensure_dynamic_lds(kern, lds, st)) return rc;
   int dev = 0;
   NNCF_HIP_CHECK(hipGetDevice(&dev));
-  NNCF_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d beyond %d", dev, kMaxDevices);
-  if (!st.attr_set[dev]) {
-    NNCF_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    st.attr_set[dev] = true;
-  }
   if (st.capacity[dev] < 0) {
     int per_cu = 0, cus = 0;
     NNCF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));

@@ -17,6 +17,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_integrity  # noqa: E402
 
 from oracle import sampler_oracle as so  # noqa: E402
 
@@ -36,7 +38,7 @@ def count_jit(x, dist):
 
 
 def ref_class():
-    lines = open(os.path.join(REF, "configs", "data_utils.py")).read().split("\n")
+    lines = ref_integrity.lines("configs/data_utils.py")
     start = next(i for i, l in enumerate(lines) if l.startswith("class GroupSampler"))
     src = "\n".join(lines[start:])
     src = re.sub(r"print '\[INFO\] In GroupSampler, setting neg_sampling_power' \\\n\s+'to user defined \{\}'\.format\(neg_sampling_power\)",

@@ -18,17 +18,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_integrity  # noqa: E402
 
 
 def ref_eval_multiple():
     sys.modules["bottleneck"] = types.SimpleNamespace(argpartition=np.argpartition)
+    ref_integrity.read_reviewed("utils/metrics_ranking.py")      # hashed before it is imported
     sys.path.insert(0, os.path.join(REF, "utils"))
     import metrics_ranking
     return metrics_ranking.eval_multiple
 
 
 def ref_group_shuffle():
-    lines = open(os.path.join(REF, "configs", "data_utils.py")).read().split("\n")
+    lines = ref_integrity.lines("configs/data_utils.py")
     src = "\n".join(lines[217:241])  # def group_shuffle_train ... return train
     ns = {"np": np}
     exec(compile(src, "ref_group_shuffle_train", "exec"), ns)
@@ -39,7 +42,7 @@ def ref_group_shuffle_stable():
     """The same source lines with ONE token changed in memory: `.argsort()` (:234, an unstable quicksort whose
     within-group order is NumPy-build specific) -> `.argsort(kind='stable')`, the documented deviation of the build.
     With it the chop > 0 outputs are reproducible, and the build's function must equal them exactly."""
-    lines = open(os.path.join(REF, "configs", "data_utils.py")).read().split("\n")
+    lines = ref_integrity.lines("configs/data_utils.py")
     src = "\n".join(lines[217:241])
     assert src.count(".argsort()") == 1
     ns = {"np": np}

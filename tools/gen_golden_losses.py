@@ -37,6 +37,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_integrity  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from golden_inputs import case_inputs  # noqa: E402
 LOSSES = ("skip-gram", "mse", "log-loss", "max-margin")
@@ -190,7 +192,7 @@ class TFBackend(object):
 # the reference's text, exec'd from where it lies
 # ---------------------------------------------------------------------------------------------
 def _lines(path):
-    return open(os.path.join(REF, path)).read().split("\n")
+    return ref_integrity.lines(path)        # sha256-checked against the reviewed revision before anything is exec'd
 
 
 def _strip_py2_prints(src):
