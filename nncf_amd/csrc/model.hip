@@ -10,6 +10,7 @@
 #include "model.h"
 #include "step.h"
 #include "step_fused.h"
+#include "step_pair.h"
 
 using namespace nncf;
 
@@ -74,6 +75,11 @@ bool shared_step_fuses(const nncf_model* m, const StepArgs& a) {
   return m->use_fused && fused_eligible(a) && (!a.bn_z || fused_max_blocks(a.b) <= 64);
 }
 
+// pairwise losses: the strip form (step_pair.hip) above the slab path's batch cap, or wherever NNCF_SHARED_PATH=pairwide asks
+bool shared_step_pair_wide(const nncf_model* m, const StepArgs& a) {
+  return pair_wide_eligible(a) && (!m->tile_ok || m->pair_wide);
+}
+
 int flush_pending_loss(nncf_model* m, hipStream_t st) {
   if (!m->pend_out) return NNCF_OK;
   const int mb = fused_max_blocks(m->cfg.batch_size_p) * fused_split(m->cfg.batch_size_p);
@@ -85,9 +91,21 @@ int flush_pending_loss(nncf_model* m, hipStream_t st) {
 int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
                 const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower) {
   if (!shared_step_fuses(m, a)) {
+    if (shared_step_pair_wide(m, a)) {   // pairwise losses without slabs: anchors -> wide strips -> commit (step_pair.hip)
+      if (int rc = flush_pending_loss(m, st)) return rc;
+      PairArgs p;
+      p.anchor = m->panchor;
+      p.uhat = m->sws.Uhat;
+      p.vhat = m->sws.Vrow;
+      p.t_part = m->sws.c_part;      // [b / 32][b] floats carved; b / (16 MT) strips are used
+      p.stage = m->fstage;
+      p.loss_part = m->fpart;
+      return launch_pair_wide(a, group, uid, cid, p, pu, pv, loss_out, update, st);
+    }
     if (!m->tile_ok)
-      return fail(NNCF_ERR_INVALID, "batch_size_p = %d: above %d only the one-launch step is built (skip-gram / mse, no "
-                  "interaction bias, NNCF_SHARED_PATH unset)", a.b, kTileMaxBatch);
+      return fail(NNCF_ERR_INVALID, "batch_size_p = %d: above %d the shared-negative schemes run the one-launch step (skip-gram / "
+                  "mse) or the strip form of the pairwise losses (id tables); neither takes an interaction bias, exported "
+                  "gradients or the as-written sparse Adam (NNCF_SHARED_PATH unset)", a.b, kTileMaxBatch);
     if (int rc = flush_pending_loss(m, st)) return rc;
     SharedWs w = m->sws;
     if (tower && tower->stats) {   // text tower: the tile workgroups derive the BatchNorm statistics (no statistics launch)
@@ -169,6 +187,7 @@ void carve(nncf_model* m, Carver& c) {
     m->fdone = c.take<int>(2);
     m->ferr = c.take<int>(2);
     m->fstage = c.take<float>(2 * (size_t)b * 128);
+    m->panchor = c.take<float>(b);
   }
   m->cap_u = n;  // row-wise batches list a user per row
   m->cap_v = n;  // item list of `original`; the shared schemes use the first b entries
@@ -243,7 +262,10 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   m->U = d_user_table;
   m->V = d_item_table;
   m->device = device;
-  if (const char* e = getenv("NNCF_SHARED_PATH")) m->use_fused = std::string(e) != "tile";
+  if (const char* e = getenv("NNCF_SHARED_PATH")) {
+    m->use_fused = std::string(e) != "tile";
+    m->pair_wide = std::string(e) == "pairwide";
+  }
   if (const char* e = getenv("NNCF_FUSED_SPIN_MS")) {
     const double ms = atof(e);
     if (ms > 0) m->spin_ticks = (long long)(ms * 1e5);   // 100 MHz wall clock

@@ -270,6 +270,8 @@ struct nncf_model {
   bool tile_ok = true;        // the tile + apply workspace exists (batch_size_p <= kTileMaxBatch)
   int dup_as_written = 0;     // nncf_model_set_sparse_adam_duplicates
   int use_fused = 1;          // NNCF_SHARED_PATH=tile forces the two-launch tile + apply path
+  int pair_wide = 0;          // NNCF_SHARED_PATH=pairwide: pairwise losses take the strip form (step_pair.hip) at any batch size
+  float* panchor = nullptr;   // [b] positive score of every batch position (PairArgs::anchor)
   float* fpart = nullptr;     // [2][fused_max_blocks(b) * fused_split(b)]
   float* fslab = nullptr;     // [2 strips per side][split][16][128] partial output rows of split strips
   int* fcnt = nullptr;        // [2 strips per side] arrival tickets (zero between launches)
@@ -291,6 +293,7 @@ struct FusedArgs;
 int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
                 const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower = nullptr);
 bool shared_step_fuses(const nncf_model* m, const StepArgs& a);
+bool shared_step_pair_wide(const nncf_model* m, const StepArgs& a);   // pairwise losses: anchors -> wide strips -> commit
 // sums the loss partials the last fused launch left behind (every entry point calls it before it returns)
 int flush_pending_loss(nncf_model* m, hipStream_t st);
 StepArgs make_args(const nncf_model* m);

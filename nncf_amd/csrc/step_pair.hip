@@ -1,0 +1,584 @@
+// train_scheme = neg_shared / group_neg_shared, PAIRWISE losses (log-loss, max-margin) at batch sizes the slab-based
+// tile + apply pair does not allocate for (batch_size_p > 2,048; id tables): anchors -> wide strips -> commit.
+//
+// Reference path: models/train_neg_shared.py:46-51 / train_group_neg_shared.py:53-61 -> InteractionDot 'matmul'
+// (modules/interaction/interaction_dot.py:100-103) -> get_neg_shared_loss / get_group_neg_shared_loss, the
+// log-loss and max-margin branches (utils/objectives.py:90-98,175,194-201).
+//
+// A pairwise loss compares every score with the positive score of its column (neg_shared:
+// diff[i,j] = S[j,j] - S[i,j]) or of its row (group: diff[i,j] = S[i,pos_i] - S[i,j]).  With h = d loss / dS off the
+// positive element,   dL/dS = h - (column | row sums of h, placed on the positive element).
+// Both anchors are the same b numbers: D[p] = Uhat[uid[p]] . Vhat[cid[p]], one per batch POSITION p.
+//
+//   pair_anchor_kernel   D[p], one 16-lane group per position (+ both normalised rows of the position, for the commit);
+//   pair_wide_kernel     the strips of step_fused.hip's large-batch kernel (a workgroup owns 16 MT UNIQUE rows of one
+//                        side, streams the other side through LDS in stages of 128, S and the back-GEMM on the
+//                        fp32 MFMA).  One side streams BY POSITION, anchor D[p] beside every streamed row
+//                        (neg_shared: the user strips; group: the item strips): it also emits the loss and, per strip
+//                        and position, the partial sum T[strip][p] of h over its own rows.  The other side's own rows
+//                        carry a LIST of (key, anchor), one entry per batch position of that row.
+//                        Output: the unique rows' dL/d(normalised row) WITHOUT the positive element's term,
+//                        staged by rank;
+//   pair_commit_kernel   per table row (chunks of the duplicate plan, chunk_reduce.h): staged row
+//                        - sum over the row's positions p of T[p] * (the other side's normalised row at p), then the
+//                        normalisation backward, the regulariser and the optimiser step; its last workgroup sums the loss.
+// Three launches, no slabs (the tile + apply pair would need 2 x 1 GB of them at b = 8,192), no float atomics,
+// every sum in a fixed order.
+#include "chunk_reduce.h"
+#include "common.h"
+#include "devutil.h"
+#include "model.h"
+#include "step.h"
+#include "step_pair.h"
+
+namespace nncf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPNB = 128;          // opposite rows per stage
+constexpr int kPDP = 128 + 4;      // LDS row pitch (floats): conflict-free ds_read_b128 fragments
+constexpr int kPGP = kPNB + 4;     // pitch of the gradient tile
+constexpr int kPOP = 132;          // pitch of the output rows
+constexpr int kPKeys = 128;        // list entries held in LDS per 16 own rows
+
+template <int MT>
+__host__ __device__ constexpr size_t pair_lds_bytes() {
+  return sizeof(float) * (16 * MT * kPDP + kPNB * kPDP + 16 * MT * kPGP + 16 * MT + 16 * MT + 8 + kPNB + kPKeys * MT) +
+         sizeof(int) * (kPNB + kPKeys * MT + 16 * MT + 16 * MT + 4);
+}
+
+__device__ __forceinline__ void lds_store_row_p(float* dst, int q, Row v) {
+  reinterpret_cast<float4*>(dst)[q] = v.a;
+  reinterpret_cast<float4*>(dst)[q + 16] = v.b;
+}
+
+#define NNCF_PMFMA4(A, B, C0, C1)                                       \
+  C0 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, C0, 0, 0, 0); \
+  C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, C1, 0, 0, 0); \
+  C0 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (B).z, C0, 0, 0, 0); \
+  C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, C1, 0, 0, 0)
+
+// d loss / dS of one off-positive element (x = anchor - score), without the 1 / (b N) of K.mean
+template <int LOSS>
+__device__ __forceinline__ float pair_h(float x, float gamma) {
+  if (LOSS == NNCF_LOSS_LOG_LOSS) {   // -log sigmoid(gamma x): objectives.py:97,200
+    float sp, sg;
+    softplus_sigmoid(-gamma * x, sp, sg);
+    return gamma * sg;
+  }
+  return (gamma - x > 0.f) ? 1.f : 0.f;   // max(0, gamma - x): objectives.py:92-93,195-197
+}
+template <int LOSS>
+__device__ __forceinline__ void pair_lh(float x, float gamma, float& l, float& h) {
+  if (LOSS == NNCF_LOSS_LOG_LOSS) {
+    float sp, sg;
+    softplus_sigmoid(-gamma * x, sp, sg);
+    l = sp;
+    h = gamma * sg;
+  } else {
+    const float act = gamma - x;
+    l = fmaxf(act, 0.f);
+    h = act > 0.f ? 1.f : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256) pair_anchor_kernel(StepArgs a, const int32_t* __restrict__ uid,
+                                                          const int32_t* __restrict__ cid, float* __restrict__ anchor,
+                                                          float* __restrict__ uhat, float* __restrict__ vhat) {
+  const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
+  const int p = blockIdx.x * 16 + g;
+  if (p >= a.b) return;
+  const int d4 = a.d >> 2;
+  Row ru = row_load(a.U, uid[p], a.stride, d4, q);
+  Row rv = row_load(a.V, cid[p], a.stride, d4, q);
+  if (a.norm_u) ru = row_scale(ru, inv_norm(row16_sum(row_dot_partial(ru, ru))));
+  if (a.norm_v) rv = row_scale(rv, inv_norm(row16_sum(row_dot_partial(rv, rv))));
+  const float s = row_dot(ru, rv);
+  if (q == 0) anchor[p] = s;
+  // the commit kernel steps both tables in place: the rows its corrections need are kept as they were
+  row_store(uhat, p, a.d, d4, q, ru);
+  row_store(vhat, p, a.d, d4, q, rv);
+}
+
+// POS (this side streams by position and owns the loss and the T sums): USIDE for neg_shared, the item side for group.
+template <int LOSS, bool GROUP, bool USIDE, int MT>
+__device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __restrict__ uid,
+                                          const int32_t* __restrict__ cid, const PairArgs& p, const PlanView& pu,
+                                          const PlanView& pv, int blk, int gu, int update, float* smem) {
+  constexpr bool POS = USIDE != GROUP;
+  constexpr int OWN = 16 * MT;
+  constexpr int RPG = (OWN + 31) / 32;      // own rows per 16-lane group
+  float* sOwn = smem;                       // [OWN][kPDP]
+  float* sOpp = sOwn + OWN * kPDP;          // [128][kPDP]
+  float* sG = sOpp + kPNB * kPDP;           // [OWN][kPGP]
+  float* sCnt = sG + OWN * kPGP;            // [OWN] multiplicity of every own row
+  float* sRowReg = sCnt + OWN;              // [OWN]
+  float* sRed = sRowReg + OWN;              // [8]
+  float* sOppD = sRed + 8;                  // [128] anchor of every streamed position (POS)
+  float* sAnch = sOppD + kPNB;              // [kPKeys MT] anchors of the own rows' list entries (LIST side)
+  int* sOppKey = reinterpret_cast<int*>(sAnch + kPKeys * MT);  // [128]
+  int* sKeys = sOppKey + kPNB;              // [kPKeys MT]
+  int* sKeyStart = sKeys + kPKeys * MT;     // [OWN]
+  int* sKeyCnt = sKeyStart + OWN;           // [OWN]  < 0: the list did not fit, read it from the plan
+  int* sTop = sKeyCnt + OWN;                // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid >> 4, q = tid & 15;
+  const int b = a.b, d = a.d, d4 = d >> 2;
+  const int NP = (d + 15) & ~15;
+  const int n_items = GROUP ? pv.counts[0] : b;
+  const int n_opp = USIDE ? n_items : b;
+  const PlanView& po = USIDE ? pu : pv;
+  const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
+  const bool norm_own = USIDE ? a.norm_u : a.norm_v, norm_opp = USIDE ? a.norm_v : a.norm_u;
+
+  if (tid == 0) sTop[0] = 0;
+  auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
+  // POS: the rank of the streamed position's own-side id (a match = that position is the positive of this own row);
+  // LIST: the streamed row's index itself (a batch position for neg_shared, a unique-item rank for group)
+  auto opp_key = [&](int j) -> int { return POS ? (USIDE ? pu.inverse[j] : pv.inverse[j]) : j; };
+  const int nst = (n_opp + kPNB - 1) / kPNB;
+  int idA[4], keyA[4], idB[4], keyB[4];
+  float dA[4], dB[4];
+  auto load_ids = [&](int st, int* ids, int* keys, float* dd) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = st * kPNB + g + 32 * e;
+      const bool ok = st < nst && j < n_opp;
+      ids[e] = ok ? opp_id(j) : -1;
+      keys[e] = ok ? opp_key(j) : -1;
+      dd[e] = (POS && ok) ? p.anchor[j] : 0.f;
+    }
+  };
+  load_ids(0, idA, keyA, dA);
+  load_ids(1, idB, keyB, dB);
+  __syncthreads();
+
+  Row rcur[4], rnext[4];
+  int kcur[4];
+  float dcur[4];
+  auto load_rows = [&](const int* ids, Row* rows) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      rows[e] = (ids[e] >= 0) ? row_load(USIDE ? a.V : a.U, ids[e], a.stride, d4, q) : row_zero();
+  };
+  load_rows(idA, rcur);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    kcur[e] = keyA[e];
+    dcur[e] = dA[e];
+    idA[e] = idB[e];
+    keyA[e] = keyB[e];
+    dA[e] = dB[e];
+  }
+  load_ids(2, idB, keyB, dB);
+
+  // ---- own rows: 16 MT unique ids of this side ---------------------------------------------------------------
+  // {table row, multiplicity, rank (= stage slot; POS: also the key), list start, list length}
+  auto own_desc = [&](int o, int& id, float& c, int& rank, int& cnt, int& start) -> bool {
+    const int s_own = blk * OWN + o;
+    id = -1;
+    c = 0.f;
+    rank = 0;
+    cnt = 0;
+    start = 0;
+    if (o >= OWN || s_own >= n_own) return false;
+    if (GROUP && !USIDE) {
+      id = pv.uniq[s_own];
+      rank = s_own;
+      c = 1.f;   // a unique item is one column however often it occurs in the batch
+    } else {
+      const int4 ds = reinterpret_cast<const int4*>(po.desc)[s_own];   // {id, first position, start, count}
+      id = ds.x;
+      c = (float)ds.w;
+      start = ds.z;
+      cnt = ds.w;
+      rank = po.inverse[ds.y];
+    }
+    return true;
+  };
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    const int o = g + 32 * rr;
+    if (o < OWN) {
+      int id, rank, cnt, start;
+      float c;
+      const bool ok = own_desc(o, id, c, rank, cnt, start);
+      Row hat = row_zero();
+      float ss = 0.f;
+      int kstart = 0, kcnt = 0;
+      if (ok) {
+        const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
+        ss = row16_sum(row_dot_partial(raw, raw));
+        hat = norm_own ? row_scale(raw, inv_norm(ss)) : raw;
+        if (POS) {
+          kstart = rank;   // the single key: held directly
+          kcnt = 1;
+        } else {
+          kcnt = cnt;
+          if (q == 0) {
+            kstart = atomicAdd(&sTop[0], cnt);   // order of allocation is irrelevant: every list is summed in its own order
+            if (kstart + cnt > kPKeys * MT) kcnt = -cnt;
+          }
+          kstart = __shfl(kstart, lane & 48);
+          kcnt = __shfl(kcnt, lane & 48);
+          if (kcnt > 0) {
+            for (int t = q; t < cnt; t += 16) {
+              const int pos = po.order[start + t];
+              sKeys[kstart + t] = GROUP ? pv.inverse[pos] : pos;
+              sAnch[kstart + t] = p.anchor[pos];
+            }
+          } else {
+            kstart = start;   // overflow: the element-wise stage walks po.order[start + t] itself
+          }
+        }
+      }
+      lds_store_row_p(sOwn + o * kPDP, q, hat);
+      if (q == 0) {
+        sCnt[o] = c;
+        sRowReg[o] = c * ss;
+        sKeyStart[o] = kstart;
+        sKeyCnt[o] = kcnt;
+      }
+    }
+  }
+  __syncthreads();
+  const float inv_b = 1.f / (float)b;
+  if (!update && !POS) {   // loss only: the LIST side contributes the regulariser (user strips) and nothing else
+    if (USIDE && tid == 0) {
+      float reg = 0.f;
+      for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
+      p.loss_part[blk] = a.u_reg * reg * inv_b;
+    }
+    return;
+  }
+  const int x = lane & 15, kq = lane >> 4;
+  float cnt_r[MT][4];
+  int ks_r[MT][4], kc_r[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * mt + 4 * kq + r;
+      cnt_r[mt][r] = sCnt[i];
+      ks_r[mt][r] = sKeyStart[i];
+      kc_r[mt][r] = sKeyCnt[i];
+    }
+
+  const float inv_m = 1.f / ((float)b * (float)n_items);   // K.mean over the b x N matrix
+  const float gamma = a.gamma;
+  // the positive element's own loss term: -log sigmoid(0) (log-loss); max(0, gamma - 0) for group's max-margin, none
+  // for neg_shared's (objectives.py:93 exempts the diagonal, :195-197 does not)
+  const float l_pos = LOSS == NNCF_LOSS_LOG_LOSS ? 0.6931471805599453f : (GROUP ? fmaxf(gamma, 0.f) : 0.f);
+  f32x4 accD0[MT], accD1[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    accD0[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accD1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float lsum = 0.f;
+  const bool back_wave = wave * 16 < NP;
+
+  for (int st = 0; st < nst; ++st) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      Row r = rcur[e];
+      if (norm_opp) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
+      lds_store_row_p(sOpp + (g + 32 * e) * kPDP, q, r);
+      if (q == 0) {
+        sOppKey[g + 32 * e] = kcur[e];
+        if (POS) sOppD[g + 32 * e] = dcur[e];
+      }
+    }
+    __syncthreads();
+    load_rows(idA, rnext);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kcur[e] = keyA[e];
+      dcur[e] = dA[e];
+      idA[e] = idB[e];
+      keyA[e] = keyB[e];
+      dA[e] = dB[e];
+    }
+    load_ids(st + 3, idB, keyB, dB);
+
+    // S tiles and dL/dS: the MFMAs of tile m + 1 are issued before the element-wise work of tile m
+    {
+      const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kPDP + 4 * kq);
+      float4 fb[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) fb[t] = pb4[4 * t];
+      auto s_one = [&](int mt) -> f32x4 {
+        const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kPDP + 4 * kq);
+        float4 fa[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[t] = pa4[4 * t];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          NNCF_PMFMA4(fa[t], fb[t], acc0, acc1);
+        }
+        return acc0 + acc1;
+      };
+      const int j = 16 * wave + x;
+      const int okey = sOppKey[j];
+      const float od = POS ? sOppD[j] : 0.f;
+      const bool cvalid = st * kPNB + j < n_opp;
+      float tsum = 0.f;
+      f32x4 acc = s_one(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 nxt = acc;
+        if (mt + 1 < MT) nxt = s_one(mt + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * kq + r;
+          const float sc = acc[r];
+          float h = 0.f;
+          if (POS) {
+            const float c = cnt_r[mt][r];
+            const float m = (ks_r[mt][r] == okey) ? 1.f : 0.f;
+            float l;
+            pair_lh<LOSS>(od - sc, gamma, l, h);
+            l = (c - m) * l + m * l_pos;
+            h = (c - m) * h;
+            if (!cvalid || c == 0.f) {
+              l = 0.f;
+              h = 0.f;
+            }
+            lsum += l;
+            tsum += h;
+          } else if (cvalid) {
+            const int ks = ks_r[mt][r], kc = kc_r[mt][r];
+            if (kc >= 0) {
+              for (int t = 0; t < kc; ++t)
+                if (sKeys[ks + t] != okey) h += pair_h<LOSS>(sAnch[ks + t] - sc, gamma);
+            } else {
+              for (int t = 0; t < -kc; ++t) {
+                const int pos = po.order[ks + t];
+                if ((GROUP ? pv.inverse[pos] : pos) != okey) h += pair_h<LOSS>(p.anchor[pos] - sc, gamma);
+              }
+            }
+          }
+          sG[i * kPGP + j] = h * inv_m;
+        }
+        acc = nxt;
+      }
+      if (POS) {   // this strip's part of the column (row) sum of h at the streamed position: the four row quarters
+        tsum += __shfl_xor(tsum, 16);
+        tsum += __shfl_xor(tsum, 32);
+        if (kq == 0 && cvalid) p.t_part[(int64_t)blk * b + st * kPNB + j] = tsum * inv_m;
+      }
+    }
+    __syncthreads();
+    if (back_wave && update) {
+      const float* pbv = sOpp + (4 * kq) * kPDP + 16 * wave + x;
+#pragma unroll
+      for (int t = 0; t < kPNB / 16; ++t) {
+        const float* pr = pbv + 16 * t * kPDP;
+        const float4 v = make_float4(pr[0], pr[kPDP], pr[2 * kPDP], pr[3 * kPDP]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4 gg = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kPGP + 4 * kq)[4 * t];
+          NNCF_PMFMA4(gg, v, accD0[mt], accD1[mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rcur[e] = rnext[e];
+    __syncthreads();
+  }
+
+  float* sOut = sOpp;  // [OWN][kPOP]
+  if (back_wave) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 accD = accD0[mt] + accD1[mt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sOut[(16 * mt + 4 * kq + r) * kPOP + 16 * wave + x] = accD[r];
+    }
+  }
+  if (POS) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) sRed[wave] = lsum;
+  }
+  __syncthreads();
+  if (tid == 0 && (POS || USIDE)) {
+    float reg = 0.f;
+    for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
+    float l = 0.f;
+    if (POS) l = (((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]))) * inv_m;
+    // utilities.py:122-135 over the b rows: by the user strips
+    p.loss_part[(USIDE ? 0 : gu) + blk] = l + (USIDE ? a.u_reg * reg * inv_b : 0.f);
+  }
+  if (!update) return;
+  // ---- staged by rank: dL/d(normalised row) without the positive element's term --------------------------------
+  float* stage = p.stage + (USIDE ? 0 : (int64_t)b * 128);
+#pragma unroll
+  for (int rr = 0; rr < RPG; ++rr) {
+    const int o = g + 32 * rr;
+    int id, rank, cnt, start;
+    float c;
+    if (!own_desc(o, id, c, rank, cnt, start)) continue;
+    Row acc;
+    acc.a = reinterpret_cast<const float4*>(sOut + o * kPOP)[q];
+    acc.b = reinterpret_cast<const float4*>(sOut + o * kPOP)[q + 16];
+    if (q >= d4) acc.a = zero4();
+    if (q + 16 >= d4) acc.b = zero4();
+    row_store(stage, rank, 128, d4, q, acc);
+  }
+}
+
+// grid = 2 gu workgroups: gu U strips and gu V strips of 16 MT unique rows, alternating (both kinds spread over the XCDs)
+template <int LOSS, bool GROUP, int MT>
+__global__ void __launch_bounds__(512) pair_wide_kernel(StepArgs a, const int32_t* __restrict__ uid,
+                                                        const int32_t* __restrict__ cid, PairArgs p, PlanView pu,
+                                                        PlanView pv, int update, int gu) {
+  extern __shared__ __attribute__((aligned(16))) float pair_smem[];
+  const int id = blockIdx.x;
+  const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
+  const int strip = id >> 1;
+  if (!(id & 1)) {
+    if (strip * 16 * MT >= nseg_u) {
+      if (threadIdx.x == 0) p.loss_part[strip] = 0.f;
+      return;
+    }
+    pair_body<LOSS, GROUP, true, MT>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
+  } else {
+    if (strip * 16 * MT >= nseg_v) {
+      if (GROUP && threadIdx.x == 0) p.loss_part[gu + strip] = 0.f;
+      return;
+    }
+    pair_body<LOSS, GROUP, false, MT>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
+  }
+}
+
+__device__ __forceinline__ float pair_t_sum(const float* __restrict__ part, int64_t sstride, int cnt, int idx, int q) {
+  float w = 0.f;
+  for (int j = q; j < cnt; j += 16) w += part[(int64_t)j * sstride + idx];
+  return row16_sum(w);
+}
+
+// Workgroups [0, max_chunks): user rows, [max_chunks, 2 max_chunks): item rows (a chunk of the duplicate plan each);
+// the last workgroup sums the loss.
+template <bool GROUP>
+__global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p, PlanView pu,
+                                                          PlanView pv, float* __restrict__ loss_out, int update,
+                                                          int max_chunks, int own_rows, int n_loss) {
+  __shared__ __attribute__((aligned(16))) float sR[kChunkSlots * kChunkPitch];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = tid & 15;
+  const int b = a.b, d4 = a.d >> 2;
+  if (blockIdx.x == gridDim.x - 1) {
+    if (tid >= 64) return;
+    float l = 0.f;
+    for (int t0 = lane; t0 < n_loss; t0 += 64 * 8) {
+      float u[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u[e] = t0 + 64 * e < n_loss ? p.loss_part[t0 + 64 * e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) l += u[e];
+    }
+    l = wave_sum(l);
+    if (lane == 0) *loss_out = l;
+    return;
+  }
+  if (!update) return;
+  // strips of the position-streaming side that ran (the others left their T rows untouched)
+  const int nact = ((GROUP ? pv.counts[0] : pu.counts[0]) + own_rows - 1) / own_rows;
+  if (blockIdx.x < max_chunks) {
+    chunk_reduce(
+        pu, blockIdx.x, sR, [&](int u) { return row_load(a.U, u, a.stride, d4, q); },
+        [&](int pos, bool is_head) {
+          Row row = is_head ? row_load(p.stage, pu.inverse[pos], 128, d4, q) : row_zero();
+          // - T[pos] * Vhat of the position's own item: the positive element of column (row) pos
+          return row_fma(-pair_t_sum(p.t_part, b, nact, pos, q), row_load(p.vhat, pos, a.d, d4, q), row);
+        },
+        [&](int u, int cnt, Row uraw, Row acc, Row) {
+          Row grad = acc;
+          if (a.norm_u) {
+            const float ss = row16_sum(row_dot_partial(uraw, uraw));
+            const float inv = inv_norm(ss);
+            grad = norm_backward(row_scale(uraw, inv), inv, ss, acc);
+          }
+          grad = row_fma(2.f * a.u_reg * (float)cnt / (float)b, uraw, grad);
+          apply_update(a, a.au, a.U, u, uraw, grad, d4, q);
+        });
+  } else {
+    chunk_reduce(
+        pv, blockIdx.x - max_chunks, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
+        [&](int pos, bool is_head) {
+          Row row = is_head ? row_load(p.stage + (int64_t)b * 128, pv.inverse[pos], 128, d4, q) : row_zero();
+          return row_fma(-pair_t_sum(p.t_part, b, nact, pos, q), row_load(p.uhat, pos, a.d, d4, q), row);
+        },
+        [&](int c, int, Row vraw, Row acc, Row) {
+          Row grad = acc;
+          if (a.norm_v) {
+            const float ss = row16_sum(row_dot_partial(vraw, vraw));
+            const float inv = inv_norm(ss);
+            grad = norm_backward(row_scale(vraw, inv), inv, ss, acc);
+          }
+          apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
+        });
+  }
+}
+
+namespace {
+
+template <int LOSS, bool GROUP, int MT>
+int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
+              const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+  const int gu = (a.b + 16 * MT - 1) / (16 * MT);
+  auto kern = pair_wide_kernel<LOSS, GROUP, MT>;
+  static KernelDeviceState kds;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pair_lds_bytes<MT>(), kds)) return rc;
+  {
+    ProfScope _ps("pair_anchor_kernel", stream);
+    hipLaunchKernelGGL(pair_anchor_kernel, dim3((a.b + 15) / 16), dim3(256), 0, stream, a, uid, cid, p.anchor, p.uhat, p.vhat);
+  }
+  {
+    ProfScope _ps("pair_wide_kernel", stream);
+    hipLaunchKernelGGL(kern, dim3(2 * gu), dim3(512), pair_lds_bytes<MT>(), stream, a, uid, cid, p, pu, pv, update, gu);
+  }
+  const int max_chunks = (a.b + kChunkSlots - 1) / kChunkSlots;
+  {
+    ProfScope _ps("pair_commit_kernel", stream);
+    hipLaunchKernelGGL(pair_commit_kernel<GROUP>, dim3(2 * max_chunks + 1), dim3(256), 0, stream, a, p, pu, pv,
+                       loss_out, update, max_chunks, 16 * MT, GROUP ? 2 * gu : gu);
+  }
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+template <int LOSS, bool GROUP>
+int launch_pm(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
+              const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+  if (pair_row_tiles(a) == 4) return launch_pw<LOSS, GROUP, 4>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+  return launch_pw<LOSS, GROUP, 2>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+}
+
+}  // namespace
+
+bool pair_wide_eligible(const StepArgs& a) {
+  return (a.loss == NNCF_LOSS_LOG_LOSS || a.loss == NNCF_LOSS_MAX_MARGIN) && !a.ub && !a.cb && !a.bn_z && !a.gV && !a.gU &&
+         !a.bc && !(a.opt == 1 && a.dup_as_written) && a.b % 16 == 0;
+}
+
+// 16-row tiles per workgroup: 4 from b = 8,192 (>= 256 workgroups), else 2.  NNCF_FUSED_MT = 2 | 4 overrides (tests).
+int pair_row_tiles(const StepArgs& a) {
+  const char* e = getenv("NNCF_FUSED_MT");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 2 || forced == 4) return forced;
+  return a.b >= 8192 ? 4 : 2;
+}
+
+int launch_pair_wide(const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PairArgs& p,
+                     const PlanView& pu, const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+  if (a.loss == NNCF_LOSS_LOG_LOSS)
+    return group ? launch_pm<NNCF_LOSS_LOG_LOSS, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
+                 : launch_pm<NNCF_LOSS_LOG_LOSS, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+  return group ? launch_pm<NNCF_LOSS_MAX_MARGIN, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
+               : launch_pm<NNCF_LOSS_MAX_MARGIN, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+}
+
+}  // namespace nncf

@@ -137,9 +137,7 @@ def test_fused_large_batch(b, d):
     assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
-    with pytest.raises(ValueError):     # pairwise losses need the slab path, which stops at b = 2048
-        e2 = Engine(nu, ni, d, b, 0, "log-loss", 10., 128., 1e-6, 0.05, True, False, seed=1)
-        e2.step_neg_shared(e2.ids(uid), e2.ids(cid))
+    # (pairwise losses at these sizes: tests/test_pair_gpu.py::test_pairwise_large_batch)
 
 
 @pytest.fixture

@@ -1,0 +1,195 @@
+"""GPU: pairwise losses (log-loss, max-margin) of the shared-negative schemes through the strip form
+(csrc/step_pair.hip: anchors -> wide strips -> commit; the path of batch_size_p > 2,048 where the slab-based
+tile + apply pair does not exist) against the numpy oracle, and against the tile + apply pair at sizes both run --
+duplicates on both sides, list overflow, ragged strips and stages, loss-only mode, Adam, the epoch runner,
+b = 4,096 / 8,192.  Reference: utils/objectives.py:90-98,175,194-201."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+from oracle import step_oracle as so  # noqa: E402
+from nncf_amd.engine import Engine  # noqa: E402
+
+GAMMA = {"max-margin": 0.1, "log-loss": 10.}
+
+
+def _engine(path, *args, **kw):
+    old = os.environ.get("NNCF_SHARED_PATH")
+    os.environ["NNCF_SHARED_PATH"] = path
+    try:
+        return Engine(*args, **kw)
+    finally:
+        if old is None:
+            del os.environ["NNCF_SHARED_PATH"]
+        else:
+            os.environ["NNCF_SHARED_PATH"] = old
+
+
+def _mk(loss, b, d, nu, ni, model, path, seed=0, lr=0.05, u_reg=1e-3):
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=GAMMA[loss], u_reg=u_reg, learn_rate=lr,
+                         model_choice=model)
+    eng = _engine(path, nu, ni, d, b, 0, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                  conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    return conf, eng, orc
+
+
+def _batch(rs, b, nu, ni, group):
+    uid = rs.randint(0, nu, b)
+    uid[:6] = uid[0]                      # one user six times
+    if group:
+        cid = np.repeat(np.minimum((ni * rs.power(0.4, b // 4)).astype(np.int64), ni - 1), 4)
+    else:
+        cid = np.minimum((ni * rs.power(0.4, b)).astype(np.int64), ni - 1)   # popular items repeat
+    return uid, cid
+
+
+@pytest.fixture
+def force_row_tiles():
+    old = os.environ.get("NNCF_FUSED_MT")
+
+    def set_(mt):
+        os.environ["NNCF_FUSED_MT"] = str(mt)
+    yield set_
+    if old is None:
+        os.environ.pop("NNCF_FUSED_MT", None)
+    else:
+        os.environ["NNCF_FUSED_MT"] = old
+
+
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("loss", ["log-loss", "max-margin"])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+@pytest.mark.parametrize("model", ["mf", "content"])
+@pytest.mark.parametrize("shape", [(64, 20, 50, 300), (512, 100, 700, 600), (288, 128, 3000, 90), (32, 4, 10, 12)])
+def test_pair_strips_match_oracle_and_tile_path(force_row_tiles, mt, loss, scheme, model, shape):
+    """ragged last strips (288 = 4 x 64 + 32), ragged stages, d = 4 / 20 / 100 / 128, duplicates on both sides;
+    'content' normalises the item rows too"""
+    b, d, nu, ni = shape
+    group = scheme == "group_neg_shared"
+    force_row_tiles(mt)
+    conf, eng, orc = _mk(loss, b, d, nu, ni, model, "pairwide", seed=2)
+    _, eng_t, _ = _mk(loss, b, d, nu, ni, model, "tile", seed=2)
+    rs = np.random.RandomState(3)
+    for step in range(3):
+        uid, cid = _batch(rs, b, nu, ni, group)
+        if group:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            ref = eng_t.step_group_neg_shared(eng_t.ids(uid), eng_t.ids(cid)).item()
+        else:
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+            ref = eng_t.step_neg_shared(eng_t.ids(uid), eng_t.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (step, got, ref)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(eng_t.U.cpu().numpy(), orc.U, rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(eng_t.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mt", [2, 4])
+@pytest.mark.parametrize("loss", ["log-loss", "max-margin"])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+def test_pair_strips_list_overflow_and_loss_only(force_row_tiles, mt, loss, scheme):
+    """one user in 300 of 512 positions (group: its list of (positive column, anchor) does not fit LDS) / four items
+    in 128 positions each (neg_shared: the item lists do not fit); both sides normalised; update = 0 leaves the tables
+    alone and returns the same loss"""
+    force_row_tiles(mt)
+    b, d, nu, ni = 512, 24, 100, 400
+    group = scheme == "group_neg_shared"
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=GAMMA[loss], u_reg=1e-3, learn_rate=0.05,
+                         model_choice="basic_embedding", emb_normalization=True)
+    eng = _engine("pairwide", nu, ni, d, b, 0, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                  True, True, seed=5, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(1)
+    uid = rs.randint(0, nu, b)
+    if group:
+        uid[rs.choice(b, 300, replace=False)] = 17
+        cid = np.repeat(rs.choice(ni, b // 4, replace=False), 4)
+    else:
+        uid[rs.choice(b, 200, replace=False)] = 17
+        cid = rs.choice(rs.choice(ni, 4, replace=False), b)
+    f = eng.step_group_neg_shared if group else eng.step_neg_shared
+    fo = orc.step_group_neg_shared if group else orc.step_neg_shared
+    U0, V0 = eng.U.clone(), eng.V.clone()
+    l0 = f(eng.ids(uid), eng.ids(cid), update=False).item()
+    assert torch.equal(eng.U, U0) and torch.equal(eng.V, V0)
+    want = fo(uid, cid)
+    got = f(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)) and abs(l0 - want) <= 1e-5 * max(1.0, abs(want)), (got, l0, want)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=4e-6)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=4e-6)
+
+
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+@pytest.mark.parametrize("b,d,loss", [(4096, 128, "log-loss"), (8192, 64, "max-margin"), (8192, 128, "log-loss")])
+def test_pairwise_large_batch(scheme, b, d, loss):
+    """pairwise losses above b = 2,048 (no tile + apply workspace there): one step against the
+    float64 oracle, default path selection (no environment switch)"""
+    nu, ni = 3 * b, 2 * b
+    group = scheme == "group_neg_shared"
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=GAMMA[loss], u_reg=1e-3, learn_rate=0.05,
+                         model_choice="mf")
+    eng = Engine(nu, ni, d, b, 0, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=6, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(2)
+    uid = rs.randint(0, nu, b)
+    if group:
+        cid = np.repeat(np.minimum((ni * rs.power(0.6, b // 4)).astype(np.int64), ni - 1), 4)
+        want = orc.step_group_neg_shared(uid, cid)
+        got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    else:
+        cid = np.minimum((ni * rs.power(0.6, b)).astype(np.int64), ni - 1)
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+@pytest.mark.parametrize("scheme", ["neg_shared", "group_neg_shared"])
+def test_pair_strips_adam_equals_tile_path(force_row_tiles, kind, scheme):
+    """Keras (dense) Adam and the lazy-sparse Adam ('sum' duplicates) through the commit kernel: the same rows as the
+    tile + apply pair produces, three steps"""
+    force_row_tiles(2)
+    b, d, nu, ni = 128, 40, 300, 200
+    group = scheme == "group_neg_shared"
+    engs = []
+    for path in ("pairwide", "tile"):
+        e = _engine(path, nu, ni, d, b, 0, "log-loss", 10., 128., 1e-3, 0.01, True, False, seed=3, init_scale=0.5)
+        e.set_optimizer(kind)
+        engs.append(e)
+    rs = np.random.RandomState(4)
+    for step in range(3):
+        uid, cid = _batch(rs, b, nu, ni, group)
+        ls = []
+        for e in engs:
+            f = e.step_group_neg_shared if group else e.step_neg_shared
+            ls.append(f(e.ids(uid), e.ids(cid)).item())
+        assert abs(ls[0] - ls[1]) <= 1e-5 * max(1.0, abs(ls[1])), (step, ls)
+        np.testing.assert_allclose(engs[0].U.cpu().numpy(), engs[1].U.cpu().numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(engs[0].V.cpu().numpy(), engs[1].V.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_pair_strips_epoch_runner_equals_step_by_step(force_row_tiles):
+    force_row_tiles(2)
+    b, d, nu, ni, steps = 128, 40, 900, 800, 70     # 70 > one plan chunk of 64
+    _, e1, _ = _mk("log-loss", b, d, nu, ni, "mf", "pairwide", seed=4)
+    _, e2, _ = _mk("log-loss", b, d, nu, ni, "mf", "pairwide", seed=4)
+    rs = np.random.RandomState(8)
+    uid, cid = rs.randint(0, nu, steps * b), rs.randint(0, ni, steps * b)
+    ua, ca = e1.ids(uid), e1.ids(cid)
+    l1 = e1.epoch_neg_shared(ua, ca, steps).cpu().numpy()
+    l2 = np.array([e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)])
+    assert np.array_equal(l1, l2.astype(np.float32))
+    assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V)
