@@ -905,6 +905,8 @@ def main():
                                "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item pass)"),
         "fused_wide_kernel": ("mfma", 6.0 * b * b * d,
                               "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item pass)"),
+        "pair_wide_kernel": ("mfma", 6.0 * b * b * d,
+                             "6*b*N*d flop (S, G.V, G^T.U); the kernel issues 8*b*N*d (S recomputed by the item strips)"),
         "original_score_kernel": ("hbm", b * (4.0 * d * (2 + k) + 8 * (1 + k)), "read half of 8d(2+k)+8(1+k) B/link"),
         "tower_pool_kernel": ("hbm", 4.0 * mean_n_u * L * d * keep,
                               "4*L*word_dim*(1-dropout) B per unique item, n_u = %.1f unique items per launch" % mean_n_u),
@@ -918,6 +920,8 @@ def main():
     shared_kernel = "fused_strip_kernel" if (pointwise and os.environ.get("NNCF_SHARED_PATH") != "tile") else "shared_tile_kernel"
     if shared_kernel == "fused_strip_kernel" and args.model == "mf" and b >= 4096 and os.environ.get("NNCF_FUSED_MT") != "1":
         shared_kernel = "fused_wide_kernel"     # step_fused.hip fused_row_tiles: 2 or 4 row tiles per workgroup
+    if not pointwise and args.model == "mf" and (b > 2048 or os.environ.get("NNCF_SHARED_PATH") == "pairwide"):
+        shared_kernel = "pair_wide_kernel"      # step_pair.hip: anchors -> wide strips -> commit
     default_kernel = {"mf": {"original": "original_score_kernel"}, "basic_embedding": {"original": "tower_word_kernel"}}.get(
         args.model, {}).get(args.scheme) or {"cnn_embedding": "cnn_conv_bwd_kernel"}.get(args.model, shared_kernel)
     names = [args.roofline_kernel or default_kernel]
@@ -925,7 +929,8 @@ def main():
         names += [n for n in ("tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel",
                               "fused_strip_kernel", "shared_tile_kernel") if n not in names]
     if args.model == "mf":
-        names += [n for n in ("fused_strip_kernel", "fused_wide_kernel", "shared_tile_kernel", "shared_apply_kernel") if n not in names]
+        names += [n for n in ("fused_strip_kernel", "fused_wide_kernel", "shared_tile_kernel", "shared_apply_kernel",
+                              "pair_commit_kernel", "pair_anchor_kernel") if n not in names]
     if args.model == "cnn_embedding":
         names += [n for n in ("cnn_conv_fwd_kernel", "tower_word_kernel", "shared_tile_kernel") if n not in names]
     prof_n = min(K, args.profile_launches)

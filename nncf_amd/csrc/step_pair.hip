@@ -15,11 +15,13 @@
 //                        side, streams the other side through LDS in stages of 128, S and the back-GEMM on the
 //                        fp32 MFMA).  One side streams BY POSITION, anchor D[p] beside every streamed row
 //                        (neg_shared: the user strips; group: the item strips): it also emits the loss and, per strip
-//                        and position, the partial sum T[strip][p] of h over its own rows.  The other side's own rows
-//                        carry a LIST of (key, anchor), one entry per batch position of that row.
-//                        Output: the unique rows' dL/d(normalised row) WITHOUT the positive element's term,
-//                        staged by rank;
-//   pair_commit_kernel   per table row (chunks of the duplicate plan, chunk_reduce.h): staged row
+//                        and position, the partial sum T[strip][p] of h over its own rows.  The OTHER side's strips own
+//                        16 MT batch POSITIONS each (one anchor per own row; a row that occurs c times would need c
+//                        anchors per score -- with Zipf-distributed items the strip holding the popular ones became the
+//                        long pole of the launch: 2.05 ms against 0.74 ms for the pointwise step at b = 8,192).
+//                        Output: dL/d(normalised row) WITHOUT the positive element's term, staged by rank (unique
+//                        side) or by position;
+//   pair_commit_kernel   per table row (chunks of the duplicate plan, chunk_reduce.h): the row's staged row(s)
 //                        - sum over the row's positions p of T[p] * (the other side's normalised row at p), then the
 //                        normalisation backward, the regulariser and the optimiser step; its last workgroup sums the loss.
 // Three launches, no slabs (the tile + apply pair would need 2 x 1 GB of them at b = 8,192), no float atomics,
@@ -39,12 +41,11 @@ constexpr int kPNB = 128;          // opposite rows per stage
 constexpr int kPDP = 128 + 4;      // LDS row pitch (floats): conflict-free ds_read_b128 fragments
 constexpr int kPGP = kPNB + 4;     // pitch of the gradient tile
 constexpr int kPOP = 132;          // pitch of the output rows
-constexpr int kPKeys = 128;        // list entries held in LDS per 16 own rows
 
 template <int MT>
 __host__ __device__ constexpr size_t pair_lds_bytes() {
-  return sizeof(float) * (16 * MT * kPDP + kPNB * kPDP + 16 * MT * kPGP + 16 * MT + 16 * MT + 8 + kPNB + kPKeys * MT) +
-         sizeof(int) * (kPNB + kPKeys * MT + 16 * MT + 16 * MT + 4);
+  return sizeof(float) * (16 * MT * kPDP + kPNB * kPDP + 16 * MT * kPGP + 16 * MT + 16 * MT + 8 + kPNB + 16 * MT) +
+         sizeof(int) * (kPNB + 16 * MT + 4);
 }
 
 __device__ __forceinline__ void lds_store_row_p(float* dst, int q, Row v) {
@@ -115,12 +116,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   float* sRowReg = sCnt + OWN;              // [OWN]
   float* sRed = sRowReg + OWN;              // [8]
   float* sOppD = sRed + 8;                  // [128] anchor of every streamed position (POS)
-  float* sAnch = sOppD + kPNB;              // [kPKeys MT] anchors of the own rows' list entries (LIST side)
-  int* sOppKey = reinterpret_cast<int*>(sAnch + kPKeys * MT);  // [128]
-  int* sKeys = sOppKey + kPNB;              // [kPKeys MT]
-  int* sKeyStart = sKeys + kPKeys * MT;     // [OWN]
-  int* sKeyCnt = sKeyStart + OWN;           // [OWN]  < 0: the list did not fit, read it from the plan
-  int* sTop = sKeyCnt + OWN;                // [4]
+  float* sAnch = sOppD + kPNB;              // [OWN] anchor of every own position (the by-position side)
+  int* sOppKey = reinterpret_cast<int*>(sAnch + OWN);  // [128]
+  int* sKey = sOppKey + kPNB;               // [OWN] POS: rank of the own row; else the own position's key
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tid >> 4, q = tid & 15;
@@ -129,13 +127,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   const int n_items = GROUP ? pv.counts[0] : b;
   const int n_opp = USIDE ? n_items : b;
   const PlanView& po = USIDE ? pu : pv;
-  const int n_own = (GROUP && !USIDE) ? n_items : po.counts[0];
+  const int n_own = !POS ? b : (GROUP ? n_items : po.counts[0]);   // unique rows (POS) or batch positions
   const bool norm_own = USIDE ? a.norm_u : a.norm_v, norm_opp = USIDE ? a.norm_v : a.norm_u;
 
-  if (tid == 0) sTop[0] = 0;
   auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
   // POS: the rank of the streamed position's own-side id (a match = that position is the positive of this own row);
-  // LIST: the streamed row's index itself (a batch position for neg_shared, a unique-item rank for group)
+  // by-position side: the streamed row's index itself (a batch position for neg_shared, a unique-item rank for group)
   auto opp_key = [&](int j) -> int { return POS ? (USIDE ? pu.inverse[j] : pv.inverse[j]) : j; };
   const int nst = (n_opp + kPNB - 1) / kPNB;
   int idA[4], keyA[4], idB[4], keyB[4];
@@ -173,27 +170,31 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   }
   load_ids(2, idB, keyB, dB);
 
-  // ---- own rows: 16 MT unique ids of this side ---------------------------------------------------------------
-  // {table row, multiplicity, rank (= stage slot; POS: also the key), list start, list length}
-  auto own_desc = [&](int o, int& id, float& c, int& rank, int& cnt, int& start) -> bool {
+  // ---- own rows: 16 MT unique ids (POS) or 16 MT batch positions of this side ----------------------------------
+  // {table row, multiplicity, key (POS: the rank; else what a streamed row's key is compared with), stage slot, anchor}
+  auto own_desc = [&](int o, int& id, float& c, int& key, int& slot, float& anch) -> bool {
     const int s_own = blk * OWN + o;
     id = -1;
     c = 0.f;
-    rank = 0;
-    cnt = 0;
-    start = 0;
+    key = -2;
+    slot = 0;
+    anch = 0.f;
     if (o >= OWN || s_own >= n_own) return false;
-    if (GROUP && !USIDE) {
+    if (!POS) {            // position s_own: its own anchor; exempt where the streamed row IS its positive
+      id = USIDE ? uid[s_own] : cid[s_own];
+      c = 1.f;
+      key = GROUP ? pv.inverse[s_own] : s_own;
+      slot = s_own;
+      anch = p.anchor[s_own];
+    } else if (GROUP) {    // item strips of group: a unique item is one column however often it occurs in the batch
       id = pv.uniq[s_own];
-      rank = s_own;
-      c = 1.f;   // a unique item is one column however often it occurs in the batch
-    } else {
+      c = 1.f;
+      key = slot = s_own;
+    } else {               // user strips of neg_shared: unique users, c positions each
       const int4 ds = reinterpret_cast<const int4*>(po.desc)[s_own];   // {id, first position, start, count}
       id = ds.x;
       c = (float)ds.w;
-      start = ds.z;
-      cnt = ds.w;
-      rank = po.inverse[ds.y];
+      key = slot = po.inverse[ds.y];
     }
     return true;
   };
@@ -201,44 +202,22 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   for (int rr = 0; rr < RPG; ++rr) {
     const int o = g + 32 * rr;
     if (o < OWN) {
-      int id, rank, cnt, start;
-      float c;
-      const bool ok = own_desc(o, id, c, rank, cnt, start);
+      int id, key, slot;
+      float c, anch;
+      const bool ok = own_desc(o, id, c, key, slot, anch);
       Row hat = row_zero();
       float ss = 0.f;
-      int kstart = 0, kcnt = 0;
       if (ok) {
         const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
         ss = row16_sum(row_dot_partial(raw, raw));
         hat = norm_own ? row_scale(raw, inv_norm(ss)) : raw;
-        if (POS) {
-          kstart = rank;   // the single key: held directly
-          kcnt = 1;
-        } else {
-          kcnt = cnt;
-          if (q == 0) {
-            kstart = atomicAdd(&sTop[0], cnt);   // order of allocation is irrelevant: every list is summed in its own order
-            if (kstart + cnt > kPKeys * MT) kcnt = -cnt;
-          }
-          kstart = __shfl(kstart, lane & 48);
-          kcnt = __shfl(kcnt, lane & 48);
-          if (kcnt > 0) {
-            for (int t = q; t < cnt; t += 16) {
-              const int pos = po.order[start + t];
-              sKeys[kstart + t] = GROUP ? pv.inverse[pos] : pos;
-              sAnch[kstart + t] = p.anchor[pos];
-            }
-          } else {
-            kstart = start;   // overflow: the element-wise stage walks po.order[start + t] itself
-          }
-        }
       }
       lds_store_row_p(sOwn + o * kPDP, q, hat);
       if (q == 0) {
         sCnt[o] = c;
         sRowReg[o] = c * ss;
-        sKeyStart[o] = kstart;
-        sKeyCnt[o] = kcnt;
+        sKey[o] = key;
+        sAnch[o] = anch;
       }
     }
   }
@@ -253,18 +232,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     return;
   }
   const int x = lane & 15, kq = lane >> 4;
-  float cnt_r[MT][4];
-  int ks_r[MT][4], kc_r[MT][4];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * mt + 4 * kq + r;
-      cnt_r[mt][r] = sCnt[i];
-      ks_r[mt][r] = sKeyStart[i];
-      kc_r[mt][r] = sKeyCnt[i];
-    }
-
+  // per own row, read from LDS where it is used (broadcast reads; 32 registers less than holding them: no scratch at
+  // MT = 4): POS: multiplicity and rank; else the own position's anchor (NaN: no position in this slot) and its key
+  if (!POS) {
+    if (tid < OWN) sCnt[tid] = sCnt[tid] > 0.f ? sAnch[tid] : __builtin_nanf("");
+    __syncthreads();
+  }
   const float inv_m = 1.f / ((float)b * (float)n_items);   // K.mean over the b x N matrix
   const float gamma = a.gamma;
   // the positive element's own loss term: -log sigmoid(0) (log-loss); max(0, gamma - 0) for group's max-margin, none
@@ -336,8 +309,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
           const float sc = acc[r];
           float h = 0.f;
           if (POS) {
-            const float c = cnt_r[mt][r];
-            const float m = (ks_r[mt][r] == okey) ? 1.f : 0.f;
+            const float c = sCnt[i];
+            const float m = (sKey[i] == okey) ? 1.f : 0.f;
             float l;
             pair_lh<LOSS>(od - sc, gamma, l, h);
             l = (c - m) * l + m * l_pos;
@@ -348,17 +321,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
             }
             lsum += l;
             tsum += h;
-          } else if (cvalid) {
-            const int ks = ks_r[mt][r], kc = kc_r[mt][r];
-            if (kc >= 0) {
-              for (int t = 0; t < kc; ++t)
-                if (sKeys[ks + t] != okey) h += pair_h<LOSS>(sAnch[ks + t] - sc, gamma);
-            } else {
-              for (int t = 0; t < -kc; ++t) {
-                const int pos = po.order[ks + t];
-                if ((GROUP ? pv.inverse[pos] : pos) != okey) h += pair_h<LOSS>(p.anchor[pos] - sc, gamma);
-              }
-            }
+          } else {
+            const float an = sCnt[i];
+            h = pair_h<LOSS>(an - sc, gamma);
+            if (!cvalid || an != an || sKey[i] == okey) h = 0.f;   // an != an: no own position in this slot
           }
           sG[i * kPGP + j] = h * inv_m;
         }
@@ -412,20 +378,20 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     p.loss_part[(USIDE ? 0 : gu) + blk] = l + (USIDE ? a.u_reg * reg * inv_b : 0.f);
   }
   if (!update) return;
-  // ---- staged by rank: dL/d(normalised row) without the positive element's term --------------------------------
+  // ---- staged by rank (POS) or by position: dL/d(normalised row) without the positive element's term ------------
   float* stage = p.stage + (USIDE ? 0 : (int64_t)b * 128);
 #pragma unroll
   for (int rr = 0; rr < RPG; ++rr) {
     const int o = g + 32 * rr;
-    int id, rank, cnt, start;
-    float c;
-    if (!own_desc(o, id, c, rank, cnt, start)) continue;
+    int id, key, slot;
+    float c, anch;
+    if (!own_desc(o, id, c, key, slot, anch)) continue;
     Row acc;
     acc.a = reinterpret_cast<const float4*>(sOut + o * kPOP)[q];
     acc.b = reinterpret_cast<const float4*>(sOut + o * kPOP)[q + 16];
     if (q >= d4) acc.a = zero4();
     if (q + 16 >= d4) acc.b = zero4();
-    row_store(stage, rank, 128, d4, q, acc);
+    row_store(stage, slot, 128, d4, q, acc);
   }
 }
 
@@ -438,14 +404,15 @@ __global__ void __launch_bounds__(512) pair_wide_kernel(StepArgs a, const int32_
   const int id = blockIdx.x;
   const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
   const int strip = id >> 1;
+  // rows a side's strips share out: unique rows where it streams by position, the b batch positions where it does not
   if (!(id & 1)) {
-    if (strip * 16 * MT >= nseg_u) {
+    if (strip * 16 * MT >= (GROUP ? a.b : nseg_u)) {
       if (threadIdx.x == 0) p.loss_part[strip] = 0.f;
       return;
     }
     pair_body<LOSS, GROUP, true, MT>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
   } else {
-    if (strip * 16 * MT >= nseg_v) {
+    if (strip * 16 * MT >= (GROUP ? nseg_v : a.b)) {
       if (GROUP && threadIdx.x == 0) p.loss_part[gu + strip] = 0.f;
       return;
     }
@@ -490,7 +457,9 @@ __global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p
     chunk_reduce(
         pu, blockIdx.x, sR, [&](int u) { return row_load(a.U, u, a.stride, d4, q); },
         [&](int pos, bool is_head) {
-          Row row = is_head ? row_load(p.stage, pu.inverse[pos], 128, d4, q) : row_zero();
+          // group: the user strips staged every position; neg_shared: unique users, by rank
+          Row row = GROUP ? row_load(p.stage, pos, 128, d4, q)
+                          : (is_head ? row_load(p.stage, pu.inverse[pos], 128, d4, q) : row_zero());
           // - T[pos] * Vhat of the position's own item: the positive element of column (row) pos
           return row_fma(-pair_t_sum(p.t_part, b, nact, pos, q), row_load(p.vhat, pos, a.d, d4, q), row);
         },
@@ -508,7 +477,8 @@ __global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p
     chunk_reduce(
         pv, blockIdx.x - max_chunks, sR, [&](int c) { return row_load(a.V, c, a.stride, d4, q); },
         [&](int pos, bool is_head) {
-          Row row = is_head ? row_load(p.stage + (int64_t)b * 128, pv.inverse[pos], 128, d4, q) : row_zero();
+          const float* st = p.stage + (int64_t)b * 128;
+          Row row = GROUP ? (is_head ? row_load(st, pv.inverse[pos], 128, d4, q) : row_zero()) : row_load(st, pos, 128, d4, q);
           return row_fma(-pair_t_sum(p.t_part, b, nact, pos, q), row_load(p.uhat, pos, a.d, d4, q), row);
         },
         [&](int c, int, Row vraw, Row acc, Row) {
