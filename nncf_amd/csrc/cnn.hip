@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
 #pragma unroll
       for (int mt = 0; mt < nMb; ++mt) {
         const int p = p0 + 16 * mt + x;
-        if (p < L && k0 < a.wd) {
+        if (p < L && k0 < a.wd && !(a.cnn.dbg & 32)) {
           const float sc = sSc[p];
           float4* dst = reinterpret_cast<float4*>(a.cnn.dX + ((int64_t)s * L + p) * a.wd + k0);
           float4 v = make_float4(acc[mt][0] * sc, acc[mt][1] * sc, acc[mt][2] * sc, acc[mt][3] * sc);
@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
       else kloop(N{}, N{});
       auto put = [&](const f32x4& acc, int kt, int ft) {  // one 16-byte store per tile and lane
         const int k = kt * 16 + x, f = ft * 16 + 4 * kq;
-        if (k < a.wd && f < F) {  // streaming stores: 120 KB per workgroup, read once by cnn_update -- not worth L2 lines
+        if (k < a.wd && f < F && !(a.cnn.dbg & 16)) {  // streaming stores: 120 KB per workgroup, read once by cnn_update -- not worth L2 lines
           const int64_t el = ((int64_t)tap * a.wd + k) * F + f;   // a multiple of 4: the four floats stay in one group of 64
           float* dst = gw + (el / kCnnUpdElems) * gw_parts * kCnnUpdElems + (el % kCnnUpdElems);
           __builtin_nontemporal_store(acc[0], dst);

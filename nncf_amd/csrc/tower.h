@@ -36,7 +36,8 @@ struct CnnArgs {
   const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)
   const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
   float *mC, *vC;            // Adam moments of [Wk | bc, g1, b1 (128 each)]
-  int dbg;                   // NNCF_CNN_DBG (timing experiments only): 1 skip MFMA loops, 2 skip the gather
+  int dbg;                   // NNCF_CNN_DBG (timing experiments only; results are wrong on purpose): forward 1 skip the MFMA loop,
+                             // 2 skip the gather; backward 4 no dX strips, 8 no dWk blocks, 16 no dWk partial stores, 32 no dX stores
   // filter bank (cnn_model.py:63-81: Convolution1D of several lengths over the same input, concatenated along the
   // filter axis): every length is one CnnArgs whose F filters are columns [c_off, c_off + F) of the pooled block h /
   // dh (pitch TowerArgs::hd) and rows [c_off, ...) of the Dense weights.  Banks run one after the other:
