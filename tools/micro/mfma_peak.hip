@@ -28,6 +28,25 @@ int main() {
   int cus = 0;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   const int iters = 20000;
+  // dependent chains: NACC accumulators in rotation (1 = every MFMA waits for the previous one's result)
+  {
+    auto run = [&](auto kern, int nacc) {
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(cus), dim3(256), 0, 0, out, iters, 1.f, 2.f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 2) printf("1 wave/SIMD, %d accumulator(s) in rotation: %.1f cycles per MFMA at 2.4 GHz\n", nacc,
+                             ms * 1e-3 * 2.4e9 / (iters * 4.0 * nacc));
+      }
+    };
+    run(k<1>, 1);
+    run(k<2>, 2);
+    run(k<4>, 4);
+    run(k<8>, 8);
+  }
   for (int threads : {256, 512, 1024}) {
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0);

@@ -29,6 +29,7 @@ run_prof mf_original_kernel_trace "--stats" --model mf --scheme original --steps
 run_prof mf_group_neg_shared_kernel_trace "--stats" --model mf --scheme group_neg_shared --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b8192_kernel_trace "--stats" --large --batch 8192 --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b16384_kernel_trace "--stats" --large --batch 16384 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 5
+run_prof large_mf_b8192_logloss_kernel_trace "--stats" --large --batch 8192 --loss log-loss --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b8192_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
 (cd /tmp && NNCF_FORCE_SHARDED=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_sh -o p -- python3 $R/bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 $B > $OUT/prof_sh.log 2>&1)
 python3 $R/tools/prof_summary.py $OUT/prof_sh/p_results.db $OUT/${TAG}_mf_sharded_world1_kernel_trace.txt; rm -rf $OUT/prof_sh
@@ -51,6 +52,11 @@ python3 bench.py --large --scheme original --steps 1170 $B 2>/dev/null | tail -1
 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192.json
 python3 bench.py --large --batch 4096 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b4096.json
 python3 bench.py --large --batch 16384 --steps 50 --warmup 5 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b16384.json
+for l in log-loss max-margin; do for sc in neg_shared group_neg_shared; do
+python3 bench.py --large --batch 8192 --loss $l --scheme $sc --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_${sc}_${l}_b8192.json
+done; done
+python3 bench.py --large --batch 4096 --loss log-loss --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b4096.json
+python3 bench.py --large --batch 16384 --loss log-loss --steps 50 --warmup 5 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b16384.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_style_steps20.json
 python3 bench.py --model cnn_embedding --scheme group_neg_shared --dim 50 --filter-lens 1,3,5 --conv-dropout 0.3 --dropout 0 --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_default_preset_group_neg_shared.json
 NNCF_TILE_STATS=launch python3 bench.py --scheme group_neg_shared --cpu-seconds 0 --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared_statslaunch.json
