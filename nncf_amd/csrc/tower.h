@@ -108,6 +108,19 @@ struct TowerArgs {
   int n_hot;                 // <= kHotWords
   float* hot_part;           // [cap / 16][kHotWords][128]
   int32_t* hot_cnt;          // [cap / 16][kHotWords] cells (count sum) behind each partial: does the word take a step?
+  // Postings mode (mean-pool tower, average pooling, blocks of more than 1,024 rows: `original` and the row-wise schemes).
+  // The dense count matrix of such a block is ~1 % full and tower_word_kernel was bound by the INSTRUCTIONS of scanning it
+  // (8,001 words x 2,700 rows).  The corpus is static, so the transposed CSR -- per word the items that hold it, with the
+  // count -- is built once (nncf_tower_set_postings); a step only says where each of its items sits: the pool kernel
+  // writes slot_of[item] = {stamp of this forward, block row}.  The word kernel then walks the word's postings (6 % of the
+  // dense cells for a 2,700-row block) and keeps the entries whose item carries the current stamp.  No count cell is
+  // written or cleared for any word but the hot ones (whose cells tower_bwd_kernel's role A consumes).
+  const int32_t* post_ptr;   // [n_words + 1]
+  const int32_t* post_item;  // [nnz] ascending inside a word
+  const uint8_t* post_cnt;   // [nnz]
+  int2* slot_of;             // [item_count] {stamp, block row}; zero-initialised, stamps start at 1
+  const uint32_t* hot_bits;  // [ceil(n_words / 32)] membership of the hot list (the cells the pool kernel still writes)
+  int pm, pm_stamp;          // this forward / backward runs in postings mode; its stamp
   CnnArgs cnn;
 };
 constexpr int kHotWords = 16;
@@ -326,6 +339,13 @@ struct nncf_tower {
   int n_hot = 0;
   float* hot_part = nullptr;     // own allocation
   int32_t* hot_cnt = nullptr;
+  // postings mode (nncf_tower_set_postings; TowerArgs::post_ptr): caller-owned arrays, own hot bitmap
+  const int32_t* post_ptr = nullptr;
+  const int32_t* post_item = nullptr;
+  const uint8_t* post_cnt = nullptr;
+  int2* slot_of = nullptr;
+  uint32_t* hot_bits = nullptr;  // own allocation
+  int pm_stamp = 0;
 };
 
 namespace nncf {

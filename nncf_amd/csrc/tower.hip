@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "tower.h"
 #include "step_fused.h"
@@ -213,6 +214,11 @@ __global__ void __launch_bounds__(256, BIG ? 6 : 1) tower_pool_kernel(TowerArgs 
   }
   // backward preparation: cnt_t[w * cap + s] = occurrences of word w in this item.  Every
   // (w, s) cell is written by exactly one thread: no atomics.  Dropped words get no gradient.
+  if (a.fill && a.pm) {   // postings mode: where this item sits; count cells only for the hot words (consumed by tower_bwd's role A)
+    if (tid == 0) a.slot_of[item] = make_int2(a.pm_stamp, s);
+    if (fsc != 0.f && a.hot_bits && ((a.hot_bits[fw >> 5] >> (fw & 31)) & 1u)) a.cnt_t[(int64_t)fw * a.cap + s] = (uint8_t)fc;
+    return;
+  }
   if (a.fill && fsc != 0.f) a.cnt_t[(int64_t)fw * a.cap + s] = MAXP ? (uint8_t)1 : (uint8_t)fc;
 }
 
@@ -619,7 +625,12 @@ constexpr int kRowsInFlight = 8;
 // a second round.  <= 64 VGPRs (8 waves per SIMD) and <= 40 KB: four fit, 1,024 at once.  (Measured: no change in the step
 // time -- the kernel is bound by the instructions of its count-cell scan, 8,001 words x 2,700 rows / 64 ballot rounds
 // that are empty 3 times out of 4, not by residency.)
-template <bool CNN, bool MAXP = false, int NB = 1>
+// PM: postings mode (TowerArgs::post_ptr) -- the scan of the count matrix is replaced by a walk over the 8 words' postings:
+// per round every wave takes 64 entries of each word (8 item loads, then 8 slot_of loads in flight), keeps the entries whose
+// item carries this forward's stamp and lists them exactly as the scan lists non-zero cells.  Entries of a word are summed in
+// postings order (ascending item id) per wave, the waves' stripes in wave order: fixed order, no atomics.  Hot words are skipped
+// (their partial rows come from tower_bwd_kernel), dropped words too (no cell was ever written for them in the dense mode either).
+template <bool CNN, bool MAXP = false, int NB = 1, bool PM = false>
 __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
@@ -695,7 +706,25 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
   const float2* dh2 = reinterpret_cast<const float2*>(cnn ? a.cnn.dXw : a.dh);
   __syncthreads();
   unsigned long long hit_bits[2] = {0ull, 0ull};   // (pass, word) pairs in which this lane found a cell: up to 16 passes
-  for (int base = 0; base < n; base += 512 * NB) {
+  int pbeg[kWordsPerWG], pend[kWordsPerWG];
+  int rounds = 0;
+  if (PM) {
+#pragma unroll
+    for (int j = 0; j < kWordsPerWG; ++j) {
+      const int w = bid + j * G;
+      pbeg[j] = pend[j] = 0;
+      if (w < a.n_words && !(a.skip_words & 4)) {
+        bool skip = a.train && word_scale(a, w) == 0.f;
+        if (a.hot_bits) skip = skip || ((a.hot_bits[w >> 5] >> (w & 31)) & 1u);
+        if (!skip) {
+          pbeg[j] = a.post_ptr[w];
+          pend[j] = a.post_ptr[w + 1];
+        }
+      }
+      rounds = max(rounds, (pend[j] - pbeg[j] + 511) >> 9);
+    }
+  }
+  for (int base = 0; base < (PM ? 0 : n); base += 512 * NB) {
     unsigned c[NB][kWordsPerWG];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -790,8 +819,80 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
     }
     drain();
   }
+  if (PM) {
+    int cnt = 0;
+    auto drain = [&]() {   // as above, mean-pool rows only
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      int curj = -1;
+      float2 run = make_float2(0.f, 0.f);
+      for (int e0 = 0; e0 < cnt; e0 += kRowsInFlight) {
+        int ent[kRowsInFlight];
+        float2 r[kRowsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u)
+          r[u] = (ent[u] && lane < d2 && !(a.skip_words & 2)) ? dh2[(int64_t)((ent[u] >> 8) & 0xFFFF) * d2 + lane] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+          if (ent[u]) {  // uniform across the wave
+            const int j = ent[u] >> 24;
+            if (j != curj) {
+              if (curj >= 0) {
+                float2* p = accw + curj * 64 + lane;
+                float2 t = *p;
+                t.x += run.x;
+                t.y += run.y;
+                *p = t;
+              }
+              curj = j;
+              run = make_float2(0.f, 0.f);
+            }
+            const float cf = (float)(ent[u] & 255);
+            run.x = fmaf(cf, r[u].x, run.x);
+            run.y = fmaf(cf, r[u].y, run.y);
+          }
+        }
+      }
+      if (curj >= 0) {
+        float2* p = accw + curj * 64 + lane;
+        float2 t = *p;
+        t.x += run.x;
+        t.y += run.y;
+        *p = t;
+      }
+      __builtin_amdgcn_wave_barrier();
+      cnt = 0;
+    };
+    for (int r = 0; r < rounds; ++r) {
+      int it[kWordsPerWG];
+      unsigned cb[kWordsPerWG];
+      int2 sv[kWordsPerWG];
+#pragma unroll
+      for (int j = 0; j < kWordsPerWG; ++j) {
+        const int e = pbeg[j] + 512 * r + 64 * wave + lane;
+        const bool ok = e < pend[j];
+        it[j] = ok ? a.post_item[e] : -1;
+        cb[j] = ok ? a.post_cnt[e] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kWordsPerWG; ++j) sv[j] = it[j] >= 0 ? a.slot_of[it[j]] : make_int2(0, 0);
+#pragma unroll
+      for (int j = 0; j < kWordsPerWG; ++j) {
+        const bool hit = it[j] >= 0 && sv[j].x == a.pm_stamp && sv[j].y < n;
+        const unsigned long long mask = __ballot(hit);
+        const int pc = __popcll(mask);
+        if (cnt + pc > kListCap) drain();
+        if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (sv[j].y << 8) | (int)cb[j];
+        if (mask && lane == 0) sHit[j] = 1;
+        cnt += pc;
+      }
+      drain();
+    }
+  }
   // cleared cells leave the matrix all-zero for the next step
-  for (int pass = 0; pass * 512 < n; ++pass) {
+  for (int pass = 0; pass * 512 < (PM ? 0 : n); ++pass) {
     const unsigned bits = (unsigned)(hit_bits[pass >> 3] >> ((pass & 7) << 3)) & 255u;
     const int slot = pass * 512 + 64 * wave + lane;
 #pragma unroll
@@ -1012,6 +1113,13 @@ TowerArgs base_args(const nncf_tower* t) {
   a.n_hot = hot_ok ? t->n_hot : 0;
   a.hot_part = t->hot_part;
   a.hot_cnt = t->hot_cnt;
+  a.post_ptr = t->post_ptr;
+  a.post_item = t->post_item;
+  a.post_cnt = t->post_cnt;
+  a.slot_of = t->slot_of;
+  a.hot_bits = a.n_hot > 0 ? t->hot_bits : nullptr;
+  a.pm = 0;
+  a.pm_stamp = 0;
   return a;
 }
 
@@ -1037,6 +1145,11 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     }
     if (int rc = cnn_forward(t, a, st)) return rc;
   } else {
+    // postings mode (TowerArgs::post_ptr): training blocks of more than 1,024 rows of the average-pooling tower
+    if (train && fill && t->post_ptr && m > 1024 && !a.pool_max) {
+      a.pm = 1;
+      a.pm_stamp = ++t->pm_stamp;
+    }
     ProfScope _ps("tower_pool_kernel", st);
     if (a.pool_max) hipLaunchKernelGGL(tower_pool_kernel<true>, dim3((unsigned)m), dim3(256), 0, st, a);
     else if (m > 1024) hipLaunchKernelGGL((tower_pool_kernel<false, true>), dim3((unsigned)m), dim3(256), 0, st, a);
@@ -1109,6 +1222,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     const int ncnn = a.cnn.F > 0 ? cnn_update_blocks(a.cnn.fl * a.wd * a.cnn.F) : 0;   // cnn_update_block workgroups
     if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else if (a.pool_max) hipLaunchKernelGGL((tower_word_kernel<false, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    else if (a.pm) hipLaunchKernelGGL((tower_word_kernel<false, false, 1, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
@@ -1342,6 +1456,7 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (t && t->hot) (void)hipFree(t->hot);
   if (t && t->hot_part) (void)hipFree(t->hot_part);
   if (t && t->hot_cnt) (void)hipFree(t->hot_cnt);
+  if (t && t->hot_bits) (void)hipFree(t->hot_bits);
   if (t && t->cid_reg) (void)hipFree(t->cid_reg);
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
@@ -1509,7 +1624,28 @@ int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n
       return fail(NNCF_ERR_NOMEM, "hot-word buffers allocation failed");
   }
   if (n > 0) NNCF_HIP_CHECK(hipMemcpy(t->hot, host_words, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+  {   // membership bitmap (postings mode: the pool kernel writes count cells for these words only)
+    const size_t nw = ((size_t)t->cfg.word_count + 31) / 32;
+    if (!t->hot_bits && hipMalloc(&t->hot_bits, sizeof(uint32_t) * nw) != hipSuccess) return fail(NNCF_ERR_NOMEM, "hot-word bitmap allocation failed");
+    std::vector<uint32_t> bits(nw, 0u);
+    for (int i = 0; i < n; ++i) bits[host_words[i] >> 5] |= 1u << (host_words[i] & 31);
+    NNCF_HIP_CHECK(hipMemcpy(t->hot_bits, bits.data(), sizeof(uint32_t) * nw, hipMemcpyHostToDevice));
+  }
   t->n_hot = n;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_post_ptr, const int32_t* d_post_item, const uint8_t* d_post_cnt,
+                            int64_t* d_slot_of) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE((d_post_ptr && d_post_item && d_post_cnt && d_slot_of) || (!d_post_ptr && !d_post_item && !d_post_cnt && !d_slot_of),
+               "postings: all four arrays or none");
+  NNCF_REQUIRE(!d_post_ptr || t->cfg.conv_filters == 0, "postings mode belongs to the mean-pool tower");
+  NNCF_REQUIRE(((uintptr_t)d_slot_of & 7) == 0, "slot_of must be 8-byte aligned");
+  t->post_ptr = d_post_ptr;
+  t->post_item = d_post_item;
+  t->post_cnt = d_post_cnt;
+  t->slot_of = reinterpret_cast<int2*>(d_slot_of);
   return NNCF_OK;
 }
 

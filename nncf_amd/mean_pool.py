@@ -145,6 +145,19 @@ class MeanPoolTower(object):
             self.hot_words = top
             if top.size:
                 _lib.check(self._L.nncf_tower_set_hot_words(self.handle, top.ctypes.data_as(_lib.c_i32p), int(top.size)))
+        if not self.conv and self.cap > 1024 and os.environ.get("NNCF_WORD_POSTINGS", "1") != "0":
+            # blocks of thousands of rows (`original`, the row-wise schemes): the word kernel walks the static transposed CSR
+            # (word -> items that hold it) instead of scanning a ~1 % full count matrix (nncf_tower_set_postings); speed only
+            order = np.argsort(words, kind="stable")                       # entries by word, items ascending inside a word
+            item_of = np.repeat(np.arange(self.item_count, dtype=np.int64), np.diff(ptr))
+            pptr = np.zeros(self.word_count + 1, dtype=np.int64)
+            np.cumsum(np.bincount(words, minlength=self.word_count), out=pptr[1:])
+            self.post_ptr = torch.as_tensor(pptr.astype(np.int32)).to(dev)
+            self.post_item = torch.as_tensor(item_of[order].astype(np.int32)).to(dev)
+            self.post_cnt = torch.as_tensor(np.ascontiguousarray(cnt[order]).astype(np.uint8)).to(dev)
+            self.slot_of = torch.zeros(self.item_count, dtype=torch.int64, device=dev)   # {stamp, block row} per item
+            _lib.check(self._L.nncf_tower_set_postings(self.handle, self.post_ptr.data_ptr(), self.post_item.data_ptr(),
+                                                       self.post_cnt.data_ptr(), self.slot_of.data_ptr()))
         if self.dropout > 0 or cdrop > 0:
             self.set_dropout(self.dropout, int(seed) + 29)
 

@@ -202,9 +202,12 @@ def test_epoch_runner_equals_step_by_step(text_data):
         np.testing.assert_array_equal(h0.engine.U.cpu().numpy(), h1.engine.U.cpu().numpy())
 
 
-def test_large_block_original_matches_oracle():
+@pytest.mark.parametrize("postings", ["1", "0"])
+def test_large_block_original_matches_oracle(monkeypatch, postings):
     """More than 1024 unique items in one batch: several K-parts of the weight-gradient tiles,
-    more than 64 statistics blocks."""
+    more than 64 statistics blocks.  postings: the word-table backward walks the static word -> items lists
+    (nncf_tower_set_postings; default for such blocks) / scans the count matrix as the small blocks do."""
+    monkeypatch.setenv("NNCF_WORD_POSTINGS", postings)
     data = synthetic.make_citeulike_like(users=400, items=3000, train_links=9000, seed=4, content_len=20, vocab=150)
     conf = _conf("skip-gram", "original", b=512, k=3, d=32, lr=0.1)
     helper = get_data(dict(data), conf, rand_seed=5)
@@ -217,6 +220,7 @@ def test_large_block_original_matches_oracle():
         negs = rs.randint(0, 3000, 512 * 3)
         u, c, y = so.assemble_original(bt, negs, "skip-gram")
         assert len(np.unique(c)) > 1024
+        assert (getattr(head.core.tower, "post_ptr", None) is not None) == (postings == "1")
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
         assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
@@ -1034,3 +1038,39 @@ def test_pooling_max_and_use_content_id_match_oracle(text_data, pooling, content
     if conf.emb_normalization:
         E = E / np.sqrt(np.maximum((E * E).sum(-1, keepdims=True), 1e-12))
     np.testing.assert_allclose(emb, E, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "sparse_adam"])
+@pytest.mark.parametrize("hot_words", ["1", "0"])
+def test_postings_mode_equals_the_count_matrix_scan(monkeypatch, opt, hot_words):
+    """train_scheme = original over a block of > 1,024 rows with word-row dropout: the postings walk (default) against the
+    dense scan of the same steps -- loss bitwise (the forward is the same code), parameters to summation order; with and
+    without hot words (the pad id's postings list is every item), SGD and both Adams; a SMALL-block step (dense scan) on the
+    same towers in between: the count matrix must still be all-zero then, or the later steps' word rows differ."""
+    monkeypatch.setenv("NNCF_HOT_WORDS", hot_words)
+    data = synthetic.make_citeulike_like(users=400, items=3000, train_links=9000, seed=4, content_len=24, vocab=300)
+    heads = []
+    for postings in ("1", "0"):
+        monkeypatch.setenv("NNCF_WORD_POSTINGS", postings)
+        conf = _conf("skip-gram", "original", b=512, k=3, d=32, lr=0.01 if opt != "sgd" else 0.1)
+        conf.optimizer = opt
+        conf.word_emb_dropout_rate = 0.3
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)
+        heads.append(md)
+    assert getattr(heads[0]["model"].core.tower, "post_ptr", None) is not None
+    assert getattr(heads[1]["model"].core.tower, "post_ptr", None) is None
+    rs = np.random.RandomState(3)
+    rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
+    for step in range(4):
+        bt = data["train"][rs.choice(len(data["train"]), 512, replace=False)]
+        u, c, y = so.assemble_original(bt, rs.randint(0, 3000, 512 * 3), "skip-gram")
+        l = [md["model"].train_on_batch([u, c], [y]) for md in heads]
+        assert abs(l[0] - l[1]) <= (0 if step == 0 else 1e-6) * max(1, abs(l[1])), (step, l)   # step 0: the same forward, bitwise
+        for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+            if opt != "sgd" and name in ("bd", "rm"):
+                continue   # dL/dbd = sum dz is exactly 0 behind a BatchNorm: Adam turns its rounding noise into +-lr steps
+            a0, a1 = (getattr(md["model"].core.tower, name).cpu().numpy() for md in heads)
+            np.testing.assert_allclose(a0, a1, rtol=rt, atol=at, err_msg="%s step %d" % (name, step))
+        if step == 1:   # a small block in between (neg_shared head of the same model: 512 rows, dense scan)
+            l2 = [md["model_neg_shared"].train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]]) for md in heads]
+            assert abs(l2[0] - l2[1]) <= 1e-5 * max(1, abs(l2[1])), l2
