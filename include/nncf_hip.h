@@ -348,13 +348,19 @@ int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling);
  * row per (word, item) cell; same sums up to fp32 association.  host_words: host array. */
 int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n);
 /* Speed only (mean-pool tower, average pooling, training blocks of more than 1,024 rows -- train_scheme = original and the
- * row-wise schemes; no reference counterpart): the transposed item CSR.  d_post_ptr [word_count + 1], d_post_item / d_post_cnt
- * [number of (item, word) pairs]: for every word the items that hold it (ascending) with the word's count in the item;
- * d_slot_of [item_count] 64-bit words, zero-initialised, owned by the caller and written by the tower ({forward stamp, block
- * row} of every item of the current block).  The word-table backward then walks a word's postings and keeps the items of the
- * block instead of scanning a (word_count x block rows) count matrix that is ~1 % full.  Device arrays, borrowed; all NULL
- * switches the mode off.  Same sums up to fp32 association (items ascending instead of block rows ascending). */
-int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_post_ptr, const int32_t* d_post_item, const uint8_t* d_post_cnt,
+ * row-wise schemes; no reference counterpart): the transposed item CSR and a static schedule over it.
+ *   d_postings [number of (item, word) pairs]: for every word the items that hold it (ascending), each entry = item id |
+ *     (the word's count in the item) << 24 (item_count <= 2^24);
+ *   d_units [n_workgroups][8][4] int32: per workgroup of the word-table backward 8 units {word (-1: empty slot), first posting,
+ *     end, number of units of this word if this is its first unit else 0}; all units of a word sit in ONE workgroup, in
+ *     order, every word of the table appears exactly once as a first unit (also words without postings: the optimiser visits
+ *     them), a unit should hold <= 512 postings (more: the workgroup walks them in rounds of 512);
+ *   d_slot_of [item_count] 64-bit words, zero-initialised, owned by the caller and written by the tower ({forward stamp,
+ *     block row} of every item of the current block).
+ * The word-table backward then walks its units' postings and keeps the items of the block instead of scanning a
+ * (word_count x block rows) count matrix that is ~1 % full.  Device arrays, borrowed; all NULL (n_workgroups 0) switches the
+ * mode off.  Same sums up to fp32 association (items ascending instead of block rows ascending). */
+int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_workgroups, const uint32_t* d_postings,
                             int64_t* d_slot_of);
 /* conf.use_content_id (mean_pool.py:102-108): the tower's output becomes relu(BN(Dense(pool))) + Emb_Cid[item id] with
  * d_id_table [item_count][item_dim] (borrowed; NULL switches it off) and activity_l2(v_reg) on the Embedding's output

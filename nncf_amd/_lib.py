@@ -133,7 +133,7 @@ def _declare(lib):
         "nncf_tower_set_dropout": [vp, f32, u64],
         "nncf_tower_set_pooling": [vp, i32],
         "nncf_tower_set_hot_words": [vp, c_i32p, i32],
-        "nncf_tower_set_postings": [vp, vp, vp, vp, vp],
+        "nncf_tower_set_postings": [vp, vp, i32, vp, vp],
         "nncf_tower_set_content_id": [vp, vp, f32, vp, vp, vp],
         "nncf_tower_sync_params": [vp, vp],
         "nncf_tower_conv_mask": [vp, u64, i64, vp, vp],

@@ -111,15 +111,17 @@ struct TowerArgs {
   // Postings mode (mean-pool tower, average pooling, blocks of more than 1,024 rows: `original` and the row-wise schemes).
   // The dense count matrix of such a block is ~1 % full and tower_word_kernel was bound by the INSTRUCTIONS of scanning it
   // (8,001 words x 2,700 rows).  The corpus is static, so the transposed CSR -- per word the items that hold it, with the
-  // count -- is built once (nncf_tower_set_postings); a step only says where each of its items sits: the pool kernel
-  // writes slot_of[item] = {stamp of this forward, block row}.  The word kernel then walks the word's postings (6 % of the
-  // dense cells for a 2,700-row block) and keeps the entries whose item carries the current stamp.  No count cell is
-  // written or cleared for any word but the hot ones (whose cells tower_bwd_kernel's role A consumes).
-  const int32_t* post_ptr;   // [n_words + 1]
-  const int32_t* post_item;  // [nnz] ascending inside a word
-  const uint8_t* post_cnt;   // [nnz]
+  // count -- is built once (nncf_tower_set_postings), and with it a static SCHEDULE: every workgroup of the word kernel owns
+  // 8 units, a unit = up to 512 consecutive postings of one word, all units of a word in one workgroup, units per workgroup
+  // capped by their postings -- every workgroup walks its postings in ONE round of loads and gathers about the same number of
+  // rows.  A step only says where each of its items sits: the pool kernel writes slot_of[item] = {stamp of this forward,
+  // block row}; the word kernel keeps the postings whose item carries the current stamp.  No count cell is written or
+  // cleared for any word but the hot ones (whose cells tower_bwd_kernel's role A consumes).
+  const int4* pm_units;      // [pm_nwg][8] {word (-1: empty), first posting, end, units of this word if this is its first unit else 0}
+  const uint32_t* post_item; // [nnz] item | count << 24, items ascending inside a word
   int2* slot_of;             // [item_count] {stamp, block row}; zero-initialised, stamps start at 1
   const uint32_t* hot_bits;  // [ceil(n_words / 32)] membership of the hot list (the cells the pool kernel still writes)
+  int pm_nwg;                // workgroups of the schedule
   int pm, pm_stamp;          // this forward / backward runs in postings mode; its stamp
   CnnArgs cnn;
 };
@@ -339,10 +341,10 @@ struct nncf_tower {
   int n_hot = 0;
   float* hot_part = nullptr;     // own allocation
   int32_t* hot_cnt = nullptr;
-  // postings mode (nncf_tower_set_postings; TowerArgs::post_ptr): caller-owned arrays, own hot bitmap
-  const int32_t* post_ptr = nullptr;
-  const int32_t* post_item = nullptr;
-  const uint8_t* post_cnt = nullptr;
+  // postings mode (nncf_tower_set_postings; TowerArgs::pm_units): caller-owned arrays, own hot bitmap
+  const int4* pm_units = nullptr;
+  int pm_nwg = 0;
+  const uint32_t* post_item = nullptr;
   int2* slot_of = nullptr;
   uint32_t* hot_bits = nullptr;  // own allocation
   int pm_stamp = 0;

@@ -625,7 +625,7 @@ constexpr int kRowsInFlight = 8;
 // a second round.  <= 64 VGPRs (8 waves per SIMD) and <= 40 KB: four fit, 1,024 at once.  (Measured: no change in the step
 // time -- the kernel is bound by the instructions of its count-cell scan, 8,001 words x 2,700 rows / 64 ballot rounds
 // that are empty 3 times out of 4, not by residency.)
-// PM: postings mode (TowerArgs::post_ptr) -- the scan of the count matrix is replaced by a walk over the 8 words' postings:
+// PM: postings mode (TowerArgs::pm_units) -- the scan of the count matrix is replaced by a walk over the 8 words' postings:
 // per round every wave takes 64 entries of each word (8 item loads, then 8 slot_of loads in flight), keeps the entries whose
 // item carries this forward's stamp and lists them exactly as the scan lists non-zero cells.  Entries of a word are summed in
 // postings order (ascending item id) per wave, the waves' stripes in wave order: fixed order, no atomics.  Hot words are skipped
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
   __shared__ int sHit[kWordsPerWG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = (a.n_words + kWordsPerWG - 1) / kWordsPerWG;
+  const int G = PM ? a.pm_nwg : (a.n_words + kWordsPerWG - 1) / kWordsPerWG;
   // CNN tower: the first workgroups of the grid sum the dWk partials and update the conv weights, conv
   // bias and BN1 scale / shift (parameters nobody else in this launch touches).  First, because their
   // chain of partial loads is the longest in the launch: they run under the word workgroups.
@@ -645,9 +645,14 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
     cnn_update_block(a, (int)blockIdx.x, reinterpret_cast<float*>(sAccW));
     return;
   }
-  const int bid = (int)blockIdx.x - ncnn;
-  if (bid >= G) {
-    const int el = (bid - G) * 512 + tid, nel = a.hd * a.d;
+  // postings mode: the parameter-update workgroups come FIRST -- the schedule may exceed what the device holds at once
+  // (1,024 workgroups of this size) by a few; behind short workgroups the late ones start after 2.5 us instead of after a
+  // whole word workgroup, and they are the rarest words' (the schedule is in word-id order: frequent words first)
+  const int nupd_pm = PM ? (int)gridDim.x - G : 0;
+  const int upd = PM ? ((int)blockIdx.x < nupd_pm ? (int)blockIdx.x : -1) : ((int)blockIdx.x - ncnn >= G ? (int)blockIdx.x - ncnn - G : -1);
+  const int bid = PM ? (int)blockIdx.x - nupd_pm : (int)blockIdx.x - ncnn;
+  if (upd >= 0) {
+    const int el = upd * 512 + tid, nel = a.hd * a.d;
     if (el < nel) {
       float g = 0.f;
       for (int p0 = 0; p0 < ks; p0 += 8) {   // K-part partials in part order, eight loads in flight (`original`: 22 parts)
@@ -660,7 +665,7 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
       if (a.gexp) a.gexp[(size_t)a.n_words * a.wd + el] = g;
       else a.Wd[el] = a.opt ? adam1(g, a.mD + el, a.vD + el, a.Wd[el], a) : a.Wd[el] - a.lr * g;
     }
-    if (bid == G && tid < a.d) {
+    if (upd == 0 && tid < a.d) {
       float gb = 0.f;
       for (int p0 = 0; p0 < ks; p0 += 8) {
         float u[8];
@@ -691,7 +696,14 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
   }
   if (a.skip_words & 1) return;
   const int n = valid_rows(a), d2 = a.wd >> 1;
-  const int my_w = bid + wave * G;  // the word this wave finishes
+  // the word this wave finishes.  Postings mode: the word of unit `wave` if that is the word's first unit (its my_nu units are
+  // stripes wave .. wave + my_nu - 1)
+  int my_w = bid + wave * G, my_nu = 1;
+  if (PM) {
+    const int4 u = a.pm_units[(int64_t)bid * kWordsPerWG + wave];
+    my_nu = u.w;
+    my_w = (u.x >= 0 && u.w > 0) ? u.x : a.n_words;
+  }
   float2 wold = make_float2(0.f, 0.f);
   if (my_w < a.n_words && lane < d2) wold = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
   if (tid < kWordsPerWG) sHit[tid] = 0;
@@ -711,14 +723,15 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
   if (PM) {
 #pragma unroll
     for (int j = 0; j < kWordsPerWG; ++j) {
-      const int w = bid + j * G;
+      const int4 u = a.pm_units[(int64_t)bid * kWordsPerWG + j];
+      const int w = u.x;
       pbeg[j] = pend[j] = 0;
-      if (w < a.n_words && !(a.skip_words & 4)) {
+      if (w >= 0 && !(a.skip_words & 4)) {
         bool skip = a.train && word_scale(a, w) == 0.f;
         if (a.hot_bits) skip = skip || ((a.hot_bits[w >> 5] >> (w & 31)) & 1u);
         if (!skip) {
-          pbeg[j] = a.post_ptr[w];
-          pend[j] = a.post_ptr[w + 1];
+          pbeg[j] = u.y;
+          pend[j] = u.z;
         }
       }
       rounds = max(rounds, (pend[j] - pbeg[j] + 511) >> 9);
@@ -873,8 +886,9 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
       for (int j = 0; j < kWordsPerWG; ++j) {
         const int e = pbeg[j] + 512 * r + 64 * wave + lane;
         const bool ok = e < pend[j];
-        it[j] = ok ? a.post_item[e] : -1;
-        cb[j] = ok ? a.post_cnt[e] : 0u;
+        const unsigned pk = ok ? a.post_item[e] : 0xFFFFFFFFu;   // item | count << 24
+        it[j] = ok ? (int)(pk & 0xFFFFFFu) : -1;
+        cb[j] = ok ? pk >> 24 : 0u;
       }
 #pragma unroll
       for (int j = 0; j < kWordsPerWG; ++j) sv[j] = it[j] >= 0 ? a.slot_of[it[j]] : make_int2(0, 0);
@@ -911,15 +925,28 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
       hot_cells = wave_sum_i(hot_cells);
     }
   }
-  if (a.gexp && my_w < a.n_words && lane < d2 && !sHit[wave] && hot_cells == 0)
+  int my_hit = sHit[wave];
+  if (PM)
+    for (int jj = 1; jj < my_nu && wave + jj < kWordsPerWG; ++jj) my_hit |= sHit[wave + jj];
+  if (a.gexp && my_w < a.n_words && lane < d2 && !my_hit && hot_cells == 0)
     reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(0.f, 0.f);
-  if (my_w < a.n_words && (sHit[wave] || hot_cells > 0) && lane < d2) {
+  if (my_w < a.n_words && (my_hit || hot_cells > 0) && lane < d2) {
     float2 sum = make_float2(0.f, 0.f);
+    if (!PM) {
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane];
-      sum.x += t.x;
-      sum.y += t.y;
+      for (int v = 0; v < 8; ++v) {
+        const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane];
+        sum.x += t.x;
+        sum.y += t.y;
+      }
+    } else {   // the word's units in order, the eight waves' shares of a unit in wave order
+      for (int jj = 0; jj < my_nu && wave + jj < kWordsPerWG; ++jj)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const float2 t = sAccW[(v * kWordsPerWG + wave + jj) * 64 + lane];
+          sum.x += t.x;
+          sum.y += t.y;
+        }
     }
     if (hot_cells > 0 && !(a.skip_words & 8)) {   // partials in workgroup order; written on other compute units: every load is a trip to memory, 16 in flight
       const int np = (n + 15) >> 4;
@@ -1113,9 +1140,9 @@ TowerArgs base_args(const nncf_tower* t) {
   a.n_hot = hot_ok ? t->n_hot : 0;
   a.hot_part = t->hot_part;
   a.hot_cnt = t->hot_cnt;
-  a.post_ptr = t->post_ptr;
+  a.pm_units = t->pm_units;
+  a.pm_nwg = t->pm_nwg;
   a.post_item = t->post_item;
-  a.post_cnt = t->post_cnt;
   a.slot_of = t->slot_of;
   a.hot_bits = a.n_hot > 0 ? t->hot_bits : nullptr;
   a.pm = 0;
@@ -1145,8 +1172,8 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     }
     if (int rc = cnn_forward(t, a, st)) return rc;
   } else {
-    // postings mode (TowerArgs::post_ptr): training blocks of more than 1,024 rows of the average-pooling tower
-    if (train && fill && t->post_ptr && m > 1024 && !a.pool_max) {
+    // postings mode (TowerArgs::pm_units): training blocks of more than 1,024 rows of the average-pooling tower
+    if (train && fill && t->pm_units && m > 1024 && !a.pool_max) {
       a.pm = 1;
       a.pm_stamp = ++t->pm_stamp;
     }
@@ -1222,7 +1249,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     const int ncnn = a.cnn.F > 0 ? cnn_update_blocks(a.cnn.fl * a.wd * a.cnn.F) : 0;   // cnn_update_block workgroups
     if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else if (a.pool_max) hipLaunchKernelGGL((tower_word_kernel<false, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
-    else if (a.pm) hipLaunchKernelGGL((tower_word_kernel<false, false, 1, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
+    else if (a.pm) hipLaunchKernelGGL((tower_word_kernel<false, false, 1, true>), dim3(a.pm_nwg + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else hipLaunchKernelGGL((tower_word_kernel<false>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
   }
   NNCF_HIP_CHECK(hipGetLastError());
@@ -1635,16 +1662,17 @@ int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n
   return NNCF_OK;
 }
 
-int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_post_ptr, const int32_t* d_post_item, const uint8_t* d_post_cnt,
-                            int64_t* d_slot_of) {
+int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_workgroups, const uint32_t* d_postings, int64_t* d_slot_of) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
-  NNCF_REQUIRE((d_post_ptr && d_post_item && d_post_cnt && d_slot_of) || (!d_post_ptr && !d_post_item && !d_post_cnt && !d_slot_of),
-               "postings: all four arrays or none");
-  NNCF_REQUIRE(!d_post_ptr || t->cfg.conv_filters == 0, "postings mode belongs to the mean-pool tower");
-  NNCF_REQUIRE(((uintptr_t)d_slot_of & 7) == 0, "slot_of must be 8-byte aligned");
-  t->post_ptr = d_post_ptr;
-  t->post_item = d_post_item;
-  t->post_cnt = d_post_cnt;
+  NNCF_REQUIRE((d_units && d_postings && d_slot_of && n_workgroups > 0) || (!d_units && !d_postings && !d_slot_of),
+               "postings: the schedule, the postings and slot_of, or none of them");
+  NNCF_REQUIRE(!d_units || t->cfg.conv_filters == 0, "postings mode belongs to the mean-pool tower");
+  NNCF_REQUIRE(!d_units || t->cfg.item_count <= (1 << 24), "postings pack the item id into 24 bits: item_count = %lld is too large",
+               (long long)t->cfg.item_count);
+  NNCF_REQUIRE(((uintptr_t)d_slot_of & 7) == 0 && ((uintptr_t)d_units & 15) == 0, "slot_of must be 8-byte, the schedule 16-byte aligned");
+  t->pm_units = reinterpret_cast<const int4*>(d_units);
+  t->pm_nwg = d_units ? n_workgroups : 0;
+  t->post_item = d_postings;
   t->slot_of = reinterpret_cast<int2*>(d_slot_of);
   return NNCF_OK;
 }

@@ -19,6 +19,42 @@ import torch
 from . import _lib
 
 
+def postings_schedule(pptr, hot_words, unit=512, per_wg=8, max_postings=2048):
+    """Static schedule of the word-table backward over the transposed item CSR (nncf_tower_set_postings): every word is cut
+    into units of <= `unit` consecutive postings (a word that would need more than `per_wg` of them: `per_wg` equal units),
+    all units of a word go to ONE workgroup, a workgroup takes words in id order while it has unit slots left and <=
+    `max_postings` postings (one word alone may exceed that).  Hot words keep a slot (the optimiser visits every word) with
+    an empty range: their gradient rows come from the Dense backward.  Returns ([n_wg * per_wg][4] int32, n_wg)."""
+    hot = set(int(w) for w in hot_words)
+    rows, cur, cur_post = [], [], 0
+
+    def flush():
+        while len(cur) < per_wg:
+            cur.append((-1, 0, 0, 0))
+        rows.extend(cur)
+        del cur[:]
+
+    for w in range(len(pptr) - 1):
+        b, e = int(pptr[w]), int(pptr[w + 1])
+        if w in hot:
+            e = b
+        df = e - b
+        k = max(1, -(-df // unit))
+        step = unit
+        if k > per_wg:
+            k, step = per_wg, -(-df // per_wg)
+        if cur and (len(cur) + k > per_wg or cur_post + df > max_postings):
+            flush()
+            cur_post = 0
+        for i in range(k):
+            cur.append((w, min(b + i * step, e), min(b + (i + 1) * step, e), k if i == 0 else 0))
+        cur_post += df
+    if cur:
+        flush()
+    units = np.asarray(rows, dtype=np.int32).reshape(-1, 4)
+    return np.ascontiguousarray(units), len(rows) // per_wg
+
+
 def build_item_csr(C):
     """Static per-item bag of words of the content matrix C (items x L):
     ptr[items+1], word[nnz] (ascending inside an item), cnt[nnz] (uint8, saturating at 255)."""
@@ -145,19 +181,20 @@ class MeanPoolTower(object):
             self.hot_words = top
             if top.size:
                 _lib.check(self._L.nncf_tower_set_hot_words(self.handle, top.ctypes.data_as(_lib.c_i32p), int(top.size)))
-        if not self.conv and self.cap > 1024 and os.environ.get("NNCF_WORD_POSTINGS", "1") != "0":
+        if not self.conv and self.cap > 1024 and self.item_count <= (1 << 24) and os.environ.get("NNCF_WORD_POSTINGS", "1") != "0":
             # blocks of thousands of rows (`original`, the row-wise schemes): the word kernel walks the static transposed CSR
             # (word -> items that hold it) instead of scanning a ~1 % full count matrix (nncf_tower_set_postings); speed only
             order = np.argsort(words, kind="stable")                       # entries by word, items ascending inside a word
             item_of = np.repeat(np.arange(self.item_count, dtype=np.int64), np.diff(ptr))
             pptr = np.zeros(self.word_count + 1, dtype=np.int64)
             np.cumsum(np.bincount(words, minlength=self.word_count), out=pptr[1:])
-            self.post_ptr = torch.as_tensor(pptr.astype(np.int32)).to(dev)
-            self.post_item = torch.as_tensor(item_of[order].astype(np.int32)).to(dev)
-            self.post_cnt = torch.as_tensor(np.ascontiguousarray(cnt[order]).astype(np.uint8)).to(dev)
+            packed = (item_of[order] | (cnt[order].astype(np.int64) << 24)).astype(np.uint32)   # item | count << 24
+            units, n_wg = postings_schedule(pptr, getattr(self, "hot_words", ()))
+            self.post_units = torch.as_tensor(units).to(dev)
+            self.post_item = torch.as_tensor(packed.view(np.int32)).to(dev)
             self.slot_of = torch.zeros(self.item_count, dtype=torch.int64, device=dev)   # {stamp, block row} per item
-            _lib.check(self._L.nncf_tower_set_postings(self.handle, self.post_ptr.data_ptr(), self.post_item.data_ptr(),
-                                                       self.post_cnt.data_ptr(), self.slot_of.data_ptr()))
+            _lib.check(self._L.nncf_tower_set_postings(self.handle, self.post_units.data_ptr(), n_wg, self.post_item.data_ptr(),
+                                                       self.slot_of.data_ptr()))
         if self.dropout > 0 or cdrop > 0:
             self.set_dropout(self.dropout, int(seed) + 29)
 

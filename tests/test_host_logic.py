@@ -203,3 +203,37 @@ def test_cnn_front_spec_from_the_reference_presets():
         c = get_conf("synthetic_citeulike", "best", dict({"reset_after_getconf": True}, **bad), model_choice="cnn_embedding")
         with pytest.raises(NotImplementedError):
             _conv_spec(c)
+
+
+def test_postings_schedule_invariants():
+    """nncf_amd.mean_pool.postings_schedule (the static schedule behind nncf_tower_set_postings): every word exactly once as
+    a first unit, a word's units contiguous in ONE workgroup and covering its postings in order, hot words with an empty
+    range, units of at most 512 postings unless the word needs more than 8 of them, at most 8 units per workgroup."""
+    from nncf_amd.mean_pool import postings_schedule
+    rs = np.random.RandomState(0)
+    V = 700
+    df = np.minimum((3000 * rs.power(0.2, V)).astype(np.int64), 3000)
+    df[0], df[5], df[9] = 9000, 4100, 0            # needs > 8 units / exactly 8 + 1 / no postings at all
+    pptr = np.concatenate([[0], np.cumsum(df)])
+    for hot in ((), (0, 3)):
+        units, n_wg = postings_schedule(pptr, hot)
+        assert units.dtype == np.int32 and units.shape == (n_wg * 8, 4)
+        firsts = units[units[:, 3] > 0]
+        assert sorted(firsts[:, 0].tolist()) == list(range(V))
+        for g in range(n_wg):
+            blk = units[g * 8:(g + 1) * 8]
+            j = 0
+            while j < 8:
+                w, b, e, k = (int(v) for v in blk[j])
+                if w < 0:
+                    assert (b, e, k) == (0, 0, 0)
+                    j += 1
+                    continue
+                assert k > 0 and j + k <= 8 and b == pptr[w]
+                end = pptr[w] if w in hot else pptr[w + 1]
+                assert int(blk[j + k - 1][2]) == end
+                for i in range(1, k):
+                    assert int(blk[j + i][0]) == w and int(blk[j + i][3]) == 0 and int(blk[j + i][1]) == int(blk[j + i - 1][2])
+                lens = blk[j:j + k, 2] - blk[j:j + k, 1]
+                assert lens.max() <= 512 or k == 8
+                j += k

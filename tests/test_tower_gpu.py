@@ -220,7 +220,7 @@ def test_large_block_original_matches_oracle(monkeypatch, postings):
         negs = rs.randint(0, 3000, 512 * 3)
         u, c, y = so.assemble_original(bt, negs, "skip-gram")
         assert len(np.unique(c)) > 1024
-        assert (getattr(head.core.tower, "post_ptr", None) is not None) == (postings == "1")
+        assert (getattr(head.core.tower, "post_units", None) is not None) == (postings == "1")
         want = orc.step_original(u, c, y)
         got = head.train_on_batch([u, c], [y])
         assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
@@ -1057,8 +1057,8 @@ def test_postings_mode_equals_the_count_matrix_scan(monkeypatch, opt, hot_words)
         conf.word_emb_dropout_rate = 0.3
         md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)
         heads.append(md)
-    assert getattr(heads[0]["model"].core.tower, "post_ptr", None) is not None
-    assert getattr(heads[1]["model"].core.tower, "post_ptr", None) is None
+    assert getattr(heads[0]["model"].core.tower, "post_units", None) is not None
+    assert getattr(heads[1]["model"].core.tower, "post_units", None) is None
     rs = np.random.RandomState(3)
     rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
     for step in range(4):
