@@ -538,7 +538,7 @@ int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const in
  *          one-device step on the same batch, models/train_neg_shared.py:46-51): rank g holds rows g, g + n_ranks, ... of
  *          the b x b score matrix; the model's user table is a landing buffer too (batch_size_p / n_ranks rows); the
  *          item rows of all b columns and the user rows of the local positions are fetched, both gradients go back to
- *          the owners, which add the ranks' partial rows in rank order.  Pointwise losses, sparse SGD.
+ *          the owners, which add the ranks' partial rows in rank order.  Pointwise losses.
  * Ids do not depend on the training state, so for up to 64 steps at a time
  *   nncf_shard_plan        routes and duplicate plans of the chunk, batched: landing slot of every position (= rank of its
  *                          id among the step's unique ids, ascending), the COMPACT request lists req_out (per owner, per
@@ -555,8 +555,11 @@ int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const in
  *   nncf_shard_step        the local step on the landed rows: loss (strong: this rank's share -- the step's loss is the
  *                          sum over ranks), gradients exported per landing slot to g_out (weak: user rows stepped in place)
  *   (host: all-to-all g_out -> g_in)
- *   nncf_shard_apply       table[id] -= lr * (gradient rows of id summed in rank order), then gathers the rows of
- *                          step i + 1 (after the update: synchronous SGD).
+ *   nncf_shard_apply       the owners' step on (gradient rows of id summed in rank order): table[id] -= lr * sum (sparse
+ *                          SGD), or the model's Adam (nncf_model_set_optimizer: lazy-sparse on the touched rows / Keras
+ *                          dense with the zero-gradient step on every other row of the shard) with the shard's own state
+ *                          (nncf_shard_set_optimizer); advances the optimiser's step counter; then gathers the rows of
+ *                          step i + 1 (after the update: synchronous steps).
  * With n_ranks == 1 both ends of every exchange are the same memory: nothing is copied.
  * nncf_shard_counts / nncf_shard_buffers return the device pointers the host hands to its collectives (exchange 0:
  * items, 1: users in the strong form). */
@@ -565,6 +568,11 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
                       float* d_user_shard, int32_t user_stride, int32_t user_shard, int32_t user_offset, int32_t n_ranks,
                       int32_t rank, int device, nncf_shard** out);
 int nncf_shard_destroy(nncf_shard* h);
+/* Adam on the sharded paths: moment arrays of this rank's shard of `exchange` (0 items, 1 users of the strong form), shaped
+ * and strided like the shard; d_stamp [shard rows] int32 zeros for Keras (dense) Adam, NULL for the lazy-sparse form.
+ * Required before the first step when the model was given an Adam optimiser (the weak form's local user rows use the
+ * model's own state).  The as-written duplicate rule of the sparse Adam is refused at nncf_shard_create. */
+int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float* d_v, int32_t* d_stamp);
 int nncf_shard_counts(nncf_shard* h, int32_t** cnt_out, int32_t** cnt_in, int32_t* n_exchanges);
 int nncf_shard_buffers(nncf_shard* h, int32_t exchange, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in,
                        float** g_out, float** g_in, int32_t* ids_per_step);

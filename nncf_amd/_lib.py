@@ -125,6 +125,7 @@ def _declare(lib):
         "nncf_shard_plan_owner": [vp, i64, vp, vp],
         "nncf_shard_step": [vp, i64, vp, vp, vp],
         "nncf_shard_apply": [vp, i64, i64, f32, vp],
+        "nncf_shard_set_optimizer": [vp, i32, vp, vp, vp],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
         "nncf_scatter_merge": [vp, i32, i32, vp, i32, i32, i32, vp, f32, vp],
         "nncf_tower_create": [ctypes.POINTER(TowerCfg), ctypes.POINTER(TowerParams), i32, ctypes.POINTER(vp)],

@@ -209,6 +209,7 @@ struct Exch {
   int32_t* step_off = nullptr;   // [kPlanChunk][ranks + 1]   owner side: the rows of step s for rank r start here
   int32_t *req_out = nullptr, *req_in = nullptr;
   float *rows_out = nullptr, *land = nullptr, *g_out = nullptr, *g_in = nullptr;
+  nncf::AdamTable ad;            // Adam state of this rank's shard (nncf_shard_set_optimizer): moments [shard_rows][stride], stamps
 };
 
 struct nncf_shard {
@@ -324,11 +325,14 @@ __global__ void __launch_bounds__(256) gather_step_kernel(const float* __restric
 // gradient rows of an id are at most one per rank: the group of (rank r, k) looks the id up in the other ranks' blocks
 // by binary search -- a lower rank that asked for it too owns the sum; otherwise this group adds the higher ranks' rows
 // in rank order (fixed order, no atomics) and steps the row.
-__global__ void __launch_bounds__(256) merge_step_kernel(float* __restrict__ table, int stride, int d, float lr, int id_offset,
+// `a`: the step's optimiser constants (StepArgs::opt, lr / lr_t, betas, step_no; stride = the shard's row pitch); `ad`: the
+// shard's Adam state (unused for SGD).
+__global__ void __launch_bounds__(256) merge_step_kernel(StepArgs a, AdamTable ad, float* __restrict__ table, int id_offset,
                                                          const float* __restrict__ rows, const int32_t* __restrict__ req_in,
                                                          const int32_t* __restrict__ recv_off, const int32_t* __restrict__ step_off,
                                                          int ranks, int s) {
   const int64_t t = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int d = a.d, stride = a.stride;
   const int q = threadIdx.x & 15, d4 = d >> 2;
   int r, k;
   if (!owner_row(step_off, ranks, s, t, r, k)) return;
@@ -352,7 +356,7 @@ __global__ void __launch_bounds__(256) merge_step_kernel(float* __restrict__ tab
     if (p >= 0) acc = row_add(acc, row_load(rows, (int64_t)so[rr] + p, d, d4, q));
   }
   const Row raw = row_load(table, id - id_offset, stride, d4, q);
-  row_store(table, id - id_offset, stride, d4, q, row_fma(-lr, acc, raw));
+  apply_update(a, ad, table, id - id_offset, raw, acc, d4, q);   // sparse SGD, or Adam on the summed gradient (step.h)
 }
 
 }  // namespace nncf
@@ -403,7 +407,8 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   const bool strong = d_user_shard != nullptr;
   NNCF_REQUIRE(b % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
   NNCF_REQUIRE(m->cfg.item_count >= b, "the model's item table is the landing buffer: it must hold batch_size_p rows");
-  NNCF_REQUIRE(m->opt == 0, "the sharded trainers step the owners' rows with sparse SGD (scatter-merge): create the model without an Adam optimiser");
+  NNCF_REQUIRE(!(m->opt == 1 && m->dup_as_written), "the sharded trainers sum an id's gradient rows before the step: the as-written "
+               "sparse Adam (last occurrence wins) has no meaning across ranks");
   if (strong) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
@@ -432,6 +437,14 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   real.base = static_cast<char*>(h->arena);
   carve_shard(h, real);
   *out = h;
+  return NNCF_OK;
+}
+
+int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float* d_v, int32_t* d_stamp) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
+  NNCF_REQUIRE((d_m && d_v) || (!d_m && !d_v && !d_stamp), "both moment arrays or none");
+  h->x[exchange].ad = AdamTable{d_m, d_v, d_stamp};
   return NNCF_OK;
 }
 
@@ -546,7 +559,15 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
     uid = h->x[1].slot + index * h->x[1].n;
   }
   NNCF_REQUIRE(uid != nullptr, "NULL argument");
+  if (m->opt) {
+    NNCF_REQUIRE(h->x[0].ad.m && (!h->strong || h->x[1].ad.m), "the model steps with Adam: the shards need their moment arrays (nncf_shard_set_optimizer)");
+    NNCF_REQUIRE(m->opt != 2 || (h->x[0].ad.stamp && (!h->strong || h->x[1].ad.stamp)), "dense Adam: the shards need their stamp arrays");
+  }
   int rc = shared_step(m, a, 0, uid, h->x[0].slot + index * h->b, m->plan_u.at(index), m->plan_v.at(index), d_loss, 1, st);
+  if (rc) return rc;
+  // Keras (dense) Adam, weak form: the local user rows the batch did not touch take the zero-gradient step (the owners'
+  // shards take theirs in nncf_shard_apply, which also advances the step counter)
+  if (m->opt == 2 && !h->strong) rc = launch_adam_idle(a, m->U, m->au, m->cfg.user_count, st);
   return rc;
 }
 
@@ -557,15 +578,21 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
   for (int xi = 0; xi < h->nx; ++xi) {
     Exch& e = h->x[xi];
     const int64_t rows = h->have_bound ? h->bound[xi][index] : (int64_t)h->ranks * e.n;
+    StepArgs a = make_args(h->m);   // optimiser constants of THIS step (the counter advances below, once per step)
+    a.stride = e.stride;
+    a.lr = lr;
     if (rows > 0) {
       ProfScope _ps("scatter_merge_kernel", st);
-      hipLaunchKernelGGL(merge_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, lr, e.i0, e.g_in,
+      hipLaunchKernelGGL(merge_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a, e.ad, e.shard, e.i0, e.g_in,
                          e.req_in, e.recv_off, e.step_off, h->ranks, (int)index);
       NNCF_HIP_CHECK(hipGetLastError());
     }
+    if (a.opt == 2)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
+      if (int rc = launch_adam_idle(a, e.shard, e.ad, e.shard_rows, st)) return rc;
     if (index + 1 < n_steps)   // rows of the next step, after this step's update (synchronous SGD)
       if (int rc = gather_step(h, xi, index + 1, st)) return rc;
   }
+  if (h->m->opt) h->m->adam_t++;
   if (index + 1 < n_steps) return NNCF_OK;
   return flush_pending_loss(h->m, st);
 }

@@ -17,7 +17,7 @@ link of its users, so user rows are always local.  One global step (all ranks to
   4. local neg_shared step on [local user shard, fetched item rows]: user rows are updated in
      place, item gradients are exported per landing slot
   5. item gradients -> owners                     (all-to-all), which add the ranks' rows of an id in rank order and
-     apply the sparse SGD update (deterministic, no atomics).
+     apply the update -- sparse SGD, or the model's Adam with the shard's own moments (deterministic, no atomics).
 This is synchronous data-parallel SGD: all ranks' batches see the same pre-step item rows and
 the owners apply the sum of the per-rank gradients (`simulate_global_steps` in tests/test_sharded_gloo.py restates it).
 
@@ -88,9 +88,13 @@ class HipBackend(object):
             # the model's "item table" is the landing buffer of fetched rows; world * cap slots for the per-step protocol
             # (step(): static capacity b per peer), of which the chunked protocol uses the first b
             kw["item_count"] = self.world * self.cap
+        self.optimizer = kw.pop("optimizer", "sgd")     # 'sgd' | 'sparse_adam' | 'adam' (Engine.set_optimizer), chunked protocol only
         self.engine = Engine(device=device, seed=seed, **kw)
         if shared_device:
             self.engine.set_shared_device(True)
+        if self.optimizer != "sgd":
+            # the engine's own state: the weak form's local user rows (its landing buffers never take a step)
+            self.engine.set_optimizer(self.optimizer)
         self.rows_in = self.engine.V                # landing buffer of item rows
         dim_l = int(kw["dim"])
 
@@ -167,6 +171,15 @@ class HipBackend(object):
                     ctypes.c_void_p(self.U.data_ptr()) if strong else ctypes.c_void_p(), self.dim, self.user_shard, self.u0,
                     self.world, self.rank, self.device.index, ctypes.byref(h)))
             self._sh = h
+            if self.optimizer != "sgd":   # Adam state of this rank's shards (items; users too in the strong form)
+                dense = self.optimizer == "adam"
+                self._adam = []
+                for xi, tab in enumerate([self.V] + ([self.U] if strong else [])):
+                    m_, v_ = torch.zeros_like(tab), torch.zeros_like(tab)
+                    st_ = torch.zeros(tab.shape[0], dtype=torch.int32, device=self.device) if dense else None
+                    self._adam.append((m_, v_, st_))
+                    self._lib.check(L.nncf_shard_set_optimizer(h, xi, ctypes.c_void_p(m_.data_ptr()), ctypes.c_void_p(v_.data_ptr()),
+                                                               ctypes.c_void_p(st_.data_ptr()) if dense else ctypes.c_void_p()))
             W, CH = self.world, self.CHUNK
             co, ci, nx = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32()
             self._lib.check(L.nncf_shard_counts(h, ctypes.byref(co), ctypes.byref(ci), ctypes.byref(nx)))

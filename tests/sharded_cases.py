@@ -12,14 +12,21 @@ def shard_size(count, world):
     return (int(count) + world - 1) // world
 
 
-def conf(loss="skip-gram", model="mf"):
+LR_ADAM = 0.01
+
+
+def conf(loss="skip-gram", model="mf", optimizer="sgd"):
     return so.OracleConf(batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=LAMBDA, u_reg=UREG,
-                         learn_rate=LR, model_choice=model)
+                         learn_rate=LR if optimizer == "sgd" else LR_ADAM, model_choice=model, optimizer=optimizer)
 
 
-def engine_kwargs(loss="skip-gram"):
-    return dict(user_count=NU, item_count=NI, dim=D, batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10.,
-                neg_loss_weight=LAMBDA, u_reg=UREG, learn_rate=LR, normalize_user=False, normalize_item=False)
+def engine_kwargs(loss="skip-gram", optimizer="sgd"):
+    kw = dict(user_count=NU, item_count=NI, dim=D, batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10.,
+              neg_loss_weight=LAMBDA, u_reg=UREG, learn_rate=LR if optimizer == "sgd" else LR_ADAM, normalize_user=False,
+              normalize_item=False)
+    if optimizer != "sgd":
+        kw["optimizer"] = optimizer      # HipBackend: the engine's and the shards' Adam state
+    return kw
 
 
 def tables(seed=0):
@@ -72,9 +79,9 @@ def simulate_weak(loss, world):
     return U, V, np.asarray(losses)
 
 
-def simulate_strong(loss):
+def simulate_strong(loss, optimizer="sgd"):
     """the one-device step (models/train_neg_shared.py:46-51 semantics) on the global batches, float64"""
-    c = conf(loss)
+    c = conf(loss, optimizer=optimizer)
     U, V = tables()
     o = so.StepOracle(U, V, c, dtype=np.float64)
     losses = [o.step_neg_shared(u, cc) for u, cc in global_batches()]

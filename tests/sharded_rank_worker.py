@@ -1,4 +1,4 @@
-"""One rank of tests/test_sharded_two_ranks_gpu.py: `python sharded_rank_worker.py CASE RANK WORLD PORT OUTDIR [LOSS]`.
+"""One rank of tests/test_sharded_two_ranks_gpu.py: `python sharded_rank_worker.py CASE RANK WORLD PORT OUTDIR [LOSS [OPTIMIZER]]`.
 All ranks share GPU 0 (the one-GPU box), collectives over gloo with the payloads staged through host memory
 (nncf_amd/sharded.py: _Exchanger.stage_host); the HIP kernels are the product's."""
 import os
@@ -17,6 +17,7 @@ from tests import sharded_cases as sc  # noqa: E402
 def main():
     case, rank, world, port, outdir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     loss = sys.argv[6] if len(sys.argv) > 6 else "skip-gram"
+    optimizer = sys.argv[7] if len(sys.argv) > 7 else "sgd"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from nncf_amd.sharded import HipBackend, ShardedGlobalBatch, ShardedNegShared
@@ -25,7 +26,7 @@ def main():
         U, V = sc.tables()
         us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
         ul, il = min(us, sc.NU - rank * us), min(isz, sc.NI - rank * isz)
-        be = HipBackend(sc.engine_kwargs(loss), ul, il, 0, world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
+        be = HipBackend(sc.engine_kwargs(loss, optimizer), ul, il, 0, world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
                         mode=case, user_shard=us, user_offset=rank * us, shared_device=True)
         be.U[:, :sc.D].copy_(torch.from_numpy(U[rank * us:rank * us + ul]))
         be.V[:, :sc.D].copy_(torch.from_numpy(V[rank * isz:rank * isz + il]))

@@ -354,3 +354,39 @@ def test_rectangular_step_shares_add_up_to_the_square_step():
     scale = max(np.abs(gu_want).max(), np.abs(gv_want).max())
     np.testing.assert_allclose(gu_got, gu_want, rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(gv_got, gv_want, rtol=0, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("form", ["weak", "strong"])
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_sharded_world1_adam_equals_the_plain_engine_and_the_oracle(form, kind):
+    """Adam on the sharded paths (nncf_shard_set_optimizer): the owners step their shards with the model's Adam on the summed
+    gradient rows -- Keras (dense) Adam incl. the zero-gradient step of every untouched shard row, and the lazy-sparse form;
+    70 steps of both forms at world 1 == the plain engine's epoch with the same optimiser == the oracle."""
+    from nncf_amd.sharded import ShardedGlobalBatch
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.01, normalize_user=False, normalize_item=False)
+    plain = Engine(seed=5, init_scale=0.5, **kw)
+    plain.set_optimizer(kind)
+    be = HipBackend(dict(kw, optimizer=kind), nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode=form, user_shard=nu)
+    be.U.copy_(plain.U)
+    be.V.copy_(plain.V)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.01, model_choice="mf", optimizer=kind)
+    orc = so.StepOracle(plain.U.cpu().numpy(), plain.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    uid[:6] = uid[0]
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr = (ShardedGlobalBatch if form == "strong" else ShardedNegShared)(be, nu, ni, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    be.engine.check()
+    ref = plain.epoch_neg_shared(plain.ids(uid), plain.ids(cid), steps).cpu().numpy()
+    l = losses.cpu().numpy()
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l[t] - want) <= 1e-5 * max(1, abs(want)), (t, l[t], want)
+        assert abs(l[t] - ref[t]) <= 1e-5 * max(1, abs(ref[t])), (t, l[t], ref[t])
+    for got, want in ((be.U, orc.U), (be.V, orc.V), (plain.U, orc.U), (plain.V, orc.V)):
+        np.testing.assert_allclose(got.cpu().numpy()[:, :d], want, rtol=5e-4, atol=5e-5)

@@ -31,11 +31,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, world, tmp_path, loss="skip-gram"):
+def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd"):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_rank_worker.py"), case, str(r), str(world), port,
-                               str(tmp_path), loss], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(tmp_path), loss, optimizer], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = []
     for p in procs:
@@ -79,6 +79,19 @@ def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss):
         np.testing.assert_allclose(got[r]["losses"], losses, rtol=1e-5)
         np.testing.assert_allclose(got[r]["U"], U[r * us:(r + 1) * us], rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(got[r]["V"], V[r * isz:(r + 1) * isz], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_strong_form_two_ranks_with_adam_equal_the_single_device_step(tmp_path, kind):
+    """the same with the owners stepping their shards by Adam (Keras dense / lazy-sparse) on the rank-ordered sums"""
+    world = 2
+    got = _run_ranks("strong", world, tmp_path, "skip-gram", kind)
+    U, V, losses = sc.simulate_strong("skip-gram", kind)
+    us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], losses, rtol=1e-5)
+        np.testing.assert_allclose(got[r]["U"], U[r * us:(r + 1) * us], rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(got[r]["V"], V[r * isz:(r + 1) * isz], rtol=5e-4, atol=5e-5)
 
 
 def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path):
