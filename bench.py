@@ -577,6 +577,8 @@ def main_sharded(args, conf, rank, world, local_rank):
     kw = dict(user_count=users, item_count=items, dim=d, batch_size_p=b, num_negatives=0, loss=conf.loss,
               loss_gamma=conf.loss_gamma, neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg,
               learn_rate=abs(conf.learn_rate), normalize_user=norm, normalize_item=False)   # mf: model_framework.py:85-88
+    if args.optimizer != "sgd":
+        kw["optimizer"] = args.optimizer      # the owners step their shards with Adam (nncf_shard_set_optimizer)
     us, isz = shard_size(users, world), shard_size(items, world)
     be = HipBackend(kw, max(1, min(us, users - rank * us)), max(1, min(isz, items - rank * isz)), local_rank,
                     world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
@@ -631,9 +633,10 @@ def main_sharded(args, conf, rank, world, local_rank):
             "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init tables" if args.large else
                      "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links), random-init tables"),
             "config": {"workload": "%s, id-table towers (model_choice=mf), tables sharded by id "
-                                   "range, d=%d, train_scheme=neg_shared, loss=%s, %s, sparse SGD"
+                                   "range, d=%d, train_scheme=neg_shared, loss=%s, %s, %s"
                                    % ("config-4-shaped 10M x 1M" if args.large else "CiteULike-a-shaped", d, conf.loss,
-                                      ("ONE global batch b=%d per step, rows split over the GPUs" % b) if strong else ("b=%d per GPU" % b)),
+                                      ("ONE global batch b=%d per step, rows split over the GPUs" % b) if strong else ("b=%d per GPU" % b),
+                                      {"sgd": "sparse SGD", "adam": "Keras Adam (dense)", "sparse_adam": "lazy-sparse Adam"}[args.optimizer]),
                        "global_batch": gb,
                        "parallelism": ("1 process per GPU; user AND item rows range-sharded and fetched per step (users of the local "
                                        "rows, items of all columns), both gradients returned to the owners" if strong else
