@@ -8,22 +8,31 @@
 
 namespace nncf {
 
-// Exclusive block scan of one int per thread (NT threads), result via LDS scratch[NT].
+// Exclusive block scan of one int per thread (NT threads), result via LDS scratch[>= NT / 64 + 1]: inclusive scan inside every
+// wave by shuffles, the waves' totals through LDS (two barriers instead of two per doubling step).
 template <int NT>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
-  const int tid = threadIdx.x;
-  scratch[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < NT; off <<= 1) {
-    int t = (tid >= off) ? scratch[tid - off] : 0;
-    __syncthreads();
-    scratch[tid] += t;
-    __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NT / 64;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
   }
-  const int incl = scratch[tid];
-  *total = scratch[NT - 1];
+  __syncthreads();                    // scratch may still be read from an earlier use
+  if (lane == 63) scratch[wave] = incl;
   __syncthreads();
-  return incl - v;
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {      // NW <= 16 broadcast reads
+    const int t = scratch[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + incl - v;
 }
 
 // ids of list L = concat(ids_a[L*stride_a .. +na), ids_b[L*stride_b .. +nb)); n = na + nb <= CAP.
@@ -161,16 +170,23 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
     scratch[m] = bslot;
   }
   __syncthreads();
-  if (tid == 0) {
-    int c = 0, last = -1;
-    for (int m = 0; m < nm; ++m) {
-      const int bs = scratch[m];
-      if (bs != last && bs < n) chunk_start[c++] = bs;
-      last = bs;
+  // distinct boundaries, in order (a boundary repeats when a segment spans several multiples of kChunkSlots): flag + scan
+  // (was one thread walking all nm entries: 352 dependent LDS reads for `original`'s 5,632 ids)
+  {
+    int bs = n, keep = 0;
+    if (tid < nm) {
+      bs = scratch[tid];
+      const int prev = tid > 0 ? scratch[tid - 1] : -1;
+      keep = (bs != prev && bs < n) ? 1 : 0;
     }
-    counts[2] = c;
-    counts[3] = 0;
-    for (; c <= nm; ++c) chunk_start[c] = n;  // unused chunks are empty ranges [n, n)
+    int c_total;
+    const int c = block_exclusive_scan<NT>(keep, scratch + NT, &c_total);   // scratch[NT ..]: a second small area (see the carve)
+    if (keep) chunk_start[c] = bs;
+    for (int e = c_total + tid; e <= nm; e += NT) chunk_start[e] = n;       // unused chunks are empty ranges [n, n)
+    if (tid == 0) {
+      counts[2] = c_total;
+      counts[3] = 0;
+    }
   }
 }
 
@@ -268,13 +284,13 @@ int launch_plan_steps(const int32_t* uid, int64_t stride_u, int nu, const PlanVi
   const int n = nu > na + nb ? nu : na + nb;
   if (n_lists <= 0 || n <= 0) return NNCF_OK;
   if (n <= 1024)
-    return launch_plan_steps_t<1024, 256>(1024 * 8 + 1024 * 4 * 2 + 256 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
+    return launch_plan_steps_t<1024, 256>(1024 * 8 + 1024 * 4 * 2 + 256 * 4 + 256, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
                                           stride_b, nb, pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
   if (n <= 8192)
-    return launch_plan_steps_t<8192, 1024>(8192 * 8 + 8192 * 4 * 2 + 1024 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
+    return launch_plan_steps_t<8192, 1024>(8192 * 8 + 8192 * 4 * 2 + 1024 * 4 + 256, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b,
                                            stride_b, nb, pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
   if (n <= 16384 && pu.aux && pv.aux)
-    return launch_plan_steps_t<16384, 1024>(16384 * 8 + 1024 * 4, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b, stride_b, nb,
+    return launch_plan_steps_t<16384, 1024>(16384 * 8 + 1024 * 4 + 256, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b, stride_b, nb,
                                             pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
   return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (16384 with a scratch array, 8192 without)", n);
 }
@@ -287,7 +303,7 @@ int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const in
     return launch_plan(ids1, 0, n1, nullptr, 0, 0, out1, 1, stream);
   }
   constexpr int CAP = 1024, NT = 256;
-  const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;
+  const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4 + 256;
   {
     ProfScope _ps("plan_kernel", stream);
     hipLaunchKernelGGL((plan_pair_kernel<CAP, NT>), dim3(2), dim3(NT), lds, stream, ids0, n0, out0, ids1, n1, out1);
@@ -302,7 +318,7 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
   if (n_lists <= 0 || n <= 0) return NNCF_OK;
   if (n <= 1024) {
     constexpr int CAP = 1024, NT = 256;
-    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;
+    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4 + 256;
     {
       ProfScope _ps("plan_kernel", stream);
       hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
@@ -310,7 +326,7 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
     }
   } else if (n <= 8192) {
     constexpr int CAP = 8192, NT = 1024;
-    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4;  // 132 KiB of the CU's 160 KiB
+    const size_t lds = CAP * 8 + CAP * 4 * 2 + NT * 4 + 256;  // 132 KiB of the CU's 160 KiB
     static KernelDeviceState kds;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>), lds, kds)) return rc;
     {
@@ -320,7 +336,7 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
     }
   } else if (n <= 16384 && out.aux) {
     constexpr int CAP = 16384, NT = 1024;
-    const size_t lds = CAP * 8 + NT * 4;  // keys only: 132 KiB
+    const size_t lds = CAP * 8 + NT * 4 + 256;  // keys only: 132 KiB
     static KernelDeviceState kds;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>), lds, kds)) return rc;
     {
