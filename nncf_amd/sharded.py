@@ -124,6 +124,9 @@ class HipBackend(object):
 
     # -- per-step protocol (weak form; static capacity b per peer, -1 padded) ------------------------------
     def route(self, cid):
+        if self.optimizer != "sgd":
+            raise NotImplementedError("the per-step protocol (static splits) steps the owners' rows with sparse SGD only; "
+                                      "run_epoch (the chunked protocol) carries the Adam state of the shards")
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self._lib.check(self._lib.lib().nncf_shard_route(p(cid), cid.numel(), self.item_shard, self.world, self.cap,
                                                          p(self.req), p(self.slot), p(self._ws_route), self._stream()))
