@@ -30,6 +30,7 @@ run_prof mf_group_neg_shared_kernel_trace "--stats" --model mf --scheme group_ne
 run_prof large_mf_b8192_kernel_trace "--stats" --large --batch 8192 --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b16384_kernel_trace "--stats" --large --batch 16384 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 5
 run_prof large_mf_b8192_logloss_kernel_trace "--stats" --large --batch 8192 --loss log-loss --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
+run_prof large_mf_b8192_logloss_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --loss log-loss --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
 run_prof large_mf_b8192_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
 (cd /tmp && NNCF_FORCE_SHARDED=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_sh -o p -- python3 $R/bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 $B > $OUT/prof_sh.log 2>&1)
 python3 $R/tools/prof_summary.py $OUT/prof_sh/p_results.db $OUT/${TAG}_mf_sharded_world1_kernel_trace.txt; rm -rf $OUT/prof_sh
