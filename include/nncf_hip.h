@@ -340,7 +340,9 @@ int nncf_tower_sync_params(nncf_tower* t, void* stream);
 /* conf.pooling (modules/content/mean_pool.py:68-76): 0 = 'average' (AverageEmbeddings: sum of the word rows / L, :27-33;
  * default), != 0 = 'max' (MaxPooling1D over the whole length, :70-72: per column the largest scale[w] W[w][c] of the item's
  * tokens -- rows dropped by Embedding(dropout) are zeros and take part; the gradient of a column goes to the word that
- * supplied its maximum).  Mean-pool tower only. */
+ * supplied its maximum).  CNN tower (cnn_embedding): conf.poolings[0] (modules/content/cnn_model.py:100-109) -- how the conv
+ * output (BatchNorm, relu, Dropout) is pooled over the item's positions: != 0 = MaxPooling1D over the whole length (the
+ * gradient of a filter goes to the position that supplied its maximum, first maximum in position order). */
 int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling);
 /* Speed only (mean-pool tower, average pooling; no reference counterpart): up to 16 word ids that occur in most items of
  * any batch (the pad id, the corpus's most frequent words).  Their word-row gradient sum_s count[w][s] dL/dh[s] is

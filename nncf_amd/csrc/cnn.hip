@@ -310,9 +310,14 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
 // needs no pass of its own for them (cnn_merge_kernel weighs them with dh).
 // 512 threads = 32 row groups: the item's L <= 224 positions are one round of loads (seven rows per group
 // in flight); the four groups of a wave are combined by shuffles, the 8 waves through LDS in wave order.
+// MAXP (poolings = ['max'], cnn_model.py:107-109: MaxPooling1D over the whole length): h[s][c] = max_p a[p][c]; the position
+// that supplied it goes to CnnArgs::amax (first maximum in position order), the BN1 backward factors shrink to that position:
+// M1 = m[p*], M2 = m[p*] xhat[p*], and da[p][c] = dh[s][c] m[p][c] [p == p*] -- no 1/L (cnn_merge_kernel, cnn_conv_bwd_kernel).
 constexpr int kPoolThreads = 512;
+template <bool MAXP>
 __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs a) {
   __shared__ __attribute__((aligned(16))) float sR[3][16 * kTP];
+  __shared__ int sRp[MAXP ? 16 * kTP : 1];
   __shared__ __attribute__((aligned(16))) float sH[kTP];
   __shared__ __attribute__((aligned(16))) float4 sP[8 * 32];
   __shared__ __attribute__((aligned(16))) float sMul[128], sAdd[128], sMu[128], sInv[128];
@@ -346,6 +351,14 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
   }
   __syncthreads();
   Row acc = row_zero(), m1 = row_zero(), m2 = row_zero();
+  int bp[8];   // MAXP: position of this lane's running maximum per column (acc = the maximum, m1 / m2 = m, m xhat there)
+  if (MAXP) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      relem(acc, k) = -1.f;   // activations are >= 0: the first position always wins
+      bp[k] = 0x7FFFFFFF;
+    }
+  }
   const bool drop = a.train && a.cnn.keep < 1.f;
   // this lane's eight columns are the same for every row: scale / shift live in registers
   Row rmul, radd;
@@ -374,10 +387,20 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
           const float pre = fmaf(yv, relem(rmul, k), relem(radd, k));
           float m = 0.f;
           if (pre > 0.f) m = drop ? conv_keep(a, (int64_t)s * L + p, c) : 1.f;
-          relem(acc, k) = fmaf(pre, m, relem(acc, k));
-          if (prep) {
-            relem(m1, k) += m;
-            relem(m2, k) = fmaf(m, (yv - relem(rmu, k)) * relem(rinv, k), relem(m2, k));
+          if (MAXP) {
+            const float av = pre * m;   // positions ascend inside a lane: strictly greater keeps the first maximum
+            if (av > relem(acc, k)) {
+              relem(acc, k) = av;
+              bp[k] = p;
+              relem(m1, k) = m;
+              relem(m2, k) = m * (yv - relem(rmu, k)) * relem(rinv, k);
+            }
+          } else {
+            relem(acc, k) = fmaf(pre, m, relem(acc, k));
+            if (prep) {
+              relem(m1, k) += m;
+              relem(m2, k) = fmaf(m, (yv - relem(rmu, k)) * relem(rinv, k), relem(m2, k));
+            }
           }
         }
       }
@@ -392,15 +415,36 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
       relem(r, k) = v;
     }
   };
-  wave_fold(acc);
-  if (prep) {
-    wave_fold(m1);
-    wave_fold(m2);
+  if (MAXP) {   // the wave's four groups: larger value, then earlier position
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float ov = __shfl_xor(relem(acc, k), off), o1 = __shfl_xor(relem(m1, k), off), o2 = __shfl_xor(relem(m2, k), off);
+        const int op = __shfl_xor(bp[k], off);
+        if (ov > relem(acc, k) || (ov == relem(acc, k) && op < bp[k])) {
+          relem(acc, k) = ov;
+          bp[k] = op;
+          relem(m1, k) = o1;
+          relem(m2, k) = o2;
+        }
+      }
+    }
+  } else {
+    wave_fold(acc);
+    if (prep) {
+      wave_fold(m1);
+      wave_fold(m2);
+    }
   }
   const int wv = tid >> 6;
   if ((tid & 63) < 16) {
     reinterpret_cast<float4*>(sR[0] + wv * kTP)[q] = acc.a;
     reinterpret_cast<float4*>(sR[0] + wv * kTP)[q + 16] = acc.b;
+    if (MAXP) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sRp[wv * kTP + col_of(q, k)] = bp[k];
+    }
     if (prep) {
       reinterpret_cast<float4*>(sR[1] + wv * kTP)[q] = m1.a;
       reinterpret_cast<float4*>(sR[1] + wv * kTP)[q + 16] = m1.b;
@@ -409,6 +453,42 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
     }
   }
   __syncthreads();
+  if (MAXP) {
+    if (grp == 0) {   // the eight waves' candidates: larger value, then earlier position; its m / m xhat; the position kept
+      Row best = row_zero(), b1 = row_zero(), b2 = row_zero();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = col_of(q, k);
+        float v = -1.f, u1 = 0.f, u2 = 0.f;
+        int pp = 0x7FFFFFFF;
+        for (int g = 0; g < kPoolThreads / 64; ++g) {
+          const float ov = sR[0][g * kTP + c];
+          const int op = sRp[g * kTP + c];
+          if (ov > v || (ov == v && op < pp)) {
+            v = ov;
+            pp = op;
+            u1 = prep ? sR[1][g * kTP + c] : 0.f;
+            u2 = prep ? sR[2][g * kTP + c] : 0.f;
+          }
+        }
+        const bool real = c < F;
+        relem(best, k) = real ? fmaxf(v, 0.f) : 0.f;
+        relem(b1, k) = real ? u1 : 0.f;
+        relem(b2, k) = real ? u2 : 0.f;
+        if (prep && real) a.cnn.amax[(int64_t)s * 128 + c] = (uint8_t)pp;
+      }
+      if (prep) {
+        float4* out = reinterpret_cast<float4*>(a.cnn.bpart + (int64_t)s * 256);
+        out[q] = b1.a;
+        out[q + 16] = b1.b;
+        out[32 + q] = b2.a;
+        out[32 + q + 16] = b2.b;
+      }
+      if (a.train) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, best);
+      reinterpret_cast<float4*>(sH)[q] = best.a;
+      reinterpret_cast<float4*>(sH)[q + 16] = best.b;
+    }
+  } else {
   if (prep && (grp == 1 || grp == 2)) {  // M1 / M2 of this item, groups in order
     Row sum = row_zero();
     for (int g = 0; g < kPoolThreads / 64; ++g) {
@@ -429,6 +509,7 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
     if (a.train) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, sum);   // this bank's columns of the pooled block
     reinterpret_cast<float4*>(sH)[q] = sum.a;
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
+  }
   }
   __syncthreads();
   if (tid < 256) {
@@ -475,7 +556,7 @@ __device__ __forceinline__ float conv_da(const TowerArgs& a, float dhc, float pr
 __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7, n = valid_rows(a), F = a.cnn.F;
-  const float rL = 1.f / (float)a.L;
+  const float rL = a.cnn.pool_max ? 1.f : 1.f / (float)a.L;   // max pooling: the one position that supplied the maximum, no 1/L
   float a1 = 0.f, a2 = 0.f;
   if (c < F) {
     for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 triples of loads in flight
@@ -540,7 +621,11 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
     sS1[tid] = a.cnn.st1[640 + tid];
     sS2[tid] = a.cnn.st1[768 + tid];
   }
-  const Row dhr = row_scale(row_load(a.dh + a.cnn.c_off, s, a.hd, f4, q), 1.f / (float)L);
+  const bool maxp = a.cnn.pool_max != 0;
+  const Row dhr = row_scale(row_load(a.dh + a.cnn.c_off, s, a.hd, f4, q), maxp ? 1.f : 1.f / (float)L);
+  int am[8];   // max pooling: the position whose activation was the item's maximum in this lane's eight columns
+#pragma unroll
+  for (int k = 0; k < 8; ++k) am[k] = (maxp && col_of(q, k) < F) ? (int)a.cnn.amax[(int64_t)s * 128 + col_of(q, k)] : -1;
   __syncthreads();
   stage_rows(a, sTok, sSc, sX, XP, p0 - pad, rows);
   // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
@@ -569,7 +654,8 @@ __global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a,
             for (int k = 0; k < 8; ++k) {
               const int c = col_of(q, k);
               const float yv = relem(y[e], k);
-              const float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
+              float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
+              if (maxp && p != am[k]) da = 0.f;
               relem(o, k) = relem(rmul, k) * rN * (N * da - relem(rs1, k) - (yv - relem(rmu, k)) * relem(rinv, k) * relem(rs2, k));
             }
           }
@@ -894,6 +980,7 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
     a.part1 = c.take<float>(cap * kFwdSplit * 256);
     a.st1 = c.take<float>(7 * 128);
     a.bpart = c.take<float>(cap * 256);
+    a.amax = c.take<uint8_t>(cap * 128);
     a.gWpart = c.take<float>(cap * nblk * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
     a.gbpart = c.take<float>(cap * nblk * 128);
   }
@@ -923,6 +1010,7 @@ static TowerArgs bank_args(const nncf_tower* t, const TowerArgs& a, int g) {
     b.cnn.keep = a.cnn.keep;
     b.cnn.seed = splitmix64(a.cnn.seed + 0x9E3779B97F4A7C15ull * (uint64_t)g);
     b.cnn.dbg = a.cnn.dbg;
+    b.cnn.pool_max = a.cnn.pool_max;
   }
   b.cnn.c_off = g * a.cnn.F;
   b.cnn.z_acc = g > 0;
@@ -972,7 +1060,8 @@ static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_pool_dense_kernel", st);
-    hipLaunchKernelGGL(cnn_pool_dense_kernel, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
+    if (a.cnn.pool_max) hipLaunchKernelGGL(cnn_pool_dense_kernel<true>, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
+    else hipLaunchKernelGGL(cnn_pool_dense_kernel<false>, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

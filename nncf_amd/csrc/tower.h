@@ -31,6 +31,8 @@ struct CnnArgs {
   float* part1;              // [m][2][128]   per-slot sums of (y-b), (y-b)^2
   float* st1;                // 7 x 128: mu, inv, var, mul, add, sum da, sum da*xhat
   float* bpart;              // [m][2][128]
+  uint8_t* amax;             // [m][128] max pooling: the position that supplied each filter's maximum
+  int pool_max;              // poolings = ['max'] (cnn_model.py:107-109) over the whole length instead of the average
   float* gWpart;             // [ceil(fl*wd*F / 64)][cap*nblk][64]: dWk partials, element-group major
   float* gbpart;             // [m*nblk][128]
   const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)

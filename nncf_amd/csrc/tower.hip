@@ -1133,7 +1133,8 @@ TowerArgs base_args(const nncf_tower* t) {
   a.cnn = t->cnn;
   a.cnn.keep = 1.f;
   a.hd = t->hd();
-  a.pool_max = t->pool_max;
+  a.pool_max = t->cnn.F > 0 ? 0 : t->pool_max;        // mean-pool tower: max over the item's tokens
+  a.cnn.pool_max = t->cnn.F > 0 ? t->pool_max : 0;    // CNN tower: max over the positions of the conv output
   a.amax = t->amax;
   const bool hot_ok = t->n_hot > 0 && t->cnn.F == 0 && !t->pool_max;
   a.hot = t->hot;
@@ -1679,8 +1680,7 @@ int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_wor
 
 int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
-  NNCF_REQUIRE(!max_pooling || t->cfg.conv_filters == 0, "pooling = 'max' belongs to the mean-pool tower (cnn_embedding pools its conv output)");
-  if (max_pooling && !t->amax) {
+  if (max_pooling && !t->amax && t->cfg.conv_filters == 0) {   // the CNN tower's positions are bytes in its own workspace
     DeviceGuard guard(t->device);
     if (hipMalloc(&t->amax, sizeof(int32_t) * (size_t)t->cfg.max_rows * t->cfg.word_dim) != hipSuccess)
       return fail(NNCF_ERR_NOMEM, "argmax buffer allocation failed");

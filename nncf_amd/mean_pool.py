@@ -253,9 +253,9 @@ class MeanPoolTower(object):
             self._bind_content_id(kind)
 
     def set_pooling(self, pooling):
-        """conf.pooling (mean_pool.py:68-76): 'average' (default) | 'max' (MaxPooling1D over the whole length)."""
+        """Mean-pool tower: conf.pooling (mean_pool.py:68-76): 'average' (default) | 'max' (MaxPooling1D over the whole
+        length).  CNN tower: conf.poolings[0] (cnn_model.py:100-109): how the conv output is pooled over the positions."""
         assert pooling in ("average", "max"), "[ERROR] unknown pooling: %s" % pooling
-        assert not (self.conv and pooling == "max"), "pooling = 'max' belongs to the mean-pool tower"
         self.pooling = pooling
         with torch.cuda.device(self.device):
             _lib.check(self._L.nncf_tower_set_pooling(self.handle, int(pooling == "max")))

@@ -426,13 +426,13 @@ def _conv_spec(conf):
     """The convolutional front of cnn_embedding as this build runs it (cnn_model.py:61-111): one convolution layer --
     a single odd filter length (the 'best' preset, filter_lengths [3]) or a bank of up to four odd lengths whose
     outputs are concatenated (the 'default' preset, filter_lengths [[1, 3, 5]]; :63-81) -- BatchNorm, relu,
-    whole-length average pooling."""
+    whole-length average or max pooling (:100-109)."""
     fls, nfs = list(conf.filter_lengths), list(conf.num_filters)
     bank = None
     if len(fls) == 1:
         bank = [int(v) for v in fls[0]] if isinstance(fls[0], (list, tuple)) else [int(fls[0])]
     ok = (bank is not None and 1 <= len(bank) <= 4 and all(v % 2 == 1 and 1 <= v <= 7 for v in bank) and len(nfs) == 1 and
-          list(conf.poolings) == ["average"] and list(conf.pool_lengths)[0] <= 0 and conf.conv_activation == "relu" and
+          list(conf.poolings) in (["average"], ["max"]) and list(conf.pool_lengths)[0] <= 0 and conf.conv_activation == "relu" and
           conf.conv_batch_normalization and not getattr(conf, "no_BN", False) and
           not getattr(conf, "contextual_spatial_gated_input", None) and
           not getattr(conf, "contextual_temporal_gated_input", None))
@@ -440,9 +440,10 @@ def _conv_spec(conf):
         raise NotImplementedError(
             "cnn_embedding is built for ONE convolution layer (filter_lengths=[3], the 'best' preset, or a bank of up "
             "to four odd lengths <= 7 such as [[1, 3, 5]], the 'default' preset), conv BatchNorm + relu, "
-            "poolings=['average'] over the whole length, no gating; got filter_lengths=%r num_filters=%r poolings=%r "
+            "poolings=['average'] or ['max'] over the whole length, no gating; got filter_lengths=%r num_filters=%r poolings=%r "
             "pool_lengths=%r" % (fls, nfs, conf.poolings, conf.pool_lengths))
-    return dict(filters=int(nfs[0]), filter_len=bank[0], filter_lens=bank, dropout=float(conf.conv_dropout_rate))
+    return dict(filters=int(nfs[0]), filter_len=bank[0], filter_lens=bank, dropout=float(conf.conv_dropout_rate),
+                pooling=str(list(conf.poolings)[0]))
 
 
 def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
@@ -465,6 +466,8 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
                           dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap, conv=conv)
     if conv is None and pooling == "max":
         tower.set_pooling("max")                                        # mean_pool.py:70-72
+    if conv is not None and conv.get("pooling") == "max":
+        tower.set_pooling("max")                                        # cnn_model.py:107-109
     if getattr(conf, "use_content_id", False):                          # mean_pool.py:102-108
         tower.set_content_id(getattr(conf, "v_reg", 0.0), seed=seed)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)

@@ -561,6 +561,11 @@ class CnnTowerOracle(TowerOracle):
         mask = self.conv_mask[:n] if (train and self.conv_mask is not None) else None   # rows = block slots
         if mask is not None:
             a = a * mask
+        if getattr(self, "conv_pooling", "average") == "max":   # cnn_model.py:107-109: MaxPooling1D over the whole length
+            amax = a.argmax(axis=1)                              # [K-mem] first maximum in position order
+            if train:
+                self.cache.update(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var, amax=amax)
+            return np.take_along_axis(a, amax[:, None, :], axis=1)[:, 0, :].astype(self.dt)
         if train:
             self.cache.update(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var)
         return (a.sum(axis=1) / self.dt.type(L)).astype(self.dt)
@@ -570,7 +575,11 @@ class CnnTowerOracle(TowerOracle):
         fl, pad = self.Wc.shape[0], self.Wc.shape[0] // 2
         n, Lp, wd = c["Xp"].shape
         L = Lp - 2 * pad
-        da = np.repeat(dh[:, None, :], L, axis=1) / self.dt.type(L)
+        if getattr(self, "conv_pooling", "average") == "max":   # the gradient goes to the position that supplied the maximum
+            da = np.zeros((n, L, dh.shape[1]), dtype=self.dt)
+            np.put_along_axis(da, c["amax"][:, None, :], dh[:, None, :].astype(self.dt), axis=1)
+        else:
+            da = np.repeat(dh[:, None, :], L, axis=1) / self.dt.type(L)
         if c["mask"] is not None:
             da = da * c["mask"]
         dy1 = da * (c["y1"] > 0)
@@ -646,8 +655,13 @@ class CnnBankTowerOracle(TowerOracle):
             mask = self.conv_mask[g][:n] if (train and self.conv_mask is not None) else None
             if mask is not None:
                 a = a * mask
-            banks.append(dict(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var))
-            hs.append(a.sum(axis=1) / self.dt.type(L))
+            bk = dict(Xp=Xp, xh1=xh, inv1=inv, y1=y1, mask=mask, mu1=mu, var1=var)
+            if getattr(self, "conv_pooling", "average") == "max":
+                bk["amax"] = a.argmax(axis=1)
+                hs.append(np.take_along_axis(a, bk["amax"][:, None, :], axis=1)[:, 0, :])
+            else:
+                hs.append(a.sum(axis=1) / self.dt.type(L))
+            banks.append(bk)
         if train:
             self.cache["banks"] = banks
         return np.concatenate(hs, axis=1).astype(self.dt)       # Merge(mode='concat', concat_axis=-1)
@@ -662,7 +676,11 @@ class CnnBankTowerOracle(TowerOracle):
         for g in range(self.nb):
             b, Wc = c["banks"][g], self.Wc[g]
             fl, pad, F = Wc.shape[0], Wc.shape[0] // 2, Wc.shape[2]
-            da = np.repeat(dh[:, None, off:off + F], L, axis=1) / self.dt.type(L)
+            if getattr(self, "conv_pooling", "average") == "max":
+                da = np.zeros((n, L, F), dtype=self.dt)
+                np.put_along_axis(da, b["amax"][:, None, :], dh[:, None, off:off + F].astype(self.dt), axis=1)
+            else:
+                da = np.repeat(dh[:, None, off:off + F], L, axis=1) / self.dt.type(L)
             off += F
             if b["mask"] is not None:
                 da = da * b["mask"]

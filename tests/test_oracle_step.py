@@ -385,10 +385,11 @@ def test_step_oracle_adam_moves_idle_rows_only_when_dense():
         assert o.t == 2
 
 
-def test_cnn_tower_oracle_vs_autograd_full_chain():
+@pytest.mark.parametrize("pool", ["average", "max"])
+def test_cnn_tower_oracle_vs_autograd_full_chain(pool):
     """CnnTowerOracle (explicit forward / backward) against torch autograd of the same graph written
-    with torch ops (conv1d 'same', batch_norm over (items, positions), relu, mask, mean, linear,
-    batch_norm, relu), float64, through a neg_shared step."""
+    with torch ops (conv1d 'same', batch_norm over (items, positions), relu, mask, mean | max over the positions
+    (cnn_model.py:100-109), linear, batch_norm, relu), float64, through a neg_shared step."""
     rs = np.random.RandomState(3)
     n_items, L, V, wd, F, d, b, nu, fl = 40, 9, 30, 6, 7, 5, 16, 12, 3
     C = rs.randint(0, V, (n_items, L))
@@ -404,6 +405,7 @@ def test_cnn_tower_oracle_vs_autograd_full_chain():
     conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="log-loss", u_reg=1e-3, learn_rate=0.1,
                          model_choice="basic_embedding")
     to = so.CnnTowerOracle(C, W, Wc, bc, g1, b1, Wd, bd, gamma, beta, 0.1, dtype=np.float64)
+    to.conv_pooling = pool
     cid_u, cid_x = so.tf_unique(cid)
     mask = ((rs.rand(len(cid_u), L, F) < 0.8) / 0.8)
     to.conv_mask = mask
@@ -418,7 +420,7 @@ def test_cnn_tower_oracle_vs_autograd_full_chain():
     Y = torch.nn.functional.conv1d(X.transpose(1, 2), tWc.permute(2, 1, 0), bias=tbc, padding=fl // 2).transpose(1, 2)
     mu, var = Y.mean(dim=(0, 1)), Y.var(dim=(0, 1), unbiased=False)
     a = torch.relu(tg1 * (Y - mu) / torch.sqrt(var + 1e-3) + tb1) * torch.tensor(mask)
-    h = a.mean(dim=1)
+    h = a.mean(dim=1) if pool == "average" else a.max(dim=1).values
     z = h @ tWd + tbd
     E = torch.relu(tga * (z - z.mean(0)) / torch.sqrt(z.var(0, unbiased=False) + 1e-3) + tbe)
     lt = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cid_x), conf)
