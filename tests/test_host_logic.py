@@ -185,24 +185,27 @@ def test_shuffle_rows_is_np_random_shuffle():
 def test_cnn_front_spec_from_the_reference_presets():
     """model_framework._conv_spec: what of cnn_embedding_conf.py's conv settings the build runs -- the `default`
     preset's filter bank [[1, 3, 5]] x 50 (cnn_embedding_conf.py:42-45) and the `best` preset's single length 3
-    (:129); stacked layers, even lengths, max pooling and gating are refused with NotImplementedError."""
+    (:129), average or max pooling over the whole length (:100-109); stacked layers, even lengths, pooling windows shorter than
+    the text and gating are refused with NotImplementedError."""
     import pytest
     from nncf_amd.conf import get_conf
     from nncf_amd.model_framework import _conv_spec
     d = get_conf("synthetic_citeulike", "default", None, model_choice="cnn_embedding")
     assert (d.filter_lengths, d.num_filters, d.word_dim, d.item_dim) == ([[1, 3, 5]], [50], 50, 50)
-    assert _conv_spec(d) == dict(filters=50, filter_len=1, filter_lens=[1, 3, 5], dropout=float(d.conv_dropout_rate))
+    assert _conv_spec(d) == dict(filters=50, filter_len=1, filter_lens=[1, 3, 5], dropout=float(d.conv_dropout_rate), pooling="average")
     b = get_conf("synthetic_citeulike", "best", None, model_choice="cnn_embedding")
     spec = _conv_spec(b)
     assert spec["filter_lens"] == [int(b.filter_lengths[0])] and spec["filters"] == int(b.num_filters[0])
     for bad in ({"filter_lengths": [3, 3], "num_filters": [50, 50], "poolings": ["average", "average"], "pool_lengths": [-1, -1]},
-                {"filter_lengths": [[2, 3]]}, {"filter_lengths": [[1, 3, 5, 7, 9]]}, {"poolings": ["max"]},
+                {"filter_lengths": [[2, 3]]}, {"filter_lengths": [[1, 3, 5, 7, 9]]}, {"poolings": ["min"]}, {"pool_lengths": [4]},
                 {"contextual_spatial_gated_input": {"gating_hidden_dim": 3}}):
         # 'best' + reset_after_getconf: the override lands after _post_init (which resets the gating fields, as the
         # reference's does: cnn_embedding_conf.py:87-90)
         c = get_conf("synthetic_citeulike", "best", dict({"reset_after_getconf": True}, **bad), model_choice="cnn_embedding")
         with pytest.raises(NotImplementedError):
             _conv_spec(c)
+    mx = get_conf("synthetic_citeulike", "best", {"reset_after_getconf": True, "poolings": ["max"]}, model_choice="cnn_embedding")
+    assert _conv_spec(mx)["pooling"] == "max"
 
 
 def test_postings_schedule_invariants():
