@@ -332,6 +332,12 @@ typedef struct nncf_tower_params {
   const uint8_t* item_start;  /* per CSR entry: index of its first position in the item's row of item_spos */
 } nncf_tower_params;
 
+/* Developer hook: per-workgroup clock stamps of the last conv forward / backward launches of a CNN tower created with
+ * NNCF_CNN_DBG=64 in the environment: out[kernel (0 fwd, 1 bwd)][workgroup][16], workgroups = max_rows * filter groups.
+ * Synchronous copy. */
+int nncf_tower_debug_stamps(nncf_tower* t, long long* out_host, int64_t n);
+
+
 int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* params, int device, nncf_tower** out);
 int nncf_tower_destroy(nncf_tower* t);
 int nncf_tower_set_learn_rate(nncf_tower* t, float learn_rate);

@@ -102,6 +102,7 @@ def _declare(lib):
         "nncf_model_set_sparse_adam_duplicates": [vp, i32],
         "nncf_model_set_bias": [vp, vp, vp, i64, vp, vp, vp, vp],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
+        "nncf_tower_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],
         "nncf_profile_begin": [ctypes.c_char_p, i64],
         "nncf_profile_end": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                              ctypes.POINTER(ctypes.c_double)],

@@ -3,24 +3,37 @@
 //   word Embedding (+ row dropout) -> Convolution1D(F, fl, 'same', linear) -> BatchNormalization
 //   over (items, positions) per filter -> relu -> Dropout(conv_dropout) -> AveragePooling1D over
 //   the whole length -> [Dense -> BatchNorm -> ReLU: the tail shared with MeanPool, tower.hip].
-// One workgroup per unique item (per 112 positions in the backward); the convolution is a GEMM
-// [L x fl*wd] . [fl*wd x F] per item on fp32 MFMA (v_mfma_f32_16x16x4_f32) with the gathered word
-// rows of the item staged once in LDS (each shifted tap re-reads them) and the filter fragments
-// held in registers across the item's 13 row tiles.  Per training step:
-//   cnn_conv_fwd    gather (dropped rows never loaded) -> LDS; Y = conv + b -> HBM; per-item sums
-//                   of (y-b), (y-b)^2 per filter; transposes the item's bag of words for the backward
+//
+// Round 4: the convolution runs over an item's DISTINCT words, not over its positions.  The input
+// row of position p is scale[w] W[w] with w = token(p): an item's L = 200 positions hold ~90 distinct
+// words (~45 after the 0.5 row dropout; the pad id alone fills half the text), and the convolution is
+// linear in its input rows, so
+//   forward   P[c][tap][f] = sum_k Xe[c][k] Wk[tap][k][f]          one row per distinct kept word c
+//             Y[p][f]      = b[f] + sum_tap P[c(p + tap - pad)][tap][f]   assembled from LDS
+//   backward  S[c][tap][f] = sum_{q : token(q) = word c} dY[q - tap + pad][f]   summed in LDS first
+//             dL/dW[w_c][k]  = scale_c sum_{tap,f} S[c][tap][f] Wk[tap][k][f]
+//             dWk[tap][k][f] = sum_c Xe[c][k] S[c][tap][f]
+// are the reference's convolution and its gradients exactly (sums reordered), with the GEMMs n_c rows
+// tall instead of L: 4.4x fewer MFMAs at the CiteULike shape with the `best` preset's dropout, 2.3x
+// without, and the per-position dX block, its per-(item, word) pre-summation launch (cnn_presum) and
+// the 202-row gathers are gone.  The index (token -> distinct-word ordinal, positions sorted by word)
+// is static per item and built once (nncf_amd/mean_pool.py: item_spos; tower_entries_kernel).
+// A workgroup = (item, group of 16 kCnnNTG filters): every filter group is independent in the forward
+// and in dWk; dL/dW is a sum over the filters, so the groups leave kCnnGroups(F) partial rows per
+// (item, word) that tower_word_kernel adds in group order while it gathers them.  Per training step:
+//   cnn_conv_fwd    distinct kept rows -> LDS; P (fp32 MFMA) -> LDS; Y = assembled + b -> HBM; per-item
+//                   sums of (y-b), (y-b)^2 per filter; the item's bag of words transposed for the backward
 //   cnn_stats       BatchNorm statistics over n_u*L positions -> mu, inv, mul, add; running stats
 //   cnn_pool_dense  a = relu(y*mul+add) * dropout mask, mean over L -> h; z = h.Wd + bd; per-item sums
 //                   of mask and mask*xhat for the backward
 //   (tower tail + step kernels + tower_bwd: dL/dh)
 //   cnn_merge       sums of da and da*xhat (da = dh/L * mask * [a>0]) over (items, positions) from the
 //                   per-item mask sums the pooling pass left behind, weighted with dh
-//   cnn_conv_bwd    dY = BN backward of da -> LDS; dX = sum_tap dY(shifted).Wk[tap]^T (MFMA) -> HBM;
-//                   partial dWk[tap] = X(shifted)^T.dY (MFMA) per workgroup
-//   cnn_presum      per item: dX rows summed per distinct word (static sorted-position index)
+//   cnn_conv_bwd    dY = BN backward of da -> LDS; S -> LDS; partial dL/dW rows and this item's dWk
+//                   block of the group's filters (fp32 MFMA) -> HBM
 //   tower_word_kernel (tower.hip) then reduces the per-(item, word) rows per word as for MeanPool; extra
 //                   workgroups of the same launch (cnn_update_block, tower.h) sum the dWk partials in
-//                   workgroup order and take the SGD / Adam step on Wk (+ transposed copy), conv bias,
+//                   item order and take the SGD / Adam step on Wk (+ transposed copy), conv bias,
 //                   BN1 gamma / beta -- disjoint parameters, one launch less
 // Everything has a fixed summation order (no float atomics); conv dropout is a counter-based hash.
 #include <type_traits>
@@ -64,27 +77,96 @@ __device__ __forceinline__ float conv_keep(const TowerArgs& a, int64_t pos_index
   return u < a.cnn.keep ? 1.f / a.cnn.keep : 0.f;
 }
 
-// tokens of the item + their row-dropout scales -> LDS; gathered (scaled) word rows for positions
-// [p_lo, p_lo + rows) -> sX rows (zero outside [0, L) and past wd)
-__device__ __forceinline__ void stage_tokens(const TowerArgs& a, int item, int* sTok, float* sSc) {
-  const int tid = threadIdx.x;
-  if (tid < a.L) {
-    const int tk = a.content[(int64_t)item * a.L + tid];
-    sTok[tid] = tk;
-    sSc[tid] = a.train ? word_scale(a, tk) : 1.f;
-  }
+
+// developer timing (NNCF_CNN_DBG=64): thread 0 of every workgroup stamps the phases of the conv kernels
+__device__ __forceinline__ void cnn_stamp(const TowerArgs& a, int kernel, int idx) {
+  if ((a.cnn.dbg & 64) && threadIdx.x == 0)
+    a.cnn.stamps[((int64_t)kernel * a.cap * a.cnn.np + blockIdx.x) * 16 + idx] = (long long)wall_clock64();
 }
-__device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, const float* sSc, float* sX, int XP,
-                                           int p_lo, int rows) {
+
+// ---- the item's static word index, rebuilt in LDS by every workgroup ---------------------------
+// Entry j of an item = its j-th distinct word (ascending id) with its count (ent_word / ent_cnt at a
+// fixed stride of L per item: no pointer hop); item_spos = the item's positions sorted by (word,
+// position), so entry j owns sorted indices [start_j, start_j + cnt_j).  Kept entries (row dropout
+// scale != 0) get compact indices 0 .. nc-1 in entry order.
+struct ItemIdx {
+  uint8_t pos[256];    // sorted index -> position
+  uint8_t start[256];  // entry -> first sorted index (exclusive scan of the counts; L past the last entry)
+  uint8_t cnt[256];    // entry -> occurrences
+  uint8_t cidx[256];   // entry -> compact index, 255 = dropped / no such entry
+  uint8_t ord[256];    // position -> compact index of its word, 255 = dropped
+  uint8_t cj[256];     // compact index -> entry
+  int cw[256];         // compact index -> word id
+  float cs[256];       // compact index -> row-dropout scale
+  int wtot[4];
+  int nc;
+};
+
+// Threads [0, 256) of the workgroup (blockDim >= 256, L <= 254); returns the number of kept entries.
+// fill: cnt_t[w][s] = 1 + entry ordinal of word w in this item (what tower_word_kernel lists).
+__device__ __forceinline__ int item_index(const TowerArgs& a, int item, int s, bool fill, ItemIdx& ix) {
+  const int tid = threadIdx.x, lane = tid & 63, L = a.L;
+  int ew = -1, v = 0, incl = 0;
+  float sc = 0.f;
+  bool keep = false;
+  if (tid < 256) {
+    int ec = 0;
+    if (tid < L) {
+      ew = a.ent_word[(int64_t)item * L + tid];
+      ec = a.ent_cnt[(int64_t)item * L + tid];
+      ix.pos[tid] = a.cnn.item_spos[(int64_t)item * L + tid];
+    }
+    if (ew >= 0) sc = a.train ? word_scale(a, ew) : 1.f;
+    keep = ew >= 0 && sc != 0.f;
+    v = ec | ((int)keep << 16);   // both prefix sums in one scan: counts below, kept flags above
+    incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) ix.wtot[tid >> 6] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += ix.wtot[w];
+    const int excl = base + incl - v, c = excl >> 16;
+    ix.start[tid] = (uint8_t)(excl & 0xFFFF);
+    ix.cnt[tid] = (uint8_t)(v & 0xFFFF);
+    ix.cidx[tid] = keep ? (uint8_t)c : (uint8_t)255;
+    if (keep) {
+      ix.cw[c] = ew;
+      ix.cs[c] = sc;
+      ix.cj[c] = (uint8_t)tid;
+      if (fill) a.cnt_t[(int64_t)ew * a.cap + s] = (uint8_t)(tid + 1);
+    }
+    if (tid == 0) ix.nc = (ix.wtot[0] + ix.wtot[1] + ix.wtot[2] + ix.wtot[3]) >> 16;
+  }
+  __syncthreads();
+  if (tid < L) {   // sorted index tid belongs to the last entry whose start is <= tid (real entries have count >= 1)
+    int lo = 0, hi = L - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int)ix.start[mid] <= tid) lo = mid;
+      else hi = mid - 1;
+    }
+    ix.ord[ix.pos[tid]] = ix.cidx[lo];
+  }
+  __syncthreads();
+  return ix.nc;
+}
+
+// scaled word rows of compact entries [c0, c0 + n) -> sX rows [0, n); rows [n, rows) and the columns past wd: zeros
+__device__ __forceinline__ void stage_words(const TowerArgs& a, const ItemIdx& ix, int c0, int n, int rows, float* sX, int XP) {
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, wd4 = a.wd >> 2, xp4 = XP >> 2;
   const int ng = blockDim.x >> 4;
   for (int r0 = grp; r0 < rows; r0 += 4 * ng) {  // 4 rows of this group in flight
     Row v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = r0 + ng * e, p = p_lo + r;
-      const bool ok = r < rows && p >= 0 && p < a.L && sSc[p >= 0 && p < a.L ? p : 0] != 0.f;
-      v[e] = ok ? row_scale(row_load(a.W, sTok[p], a.wd, wd4, q), sSc[p]) : row_zero();
+      const int r = r0 + ng * e;
+      v[e] = r < n ? row_scale(row_load(a.W, ix.cw[c0 + r], a.wd, wd4, q), ix.cs[c0 + r]) : row_zero();
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -100,148 +182,163 @@ __device__ __forceinline__ void stage_rows(const TowerArgs& a, const int* sTok, 
 
 // ---- forward ---------------------------------------------------------------------------------
 
-// Two workgroups per item (kFwdSplit): each computes half of the positions, so that a group-shared
-// batch of ~100 unique items still fills the 256 CUs.
-constexpr int kFwdSplit = 2;
-// Eight waves per workgroup, two per SIMD: a workgroup is alone on its CU at these batch sizes, and
-// with one wave per SIMD nothing covered the operand loads and the epilogue stores (41 % of the
-// cycles waiting, profiles/r01_cnn_embedding_group_neg_shared_pmc_mfma.txt).
-constexpr int kConvThreads = 512, kConvWaves = kConvThreads / 64;
-constexpr int kFwdMt = 8;  // row tiles of 16 positions per workgroup: L <= 2 * 8 * 16 = 256
+constexpr int kCnnNTG = 2;          // 16-filter tiles per workgroup: 32 filters = one 128-byte run of every Y row
+__host__ __device__ inline int cnn_groups(int F) { return ((F + 15) / 16 + kCnnNTG - 1) / kCnnNTG; }
+constexpr int kCnnCW = 96;          // distinct kept words per pass of the forward (six row tiles): one pass for ~every item
+constexpr int kFwdThreads = 512;    // 8 waves, <= 128 VGPRs, ~80 KB of LDS: two workgroups per CU
+// 16-byte-aligned LDS rows read as 16-byte fragments by 16 consecutive rows at a time: conflict-free when pitch / 4 is odd
+__host__ __device__ inline int odd_pitch(int w) {
+  int p = (w + 3) & ~3;
+  if (((p >> 2) & 1) == 0) p += 4;
+  return p;
+}
+__host__ __device__ inline int fwd_xpitch(int wd, bool exact) { return odd_pitch(exact ? wd : ((wd + 15) & ~15)); }
 
-// NMT / NKT: row tiles per workgroup and 16-column K groups of the word dimension as compile-time
-// loop bounds.  MASK = false: the shape matches exactly (the LDS tile is zero-padded past L and
-// past wd, so no per-fragment guards remain between the MFMAs); MASK = true: any smaller shape.
-// TAIL = 1: word_dim = 16 NKT + 4 -- the last four columns are ONE k-step (lane kq takes column
-// 16 NKT + kq of both operands as dwords) instead of a zero-padded 16-column group of four.
-template <int NMT, int NKT, bool MASK, int TAIL = 0>
-__global__ void __launch_bounds__(kConvThreads) cnn_conv_fwd_kernel(TowerArgs a) {
+// NKT 16-column groups + NTAIL 4-column k-steps cover word_dim exactly (NTAIL: lane kq takes column 16 NKT + 4 tt + kq of both
+// operands as dwords -- 100 = 6 x 16 + 4 costs 25 k-steps instead of 28).  MASK: any smaller width (zero-padded LDS rows,
+// zero filter fragments past wd).
+template <int NKT, int NTAIL, bool MASK, int NTG>
+__global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs a, int ngrp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int sTok[256];
-  __shared__ float sSc[256];
+  __shared__ ItemIdx ix;
   const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile loops and their guards stay on the SALU
-  const int s = blockIdx.x / kFwdSplit, half = blockIdx.x % kFwdSplit;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / ngrp, g = blockIdx.x % ngrp;
   if (s >= valid_rows(a)) return;
   const int item = a.ids[s];
-  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L;
-  const int XP = conv_pitch(a.wd);
-  const int nMtAll = (L + 15) >> 4, nMtH = (nMtAll + kFwdSplit - 1) / kFwdSplit;
-  const int mt0 = half * nMtH;  // this workgroup's row tiles: [mt0, mt0 + nMt)
-  const int nMt = MASK ? min(nMtH, nMtAll - mt0) : NMT, nKt = MASK ? (a.wd + 15) >> 4 : NKT;
-  const int nNt = (F + 15) >> 4;
-  const int p_base = 16 * mt0;
-  const int rows = 16 * nMtH + fl - 1;
-  float* sX = smem;
-  stage_tokens(a, item, sTok, sSc);
-  // backward preparation: cnt_t[w][s] = 1 + ordinal of word w among the item's distinct words
-  if (a.fill && half == 0 && a.cnn.c_off == 0) {   // once per item: by the first bank
-    const int e0 = a.item_ptr[item], e1 = a.item_ptr[item + 1];
-    for (int e = e0 + tid; e < e1; e += kConvThreads) {
-      const int wv = a.item_word[e];
-      if (word_scale(a, wv) != 0.f) a.cnt_t[(int64_t)wv * a.cap + s] = (uint8_t)(e - e0 + 1);
+  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
+  const int KW = fl * wd;
+  const int XP = fwd_xpitch(wd, !MASK), PP = fl * 16 * NTG + 4;   // PP / 4 odd too: the MFMA result's 16-byte stores do not collide
+  float* sX = smem;                        // [kCnnCW][XP]      scaled rows of the distinct kept words
+  float* sP = smem + kCnnCW * XP;          // [kCnnCW + 1][PP]  their projections, all taps, this group's filters; last row: zeros
+  const int nKt = MASK ? (wd + 15) >> 4 : NKT;
+  // (tap, filter tile) strips of P; a wave keeps a strip's filter fragment in registers.  Tiles past F are skipped.
+  const int ntl = min(NTG, (F - 16 * NTG * g + 15) >> 4), nunit = fl * ntl;
+  float4 bf[NKT];
+  float bt[NTAIL ? NTAIL : 1];
+  auto load_b = [&](int u) {
+    // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
+    // 16t+4kq serves k-step (t, e) on both operands)
+    const int tap = u / ntl, col = (g * NTG + u % ntl) * 16 + x;
+    const float* wrow = a.cnn.Wt + (int64_t)col * KW + tap * wd;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int c0 = 16 * t + 4 * kq;
+      bf[t] = (col < F && c0 < wd) ? *reinterpret_cast<const float4*>(wrow + c0) : zero4();
     }
-  }
-  const int KW = fl * a.wd;
-  // B fragments of up to three taps at once (all their loads in flight before the first MFMA):
-  // Wt[col][tap*wd + 16t + 4kq ..+4)  (K index permuted: component e of the float4 at column
-  // 16t+4kq serves k-step (t, e) on both operands)
-  float4 bf[3][NKT];
-  float bt[3] = {0.f, 0.f, 0.f};
-  auto load_b = [&](int nt, int tap0) {
-    const int col = nt * 16 + x;
 #pragma unroll
-    for (int tt = 0; tt < 3; ++tt) {
-      const int tap = tap0 + tt;
-      const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wt + (int64_t)col * KW + tap * a.wd);
-#pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        const int c0 = 16 * t + 4 * kq;
-        bf[tt][t] = (tap < fl && t < nKt && col < F && c0 < a.wd) ? wrow[c0 >> 2] : zero4();
-      }
-      if (TAIL) bt[tt] = (tap < fl && col < F) ? a.cnn.Wt[(int64_t)col * KW + tap * a.wd + 16 * NKT + kq] : 0.f;
+    for (int tt = 0; tt < NTAIL; ++tt) {
+      const int kk = 16 * NKT + 4 * tt + kq;
+      bt[tt] = (col < F && kk < wd) ? wrow[kk] : 0.f;
     }
   };
-  // the wave's first strip is known now: its filter fragments travel while the rows are staged
-  if (wave < nNt) load_b(wave, 0);
-  __syncthreads();
-  if (!(a.cnn.dbg & 2)) stage_rows(a, sTok, sSc, sX, XP, p_base - pad, rows);
-  __syncthreads();
-  for (int nt = wave; nt < nNt; nt += kConvWaves) {
-    f32x4 acc[NMT];
+  cnn_stamp(a, 0, 0);
+  if (wave < nunit) load_b(wave);   // the first strip's fragment travels while the index is built and the rows are gathered
+  if (tid < PP / 4) reinterpret_cast<float4*>(sP + kCnnCW * PP)[tid] = zero4();
+  const int nc = item_index(a, item, s, a.fill && g == 0 && a.cnn.c_off == 0, ix);
+  cnn_stamp(a, 0, 1);
+  constexpr int CH = 4 * NTG;                 // 16-byte chunks of this group's filters per position
+  constexpr int PSTEP = kFwdThreads / CH;     // a thread owns chunk fq of positions prow, prow + PSTEP, ...
+  constexpr int NPOS = (256 + PSTEP - 1) / PSTEP;   // at most this many (L <= 256)
+  const int fq = tid & (CH - 1), prow = tid / CH;
+  float4 yacc[NPOS];
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tap0 = 0; tap0 < ((a.cnn.dbg & 1) ? 0 : fl); tap0 += 3) {
-      if (nt != wave || tap0 != 0) load_b(nt, tap0);
+  for (int j = 0; j < NPOS; ++j) yacc[j] = zero4();
+  for (int c0 = 0; c0 < nc; c0 += kCnnCW) {
+    const int ncl = min(kCnnCW, nc - c0), nmt = (ncl + 15) >> 4;
+    if (c0) __syncthreads();   // the previous pass's assembly has read sP
+    stage_words(a, ix, c0, ncl, 16 * nmt, sX, XP);
+    __syncthreads();
+    cnn_stamp(a, 0, 2);
+    for (int u = wave; u < nunit; u += kFwdThreads / 64) {
+      if (u != wave || c0) load_b(u);
+      const int pcol = ((u / ntl) * NTG + u % ntl) * 16 + 4 * kq;
+      const float* abase = sX + (int64_t)x * XP + 4 * kq;
 #pragma unroll
-      for (int tt = 0; tt < 3; ++tt) {
-        const int tap = tap0 + tt;
-        if (tap < fl) {
-          const float* abase = sX + (int64_t)(x + tap) * XP + 4 * kq;
+      for (int mh = 0; mh < kCnnCW / 16; mh += 3) {   // three row tiles at a time
+        if (mh < nmt) {
+          f32x4 acc[3];
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int t = 0; t < NKT; ++t) {
             if (!MASK || t < nKt) {
-              // all row tiles' A fragments first, then the MFMAs interleaved over the tiles: no two
-              // consecutive MFMAs touch the same accumulator
-              float4 af[NMT];
+              float4 af[3];
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt)
-                af[mt] = (!MASK || mt < nMt) ? *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * XP + 16 * t) : zero4();
+              for (int mt = 0; mt < 3; ++mt) af[mt] = *reinterpret_cast<const float4*>(abase + (int64_t)16 * (mh + mt) * XP + 16 * t);
 #pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].x, af[mt].x, acc[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].y, af[mt].y, acc[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].z, af[mt].z, acc[mt], 0, 0, 0);
-#pragma unroll
-              for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
+              for (int mt = 0; mt < 3; ++mt) {
+                if (mh + mt < nmt) {
+                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t].x, af[mt].x, acc[mt], 0, 0, 0);
+                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t].y, af[mt].y, acc[mt], 0, 0, 0);
+                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t].z, af[mt].z, acc[mt], 0, 0, 0);
+                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t].w, af[mt].w, acc[mt], 0, 0, 0);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);   // one k-group's row fragments in registers at a time (the other waves cover the reads)
             }
           }
-          if (TAIL) {
-            const float* tbase = sX + (int64_t)(x + tap) * XP + 16 * NKT + kq;
-            float at[NMT];
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) at[mt] = tbase[(int64_t)16 * mt * XP];
+          for (int tt = 0; tt < NTAIL; ++tt) {
+            const float* tbase = sX + (int64_t)x * XP + 16 * NKT + 4 * tt + kq;
 #pragma unroll
-            for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[tt], at[mt], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < 3; ++mt)
+              if (mh + mt < nmt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[tt], tbase[(int64_t)16 * (mh + mt) * XP], acc[mt], 0, 0, 0);
           }
+          // the filter fragment is the MFMA's A operand: D[i = 4kq + r][j = x] = P[word 16mt + x][filter 16 tile + 4kq + r]
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt)
+            if (mh + mt < nmt)
+              *reinterpret_cast<float4*>(sP + (int64_t)(16 * (mh + mt) + x) * PP + pcol) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
         }
       }
     }
-    // epilogue.  The filter fragment is the MFMA's A operand, so D[i = 4kq + r][j = x] is filter
-    // 16nt + 4kq + r at position p_base + 16mt + x: a lane owns four consecutive filters of one
-    // position -- one 16-byte store per row tile.  Statistics of (y - b) per filter: over the row
-    // tiles in the lane, then over the 16 position lanes.
-    const int f0 = nt * 16 + 4 * kq;
-    const float4 bias = f0 < F ? *reinterpret_cast<const float4*>(a.cnn.bc + f0) : zero4();
-    float4 s1 = zero4(), s2 = zero4();
+    __syncthreads();
+    cnn_stamp(a, 0, 3);
+    // assembly: Y[p] += P[word of position p + tap - pad][tap] for the words of this pass; a dropped word, a position outside
+    // the text or a word of another pass reads the zero row -- no branches, every read of a position in flight
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-      const int p = p_base + 16 * mt + x;
-      if (mt < nMt && p < L && f0 < F) {
-        const float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-        *reinterpret_cast<float4*>(a.cnn.Y + ((int64_t)s * L + p) * F + f0) = add4(v, bias);
-        s1 = add4(s1, v);
-        s2 = fma4v(v, v, s2);
+    for (int j = 0; j < NPOS; ++j) {
+      const int p = prow + j * PSTEP;
+      if (p < L) {
+        for (int tap = 0; tap < fl; ++tap) {
+          const int pp = p + tap - pad;
+          const int o = (int)ix.ord[min(max(pp, 0), L - 1)] - c0;
+          const int row = ((unsigned)pp < (unsigned)L && (unsigned)o < (unsigned)ncl) ? o : kCnnCW;   // ord = 255 - c0 >= ncl only while
+          yacc[j] = add4(yacc[j], *reinterpret_cast<const float4*>(sP + (int64_t)row * PP + tap * 16 * NTG + 4 * fq));   // c0 + ncl <= 254: L <= 254
+        }
       }
     }
+  }
+  cnn_stamp(a, 0, 4);
+  // epilogue: Y = assembled + b in 16-byte stores (a position's CH chunks = one contiguous run); statistics of (y - b)
+  // per filter: over the thread's positions, then over the PSTEP threads that share a chunk, in thread order
+  const int f0 = 16 * NTG * g + 4 * fq;
+  const float4 bias = f0 < F ? *reinterpret_cast<const float4*>(a.cnn.bc + f0) : zero4();
+  float4 s1 = zero4(), s2 = zero4();
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-      s1.x += __shfl_xor(s1.x, m);
-      s1.y += __shfl_xor(s1.y, m);
-      s1.z += __shfl_xor(s1.z, m);
-      s1.w += __shfl_xor(s1.w, m);
-      s2.x += __shfl_xor(s2.x, m);
-      s2.y += __shfl_xor(s2.y, m);
-      s2.z += __shfl_xor(s2.z, m);
-      s2.w += __shfl_xor(s2.w, m);
-    }
-    if (x == 0 && a.train) {  // columns past F: zeros (their filter fragments are zero)
-      float* part = a.cnn.part1 + (int64_t)blockIdx.x * 256;
-      *reinterpret_cast<float4*>(part + f0) = s1;
-      *reinterpret_cast<float4*>(part + 128 + f0) = s2;
+  for (int j = 0; j < NPOS; ++j) {
+    const int p = prow + j * PSTEP;
+    if (p < L && f0 < F) {
+      *reinterpret_cast<float4*>(a.cnn.Y + ((int64_t)s * L + p) * F + f0) = add4(yacc[j], bias);
+      s1 = add4(s1, yacc[j]);
+      s2 = fma4v(yacc[j], yacc[j], s2);
     }
   }
+  if (!a.train) return;
+  __syncthreads();
+  cnn_stamp(a, 0, 5);
+  float4* red = reinterpret_cast<float4*>(smem);   // [PSTEP][2][CH]
+  red[(prow * 2 + 0) * CH + fq] = s1;
+  red[(prow * 2 + 1) * CH + fq] = s2;
+  __syncthreads();
+  if (tid < 2 * CH) {
+    float4 t = zero4();
+    for (int r = 0; r < PSTEP; ++r) t = add4(t, red[r * 2 * CH + tid]);
+    const int f = 16 * NTG * g + 4 * (tid & (CH - 1));
+    if (f < 128) *reinterpret_cast<float4*>(a.cnn.part1 + (int64_t)s * 256 + (tid / CH) * 128 + f) = t;   // zeros past F
+  }
+  cnn_stamp(a, 0, 6);
 }
 
 // column totals of per-slot partials [n][2][128] in slot order (1024 threads: 8 slot groups x 128)
@@ -279,7 +376,7 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int nv = valid_rows(a), c = threadIdx.x;
   float t1, t2;
-  merge_slot_partials(a.cnn.part1, nv * kFwdSplit, sRed, t1, t2);
+  merge_slot_partials(a.cnn.part1, nv, sRed, t1, t2);
   if (c < 128) {
     float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
     if (c < a.cnn.F) {
@@ -589,363 +686,358 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   }
 }
 
-// One workgroup per (slot, block of kConvLB positions).  NFT: 16-column groups of the filter
-// dimension as a compile-time bound of (a)'s K loop (MASK = false: exactly ceil(F/16) == NFT).
-// TAIL = 1: F = 16 NFT + 4 -- (a)'s last four filters are one k-step of dword operands (as in the forward).
-template <int NFT, bool MASK, int TAIL = 0>
-__global__ void __launch_bounds__(kConvThreads) cnn_conv_bwd_kernel(TowerArgs a, int nblk) {
+
+// One workgroup per (slot, group of 16 NTG filters).  FLMAX: compile-time bound of the filter length (register arrays).
+//   dY tile  [L + fl - 1][16 NTG]: BN1 backward of da, zero outside [0, L)                          -> LDS
+//   S'       [n_c][fl][16 NTG] = scale_c * (per distinct kept word c, the sum of the dY rows its positions see, per tap):
+//            LDS -> LDS, positions in order; one 8-lane group per (word, tap), a 32-lane team per (heavy word, tap) whose
+//            four groups take every fourth position and meet by two shuffles (the pad id's ~100 rows: 25 reads per group)
+//   (a) partial dL/dW[w_c][k] = sum_{tap, f in group} S'[c][tap][f] Wk[tap][k][f]        M = n_c, N = wd, K = fl 16 NTG
+//   (b) dWk[tap][k][f in group] = sum_c W[w_c][k] S'[c][tap][f]                           M = 16 NTG, N = wd, K = n_c
+// A wave owns 16-column strips kt of wd for BOTH products: Wk's fragment of the strip ((a)'s A operand) and the words' rows
+// of the strip ((b)'s B operand, straight from the table: no LDS copy of the rows) are requested before S' is built and
+// arrive under it.  Words in passes of kCnnCWB; (b)'s accumulators stay in registers across the passes, so an item leaves
+// ONE dWk block.  A ragged filter tile (F = 100: the last group holds 4 filters) costs (a) one dword k-step per tap.
+constexpr int kCnnCWB = 96;
+constexpr int kHeavy = 16;         // a word with more positions than this is summed by a 32-lane team
+// kBwdThreads = 512 (filter lengths <= 3): 8 waves, <= 128 VGPRs, ~72 KB of LDS: two workgroups per CU; 256 for the longer
+// filters' register arrays (one strip pair per wave)
+template <int NTG, int FLMAX, int kBwdThreads>
+__global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_conv_bwd_kernel(TowerArgs a, int ngrp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int sTok[256];
-  __shared__ float sSc[256];
-  __shared__ float sMu[128], sInv[128], sMul[128], sAdd[128], sS1[128], sS2[128];
-  __shared__ int sNext;
+  __shared__ ItemIdx ix;
+  __shared__ __attribute__((aligned(16))) float4 sGb[(kBwdThreads / 64) * 4 * NTG];
+  __shared__ uint8_t sHeavy[128];
+  __shared__ int sNH[2];
+  constexpr int NW = kBwdThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
-  const int grp = tid >> 4, q = tid & 15;
-  const int s = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / ngrp, g = blockIdx.x % ngrp;
   const int nv = valid_rows(a);
   if (s >= nv) return;
   const int item = a.ids[s];
-  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, f4 = F >> 2;
-  const int XP = conv_pitch32(a.wd), FP = conv_pitch32(F);  // (b) reads both tiles dword-wise, 2 per MFMA
-  const int p0 = blk * kConvLB;
-  const int rows = kConvLB + fl - 1;       // positions [p0 - pad, p0 + kConvLB + pad)
-  float* sX = smem;                        // [rows][XP]  gathered (scaled) word rows
-  float* sD = smem + (int64_t)rows * XP;   // [rows][FP]  dY
-  stage_tokens(a, item, sTok, sSc);
-  if (tid == 0) sNext = 0;
-  if (tid < 128) {
-    sMu[tid] = a.cnn.st1[tid];
-    sInv[tid] = a.cnn.st1[128 + tid];
-    sMul[tid] = a.cnn.st1[384 + tid];
-    sAdd[tid] = a.cnn.st1[512 + tid];
-    sS1[tid] = a.cnn.st1[640 + tid];
-    sS2[tid] = a.cnn.st1[768 + tid];
-  }
+  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
+  constexpr int CH = 4 * NTG, FW = 16 * NTG;
+  const int DP = FW + 4;                  // dY tile pitch: rows 4 banks apart
+  const int SP = fl * FW + 4;             // SP / 4 odd: conflict-free 16-byte fragment reads in (a)
+  const int rows = L + fl - 1;            // positions [-pad, L + pad)
+  float* sD = smem;                       // [rows][DP]
+  float* sS = sD + (int64_t)rows * DP;    // [kCnnCWB][SP]
+  // this thread's four filters: every per-filter factor lives in registers
+  const int fq = tid & (CH - 1), f0 = FW * g + 4 * fq;
+  const bool fok = f0 < F;
   const bool maxp = a.cnn.pool_max != 0;
-  const Row dhr = row_scale(row_load(a.dh + a.cnn.c_off, s, a.hd, f4, q), maxp ? 1.f : 1.f / (float)L);
-  int am[8];   // max pooling: the position whose activation was the item's maximum in this lane's eight columns
+  cnn_stamp(a, 1, 0);
+  // the first round of Y rows does not wait for the index
+  constexpr int NY = 4;
+  const int nit = rows * CH;
+  float4 y[NY];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) am[k] = (maxp && col_of(q, k) < F) ? (int)a.cnn.amax[(int64_t)s * 128 + col_of(q, k)] : -1;
-  __syncthreads();
-  stage_rows(a, sTok, sSc, sX, XP, p0 - pad, rows);
+  for (int e = 0; e < NY; ++e) {
+    const int i = tid + e * kBwdThreads, p = i / CH - pad;
+    y[e] = (i < nit && fok && (unsigned)p < (unsigned)L) ? *reinterpret_cast<const float4*>(a.cnn.Y + ((int64_t)s * L + p) * F + f0) : zero4();
+  }
+  float4 cmu = zero4(), cinv = zero4(), cmul = zero4(), cadd = zero4(), cs1 = zero4(), cs2 = zero4(), cdh = zero4();
+  int am[4] = {-1, -1, -1, -1};
+  if (fok) {
+    cmu = *reinterpret_cast<const float4*>(a.cnn.st1 + f0);
+    cinv = *reinterpret_cast<const float4*>(a.cnn.st1 + 128 + f0);
+    cmul = *reinterpret_cast<const float4*>(a.cnn.st1 + 384 + f0);
+    cadd = *reinterpret_cast<const float4*>(a.cnn.st1 + 512 + f0);
+    cs1 = *reinterpret_cast<const float4*>(a.cnn.st1 + 640 + f0);
+    cs2 = *reinterpret_cast<const float4*>(a.cnn.st1 + 768 + f0);
+    cdh = scale4(*reinterpret_cast<const float4*>(a.dh + (int64_t)s * a.hd + a.cnn.c_off + f0), maxp ? 1.f : 1.f / (float)L);
+    if (maxp) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) am[k] = (int)a.cnn.amax[(int64_t)s * 128 + f0 + k];
+    }
+  }
+  const int nc = item_index(a, item, s, false, ix);
+  cnn_stamp(a, 1, 1);
   // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
+  float4 gb = zero4();   // column sums over the item's positions: the conv bias gradient
   {
     const float N = (float)nv * (float)L, rN = 1.f / N;
-    Row rmu = row_load(a.cnn.st1, 0, 128, 32, q), rinv = row_load(a.cnn.st1 + 128, 0, 128, 32, q);
-    Row rmul = row_load(a.cnn.st1 + 384, 0, 128, 32, q), radd = row_load(a.cnn.st1 + 512, 0, 128, 32, q);
-    Row rs1 = row_load(a.cnn.st1 + 640, 0, 128, 32, q), rs2 = row_load(a.cnn.st1 + 768, 0, 128, 32, q);
-    const int fp4 = FP >> 2;
-    constexpr int ng = kConvThreads / 16;
-    for (int r0 = grp; r0 < rows; r0 += 4 * ng) {
-      Row y[4];
+    const float mu[4] = {cmu.x, cmu.y, cmu.z, cmu.w}, iv[4] = {cinv.x, cinv.y, cinv.z, cinv.w};
+    const float ml[4] = {cmul.x, cmul.y, cmul.z, cmul.w}, ad[4] = {cadd.x, cadd.y, cadd.z, cadd.w};
+    const float t1[4] = {cs1.x, cs1.y, cs1.z, cs1.w}, t2[4] = {cs2.x, cs2.y, cs2.z, cs2.w}, dh[4] = {cdh.x, cdh.y, cdh.z, cdh.w};
+    for (int i0 = tid; i0 < nit; i0 += NY * kBwdThreads) {
+      if (i0 != tid) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = r0 + ng * e, p = p0 - pad + r;
-        y[e] = (r < rows && p >= 0 && p < L) ? row_load(a.cnn.Y, (int64_t)s * L + p, F, f4, q) : row_zero();
+        for (int e = 0; e < NY; ++e) {
+          const int i = i0 + e * kBwdThreads, p = i / CH - pad;
+          y[e] = (i < nit && fok && (unsigned)p < (unsigned)L) ? *reinterpret_cast<const float4*>(a.cnn.Y + ((int64_t)s * L + p) * F + f0) : zero4();
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = r0 + ng * e, p = p0 - pad + r;
-        if (r < rows) {
-          Row o = row_zero();
-          if (p >= 0 && p < L) {
-            Row dd = dhr;
+      for (int e = 0; e < NY; ++e) {
+        const int i = i0 + e * kBwdThreads, r = i / CH, p = r - pad;
+        if (i < nit) {
+          float4 o = zero4();
+          if (fok && (unsigned)p < (unsigned)L) {
+            const float yy[4] = {y[e].x, y[e].y, y[e].z, y[e].w};
+            float ov[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const int c = col_of(q, k);
-              const float yv = relem(y[e], k);
-              float da = conv_da(a, relem(dd, k), fmaf(yv, relem(rmul, k), relem(radd, k)), (int64_t)s * L + p, c);
+            for (int k = 0; k < 4; ++k) {
+              float da = conv_da(a, dh[k], fmaf(yy[k], ml[k], ad[k]), (int64_t)s * L + p, f0 + k);
               if (maxp && p != am[k]) da = 0.f;
-              relem(o, k) = relem(rmul, k) * rN * (N * da - relem(rs1, k) - (yv - relem(rmu, k)) * relem(rinv, k) * relem(rs2, k));
+              ov[k] = ml[k] * rN * (N * da - t1[k] - (yy[k] - mu[k]) * iv[k] * t2[k]);
             }
+            o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            gb = add4(gb, o);
           }
-          float4* dst = reinterpret_cast<float4*>(sD + (int64_t)r * FP);
-          if (q < fp4) dst[q] = o.a;  // mul = 0 past F: those columns are exactly 0
-          if (q + 16 < fp4) dst[q + 16] = o.b;
+          *reinterpret_cast<float4*>(sD + (int64_t)r * DP + 4 * fq) = o;
         }
       }
     }
   }
-  __syncthreads();
-  const int nMb = kConvLB / 16;
-  // The two MFMA parts only read the LDS tiles, so their pieces -- (a) one 16-column strip of dX,
-  // (b) one 2 x 2 tile block of one tap's dWk -- go through ONE queue that the eight waves drain as
-  // they become free (LDS counter; which wave computes a piece does not change its value).  The
-  // long (a) strips are handed out first, then (b) blocks from full to ragged: the four SIMDs finish
-  // together, and waves drift out of phase, so one wave's operand loads and stores sit under the
-  // other's MFMAs.  Static per-wave loops left one SIMD half idle and the waves in lock step.
-  const int nKw = (a.wd + 15) >> 4, nFt = (F + 15) >> 4;
-  const int nKp = (nKw + 1) >> 1, nFp = (nFt + 1) >> 1, nKf = nKw >> 1, nFf = nFt >> 1;
-  const int nblock = fl * nKp * nFp;
-  const int nA = (a.cnn.dbg & 4) ? 0 : nKw, nB = (a.cnn.dbg & 8) ? 0 : nblock;
-  // dWk partials, element-group major: gWpart[element / 64][part = this workgroup][64] -- the update workgroup of an element
-  // group then reads ONE contiguous run of (parts x 256 B) instead of 256-byte pieces 120 KB apart
-  const int64_t gw_parts = (int64_t)a.cap * nblk;
-  float* gw = a.cnn.gWpart + (int64_t)blockIdx.x * kCnnUpdElems;
-  if (tid >= kConvThreads - 128) {  // column sums of dY over the block's own positions (conv bias
-    const int c = tid - (kConvThreads - 128);  // gradient): the last two waves, before they join the queue
-    float t = 0.f;
-    if (c < F) {
-#pragma unroll 8
-      for (int r = pad; r < pad + kConvLB; ++r) t += sD[(int64_t)r * FP + c];
-    }
-    a.cnn.gbpart[(int64_t)blockIdx.x * 128 + c] = t;
+  // conv bias gradient of this item: the wave's eight threads of a chunk by shuffles, the waves in wave order
+#pragma unroll
+  for (int o = CH; o < 64; o <<= 1) {
+    gb.x += __shfl_xor(gb.x, o);
+    gb.y += __shfl_xor(gb.y, o);
+    gb.z += __shfl_xor(gb.z, o);
+    gb.w += __shfl_xor(gb.w, o);
   }
-  for (;;) {
-    int piece = 0;
-    if (lane == 0) piece = atomicAdd(&sNext, 1);
-    piece = __builtin_amdgcn_readfirstlane(piece);
-    if (piece >= nA + nB) break;
-    if (piece < nA) {
-      // ---- (a) dX[p][k] = sum_tap sum_f dY[p - tap + pad][f] Wk[tap][k][f] ----------------------
-      const int kt = piece;
-      const int kcol = kt * 16 + x;
-      f32x4 acc[kConvLB / 16];
+  if (lane < CH) sGb[wave * CH + lane] = gb;
+  __syncthreads();
+  cnn_stamp(a, 1, 2);
+  if (tid < CH) {
+    float4 t = zero4();
 #pragma unroll
-      for (int mt = 0; mt < nMb; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int tap0 = 0; tap0 < fl; tap0 += 3) {
-        float4 bf[3][NFT];
-        float bt[3] = {0.f, 0.f, 0.f};
+    for (int w = 0; w < NW; ++w) t = add4(t, sGb[w * CH + tid]);
+    const int f = FW * g + 4 * tid;
+    if (f < 128) *reinterpret_cast<float4*>(a.cnn.gbpart + (int64_t)s * 128 + f) = t;
+  }
+  const int nKw = (wd + 15) >> 4;
+  const int ntl = min(NTG, (F - FW * g + 15) >> 4);           // filter tiles of this group that hold a real filter
+  const int nfull = min(NTG, max(0, (F - FW * g) >> 4));        // ... that are full; the next one (if any) holds nrag4 x 4 filters
+  const int nrag4 = nfull < ntl ? ((F - FW * g - 16 * nfull) >> 2) : 0;
+  constexpr int KPW = (8 + NW - 1) / NW;      // wd strips per wave (wd <= 128)
+  // this item's dWk block of the group's filters, element-group major: gWpart[element / 64][slot][64] -- the update workgroup of
+  // an element group reads ONE contiguous run of (slots x 256 B).  Always written (zeros for an item whose words were all
+  // dropped); a second pass of words (more than kCnnCWB kept: rare) adds to what the first one stored.
+  float* gw = a.cnn.gWpart + (int64_t)s * kCnnUpdElems;
+  auto put_tile = [&](const f32x4& c, int kt, int tap, int ftl, bool add) {
+    const int k = kt * 16 + x, f = FW * g + 16 * ftl + 4 * kq;
+    if (k < wd && f < F) {   // streaming stores: read once by cnn_update -- not worth L2 lines
+      const int64_t el = ((int64_t)tap * wd + k) * F + f;   // a multiple of 4: the four floats stay in one group of 64
+      float* dst = gw + (el / kCnnUpdElems) * (int64_t)a.cap * kCnnUpdElems + (el % kCnnUpdElems);
+      float4 v = make_float4(c[0], c[1], c[2], c[3]);
+      if (add) v = add4(v, *reinterpret_cast<const float4*>(dst));
+      __builtin_nontemporal_store(v.x, dst);
+      __builtin_nontemporal_store(v.y, dst + 1);
+      __builtin_nontemporal_store(v.z, dst + 2);
+      __builtin_nontemporal_store(v.w, dst + 3);
+    }
+  };
+  if (nc == 0) {
+    for (int ks = 0; ks < KPW; ++ks)
+      for (int tap = 0; tap < fl; ++tap)
+        for (int ftl = 0; ftl < ntl; ++ftl)
+          if (wave + NW * ks < nKw) put_tile(f32x4{0.f, 0.f, 0.f, 0.f}, wave + NW * ks, tap, ftl, false);
+  }
+  float* dxw = a.cnn.dXw + (int64_t)g * a.cnn.pstride;
+  for (int c0 = 0; c0 < nc; c0 += kCnnCWB) {
+    const int ncl = min(kCnnCWB, nc - c0), nmt = (ncl + 15) >> 4, nst = (ncl + 3) >> 2;
+    if (c0) __syncthreads();   // the previous pass's MFMAs have read sS
+    // heavy words of the pass (one wave lists them by ballot, in word order)
+    if (wave == 0) {
+      int nh = 0;
+      for (int b0 = 0; b0 < ncl; b0 += 64) {
+        const int cl = b0 + lane;
+        const bool hv = cl < ncl && (int)ix.cnt[ix.cj[c0 + cl]] > kHeavy;
+        const unsigned long long m = __ballot(hv);
+        if (hv) sHeavy[nh + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)cl;
+        nh += __popcll(m);
+      }
+      if (lane == 0) sNH[0] = nh;
+    }
+    // this wave's strip of wd: Wk's fragment ((a)) and the words' table rows ((b)) travel while S' is built
+    float4 wf[KPW][FLMAX * NTG];
+    float wr[KPW][FLMAX];      // the ragged tile's dword fragment: filter 16 nfull + 4 tt + kq, tt < nrag4 <= 3 (one per tap: nrag4 == 1 only)
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-          const int tap = tap0 + tt;
-          const float4* wrow = reinterpret_cast<const float4*>(a.cnn.Wk + ((int64_t)tap * a.wd + kcol) * F);
+    for (int ks = 0; ks < KPW; ++ks) {
+      const int kt = wave + NW * ks, kcol = kt * 16 + x;
 #pragma unroll
-          for (int t = 0; t < NFT; ++t) {
-            const int c0 = 16 * t + 4 * kq;
-            bf[tt][t] = (tap < fl && t < (TAIL ? NFT : nFt) && kcol < a.wd && c0 < F) ? wrow[c0 >> 2] : zero4();
-          }
-          if (TAIL) bt[tt] = (tap < fl && kcol < a.wd) ? a.cnn.Wk[((int64_t)tap * a.wd + kcol) * F + 16 * NFT + kq] : 0.f;
+      for (int tap = 0; tap < FLMAX; ++tap) {
+#pragma unroll
+        for (int ftl = 0; ftl < NTG; ++ftl) {
+          const int fc = FW * g + 16 * ftl + 4 * kq;
+          wf[ks][tap * NTG + ftl] = (kt < nKw && tap < fl && ftl < ntl && kcol < wd && fc < F)
+                                        ? *reinterpret_cast<const float4*>(a.cnn.Wk + ((int64_t)tap * wd + kcol) * F + fc) : zero4();
         }
+        const int fr = FW * g + 16 * nfull + kq;
+        wr[ks][tap] = (kt < nKw && tap < fl && nrag4 == 1 && kcol < wd && fr < F) ? a.cnn.Wk[((int64_t)tap * wd + kcol) * F + fr] : 0.f;
+      }
+    }
+    __syncthreads();   // sHeavy / sNH
+    const int nh = sNH[0];
+    // S' rows of the pass (rows past ncl: zeros -- they are K rows of (b))
+    {   // light words and the zero rows: one 8-lane group per (word, tap)
+      for (int u = tid / CH; u < 16 * nmt * fl; u += kBwdThreads / CH) {
+        const int cl = u / fl, tap = u - cl * fl;
+        float4 acc = zero4();
+        bool mine = true;
+        if (cl < ncl) {
+          const int j = ix.cj[c0 + cl], st = ix.start[j], cn = ix.cnt[j];
+          mine = cn <= kHeavy;
+          if (mine) {
+            const float* src = sD + (int64_t)(fl - 1 - tap) * DP + 4 * fq;
+            int i = 0;
+            for (; i + 4 <= cn; i += 4) {
+              const float4 r0 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i] * DP);
+              const float4 r1 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 1] * DP);
+              const float4 r2 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 2] * DP);
+              const float4 r3 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 3] * DP);
+              acc = add4(add4(add4(add4(acc, r0), r1), r2), r3);
+            }
+            for (; i < cn; ++i) acc = add4(acc, *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i] * DP));
+            acc = scale4(acc, ix.cs[c0 + cl]);
+          }
+        }
+        if (mine) *reinterpret_cast<float4*>(sS + (int64_t)cl * SP + tap * FW + 4 * fq) = acc;
+      }
+      // heavy words: a team of four 8-lane groups per (word, tap); group t takes positions t, t + 4, ...
+      constexpr int TEAM = 4 * CH;
+      const int team = tid / TEAM, tg = (tid % TEAM) / CH;
+      for (int u = team; u < nh * fl; u += kBwdThreads / TEAM) {
+        const int hi = u / fl, tap = u - hi * fl, cl = sHeavy[hi];
+        const int j = ix.cj[c0 + cl], st = ix.start[j], cn = ix.cnt[j];
+        const float* src = sD + (int64_t)(fl - 1 - tap) * DP + 4 * fq;
+        float4 acc = zero4();
+        int i = tg;
+        for (; i + 12 < cn; i += 16) {
+          const float4 r0 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i] * DP);
+          const float4 r1 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 4] * DP);
+          const float4 r2 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 8] * DP);
+          const float4 r3 = *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i + 12] * DP);
+          acc = add4(add4(add4(add4(acc, r0), r1), r2), r3);
+        }
+        for (; i < cn; i += 4) acc = add4(acc, *reinterpret_cast<const float4*>(src + (int64_t)ix.pos[st + i] * DP));
 #pragma unroll
-        for (int tt = 0; tt < 3; ++tt) {
-          const int tap = tap0 + tt;
-          if (tap < fl) {
-            const float* abase = sD + (int64_t)(x + (fl - 1 - tap)) * FP + 4 * kq;
+        for (int o = CH; o < TEAM; o <<= 1) {   // (0 + 1) + (2 + 3): the same order in every lane
+          acc.x += __shfl_xor(acc.x, o);
+          acc.y += __shfl_xor(acc.y, o);
+          acc.z += __shfl_xor(acc.z, o);
+          acc.w += __shfl_xor(acc.w, o);
+        }
+        if (tg == 0) *reinterpret_cast<float4*>(sS + (int64_t)cl * SP + tap * FW + 4 * fq) = scale4(acc, ix.cs[c0 + cl]);
+      }
+    }
+    __syncthreads();
+    cnn_stamp(a, 1, 3);
+    float xb[KPW][kCnnCWB / 4];   // the words' rows of the strip: requested now, used after (a)
 #pragma unroll
-            for (int t = 0; t < NFT; ++t) {
-              if (!MASK || t < nFt) {
-                float4 af[kConvLB / 16];
+    for (int ks = 0; ks < KPW; ++ks) {
+      const int kt = wave + NW * ks, kcol = kt * 16 + x;
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) af[mt] = *reinterpret_cast<const float4*>(abase + (int64_t)16 * mt * FP + 16 * t);
+      for (int st = 0; st < kCnnCWB / 4; ++st) {
+        const int cl = 4 * st + kq;
+        xb[ks][st] = (kt < nKw && cl < ncl && kcol < wd) ? a.W[(int64_t)ix.cw[c0 + cl] * wd + kcol] : 0.f;
+      }
+    }
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].x, af[mt].x, acc[mt], 0, 0, 0);
+    for (int ks = 0; ks < KPW; ++ks) {
+      const int kt = wave + NW * ks;
+      if (kt < nKw) {
+        // ---- (a) partial dL/dW rows of the pass's words, columns [16kt, 16kt + 16) -----------------------------------
+        // the filter fragment is the A operand: D[i = 4kq + r][j = x] = dL/dW[word 16mt + x][16kt + 4kq + r]
+        const int k0 = kt * 16 + 4 * kq;
+        const float* abase = sS + (int64_t)x * SP + 4 * kq;
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].y, af[mt].y, acc[mt], 0, 0, 0);
+        for (int mh = 0; mh < kCnnCWB / 16; mh += 3) {   // three row tiles at a time
+          if (mh < nmt) {
+            f32x4 acc[3];
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].z, af[mt].z, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < 3; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[tt][t].w, af[mt].w, acc[mt], 0, 0, 0);
+            for (int tap = 0; tap < FLMAX; ++tap) {
+              if (tap < fl) {
+#pragma unroll
+                for (int ftl = 0; ftl < NTG; ++ftl) {
+                  if (ftl < nfull) {
+                    const float4 w4 = wf[ks][tap * NTG + ftl];
+                    float4 af[3];
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) af[mt] = *reinterpret_cast<const float4*>(abase + (int64_t)16 * (mh + mt) * SP + (tap * NTG + ftl) * 16);
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) {
+                      if (mh + mt < nmt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, af[mt].x, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, af[mt].y, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, af[mt].z, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, af[mt].w, acc[mt], 0, 0, 0);
+                      }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one (tap, tile) group's S' fragments in registers at a time
+                  } else if (ftl < ntl) {   // the ragged tile
+                    if (nrag4 == 1) {       // four filters: ONE k-step, lane kq takes filter 16 nfull + kq of both operands
+                      const float* tb = sS + (int64_t)x * SP + (tap * NTG + ftl) * 16 + kq;
+#pragma unroll
+                      for (int mt = 0; mt < 3; ++mt)
+                        if (mh + mt < nmt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[ks][tap], tb[(int64_t)16 * (mh + mt) * SP], acc[mt], 0, 0, 0);
+                    } else {                // 8 or 12 filters: the zero-padded 16-filter group
+                      const float4 w4 = wf[ks][tap * NTG + ftl];
+#pragma unroll
+                      for (int mt = 0; mt < 3; ++mt) {
+                        if (mh + mt < nmt) {
+                          const float4 af = *reinterpret_cast<const float4*>(abase + (int64_t)16 * (mh + mt) * SP + (tap * NTG + ftl) * 16);
+                          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, af.x, acc[mt], 0, 0, 0);
+                          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, af.y, acc[mt], 0, 0, 0);
+                          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, af.z, acc[mt], 0, 0, 0);
+                          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, af.w, acc[mt], 0, 0, 0);
+                        }
+                      }
+                    }
+                  }
+                }
               }
             }
-            if (TAIL) {
-              const float* tbase = sD + (int64_t)(x + (fl - 1 - tap)) * FP + 16 * NFT + kq;
-              float at[kConvLB / 16];
 #pragma unroll
-              for (int mt = 0; mt < nMb; ++mt) at[mt] = tbase[(int64_t)16 * mt * FP];
+            for (int mt = 0; mt < 3; ++mt) {
+              const int cl = 16 * (mh + mt) + x;
+              if (mh + mt < nmt && cl < ncl && k0 < wd) {
+                float4* dst = reinterpret_cast<float4*>(dxw + ((int64_t)s * L + ix.cj[c0 + cl]) * wd + k0);
+                float4 v = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+                if (a.cnn.dx_acc) v = add4(*dst, v);   // a filter bank: dL/dW is the sum over the banks, in bank order
+                *dst = v;
+              }
+            }
+          }
+        }
+        cnn_stamp(a, 1, 4);
+        // ---- (b) dWk tiles of the strip: K = the pass's words; S' one dword per lane from LDS, the rows from registers ----
+        // dY's side is the MFMA's A operand: D[i = 4kq + r][j = x] = dWk[tap][16kt + x][16ftl + 4kq + r]
 #pragma unroll
-              for (int mt = 0; mt < nMb; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bt[tt], at[mt], acc[mt], 0, 0, 0);
+        for (int tap = 0; tap < FLMAX; ++tap) {
+          if (tap < fl) {
+#pragma unroll
+            for (int ftl = 0; ftl < NTG; ++ftl) {
+              if (ftl < ntl) {
+                const float* pa = sS + (int64_t)kq * SP + (tap * NTG + ftl) * 16 + x;
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st0 = 0; st0 < kCnnCWB / 4; st0 += 4) {   // four k-steps' operands in flight
+                  if (st0 < nst) {   // rows past the pass's words are zero in S'
+                    float av[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = pa[(int64_t)4 * (st0 + e) * SP];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], xb[ks][st0 + e], c, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+                }
+                put_tile(c, kt, tap, ftl, c0 > 0);
+              }
             }
           }
         }
       }
-      // the filter fragment is the A operand: D[i = 4kq + r][j = x] = dX[p0 + 16mt + x][16kt + 4kq + r],
-      // four consecutive columns of one position per lane -- one 16-byte store per row tile
-      const int k0 = kt * 16 + 4 * kq;
-#pragma unroll
-      for (int mt = 0; mt < nMb; ++mt) {
-        const int p = p0 + 16 * mt + x;
-        if (p < L && k0 < a.wd && !(a.cnn.dbg & 32)) {
-          const float sc = sSc[p];
-          float4* dst = reinterpret_cast<float4*>(a.cnn.dX + ((int64_t)s * L + p) * a.wd + k0);
-          float4 v = make_float4(acc[mt][0] * sc, acc[mt][1] * sc, acc[mt][2] * sc, acc[mt][3] * sc);
-          if (a.cnn.dx_acc) v = add4(*dst, v);   // a filter bank: dL/dX is the sum over the banks, in bank order
-          *dst = v;
-        }
-      }
-    } else {
-      // ---- (b) partial dWk[tap][k][f] = sum_{p in block} X[p + tap - pad][k] dY[p][f] ------------
-      // 2 x 2 register blocking: a wave computes tiles (kt, kt+1) x (ft, ft+1) of one tap together --
-      // two A and two B dwords from LDS feed four MFMAs on independent accumulators.  Order: all
-      // taps of the full blocks, then the blocks ragged in F, in K, in both.
-      const int j = piece - nA, tap = j % fl;
-      int r = j / fl, kp, fp;
-      if (r < nKf * nFf) {
-        kp = r / nFf;
-        fp = r % nFf;
-      } else {
-        r -= nKf * nFf;
-        const int nRf = (nFp > nFf) ? nKf : 0;  // blocks whose second F tile is missing
-        if (r < nRf) {
-          kp = r;
-          fp = nFf;
-        } else if (r - nRf < ((nKp > nKf) ? nFf : 0)) {
-          kp = nKf;
-          fp = r - nRf;
-        } else {
-          kp = nKf;
-          fp = nFf;
-        }
-      }
-      const int kt0 = 2 * kp, ft0 = 2 * fp;
-      const bool k1 = kt0 + 1 < nKw, f1 = ft0 + 1 < nFt;
-      f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
-      const float* pa0 = sX + (int64_t)(kq + tap) * XP + kt0 * 16 + x;   // position p0 + 4st + kq, shifted by the tap
-      const float* pb0 = sD + (int64_t)(kq + pad) * FP + ft0 * 16 + x;
-      // K loop over the block's positions in groups of four k-steps, the next group's operands
-      // loaded before the current group's MFMAs (straight-line code per (k1, f1) case: a guard per
-      // MFMA would end the basic block and with it the overlap)
-      auto kloop = [&](auto K1, auto F1) {
-        constexpr bool kk = decltype(K1)::value, ff = decltype(F1)::value;
-        constexpr int NS = kConvLB / 4, G = 2, NG = NS / G;
-        static_assert(NS % G == 0, "kConvLB must be a multiple of 8");
-        float A0[2][G], A1[2][G], B0[2][G], B1[2][G];
-        auto load = [&](int g, int buf) {
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            const int st = g * G + u;
-            A0[buf][u] = pa0[(int64_t)4 * st * XP];
-            B0[buf][u] = pb0[(int64_t)4 * st * FP];
-            if (kk) A1[buf][u] = pa0[(int64_t)4 * st * XP + 16];
-            if (ff) B1[buf][u] = pb0[(int64_t)4 * st * FP + 16];
-          }
-        };
-        load(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          if (g + 1 < NG) load(g + 1, (g + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
-#pragma unroll
-          for (int u = 0; u < G; ++u) {
-            const int b = g & 1;
-            // dY is the MFMA's A operand: D[i = 4kq + r][j = x] = dWk[tap][16kt + x][16ft + 4kq + r]
-            acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(B0[b][u], A0[b][u], acc00, 0, 0, 0);
-            if (ff) acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(B1[b][u], A0[b][u], acc01, 0, 0, 0);
-            if (kk) acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(B0[b][u], A1[b][u], acc10, 0, 0, 0);
-            if (kk && ff) acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(B1[b][u], A1[b][u], acc11, 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      using T = std::true_type;
-      using N = std::false_type;
-      if (k1 && f1) kloop(T{}, T{});
-      else if (k1) kloop(T{}, N{});
-      else if (f1) kloop(N{}, T{});
-      else kloop(N{}, N{});
-      auto put = [&](const f32x4& acc, int kt, int ft) {  // one 16-byte store per tile and lane
-        const int k = kt * 16 + x, f = ft * 16 + 4 * kq;
-        if (k < a.wd && f < F && !(a.cnn.dbg & 16)) {  // streaming stores: 120 KB per workgroup, read once by cnn_update -- not worth L2 lines
-          const int64_t el = ((int64_t)tap * a.wd + k) * F + f;   // a multiple of 4: the four floats stay in one group of 64
-          float* dst = gw + (el / kCnnUpdElems) * gw_parts * kCnnUpdElems + (el % kCnnUpdElems);
-          __builtin_nontemporal_store(acc[0], dst);
-          __builtin_nontemporal_store(acc[1], dst + 1);
-          __builtin_nontemporal_store(acc[2], dst + 2);
-          __builtin_nontemporal_store(acc[3], dst + 3);
-        }
-      };
-      put(acc00, kt0, ft0);
-      if (f1) put(acc01, kt0, ft0 + 1);
-      if (k1) put(acc10, kt0 + 1, ft0);
-      if (k1 && f1) put(acc11, kt0 + 1, ft0 + 1);
     }
   }
-}
-
-// per item: rows of dX summed per distinct word, through the static sorted-position index.  The
-// item's entry table and position order are staged in LDS first, so the row loads are the only
-// dependent round trip.  Work units = chunks of up to kLight positions of one word: a word with up
-// to kLight occurrences is one unit whose sum goes straight to dXw; a heavier word (the pad id,
-// typically half the item) is cut into chunks whose sums meet in LDS and are added in chunk order
-// afterwards.  One 16-lane group per unit, four units of a group in flight: every word of the item,
-// however often it occurs, is covered by the same one or two rounds of loads.
-constexpr int kLight = 4;
-constexpr int kMaxChunks = 104;  // chunks of heavy words per item: sum ceil(c/4) over words with c >= 5, sum c <= L <= 255
-__global__ void __launch_bounds__(256) cnn_presum_kernel(TowerArgs a) {
-  __shared__ uint8_t sPos[256], sStart[256], sCnt[256];
-  __shared__ int sHeavy[64], sHBase[65], sNH;
-  __shared__ uint8_t sUnitH[kMaxChunks];                           // chunk -> index into sHeavy
-  __shared__ __attribute__((aligned(16))) float sPart[kMaxChunks * kTP];
-  const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15, wd4 = a.wd >> 2, L = a.L;
-  const int s = blockIdx.x;
-  if (s >= valid_rows(a)) return;
-  const int item = a.ids[s];
-  const int e0 = a.item_ptr[item], ne = a.item_ptr[item + 1] - e0;
-  if (tid == 0) sNH = 0;
-  __syncthreads();
-  if (tid < L) sPos[tid] = a.cnn.item_spos[(int64_t)item * L + tid];
-  if (tid < ne) {
-    const int cn = a.item_cnt[e0 + tid];
-    sStart[tid] = a.cnn.item_start[e0 + tid];
-    sCnt[tid] = (uint8_t)cn;
-    if (cn > kLight) sHeavy[atomicAdd(&sNH, 1)] = tid;  // at most L / (kLight + 1) < 64 of them; the order only
-  }                                                     // decides where a word's chunks sit in LDS
-  __syncthreads();
-  const int nh = sNH;
-  if (tid == 0) {
-    int acc = 0;
-    for (int hi = 0; hi < nh; ++hi) {
-      sHBase[hi] = acc;
-      acc += (sCnt[sHeavy[hi]] + kLight - 1) / kLight;
-    }
-    sHBase[nh] = acc;
-  }
-  __syncthreads();
-  const int nchunk = sHBase[nh];
-  if (tid < nchunk) {
-    int hi = 0;
-    while (sHBase[hi + 1] <= tid) ++hi;
-    sUnitH[tid] = (uint8_t)hi;
-  }
-  __syncthreads();
-  const float* dXs = a.cnn.dX + (int64_t)s * L * a.wd;
-  // units [0, ne): the item's entries (heavy ones skipped here); units [ne, ne + nchunk): heavy chunks
-  const int nunit = ne + nchunk;
-  for (int ub = grp; ub < nunit; ub += 64) {
-    Row r[4][kLight];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int un = ub + 16 * u;
-      int st = 0, cn = 0;
-      if (un < ne) {
-        if (sCnt[un] <= kLight) {
-          st = sStart[un];
-          cn = sCnt[un];
-        }
-      } else if (un < nunit) {
-        const int ch = un - ne, hi = sUnitH[ch], e = sHeavy[hi], off = (ch - sHBase[hi]) * kLight;
-        st = sStart[e] + off;
-        cn = min(kLight, (int)sCnt[e] - off);
-      }
-#pragma unroll
-      for (int t = 0; t < kLight; ++t) r[u][t] = (t < cn) ? row_load(dXs, sPos[st + t], a.wd, wd4, q) : row_zero();
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int un = ub + 16 * u;
-      if (un >= nunit || (un < ne && sCnt[un] > kLight)) continue;
-      Row sum = r[u][0];
-#pragma unroll
-      for (int t = 1; t < kLight; ++t) sum = row_add(sum, r[u][t]);
-      if (un < ne) {
-        row_store(a.cnn.dXw, (int64_t)s * L + un, a.wd, wd4, q, sum);
-      } else {
-        float4* dst = reinterpret_cast<float4*>(sPart + (un - ne) * kTP);
-        dst[q] = sum.a;
-        dst[q + 16] = sum.b;
-      }
-    }
-  }
-  __syncthreads();
-  for (int hi = grp; hi < nh; hi += 16) {  // a heavy word's chunks, in chunk order
-    Row tot = row_zero();
-    for (int ch = sHBase[hi]; ch < sHBase[hi + 1]; ++ch) {
-      const float4* src = reinterpret_cast<const float4*>(sPart + ch * kTP);
-      tot.a = add4(tot.a, src[q]);
-      tot.b = add4(tot.b, src[q + 16]);
-    }
-    row_store(a.cnn.dXw, (int64_t)s * L + sHeavy[hi], a.wd, wd4, q, tot);
-  }
+  cnn_stamp(a, 1, 5);
+  cnn_stamp(a, 1, 6);
 }
 
 __global__ void cnn_transpose_kernel(CnnArgs c, int wd) {
@@ -963,26 +1055,25 @@ __global__ void cnn_mask_kernel(TowerArgs a, int64_t n, float* __restrict__ out)
 
 // ---- host side ---------------------------------------------------------------------------------
 
-static int conv_blocks(int L) { return (L + kConvLB - 1) / kConvLB; }
-
 size_t cnn_carve(nncf_tower* t, Carver& c) {
   const int64_t cap = t->cfg.max_rows, L = t->cfg.content_len, wd = t->cfg.word_dim, F = t->cfg.conv_filters;
-  const int64_t nblk = conv_blocks((int)L);
-  float* dX = c.take<float>(cap * L * wd);     // shared by the banks (the backward accumulates into it)
-  float* dXw = c.take<float>(cap * L * wd);
+  const int64_t np = cnn_groups((int)F);
+  float* dXw = c.take<float>(np * cap * L * wd);   // shared by the banks (the backward accumulates into it)
   for (int g = 0; g < t->nb; ++g) {
     CnnArgs& a = t->bank_at(g);
     const int64_t fl = a.fl;
-    a.dX = dX;
     a.dXw = dXw;
+    a.np = (int)np;
+    a.pstride = cap * L * wd;
     a.Wt = c.take<float>(F * fl * wd);
     a.Y = c.take<float>(cap * L * F);
-    a.part1 = c.take<float>(cap * kFwdSplit * 256);
+    a.part1 = c.take<float>(cap * 256);
     a.st1 = c.take<float>(7 * 128);
     a.bpart = c.take<float>(cap * 256);
     a.amax = c.take<uint8_t>(cap * 128);
-    a.gWpart = c.take<float>(cap * nblk * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
-    a.gbpart = c.take<float>(cap * nblk * 128);
+    a.gWpart = c.take<float>(cap * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
+    a.gbpart = c.take<float>(cap * 128);
+    a.stamps = c.take<long long>(2 * cap * np * 16);
   }
   return c.off;
 }
@@ -1031,27 +1122,22 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
 }
 
 static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
-  const int L = a.L, fl = a.cnn.fl;
-  const int nMtH = (((L + 15) / 16) + kFwdSplit - 1) / kFwdSplit;
-  const size_t lds = (size_t)(16 * nMtH + fl - 1) * conv_pitch(a.wd) * sizeof(float);
-  NNCF_REQUIRE(nMtH <= kFwdMt, "content_len too long for the conv forward tile");
-  NNCF_REQUIRE(lds <= 150 * 1024, "content_len x word_dim tile of %zu bytes exceeds the LDS", lds);
-  const int nKt = (a.wd + 15) / 16;
+  const int fl = a.cnn.fl, ngrp = cnn_groups(a.cnn.F);
+  const bool exact = a.wd == 100;
+  const size_t lds = ((size_t)kCnnCW * fwd_xpitch(a.wd, exact) + (size_t)(kCnnCW + 1) * (fl * 16 * kCnnNTG + 4)) * sizeof(float);
+  NNCF_REQUIRE(lds <= 150 * 1024, "conv forward tiles of %zu bytes exceed the LDS", lds);
   {
     ProfScope _ps("cnn_conv_fwd_kernel", st);
-    const dim3 grid((unsigned)a.m * kFwdSplit);
-    if (nMtH == 7 && a.wd == 100) {  // L in (192, 224], word_dim 100 = 6 K groups + a 4-column tail: the CiteULike shape
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 6, false, 1>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 6, false, 1>), grid, dim3(kConvThreads), lds, st, a);
-    } else if (nMtH == 7 && nKt == 7) {  // L in (192, 224], word_dim in (96, 112]
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<7, 7, false>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<7, 7, false>), grid, dim3(kConvThreads), lds, st, a);
-    } else if (nMtH <= 4 && nKt <= 4) {
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<4, 4, true>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 4, true>), grid, dim3(kConvThreads), lds, st, a);
+    const dim3 grid((unsigned)(a.m * ngrp));
+    if (a.wd == 100) {  // 6 K groups + one 4-column k-step: the CiteULike shape
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<6, 1, false, kCnnNTG>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<6, 1, false, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
+    } else if (a.wd <= 64) {
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<4, 0, true, kCnnNTG>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 0, true, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
     } else {
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<kFwdMt, 8, true>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<kFwdMt, 8, true>), grid, dim3(kConvThreads), lds, st, a);
+      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<8, 0, true, kCnnNTG>), lds)) return rc;
+      hipLaunchKernelGGL((cnn_conv_fwd_kernel<8, 0, true, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
     }
   }
   if (a.train) {
@@ -1072,8 +1158,8 @@ __global__ void __launch_bounds__(512) cnn_update_kernel(TowerArgs a) {
   cnn_update_block(a, (int)blockIdx.x, sG);
 }
 
-// after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) rows.  Banks 1 .. take their
-// parameter step here (bank 0's rides in the word kernel's launch, tower.hip).
+// after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) gradient rows.  Banks 1 .. take
+// their parameter step here (bank 0's rides in the word kernel's launch, tower.hip).
 int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   for (int g = 0; g < t->nb; ++g) {
     TowerArgs b = bank_args(t, a, g);
@@ -1088,24 +1174,16 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
       hipLaunchKernelGGL(cnn_update_kernel, dim3(ncnn), dim3(512), 0, st, b);
     }
   }
-  {
-    ProfScope _ps("cnn_presum_kernel", st);
-    hipLaunchKernelGGL(cnn_presum_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
-  }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
 
 static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
-  const int nblk = conv_blocks(a.L), fl = a.cnn.fl;
-  const size_t lds = (size_t)(kConvLB + fl - 1) * (conv_pitch32(a.wd) + conv_pitch32(a.cnn.F)) * sizeof(float);
-  NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tile of %zu bytes exceeds the LDS", lds);
-  const int nFt = (a.cnn.F + 15) / 16;
-  const bool tail = a.cnn.F == 100;   // 6 K groups + a 4-filter tail in (a)
-  const void* bwd_fn = tail ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<6, false, 1>)
-                       : nFt == 7 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<7, false>)
-                       : nFt <= 4 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<4, true>)
-                                  : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<8, true>);
+  const int fl = a.cnn.fl, ngrp = cnn_groups(a.cnn.F), FW = 16 * kCnnNTG;
+  const size_t lds = ((size_t)(a.L + fl - 1) * (FW + 4) + (size_t)kCnnCWB * (fl * FW + 4)) * sizeof(float);
+  NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tiles of %zu bytes exceed the LDS", lds);
+  const void* bwd_fn = fl <= 3 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 3, 512>)
+                               : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 7, 256>);
   if (int rc = set_lds(bwd_fn, lds)) return rc;
   {
     ProfScope _ps("cnn_merge_kernel", st);
@@ -1113,11 +1191,9 @@ static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);
-    const dim3 grid((unsigned)(a.m * nblk));
-    if (tail) hipLaunchKernelGGL((cnn_conv_bwd_kernel<6, false, 1>), grid, dim3(kConvThreads), lds, st, a, nblk);
-    else if (nFt == 7) hipLaunchKernelGGL((cnn_conv_bwd_kernel<7, false>), grid, dim3(kConvThreads), lds, st, a, nblk);
-    else if (nFt <= 4) hipLaunchKernelGGL((cnn_conv_bwd_kernel<4, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
-    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<8, true>), grid, dim3(kConvThreads), lds, st, a, nblk);
+    const dim3 grid((unsigned)(a.m * ngrp));
+    if (fl <= 3) hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 3, 512>), grid, dim3(512), lds, st, a, ngrp);
+    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 7, 256>), grid, dim3(256), lds, st, a, ngrp);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

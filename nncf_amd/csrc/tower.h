@@ -26,20 +26,21 @@ struct CnnArgs {
   float* Wt;                 // [F][fl*wd]    transposed copy (owned by the tower)
   float *bc, *g1, *b1, *rm1, *rv1;
   float* Y;                  // [m*L][F]      conv output before BatchNorm
-  float* dX;                 // [m*L][wd]     dL/d(word row at every position), dropout scale applied
-  float* dXw;                // [m*L][wd]     the same summed per (slot, distinct word)
+  float* dXw;                // [np][m*L][wd] dL/d(word row) per (slot, distinct word ordinal), dropout scale applied: np partial
+  int np;                    //               rows per (slot, word) -- one per filter group of the conv backward (cnn.hip),
+  long long pstride;         //               pstride floats apart; tower_word_kernel adds them in group order
   float* part1;              // [m][2][128]   per-slot sums of (y-b), (y-b)^2
   float* st1;                // 7 x 128: mu, inv, var, mul, add, sum da, sum da*xhat
   float* bpart;              // [m][2][128]
   uint8_t* amax;             // [m][128] max pooling: the position that supplied each filter's maximum
   int pool_max;              // poolings = ['max'] (cnn_model.py:107-109) over the whole length instead of the average
-  float* gWpart;             // [ceil(fl*wd*F / 64)][cap*nblk][64]: dWk partials, element-group major
-  float* gbpart;             // [m*nblk][128]
+  float* gWpart;             // [ceil(fl*wd*F / 64)][cap][64]: per-slot dWk blocks, element-group major
+  float* gbpart;             // [m][128]      per-slot column sums of dY (conv bias gradient)
   const uint8_t* item_spos;  // [item_count][L] positions of an item's tokens sorted by (word, position)
   const uint8_t* item_start; // per CSR entry: index of its first position in the item's item_spos row
   float *mC, *vC;            // Adam moments of [Wk | bc, g1, b1 (128 each)]
-  int dbg;                   // NNCF_CNN_DBG (timing experiments only; results are wrong on purpose): forward 1 skip the MFMA loop,
-                             // 2 skip the gather; backward 4 no dX strips, 8 no dWk blocks, 16 no dWk partial stores, 32 no dX stores
+  int dbg;                   // NNCF_CNN_DBG developer switches: 64 = clock stamps of the conv kernels' phases -> stamps
+  long long* stamps;         // [2][cap * groups][16] (nncf_tower_debug_stamps)
   // filter bank (cnn_model.py:63-81: Convolution1D of several lengths over the same input, concatenated along the
   // filter axis): every length is one CnnArgs whose F filters are columns [c_off, c_off + F) of the pooled block h /
   // dh (pitch TowerArgs::hd) and rows [c_off, ...) of the Dense weights.  Banks run one after the other:
@@ -49,7 +50,6 @@ struct CnnArgs {
   int dx_acc;                // conv backward: add to the dX of the earlier banks (0: store)
   long long gexp_off;        // this bank's [Wk | bc, g1, b1 (128 each)] block in the flat gradient, from the start of the conv section
 };
-constexpr int kConvLB = 112;  // positions per workgroup of the conv backward
 struct CnnBanks {             // all banks of a tower (kernels that walk the whole flat gradient)
   int nb;
   CnnArgs b[4];
@@ -223,12 +223,11 @@ namespace nncf {
 // through LDS -- and the SGD / Adam step is taken on Wk (+ its transposed copy).  Block nb (the last)
 // handles the conv bias and the BN1 scale / shift.  sG: 4 x 128 floats of LDS.
 constexpr int kCnnUpdElems = 64;                      // elements of dWk per workgroup
-constexpr int kCnnUpdGroups = 512 / kCnnUpdElems;     // part-groups (one wave each): 250 partials = 2 rounds of 16 loads per wave
+constexpr int kCnnUpdGroups = 512 / kCnnUpdElems;     // part-groups (one wave each): 125 slots = 1 round of 16 loads per wave
 __host__ __device__ inline int cnn_update_blocks(int nel) { return (nel + kCnnUpdElems - 1) / kCnnUpdElems + 1; }
 __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, float* sG) {
   const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
-  const int nblk = (a.L + kConvLB - 1) / kConvLB;
-  const int nparts = valid_rows(a) * nblk;  // slots [0, n_valid) x position blocks, contiguous
+  const int nparts = valid_rows(a);  // one dWk block per slot [0, n_valid), contiguous
   const int nb = (nel + kCnnUpdElems - 1) / kCnnUpdElems;
   if (blk < nb) {
     const int c = threadIdx.x & (kCnnUpdElems - 1), g = threadIdx.x / kCnnUpdElems;
@@ -240,7 +239,7 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           u[e] = (p0 + kCnnUpdGroups * e < nparts)
-                     ? a.cnn.gWpart[((int64_t)blk * a.cap * nblk + (p0 + kCnnUpdGroups * e)) * kCnnUpdElems + c] : 0.f;
+                     ? a.cnn.gWpart[((int64_t)blk * a.cap + (p0 + kCnnUpdGroups * e)) * kCnnUpdElems + c] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc += u[e];
       }

@@ -631,7 +631,7 @@ constexpr int kRowsInFlight = 8;
 // postings order (ascending item id) per wave, the waves' stripes in wave order: fixed order, no atomics.  Hot words are skipped
 // (their partial rows come from tower_bwd_kernel), dropped words too (no cell was ever written for them in the dense mode either).
 template <bool CNN, bool MAXP = false, int NB = 1, bool PM = false>
-__global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
+__global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
   __shared__ int sHit[kWordsPerWG];
@@ -751,6 +751,7 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
     // list the non-zero cells word by word (ballot + prefix count); the list holds kListCap
     // entries: it is drained whenever the next word might not fit (rare: > 256 hits per 64 slots)
     int cnt = 0;
+    constexpr int RIF = CNN ? 4 : kRowsInFlight;   // CNN: np partial rows per cell -- 4 cells x np rows in flight
     auto drain = [&]() {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the list lives in LDS and is this wave's own: LDS operations of a
       __builtin_amdgcn_wave_barrier();                       // wave complete in order -- nothing here waits for global memory
@@ -759,19 +760,40 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
       // a popular word through LDS latency).
       int curj = -1;
       float2 run = make_float2(0.f, 0.f);
-      for (int e0 = 0; e0 < cnt; e0 += kRowsInFlight) {  // rows of dh in flight
-        int ent[kRowsInFlight];
-        float2 r[kRowsInFlight];
+      for (int e0 = 0; e0 < cnt; e0 += RIF) {  // rows of dh in flight
+        int ent[RIF];
+        float2 r[RIF];
 #pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
+        for (int u = 0; u < RIF; ++u) ent[u] = (e0 + u < cnt) ? list[e0 + u] : 0;
 #pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u)
+        for (int u = 0; u < RIF; ++u)
           r[u] = (ent[u] && lane < d2 && !(a.skip_words & 2))
                      ? dh2[(cnn ? (int64_t)((ent[u] >> 8) & 0xFFFF) * a.L + ((ent[u] & 255) - 1) : (int64_t)((ent[u] >> 8) & 0xFFFF)) * d2 + lane]
                      : make_float2(0.f, 0.f);
+        if (cnn && a.cnn.np > 1) {   // the conv backward leaves one partial row per filter group (<= 4): added in group order,
+#pragma unroll                   // all of a half batch's rows requested before the first is used
+          for (int h = 0; h < RIF; h += 4) {   // (one half batch: RIF = 4)
+            float2 t[3][4];
+#pragma unroll
+            for (int pg = 0; pg < 3; ++pg)
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                t[pg][u] = (pg + 1 < a.cnn.np && ent[h + u] && lane < d2 && !(a.skip_words & 2))   // 32-bit element offsets: np cap L wd / 2 < 2^32
+                               ? dh2[(unsigned)(pg + 1) * (unsigned)(a.cnn.pstride >> 1) +
+                                     ((unsigned)((ent[h + u] >> 8) & 0xFFFF) * (unsigned)a.L + (unsigned)((ent[h + u] & 255) - 1)) * (unsigned)d2 + (unsigned)lane]
+                               : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int pg = 0; pg < 3; ++pg)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                r[h + u].x += t[pg][u].x;
+                r[h + u].y += t[pg][u].y;
+              }
+          }
+        }
         if (MAXP) {
 #pragma unroll
-          for (int u = 0; u < kRowsInFlight; ++u) {
+          for (int u = 0; u < RIF; ++u) {
             if (ent[u] && lane < d2) {
               const int2 am = reinterpret_cast<const int2*>(a.amax)[(int64_t)((ent[u] >> 8) & 0xFFFF) * d2 + lane];
               const int w = bid + (ent[u] >> 24) * G;
@@ -781,7 +803,7 @@ __global__ void __launch_bounds__(512, 8) tower_word_kernel(TowerArgs a, int ks,
           }
         }
 #pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u) {
+        for (int u = 0; u < RIF; ++u) {
           if (ent[u]) {  // uniform across the wave
             const int j = ent[u] >> 24;
             if (j != curj) {
@@ -1108,10 +1130,8 @@ void carve_tower(nncf_tower* t, Carver& c) {
   t->ws = c.take<float>(ws_total((int)wide, (int)d, t->ks));
   if (t->cfg.conv_filters > 0) cnn_carve(t, c);
   t->cnt_t = c.take<uint8_t>((int64_t)t->cfg.word_count * cap);
-  if (t->cfg.conv_filters == 0) {
-    t->ent_word = c.take<int32_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
-    t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
-  }
+  t->ent_word = c.take<int32_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
+  t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
   t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
@@ -1466,7 +1486,8 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
       nncf_tower_destroy(t);
       return rc;
     }
-  } else {
+  }
+  {   // fixed-stride copy of the item CSR (both towers: the pool kernel's and the conv kernels' one-hop entry table)
     const int64_t n = (int64_t)cfg->item_count * cfg->content_len;
     hipLaunchKernelGGL(tower_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, base_args(t),
                        (int64_t)cfg->item_count, t->ent_word, t->ent_cnt);
@@ -1490,6 +1511,14 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (t->arena) hipFree(t->arena);
   if (t->stamps) hipFree(t->stamps);
   delete t;
+  return NNCF_OK;
+}
+
+int nncf_tower_debug_stamps(nncf_tower* t, long long* out_host, int64_t n) {
+  NNCF_REQUIRE(t != nullptr && out_host != nullptr, "tower / output is NULL");
+  NNCF_REQUIRE(t->cnn.F > 0 && (t->cnn.dbg & 64), "not a CNN tower created with NNCF_CNN_DBG=64");
+  NNCF_REQUIRE(n >= 0 && n <= (int64_t)2 * t->cfg.max_rows * t->cnn.np * 16, "more stamps requested than the tower holds");
+  NNCF_HIP_CHECK(hipMemcpy(out_host, t->cnn.stamps, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
   return NNCF_OK;
 }
 
