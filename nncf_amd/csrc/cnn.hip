@@ -372,29 +372,41 @@ __device__ __forceinline__ void merge_slot_partials(const float* part, int n, fl
   }
 }
 
+// column c (< 128): BatchNorm statistics from the totals of (y-b), (y-b)^2 over nv * L positions
+__device__ __forceinline__ void bn1_from_totals(const TowerArgs& a, int nv, int c, float t1, float t2, float& mu, float& inv, float& var,
+                                                float& mul, float& add) {
+  mu = inv = var = mul = add = 0.f;
+  if (c < a.cnn.F) {
+    const float rn = 1.f / (float)max(nv * a.L, 1);
+    const float m1 = t1 * rn;
+    mu = a.cnn.bc[c] + m1;
+    var = fmaxf(t2 * rn - m1 * m1, 0.f);
+    inv = rsqrtf(var + a.eps);
+    mul = a.cnn.g1[c] * inv;
+    add = a.cnn.b1[c] - mu * mul;
+  }
+}
+__device__ __forceinline__ void bn1_publish(const TowerArgs& a, int c, float mu, float inv, float var, float mul, float add) {
+  if (c < a.cnn.F) {
+    a.cnn.rm1[c] = a.momentum * a.cnn.rm1[c] + (1.f - a.momentum) * mu;
+    a.cnn.rv1[c] = a.momentum * a.cnn.rv1[c] + (1.f - a.momentum) * var;
+  }
+  a.cnn.st1[c] = mu;
+  a.cnn.st1[128 + c] = inv;
+  a.cnn.st1[256 + c] = var;
+  a.cnn.st1[384 + c] = mul;
+  a.cnn.st1[512 + c] = add;
+}
+
 __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int nv = valid_rows(a), c = threadIdx.x;
   float t1, t2;
   merge_slot_partials(a.cnn.part1, nv, sRed, t1, t2);
   if (c < 128) {
-    float mu = 0.f, inv = 0.f, var = 0.f, mul = 0.f, add = 0.f;
-    if (c < a.cnn.F) {
-      const float rn = 1.f / (float)max(nv * a.L, 1);
-      const float m1 = t1 * rn;
-      mu = a.cnn.bc[c] + m1;
-      var = fmaxf(t2 * rn - m1 * m1, 0.f);
-      inv = rsqrtf(var + a.eps);
-      mul = a.cnn.g1[c] * inv;
-      add = a.cnn.b1[c] - mu * mul;
-      a.cnn.rm1[c] = a.momentum * a.cnn.rm1[c] + (1.f - a.momentum) * mu;
-      a.cnn.rv1[c] = a.momentum * a.cnn.rv1[c] + (1.f - a.momentum) * var;
-    }
-    a.cnn.st1[c] = mu;
-    a.cnn.st1[128 + c] = inv;
-    a.cnn.st1[256 + c] = var;
-    a.cnn.st1[384 + c] = mul;
-    a.cnn.st1[512 + c] = add;
+    float mu, inv, var, mul, add;
+    bn1_from_totals(a, nv, c, t1, t2, mu, inv, var, mul, add);
+    bn1_publish(a, c, mu, inv, var, mul, add);
   }
 }
 
@@ -430,7 +442,46 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
     const int k = kp * kper + i;
     w[i] = (tid < 256 && i < kper && k < F && c4 < d4) ? reinterpret_cast<const float4*>(a.Wd + (int64_t)(a.cnn.c_off + k) * a.d)[c4] : zero4();
   }
-  if (tid < 128) {
+  if (a.train && a.cnn.fold) {
+    // the forward's per-item statistics partials, merged by every workgroup itself (same order everywhere: the same bits):
+    // thread = (16-byte column chunk c4, slot group sg), sixteen slots of a group in flight; groups combined in group order
+    float4* red = reinterpret_cast<float4*>(&sR[0][0]);   // [16][2][32]
+    const int nv = valid_rows(a), cc = tid & 31, sg = tid >> 5;
+    float4 a1 = zero4(), a2 = zero4();
+    for (int s0 = sg; s0 < nv; s0 += 16 * 8) {
+      float4 u1[8], u2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ss = s0 + 16 * e;
+        u1[e] = ss < nv ? reinterpret_cast<const float4*>(a.cnn.part1 + (int64_t)ss * 256)[cc] : zero4();
+        u2[e] = ss < nv ? reinterpret_cast<const float4*>(a.cnn.part1 + (int64_t)ss * 256 + 128)[cc] : zero4();
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a1 = add4(a1, u1[e]);
+        a2 = add4(a2, u2[e]);
+      }
+    }
+    red[(sg * 2 + 0) * 32 + cc] = a1;
+    red[(sg * 2 + 1) * 32 + cc] = a2;
+    __syncthreads();
+    if (tid < 128) {
+      const float* rf = reinterpret_cast<const float*>(red);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 16; ++gg) {
+        t1 += rf[(gg * 2 + 0) * 128 + tid];
+        t2 += rf[(gg * 2 + 1) * 128 + tid];
+      }
+      float mu, inv, var, mul, add;
+      bn1_from_totals(a, nv, tid, t1, t2, mu, inv, var, mul, add);
+      sMul[tid] = mul;
+      sAdd[tid] = add;
+      sMu[tid] = mu;
+      sInv[tid] = inv;
+      if (blockIdx.x == 0) bn1_publish(a, tid, mu, inv, var, mul, add);   // for the backward; the running statistics
+    }
+  } else if (tid < 128) {
     float mul = 0.f, add = 0.f;
     if (tid < F) {
       if (a.train) {
@@ -707,6 +758,7 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ ItemIdx ix;
   __shared__ __attribute__((aligned(16))) float4 sGb[(kBwdThreads / 64) * 4 * NTG];
+  __shared__ __attribute__((aligned(16))) float4 sTot[(kBwdThreads / 64) * 2 * 4 * NTG];
   __shared__ uint8_t sHeavy[128];
   __shared__ int sNH[2];
   constexpr int NW = kBwdThreads / 64;
@@ -752,7 +804,52 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
       for (int k = 0; k < 4; ++k) am[k] = (int)a.cnn.amax[(int64_t)s * 128 + f0 + k];
     }
   }
+  if (a.cnn.fold) {
+    // BatchNorm backward sums over (items, positions) of this group's filters, merged by every workgroup itself instead of a
+    // one-workgroup launch: sum da = sum_s dh[s][c]/L M1[s][c], sum da xhat = sum_s dh[s][c]/L M2[s][c] (cnn_pool_dense left
+    // M1 / M2 per item).  Thread = (chunk fq, slot group): its slots in order, the wave's groups by shuffles, the waves in
+    // wave order through LDS (read after the index build's barriers) -- the same bits in every workgroup of the group.
+    constexpr int NSG = kBwdThreads / CH;
+    const float rL = maxp ? 1.f : 1.f / (float)L;
+    float4 p1 = zero4(), p2 = zero4();
+    for (int s0 = tid / CH; s0 < nv; s0 += 2 * NSG) {
+      const int sb = s0 + NSG;
+      const bool okb = sb < nv && fok;
+      const float4 m1a = fok ? *reinterpret_cast<const float4*>(a.cnn.bpart + (int64_t)s0 * 256 + f0) : zero4();
+      const float4 m2a = fok ? *reinterpret_cast<const float4*>(a.cnn.bpart + (int64_t)s0 * 256 + 128 + f0) : zero4();
+      const float4 dva = fok ? *reinterpret_cast<const float4*>(a.dh + (int64_t)s0 * a.hd + a.cnn.c_off + f0) : zero4();
+      const float4 m1b = okb ? *reinterpret_cast<const float4*>(a.cnn.bpart + (int64_t)sb * 256 + f0) : zero4();
+      const float4 m2b = okb ? *reinterpret_cast<const float4*>(a.cnn.bpart + (int64_t)sb * 256 + 128 + f0) : zero4();
+      const float4 dvb = okb ? *reinterpret_cast<const float4*>(a.dh + (int64_t)sb * a.hd + a.cnn.c_off + f0) : zero4();
+      p1 = fma4v(scale4(dva, rL), m1a, p1);
+      p2 = fma4v(scale4(dva, rL), m2a, p2);
+      p1 = fma4v(scale4(dvb, rL), m1b, p1);
+      p2 = fma4v(scale4(dvb, rL), m2b, p2);
+    }
+#pragma unroll
+    for (int o = CH; o < 64; o <<= 1) {
+      p1.x += __shfl_xor(p1.x, o); p1.y += __shfl_xor(p1.y, o); p1.z += __shfl_xor(p1.z, o); p1.w += __shfl_xor(p1.w, o);
+      p2.x += __shfl_xor(p2.x, o); p2.y += __shfl_xor(p2.y, o); p2.z += __shfl_xor(p2.z, o); p2.w += __shfl_xor(p2.w, o);
+    }
+    if (lane < CH) {
+      sTot[(wave * 2 + 0) * CH + lane] = p1;
+      sTot[(wave * 2 + 1) * CH + lane] = p2;
+    }
+  }
   const int nc = item_index(a, item, s, false, ix);
+  if (a.cnn.fold) {
+    cs1 = zero4();
+    cs2 = zero4();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      cs1 = add4(cs1, sTot[(w * 2 + 0) * CH + fq]);
+      cs2 = add4(cs2, sTot[(w * 2 + 1) * CH + fq]);
+    }
+    if (s == 0 && tid < CH && f0 < 128) {   // for the parameter step (cnn_update_block): dbeta1, dgamma1
+      *reinterpret_cast<float4*>(a.cnn.st1 + 640 + f0) = cs1;
+      *reinterpret_cast<float4*>(a.cnn.st1 + 768 + f0) = cs2;
+    }
+  }
   cnn_stamp(a, 1, 1);
   // dY rows: mul/N * (N da - S1 - xhat S2); zero outside [0, L)
   float4 gb = zero4();   // column sums over the item's positions: the conv bias gradient
@@ -1088,6 +1185,11 @@ int cnn_sync_weights(nncf_tower* t, hipStream_t st) {
   return NNCF_OK;
 }
 
+static bool getenv_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] && e[0] != '0';
+}
+
 static int set_lds(const void* fn, size_t bytes) {
   NNCF_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return NNCF_OK;
@@ -1107,6 +1209,7 @@ static TowerArgs bank_args(const nncf_tower* t, const TowerArgs& a, int g) {
   b.cnn.z_acc = g > 0;
   b.cnn.dx_acc = g > 0;
   b.cnn.last = g == t->nb - 1;
+  b.cnn.fold = a.m <= kCnnFoldRows && !getenv_flag("NNCF_CNN_NOFOLD");
   return b;
 }
 
@@ -1140,7 +1243,7 @@ static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
       hipLaunchKernelGGL((cnn_conv_fwd_kernel<8, 0, true, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
     }
   }
-  if (a.train) {
+  if (a.train && !a.cnn.fold) {
     ProfScope _ps("cnn_stats_kernel", st);
     hipLaunchKernelGGL(cnn_stats_kernel, dim3(1), dim3(1024), 0, st, a);
   }
@@ -1185,7 +1288,7 @@ static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const void* bwd_fn = fl <= 3 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 3, 512>)
                                : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 7, 256>);
   if (int rc = set_lds(bwd_fn, lds)) return rc;
-  {
+  if (!a.cnn.fold) {
     ProfScope _ps("cnn_merge_kernel", st);
     hipLaunchKernelGGL(cnn_merge_kernel, dim3(1), dim3(1024), 0, st, a);
   }

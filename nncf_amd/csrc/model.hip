@@ -90,6 +90,15 @@ int flush_pending_loss(nncf_model* m, hipStream_t st) {
 
 int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid, const int32_t* cid, const PlanView& pu,
                 const PlanView& pv, float* loss_out, int update, hipStream_t st, const FusedArgs* tower) {
+  // the rectangular form (StepArgs::bc: a row share of a bc x bc score matrix) and the exported user gradient (gU) exist in
+  // the one-launch step's 16-row strips only: the tile + apply pair would run a square b x b step over cid[0, b) and step
+  // the landing buffer in place, the wide kernel ignores gU -- a silently wrong multi-GPU step
+  if (a.bc || a.gU) {
+    NNCF_REQUIRE(shared_step_fuses(m, a), "the rectangular / user-gradient-exporting step needs the one-launch path (pointwise loss, "
+                 "no interaction bias, NNCF_SHARED_PATH unset): it has no tile + apply form");
+    NNCF_REQUIRE(a.bc > 0 && a.gU != nullptr, "StepArgs::gU and StepArgs::bc go together (the strong form exports both gradients)");
+    NNCF_REQUIRE(fused_row_tiles(a) == 1, "the rectangular step runs on 16-row strips only (b = %d, bc = %d)", a.b, a.bc);
+  }
   if (!shared_step_fuses(m, a)) {
     if (shared_step_pair_wide(m, a)) {   // pairwise losses without slabs: anchors -> wide strips -> commit (step_pair.hip)
       if (int rc = flush_pending_loss(m, st)) return rc;

@@ -48,8 +48,11 @@ struct CnnArgs {
   int z_acc;                 // pooling pass: add this bank's h.Wd to the z the earlier banks left (0: start from bd)
   int last;                  // pooling pass, inference: this bank completes z -> BatchNorm -> ReLU -> E
   int dx_acc;                // conv backward: add to the dX of the earlier banks (0: store)
+  int fold;                  // blocks of <= kCnnFoldRows rows: cnn_pool_dense merges the forward's statistics partials itself and
+                             // cnn_conv_bwd the BatchNorm backward's sums (no cnn_stats / cnn_merge launch); workgroup 0 publishes st1
   long long gexp_off;        // this bank's [Wk | bc, g1, b1 (128 each)] block in the flat gradient, from the start of the conv section
 };
+constexpr int kCnnFoldRows = 512;
 struct CnnBanks {             // all banks of a tower (kernels that walk the whole flat gradient)
   int nb;
   CnnArgs b[4];

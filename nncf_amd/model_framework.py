@@ -452,6 +452,12 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     if getattr(conf, "pretrain", None):
         raise NotImplementedError("the text towers are built for pretrain=None (what the demo scripts run: the pretrained "
                                   "sentence vectors are not in the repo)")
+    if float(getattr(conf, "c_reg", 0) or 0) != 0.0:
+        # mean_pool.py:56-59 / cnn_model.py:45-48: activity_l2(conf.c_reg) on the word Embedding's OUTPUT.  Every preset of the
+        # reference sets it to 0 (basic_embedding_conf.py:38,106; cnn_embedding_conf.py:38,114); whether Keras 1.2.2 applies
+        # an Embedding's activity regulariser before or after its row dropout cannot be pinned here.  Refused, not ignored.
+        raise NotImplementedError("c_reg = %r: the activity regulariser on the word-embedding output is not built (every preset "
+                                  "of the reference runs c_reg = 0); set c_reg = 0" % conf.c_reg)
     pooling = getattr(conf, "pooling", "average")
     assert conv is not None or pooling in ("average", "max"), "[ERROR] unknown pooling: %s" % pooling   # mean_pool.py:76
     idt = conf.item_dense_transform

@@ -47,7 +47,41 @@ def test_bench_line_contract(extra):
     assert w["count"] >= 5 and w["timed_seconds_total"] >= 0.2 and w["steps_each"] == 8     # several windows, the median reported
     assert abs(j["ms_per_step"] - w["ms_per_step_median"]) <= 1e-9
     assert r["kernel_ms_source"].startswith("HIP event bracket of this run")                 # frac is what THIS run measured
-    assert abs(r["kernel_ms"] - (r["event_bracket_ms"] - r["empty_bracket_ms"])) <= 1e-9
+    if "bracket_cost_ms" in r:     # calibrated: every kernel of the step was bracketed and the brackets add up to the step
+        assert 0 <= r["bracket_cost_ms"] <= 1.05 * r["empty_bracket_ms"] + 1e-9
+        assert abs(r["kernel_ms"] - (r["event_bracket_ms"] - r["bracket_cost_ms"])) <= 1e-9
+    else:                          # (the 8-step --small run is host-bound: the brackets need not add up)
+        assert "bracket_calibration" in r and abs(r["kernel_ms"] - (r["event_bracket_ms"] - r["empty_bracket_ms"])) <= 1e-9
+
+
+def _run_full(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "390", "--warmup", "39", "--cpu-seconds", "0",
+           "--recall-epochs", "0"] + list(extra)
+    out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_headline_kernel_times_sum_to_the_step():
+    """at the BASELINE size the live per-kernel figures of the headline add up to the driver-timed step
+    (sum kernel_ms <= ms_per_step <= sum kernel_ms + 5 %): no bracket correction that flatters the kernels."""
+    j = _run_full()
+    ks = [k for k in [j["roofline"]] + j["roofline_other_kernels"] if k.get("launches")]
+    assert {"fused_strip_kernel", "tower_pool_kernel", "tower_bwd_kernel", "tower_word_kernel"} <= {k["kernel"] for k in ks}
+    tot = sum(k["launches_per_step"] * k["kernel_ms"] for k in ks)
+    assert tot <= j["ms_per_step"] * 1.0005 and j["ms_per_step"] <= tot * 1.05, (tot, j["ms_per_step"])
+    assert all("bracket_cost_ms" in k for k in ks)
+
+
+def test_config2_tile_work_is_the_measured_unique_items():
+    """group_neg_shared's tile kernel is priced at 6 b n_u d with the run's measured n_u, not at N = b."""
+    j = _run_full("--scheme", "group_neg_shared")
+    tile = [k for k in [j["roofline"]] + j["roofline_other_kernels"] if k["kernel"] == "shared_tile_kernel"][0]
+    n_u = j["mean_unique_items_per_step"]
+    assert 60 < n_u < 300
+    assert abs(tile["algorithmic_per_launch"] - 6.0 * 512 * n_u * 100) <= 1e-6 * tile["algorithmic_per_launch"]
 
 
 @pytest.mark.parametrize("extra", [("--model", "mf"), ("--model", "mf", "--scaling", "strong"), ()])

@@ -300,6 +300,23 @@ def test_strong_form_world1_equals_plain_step_and_oracle(loss, norm):
     np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
 
 
+def test_strong_form_refuses_the_tile_path_loudly(monkeypatch):
+    """with NNCF_SHARED_PATH=tile the one-launch step is off; the strong form's rectangular step (bc, exported user
+    gradient) has no tile + apply form and must fail loudly instead of running a square step over the first b / G columns."""
+    from nncf_amd.sharded import ShardedGlobalBatch
+    monkeypatch.setenv("NNCF_SHARED_PATH", "tile")
+    b, d, nu, ni = 64, 20, 300, 500
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode="strong", user_shard=nu)
+    rs = np.random.RandomState(3)
+    uid, cid = rs.randint(0, nu, 2 * b), rs.randint(0, ni, 2 * b)
+    tr = ShardedGlobalBatch(be, nu, ni, b, d)
+    losses = torch.zeros(2, dtype=torch.float32, device=be.device)
+    with pytest.raises(Exception, match="one-launch path"):
+        tr.run_epoch(be.ids(uid), be.ids(cid), 2, losses)
+
+
 def test_rectangular_step_shares_add_up_to_the_square_step():
     """The rectangular form of the one-launch step (StepArgs::bc; rows g, g + G, ... of the b x b matrix) run for
     g = 0 .. G-1 on the SAME landed rows: the loss shares and the exported gradient rows add up to the square step's

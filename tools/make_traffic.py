@@ -31,24 +31,15 @@ def pmc_mean(path, kernel, counter):
 
 
 def trace_avg_us(path, kernel):
-    """average duration (us) of `kernel` in a tools/prof_summary.py kernel-trace summary"""
-    if not os.path.exists(path):
-        return None
-    for line in open(path):
-        if line.startswith("# PMC counters"):
-            break
-        if kernel in line:
-            parts = line.split()
-            try:
-                return float(parts[-2])
-            except (ValueError, IndexError):
-                continue
-    return None
+    """average duration (us) of `kernel` (its most-called template variant) in a tools/prof_summary.py kernel-trace summary"""
+    ent = all_kernel_avgs(path).get(kernel)
+    return ent["rocprof_avg_us"] if ent else None
 
 
 def all_kernel_avgs(path):
-    """{kernel: avg_us} of every kernel in a kernel-trace summary"""
-    res = {}
+    """{kernel: avg_us} of every kernel in a kernel-trace summary; of a kernel's template variants the one with the MOST calls
+    (the 4-call inference variant of tower_pool_kernel used to overwrite the 5,121-call training one)"""
+    res, calls_of = {}, {}
     if not os.path.exists(path):
         return res
     for line in open(path):
@@ -59,9 +50,12 @@ def all_kernel_avgs(path):
         if len(parts) >= 5 and tok:
             try:
                 name = tok[0].split("<")[0].split("::")[-1]
-                res[name] = {"rocprof_avg_us": float(parts[-2])}
+                calls, avg = int(parts[-4]), float(parts[-2])
             except ValueError:
-                pass
+                continue
+            if calls > calls_of.get(name, -1):
+                calls_of[name] = calls
+                res[name] = {"rocprof_avg_us": avg, "calls": calls, "variant": line[:72].strip()}
     return res
 
 
