@@ -536,6 +536,32 @@ int64_t nncf_scatter_apply_ws_ints(int32_t n);
 int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const int32_t* d_req, int32_t n_ranks, int32_t cap,
                        int32_t id_offset, const float* d_rows, float lr, void* stream);
 
+/* Transport of the multi-GPU trainers (no reference counterpart: /root/reference/main.py:34-35 selects ONE device;
+ * contract = SURVEY.md 8(e)): a communicator over RCCL -- librccl.so.1 is opened at run time, so the process shares the
+ * copy torch.distributed already holds -- with one process per GPU.  Bootstrap: rank 0 draws the 128-byte unique id
+ * (nncf_comm_unique_id), the caller broadcasts it (torch.distributed, MPI, a file), every rank calls nncf_comm_create.
+ * All operations are enqueued on the caller's stream.
+ *   nncf_comm_all_to_all      variable-split all-to-all: peer r is sent d_send[sum_{q<r} send_cnt[q] ..+send_cnt[r]) and
+ *                             fills d_recv[sum_{q<r} recv_cnt[q] ..+recv_cnt[r]); counts in elements of elem_bytes bytes
+ *                             (host arrays of n_ranks); grouped ncclSend / ncclRecv, the rank's own share by a
+ *                             device-to-device copy (NNCF_COMM_SELF_VIA_RCCL=1: through RCCL too -- single-GPU tests)
+ *   nncf_comm_all_reduce_f32  in-place sum
+ *   nncf_comm_create_callback the same interface over a host callback (tests: gloo through Python on a CPU box or with
+ *                             two ranks on one GPU); the callback returns 0 on success; elem_bytes == 0 marks an
+ *                             all-reduce of send_cnt[0] floats in place
+ *   nncf_comm_wire_bytes      payload bytes handed to the transport so far (own share included) */
+typedef struct nncf_comm nncf_comm;
+typedef int (*nncf_xfer_fn)(void* user, const void* d_send, const int64_t* send_cnt, void* d_recv, const int64_t* recv_cnt,
+                            int32_t elem_bytes, int32_t n_ranks, void* stream);
+int nncf_comm_unique_id(void* out_id128);
+int nncf_comm_create(const void* id128, int32_t n_ranks, int32_t rank, int device, nncf_comm** out);
+int nncf_comm_create_callback(nncf_xfer_fn fn, void* user, int32_t n_ranks, int32_t rank, nncf_comm** out);
+int nncf_comm_destroy(nncf_comm* c);
+int nncf_comm_all_to_all(nncf_comm* c, const void* d_send, const int64_t* send_cnt, void* d_recv, const int64_t* recv_cnt,
+                         int32_t elem_bytes, void* stream);
+int nncf_comm_all_reduce_f32(nncf_comm* c, float* d_buf, int64_t n, void* stream);
+int nncf_comm_wire_bytes(nncf_comm* c, int64_t* out, int32_t reset);
+
 /* Chunked sharded neg_shared trainer (no reference counterpart: /root/reference/main.py:34-35 selects ONE device;
  * SURVEY.md 8(e), BASELINE configs[3]).  One object per rank around a model whose "item table" is the landing buffer of
  * fetched item rows (batch_size_p rows) and this rank's shard of the real item table (rows [item_offset, item_offset +
@@ -568,9 +594,15 @@ int nncf_scatter_merge(float* d_table, int32_t row_stride, int32_t dim, const in
  *                          dense with the zero-gradient step on every other row of the shard) with the shard's own state
  *                          (nncf_shard_set_optimizer); advances the optimiser's step counter; then gathers the rows of
  *                          step i + 1 (after the update: synchronous steps).
- * With n_ranks == 1 both ends of every exchange are the same memory: nothing is copied.
+ * With n_ranks == 1 both ends of every exchange are the same memory: nothing is copied (NNCF_SHARD_NOALIAS=1 in the
+ * environment at nncf_shard_create keeps them apart, so that ONE rank drives the real collectives: single-GPU tests).
  * nncf_shard_counts / nncf_shard_buffers return the device pointers the host hands to its collectives (exchange 0:
- * items, 1: users in the strong form). */
+ * items, 1: users in the strong form).
+ *   nncf_shard_run_chunk   all of the above for up to 64 steps in ONE native call over a communicator
+ *                          (nncf_shard_set_comm): plan -> counts all-to-all -> one host read of both count tables (the
+ *                          chunk's only synchronisation) -> ids all-to-all -> per step: rows all-to-all, local step,
+ *                          gradients all-to-all, owners' apply -- every exchange enqueued on `stream` between the kernels
+ *                          it feeds.  d_uid / d_cid as nncf_shard_plan; d_losses [n_steps] (or NULL). */
 typedef struct nncf_shard nncf_shard;
 int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, int32_t item_shard, int32_t item_offset,
                       float* d_user_shard, int32_t user_stride, int32_t user_shard, int32_t user_offset, int32_t n_ranks,
@@ -588,6 +620,9 @@ int nncf_shard_plan(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, i
 int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, const int64_t* rows_per_step, void* stream);
 int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d_loss, void* stream);
 int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, void* stream);
+int nncf_shard_set_comm(nncf_shard* h, nncf_comm* c);
+int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, int64_t n_steps, float* d_losses, float lr,
+                         void* stream);
 
 /* Duplicate-row plan of one id list (exposed for tests): positions sorted by (id, position),
  * segment starts, and tf.unique-style first-occurrence outputs.

@@ -71,6 +71,11 @@ class TowerParams(ctypes.Structure):
 LOSS_CODES = {"skip-gram": 0, "mse": 1, "log-loss": 2, "max-margin": 3}
 
 
+# nncf_xfer_fn (include/nncf_hip.h): the callback transport of the multi-GPU tests
+XFER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                           ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p)
+
+
 def _declare(lib):
     vp, i32, i64, u64, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_double
     lib.nncf_last_error.restype = ctypes.c_char_p
@@ -127,6 +132,15 @@ def _declare(lib):
         "nncf_shard_step": [vp, i64, vp, vp, vp],
         "nncf_shard_apply": [vp, i64, i64, f32, vp],
         "nncf_shard_set_optimizer": [vp, i32, vp, vp, vp],
+        "nncf_shard_set_comm": [vp, vp],
+        "nncf_shard_run_chunk": [vp, vp, vp, i64, vp, f32, vp],
+        "nncf_comm_unique_id": [vp],
+        "nncf_comm_create": [vp, i32, i32, i32, ctypes.POINTER(vp)],
+        "nncf_comm_create_callback": [XFER_FN, vp, i32, i32, ctypes.POINTER(vp)],
+        "nncf_comm_destroy": [vp],
+        "nncf_comm_all_to_all": [vp, vp, ctypes.POINTER(ctypes.c_int64), vp, ctypes.POINTER(ctypes.c_int64), i32, vp],
+        "nncf_comm_all_reduce_f32": [vp, vp, i64, vp],
+        "nncf_comm_wire_bytes": [vp, ctypes.POINTER(ctypes.c_int64), i32],
         "nncf_scatter_apply": [vp, i32, i32, vp, i32, i32, vp, f32, vp, vp],
         "nncf_scatter_merge": [vp, i32, i32, vp, i32, i32, i32, vp, f32, vp],
         "nncf_tower_create": [ctypes.POINTER(TowerCfg), ctypes.POINTER(TowerParams), i32, ctypes.POINTER(vp)],

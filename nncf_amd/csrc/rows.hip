@@ -2,8 +2,10 @@
 // deterministic scatter-SGD  table[ids[i]] -= lr * rows[i]  with duplicates summed in list order.
 // No reference counterpart (the reference is single-process); SURVEY.md section 8(e).
 #include <new>
+#include <vector>
 
 #include "chunk_reduce.h"
+#include "comm.h"
 #include "common.h"
 #include "devutil.h"
 #include "model.h"
@@ -220,6 +222,10 @@ struct nncf_shard {
   int32_t *cnt_out = nullptr, *cnt_in = nullptr;   // [ranks][nx][kPlanChunk]: unique ids of step s asked of / by rank r
   int64_t bound[2][nncf::kPlanChunk];              // host: rows the owner side handles per step (grid sizes)
   bool have_bound = false;
+  bool alias = true;               // one rank: both ends of every exchange are the same memory (NNCF_SHARD_NOALIAS=1: kept apart)
+  nncf_comm* comm = nullptr;       // borrowed (nncf_shard_set_comm): the transport of nncf_shard_run_chunk
+  float* loss_scratch = nullptr;   // one float: the step's loss when the caller does not want it
+  int32_t* h_cnt = nullptr;        // pinned host copy of both count tables [2][ranks][nx][kPlanChunk]
 };
 
 namespace nncf {
@@ -363,7 +369,8 @@ __global__ void __launch_bounds__(256) merge_step_kernel(StepArgs a, AdamTable a
 
 static void carve_shard(nncf_shard* h, Carver& c) {
   const int R = h->ranks;
-  const bool alias = R == 1;   // one rank: both ends of every exchange are the same memory
+  const bool alias = h->alias;   // one rank: both ends of every exchange are the same memory
+  h->loss_scratch = c.take<float>(4);
   h->cnt_out = c.take<int32_t>((size_t)R * h->nx * kPlanChunk);
   h->cnt_in = alias ? h->cnt_out : c.take<int32_t>((size_t)R * h->nx * kPlanChunk);
   for (int xi = 0; xi < h->nx; ++xi) {
@@ -419,6 +426,10 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   h->m = m; h->d = m->cfg.dim; h->b = b; h->ranks = n_ranks; h->rank = rank; h->device = device;
   h->strong = strong ? 1 : 0;
   h->nx = strong ? 2 : 1;
+  {
+    const char* e = getenv("NNCF_SHARD_NOALIAS");
+    h->alias = n_ranks == 1 && !(e && e[0] && e[0] != '0');
+  }
   h->x[0].shard = d_item_shard; h->x[0].stride = item_stride; h->x[0].shard_rows = item_shard; h->x[0].i0 = item_offset;
   h->x[0].n = b; h->x[0].land = m->V;
   if (strong) {
@@ -451,6 +462,7 @@ int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float*
 int nncf_shard_destroy(nncf_shard* h) {
   if (!h) return NNCF_OK;
   if (h->arena) hipFree(h->arena);
+  if (h->h_cnt) (void)hipHostFree(h->h_cnt);
   delete h;
   return NNCF_OK;
 }
@@ -493,7 +505,7 @@ int nncf_shard_plan(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, i
     ProfScope _ps("route_kernel", st);
     hipLaunchKernelGGL(shard_count_kernel, dim3((unsigned)n_steps), dim3(64), 0, st, e.plan, e.shard_rows, h->ranks, h->nx, xi, h->cnt_out);
     hipLaunchKernelGGL(shard_offsets_kernel, dim3(1), dim3(64), 0, st, h->cnt_out, h->ranks, h->nx, xi, e.send_off,
-                       h->ranks == 1 ? e.step_off : (int32_t*)nullptr);
+                       h->alias ? e.step_off : (int32_t*)nullptr);
     hipLaunchKernelGGL(route_compact_kernel, dim3((e.n + 255) / 256, (unsigned)n_steps), dim3(256), 0, st, e.plan, e.n, e.shard_rows,
                        h->ranks, e.send_off, e.req_out, e.slot);
     NNCF_HIP_CHECK(hipGetLastError());
@@ -520,7 +532,7 @@ static int gather_step(nncf_shard* h, int xi, int64_t s, hipStream_t st) {
 int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, const int64_t* rows_per_step, void* stream) {
   NNCF_REQUIRE(h != nullptr, "shard is NULL");
   NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps per chunk", kPlanChunk);
-  NNCF_REQUIRE(h->ranks == 1 || rows_per_step, "with several ranks the host passes the rows every step handles (from the exchanged counts)");
+  NNCF_REQUIRE(h->alias || rows_per_step, "with several ranks the host passes the rows every step handles (from the exchanged counts)");
   hipStream_t st = as_stream(stream);
   if (rows_per_step) {   // [n_exchanges][n_steps]: what this rank's shard is asked for, per step
     for (int xi = 0; xi < h->nx; ++xi)
@@ -533,7 +545,7 @@ int nncf_shard_plan_owner(nncf_shard* h, int64_t n_steps, const int64_t* rows_pe
   }
   for (int xi = 0; xi < h->nx; ++xi) {
     Exch& e = h->x[xi];
-    if (h->ranks > 1) {
+    if (!h->alias) {
       hipLaunchKernelGGL(shard_offsets_kernel, dim3(1), dim3(64), 0, st, h->cnt_in, h->ranks, h->nx, xi, e.recv_off, e.step_off);
       NNCF_HIP_CHECK(hipGetLastError());
     }
@@ -595,6 +607,82 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
   if (h->m->opt) h->m->adam_t++;
   if (index + 1 < n_steps) return NNCF_OK;
   return flush_pending_loss(h->m, st);
+}
+
+int nncf_shard_set_comm(nncf_shard* h, nncf_comm* c) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(!c || (c->n_ranks == h->ranks && c->rank == h->rank), "communicator of rank %d / %d on a session of rank %d / %d",
+               c ? c->rank : -1, c ? c->n_ranks : -1, h->rank, h->ranks);
+  h->comm = c;
+  return NNCF_OK;
+}
+
+// One chunk of up to 64 global steps, every exchange issued from here on the step's stream.
+int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_cid, int64_t n_steps, float* d_losses, float lr,
+                         void* stream) {
+  NNCF_REQUIRE(h && d_uid && d_cid, "NULL argument");
+  NNCF_REQUIRE(n_steps >= 1 && n_steps <= kPlanChunk, "1..%d steps per chunk", kPlanChunk);
+  NNCF_REQUIRE(h->alias || h->comm, "several ranks (or NNCF_SHARD_NOALIAS): nncf_shard_set_comm first");
+  hipStream_t st = as_stream(stream);
+  const int R = h->ranks, nx = h->nx, nu = h->strong ? h->x[1].n : h->b;
+  if (int rc = nncf_shard_plan(h, d_uid, d_cid, n_steps, stream)) return rc;
+  std::vector<int64_t> sc(R), rc_(R);
+  const int32_t *snd = nullptr, *rcv = nullptr;   // [peer][exchange][step]
+  if (!h->alias) {
+    const size_t tab = (size_t)R * nx * kPlanChunk;
+    if (!h->h_cnt) NNCF_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->h_cnt), 2 * tab * sizeof(int32_t)));
+    for (int r = 0; r < R; ++r) sc[r] = rc_[r] = (int64_t)nx * kPlanChunk;       // static: nx * 64 counts per peer
+    if (int rc = comm_all_to_all(h->comm, h->cnt_out, sc.data(), h->cnt_in, rc_.data(), sizeof(int32_t), st)) return rc;
+    NNCF_HIP_CHECK(hipMemcpyAsync(h->h_cnt, h->cnt_out, tab * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NNCF_HIP_CHECK(hipMemcpyAsync(h->h_cnt + tab, h->cnt_in, tab * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    NNCF_HIP_CHECK(hipStreamSynchronize(st));                                     // the chunk's one host read
+    snd = h->h_cnt;
+    rcv = h->h_cnt + tab;
+    std::vector<int64_t> rows((size_t)nx * n_steps, 0);
+    for (int xi = 0; xi < nx; ++xi) {                                             // the chunk's requested ids -> owners
+      for (int r = 0; r < R; ++r) {
+        int64_t a = 0, b = 0;
+        for (int64_t s = 0; s < n_steps; ++s) {
+          a += snd[((size_t)r * nx + xi) * kPlanChunk + s];
+          b += rcv[((size_t)r * nx + xi) * kPlanChunk + s];
+          rows[(size_t)xi * n_steps + s] += rcv[((size_t)r * nx + xi) * kPlanChunk + s];
+        }
+        sc[r] = a;
+        rc_[r] = b;
+      }
+      Exch& e = h->x[xi];
+      if (int rc = comm_all_to_all(h->comm, e.req_out, sc.data(), e.req_in, rc_.data(), sizeof(int32_t), st)) return rc;
+    }
+    if (int rc = nncf_shard_plan_owner(h, n_steps, rows.data(), stream)) return rc;
+  } else {
+    if (int rc = nncf_shard_plan_owner(h, n_steps, nullptr, stream)) return rc;   // rows of step 0 gathered
+  }
+  const int eb = (int)sizeof(float) * h->d;
+  for (int64_t i = 0; i < n_steps; ++i) {
+    if (!h->alias) {
+      for (int xi = 0; xi < nx; ++xi) {                                           // rows -> requesters
+        Exch& e = h->x[xi];
+        for (int r = 0; r < R; ++r) {
+          sc[r] = rcv[((size_t)r * nx + xi) * kPlanChunk + i];                    // what rank r asked of this shard
+          rc_[r] = snd[((size_t)r * nx + xi) * kPlanChunk + i];                   // what this rank asked of rank r
+        }
+        if (int rc = comm_all_to_all(h->comm, e.rows_out, sc.data(), e.land, rc_.data(), eb, st)) return rc;
+      }
+    }
+    if (int rc = nncf_shard_step(h, i, h->strong ? nullptr : d_uid + i * nu, d_losses ? d_losses + i : h->loss_scratch, stream)) return rc;
+    if (!h->alias) {
+      for (int xi = 0; xi < nx; ++xi) {                                           // gradients -> owners
+        Exch& e = h->x[xi];
+        for (int r = 0; r < R; ++r) {
+          sc[r] = snd[((size_t)r * nx + xi) * kPlanChunk + i];
+          rc_[r] = rcv[((size_t)r * nx + xi) * kPlanChunk + i];
+        }
+        if (int rc = comm_all_to_all(h->comm, e.g_out, sc.data(), e.g_in, rc_.data(), eb, st)) return rc;
+      }
+    }
+    if (int rc = nncf_shard_apply(h, i, n_steps, lr, stream)) return rc;          // apply; rows of step i + 1 gathered
+  }
+  return NNCF_OK;
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ backend and run the same code over gloo on CPU; with a gloo process group and CU
 through host memory (two ranks sharing one GPU in the tests).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -198,7 +199,7 @@ class HipBackend(object):
                 n = ctypes.c_int32()
                 self._lib.check(L.nncf_shard_buffers(h, xi, *([ctypes.byref(q) for q in ptrs] + [ctypes.byref(n)])))
                 n = n.value
-                own = W * n if W > 1 else n      # owner-side capacity (one rank: the two ends are the same memory)
+                own = W * n                      # owner-side capacity (W = 1: n, aliased or not)
                 bufs["x"].append(dict(
                     n=n,
                     req_out=view(ptrs[0], CH * n, torch.int32, (CH * n,)),
@@ -239,6 +240,20 @@ class HipBackend(object):
         with torch.cuda.device(self.device):
             self._lib.check(self._lib.lib().nncf_shard_apply(self._session(), int(index), int(n_steps), self.lr, self._stream()))
 
+    def set_comm(self, comm):
+        """the transport of run_chunk_native (a Communicator; None: one aliased rank needs none)"""
+        self._comm = comm
+        self._lib.check(self._lib.lib().nncf_shard_set_comm(self._session(), comm.handle if comm is not None else ctypes.c_void_p()))
+
+    def run_chunk_native(self, uid_chunk, cid_chunk, n_steps, losses):
+        """up to CHUNK global steps in ONE native call: plan, the counts / ids exchanges and, per step, rows -> local step ->
+        gradients -> apply, every exchange enqueued on the step's stream by the library (nncf_shard_run_chunk)"""
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().nncf_shard_run_chunk(self._session(), p(uid_chunk), p(cid_chunk), int(n_steps),
+                                                                 p(losses) if losses is not None else ctypes.c_void_p(), self.lr,
+                                                                 self._stream()))
+
     def close(self):
         h, self._sh = getattr(self, "_sh", None), None
         if h:
@@ -257,21 +272,143 @@ def _wrap_device_pointer(ptr, count, dtype, device):
         pass
     holder = _Holder()
     holder.__cuda_array_interface__ = {
-        "shape": (int(count),), "typestr": {torch.int32: "<i4", torch.float32: "<f4"}[dtype], "data": (int(ptr), False),
+        "shape": (int(count),), "typestr": {torch.int32: "<i4", torch.float32: "<f4", torch.uint8: "|u1"}[dtype], "data": (int(ptr), False),
         "version": 3, "strides": None}
     return torch.as_tensor(holder, device=device)
 
 
+class Communicator(object):
+    """nncf_comm_* (include/nncf_hip.h): the native transport of the sharded trainers.
+      Communicator.rccl(group, device)      RCCL over xGMI: rank 0 draws the unique id, the process group broadcasts its 128
+                                            bytes, every rank joins (one process per GPU; works for ONE rank too)
+      Communicator.callback(group, device)  the same native call sequence over a Python callback: device buffers staged through
+                                            host memory and exchanged by the process group (gloo) -- the two-ranks-on-one-GPU
+                                            tests, where RCCL cannot run (it refuses two ranks on one device)"""
+
+    def __init__(self, handle, kind, keep=None):
+        from . import _lib
+        self._lib, self.handle, self.kind, self._keep = _lib, handle, kind, keep
+
+    @classmethod
+    def rccl(cls, group, device):
+        from . import _lib
+        L = _lib.lib()
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.nncf_comm_unique_id(buf))
+        box = [bytes(buf.raw)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = ctypes.c_void_p()
+        idx = torch.device(device).index or 0
+        _lib.check(L.nncf_comm_create(ctypes.c_char_p(box[0]), world, rank, idx, ctypes.byref(h)))
+        return cls(h, "rccl")
+
+    @classmethod
+    def callback(cls, group, device):
+        from . import _lib
+        L = _lib.lib()
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = torch.device(device)
+
+        def xfer(user, d_send, send_cnt, d_recv, recv_cnt, elem_bytes, n_ranks, stream):
+            try:
+                torch.cuda.synchronize(dev)      # the kernels that produced the payload were enqueued just before
+                if elem_bytes == 0:              # all-reduce (sum) of send_cnt[0] floats in place
+                    n = int(send_cnt[0])
+                    if n:
+                        t = _wrap_device_pointer(d_send, n, torch.float32, dev)
+                        c = t.cpu()
+                        if world > 1:
+                            dist.all_reduce(c, group=group)
+                        t.copy_(c)
+                else:
+                    sc = [int(send_cnt[r]) * elem_bytes for r in range(n_ranks)]
+                    rc = [int(recv_cnt[r]) * elem_bytes for r in range(n_ranks)]
+                    inp = _wrap_device_pointer(d_send, sum(sc), torch.uint8, dev).cpu() if sum(sc) else torch.empty(0, dtype=torch.uint8)
+                    out = torch.empty(sum(rc), dtype=torch.uint8)
+                    if world > 1:
+                        dist.all_to_all_single(out, inp, rc, sc, group=group)
+                    else:
+                        out.copy_(inp)
+                    if sum(rc):
+                        _wrap_device_pointer(d_recv, sum(rc), torch.uint8, dev).copy_(out)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:   # noqa: BLE001 -- an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        fn = _lib.XFER_FN(xfer)
+        h = ctypes.c_void_p()
+        _lib.check(L.nncf_comm_create_callback(fn, ctypes.c_void_p(), world, rank, ctypes.byref(h)))
+        return cls(h, "callback", keep=fn)
+
+    def all_reduce_(self, t, stream=None):
+        """in-place sum of a float32 device tensor over the ranks, on torch's current stream"""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._lib.check(self._lib.lib().nncf_comm_all_reduce_f32(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(),
+                                                                 self._lib.stream_ptr(stream)))
+
+    def wire_bytes(self, reset=False):
+        out = ctypes.c_int64()
+        self._lib.check(self._lib.lib().nncf_comm_wire_bytes(self.handle, ctypes.byref(out), 1 if reset else 0))
+        return out.value
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h:
+            self._lib.lib().nncf_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
+
 class _Exchanger(object):
-    """all-to-alls of one rank's trainer: static and variable splits; aliasing (one rank), host staging (gloo process
-    group with device tensors: the CPU-box and two-ranks-on-one-GPU tests) or the process group's own transport (RCCL)."""
+    """all-to-alls of one rank's trainer.  Transports (NNCF_SHARD_TRANSPORT overrides the choice):
+      native    the library issues every exchange itself over RCCL, one native call per 64-step chunk (nncf_shard_run_chunk over
+                a Communicator.rccl): the default whenever the process group's backend is nccl and the backend is the HIP one
+      callback  the same native call sequence over Communicator.callback (gloo + host staging): two ranks on one GPU
+      torch     this module issues torch.distributed collectives between the library's calls: the process group's own
+                transport for device tensors (nccl), host staging for a gloo group; the numpy backends of the CPU tests
+    One rank: the native session aliases both ends of every exchange and nothing is exchanged -- unless NNCF_SHARD_NOALIAS=1
+    keeps them apart, in which case that ONE rank drives the real collectives (single-GPU tests of the multi-GPU code)."""
 
     def _init_group(self, group):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.stage_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
-        self.wire_bytes = 0       # payload bytes this rank handed to all_to_all_single (incl. its own share), for the record
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.stage_host = backend == "gloo"
+        self._wire = 0            # payload bytes this rank handed to all_to_all_single (incl. its own share), for the record
+        native_ok = hasattr(self.be, "run_chunk_native")
+        want = os.environ.get("NNCF_SHARD_TRANSPORT", "")
+        if want not in ("", "native", "callback", "torch"):
+            raise ValueError("NNCF_SHARD_TRANSPORT must be native, callback or torch")
+        self.transport = want or ("native" if (native_ok and backend == "nccl") else "torch")
+        if self.transport != "torch" and not native_ok:
+            raise ValueError("NNCF_SHARD_TRANSPORT=%s needs the HIP backend" % self.transport)
+        self.comm = None
+
+    @property
+    def wire_bytes(self):
+        return self._wire + (self.comm.wire_bytes() if self.comm is not None else 0)
+
+    @wire_bytes.setter
+    def wire_bytes(self, v):
+        self._wire = int(v)
+        if self.comm is not None:
+            self.comm.wire_bytes(reset=True)
+
+    def _aliased(self):
+        bufs = self.be.chunk_buffers()
+        return bufs["cnt_in"].data_ptr() == bufs["cnt_out"].data_ptr()
 
     def _a2a(self, out, inp, out_splits=None, in_splits=None):
         if out.data_ptr() == inp.data_ptr():
@@ -279,10 +416,10 @@ class _Exchanger(object):
         if out_splits is not None:
             out, inp = out[:int(sum(out_splits))], inp[:int(sum(in_splits))]
             out_splits, in_splits = [int(v) for v in out_splits], [int(v) for v in in_splits]
-        if self.world == 1:
+        if not dist.is_initialized():
             out.copy_(inp)
             return
-        self.wire_bytes += inp.numel() * inp.element_size()
+        self._wire += inp.numel() * inp.element_size()
         if self.stage_host and inp.is_cuda:
             oc = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(oc, inp.cpu(), out_splits, in_splits, group=self.group)
@@ -296,11 +433,21 @@ class _Exchanger(object):
         be = self.be
         bufs = be.chunk_buffers()
         ch, nx, W = be.CHUNK, be.nx, self.world
+        exchange = not self._aliased()
+        if self.transport in ("native", "callback"):
+            if exchange and self.comm is None:
+                self.comm = (Communicator.rccl if self.transport == "native" else Communicator.callback)(self.group, be.device)
+                be.set_comm(self.comm)
+            for t0 in range(0, n_steps, ch):
+                cnt = min(ch, n_steps - t0)
+                be.run_chunk_native(uid_all[t0 * nu:(t0 + cnt) * nu], cid_all[t0 * nc:(t0 + cnt) * nc], cnt,
+                                    losses[t0:t0 + cnt] if losses is not None else None)
+            return losses
         for t0 in range(0, n_steps, ch):
             cnt = min(ch, n_steps - t0)
             be.plan_chunk(uid_all[t0 * nu:(t0 + cnt) * nu], cid_all[t0 * nc:(t0 + cnt) * nc], cnt)
             send = recv = None
-            if W > 1:
+            if exchange:
                 self._a2a(bufs["cnt_in"], bufs["cnt_out"])              # static: nx * CHUNK counts per peer
                 both = torch.stack([bufs["cnt_out"], bufs["cnt_in"]]).cpu().numpy().reshape(2, W, nx, ch)   # the chunk's one host read
                 send, recv = both[0], both[1]                            # [peer][exchange][step]
@@ -314,7 +461,7 @@ class _Exchanger(object):
                 t = t0 + i
                 for xi in range(nx):                                     # rows -> requesters
                     xb = bufs["x"][xi]
-                    if W > 1:
+                    if exchange:
                         self._a2a(xb["rows_in"], xb["rows_out"], send[:, xi, i], recv[:, xi, i])
                     else:
                         self._a2a(xb["rows_in"], xb["rows_out"])
@@ -322,7 +469,7 @@ class _Exchanger(object):
                 be.local_step_at(i, uid_all[t * nu:(t + 1) * nu] if uid_per_step else None, lo)
                 for xi in range(nx):                                     # gradients -> owners
                     xb = bufs["x"][xi]
-                    if W > 1:
+                    if exchange:
                         self._a2a(xb["g_in"], xb["g_out"], recv[:, xi, i], send[:, xi, i])
                     else:
                         self._a2a(xb["g_in"], xb["g_out"])
@@ -473,11 +620,29 @@ class DataParallelTower(object):
         self.be = replica
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        backend = dist.get_backend(group) if dist.is_initialized() else None
+        hip = hasattr(replica, "tower")            # HipTowerReplica (the numpy replicas of the CPU tests have no device)
+        want = os.environ.get("NNCF_SHARD_TRANSPORT", "")
+        self.transport = want or ("native" if (hip and backend == "nccl") else "torch")
+        # one rank has nothing to reduce -- unless NNCF_SHARD_NOALIAS=1 asks that ONE rank to drive the real collective
+        self.reduce = self.world > 1 or (dist.is_initialized() and os.environ.get("NNCF_SHARD_NOALIAS", "0") not in ("", "0"))
+        self.comm = None
+        if self.reduce and self.transport in ("native", "callback") and hip:
+            self.comm = (Communicator.rccl if self.transport == "native" else Communicator.callback)(group, replica.engine.device)
+        self.wire_bytes = 0
+
+    def _all_reduce(self):
+        g = self.be.grad
+        self.wire_bytes += g.numel() * g.element_size()
+        if self.comm is not None:
+            self.comm.all_reduce_(g)        # RCCL (or the callback transport), enqueued by the library on the step's stream
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, uid, cid, loss_out=None):
         loss = self.be.step(uid, cid, loss_out)
-        if self.world > 1:
-            dist.all_reduce(self.be.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.reduce:
+            self._all_reduce()
         self.be.apply(1.0)
         return loss
 
@@ -498,6 +663,6 @@ class DataParallelTower(object):
                     be.step_at(i, uid_all[t * b:(t + 1) * b], lo)
                 else:
                     be.step(uid_all[t * b:(t + 1) * b], cid_all[t * b:(t + 1) * b], lo)
-                if self.world > 1:
-                    dist.all_reduce(be.grad, op=dist.ReduceOp.SUM, group=self.group)
+                if self.reduce:
+                    self._all_reduce()
                 be.apply(1.0)

@@ -19,7 +19,10 @@ def main():
     loss = sys.argv[6] if len(sys.argv) > 6 else "skip-gram"
     optimizer = sys.argv[7] if len(sys.argv) > 7 else "sgd"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("NNCF_TEST_BACKEND", "gloo")    # "nccl": RCCL (one rank per GPU: the world-1 tests of the native transport)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from nncf_amd.sharded import HipBackend, ShardedGlobalBatch, ShardedNegShared
     out = {}
     if case in ("weak", "strong"):
@@ -43,8 +46,10 @@ def main():
             cid = be.ids(np.concatenate([c for _, c in bt]))
         tr.run_epoch(uid, cid, sc.STEPS, losses)
         be.engine.check()
+        want = os.environ.get("NNCF_SHARD_TRANSPORT")
+        assert not want or tr.transport == want, (tr.transport, want)
         lc = losses.cpu()
-        if case == "strong":
+        if case == "strong" and world > 1:
             dist.all_reduce(lc)               # a step's loss = the sum of the ranks' shares
         out = dict(U=be.U[:, :sc.D].cpu().numpy(), V=be.V[:, :sc.D].cpu().numpy(), losses=lc.numpy(), wire=np.int64(tr.wire_bytes))
     elif case == "tower":
@@ -64,13 +69,15 @@ def main():
         losses = torch.zeros(sc.STEPS, dtype=torch.float32, device=e.device)
         dp.run_epoch(e.ids(stream[:, 0]), e.ids(stream[:, 1]), sc.STEPS, 64, losses)
         e.check()
+        assert dp.reduce == (world > 1 or os.environ.get("NNCF_SHARD_NOALIAS", "0") == "1")
         tw = rep.tower
         out = dict(U=e.U.cpu().numpy(), losses=losses.cpu().numpy(),
                    **{k: getattr(tw, k).cpu().numpy() for k in ("W", "Wd", "bd", "gamma", "beta")})
     else:
         raise SystemExit("unknown case %r" % case)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     dist.destroy_process_group()
 
 

@@ -31,9 +31,13 @@ def _free_port():
     return p
 
 
-def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd"):
+def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd", **env_extra):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("NNCF_SHARD_TRANSPORT", "NNCF_SHARD_NOALIAS", "NNCF_COMM_SELF_VIA_RCCL", "NNCF_TEST_BACKEND"):
+        env.pop(k, None)
+    env.update(env_extra)
+    os.makedirs(str(tmp_path), exist_ok=True)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_rank_worker.py"), case, str(r), str(world), port,
                                str(tmp_path), loss, optimizer], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
@@ -51,11 +55,13 @@ def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd"):
     return [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
 
 
-@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
-def test_weak_form_two_ranks_on_one_gpu(tmp_path, loss):
-    """item-sharded weak form: every rank its own batch per step, compact variable-split exchanges"""
+@pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback")])
+def test_weak_form_two_ranks_on_one_gpu(tmp_path, loss, transport):
+    """item-sharded weak form: every rank its own batch per step, compact variable-split exchanges.  transport = callback: ONE
+    native call per 64-step chunk (nncf_shard_run_chunk) issues every exchange -- what runs over RCCL on a multi-GPU node, here
+    over the callback communicator (gloo + host staging: RCCL refuses two ranks on one device)"""
     world = 2
-    got = _run_ranks("weak", world, tmp_path, loss)
+    got = _run_ranks("weak", world, tmp_path, loss, NNCF_SHARD_TRANSPORT=transport)
     U, V, losses = sc.simulate_weak(loss, world)
     us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
     for r in range(world):
@@ -68,11 +74,11 @@ def test_weak_form_two_ranks_on_one_gpu(tmp_path, loss):
     assert got[0]["wire"] < 1.6 * rows_bytes + 4 * uniq + 2 * 2 * 64 * 4 * 2
 
 
-@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
-def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss):
+@pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback")])
+def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss, transport):
     """same-global-batch form: the b x b step split by rows over two ranks == the one-device step on identical inputs"""
     world = 2
-    got = _run_ranks("strong", world, tmp_path, loss)
+    got = _run_ranks("strong", world, tmp_path, loss, NNCF_SHARD_TRANSPORT=transport)
     U, V, losses = sc.simulate_strong(loss)
     us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
     for r in range(world):
@@ -94,9 +100,11 @@ def test_strong_form_two_ranks_with_adam_equal_the_single_device_step(tmp_path, 
         np.testing.assert_allclose(got[r]["V"], V[r * isz:(r + 1) * isz], rtol=5e-4, atol=5e-5)
 
 
-def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("transport", ["torch", "callback"])
+def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path, transport):
     """basic_embedding, data parallel: both ranks' HIP towers export their gradients, ONE all-reduce per step, the
-    replicas apply the sum -- against the same loop on two oracle replicas"""
+    replicas apply the sum -- against the same loop on two oracle replicas (callback: the all-reduce issued through the
+    native communicator interface)"""
     import torch
     from oracle import step_oracle as so
     from nncf_amd import synthetic
@@ -104,7 +112,7 @@ def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path):
     from nncf_amd.data_utils import get_data
     from nncf_amd.model_framework import get_model
     world = 2
-    got = _run_ranks("tower", world, tmp_path)
+    got = _run_ranks("tower", world, tmp_path, NNCF_SHARD_TRANSPORT=transport)
     data = synthetic.make_citeulike_like(**sc.TW)
     conf = get_conf("synthetic", "best", dict(sc.TW_PD), model_choice="basic_embedding")
     md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)    # the ranks' initial state
@@ -138,3 +146,25 @@ def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path):
         own = slice(r * us, (r + 1) * us)
         np.testing.assert_allclose(got[r]["U"][own], reps[r][0].U[own], rtol=1e-4, atol=2e-5)
     del torch
+
+
+# ---- ONE rank over RCCL: the multi-GPU code paths on the one-GPU box ----------------------------------------------------
+RCCL1 = dict(NNCF_TEST_BACKEND="nccl", NNCF_SHARD_NOALIAS="1", NNCF_COMM_SELF_VIA_RCCL="1")
+
+
+@pytest.mark.parametrize("case", ["weak", "strong", "tower"])
+@pytest.mark.parametrize("transport", ["native", "torch"])
+def test_one_rank_drives_the_real_rccl_collectives(tmp_path, case, transport):
+    """before this round no RCCL collective had executed -- one rank aliased both ends of every exchange.
+    With NNCF_SHARD_NOALIAS=1 the session keeps them apart and the ONE rank of an nccl process group runs the real thing:
+      native  nncf_shard_run_chunk issues grouped ncclSend / ncclRecv with the variable splits on the step's stream (the rank's own
+              share through RCCL too: NNCF_COMM_SELF_VIA_RCCL=1); the data-parallel tower's all-reduce is ncclAllReduce
+      torch   torch.distributed.all_to_all_single / all_reduce on the nccl backend over the library's device views
+    Result == the aliased run of the same rank, BITWISE (the exchanges only move bytes)."""
+    ref = _run_ranks(case, 1, tmp_path / "alias")[0]
+    got = _run_ranks(case, 1, tmp_path / "rccl", NNCF_SHARD_TRANSPORT=transport, **RCCL1)[0]
+    for k in ref:
+        if k != "wire":
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    if case != "tower":
+        assert ref["wire"] == 0 and got["wire"] > 0       # nothing travels when the ends alias; the real exchanges carry the rows
