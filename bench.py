@@ -652,12 +652,14 @@ def main_sharded(args, conf, rank, world, local_rank):
     if not np.isfinite(mean_loss):
         raise SystemExit("ERROR (nan)! cost is %r" % mean_loss)
     # roofline leg: the same kernel as the N = 1 line of this model (the one-launch step), rank 0's brackets
-    name = args.roofline_kernel or ("fused_strip_kernel" if (b < 4096 or strong) else "fused_wide_kernel")
+    replicated = bool(getattr(be, "replicated", False))   # pairwise loss on the strong form: every rank runs the whole b x b step
+    name = args.roofline_kernel or ("shared_tile_kernel" if replicated else
+                                    ("fused_strip_kernel" if (b < 4096 or strong) else "fused_wide_kernel"))
     prof_n = min(K, args.profile_launches)
     nengine.profile_begin(name, prof_n)
     run(W, prof_n, False)
     raw_ms, launches, ov_ms = nengine.profile_end()
-    rows = b // world if strong else b
+    rows = b // world if (strong and not replicated) else b
     work = 6.0 * rows * b * d
     roof = roof_entry(name, "mfma", work, "6*rows*b*d flop (S, G.V, G^T.U) of this rank's %d x %d block of the score matrix; the kernel "
                       "issues 8*rows*b*d (S recomputed by the item pass)" % (rows, b), raw_ms, ov_ms, launches) if launches else None

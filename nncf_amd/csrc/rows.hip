@@ -223,6 +223,7 @@ struct nncf_shard {
   int64_t bound[2][nncf::kPlanChunk];              // host: rows the owner side handles per step (grid sizes)
   bool have_bound = false;
   bool alias = true;               // one rank: both ends of every exchange are the same memory (NNCF_SHARD_NOALIAS=1: kept apart)
+  bool replicated = false;         // strong form, pairwise loss: every rank fetches ALL 2 b rows and runs the whole b x b step
   nncf_comm* comm = nullptr;       // borrowed (nncf_shard_set_comm): the transport of nncf_shard_run_chunk
   float* loss_scratch = nullptr;   // one float: the step's loss when the caller does not want it
   int32_t* h_cnt = nullptr;        // pinned host copy of both count tables [2][ranks][nx][kPlanChunk]
@@ -365,6 +366,24 @@ __global__ void __launch_bounds__(256) merge_step_kernel(StepArgs a, AdamTable a
   apply_update(a, ad, table, id - id_offset, raw, acc, d4, q);   // sparse SGD, or Adam on the summed gradient (step.h)
 }
 
+// Replicated strong form: after the local (whole) step stepped the landing rows in place, every rank writes the rows of the
+// ids IT owns back into its shard.  The ids this rank asked of itself at step s are the block (owner = me, step s) of its own
+// request list, ascending; their landing slots follow the blocks of the lower-ranked owners.  One 16-lane group per id.
+__global__ void __launch_bounds__(256) copy_back_kernel(float* __restrict__ shard, int stride, int d, int id_offset,
+                                                        const float* __restrict__ land, int land_stride,
+                                                        const int32_t* __restrict__ req_out, const int32_t* __restrict__ send_off,
+                                                        const int32_t* __restrict__ cnt_out, int nx, int xi, int me, int s) {
+  const int k = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = d >> 2;
+  const int mine = cnt_out[(me * nx + xi) * kPlanChunk + s];
+  if (k >= mine) return;
+  int base = 0;
+  for (int o = 0; o < me; ++o) base += cnt_out[(o * nx + xi) * kPlanChunk + s];
+  const int id = req_out[send_off[me * kPlanChunk + s] + k];
+  row_store(shard, id - id_offset, stride, d4, q, row_load(land, base + k, land_stride, d4, q));
+}
+
+__global__ void scale_loss_kernel(float* __restrict__ loss, float f) { *loss *= f; }
+
 }  // namespace nncf
 
 static void carve_shard(nncf_shard* h, Carver& c) {
@@ -416,10 +435,22 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   NNCF_REQUIRE(m->cfg.item_count >= b, "the model's item table is the landing buffer: it must hold batch_size_p rows");
   NNCF_REQUIRE(!(m->opt == 1 && m->dup_as_written), "the sharded trainers sum an id's gradient rows before the step: the as-written "
                "sparse Adam (last occurrence wins) has no meaning across ranks");
-  if (strong) {
+  // Pairwise losses (objectives.py:90-98: every score against its column's positive) in the strong form: dL/dS of a
+  // column needs sums over ALL rows, i.e. over all ranks -- two more collectives per step in the row-partitioned form.
+  // They run REPLICATED instead: every rank fetches the rows of all b users and all b items and runs the whole b x b step
+  // on its landing buffers (the one-device kernels, bit for bit); the owners write their rows back into their shards.  No
+  // gradient exchange at all (2 b rows in per rank and step against 2 b + 2 b / n_ranks rows in + out of the partitioned
+  // form); the compute is redundant n_ranks times, which is why this is the parity form, not the throughput form.
+  const bool replicated = strong && (m->cfg.loss == NNCF_LOSS_LOG_LOSS || m->cfg.loss == NNCF_LOSS_MAX_MARGIN);
+  if (strong && !replicated) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
     NNCF_REQUIRE(m->cfg.user_count >= b / n_ranks, "the model's user table is the landing buffer: it must hold batch_size_p / n_ranks rows");
+  }
+  if (replicated) {
+    NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
+    NNCF_REQUIRE(m->cfg.user_count >= b, "replicated strong form (pairwise loss): the model's user table is the landing buffer of ALL batch_size_p positions");
+    NNCF_REQUIRE(!m->ub && !m->cb, "interaction_bias is not built for the sharded trainers");
   }
   nncf_shard* h = new (std::nothrow) nncf_shard();
   if (!h) return fail(NNCF_ERR_NOMEM, "out of host memory");
@@ -434,8 +465,9 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   h->x[0].n = b; h->x[0].land = m->V;
   if (strong) {
     h->x[1].shard = d_user_shard; h->x[1].stride = user_stride; h->x[1].shard_rows = user_shard; h->x[1].i0 = user_offset;
-    h->x[1].n = b / n_ranks; h->x[1].land = m->U;
+    h->x[1].n = replicated ? b : b / n_ranks; h->x[1].land = m->U;
   }
+  h->replicated = replicated;
   Carver dry;
   carve_shard(h, dry);
   DeviceGuard guard(device);
@@ -562,6 +594,24 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
   StepArgs a = make_args(m);
   a.gV = h->x[0].g_out;
   const int32_t* uid = d_uid;
+  if (h->replicated) {   // the whole b x b step on the landing buffers, then the owned rows back into the shards
+    NNCF_REQUIRE(m->opt == 0, "the replicated strong form (pairwise losses) steps with sparse SGD: the owners' Adam state does not travel");
+    a.gV = nullptr;
+    a.gU = nullptr;
+    uid = h->x[1].slot + index * h->x[1].n;
+    int rc = shared_step(m, a, 0, uid, h->x[0].slot + index * h->b, m->plan_u.at(index), m->plan_v.at(index), d_loss, 1, st);
+    if (rc) return rc;
+    if ((rc = flush_pending_loss(m, st))) return rc;
+    if (h->ranks > 1) hipLaunchKernelGGL(scale_loss_kernel, dim3(1), dim3(1), 0, st, d_loss, 1.f / (float)h->ranks);   // the ranks' shares add up to the loss
+    for (int xi = 0; xi < h->nx; ++xi) {
+      Exch& e = h->x[xi];
+      ProfScope _ps("scatter_merge_kernel", st);
+      hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)((e.n + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.land,
+                         m->cfg.row_stride, e.req_out, e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+    }
+    NNCF_HIP_CHECK(hipGetLastError());
+    return NNCF_OK;
+  }
   if (h->strong) {   // rows rank, rank + ranks, ... of the b x b score matrix; both tables are landing buffers
     a.gU = h->x[1].g_out;
     a.bc = h->b;
@@ -593,13 +643,13 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
     StepArgs a = make_args(h->m);   // optimiser constants of THIS step (the counter advances below, once per step)
     a.stride = e.stride;
     a.lr = lr;
-    if (rows > 0) {
+    if (rows > 0 && !h->replicated) {
       ProfScope _ps("scatter_merge_kernel", st);
       hipLaunchKernelGGL(merge_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a, e.ad, e.shard, e.i0, e.g_in,
                          e.req_in, e.recv_off, e.step_off, h->ranks, (int)index);
       NNCF_HIP_CHECK(hipGetLastError());
     }
-    if (a.opt == 2)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
+    if (a.opt == 2 && !h->replicated)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
       if (int rc = launch_adam_idle(a, e.shard, e.ad, e.shard_rows, st)) return rc;
     if (index + 1 < n_steps)   // rows of the next step, after this step's update (synchronous SGD)
       if (int rc = gather_step(h, xi, index + 1, st)) return rc;
@@ -670,7 +720,7 @@ int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_c
       }
     }
     if (int rc = nncf_shard_step(h, i, h->strong ? nullptr : d_uid + i * nu, d_losses ? d_losses + i : h->loss_scratch, stream)) return rc;
-    if (!h->alias) {
+    if (!h->alias && !h->replicated) {
       for (int xi = 0; xi < nx; ++xi) {                                           // gradients -> owners
         Exch& e = h->x[xi];
         for (int r = 0; r < R; ++r) {

@@ -59,7 +59,10 @@ class HipBackend(object):
 
     mode = "weak": the engine's user table is this rank's user shard, its item table the landing buffer.
     mode = "strong": both engine tables are landing buffers (b / world user rows, b item rows); the shards are
-    `self.U` (local_users rows) and `self.V` (local_items rows)."""
+    `self.U` (local_users rows) and `self.V` (local_items rows).  Pairwise losses (log-loss, max-margin) run the strong form
+    REPLICATED (`self.replicated`): the gradient of a column needs sums over all ranks' rows, so every rank fetches the rows
+    of ALL b users and b items, runs the whole b x b step on its landing buffers (the one-device kernels) and the owners write
+    their rows back -- no gradient exchange, compute redundant world times: the parity form (csrc/rows.hip)."""
 
     def __init__(self, engine_kwargs, local_users, local_items, device, world, item_shard, item_offset, seed=0, rank=0,
                  mode="weak", user_shard=None, user_offset=0, shared_device=False):
@@ -78,9 +81,14 @@ class HipBackend(object):
         self.world, self.cap = int(world), self.b
         self.item_shard, self.i0 = int(item_shard), int(item_offset)
         self.user_shard, self.u0 = int(user_shard or local_users), int(user_offset)
-        if mode == "strong":
-            if kw["loss"] not in ("skip-gram", "mse"):
-                raise NotImplementedError("the same-global-batch form runs the one-launch step: pointwise losses (skip-gram, mse)")
+        self.replicated = mode == "strong" and kw["loss"] in ("log-loss", "max-margin")
+        if self.replicated:
+            if kw.get("optimizer", "sgd") != "sgd":
+                raise NotImplementedError("pairwise losses on the strong form run replicated with sparse SGD (the owners' Adam state "
+                                          "does not travel with the rows)")
+            kw["user_count"] = self.b                        # landing rows of ALL positions
+            kw["item_count"] = self.b
+        elif mode == "strong":
             assert self.b % (16 * self.world) == 0, "batch_size_p must be a multiple of 16 * world"
             kw["user_count"] = self.b // self.world          # landing rows of this rank's positions
             kw["item_count"] = self.b                        # landing rows of all columns
@@ -467,7 +475,7 @@ class _Exchanger(object):
                         self._a2a(xb["rows_in"], xb["rows_out"])
                 lo = losses[t:t + 1] if losses is not None else be._loss
                 be.local_step_at(i, uid_all[t * nu:(t + 1) * nu] if uid_per_step else None, lo)
-                for xi in range(nx):                                     # gradients -> owners
+                for xi in range(nx if not getattr(be, "replicated", False) else 0):   # gradients -> owners (replicated form: none)
                     xb = bufs["x"][xi]
                     if exchange:
                         self._a2a(xb["g_in"], xb["g_out"], recv[:, xi, i], send[:, xi, i])
@@ -536,11 +544,14 @@ class ShardedGlobalBatch(_Exchanger):
         self.isz = shard_size(item_count, self.world)
         self.b = int(batch_size_p)
         self.dim = int(dim)
-        assert self.b % self.world == 0
-        self.bl = self.b // self.world
+        self.replicated = bool(getattr(backend, "replicated", False))   # pairwise losses: every rank runs the whole step
+        assert self.replicated or self.b % self.world == 0
+        self.bl = self.b if self.replicated else self.b // self.world
 
     def local_positions(self, uid_global_all, n_steps):
-        """uid of this rank's positions (g, g + G, ...) of every step: [n_steps * b / G]"""
+        """uid of this rank's positions (g, g + G, ...) of every step: [n_steps * b / G]; replicated form: all positions"""
+        if self.replicated:
+            return uid_global_all[:n_steps * self.b]
         return uid_global_all[:n_steps * self.b].view(n_steps, self.b)[:, self.rank::self.world].contiguous().view(-1)
 
     def run_epoch(self, uid_global_all, cid_global_all, n_steps, losses=None):

@@ -21,9 +21,11 @@ def conf(loss="skip-gram", model="mf", optimizer="sgd"):
 
 
 def engine_kwargs(loss="skip-gram", optimizer="sgd"):
+    # the pairwise losses normalise the user rows by default, as the reference's conf does (basic_embedding_conf.py:52-56;
+    # OracleConf follows it), id-table items stay raw (model_framework.py:85-88)
     kw = dict(user_count=NU, item_count=NI, dim=D, batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10.,
-              neg_loss_weight=LAMBDA, u_reg=UREG, learn_rate=LR if optimizer == "sgd" else LR_ADAM, normalize_user=False,
-              normalize_item=False)
+              neg_loss_weight=LAMBDA, u_reg=UREG, learn_rate=LR if optimizer == "sgd" else LR_ADAM,
+              normalize_user=conf(loss).normalize_user, normalize_item=False)
     if optimizer != "sgd":
         kw["optimizer"] = optimizer      # HipBackend: the engine's and the shards' Adam state
     return kw

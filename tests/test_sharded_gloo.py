@@ -223,6 +223,43 @@ class StrongNumpyBackend(_CompactChunks):
         loss_out.copy_(torch.tensor([loss]).reshape(loss_out.shape))
 
 
+class ReplicatedNumpyBackend(_CompactChunks):
+    """strong form of the PAIRWISE losses (HipBackend.replicated): every rank fetches the rows of all b users and all b items,
+    runs the whole b x b step on them and writes the rows it owns back; no gradient exchange"""
+    nx = 2
+    replicated = True
+
+    def __init__(self, conf, Ushard, Vshard, world, rank, user_shard, item_shard):
+        self.conf, self.U, self.V, self.world, self.rank = conf, Ushard, Vshard, world, rank
+        self.lr = np.float32(conf.learn_rate)
+        self.b, self.usz, self.isz = conf.batch_size_p, user_shard, item_shard
+
+    def _tables(self):
+        return [(self.V, self.isz, self.rank * self.isz, self.b), (self.U, self.usz, self.rank * self.usz, self.b)]
+
+    def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
+        self._ids = [cid_chunk.numpy().reshape(n_steps, self.b), uid_chunk.numpy().reshape(n_steps, self.b)]
+        self._plan_lists([cid_chunk, uid_chunk], n_steps)
+
+    def local_step_at(self, index, uid_step, loss_out):
+        xv, xu = self._bufs["x"]
+        if self.world == 1:
+            xv["rows_in"].copy_(xv["rows_out"][:self.b])
+            xu["rows_in"].copy_(xu["rows_out"][:self.b])
+        sv, su = self._slots[0][index], self._slots[1][index]
+        o = so.StepOracle(xu["rows_in"].numpy().copy(), xv["rows_in"].numpy().copy(), self.conf, dtype=np.float32)
+        loss = o.step_neg_shared(su, sv)                     # the one-device step on the landing rows
+        for (shard, rpr, i0, n), ids, slots, land in ((self._tables()[0], self._ids[0][index], sv, o.V),
+                                                      (self._tables()[1], self._ids[1][index], su, o.U)):
+            own = (ids >= i0) & (ids < i0 + shard.shape[0])
+            shard[ids[own] - i0] = land[slots[own]]         # the owners write their rows back
+        loss_out.copy_(torch.tensor([loss / self.world]).reshape(loss_out.shape))   # the ranks' shares add up to the loss
+
+    def apply_at(self, index, n_steps):
+        if index + 1 < n_steps:
+            self._gather(index + 1)
+
+
 def simulate_global_steps(loss, world):
     """Single-process restatement: every rank's batch sees the pre-step tables; user rows are
     disjoint across ranks; item gradients are summed over ranks (rank order) and applied once."""
@@ -363,7 +400,8 @@ def _worker_strong(rank, world, port, loss, ret):
     conf = _conf(loss)
     U, V = _tables()
     us, isz = shard_size(NU, world), shard_size(NI, world)
-    be = StrongNumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, rank, us, isz)
+    cls = ReplicatedNumpyBackend if loss in ("log-loss", "max-margin") else StrongNumpyBackend
+    be = cls(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, rank, us, isz)
     tr = ShardedGlobalBatch(be, NU, NI, B, D)
     bt = _global_batches()
     uid = torch.from_numpy(np.concatenate([u for u, _ in bt]).astype(np.int32))
@@ -376,12 +414,14 @@ def _worker_strong(rank, world, port, loss, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("loss", ["skip-gram", "mse"])
+@pytest.mark.parametrize("loss", ["skip-gram", "mse", "log-loss", "max-margin"])
 @pytest.mark.parametrize("world", [2, 4])
 def test_global_batch_over_ranks_equals_the_single_device_step(loss, world):
     """Strong form (SURVEY.md 8(e) as written): ONE batch of b links per step, rank g holds rows g, g + G, ... of the
     b x b matrix, users and items fetched from their owners, both gradients returned -- loss and both tables equal the
-    one-device step (oracle, models/train_neg_shared.py:46-51 semantics) on the SAME batches to 1e-5."""
+    one-device step (oracle, models/train_neg_shared.py:46-51 semantics) on the SAME batches to 1e-5.  Pairwise losses
+    (log-loss, max-margin) run the REPLICATED form of HipBackend: all 2 b rows to every rank, the whole step everywhere, the
+    owners write their rows back (ReplicatedNumpyBackend restates that protocol)."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_strong, args=(world, _free_port(), loss, ret), nprocs=world, join=True)

@@ -270,7 +270,8 @@ def test_sharded_large_batch_world1():
     assert np.array_equal(U1[idle_u], U0[idle_u]) and np.array_equal(V1[idle_v], V0[idle_v])
 
 
-@pytest.mark.parametrize("loss,norm", [("skip-gram", False), ("mse", False), ("skip-gram", True)])
+@pytest.mark.parametrize("loss,norm", [("skip-gram", False), ("mse", False), ("skip-gram", True), ("log-loss", False),
+                                       ("max-margin", False), ("log-loss", True)])
 def test_strong_form_world1_equals_plain_step_and_oracle(loss, norm):
     """ShardedGlobalBatch at world 1: both engine tables are landing buffers, the rectangular form of the one-launch step
     (all rows) exports both gradients, the owner-side merge steps the shards -- 70 steps (a full chunk + a partial one)
@@ -281,6 +282,7 @@ def test_strong_form_world1_equals_plain_step_and_oracle(loss, norm):
               neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=norm, normalize_item=False)
     be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode="strong", user_shard=nu)
     assert be.engine.U.shape[0] == b and be.engine.V.shape[0] == b and be.U.shape[0] == nu and be.V.shape[0] == ni
+    assert be.replicated == (loss in ("log-loss", "max-margin"))   # pairwise losses: the whole step on every rank, owners write back
     conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
                          learn_rate=0.1, model_choice="mf", emb_normalization=norm)
     orc = so.StepOracle(be.U.cpu().numpy(), be.V.cpu().numpy(), conf, dtype=np.float64)

@@ -77,9 +77,12 @@ def test_weak_form_two_ranks_on_one_gpu(tmp_path, loss, transport):
     assert got[0]["wire"] < 1.6 * rows_bytes + 4 * uniq + 2 * 2 * 64 * 4 * 2
 
 
-@pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback")])
+@pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback"),
+                                            ("log-loss", "torch"), ("max-margin", "torch"), ("log-loss", "callback")])
 def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss, transport):
-    """same-global-batch form: the b x b step split by rows over two ranks == the one-device step on identical inputs"""
+    """same-global-batch form: the b x b step split by rows over two ranks == the one-device step on identical inputs.
+    Pairwise losses (log-loss, max-margin: objectives.py:90-98) run the strong form REPLICATED -- every rank fetches all
+    2 b rows and runs the whole step, the owners write their rows back, no gradient travels (csrc/rows.hip)."""
     world = 2
     got = _run_ranks("strong", world, tmp_path, loss, NNCF_SHARD_TRANSPORT=transport)
     U, V, losses = sc.simulate_strong(loss)
