@@ -523,6 +523,7 @@ def main_data_parallel(args, rank, world, local_rank):
     trace("warmup")
     run(0, W, False)
     trace("timed windows")
+    tr.wire_bytes = 0
     elapsed, win_stats = rank_windows(lambda: run(W, K, True), K, eng.device)
     trace("timed windows done")
     ml = losses.double().mean()
@@ -573,8 +574,9 @@ def main_data_parallel(args, rank, world, local_rank):
                                    % (tower_txt, d, args.scheme, pconf.loss, b),
                        "global_batch": b * world,
                        "parallelism": "1 process per GPU; users + their links partitioned by user range, text tower "
-                                      "replicated; one RCCL all-reduce of the tower gradients (%.2f MB) per step"
-                                      % (rep.grad.numel() * 4 / 1e6)},
+                                      "replicated; one RCCL all-reduce of the tower gradients (%.2f MB) per step; transport = %s"
+                                      % (rep.grad.numel() * 4 / 1e6, tr.transport),
+                       "wire_bytes_per_rank_per_step": tr.wire_bytes / float(max(1, K * win_stats["count"]))},
             "mean_loss": mean_loss,
             "roofline": roof,
             "cpu_baseline": cpu,
@@ -689,7 +691,10 @@ def main_sharded(args, conf, rank, world, local_rank):
                                        "rows, items of all columns), both gradients returned to the owners" if strong else
                                        "1 process per GPU; users + their links and item rows range-sharded") +
                                       "; RCCL all-to-alls with compact variable splits: ids + counts once per 64 steps, rows and "
-                                      "gradients per step",
+                                      "gradients per step; transport = %s%s" % (
+                                          tr.transport + (" (the library issues every exchange itself, one native call per 64-step chunk: "
+                                                          "grouped ncclSend / ncclRecv on the step's stream)" if tr.transport == "native" else ""),
+                                          "; replicated pairwise form: every rank runs the whole step, no gradients travel" if replicated else ""),
                        "wire_bytes_per_rank_per_step": wire_per_step},
             "mean_loss": mean_loss,
             "roofline": roof, "cpu_baseline": cpu,

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: bench JSON lines + rocprofv3 summaries.
-# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r03
+# usage (from the repo root, on the GPU box): bash tools/profile_round.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
@@ -21,6 +21,8 @@ run_prof basic_embedding_neg_shared_pmc_write "--pmc WRITE_SIZE" --steps 390 --w
 run_prof basic_embedding_group_neg_shared_kernel_trace "--stats" --scheme group_neg_shared --steps 780 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof basic_embedding_original_kernel_trace "--stats" --scheme original --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof cnn_embedding_group_neg_shared_kernel_trace "--stats" --model cnn_embedding --scheme group_neg_shared --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
+run_prof cnn_embedding_group_neg_shared_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" --model cnn_embedding --scheme group_neg_shared --steps 195 --warmup 39 --cpu-seconds 0 --profile-launches 10
+run_prof cnn_embedding_original_kernel_trace "--stats" --model cnn_embedding --scheme original --steps 100 --warmup 20 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_kernel_trace "--stats" --model mf --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_write "--pmc WRITE_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
@@ -67,5 +69,17 @@ NNCF_FORCE_SHARDED=1 python3 bench.py --large --steps 1170 --cpu-seconds 0 $B 2>
 NNCF_FORCE_SHARDED=1 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1_b8192.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --scaling strong --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_strong_world1.json
 NNCF_FORCE_SHARDED=1 python3 bench.py --steps 1170 --cpu-seconds 6 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_data_parallel_world1.json
+# ONE rank over RCCL with the exchanges kept real (NNCF_SHARD_NOALIAS=1; the rank's own share through ncclSend / ncclRecv too): the
+# native chunk runner (default transport on an nccl process group) and torch.distributed's collectives
+RC="NNCF_FORCE_SHARDED=1 NNCF_SHARD_NOALIAS=1 NNCF_COMM_SELF_VIA_RCCL=1"
+env $RC python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1_rccl_native.json
+env $RC NNCF_SHARD_TRANSPORT=torch python3 bench.py --model mf --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_world1_rccl_torch.json
+env $RC python3 bench.py --model mf --scaling strong --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_strong_world1_rccl_native.json
+env $RC python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_sharded_world1_b8192_rccl_native.json
+env $RC python3 bench.py --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_data_parallel_world1_rccl_native.json
+NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --scaling strong --loss log-loss --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_mf_sharded_strong_logloss_world1.json
+python3 bench.py --model cnn_embedding --scheme original --cpu-seconds 0 --steps 200 --warmup 20 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_original.json
+python3 bench.py --model cnn_embedding --scheme neg_shared --cpu-seconds 0 --steps 390 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_neg_shared.json
+NNCF_CNN_DBG=64 python3 tools/cnn_timing.py > $OUT/${TAG}_cnn_phase_stamps.txt 2>/dev/null
 python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
 ls -la $OUT/${TAG}_*
