@@ -177,6 +177,9 @@ int nncf_model_get_step(nncf_model* m, int64_t* out);
  * an evaluator on a side stream) -> every step takes the stage + commit form, which waits for nothing inside a launch
  * (same results bit for bit).  Environment default: NNCF_SHARED_DEVICE=1. */
 int nncf_model_set_shared_device(nncf_model* m, int32_t shared);
+/* Clears the sticky time-out flag nncf_model_check reports.  The flag means the tables hold a PARTIAL step: restore
+ * them from a checkpoint (and switch to nncf_model_set_shared_device(m, 1) if the GPU is shared) before training on. */
+int nncf_model_clear_error(nncf_model* m, void* stream);
 /* Synchronises `stream` and reports whether an in-launch wait ever timed out (the wait is bounded: NNCF_FUSED_SPIN_MS,
  * default 250 ms; a workgroup that times out stores nothing and every later loss of the model reads NaN):
  * NNCF_OK, or NNCF_ERR_HIP with the explanation in nncf_last_error(). */
@@ -353,7 +356,8 @@ int nncf_tower_set_pooling(nncf_tower* t, int32_t max_pooling);
 /* Speed only (mean-pool tower, average pooling; no reference counterpart): up to 16 word ids that occur in most items of
  * any batch (the pad id, the corpus's most frequent words).  Their word-row gradient sum_s count[w][s] dL/dh[s] is
  * accumulated by the Dense backward's workgroups, which hold dL/dh, instead of by one wave of the word kernel gathering a
- * row per (word, item) cell; same sums up to fp32 association.  host_words: host array. */
+ * row per (word, item) cell; same sums up to fp32 association.  host_words: host array.  Call it BEFORE
+ * nncf_tower_set_postings (NNCF_ERR_INVALID once postings are bound: their schedule is built around the hot set). */
 int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n);
 /* Speed only (mean-pool tower, average pooling, training blocks of more than 1,024 rows -- train_scheme = original and the
  * row-wise schemes; no reference counterpart): the transposed item CSR and a static schedule over it.
@@ -362,7 +366,9 @@ int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n
  *   d_units [n_workgroups][8][4] int32: per workgroup of the word-table backward 8 units {word (-1: empty slot), first posting,
  *     end, number of units of this word if this is its first unit else 0}; all units of a word sit in ONE workgroup, in
  *     order, every word of the table appears exactly once as a first unit (also words without postings: the optimiser visits
- *     them), a unit should hold <= 512 postings (more: the workgroup walks them in rounds of 512);
+ *     them), a unit should hold <= 512 postings (more: the workgroup walks them in rounds of 512); a HOT word
+ *     (nncf_tower_set_hot_words) keeps its first unit with an EMPTY range (first posting == end) -- its gradient row comes
+ *     from the Dense backward, a non-empty range would add it twice -- which this call checks (NNCF_ERR_INVALID);
  *   d_slot_of [item_count] 64-bit words, zero-initialised, owned by the caller and written by the tower ({forward stamp,
  *     block row} of every item of the current block).
  * The word-table backward then walks its units' postings and keeps the items of the block instead of scanning a
@@ -411,8 +417,9 @@ int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int6
 
 /* d_out[m][item_dim] = tower(d_item_ids).  train == 0: inference phase (running statistics, any
  * m).  train != 0: batch statistics over the first *d_n_valid rows (NULL = all m; rows past it
- * come out zero), running statistics updated, m <= max_rows; prepare_backward != 0 also lays out
- * what nncf_tower_backward needs and MUST then be followed by it.  d_row_scale: an explicit per-word scale
+ * come out zero), m <= max_rows; prepare_backward != 0 also lays out what nncf_tower_backward needs, MUST then be followed
+ * by it, and moves the running statistics (a forward that prepares no backward is a loss-only evaluation and leaves them
+ * alone -- the rule of every step entry point: update == 0 changes nothing).  d_row_scale: an explicit per-word scale
  * overriding the built-in row-dropout mask, or NULL. */
 int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, const int32_t* d_n_valid, int train,
                        int prepare_backward, const float* d_row_scale, float* d_out, void* stream);

@@ -104,6 +104,7 @@ def _declare(lib):
         "nncf_model_get_step": [vp, ctypes.POINTER(ctypes.c_int64)],
         "nncf_model_set_shared_device": [vp, i32],
         "nncf_model_check": [vp, vp],
+        "nncf_model_clear_error": [vp, vp],
         "nncf_model_set_sparse_adam_duplicates": [vp, i32],
         "nncf_model_set_bias": [vp, vp, vp, i64, vp, vp, vp, vp],
         "nncf_model_debug_stamps": [vp, ctypes.POINTER(ctypes.c_longlong), i64],

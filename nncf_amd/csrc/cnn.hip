@@ -387,7 +387,7 @@ __device__ __forceinline__ void bn1_from_totals(const TowerArgs& a, int nv, int 
   }
 }
 __device__ __forceinline__ void bn1_publish(const TowerArgs& a, int c, float mu, float inv, float var, float mul, float add) {
-  if (c < a.cnn.F) {
+  if (c < a.cnn.F && a.fill) {   // an update step (a loss-only evaluation leaves the running statistics alone: as every other path)
     a.cnn.rm1[c] = a.momentum * a.cnn.rm1[c] + (1.f - a.momentum) * mu;
     a.cnn.rv1[c] = a.momentum * a.cnn.rv1[c] + (1.f - a.momentum) * var;
   }

@@ -390,6 +390,13 @@ int nncf_model_set_shared_device(nncf_model* m, int32_t shared) {
   return NNCF_OK;
 }
 
+int nncf_model_clear_error(nncf_model* m, void* stream) {
+  if (int rc = check_model(m)) return rc;
+  DeviceGuard guard(m->device);
+  NNCF_HIP_CHECK(hipMemsetAsync(m->ferr, 0, 2 * sizeof(int), as_stream(stream)));
+  return NNCF_OK;
+}
+
 int nncf_model_check(nncf_model* m, void* stream) {
   if (int rc = check_model(m)) return rc;
   int flag = 0;

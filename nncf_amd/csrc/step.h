@@ -44,6 +44,7 @@ struct StepArgs {
   // mu / inv / var / mul / add (bn_stats) + the running statistics -- no one-workgroup merge launch in between
   const float* bn_parts = nullptr;   // [bn_nparts][2][128]
   int bn_nparts = 0;
+  int bn_update = 0;                 // move the running statistics (an update step; not a loss-only evaluation)
   float* bn_pub = nullptr;           // = bn_stats, writable
   const float* bn_gamma = nullptr;
   const float* bn_beta = nullptr;

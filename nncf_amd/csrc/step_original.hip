@@ -79,8 +79,10 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
             a.bn_pub[c] = mu;
             a.bn_pub[128 + c] = inv;
             a.bn_pub[256 + c] = var;
-            a.bn_rm[c] = a.bn_mom * a.bn_rm[c] + (1.f - a.bn_mom) * mu;
-            a.bn_rv[c] = a.bn_mom * a.bn_rv[c] + (1.f - a.bn_mom) * var;
+            if (a.bn_update) {   // as every other path: the running statistics move with an update step only
+              a.bn_rm[c] = a.bn_mom * a.bn_rm[c] + (1.f - a.bn_mom) * mu;
+              a.bn_rv[c] = a.bn_mom * a.bn_rv[c] + (1.f - a.bn_mom) * var;
+            }
           }
         }
         if (blockIdx.x == 0) {   // pad columns of the fused scale / shift are zero

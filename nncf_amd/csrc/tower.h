@@ -343,6 +343,7 @@ struct nncf_tower {
   // hot words (nncf_tower_set_hot_words; TowerArgs::hot)
   int32_t* hot = nullptr;        // own allocation [kHotWords]
   int n_hot = 0;
+  int32_t hot_host[nncf::kHotWords] = {};   // the same ids on the host (nncf_tower_set_postings checks the schedule against them)
   float* hot_part = nullptr;     // own allocation
   int32_t* hot_cnt = nullptr;
   // postings mode (nncf_tower_set_postings; TowerArgs::pm_units): caller-owned arrays, own hot bitmap

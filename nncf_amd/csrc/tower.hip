@@ -292,8 +292,10 @@ __device__ __forceinline__ void stats_finalize(const TowerArgs& a, int c, float 
     mi[256 + c] = var;
     mi[384 + c] = mul;
     mi[512 + c] = a.beta[c] - mu * mul;
-    a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mu;
-    a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * var;
+    if (a.fill) {   // the running statistics move with an UPDATE step only (a loss-only evaluation -- the monitor models of
+      a.rm[c] = a.momentum * a.rm[c] + (1.f - a.momentum) * mu;   // monitor_rate_all_loss -- leaves them alone), as on the
+      a.rv[c] = a.momentum * a.rv[c] + (1.f - a.momentum) * var;  // one-launch path and in the oracle
+    }
   } else if (c < 128) {  // pad columns of the fused scale / shift
     a.ws[ws_muinv() + 384 + c] = 0.f;
     a.ws[ws_muinv() + 512 + c] = 0.f;
@@ -1364,6 +1366,7 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
     sa.bn_eps = t->cfg.bn_eps;
     sa.bn_mom = t->cfg.bn_momentum;
     sa.bn_nv = n_u;
+    sa.bn_update = update;
   }
   FusedArgs fa;
   if (one_launch || tile_stats) {
@@ -1442,9 +1445,6 @@ int nncf_tower_create(const nncf_tower_cfg* cfg, const nncf_tower_params* prm, i
   t->prm = *prm;
   t->device = device;
   t->ks = (cfg->max_rows + kRowsPerK - 1) / kRowsPerK;
-  // the one-launch backward (tower_fused.hip) is correct and tested but, at 2 workgroups of 8 waves per CU, its
-  // 1,050 workgroups take three rounds: 23 us against 8.5 + 11.4 us of the two-kernel chain (profiles/r02) --
-  // opt-in until it wins
   if (cfg->conv_filters > 0) {
     t->nb = cfg->n_filter_lens > 1 ? cfg->n_filter_lens : 1;
     int64_t taps = 0;   // conv_w: the banks' [fl][word_dim][F] blocks one after the other
@@ -1671,6 +1671,7 @@ int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, cons
 int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE(n >= 0 && n <= kHotWords && (n == 0 || host_words), "0..%d hot words", kHotWords);
+  NNCF_REQUIRE(t->pm_units == nullptr, "set the hot words before the postings (the schedule gives hot words empty ranges)");
   for (int i = 0; i < n; ++i) NNCF_REQUIRE(host_words[i] >= 0 && host_words[i] < t->cfg.word_count, "hot word id out of range");
   DeviceGuard guard(t->device);
   if (n > 0 && !t->hot) {
@@ -1688,6 +1689,7 @@ int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n
     for (int i = 0; i < n; ++i) bits[host_words[i] >> 5] |= 1u << (host_words[i] & 31);
     NNCF_HIP_CHECK(hipMemcpy(t->hot_bits, bits.data(), sizeof(uint32_t) * nw, hipMemcpyHostToDevice));
   }
+  for (int i = 0; i < n; ++i) t->hot_host[i] = host_words[i];
   t->n_hot = n;
   return NNCF_OK;
 }
@@ -1700,6 +1702,17 @@ int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_wor
   NNCF_REQUIRE(!d_units || t->cfg.item_count <= (1 << 24), "postings pack the item id into 24 bits: item_count = %lld is too large",
                (long long)t->cfg.item_count);
   NNCF_REQUIRE(((uintptr_t)d_slot_of & 7) == 0 && ((uintptr_t)d_units & 15) == 0, "slot_of must be 8-byte, the schedule 16-byte aligned");
+  if (d_units && t->n_hot > 0) {
+    // a hot word's gradient row comes from the Dense backward: a schedule that also walks its postings would add it twice
+    DeviceGuard guard(t->device);
+    std::vector<int32_t> units((size_t)n_workgroups * 32);
+    NNCF_HIP_CHECK(hipMemcpy(units.data(), d_units, sizeof(int32_t) * units.size(), hipMemcpyDeviceToHost));
+    for (size_t u = 0; u < units.size(); u += 4)
+      for (int h = 0; h < t->n_hot; ++h)
+        NNCF_REQUIRE(units[u] != t->hot_host[h] || units[u + 1] == units[u + 2],
+                     "postings: hot word %d has a non-empty unit [%d, %d) -- hot words keep a slot with an empty range", units[u],
+                     units[u + 1], units[u + 2]);
+  }
   t->pm_units = reinterpret_cast<const int4*>(d_units);
   t->pm_nwg = d_units ? n_workgroups : 0;
   t->post_item = d_postings;

@@ -165,6 +165,11 @@ class Engine(object):
         with torch.cuda.device(self.device):
             _lib.check(self._L.nncf_model_check(self._h, self._stream()))
 
+    def clear_error(self):
+        """Clears the sticky time-out flag `check` reports; the tables hold a partial step and must be restored by the caller."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_model_clear_error(self._h, self._stream()))
+
     def set_item_grad_export(self, buf):
         """While `buf` ([rows][dim] fp32) is set, steps leave item rows untouched and write
         dL/d(item row) there instead (text towers above the item block, sharded rows)."""

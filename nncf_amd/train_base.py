@@ -115,6 +115,9 @@ class TrainerBase(object):
         mean_cost = cost / it if it > 0 else -1
         print(get_cur_time(), "epoch %d (%d it)" % (epoch, it), "cost %.5f" % mean_cost, end=" ")
         nan_detection("cost", cost)
+        eng = getattr(self.model_predict, "engine", None)     # a timed-out in-launch wait of the one-launch step (a GPU this
+        if eng is not None and hasattr(eng, "check"):          # model does not have to itself) is reported with its cause, not
+            eng.check()                                        # only as the NaN it leaves in the loss
         if monitor is not None and self.monitor_rate > 0:      # train_original.py:74-79
             costs, monitor_it = monitor
             print("(", end=" ")

@@ -233,6 +233,39 @@ def test_large_block_original_matches_oracle(monkeypatch, postings):
                                        err_msg="%s step %d" % (name, step))
 
 
+@pytest.mark.parametrize("model", ["basic_embedding", "cnn_embedding"])
+def test_loss_only_evaluation_leaves_every_parameter_and_the_running_statistics_alone(model):
+    """a step with update = False (the monitor models of monitor_rate_all_loss) changes NOTHING -- on every path:
+    the one-launch step, the tile + apply pair, and train_scheme = original with a block of more than 1,024 rows, whose
+    statistics launch / score-kernel merge used to move the BatchNorm running statistics regardless."""
+    data = synthetic.make_citeulike_like(users=400, items=3000, train_links=9000, seed=4, content_len=20, vocab=150)
+    for scheme, loss in (("original", "skip-gram"), ("neg_shared", "skip-gram"), ("group_neg_shared", "log-loss")):
+        conf = (_conf_cnn(loss, scheme, b=512, k=3, d=32, F=20) if model == "cnn_embedding" else _conf(loss, scheme, b=512, k=3, d=32, lr=0.1))
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
+        head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+        core, tw = head.core, head.core.tower
+        rs = np.random.RandomState(3)
+        bt = data["train"][rs.choice(len(data["train"]), 512, replace=False)]
+        e = core.engine
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 3000, 512 * 3), loss)
+            assert len(np.unique(c)) > 1024
+            kind = "original"
+        else:
+            u, c = bt[:, 0], bt[:, 1]
+            kind = "neg_shared" if scheme == "neg_shared" else "group_neg_shared"
+        head.train_on_batch([u, c], [np.ones(len(u))])                      # one real step first: the statistics are not the initial ones
+        names = [n for n in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv", "Wc", "bc", "g1", "b1", "rm1", "rv1") if hasattr(tw, n)]
+        before = {n: getattr(tw, n).clone() for n in names}
+        U0 = e.U.clone()
+        l1 = float(core.step(kind, e.ids(u), e.ids(c), update=False).item())
+        l2 = float(core.step(kind, e.ids(u), e.ids(c), update=False).item())
+        assert np.isfinite(l1) and np.isfinite(l2)
+        for n in names:
+            assert torch.equal(getattr(tw, n), before[n]), (model, scheme, n)
+        assert torch.equal(e.U, U0)
+
+
 def test_row_dropout_matches_oracle_with_same_mask(text_data):
     """Embedding(dropout=p) row dropout: the kernels' hash mask, materialised through
     nncf_tower_dropout_scale, fed to the oracle -> same losses and parameters; masks differ per
@@ -1086,3 +1119,29 @@ def test_postings_mode_equals_the_count_matrix_scan(monkeypatch, opt, hot_words)
         if step == 1:   # a small block in between (neg_shared head of the same model: 512 rows, dense scan)
             l2 = [md["model_neg_shared"].train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]]) for md in heads]
             assert abs(l2[0] - l2[1]) <= 1e-5 * max(1, abs(l2[1])), l2
+
+
+def test_the_postings_schedule_must_leave_the_hot_words_empty(monkeypatch):
+    """The contract of nncf_tower_set_postings / nncf_tower_set_hot_words (include/nncf_hip.h): a hot word's gradient row comes
+    from the Dense backward, so the schedule gives it an empty range -- a schedule that walks its postings as well is refused
+    (it would add the row twice), and so is changing the hot set under a bound schedule."""
+    from nncf_amd import _lib
+    data = synthetic.make_citeulike_like(users=200, items=1500, train_links=4000, seed=4, content_len=24, vocab=300)
+    conf = _conf("skip-gram", "original", b=512, k=3, d=32)
+    tw = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)["model"].core.tower
+    assert tw.post_units is not None and tw.hot_words.size > 0
+    L = _lib.lib()
+    hot = np.ascontiguousarray(tw.hot_words[:1])
+    assert L.nncf_tower_set_hot_words(tw.handle, hot.ctypes.data_as(_lib.c_i32p), 1) == -1
+    assert b"before the postings" in L.nncf_last_error()
+    # a schedule whose unit of a hot word is not empty
+    units = tw.post_units.cpu().numpy().reshape(-1, 4).copy()
+    first = np.flatnonzero(units[:, 0] == int(hot[0]))[0]
+    assert units[first, 1] == units[first, 2]
+    units[first, 2] = units[first, 1] + 1
+    bad = torch.as_tensor(units).to(tw.post_units.device)
+    rc = L.nncf_tower_set_postings(tw.handle, bad.data_ptr(), bad.shape[0] // 8, tw.post_item.data_ptr(), tw.slot_of.data_ptr())
+    assert rc == -1 and b"empty range" in L.nncf_last_error()
+    # the rejected call left the bound schedule alone: the good one is still there and binding it again is fine
+    assert L.nncf_tower_set_postings(tw.handle, tw.post_units.data_ptr(), tw.post_units.shape[0] // 8, tw.post_item.data_ptr(),
+                                     tw.slot_of.data_ptr()) == 0
