@@ -463,29 +463,43 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
     }
     sHotC[h * 16 + i] = c;
   }
-  if (tid < 128) {
-    float mu = 0.f, inv = 0.f, g = 0.f, mul = 0.f, add = 0.f, t1 = 0.f, t2 = 0.f;
-    if (tid < a.d) {
-      const float* mi = a.ws + ws_muinv();
-      mu = mi[tid];
-      inv = mi[128 + tid];
-      mul = mi[384 + tid];
-      add = mi[512 + tid];
-      g = a.gamma[tid];
-      if (nfused) {  // partials of the step's apply kernel, one per item chunk, in chunk order
-        merge_partials(a.ws + ws_bsum(), nfused, tid, t1, t2);
+  float pmu = 0.f, pinv = 0.f, pg = 0.f, pmul = 0.f, padd = 0.f;   // requested before the partials (loads complete in order)
+  if (tid < a.d) {
+    const float* mi = a.ws + ws_muinv();
+    pmu = mi[tid];
+    pinv = mi[128 + tid];
+    pmul = mi[384 + tid];
+    padd = mi[512 + tid];
+    pg = a.gamma[tid];
+  }
+  {
+    // sum dy (= dbeta) by threads [0, 128), sum dy*xhat (= dgamma) by threads [128, 256): the partials of the step's apply
+    // kernel, one per item chunk, in chunk order -- 32 requests in flight (b = 512: 32 chunks, ONE round; sixteen at a time
+    // by 128 threads were two dependent rounds at the head of every workgroup of the launch)
+    const int half = tid >> 7, c = tid & 127;
+    float tot = 0.f;
+    if (c < a.d) {
+      if (nfused) {
+        const float* part = a.ws + ws_bsum() + half * 128 + c;
+        for (int p0 = 0; p0 < nfused; p0 += 32) {
+          float u[32];
+#pragma unroll
+          for (int e = 0; e < 32; ++e) u[e] = part[(size_t)min(p0 + e, nfused - 1) * 256];   // (unconditional requests)
+#pragma unroll
+          for (int e = 0; e < 32; ++e) tot += (p0 + e < nfused) ? u[e] : 0.f;
+        }
       } else {
-        t1 = a.ws[ws_bfin() + tid];
-        t2 = a.ws[ws_bfin() + 128 + tid];
+        tot = a.ws[ws_bfin() + half * 128 + c];
       }
     }
-    sMu[tid] = mu;
-    sInv[tid] = inv;
-    sG[tid] = g;  // gamma = 0 past d: those columns of dz are exactly 0
-    sMul[tid] = mul;
-    sAdd[tid] = add;
-    sA[tid] = t1;   // sum dy       (= dbeta)
-    sBq[tid] = t2;  // sum dy*xhat  (= dgamma)
+    (half ? sBq : sA)[c] = tot;
+  }
+  if (tid < 128) {
+    sMu[tid] = pmu;
+    sInv[tid] = pinv;
+    sG[tid] = pg;  // gamma = 0 past d: those columns of dz are exactly 0
+    sMul[tid] = pmul;
+    sAdd[tid] = padd;
   }
   __syncthreads();
   const float n = (float)nv, rn = 1.f / n;
