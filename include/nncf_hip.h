@@ -620,6 +620,15 @@ int nncf_shard_destroy(nncf_shard* h);
  * Required before the first step when the model was given an Adam optimiser (the weak form's local user rows use the
  * model's own state).  The as-written duplicate rule of the sparse Adam is refused at nncf_shard_create. */
 int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float* d_v, int32_t* d_stamp);
+/* InteractionDot bias (/root/reference/modules/interaction/interaction_dot.py:62-71,96-107) on the same-global-batch form: a model
+ * with bias vectors (nncf_model_set_bias, indexed by landing slot: user_count / n_items >= batch_size_p) makes the session run
+ * REPLICATED for every loss -- all 2 b rows AND their bias values to every rank, the whole one-device step (tile + apply +
+ * bias update) on the landing buffers, the owners write rows and bias values back.  d_*_bias_shard: this rank's [user_shard] /
+ * [item_shard] floats, one per bias vector the model has (NULL for the other).  The weak form refuses a model with a bias
+ * (nncf_shard_create).  nncf_shard_bias_buffers: both ends of the bias exchange of `exchange` for a host-driven transport
+ * (NULL / NULL without a bias; with one rank both ends are the model's vector). */
+int nncf_shard_set_bias(nncf_shard* h, float* d_user_bias_shard, float* d_item_bias_shard);
+int nncf_shard_bias_buffers(nncf_shard* h, int32_t exchange, float** bias_out, float** bias_in);
 int nncf_shard_counts(nncf_shard* h, int32_t** cnt_out, int32_t** cnt_in, int32_t* n_exchanges);
 int nncf_shard_buffers(nncf_shard* h, int32_t exchange, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in,
                        float** g_out, float** g_in, int32_t* ids_per_step);

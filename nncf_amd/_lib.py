@@ -134,6 +134,8 @@ def _declare(lib):
         "nncf_shard_apply": [vp, i64, i64, f32, vp],
         "nncf_shard_set_optimizer": [vp, i32, vp, vp, vp],
         "nncf_shard_set_comm": [vp, vp],
+        "nncf_shard_set_bias": [vp, vp, vp],
+        "nncf_shard_bias_buffers": [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "nncf_shard_run_chunk": [vp, vp, vp, i64, vp, f32, vp],
         "nncf_comm_unique_id": [vp],
         "nncf_comm_create": [vp, i32, i32, i32, ctypes.POINTER(vp)],

@@ -212,6 +212,11 @@ struct Exch {
   int32_t *req_out = nullptr, *req_in = nullptr;
   float *rows_out = nullptr, *land = nullptr, *g_out = nullptr, *g_in = nullptr;
   nncf::AdamTable ad;            // Adam state of this rank's shard (nncf_shard_set_optimizer): moments [shard_rows][stride], stamps
+  // InteractionDot bias of the table's ids (interaction_dot.py:62-71; replicated strong form only, nncf_shard_set_bias): one
+  // float per id travels next to the row -- same request lists, same counts, element size 4
+  float* bshard = nullptr;       // this rank's [shard_rows] bias values
+  float* bout = nullptr;         // owner side: the values of the rows of the current step, in request order
+  float* bland = nullptr;        // requester side: the model's bias vector (indexed by landing slot, like the landing rows)
 };
 
 struct nncf_shard {
@@ -382,6 +387,25 @@ __global__ void __launch_bounds__(256) copy_back_kernel(float* __restrict__ shar
   row_store(shard, id - id_offset, stride, d4, q, row_load(land, base + k, land_stride, d4, q));
 }
 
+// the bias values that travel with gather_step_kernel's rows (one thread per row) / copy_back_kernel's (one thread per id)
+__global__ void __launch_bounds__(256) gather_bias_kernel(const float* __restrict__ bias, int id_offset, const int32_t* __restrict__ req_in,
+                                                          const int32_t* __restrict__ recv_off, const int32_t* __restrict__ step_off,
+                                                          int ranks, int s, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int r, k;
+  if (!owner_row(step_off, ranks, s, t, r, k)) return;
+  out[t] = bias[req_in[recv_off[r * kPlanChunk + s] + k] - id_offset];
+}
+__global__ void __launch_bounds__(256) copy_back_bias_kernel(float* __restrict__ bias, int id_offset, const float* __restrict__ land,
+                                                             const int32_t* __restrict__ req_out, const int32_t* __restrict__ send_off,
+                                                             const int32_t* __restrict__ cnt_out, int nx, int xi, int me, int s) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= cnt_out[(me * nx + xi) * kPlanChunk + s]) return;
+  int base = 0;
+  for (int o = 0; o < me; ++o) base += cnt_out[(o * nx + xi) * kPlanChunk + s];
+  bias[req_out[send_off[me * kPlanChunk + s] + k] - id_offset] = land[base + k];
+}
+
 __global__ void scale_loss_kernel(float* __restrict__ loss, float f) { *loss *= f; }
 
 }  // namespace nncf
@@ -404,6 +428,7 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     e.g_out = c.take<float>((size_t)n * h->d);
     e.g_in = alias ? e.g_out : c.take<float>((size_t)R * n * h->d);
     e.rows_out = alias ? nullptr : c.take<float>((size_t)R * n * h->d);   // one rank: gathered straight into the landing buffer
+    e.bout = alias ? nullptr : c.take<float>((size_t)R * n);
     PlanView& v = e.plan;
     v.list_stride = n;
     v.order = c.take<int32_t>(kPlanChunk * n);
@@ -441,7 +466,10 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   // on its landing buffers (the one-device kernels, bit for bit); the owners write their rows back into their shards.  No
   // gradient exchange at all (2 b rows in per rank and step against 2 b + 2 b / n_ranks rows in + out of the partitioned
   // form); the compute is redundant n_ranks times, which is why this is the parity form, not the throughput form.
-  const bool replicated = strong && (m->cfg.loss == NNCF_LOSS_LOG_LOSS || m->cfg.loss == NNCF_LOSS_MAX_MARGIN);
+  // The InteractionDot bias (interaction_dot.py:96-107) takes the same road for every loss: the one-launch rectangular step has
+  // no bias form, the one-device tile + apply + bias-update kernels do -- the bias values travel with the rows (nncf_shard_set_bias).
+  const bool replicated = strong && (m->cfg.loss == NNCF_LOSS_LOG_LOSS || m->cfg.loss == NNCF_LOSS_MAX_MARGIN || m->ub || m->cb);
+  NNCF_REQUIRE(strong || (!m->ub && !m->cb), "interaction_bias on the sharded trainers: the same-global-batch (strong) form only");
   if (strong && !replicated) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
@@ -450,7 +478,7 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   if (replicated) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(m->cfg.user_count >= b, "replicated strong form (pairwise loss): the model's user table is the landing buffer of ALL batch_size_p positions");
-    NNCF_REQUIRE(!m->ub && !m->cb, "interaction_bias is not built for the sharded trainers");
+    NNCF_REQUIRE(!m->cb || m->bias_items >= b, "replicated strong form: the model's item-bias vector is indexed by landing slot and must hold batch_size_p values");
   }
   nncf_shard* h = new (std::nothrow) nncf_shard();
   if (!h) return fail(NNCF_ERR_NOMEM, "out of host memory");
@@ -466,7 +494,9 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   if (strong) {
     h->x[1].shard = d_user_shard; h->x[1].stride = user_stride; h->x[1].shard_rows = user_shard; h->x[1].i0 = user_offset;
     h->x[1].n = replicated ? b : b / n_ranks; h->x[1].land = m->U;
+    h->x[1].bland = m->ub;
   }
+  h->x[0].bland = m->cb;
   h->replicated = replicated;
   Carver dry;
   carve_shard(h, dry);
@@ -488,6 +518,25 @@ int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float*
   NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
   NNCF_REQUIRE((d_m && d_v) || (!d_m && !d_v && !d_stamp), "both moment arrays or none");
   h->x[exchange].ad = AdamTable{d_m, d_v, d_stamp};
+  return NNCF_OK;
+}
+
+int nncf_shard_set_bias(nncf_shard* h, float* d_user_bias_shard, float* d_item_bias_shard) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(h->replicated, "the bias travels with the rows of the replicated strong form only");
+  NNCF_REQUIRE((d_user_bias_shard != nullptr) == (h->m->ub != nullptr) && (d_item_bias_shard != nullptr) == (h->m->cb != nullptr),
+               "one bias shard per bias vector of the model (nncf_model_set_bias), no more");
+  h->x[1].bshard = d_user_bias_shard;
+  h->x[0].bshard = d_item_bias_shard;
+  return NNCF_OK;
+}
+
+int nncf_shard_bias_buffers(nncf_shard* h, int32_t exchange, float** bias_out, float** bias_in) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
+  const Exch& e = h->x[exchange];
+  if (bias_out) *bias_out = e.bshard ? (e.bout ? e.bout : e.bland) : nullptr;
+  if (bias_in) *bias_in = e.bshard ? e.bland : nullptr;
   return NNCF_OK;
 }
 
@@ -557,6 +606,9 @@ static int gather_step(nncf_shard* h, int xi, int64_t s, hipStream_t st) {
   ProfScope _ps("gather_rows_kernel", st);
   hipLaunchKernelGGL(gather_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.req_in,
                      e.recv_off, e.step_off, h->ranks, (int)s, out);
+  if (e.bshard)
+    hipLaunchKernelGGL(gather_bias_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, e.bshard, e.i0, e.req_in, e.recv_off,
+                       e.step_off, h->ranks, (int)s, e.bout ? e.bout : e.bland);
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }
@@ -596,6 +648,7 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
   const int32_t* uid = d_uid;
   if (h->replicated) {   // the whole b x b step on the landing buffers, then the owned rows back into the shards
     NNCF_REQUIRE(m->opt == 0, "the replicated strong form (pairwise losses) steps with sparse SGD: the owners' Adam state does not travel");
+    NNCF_REQUIRE((!m->ub || h->x[1].bshard) && (!m->cb || h->x[0].bshard), "the model has an interaction bias: nncf_shard_set_bias first");
     a.gV = nullptr;
     a.gU = nullptr;
     uid = h->x[1].slot + index * h->x[1].n;
@@ -608,6 +661,9 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
       ProfScope _ps("scatter_merge_kernel", st);
       hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)((e.n + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.land,
                          m->cfg.row_stride, e.req_out, e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+      if (e.bshard)
+        hipLaunchKernelGGL(copy_back_bias_kernel, dim3((unsigned)((e.n + 255) / 256)), dim3(256), 0, st, e.bshard, e.i0, e.bland, e.req_out,
+                           e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
     }
     NNCF_HIP_CHECK(hipGetLastError());
     return NNCF_OK;
@@ -717,6 +773,8 @@ int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_c
           rc_[r] = snd[((size_t)r * nx + xi) * kPlanChunk + i];                   // what this rank asked of rank r
         }
         if (int rc = comm_all_to_all(h->comm, e.rows_out, sc.data(), e.land, rc_.data(), eb, st)) return rc;
+        if (e.bshard)   // the bias values of the same rows
+          if (int rc = comm_all_to_all(h->comm, e.bout, sc.data(), e.bland, rc_.data(), sizeof(float), st)) return rc;
       }
     }
     if (int rc = nncf_shard_step(h, i, h->strong ? nullptr : d_uid + i * nu, d_losses ? d_losses + i : h->loss_scratch, stream)) return rc;

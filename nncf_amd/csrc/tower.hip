@@ -413,16 +413,16 @@ __global__ void __launch_bounds__(1024) tower_merge_kernel(TowerArgs a, const fl
   __shared__ float sRed[8 * 2 * 128];
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float a1 = 0.f, a2 = 0.f;
-  for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 pairs of loads in flight: `original`'s 352 partials in three rounds
-    float u1[16], u2[16];
+  for (int s0 = g; s0 < n; s0 += 8 * 48) {   // 48 pairs of loads in flight: `original`'s 352 partials (44 per thread) in ONE round
+    float u1[48], u2[48];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 48; ++e) {
       const int s = s0 + 8 * e;
       u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
       u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 48; ++e) {
       a1 += u1[e];
       a2 += u2[e];
     }

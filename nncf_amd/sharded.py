@@ -73,19 +73,22 @@ class HipBackend(object):
         self.device = torch.device("cuda", device)
         self.mode, self.rank = mode, int(rank)
         kw = dict(engine_kwargs)
-        if kw.get("interaction_bias"):
-            raise NotImplementedError("interaction_bias is not built for the item-sharded path")
+        self.bias = kw.get("interaction_bias")          # None | 'user' | 'item' | 'both' (interaction_dot.py:62-71)
+        if self.bias and mode != "strong":
+            raise NotImplementedError("interaction_bias on the sharded trainers: the same-global-batch form (ShardedGlobalBatch) only -- "
+                                      "the weak form's per-rank batches step the owners' rows from exported gradients, and the "
+                                      "one-launch step that exports them has no bias form")
         kw.pop("bias_item_count", None)
         self.b = kw["batch_size_p"]
         self.dim = (int(kw["dim"]) + 3) // 4 * 4   # physical row width (Engine pads to a multiple of 4)
         self.world, self.cap = int(world), self.b
         self.item_shard, self.i0 = int(item_shard), int(item_offset)
         self.user_shard, self.u0 = int(user_shard or local_users), int(user_offset)
-        self.replicated = mode == "strong" and kw["loss"] in ("log-loss", "max-margin")
+        self.replicated = mode == "strong" and (kw["loss"] in ("log-loss", "max-margin") or bool(self.bias))
         if self.replicated:
             if kw.get("optimizer", "sgd") != "sgd":
-                raise NotImplementedError("pairwise losses on the strong form run replicated with sparse SGD (the owners' Adam state "
-                                          "does not travel with the rows)")
+                raise NotImplementedError("pairwise losses / interaction_bias on the strong form run replicated with sparse SGD (the "
+                                          "owners' Adam state does not travel with the rows)")
             kw["user_count"] = self.b                        # landing rows of ALL positions
             kw["item_count"] = self.b
         elif mode == "strong":
@@ -114,6 +117,11 @@ class HipBackend(object):
             return t.to(self.device).contiguous()
         self.V = table(local_items, int(seed) + 1)   # this rank's item shard
         self.U = table(local_users, int(seed) + 2) if mode == "strong" else self.engine.U   # this rank's user shard
+        # this rank's shards of the InteractionDot bias vectors (zero-initialised, interaction_dot.py:62-71); the engine's own
+        # vectors are their landing buffers (indexed by landing slot)
+        zb = lambda rows: torch.zeros(rows, dtype=torch.float32, device=self.device)  # noqa: E731
+        self.bu = zb(local_users) if self.bias in ("user", "both") else None
+        self.bi = zb(local_items) if self.bias in ("item", "both") else None
         self.lr = float(kw["learn_rate"])
         n = self.world * self.cap     # per-step protocol: the owner side merges the ranks' sorted request blocks (nncf_scatter_merge)
         i32 = lambda k: torch.empty(k, dtype=torch.int32, device=self.device)  # noqa: E731
@@ -183,6 +191,9 @@ class HipBackend(object):
                     ctypes.c_void_p(self.U.data_ptr()) if strong else ctypes.c_void_p(), self.dim, self.user_shard, self.u0,
                     self.world, self.rank, self.device.index, ctypes.byref(h)))
             self._sh = h
+            if self.bias:
+                pb = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
+                self._lib.check(L.nncf_shard_set_bias(h, pb(self.bu), pb(self.bi)))
             if self.optimizer != "sgd":   # Adam state of this rank's shards (items; users too in the strong form)
                 dense = self.optimizer == "adam"
                 self._adam = []
@@ -216,6 +227,10 @@ class HipBackend(object):
                     rows_in=view(ptrs[3], n * self.dim, torch.float32, (n, self.dim)),
                     g_out=view(ptrs[4], n * self.dim, torch.float32, (n, self.dim)),
                     g_in=view(ptrs[5], own * self.dim, torch.float32, (own, self.dim))))
+                bo, bi_ = ctypes.c_void_p(), ctypes.c_void_p()
+                self._lib.check(L.nncf_shard_bias_buffers(h, xi, ctypes.byref(bo), ctypes.byref(bi_)))
+                if bo.value:   # the bias values of the same rows (replicated strong form with an interaction bias)
+                    bufs["x"][-1].update(bias_out=view(bo, own, torch.float32, (own,)), bias_in=view(bi_, n, torch.float32, (n,)))
             self._bufs = bufs
         return self._sh
 
@@ -471,8 +486,12 @@ class _Exchanger(object):
                     xb = bufs["x"][xi]
                     if exchange:
                         self._a2a(xb["rows_in"], xb["rows_out"], send[:, xi, i], recv[:, xi, i])
+                        if "bias_in" in xb:                              # ... and their bias values
+                            self._a2a(xb["bias_in"], xb["bias_out"], send[:, xi, i], recv[:, xi, i])
                     else:
                         self._a2a(xb["rows_in"], xb["rows_out"])
+                        if "bias_in" in xb:
+                            self._a2a(xb["bias_in"], xb["bias_out"])
                 lo = losses[t:t + 1] if losses is not None else be._loss
                 be.local_step_at(i, uid_all[t * nu:(t + 1) * nu] if uid_per_step else None, lo)
                 for xi in range(nx if not getattr(be, "replicated", False) else 0):   # gradients -> owners (replicated form: none)

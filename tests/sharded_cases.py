@@ -15,12 +15,13 @@ def shard_size(count, world):
 LR_ADAM = 0.01
 
 
-def conf(loss="skip-gram", model="mf", optimizer="sgd"):
+def conf(loss="skip-gram", model="mf", optimizer="sgd", bias=None):
     return so.OracleConf(batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=LAMBDA, u_reg=UREG,
-                         learn_rate=LR if optimizer == "sgd" else LR_ADAM, model_choice=model, optimizer=optimizer)
+                         learn_rate=LR if optimizer == "sgd" else LR_ADAM, model_choice=model, optimizer=optimizer,
+                         interaction_bias=bias)
 
 
-def engine_kwargs(loss="skip-gram", optimizer="sgd"):
+def engine_kwargs(loss="skip-gram", optimizer="sgd", bias=None):
     # the pairwise losses normalise the user rows by default, as the reference's conf does (basic_embedding_conf.py:52-56;
     # OracleConf follows it), id-table items stay raw (model_framework.py:85-88)
     kw = dict(user_count=NU, item_count=NI, dim=D, batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10.,
@@ -28,6 +29,8 @@ def engine_kwargs(loss="skip-gram", optimizer="sgd"):
               normalize_user=conf(loss).normalize_user, normalize_item=False)
     if optimizer != "sgd":
         kw["optimizer"] = optimizer      # HipBackend: the engine's and the shards' Adam state
+    if bias:
+        kw["interaction_bias"] = bias    # InteractionDot bias (interaction_dot.py:62-71): the strong form runs replicated
     return kw
 
 
@@ -81,12 +84,15 @@ def simulate_weak(loss, world):
     return U, V, np.asarray(losses)
 
 
-def simulate_strong(loss, optimizer="sgd"):
-    """the one-device step (models/train_neg_shared.py:46-51 semantics) on the global batches, float64"""
-    c = conf(loss, optimizer=optimizer)
+def simulate_strong(loss, optimizer="sgd", bias=None):
+    """the one-device step (models/train_neg_shared.py:46-51 semantics) on the global batches, float64; with an interaction
+    bias: (U, V, losses, user bias or None, item bias or None)"""
+    c = conf(loss, optimizer=optimizer, bias=bias)
     U, V = tables()
     o = so.StepOracle(U, V, c, dtype=np.float64)
     losses = [o.step_neg_shared(u, cc) for u, cc in global_batches()]
+    if bias:
+        return o.U, o.V, np.asarray(losses), o.ub, o.cb
     return o.U, o.V, np.asarray(losses)
 
 

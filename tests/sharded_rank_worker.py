@@ -29,7 +29,8 @@ def main():
         U, V = sc.tables()
         us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
         ul, il = min(us, sc.NU - rank * us), min(isz, sc.NI - rank * isz)
-        be = HipBackend(sc.engine_kwargs(loss, optimizer), ul, il, 0, world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
+        bias = os.environ.get("NNCF_TEST_BIAS") or None
+        be = HipBackend(sc.engine_kwargs(loss, optimizer, bias), ul, il, 0, world=world, item_shard=isz, item_offset=rank * isz, seed=rank, rank=rank,
                         mode=case, user_shard=us, user_offset=rank * us, shared_device=True)
         be.U[:, :sc.D].copy_(torch.from_numpy(U[rank * us:rank * us + ul]))
         be.V[:, :sc.D].copy_(torch.from_numpy(V[rank * isz:rank * isz + il]))
@@ -52,6 +53,9 @@ def main():
         if case == "strong" and world > 1 and not os.environ.get("NNCF_DBG_NOREDUCE"):
             dist.all_reduce(lc)               # a step's loss = the sum of the ranks' shares
         out = dict(U=be.U[:, :sc.D].cpu().numpy(), V=be.V[:, :sc.D].cpu().numpy(), losses=lc.numpy(), wire=np.int64(tr.wire_bytes))
+        for name in ("bu", "bi"):        # this rank's shards of the InteractionDot bias vectors
+            if getattr(be, name, None) is not None:
+                out[name] = getattr(be, name).cpu().numpy()
     elif case == "tower":
         from nncf_amd import synthetic
         from nncf_amd.conf import get_conf

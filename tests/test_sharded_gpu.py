@@ -302,6 +302,51 @@ def test_strong_form_world1_equals_plain_step_and_oracle(loss, norm):
     np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("bias", ["user", "item", "both"])
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_strong_form_with_an_interaction_bias_equals_the_oracle(loss, bias):
+    """InteractionDot bias (interaction_dot.py:62-71,96-107) on ShardedGlobalBatch.  A model with a bias runs
+    the REPLICATED form for every loss (the rectangular one-launch step has no bias form): the bias values travel with the rows
+    (nncf_shard_set_bias), the one-device tile + apply + bias-update kernels step rows and bias on the landing buffers, the
+    owners write both back -- 70 steps == the oracle's one-device step with the same bias, tables and bias vectors."""
+    from nncf_amd.sharded import ShardedGlobalBatch
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias=bias)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode="strong", user_shard=nu)
+    assert be.replicated and (be.bu is not None) == (bias != "item") and (be.bi is not None) == (bias != "user")
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.1, model_choice="mf", emb_normalization=False, interaction_bias=bias)
+    orc = so.StepOracle(be.U.cpu().numpy(), be.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    uid[:6] = uid[0]
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr = ShardedGlobalBatch(be, nu, ni, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    be.engine.check()
+    l = losses.cpu().numpy()
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l[t] - want) <= 1e-5 * max(1, abs(want)), (t, l[t], want)
+    np.testing.assert_allclose(be.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
+    if be.bu is not None:
+        assert np.abs(orc.ub).max() > 1e-3
+        np.testing.assert_allclose(be.bu.cpu().numpy(), orc.ub, rtol=1e-4, atol=2e-5)
+    if be.bi is not None:
+        assert np.abs(orc.cb).max() > 1e-3 or loss == "log-loss"   # (neg_shared pairwise: the item bias cancels, its gradient is 0)
+        np.testing.assert_allclose(be.bi.cpu().numpy(), orc.cb, rtol=1e-4, atol=2e-5)
+
+
+def test_the_weak_form_refuses_an_interaction_bias():
+    kw = dict(user_count=300, item_count=500, dim=20, batch_size_p=64, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias="both")
+    with pytest.raises(NotImplementedError, match="same-global-batch"):
+        HipBackend(kw, 300, 500, 0, world=1, item_shard=500, item_offset=0, seed=0)
+
+
 def test_strong_form_refuses_the_tile_path_loudly(monkeypatch):
     """with NNCF_SHARED_PATH=tile the one-launch step is off; the strong form's rectangular step (bc, exported user
     gradient) has no tile + apply form and must fail loudly instead of running a square step over the first b / G columns."""

@@ -35,7 +35,7 @@ def _free_port():
 def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd", **env_extra):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    for k in ("NNCF_SHARD_TRANSPORT", "NNCF_SHARD_NOALIAS", "NNCF_COMM_SELF_VIA_RCCL", "NNCF_TEST_BACKEND"):
+    for k in ("NNCF_SHARD_TRANSPORT", "NNCF_SHARD_NOALIAS", "NNCF_COMM_SELF_VIA_RCCL", "NNCF_TEST_BACKEND", "NNCF_TEST_BIAS"):
         env.pop(k, None)
     env.update(env_extra)
     os.makedirs(str(tmp_path), exist_ok=True)
@@ -93,6 +93,32 @@ def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss, tran
         # against the float64 one-device step: a row's gradient is an fp32 sum of up to b terms, STEPS times
         assert_within_sum_bound(got[r]["U"], U[r * us:(r + 1) * us], U0[r * us:(r + 1) * us], sc.B, sc.STEPS, "U shard %d" % r)
         assert_within_sum_bound(got[r]["V"], V[r * isz:(r + 1) * isz], V0[r * isz:(r + 1) * isz], sc.B, sc.STEPS, "V shard %d" % r)
+
+
+@pytest.mark.parametrize("loss,bias,transport", [("skip-gram", "both", "torch"), ("skip-gram", "user", "callback"),
+                                                 ("log-loss", "both", "callback"), ("mse", "item", "torch")])
+def test_strong_form_two_ranks_with_an_interaction_bias(tmp_path, loss, bias, transport):
+    """InteractionDot bias (interaction_dot.py:62-71,96-107) on the same-global-batch form over two ranks: the bias values travel
+    with the rows of the replicated form (a second all-to-all of 4-byte elements with the same counts; nncf_shard_set_bias),
+    both ranks run the whole step incl. the bias update, the owners write rows AND bias values back == the one-device step."""
+    world = 2
+    got = _run_ranks("strong", world, tmp_path, loss, NNCF_SHARD_TRANSPORT=transport, NNCF_TEST_BIAS=bias)
+    U, V, losses, ub, cb = sc.simulate_strong(loss, bias=bias)
+    U0, V0 = sc.tables()
+    us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], losses, rtol=1e-5)
+        assert_within_sum_bound(got[r]["U"], U[r * us:(r + 1) * us], U0[r * us:(r + 1) * us], sc.B, sc.STEPS, "U shard %d" % r)
+        assert_within_sum_bound(got[r]["V"], V[r * isz:(r + 1) * isz], V0[r * isz:(r + 1) * isz], sc.B, sc.STEPS, "V shard %d" % r)
+        for name, want, lo, hi in (("bu", ub, r * us, (r + 1) * us), ("bi", cb, r * isz, (r + 1) * isz)):
+            assert (name in got[r]) == (want is not None)
+            if want is not None:    # a bias value: an fp32 sum of up to b score gradients per step
+                w = want[lo:hi]
+                if loss == "log-loss" and name == "bi":   # neg_shared pairwise: the item bias cancels in S[i, j] - S[j, j]; its
+                    assert np.abs(w).max() < 1e-12 and np.abs(got[r][name]).max() < 1e-7   # gradient is 0 up to float64 rounding
+                else:
+                    assert_within_sum_bound(got[r][name], w, np.zeros_like(w), sc.B, sc.STEPS, "%s shard %d" % (name, r))
+    assert (ub is None or np.abs(ub).max() > 1e-3) and (cb is None or loss == "log-loss" or np.abs(cb).max() > 1e-3)
 
 
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
