@@ -569,12 +569,23 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
     __syncthreads();
     FSTAMP(23);
     if (!sTop[1]) return;
-    if (g < kFM) {   // parts in part order, whoever arrived last
-      Row acc = row_zero();
-      for (int pp = 0; pp < parts; ++pp) {
-        const float* src = f.slab + ((int64_t)strip * P + pp) * kFM * 128 + g * 128;
-        acc.a = add4(acc.a, reinterpret_cast<const float4*>(src)[q]);
-        acc.b = add4(acc.b, reinterpret_cast<const float4*>(src)[q + 16]);
+    if (g < kFM) {   // parts in part order, whoever arrived last -- four parts requested at once (a load per iteration of a
+      Row acc = row_zero();   // loop of unknown length is a trip to L2 per part: the whole reduction is ONE trip at split 4)
+      for (int p0 = 0; p0 < parts; p0 += 4) {
+        float4 ua[4], ub[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // (unconditional requests at a clamped part: no branch per request)
+          const float* src = f.slab + ((int64_t)strip * P + min(p0 + e, parts - 1)) * kFM * 128 + g * 128;
+          ua[e] = reinterpret_cast<const float4*>(src)[q];
+          ub[e] = reinterpret_cast<const float4*>(src)[q + 16];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (p0 + e < parts) {
+            acc.a = add4(acc.a, ua[e]);
+            acc.b = add4(acc.b, ub[e]);
+          }
+        }
       }
       reinterpret_cast<float4*>(sOut + g * kFOP)[q] = acc.a;
       reinterpret_cast<float4*>(sOut + g * kFOP)[q + 16] = acc.b;
