@@ -628,6 +628,13 @@ int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float*
  * (nncf_shard_create).  nncf_shard_bias_buffers: both ends of the bias exchange of `exchange` for a host-driven transport
  * (NULL / NULL without a bias; with one rank both ends are the model's vector). */
 int nncf_shard_set_bias(nncf_shard* h, float* d_user_bias_shard, float* d_item_bias_shard);
+/* Adam on the replicated form (pairwise losses; no bias): the moment rows of the requested ids travel with the table rows --
+ * owners gather them from the shards' moment arrays (nncf_shard_set_optimizer), they land in the model's own moment arrays
+ * (indexed by landing slot), the one-device step updates them, the owners write them back; Keras' dense Adam: the owned rows
+ * the step touched carry its stamp in the shard, the rest of the shard takes the zero-gradient step.  Both ends of the two
+ * extra exchanges of `exchange` for a host-driven transport (all NULL unless the session is replicated, the model has an Adam
+ * optimiser and the shard its moment arrays; one rank: both ends are the model's arrays). */
+int nncf_shard_moment_buffers(nncf_shard* h, int32_t exchange, float** m_out, float** m_in, float** v_out, float** v_in);
 int nncf_shard_bias_buffers(nncf_shard* h, int32_t exchange, float** bias_out, float** bias_in);
 int nncf_shard_counts(nncf_shard* h, int32_t** cnt_out, int32_t** cnt_in, int32_t* n_exchanges);
 int nncf_shard_buffers(nncf_shard* h, int32_t exchange, int32_t** req_out, int32_t** req_in, float** rows_out, float** rows_in,

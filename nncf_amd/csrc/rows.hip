@@ -214,6 +214,9 @@ struct Exch {
   nncf::AdamTable ad;            // Adam state of this rank's shard (nncf_shard_set_optimizer): moments [shard_rows][stride], stamps
   // InteractionDot bias of the table's ids (interaction_dot.py:62-71; replicated strong form only, nncf_shard_set_bias): one
   // float per id travels next to the row -- same request lists, same counts, element size 4
+  // Adam on the REPLICATED strong form: the moment rows travel with the table rows (owner side: gathered into mo_out / vo_out;
+  // requester side: the model's own moment arrays, indexed by landing slot) and come back with them
+  float *mo_out = nullptr, *vo_out = nullptr;
   float* bshard = nullptr;       // this rank's [shard_rows] bias values
   float* bout = nullptr;         // owner side: the values of the rows of the current step, in request order
   float* bland = nullptr;        // requester side: the model's bias vector (indexed by landing slot, like the landing rows)
@@ -406,6 +409,18 @@ __global__ void __launch_bounds__(256) copy_back_bias_kernel(float* __restrict__
   bias[req_out[send_off[me * kPlanChunk + s] + k] - id_offset] = land[base + k];
 }
 
+// dense Adam on the replicated form: the owned rows the step touched carry the step's stamp in the shard too (the rest of the
+// shard then takes the zero-gradient step: adam_idle_kernel)
+__global__ void __launch_bounds__(256) copy_back_stamp_kernel(int32_t* __restrict__ stamp, int id_offset, const int32_t* __restrict__ land_stamp,
+                                                              const int32_t* __restrict__ req_out, const int32_t* __restrict__ send_off,
+                                                              const int32_t* __restrict__ cnt_out, int nx, int xi, int me, int s) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= cnt_out[(me * nx + xi) * kPlanChunk + s]) return;
+  int base = 0;
+  for (int o = 0; o < me; ++o) base += cnt_out[(o * nx + xi) * kPlanChunk + s];
+  stamp[req_out[send_off[me * kPlanChunk + s] + k] - id_offset] = land_stamp[base + k];
+}
+
 __global__ void scale_loss_kernel(float* __restrict__ loss, float f) { *loss *= f; }
 
 }  // namespace nncf
@@ -429,6 +444,10 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     e.g_in = alias ? e.g_out : c.take<float>((size_t)R * n * h->d);
     e.rows_out = alias ? nullptr : c.take<float>((size_t)R * n * h->d);   // one rank: gathered straight into the landing buffer
     e.bout = alias ? nullptr : c.take<float>((size_t)R * n);
+    if (!alias && h->replicated) {   // (the optimiser may be chosen after the session exists)
+      e.mo_out = c.take<float>((size_t)R * n * h->d);
+      e.vo_out = c.take<float>((size_t)R * n * h->d);
+    }
     PlanView& v = e.plan;
     v.list_stride = n;
     v.order = c.take<int32_t>(kPlanChunk * n);
@@ -540,6 +559,19 @@ int nncf_shard_bias_buffers(nncf_shard* h, int32_t exchange, float** bias_out, f
   return NNCF_OK;
 }
 
+int nncf_shard_moment_buffers(nncf_shard* h, int32_t exchange, float** m_out, float** m_in, float** v_out, float** v_in) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
+  const Exch& e = h->x[exchange];
+  const AdamTable& lt = exchange == 0 ? h->m->av : h->m->au;
+  const bool on = h->replicated && h->m->opt && e.ad.m;
+  if (m_out) *m_out = on ? (e.mo_out ? e.mo_out : lt.m) : nullptr;
+  if (m_in) *m_in = on ? lt.m : nullptr;
+  if (v_out) *v_out = on ? (e.vo_out ? e.vo_out : lt.v) : nullptr;
+  if (v_in) *v_in = on ? lt.v : nullptr;
+  return NNCF_OK;
+}
+
 int nncf_shard_destroy(nncf_shard* h) {
   if (!h) return NNCF_OK;
   if (h->arena) hipFree(h->arena);
@@ -606,6 +638,13 @@ static int gather_step(nncf_shard* h, int xi, int64_t s, hipStream_t st) {
   ProfScope _ps("gather_rows_kernel", st);
   hipLaunchKernelGGL(gather_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.req_in,
                      e.recv_off, e.step_off, h->ranks, (int)s, out);
+  if (h->replicated && h->m->opt && e.ad.m) {   // the moment rows of the same ids (landing: the model's own moment arrays)
+    const AdamTable& lt = xi == 0 ? h->m->av : h->m->au;
+    hipLaunchKernelGGL(gather_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.ad.m, e.stride, h->d, e.i0, e.req_in,
+                       e.recv_off, e.step_off, h->ranks, (int)s, e.mo_out ? e.mo_out : lt.m);
+    hipLaunchKernelGGL(gather_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e.ad.v, e.stride, h->d, e.i0, e.req_in,
+                       e.recv_off, e.step_off, h->ranks, (int)s, e.vo_out ? e.vo_out : lt.v);
+  }
   if (e.bshard)
     hipLaunchKernelGGL(gather_bias_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, e.bshard, e.i0, e.req_in, e.recv_off,
                        e.step_off, h->ranks, (int)s, e.bout ? e.bout : e.bland);
@@ -647,7 +686,12 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
   a.gV = h->x[0].g_out;
   const int32_t* uid = d_uid;
   if (h->replicated) {   // the whole b x b step on the landing buffers, then the owned rows back into the shards
-    NNCF_REQUIRE(m->opt == 0, "the replicated strong form (pairwise losses) steps with sparse SGD: the owners' Adam state does not travel");
+    if (m->opt) {
+      NNCF_REQUIRE(h->x[0].ad.m && h->x[1].ad.m, "the model steps with Adam: the shards need their moment arrays (nncf_shard_set_optimizer)");
+      NNCF_REQUIRE(m->opt != 2 || (h->x[0].ad.stamp && h->x[1].ad.stamp), "dense Adam: the shards need their stamp arrays");
+      NNCF_REQUIRE(!m->ub && !m->cb, "the replicated form with an interaction bias steps with sparse SGD (the bias moments do not travel)");
+      NNCF_REQUIRE(m->cfg.row_stride == h->d, "replicated Adam: the landing moment rows are packed (row_stride == dim)");
+    }
     NNCF_REQUIRE((!m->ub || h->x[1].bshard) && (!m->cb || h->x[0].bshard), "the model has an interaction bias: nncf_shard_set_bias first");
     a.gV = nullptr;
     a.gU = nullptr;
@@ -661,6 +705,16 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
       ProfScope _ps("scatter_merge_kernel", st);
       hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)((e.n + 15) / 16)), dim3(256), 0, st, e.shard, e.stride, h->d, e.i0, e.land,
                          m->cfg.row_stride, e.req_out, e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+      if (m->opt) {   // the moment rows of the owned ids go home with them (dense Adam: and the stamps of the rows the step touched)
+        const AdamTable& lt = xi == 0 ? m->av : m->au;
+        hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)((e.n + 15) / 16)), dim3(256), 0, st, e.ad.m, e.stride, h->d, e.i0, lt.m,
+                           m->cfg.row_stride, e.req_out, e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+        hipLaunchKernelGGL(copy_back_kernel, dim3((unsigned)((e.n + 15) / 16)), dim3(256), 0, st, e.ad.v, e.stride, h->d, e.i0, lt.v,
+                           m->cfg.row_stride, e.req_out, e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+        if (m->opt == 2)
+          hipLaunchKernelGGL(copy_back_stamp_kernel, dim3((unsigned)((e.n + 255) / 256)), dim3(256), 0, st, e.ad.stamp, e.i0, lt.stamp, e.req_out,
+                             e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
+      }
       if (e.bshard)
         hipLaunchKernelGGL(copy_back_bias_kernel, dim3((unsigned)((e.n + 255) / 256)), dim3(256), 0, st, e.bshard, e.i0, e.bland, e.req_out,
                            e.send_off, h->cnt_out, h->nx, xi, h->rank, (int)index);
@@ -705,7 +759,7 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
                          e.req_in, e.recv_off, e.step_off, h->ranks, (int)index);
       NNCF_HIP_CHECK(hipGetLastError());
     }
-    if (a.opt == 2 && !h->replicated)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
+    if (a.opt == 2)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
       if (int rc = launch_adam_idle(a, e.shard, e.ad, e.shard_rows, st)) return rc;
     if (index + 1 < n_steps)   // rows of the next step, after this step's update (synchronous SGD)
       if (int rc = gather_step(h, xi, index + 1, st)) return rc;
@@ -773,6 +827,11 @@ int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_c
           rc_[r] = snd[((size_t)r * nx + xi) * kPlanChunk + i];                   // what this rank asked of rank r
         }
         if (int rc = comm_all_to_all(h->comm, e.rows_out, sc.data(), e.land, rc_.data(), eb, st)) return rc;
+        if (e.mo_out && h->m->opt) {   // the Adam moments of the same rows (replicated form)
+          const AdamTable& lt = xi == 0 ? h->m->av : h->m->au;
+          if (int rc = comm_all_to_all(h->comm, e.mo_out, sc.data(), lt.m, rc_.data(), eb, st)) return rc;
+          if (int rc = comm_all_to_all(h->comm, e.vo_out, sc.data(), lt.v, rc_.data(), eb, st)) return rc;
+        }
         if (e.bshard)   // the bias values of the same rows
           if (int rc = comm_all_to_all(h->comm, e.bout, sc.data(), e.bland, rc_.data(), sizeof(float), st)) return rc;
       }

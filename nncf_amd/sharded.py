@@ -86,9 +86,9 @@ class HipBackend(object):
         self.user_shard, self.u0 = int(user_shard or local_users), int(user_offset)
         self.replicated = mode == "strong" and (kw["loss"] in ("log-loss", "max-margin") or bool(self.bias))
         if self.replicated:
-            if kw.get("optimizer", "sgd") != "sgd":
-                raise NotImplementedError("pairwise losses / interaction_bias on the strong form run replicated with sparse SGD (the "
-                                          "owners' Adam state does not travel with the rows)")
+            if kw.get("optimizer", "sgd") != "sgd" and self.bias:
+                raise NotImplementedError("interaction_bias on the strong form runs replicated with sparse SGD (the rows' Adam moments "
+                                          "travel with them, the bias vectors' do not)")
             kw["user_count"] = self.b                        # landing rows of ALL positions
             kw["item_count"] = self.b
         elif mode == "strong":
@@ -227,6 +227,13 @@ class HipBackend(object):
                     rows_in=view(ptrs[3], n * self.dim, torch.float32, (n, self.dim)),
                     g_out=view(ptrs[4], n * self.dim, torch.float32, (n, self.dim)),
                     g_in=view(ptrs[5], own * self.dim, torch.float32, (own, self.dim))))
+                mb = [ctypes.c_void_p() for _ in range(4)]
+                self._lib.check(L.nncf_shard_moment_buffers(h, xi, *[ctypes.byref(q) for q in mb]))
+                if mb[0].value:   # Adam on the replicated form: the moment rows of the same ids
+                    bufs["x"][-1].update(m_out=view(mb[0], own * self.dim, torch.float32, (own, self.dim)),
+                                         m_in=view(mb[1], n * self.dim, torch.float32, (n, self.dim)),
+                                         v_out=view(mb[2], own * self.dim, torch.float32, (own, self.dim)),
+                                         v_in=view(mb[3], n * self.dim, torch.float32, (n, self.dim)))
                 bo, bi_ = ctypes.c_void_p(), ctypes.c_void_p()
                 self._lib.check(L.nncf_shard_bias_buffers(h, xi, ctypes.byref(bo), ctypes.byref(bi_)))
                 if bo.value:   # the bias values of the same rows (replicated strong form with an interaction bias)
@@ -486,12 +493,14 @@ class _Exchanger(object):
                     xb = bufs["x"][xi]
                     if exchange:
                         self._a2a(xb["rows_in"], xb["rows_out"], send[:, xi, i], recv[:, xi, i])
-                        if "bias_in" in xb:                              # ... and their bias values
-                            self._a2a(xb["bias_in"], xb["bias_out"], send[:, xi, i], recv[:, xi, i])
+                        for a_, b_ in (("m_in", "m_out"), ("v_in", "v_out"), ("bias_in", "bias_out")):
+                            if a_ in xb:                                 # ... their Adam moments / bias values
+                                self._a2a(xb[a_], xb[b_], send[:, xi, i], recv[:, xi, i])
                     else:
                         self._a2a(xb["rows_in"], xb["rows_out"])
-                        if "bias_in" in xb:
-                            self._a2a(xb["bias_in"], xb["bias_out"])
+                        for a_, b_ in (("m_in", "m_out"), ("v_in", "v_out"), ("bias_in", "bias_out")):
+                            if a_ in xb:
+                                self._a2a(xb[a_], xb[b_])
                 lo = losses[t:t + 1] if losses is not None else be._loss
                 be.local_step_at(i, uid_all[t * nu:(t + 1) * nu] if uid_per_step else None, lo)
                 for xi in range(nx if not getattr(be, "replicated", False) else 0):   # gradients -> owners (replicated form: none)

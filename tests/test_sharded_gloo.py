@@ -17,9 +17,10 @@ B, D, NU, NI = 32, 8, 40, 60
 STEPS = 3
 
 
-def _conf(loss, bias=None):
+def _conf(loss, bias=None, optimizer="sgd"):
     return so.OracleConf(batch_size_p=B, num_negatives=0, loss=loss, loss_gamma=10. if loss == "log-loss" else None,
-                         u_reg=1e-3, learn_rate=0.1, model_choice="mf", interaction_bias=bias)
+                         u_reg=1e-3, learn_rate=0.1 if optimizer == "sgd" else 0.01, model_choice="mf", interaction_bias=bias,
+                         optimizer=optimizer)
 
 
 def _tables(seed=0):
@@ -98,6 +99,11 @@ class _CompactChunks(object):
                 x.append(dict(n=n, req_out=torch.zeros(CH * n, dtype=torch.int32), req_in=torch.zeros(CH * W * n, dtype=torch.int32),
                               rows_out=torch.zeros(W * n, d), rows_in=torch.zeros(n, d), g_out=torch.zeros(n, d),
                               g_in=torch.zeros(W * n, d)))
+            for xb, ms in zip(x, getattr(self, "_moment_shards", lambda: [None] * nx)()):
+                if ms is not None:       # Adam on the replicated form: the moment rows of the same ids (nncf_shard_moment_buffers)
+                    dd = xb["rows_in"].shape[1]
+                    xb.update(m_out=torch.zeros(W * xb["n"], dd), m_in=torch.zeros(xb["n"], dd), v_out=torch.zeros(W * xb["n"], dd),
+                              v_in=torch.zeros(xb["n"], dd))
             for xb, bs in zip(x, getattr(self, "_bias_shards", lambda: [None] * nx)()):
                 if bs is not None:       # the bias values of the same rows (HipBackend: nncf_shard_bias_buffers)
                     xb.update(bias_out=torch.zeros(W * xb["n"]), bias_in=torch.zeros(xb["n"]))
@@ -143,6 +149,10 @@ class _CompactChunks(object):
             bs = getattr(self, "_bias_shards", lambda: [None] * self.nx)()[xi]
             if bs is not None:
                 self._bufs["x"][xi]["bias_out"][:len(ids)] = torch.from_numpy(bs[ids - i0])
+            ms = getattr(self, "_moment_shards", lambda: [None] * self.nx)()[xi]
+            if ms is not None:
+                self._bufs["x"][xi]["m_out"][:len(ids)] = torch.from_numpy(ms[0][ids - i0])
+                self._bufs["x"][xi]["v_out"][:len(ids)] = torch.from_numpy(ms[1][ids - i0])
 
     def plan_owner(self, n_steps, rows_per_step=None):
         if self.world == 1:     # one rank: the native session aliases the two ends; the test double copies
@@ -249,6 +259,14 @@ class ReplicatedNumpyBackend(_CompactChunks):
     def _bias_shards(self):
         return [self.bi, self.bu]
 
+    def _moment_shards(self):
+        if getattr(self.conf, "optimizer", "sgd") == "sgd":
+            return [None, None]
+        if not hasattr(self, "_mom"):     # Adam state of this rank's shards: (m, v) per table; steps taken so far
+            self._mom = [(np.zeros_like(self.V), np.zeros_like(self.V)), (np.zeros_like(self.U), np.zeros_like(self.U))]
+            self._t = 0
+        return self._mom
+
     def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
         self._ids = [cid_chunk.numpy().reshape(n_steps, self.b), uid_chunk.numpy().reshape(n_steps, self.b)]
         self._plan_lists([cid_chunk, uid_chunk], n_steps)
@@ -265,11 +283,38 @@ class ReplicatedNumpyBackend(_CompactChunks):
                 if self.world == 1:
                     xb["bias_in"].copy_(xb["bias_out"][:self.b])
                 setattr(o, name, xb["bias_in"].numpy().copy())
+        adam = getattr(self.conf, "optimizer", "sgd") != "sgd"
+        if adam:                                             # the landed moment rows are the step's Adam state
+            self._moment_shards()
+            o.slot_v, o.slot_u = so.AdamSlot(o.V), so.AdamSlot(o.U)
+            for xb, slot in ((xv, o.slot_v), (xu, o.slot_u)):
+                if self.world == 1:
+                    xb["m_in"].copy_(xb["m_out"][:self.b])
+                    xb["v_in"].copy_(xb["v_out"][:self.b])
+                slot.m[...] = xb["m_in"].numpy()
+                slot.v[...] = xb["v_in"].numpy()
+            o.t = self._t
+            if self.conf.optimizer == "adam":                # Keras' dense Adam: every row of the (landing) table would step; only
+                import copy
+                o.conf = copy.copy(self.conf)                # the touched ones are real rows here
+                o.conf.optimizer = "sparse_adam"
         loss = o.step_neg_shared(su, sv)                     # the one-device step on the landing rows
-        for (shard, rpr, i0, n), ids, slots, land in ((self._tables()[0], self._ids[0][index], sv, o.V),
-                                                      (self._tables()[1], self._ids[1][index], su, o.U)):
+        for k, ((shard, rpr, i0, n), ids, slots, land, slot) in enumerate(((self._tables()[0], self._ids[0][index], sv, o.V, getattr(o, "slot_v", None)),
+                                                                          (self._tables()[1], self._ids[1][index], su, o.U, getattr(o, "slot_u", None)))):
             own = (ids >= i0) & (ids < i0 + shard.shape[0])
             shard[ids[own] - i0] = land[slots[own]]         # the owners write their rows back
+            if adam:
+                ms, vs = self._mom[k]
+                ms[ids[own] - i0] = slot.m[slots[own]]      # ... and the moment rows
+                vs[ids[own] - i0] = slot.v[slots[own]]
+                if self.conf.optimizer == "adam":            # dense Adam: the rest of the shard takes the zero-gradient step
+                    idle = np.setdiff1d(np.arange(shard.shape[0]), ids[own] - i0)
+                    lr_t = np.float32(so.adam_lr_t(self.conf.learn_rate, self.conf.beta1, self.conf.beta2, self._t + 1))
+                    ms[idle] *= np.float32(self.conf.beta1)
+                    vs[idle] *= np.float32(self.conf.beta2)
+                    shard[idle] -= lr_t * ms[idle] / (np.sqrt(vs[idle]) + np.float32(self.conf.epsilon))
+        if adam:
+            self._t += 1
         for bs, (shard, rpr, i0, n), ids, slots, land in ((self.bi, self._tables()[0], self._ids[0][index], sv, o.cb),
                                                           (self.bu, self._tables()[1], self._ids[1][index], su, o.ub)):
             if bs is not None:
@@ -414,12 +459,12 @@ def _global_batches(seed=7):
     return out
 
 
-def _worker_strong(rank, world, port, loss, ret, bias=None):
+def _worker_strong(rank, world, port, loss, ret, bias=None, optimizer="sgd"):
     from nncf_amd.sharded import ShardedGlobalBatch
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    conf = _conf(loss, bias)
+    conf = _conf(loss, bias, optimizer)
     U, V = _tables()
     us, isz = shard_size(NU, world), shard_size(NI, world)
     cls = ReplicatedNumpyBackend if (loss in ("log-loss", "max-margin") or bias) else StrongNumpyBackend
@@ -435,6 +480,27 @@ def _worker_strong(rank, world, port, loss, ret, bias=None):
         (None if be.bu is None else be.bu.copy(), None if be.bi is None else be.bi.copy()) if bias else ())
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sparse_adam"])
+def test_replicated_global_batch_with_adam_over_two_ranks(optimizer):
+    """pairwise loss + Adam on the strong form: the moment rows travel with the table rows of the replicated protocol (two more
+    exchanges per table and step with the same counts), world 2 == the one-device step; Keras' dense Adam: the untouched rows of
+    every shard take the zero-gradient step.  ShardedGlobalBatch / _Exchanger are the product's."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_strong, args=(world, _free_port(), "log-loss", ret, None, optimizer), nprocs=world, join=True)
+    conf = _conf("log-loss", None, optimizer)
+    U, V = _tables()
+    orc = so.StepOracle(U, V, conf, dtype=np.float32)
+    want = [orc.step_neg_shared(u, c) for u, c in _global_batches()]
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_, wire = ret[r]
+        np.testing.assert_allclose(lr_, want, rtol=1e-5)
+        np.testing.assert_allclose(Ur, orc.U[r * us:(r + 1) * us], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(Vr, orc.V[r * isz:(r + 1) * isz], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("loss,bias", [("skip-gram", "both"), ("log-loss", "user"), ("mse", "item")])

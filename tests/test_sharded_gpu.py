@@ -420,6 +420,40 @@ def test_rectangular_step_shares_add_up_to_the_square_step():
     np.testing.assert_allclose(gv_got, gv_want, rtol=0, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("loss", ["log-loss", "max-margin"])
+@pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
+def test_replicated_strong_form_with_adam_equals_the_oracle(loss, kind):
+    """Adam on the REPLICATED strong form (pairwise losses): the moment rows travel with the table rows into the model's own
+    moment arrays, the one-device step updates rows and moments, the owners write both back; Keras' dense Adam: the touched rows'
+    stamps come home too and the rest of every shard takes the zero-gradient step -- 70 steps at world 1 == the oracle."""
+    from nncf_amd.sharded import ShardedGlobalBatch
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.01, normalize_user=False, normalize_item=False, optimizer=kind)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0, mode="strong", user_shard=nu)
+    assert be.replicated
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.01, model_choice="mf", emb_normalization=False, optimizer=kind)
+    orc = so.StepOracle(be.U.cpu().numpy(), be.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    uid[:6] = uid[0]
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr = ShardedGlobalBatch(be, nu, ni, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    be.engine.check()
+    l = losses.cpu().numpy()
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l[t] - want) <= 1e-5 * max(1, abs(want)), (t, l[t], want)
+    for got, want in ((be.U, orc.U), (be.V, orc.V)):   # (Adam: flat tolerance, see the two-rank test)
+        np.testing.assert_allclose(got.cpu().numpy()[:, :d], want, rtol=5e-4, atol=5e-5)
+    m_u, v_u, _ = be._adam[1]
+    np.testing.assert_allclose(m_u.cpu().numpy()[:, :d], orc.slot_u.m, rtol=2e-3, atol=1e-6)   # the moments went home as well
+    np.testing.assert_allclose(v_u.cpu().numpy()[:, :d], orc.slot_u.v, rtol=2e-3, atol=1e-9)
+
+
 @pytest.mark.parametrize("form", ["weak", "strong"])
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
 def test_sharded_world1_adam_equals_the_plain_engine_and_the_oracle(form, kind):

@@ -137,6 +137,20 @@ def test_strong_form_two_ranks_with_adam_equal_the_single_device_step(tmp_path, 
         np.testing.assert_allclose(got[r]["V"], V[r * isz:(r + 1) * isz], rtol=5e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize("kind,transport", [("adam", "torch"), ("sparse_adam", "callback"), ("adam", "callback")])
+def test_replicated_strong_form_two_ranks_with_adam(tmp_path, kind, transport):
+    """pairwise loss + Adam over two ranks: rows AND their moment rows to every rank, the whole step everywhere, rows / moments /
+    (dense Adam) stamps written back by the owners, idle shard rows take the zero-gradient step == the one-device step"""
+    world = 2
+    got = _run_ranks("strong", world, tmp_path, "log-loss", kind, NNCF_SHARD_TRANSPORT=transport)
+    U, V, losses = sc.simulate_strong("log-loss", kind)
+    us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], losses, rtol=1e-5)
+        np.testing.assert_allclose(got[r]["U"], U[r * us:(r + 1) * us], rtol=5e-4, atol=5e-5)    # (Adam: see the test above)
+        np.testing.assert_allclose(got[r]["V"], V[r * isz:(r + 1) * isz], rtol=5e-4, atol=5e-5)
+
+
 @pytest.mark.parametrize("transport", ["torch", "callback"])
 def test_data_parallel_tower_two_ranks_on_one_gpu(tmp_path, transport):
     """basic_embedding, data parallel: both ranks' HIP towers export their gradients, ONE all-reduce per step, the
