@@ -1,0 +1,219 @@
+// Prototype of the large-batch step's stage loop on the bf16 matrix pipe with fp32-grade results:
+// a workgroup owns 32 rows of U, streams the N rows of V through LDS in stages of 64 as three bf16 planes (x = hi + mid + lo),
+// S = U.V^T by six piece products per k-step (v_mfma_f32_16x16x32_bf16), the skip-gram dL/dS element-wise on the accumulators,
+// dL/dS split into planes through LDS, dU += G.V by six piece products again (V read from a TRANSPOSED plane image written at
+// staging time).  Checked against float64 on the host; timed against the algorithmic 4 * 32 * N * d flop of the two products.
+// build: hipcc -O3 --offload-arch=gfx950 tools/micro/wide_split.hip -o tools/micro/wide_split
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int D = 128, OWN = 32, ST = 64;
+constexpr int PK = D + 8;      // pitch (bf16) of the row-major planes: 272 B
+constexpr int PJ = ST + 8;     // pitch (bf16) of the j-major images: 144 B
+constexpr size_t kLds = 2 * (size_t)(3 * OWN * PK + 3 * ST * PK + 3 * D * PJ + 3 * OWN * PJ);
+
+__device__ __forceinline__ unsigned short bf_trunc(float x) { return (unsigned short)(__float_as_uint(x) >> 16); }
+__device__ __forceinline__ float bf_val(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+  hi = bf_trunc(x);
+  const float r1 = x - bf_val(hi);
+  mid = bf_trunc(r1);
+  lo = bf_trunc(r1 - bf_val(mid));
+}
+__device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);   // small terms first
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// grid = n_own / 32 workgroups of 512 threads; U [n_own][D], V [n][D]; positive of own row i is column i; out: dU [n_own][D], loss parts
+__global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict__ U, const float* __restrict__ V, int n, float wneg,
+                                                         float* __restrict__ dU, float* __restrict__ loss_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* sOwn = smem;                       // [3][OWN][PK]
+  unsigned short* sOpp = sOwn + 3 * OWN * PK;        // [3][ST][PK]   row-major: 8 consecutive k per fragment read
+  unsigned short* sOppT = sOpp + 3 * ST * PK;        // [3][D][PJ]    column-major: 8 consecutive j per fragment read
+  unsigned short* sG = sOppT + 3 * D * PJ;           // [3][OWN][PJ]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, x = lane & 15, g = lane >> 4;
+  const int blk = blockIdx.x;
+  // own rows -> planes (once)
+  for (int e = tid; e < OWN * D / 4; e += 512) {
+    const int r = e / (D / 4), c4 = e % (D / 4);
+    const float4 v = reinterpret_cast<const float4*>(U + (size_t)(blk * OWN + r) * D)[c4];
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 p[3];
+    for (int k = 0; k < 4; ++k) {
+      unsigned short h, m, l;
+      split3(f[k], h, m, l);
+      p[0][k] = (short)h; p[1][k] = (short)m; p[2][k] = (short)l;
+    }
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(sOwn + (pl * OWN + r) * PK + 4 * c4) = p[pl];
+  }
+  // staging registers: a stage is 64 rows x 128 floats = 2048 float4, four per thread: thread -> (row = tid / 8 (+0), chunks ...)
+  float4 nxt[4];
+  auto load_stage = [&](int st) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // thread = (block of four rows jb, four columns c4): rows 4 jb + e
+      const int jb = tid >> 5, c4 = tid & 31, r = 4 * jb + e;
+      const int row = st * ST + r;
+      nxt[e] = row < n ? reinterpret_cast<const float4*>(V + (size_t)row * D)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put_stage = [&]() {
+    const int jb = tid >> 5, c4 = tid & 31;
+    bf16x4 pr[3][4];   // [plane][row e] four consecutive k
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float f[4] = {nxt[e].x, nxt[e].y, nxt[e].z, nxt[e].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned short h, m, l;
+        split3(f[k], h, m, l);
+        pr[0][e][k] = (short)h; pr[1][e][k] = (short)m; pr[2][e][k] = (short)l;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(sOpp + (pl * ST + 4 * jb + e) * PK + 4 * c4) = pr[pl][e];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {   // column 4 c4 + k: its four consecutive j
+        bf16x4 t;
+        t[0] = pr[pl][0][k]; t[1] = pr[pl][1][k]; t[2] = pr[pl][2][k]; t[3] = pr[pl][3][k];
+        *reinterpret_cast<bf16x4*>(sOppT + (pl * D + 4 * c4 + k) * PJ + 4 * jb) = t;
+      }
+    }
+  };
+  const int mt = wave & 1, ot = wave >> 1;      // S phase: own tile, opposite tile of this wave
+  f32x4 accD[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // back phase: column tile `wave`, both own tiles
+  float lsum = 0.f;
+  const int nst = (n + ST - 1) / ST;
+  load_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    put_stage();
+    __syncthreads();
+    if (st + 1 < nst) load_stage(st + 1);
+    // ---- S tile (own tile mt) x (opp tile ot): K = 128 in four k-steps
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bf16x8 a[3], b[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = *reinterpret_cast<const bf16x8*>(sOwn + (pl * OWN + 16 * mt + x) * PK + 32 * t + 8 * g);
+        b[pl] = *reinterpret_cast<const bf16x8*>(sOpp + (pl * ST + 16 * ot + x) * PK + 32 * t + 8 * g);
+      }
+      acc = mfma6(b, a, acc);   // S^T: the lane's four results are four CONSECUTIVE opposite rows of one own row
+    }
+    // ---- dL/dS on the accumulators: D[j = 4 g + r][i = x]
+    {
+      const int i = 16 * mt + x, gi = blk * OWN + i;
+      bf16x4 gp[3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = st * ST + 16 * ot + 4 * g + r;
+        const float s = acc[r];
+        const float m = (gi == j) ? 1.f : 0.f;
+        const float e = __expf(-fabsf(s)), u = 1.f + e, rc = __builtin_amdgcn_rcpf(u), lg = __logf(u);
+        const float sp = fmaxf(s, 0.f) + lg, spn = fmaxf(-s, 0.f) + lg;
+        const float sg = s >= 0.f ? rc : e * rc, sgn = s >= 0.f ? e * rc : rc;
+        float l = (1.f - m) * wneg * sp + m * spn, h = (1.f - m) * wneg * sg - m * sgn;
+        if (j >= n) { l = 0.f; h = 0.f; }
+        lsum += l;
+        unsigned short hh, hm, hl;
+        split3(h, hh, hm, hl);
+        gp[0][r] = (short)hh; gp[1][r] = (short)hm; gp[2][r] = (short)hl;
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x4*>(sG + (pl * OWN + i) * PJ + 16 * ot + 4 * g) = gp[pl];
+    }
+    __syncthreads();
+    // ---- back product: dU[own][cols 16 wave ..] += G[own][j] . V[j][col], K = 64 in two k-steps
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(sOppT + (pl * D + 16 * wave + x) * PJ + 32 * t + 8 * g);
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(sG + (pl * OWN + 16 * m2 + x) * PJ + 32 * t + 8 * g);
+        accD[m2] = mfma6(a, b, accD[m2]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dU[(size_t)(blk * OWN + 16 * m2 + 4 * g + r) * D + 16 * wave + x] = accD[m2][r];
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+  if (lane == 0) atomicAdd(loss_part + blk, lsum);
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 8192;
+  const int n_own = n;
+  std::vector<float> U((size_t)n_own * D), V((size_t)n * D);
+  srand(3);
+  for (auto& v : U) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.3f;
+  for (auto& v : V) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.3f;
+  float *dUm, *dVm, *dOut, *dLoss;
+  hipMalloc(&dUm, U.size() * 4); hipMalloc(&dVm, V.size() * 4); hipMalloc(&dOut, U.size() * 4); hipMalloc(&dLoss, (n_own / OWN) * 4);
+  hipMemcpy(dUm, U.data(), U.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dVm, V.data(), V.size() * 4, hipMemcpyHostToDevice);
+  hipMemset(dLoss, 0, (n_own / OWN) * 4);
+  const float wneg = 128.f / (n - 1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(wide_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {
+    hipMemset(dLoss, 0, (n_own / OWN) * 4);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(wide_split_kernel, dim3(n_own / OWN), dim3(512), kLds, 0, dUm, dVm, n, wneg, dOut, dLoss);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep) best = fminf(best, ms);
+  }
+  if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+  std::vector<float> out(U.size());
+  hipMemcpy(out.data(), dOut, out.size() * 4, hipMemcpyDeviceToHost);
+  // float64 check on a few own rows
+  double worst = 0, scale = 0;
+  for (int i : {0, 1, 17, 31, 32, 4095 % n_own, n_own - 1}) {
+    std::vector<double> ref(D, 0.0);
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      for (int k = 0; k < D; ++k) s += (double)U[(size_t)i * D + k] * V[(size_t)j * D + k];
+      const double m = (i == j) ? 1.0 : 0.0;
+      const double sg = 1.0 / (1.0 + exp(-s)), sgn = 1.0 - sg;
+      const double h = (1.0 - m) * wneg * sg - m * sgn;
+      for (int k = 0; k < D; ++k) ref[k] += h * V[(size_t)j * D + k];
+    }
+    for (int k = 0; k < D; ++k) {
+      worst = fmax(worst, fabs(out[(size_t)i * D + k] - ref[k]));
+      scale = fmax(scale, fabs(ref[k]));
+    }
+  }
+  const double flop = 4.0 * n_own * (double)n * D;   // S and G.V, algorithmic
+  printf("n = %d (one side: %d workgroups of 32 own rows, 64-row stages, %zu KB of LDS)\n", n, n_own / OWN, kLds / 1024);
+  printf("  max |dU - float64| = %.3g on rows of magnitude %.3g  (relative %.2g)\n", worst, scale, worst / scale);
+  printf("  %.1f us per launch, %.1f TFLOP/s on the algorithmic 4*n*n*d flop of S and G.V (fp32 MFMA peak: 157)\n", best * 1e3,
+         flop / (best * 1e-3) / 1e12);
+  return 0;
+}
