@@ -38,7 +38,7 @@ __device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
 
 // grid = n_own / 32 workgroups of 512 threads; U [n_own][D], V [n][D]; positive of own row i is column i; out: dU [n_own][D], loss parts
 __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict__ U, const float* __restrict__ V, int n, float wneg,
-                                                         float* __restrict__ dU, float* __restrict__ loss_part) {
+                                                         float* __restrict__ dU, float* __restrict__ loss_part, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   unsigned short* sOwn = smem;                       // [3][OWN][PK]
   unsigned short* sOpp = sOwn + 3 * OWN * PK;        // [3][ST][PK]   row-major: 8 consecutive k per fragment read
@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) *reinterpret_cast<bf16x4*>(sOpp + (pl * ST + 4 * jb + e) * PK + 4 * c4) = pr[pl][e];
+      for (int e = 0; e < 4; ++e) if (!(dbg & 1)) *reinterpret_cast<bf16x4*>(sOpp + (pl * ST + 4 * jb + e) * PK + 4 * c4) = pr[pl][e];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // column 4 c4 + k: its four consecutive j
         bf16x4 t;
         t[0] = pr[pl][0][k]; t[1] = pr[pl][1][k]; t[2] = pr[pl][2][k]; t[3] = pr[pl][3][k];
-        *reinterpret_cast<bf16x4*>(sOppT + (pl * D + 4 * c4 + k) * PJ + 4 * jb) = t;
+        if (!(dbg & 2)) *reinterpret_cast<bf16x4*>(sOppT + (pl * D + 4 * c4 + k) * PJ + 4 * jb) = t;
       }
     }
   };
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
   for (int st = 0; st < nst; ++st) {
     put_stage();
     __syncthreads();
-    if (st + 1 < nst) load_stage(st + 1);
+    if (st + 1 < nst && !(dbg & 4)) load_stage(st + 1);
     // ---- S tile (own tile mt) x (opp tile ot): K = 128 in four k-steps
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
         a[pl] = *reinterpret_cast<const bf16x8*>(sOwn + (pl * OWN + 16 * mt + x) * PK + 32 * t + 8 * g);
         b[pl] = *reinterpret_cast<const bf16x8*>(sOpp + (pl * ST + 16 * ot + x) * PK + 32 * t + 8 * g);
       }
-      acc = mfma6(b, a, acc);   // S^T: the lane's four results are four CONSECUTIVE opposite rows of one own row
+      if (!(dbg & 8)) acc = mfma6(b, a, acc);   // S^T: the lane's four results are four CONSECUTIVE opposite rows of one own row
     }
     // ---- dL/dS on the accumulators: D[j = 4 g + r][i = x]
     {
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
         const int j = st * ST + 16 * ot + 4 * g + r;
         const float s = acc[r];
         const float m = (gi == j) ? 1.f : 0.f;
-        const float e = __expf(-fabsf(s)), u = 1.f + e, rc = __builtin_amdgcn_rcpf(u), lg = __logf(u);
+        const float e = (dbg & 32) ? 0.5f : __expf(-fabsf(s)), u = 1.f + e, rc = (dbg & 32) ? 0.6f : __builtin_amdgcn_rcpf(u), lg = (dbg & 32) ? 0.4f : __logf(u);
         const float sp = fmaxf(s, 0.f) + lg, spn = fmaxf(-s, 0.f) + lg;
         const float sg = s >= 0.f ? rc : e * rc, sgn = s >= 0.f ? e * rc : rc;
         float l = (1.f - m) * wneg * sp + m * spn, h = (1.f - m) * wneg * sg - m * sgn;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
         bf16x8 a[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(sG + (pl * OWN + 16 * m2 + x) * PJ + 32 * t + 8 * g);
-        accD[m2] = mfma6(a, b, accD[m2]);
+        if (!(dbg & 16)) accD[m2] = mfma6(a, b, accD[m2]);
       }
     }
     __syncthreads();
@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(512) wide_split_kernel(const float* __restrict
 
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 8192;
+  const int dbg = argc > 2 ? atoi(argv[2]) : 0;
   const int n_own = n;
   std::vector<float> U((size_t)n_own * D), V((size_t)n * D);
   srand(3);
@@ -183,7 +184,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 4; ++rep) {
     hipMemset(dLoss, 0, (n_own / OWN) * 4);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(wide_split_kernel, dim3(n_own / OWN), dim3(512), kLds, 0, dUm, dVm, n, wneg, dOut, dLoss);
+    hipLaunchKernelGGL(wide_split_kernel, dim3(n_own / OWN), dim3(512), kLds, 0, dUm, dVm, n, wneg, dOut, dLoss, dbg);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
