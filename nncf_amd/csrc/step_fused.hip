@@ -60,6 +60,39 @@ __device__ __forceinline__ void lds_store_row_f(float* dst, int q, Row v) {
   reinterpret_cast<float4*>(dst)[q + 16] = v.b;
 }
 
+// ---- fp32 products on the fp16 matrix pipe (large batches; tools/micro/mfma_split.hip) ----------------
+// x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) 2048): two planes of 2 bytes -- the bytes of the fp32, so every LDS
+// image keeps its size -- and a . b = hi.hi' + (hi.lo' + lo.hi') / 2048: THREE v_mfma_f32_16x16x32_f16 of ~17 cycles per 32
+// k-values (the cross terms in their own accumulator) where the fp32 pipe takes eight v_mfma_f32_16x16x4_f32 of 32 cycles.
+// Measured on random tiles: 6.4e-8 of sum |a b| against float64 (the fp32 MFMA: 1.5e-7), 4.5-5 x its rate.  Domain: |x| < 65,504
+// (beyond: inf -> NaN loss -> the trainers' NaN check); elements below 6e-5 keep an ABSOLUTE precision of ~3e-11.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float kHLoScale = 2048.f;
+// dL/dS is stored times a power of two chosen from the step's negative weight (wide_gscale): its entries are count x (lambda / (N - 1)) x
+// sigmoid -- 1e-2 and below at N = 8,192, hundreds on a two-item catalogue -- and the fp16 planes want O(1) .. O(count)
+__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kHLoScale);
+}
+// row image: [hi k = 0..127][lo k = 0..127] as fp16 = 512 bytes; lane q holds columns 4q..4q+3 and 64+4q..64+4q+3
+__device__ __forceinline__ void lds_store_row_h(float* dst, int q, Row v) {
+  const float f[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
+  f16x4 h[2], l[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 hh, ll;
+    split_h(f[e], hh, ll);
+    h[e >> 2][e & 3] = hh;
+    l[e >> 2][e & 3] = ll;
+  }
+  _Float16* p = reinterpret_cast<_Float16*>(dst);
+  *reinterpret_cast<f16x4*>(p + 4 * q) = h[0];
+  *reinterpret_cast<f16x4*>(p + 64 + 4 * q) = h[1];
+  *reinterpret_cast<f16x4*>(p + 128 + 4 * q) = l[0];
+  *reinterpret_cast<f16x4*>(p + 192 + 4 * q) = l[1];
+}
+
 #define NNCF_MFMA4(A, B, C0, C1)                                        \
   C0 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (B).x, C0, 0, 0, 0); \
   C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (B).y, C1, 0, 0, 0); \
@@ -730,7 +763,7 @@ __device__ __forceinline__ void s_tiles(const float* sOwn, const float4* pb4, in
   }
 }
 
-template <int LOSS, bool GROUP, bool NU, bool NV, bool USIDE, int MT>
+template <int LOSS, bool GROUP, bool NU, bool NV, bool USIDE, int MT, bool H16>
 __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __restrict__ uid,
                                           const int32_t* __restrict__ cid, const FusedArgs& f, const PlanView& pu,
                                           const PlanView& pv, int blk, int update, float* smem) {
@@ -847,7 +880,8 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           kstart = start;
         }
       }
-      lds_store_row_f(sOwn + o * kFDP, q, hat);
+      if (H16) lds_store_row_h(sOwn + o * kFDP, q, hat);
+      else lds_store_row_f(sOwn + o * kFDP, q, hat);
       if (q == 0) {
         sCnt[o] = c;
         sRowReg[o] = c * ss;
@@ -874,6 +908,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   FSTAMP(3);
   const float inv_b = 1.f / (float)b;
   const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
+  const float gscale = exp2f(-ceilf(log2f(fmaxf(wneg, 1.f / 64.f))));   // H16: 64 at lambda / N = 1 / 64 and below, 1 / 128 at lambda = 128, N = 2
   f32x4 accD0[MT], accD1[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -890,7 +925,8 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     for (int e = 0; e < 4; ++e) {
       Row r = rcur[e];
       if (USIDE ? NV : NU) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
-      lds_store_row_f(sOpp + (g + 32 * e) * kFDP, q, r);
+      if (H16) lds_store_row_h(sOpp + (g + 32 * e) * kFDP, q, r);
+      else lds_store_row_f(sOpp + (g + 32 * e) * kFDP, q, r);
       if (q == 0) sOppKey[g + 32 * e] = kcur[e];
     }
     __syncthreads();
@@ -909,16 +945,29 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     // tile m (VALU / transcendental under the matrix pipe; one basic block for the pointwise non-group case).
     // Always 8 column groups: columns past d are zero in LDS (d = 100 issues 1/8 idle MFMAs).
     {
-      const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kFDP + 4 * kq);
+      // fp32 path: eight float4 fragments per operand (k = 16 t + 4 kq + e); fp16 planes: per k-step t of 32 the lane's eight
+      // consecutive k (32 t + 8 kq + e) of the hi plane and of the lo plane -- eight 16-byte reads per operand either way
+      const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kFDP + 4 * kq);   // (8 fp16 = 16 bytes = 4 floats)
       float4 fb[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) fb[t] = pb4[4 * t];
+      for (int t = 0; t < 8; ++t) fb[t] = H16 ? pb4[(t & 3) * 4 + (t >> 2) * 16] : pb4[4 * t];   // H16: t < 4 hi plane, t >= 4 lo plane
       auto s_one = [&](int mt) -> f32x4 {
         const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kFDP + 4 * kq);
         float4 fa[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fa[t] = pa4[4 * t];
+        for (int t = 0; t < 8; ++t) fa[t] = H16 ? pa4[(t & 3) * 4 + (t >> 2) * 16] : pa4[4 * t];
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (H16) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {   // acc0: hi.hi; acc1: the cross terms (times 2048)
+            const f16x8 ah = __builtin_bit_cast(f16x8, fa[t]), al = __builtin_bit_cast(f16x8, fa[4 + t]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, fb[t]), bl = __builtin_bit_cast(f16x8, fb[4 + t]);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc1, 0, 0, 0);
+          }
+          return acc0 + acc1 * (1.f / kHLoScale);
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           NNCF_MFMA4(fa[t], fb[t], acc0, acc1);
@@ -965,7 +1014,15 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
             l = 0.f;
             h = 0.f;
           }
-          sG[i * kFGP + j] = h * inv_b;
+          if (H16) {   // the tile of dL/dS as two fp16 planes [hi j = 0..127][lo j = 0..127] per own row, times gscale
+            _Float16 gh, gl;
+            split_h(h * gscale, gh, gl);
+            _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kFGP);
+            pg[j] = gh;
+            pg[128 + j] = gl;
+          } else {
+            sG[i * kFGP + j] = h * inv_b;
+          }
           lsum += l;
         }
         if (mt + 1 < MT && !(GROUP && USIDE)) {
@@ -982,7 +1039,29 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     __syncthreads();
     if (last_stage && tid == 0) seen = readers_seen(f);
     if (st < 4) FSTAMP(7 + 4 * st);
-    if (back_wave) {
+    if (back_wave && H16) {
+      // dOwn[own][col] += G[own][j] . Opp[j][col] over the stage's 128 opposite rows in four k-steps of 32: the lane (col x, kq) gathers
+      // column 16 wave + x of rows 32 t + 8 kq + e (hi and lo planes: 16 two-byte reads); accD0: hi.hi, accD1: the cross terms
+      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + 16 * wave + x;
+#pragma unroll
+      for (int t = 0; t < kFNB / 32; ++t) {
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const _Float16* pr = pcol + (size_t)(32 * t + 8 * kq + e) * (2 * kFDP);
+          vh[e] = pr[0];
+          vl[e] = pr[128];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kFGP + 4 * kq);
+          const f16x8 gh = __builtin_bit_cast(f16x8, pg4[4 * t]), gl = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
+          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vl, accD1[mt], 0, 0, 0);
+          accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vh, accD0[mt], 0, 0, 0);
+          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, vh, accD1[mt], 0, 0, 0);
+        }
+      }
+    } else if (back_wave) {
       const float* pbv = sOpp + (4 * kq) * kFDP + 16 * wave + x;
 #pragma unroll
       for (int t = 0; t < kFNB / 16; ++t) {
@@ -1007,7 +1086,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   if (back_wave) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 accD = accD0[mt] + accD1[mt];
+      const f32x4 accD = H16 ? (accD0[mt] + accD1[mt] * (1.f / kHLoScale)) * (inv_b / gscale) : accD0[mt] + accD1[mt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) sOut[(16 * mt + 4 * kq + r) * kFOP + 16 * wave + x] = accD[r];
     }
@@ -1072,7 +1151,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
 }
 
 // grid = 2 gu + 1 workgroups: gu U strips, gu V strips of 16 MT unique rows, the previous step's loss
-template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
+template <int LOSS, bool GROUP, bool NU, bool NV, int MT, bool H16>
 __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32_t* __restrict__ uid,
                                                          const int32_t* __restrict__ cid, FusedArgs f, PlanView pu,
                                                          PlanView pv, int update, int gu) {
@@ -1096,10 +1175,10 @@ __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32
       if (threadIdx.x == 0) f.loss_part[strip] = 0.f;
       return;
     }
-    wide_body<LOSS, GROUP, NU, NV, true, MT>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+    wide_body<LOSS, GROUP, NU, NV, true, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
   } else {
     if (!update || strip * 16 * MT >= nseg_v) return;
-    wide_body<LOSS, GROUP, NU, NV, false, MT>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+    wide_body<LOSS, GROUP, NU, NV, false, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
   }
 }
 
@@ -1163,11 +1242,17 @@ int launch_commit(const StepArgs& a, const FusedArgs& f, const PlanView& pu, con
   return NNCF_OK;
 }
 
-template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
+// NNCF_WIDE_F16SPLIT=0: the products of the wide kernel on the fp32 matrix pipe (as before round 4)
+static bool wide_f16_split() {   // (read per launch: tests switch it inside one process)
+  const char* e = getenv("NNCF_WIDE_F16SPLIT");
+  return !(e && atoi(e) == 0);
+}
+
+template <int LOSS, bool GROUP, bool NU, bool NV, int MT, bool H16>
 int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream) {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
-  auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT>;
+  auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT, H16>;
   static KernelDeviceState kds;
   int capacity = 0;
   if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), kds, &capacity)) return rc;
@@ -1186,8 +1271,10 @@ template <int LOSS, bool GROUP, bool NU, bool NV>
 int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream) {
   const int mt = fused_row_tiles(a);
-  if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4>(a, uid, cid, f, pu, pv, update, stream);
-  if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 4 && wide_f16_split()) return launch_w<LOSS, GROUP, NU, NV, 4, true>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 2 && wide_f16_split()) return launch_w<LOSS, GROUP, NU, NV, 2, true>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4, false>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2, false>(a, uid, cid, f, pu, pv, update, stream);
   const int gu = (a.b + kFM - 1) / kFM;                       // user strips: this launch's rows
   const int gv = ((a.bc ? a.bc : a.b) + kFM - 1) / kFM;       // item strips: all columns
   const int nblk = ((gu + gv + 7) / 8) * 8 * f.split;

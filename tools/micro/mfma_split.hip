@@ -11,6 +11,7 @@
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short bf_trunc(float x) { return (unsigned short)(__float_as_uint(x) >> 16); }
 __device__ __forceinline__ float bf_val(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
@@ -22,12 +23,36 @@ __device__ __forceinline__ void split3(float x, unsigned short& hi, unsigned sho
   lo = bf_trunc(r2);
 }
 
-// C[16][16] = A[16][K] . B[K][16], K = 128, one wave; mode 0: fp32 MFMA, 1: six-product split, 2: three-product split (hi.hi, hi.mid, mid.hi)
+// fp16 variant: x = hi + lo 2^-11 with hi = fp16(x) and lo = fp16((x - hi) 2^11) -- two planes of 2 bytes, i.e. the bytes of the fp32 --
+// and A.B = hi.hi + 2^-11 (hi.lo + lo.hi): THREE v_mfma_f32_16x16x32_f16 per k-step, the cross terms in their own accumulator
+__device__ __forceinline__ void split2h(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * 2048.f);
+}
+
+// C[16][16] = A[16][K] . B[K][16], K = 128, one wave; mode 0: fp32 MFMA, 1: six-product split, 2: three-product split (hi.hi, hi.mid, mid.hi),
+// 3: fp16 two-plane split, three products
 __global__ void tile_kernel(const float* A, const float* B, float* C, int mode) {
   const int lane = threadIdx.x, x = lane & 15, g = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (mode == 0) {
     for (int k0 = 0; k0 < 128; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[x * 128 + k0 + g], B[(k0 + g) * 16 + x], acc, 0, 0, 0);
+  } else if (mode == 3) {
+    f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < 128; k0 += 32) {
+      f16x8 ah, al, bh, bl;
+      for (int e = 0; e < 8; ++e) {
+        _Float16 h, l;
+        split2h(A[x * 128 + k0 + 8 * g + e], h, l);
+        ah[e] = h; al[e] = l;
+        split2h(B[(k0 + 8 * g + e) * 16 + x], h, l);
+        bh[e] = h; bl[e] = l;
+      }
+      accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accx, 0, 0, 0);
+      accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accx, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) acc[r] = fmaf(accx[r], 1.f / 2048.f, acc[r]);
   } else {
     for (int k0 = 0; k0 < 128; k0 += 32) {   // lane (x, g): A[x][k0 + 8 g .. + 7], B[k0 + 8 g .. + 7][x]
       bf16x8 ah, am, al, bh, bm, bl;
@@ -65,6 +90,13 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters, float 
       for (int u = 0; u < 32; ++u)
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf, s, acc[i], 0, 0, 0);
+    } else if (MODE == 3) {
+      f16x8 ha, hb;
+      for (int e = 0; e < 8; ++e) { ha[e] = (_Float16)(float)(threadIdx.x + e); hb[e] = (_Float16)(float)(e + 1); }
+#pragma unroll
+      for (int u = 0; u < 12; ++u)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, acc[i], 0, 0, 0);
     } else {
 #pragma unroll
       for (int u = 0; u < (MODE == 1 ? 24 : 12); ++u)
@@ -81,7 +113,7 @@ int main() {
   // ---- accuracy
   std::vector<float> A(16 * 128), B(128 * 16), C(256);
   srand(7);
-  double worst[3] = {0, 0, 0}, scale = 0;
+  double worst[4] = {0, 0, 0, 0}, scale = 0;
   float *dA, *dB, *dC;
   hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 256 * 4);
   for (int trial = 0; trial < 20; ++trial) {
@@ -98,7 +130,7 @@ int main() {
         ref[i * 16 + j] = s;
         mag = fmax(mag, m);
       }
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       hipLaunchKernelGGL(tile_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC, mode);
       hipMemcpy(C.data(), dC, 256 * 4, hipMemcpyDeviceToHost);
       for (int e = 0; e < 256; ++e) worst[mode] = fmax(worst[mode], fabs(C[e] - ref[e]) / mag);   // relative to sum |a b|
@@ -108,6 +140,7 @@ int main() {
   printf("error of a 16x16x128 tile product against float64, relative to sum_k |a_k b_k| (20 random tiles):\n");
   printf("  fp32 MFMA 16x16x4          : %.3g\n  bf16 split, six products   : %.3g\n  bf16 split, three products : %.3g   (fp32 eps = 5.96e-8)\n",
          worst[0], worst[1], worst[2]);
+  printf("  fp16 two planes, 3 products: %.3g\n", worst[3]);
   (void)scale;
   // ---- rate
   hipEvent_t e0, e1;
@@ -137,6 +170,7 @@ int main() {
     run(rate_kernel<0, 4>, "fp32 MFMA (32 per tile)", 4, w);
     run(rate_kernel<1, 4>, "bf16 split-6 (24 per tile)", 4, w);
     run(rate_kernel<2, 4>, "bf16 split-3 (12 per tile)", 4, w);
+    run(rate_kernel<3, 4>, "fp16 2 planes (12 per tile)", 4, w);
   }
   return 0;
 }
