@@ -128,6 +128,40 @@ __device__ __forceinline__ void softplus_sigmoid(float z, float& sp, float& sg) 
   sg = z >= 0.f ? r : e * r;
 }
 
+// ---- fp32 products on the fp16 matrix pipe (the large-batch step kernels: step_fused.hip fused_wide, step_pair.hip pair_wide;
+// tools/micro/mfma_split.hip) ----------------
+// x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) 2048): two planes of 2 bytes -- the bytes of the fp32, so every LDS
+// image keeps its size -- and a . b = hi.hi' + (hi.lo' + lo.hi') / 2048: THREE v_mfma_f32_16x16x32_f16 of ~17 cycles per 32
+// k-values (the cross terms in their own accumulator) where the fp32 pipe takes eight v_mfma_f32_16x16x4_f32 of 32 cycles.
+// Measured on random tiles: 6.4e-8 of sum |a b| against float64 (the fp32 MFMA: 1.5e-7), 4.5-5 x its rate.  Domain: |x| < 65,504
+// (beyond: inf -> NaN loss -> the trainers' NaN check); elements below 6e-5 keep an ABSOLUTE precision of ~3e-11.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr float kHLoScale = 2048.f;
+// dL/dS is stored times a power of two chosen from the step's negative weight (wide_gscale): its entries are count x (lambda / (N - 1)) x
+// sigmoid -- 1e-2 and below at N = 8,192, hundreds on a two-item catalogue -- and the fp16 planes want O(1) .. O(count)
+__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kHLoScale);
+}
+// row image: [hi k = 0..127][lo k = 0..127] as fp16 = 512 bytes; lane q holds columns 4q..4q+3 and 64+4q..64+4q+3
+__device__ __forceinline__ void lds_store_row_h(float* dst, int q, Row v) {
+  const float f[8] = {v.a.x, v.a.y, v.a.z, v.a.w, v.b.x, v.b.y, v.b.z, v.b.w};
+  f16x4 h[2], l[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    _Float16 hh, ll;
+    split_h(f[e], hh, ll);
+    h[e >> 2][e & 3] = hh;
+    l[e >> 2][e & 3] = ll;
+  }
+  _Float16* p = reinterpret_cast<_Float16*>(dst);
+  *reinterpret_cast<f16x4*>(p + 4 * q) = h[0];
+  *reinterpret_cast<f16x4*>(p + 64 + 4 * q) = h[1];
+  *reinterpret_cast<f16x4*>(p + 128 + 4 * q) = l[0];
+  *reinterpret_cast<f16x4*>(p + 192 + 4 * q) = l[1];
+}
+
 // both signs from the same exponential: softplus(z), sigmoid(z), softplus(-z), sigmoid(-z)
 __device__ __forceinline__ void softplus_sigmoid_both(float z, float& sp, float& sg, float& spn, float& sgn) {
   const float e = __expf(-fabsf(z));

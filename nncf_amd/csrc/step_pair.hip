@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) pair_anchor_kernel(StepArgs a, const int3
 }
 
 // POS (this side streams by position and owns the loss and the T sums): USIDE for neg_shared, the item side for group.
-template <int LOSS, bool GROUP, bool USIDE, int MT>
+template <int LOSS, bool GROUP, bool USIDE, int MT, bool H16>
 __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __restrict__ uid,
                                           const int32_t* __restrict__ cid, const PairArgs& p, const PlanView& pu,
                                           const PlanView& pv, int blk, int gu, int update, float* smem) {
@@ -212,7 +212,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
         ss = row16_sum(row_dot_partial(raw, raw));
         hat = norm_own ? row_scale(raw, inv_norm(ss)) : raw;
       }
-      lds_store_row_p(sOwn + o * kPDP, q, hat);
+      if (H16) lds_store_row_h(sOwn + o * kPDP, q, hat);   // two fp16 planes per row (devutil.h): the products run on the fp16 pipe
+      else lds_store_row_p(sOwn + o * kPDP, q, hat);
       if (q == 0) {
         sCnt[o] = c;
         sRowReg[o] = c * ss;
@@ -257,7 +258,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     for (int e = 0; e < 4; ++e) {
       Row r = rcur[e];
       if (norm_opp) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
-      lds_store_row_p(sOpp + (g + 32 * e) * kPDP, q, r);
+      if (H16) lds_store_row_h(sOpp + (g + 32 * e) * kPDP, q, r);
+      else lds_store_row_p(sOpp + (g + 32 * e) * kPDP, q, r);
       if (q == 0) {
         sOppKey[g + 32 * e] = kcur[e];
         if (POS) sOppD[g + 32 * e] = dcur[e];
@@ -280,13 +282,24 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       const float4* pb4 = reinterpret_cast<const float4*>(sOpp + (16 * wave + x) * kPDP + 4 * kq);
       float4 fb[8];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) fb[t] = pb4[4 * t];
+      for (int t = 0; t < 8; ++t) fb[t] = H16 ? pb4[(t & 3) * 4 + (t >> 2) * 16] : pb4[4 * t];   // H16: t < 4 hi plane, t >= 4 lo plane
       auto s_one = [&](int mt) -> f32x4 {
         const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kPDP + 4 * kq);
         float4 fa[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fa[t] = pa4[4 * t];
+        for (int t = 0; t < 8; ++t) fa[t] = H16 ? pa4[(t & 3) * 4 + (t >> 2) * 16] : pa4[4 * t];
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (H16) {   // as step_fused.hip wide_body: acc0 hi.hi, acc1 the cross terms (times 2048)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, fa[t]), al = __builtin_bit_cast(f16x8, fa[4 + t]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, fb[t]), bl = __builtin_bit_cast(f16x8, fb[4 + t]);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc1, 0, 0, 0);
+          }
+          return acc0 + acc1 * (1.f / kHLoScale);
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
           NNCF_PMFMA4(fa[t], fb[t], acc0, acc1);
@@ -326,7 +339,15 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
             h = pair_h<LOSS>(an - sc, gamma);
             if (!cvalid || an != an || sKey[i] == okey) h = 0.f;   // an != an: no own position in this slot
           }
-          sG[i * kPGP + j] = h * inv_m;
+          if (H16) {   // dL/dS unscaled (a multiplicity times a sigmoid / 0 or 1) as two fp16 planes; 1 / (b N) at the output
+            _Float16 gh, gl;
+            split_h(h, gh, gl);
+            _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kPGP);
+            pg[j] = gh;
+            pg[128 + j] = gl;
+          } else {
+            sG[i * kPGP + j] = h * inv_m;
+          }
         }
         acc = nxt;
       }
@@ -337,7 +358,27 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       }
     }
     __syncthreads();
-    if (back_wave && update) {
+    if (back_wave && update && H16) {
+      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + 16 * wave + x;
+#pragma unroll
+      for (int t = 0; t < kPNB / 32; ++t) {
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const _Float16* pr = pcol + (size_t)(32 * t + 8 * kq + e) * (2 * kPDP);
+          vh[e] = pr[0];
+          vl[e] = pr[128];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kPGP + 4 * kq);
+          const f16x8 gh = __builtin_bit_cast(f16x8, pg4[4 * t]), gl = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
+          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vl, accD1[mt], 0, 0, 0);
+          accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vh, accD0[mt], 0, 0, 0);
+          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, vh, accD1[mt], 0, 0, 0);
+        }
+      }
+    } else if (back_wave && update) {
       const float* pbv = sOpp + (4 * kq) * kPDP + 16 * wave + x;
 #pragma unroll
       for (int t = 0; t < kPNB / 16; ++t) {
@@ -359,7 +400,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   if (back_wave) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 accD = accD0[mt] + accD1[mt];
+      const f32x4 accD = H16 ? (accD0[mt] + accD1[mt] * (1.f / kHLoScale)) * inv_m : accD0[mt] + accD1[mt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) sOut[(16 * mt + 4 * kq + r) * kPOP + 16 * wave + x] = accD[r];
     }
@@ -396,7 +437,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
 }
 
 // grid = 2 gu workgroups: gu U strips and gu V strips of 16 MT unique rows, alternating (both kinds spread over the XCDs)
-template <int LOSS, bool GROUP, int MT>
+template <int LOSS, bool GROUP, int MT, bool H16>
 __global__ void __launch_bounds__(512) pair_wide_kernel(StepArgs a, const int32_t* __restrict__ uid,
                                                         const int32_t* __restrict__ cid, PairArgs p, PlanView pu,
                                                         PlanView pv, int update, int gu) {
@@ -410,13 +451,13 @@ __global__ void __launch_bounds__(512) pair_wide_kernel(StepArgs a, const int32_
       if (threadIdx.x == 0) p.loss_part[strip] = 0.f;
       return;
     }
-    pair_body<LOSS, GROUP, true, MT>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
+    pair_body<LOSS, GROUP, true, MT, H16>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
   } else {
     if (strip * 16 * MT >= (GROUP ? nseg_v : a.b)) {
       if (GROUP && threadIdx.x == 0) p.loss_part[gu + strip] = 0.f;
       return;
     }
-    pair_body<LOSS, GROUP, false, MT>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
+    pair_body<LOSS, GROUP, false, MT, H16>(a, uid, cid, p, pu, pv, strip, gu, update, pair_smem);
   }
 }
 
@@ -495,11 +536,11 @@ __global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p
 
 namespace {
 
-template <int LOSS, bool GROUP, int MT>
+template <int LOSS, bool GROUP, int MT, bool H16>
 int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
               const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
-  auto kern = pair_wide_kernel<LOSS, GROUP, MT>;
+  auto kern = pair_wide_kernel<LOSS, GROUP, MT, H16>;
   static KernelDeviceState kds;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pair_lds_bytes<MT>(), kds)) return rc;
   {
@@ -523,8 +564,13 @@ int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const P
 template <int LOSS, bool GROUP>
 int launch_pm(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
               const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
-  if (pair_row_tiles(a) == 4) return launch_pw<LOSS, GROUP, 4>(a, uid, cid, p, pu, pv, loss_out, update, stream);
-  return launch_pw<LOSS, GROUP, 2>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+  const char* e = getenv("NNCF_WIDE_F16SPLIT");   // 0: the products on the fp32 matrix pipe (as before round 4; step_fused.hip)
+  const bool h16 = !(e && atoi(e) == 0);
+  if (pair_row_tiles(a) == 4)
+    return h16 ? launch_pw<LOSS, GROUP, 4, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
+               : launch_pw<LOSS, GROUP, 4, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+  return h16 ? launch_pw<LOSS, GROUP, 2, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
+             : launch_pw<LOSS, GROUP, 2, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
 }
 
 }  // namespace
