@@ -42,6 +42,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (nncf_amd/__init__.py says why); before HIP initialises
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense f16 / bf16 MFMA (the guide's ~2.5 PFLOP/s)
+# the large-batch kernels (fused_wide / pair_wide) form their fp32 products on the f16 matrix pipe: x = hi + lo / 2048, three f16
+# MFMAs per 32 k-values with the cross terms in their own fp32 accumulator (csrc/devutil.h split_h; NNCF_WIDE_F16SPLIT=0: fp32 pipe)
+WIDE_KERNELS = ("fused_wide_kernel", "pair_wide_kernel")
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 
@@ -1011,6 +1015,17 @@ def main():
         roofs = [{"kernel": names[0], "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                   "note": "kernel not launched by this configuration"}]
     calibrate_brackets(roofs, elapsed / K * 1e3, prof_n)
+    split_on = os.environ.get("NNCF_WIDE_F16SPLIT", "1") != "0"
+    for r in roofs:
+        if r.get("kernel") in WIDE_KERNELS and r.get("kernel_ms"):
+            # `frac` stays "algorithmic fp32 flop against the fp32-MFMA peak" (comparable across rounds; above 0.64 = 6/8 of it the
+            # fp32 pipe could not have done it at all); what the matrix pipe is actually asked for is named beside it
+            r["pipe"] = ("f16 MFMA: 3 v_mfma_f32_16x16x32_f16 per fp32-equivalent 16x16x32 product (hi.hi + (hi.lo + lo.hi) / 2048), fp32 "
+                         "accumulate" if split_on else "f32 MFMA (NNCF_WIDE_F16SPLIT=0)")
+            if split_on:
+                issued = 4.0 * r["algorithmic_per_launch"]          # 8/6 (S recomputed) x 3 piece products
+                r["issued_f16_tflops"] = issued / (r["kernel_ms"] * 1e-3) / 1e12
+                r["frac_of_f16_mfma_peak"] = r["issued_f16_tflops"] / PEAK_F16_MFMA_TFLOPS
     roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d, roof["kernel"])
 
@@ -1048,7 +1063,10 @@ def main():
         line = {
             "metric": "positive-links/sec (train step)", "value": value, "unit": "positive-links/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "windows": win_stats,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (products of the large-batch kernel: fp16 hi / lo planes on the f16 matrix pipe, fp32 accumulate -- error "
+                      "against float64 below the fp32 MFMA's)" if (roof.get("kernel") in WIDE_KERNELS and split_on) else "f32"),
+            "windows": win_stats,
             "data": ("synthetic config-4-shaped (10M users x 1M items, Zipf links), random-init parameters" if args.large
                      else "synthetic CiteULike-a-shaped (16K users x 17K items x 200K links%s), random-init parameters"
                      % (", item text" if args.model != "mf" else "")),

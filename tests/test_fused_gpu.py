@@ -140,6 +140,50 @@ def test_fused_large_batch(b, d):
     # (pairwise losses at these sizes: tests/test_pair_gpu.py::test_pairwise_large_batch)
 
 
+@pytest.mark.parametrize("scale", [1.0, 300.0, 1e-4])
+def test_wide_kernel_on_the_fp16_pipe_is_as_close_to_float64_as_on_the_fp32_pipe(monkeypatch, scale):
+    """Round 4: the large-batch kernels form their products on the fp16 matrix pipe -- x = hi + lo / 2048, two fp16 planes, three
+    MFMAs per 32 k-values, the cross terms in their own accumulator (devutil.h split_h; NNCF_WIDE_F16SPLIT=0: the fp32 pipe).
+    Same step, both pipes, against the float64 oracle: the loss to 1e-5, the tables to the same tolerance, and the split's error
+    no more than twice the fp32 pipe's (measured: smaller) -- with rows of magnitude 1, 300 (fp16 would overflow at 65,504: the
+    dot products reach 1e6, in fp32 accumulators) and 1e-4 (below fp16's normal range: the planes keep an absolute precision)."""
+    b, d = 4096, 128
+    nu, ni = 2 * b, b
+    errs = {}
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("NNCF_WIDE_F16SPLIT", pipe)
+        conf, eng, orc = _mk("skip-gram", b, d, nu, ni, "mf", "fused", seed=6, lr=0.05)
+        if scale != 1.0:
+            eng.U.mul_(scale)
+            eng.V.mul_(1.0 / scale if scale > 1 else scale)     # scores stay O(1) at scale 300; both sides tiny at 1e-4
+            orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+        U0 = eng.U.cpu().numpy().copy()
+        rs = np.random.RandomState(2)
+        uid = rs.randint(0, nu, b)
+        cid = np.minimum((ni * rs.power(0.6, b)).astype(np.int64), ni - 1)
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (pipe, got, want)
+        step_u = np.abs(orc.U - U0).max()
+        errs[pipe] = (np.abs(eng.U.cpu().numpy() - orc.U).max() / step_u, np.abs(eng.V.cpu().numpy() - orc.V).max())
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-5, atol=1e-5 * max(1.0, scale))
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-5, atol=1e-5)
+    assert errs["1"][0] <= 2 * errs["0"][0] + 1e-7, errs      # error of the step relative to the largest step, fp16 split vs fp32 pipe
+
+
+def test_wide_kernel_fp16_pipe_fails_loudly_outside_its_domain():
+    """|x| >= 65,504 does not fit the hi plane: the score becomes inf / NaN, the loss NaN -- which the trainers' NaN check turns
+    into an abort (never a silently wrong step); NNCF_WIDE_F16SPLIT=0 is the way out for such tables."""
+    b, d = 4096, 32
+    conf, eng, orc = _mk("skip-gram", b, d, 2 * b, b, "mf", "fused", seed=6, lr=0.05)
+    eng.U[0, 0] = 1e5
+    rs = np.random.RandomState(2)
+    uid = rs.randint(0, 2 * b, b)
+    uid[0] = 0
+    got = eng.step_neg_shared(eng.ids(uid), eng.ids(rs.randint(0, b, b))).item()
+    assert got != got or abs(got) == float("inf")
+
+
 @pytest.fixture
 def force_row_tiles():
     """NNCF_FUSED_MT (read per launch by fused_row_tiles): run the large-batch kernel at test sizes"""

@@ -53,6 +53,9 @@ python3 bench.py --large --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_ben
 python3 bench.py --large --device-links 1e9 --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_devicelinks1e9.json
 python3 bench.py --large --scheme original --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_original.json
 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192.json
+# the same with the large-batch kernel's products on the fp32 matrix pipe (round 4 moved them to the f16 pipe: devutil.h split_h)
+NNCF_WIDE_F16SPLIT=0 python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192_fp32pipe.json
+NNCF_WIDE_F16SPLIT=0 python3 bench.py --large --batch 8192 --loss log-loss --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b8192_fp32pipe.json
 python3 bench.py --large --batch 4096 --steps 100 --warmup 10 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b4096.json
 python3 bench.py --large --batch 16384 --steps 50 --warmup 5 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b16384.json
 for l in log-loss max-margin; do for sc in neg_shared group_neg_shared; do
