@@ -482,12 +482,12 @@ def _worker_strong(rank, world, port, loss, ret, bias=None, optimizer="sgd"):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("optimizer", ["adam", "sparse_adam"])
-def test_replicated_global_batch_with_adam_over_two_ranks(optimizer):
+def test_replicated_global_batch_with_adam_over_two_ranks(optimizer, world):
     """pairwise loss + Adam on the strong form: the moment rows travel with the table rows of the replicated protocol (two more
     exchanges per table and step with the same counts), world 2 == the one-device step; Keras' dense Adam: the untouched rows of
     every shard take the zero-gradient step.  ShardedGlobalBatch / _Exchanger are the product's."""
-    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_strong, args=(world, _free_port(), "log-loss", ret, None, optimizer), nprocs=world, join=True)
@@ -503,12 +503,12 @@ def test_replicated_global_batch_with_adam_over_two_ranks(optimizer):
         np.testing.assert_allclose(Vr, orc.V[r * isz:(r + 1) * isz], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("loss,bias", [("skip-gram", "both"), ("log-loss", "user"), ("mse", "item")])
-def test_global_batch_with_an_interaction_bias_over_two_ranks(loss, bias):
+def test_global_batch_with_an_interaction_bias_over_two_ranks(loss, bias, world):
     """InteractionDot bias (interaction_dot.py:62-71,96-107) on the strong form: the replicated protocol with the bias values
     travelling next to the rows (a second exchange with the same counts), world 2 == the one-device step to 1e-5 -- rows, bias
     vectors and losses.  ShardedGlobalBatch / _Exchanger are the product's; the backend restates HipBackend on the oracle."""
-    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker_strong, args=(world, _free_port(), loss, ret, bias), nprocs=world, join=True)
