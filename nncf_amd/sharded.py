@@ -62,7 +62,9 @@ class HipBackend(object):
     `self.U` (local_users rows) and `self.V` (local_items rows).  Pairwise losses (log-loss, max-margin) run the strong form
     REPLICATED (`self.replicated`): the gradient of a column needs sums over all ranks' rows, so every rank fetches the rows
     of ALL b users and b items, runs the whole b x b step on its landing buffers (the one-device kernels) and the owners write
-    their rows back -- no gradient exchange, compute redundant world times: the parity form (csrc/rows.hip)."""
+    their rows back -- no gradient exchange, compute redundant world times: the parity form (csrc/rows.hip).  An
+    `interaction_bias` takes the same road for every loss (the bias values travel with the rows: `self.bu` / `self.bi` are this
+    rank's bias shards, sparse SGD); with an Adam optimiser the moment rows travel with the table rows (`self._adam`)."""
 
     def __init__(self, engine_kwargs, local_users, local_items, device, world, item_shard, item_offset, seed=0, rank=0,
                  mode="weak", user_shard=None, user_offset=0, shared_device=False):
