@@ -341,6 +341,9 @@ __global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs 
   cnn_stamp(a, 0, 6);
 }
 
+// workgroups of cnn_stats / cnn_merge: at least 64 slots each, at most kCnnMergeWG
+inline int cnn_merge_grid(int m) { return m <= 128 ? 1 : (m / 64 < kCnnMergeWG ? m / 64 : kCnnMergeWG); }
+
 // column totals of per-slot partials [n][2][128] in slot order (1024 threads: 8 slot groups x 128)
 __device__ __forceinline__ void merge_slot_partials(const float* part, int n, float* sRed, float& t1, float& t2) {
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
@@ -398,11 +401,36 @@ __device__ __forceinline__ void bn1_publish(const TowerArgs& a, int c, float mu,
   a.cnn.st1[512 + c] = add;
 }
 
+// grid = 1, or several workgroups over contiguous slot ranges: each leaves its partial totals, the last to arrive
+// (last_block_arrives: device-scope counter, re-armed) adds them in workgroup order and finishes -- the result does not depend on who
+// is last.  One workgroup reads `original`'s 2,700 x 1 KB at one compute unit's ~25 GB/s; 32 read in parallel.
+__device__ __forceinline__ bool merge_ranges(const TowerArgs& a, int which, float& t1, float& t2) {
+  if (gridDim.x == 1) return true;
+  const int c = threadIdx.x;
+  float* mp = a.cnn.mpart + (size_t)which * kCnnMergeWG * 256;
+  if (c < 128) {
+    mp[blockIdx.x * 256 + c] = t1;
+    mp[blockIdx.x * 256 + 128 + c] = t2;
+  }
+  if (!last_block_arrives(a.cnn.mcnt + which)) return false;
+  t1 = 0.f;
+  t2 = 0.f;
+  if (c < 128) {
+    for (int w = 0; w < (int)gridDim.x; ++w) {
+      t1 += mp[w * 256 + c];
+      t2 += mp[w * 256 + 128 + c];
+    }
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int nv = valid_rows(a), c = threadIdx.x;
+  const int ch = (nv + (int)gridDim.x - 1) / (int)gridDim.x, lo = min(nv, (int)blockIdx.x * ch), hi = min(nv, lo + ch);
   float t1, t2;
-  merge_slot_partials(a.cnn.part1, nv, sRed, t1, t2);
+  merge_slot_partials(a.cnn.part1 + (int64_t)lo * 256, hi - lo, sRed, t1, t2);
+  if (!merge_ranges(a, 0, t1, t2)) return;
   if (c < 128) {
     float mu, inv, var, mul, add;
     bn1_from_totals(a, nv, c, t1, t2, mu, inv, var, mul, add);
@@ -705,16 +733,17 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   __shared__ float sRed[8 * 2 * 128];
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7, n = valid_rows(a), F = a.cnn.F;
   const float rL = a.cnn.pool_max ? 1.f : 1.f / (float)a.L;   // max pooling: the one position that supplied the maximum, no 1/L
+  const int ch = (n + (int)gridDim.x - 1) / (int)gridDim.x, lo = min(n, (int)blockIdx.x * ch), hi = min(n, lo + ch);   // this workgroup's slots
   float a1 = 0.f, a2 = 0.f;
   if (c < F) {
-    for (int s0 = g; s0 < n; s0 += 8 * 16) {   // 16 triples of loads in flight
+    for (int s0 = lo + g; s0 < hi; s0 += 8 * 16) {   // 16 triples of loads in flight
       float u1[16], u2[16], dv[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int s = s0 + 8 * e;
-        u1[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + c] : 0.f;
-        u2[e] = s < n ? a.cnn.bpart[(int64_t)s * 256 + 128 + c] : 0.f;
-        dv[e] = s < n ? a.dh[(int64_t)s * a.hd + a.cnn.c_off + c] * rL : 0.f;
+        u1[e] = s < hi ? a.cnn.bpart[(int64_t)s * 256 + c] : 0.f;
+        u2[e] = s < hi ? a.cnn.bpart[(int64_t)s * 256 + 128 + c] : 0.f;
+        dv[e] = s < hi ? a.dh[(int64_t)s * a.hd + a.cnn.c_off + c] * rL : 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -726,12 +755,15 @@ __global__ void __launch_bounds__(1024) cnn_merge_kernel(TowerArgs a) {
   sRed[(g * 2 + 0) * 128 + c] = a1;
   sRed[(g * 2 + 1) * 128 + c] = a2;
   __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
   if (threadIdx.x < 128) {
-    float t1 = 0.f, t2 = 0.f;
     for (int gg = 0; gg < 8; ++gg) {
       t1 += sRed[(gg * 2 + 0) * 128 + c];
       t2 += sRed[(gg * 2 + 1) * 128 + c];
     }
+  }
+  if (!merge_ranges(a, 1, t1, t2)) return;
+  if (threadIdx.x < 128) {
     a.cnn.st1[640 + threadIdx.x] = t1;  // sum da        (= dbeta1)
     a.cnn.st1[768 + threadIdx.x] = t2;  // sum da*xhat   (= dgamma1)
   }
@@ -1167,6 +1199,8 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
     a.part1 = c.take<float>(cap * 256);
     a.st1 = c.take<float>(7 * 128);
     a.bpart = c.take<float>(cap * 256);
+    a.mpart = c.take<float>(2 * kCnnMergeWG * 256);
+    a.mcnt = c.take<unsigned>(4);
     a.amax = c.take<uint8_t>(cap * 128);
     a.gWpart = c.take<float>(cap * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
     a.gbpart = c.take<float>(cap * 128);
@@ -1245,7 +1279,7 @@ static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   if (a.train && !a.cnn.fold) {
     ProfScope _ps("cnn_stats_kernel", st);
-    hipLaunchKernelGGL(cnn_stats_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(cnn_stats_kernel, dim3(cnn_merge_grid(a.m)), dim3(1024), 0, st, a);
   }
   {
     ProfScope _ps("cnn_pool_dense_kernel", st);
@@ -1290,7 +1324,7 @@ static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   if (int rc = set_lds(bwd_fn, lds)) return rc;
   if (!a.cnn.fold) {
     ProfScope _ps("cnn_merge_kernel", st);
-    hipLaunchKernelGGL(cnn_merge_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(cnn_merge_kernel, dim3(cnn_merge_grid(a.m)), dim3(1024), 0, st, a);
   }
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);

@@ -32,6 +32,8 @@ struct CnnArgs {
   float* part1;              // [m][2][128]   per-slot sums of (y-b), (y-b)^2
   float* st1;                // 7 x 128: mu, inv, var, mul, add, sum da, sum da*xhat
   float* bpart;              // [m][2][128]
+  float* mpart;              // [2][kCnnMergeWG][2][128] partial totals of the multi-workgroup cnn_stats / cnn_merge (blocks above
+  unsigned* mcnt;            //   kCnnFoldRows rows) and their two arrival counters (zero between launches)
   uint8_t* amax;             // [m][128] max pooling: the position that supplied each filter's maximum
   int pool_max;              // poolings = ['max'] (cnn_model.py:107-109) over the whole length instead of the average
   float* gWpart;             // [ceil(fl*wd*F / 64)][cap][64]: per-slot dWk blocks, element-group major
@@ -53,6 +55,8 @@ struct CnnArgs {
   long long gexp_off;        // this bank's [Wk | bc, g1, b1 (128 each)] block in the flat gradient, from the start of the conv section
 };
 constexpr int kCnnFoldRows = 512;
+constexpr int kCnnMergeWG = 32;   // workgroups of cnn_stats / cnn_merge on such blocks: one compute unit reads 2,700 slots' partials at
+                                  // ~25 GB/s (122 us); 32 read them in parallel and the last to arrive adds the 32 rows
 struct CnnBanks {             // all banks of a tower (kernels that walk the whole flat gradient)
   int nb;
   CnnArgs b[4];
