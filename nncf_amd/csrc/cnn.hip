@@ -415,10 +415,18 @@ __device__ __forceinline__ bool merge_ranges(const TowerArgs& a, int which, floa
   if (!last_block_arrives(a.cnn.mcnt + which)) return false;
   t1 = 0.f;
   t2 = 0.f;
-  if (c < 128) {
-    for (int w = 0; w < (int)gridDim.x; ++w) {
-      t1 += mp[w * 256 + c];
-      t2 += mp[w * 256 + 128 + c];
+  if (c < 128) {   // all rows requested at once (one trip, not gridDim.x), added in workgroup order
+    float u1[kCnnMergeWG], u2[kCnnMergeWG];
+#pragma unroll
+    for (int w = 0; w < kCnnMergeWG; ++w) {
+      const int ww = min(w, (int)gridDim.x - 1);
+      u1[w] = mp[ww * 256 + c];
+      u2[w] = mp[ww * 256 + 128 + c];
+    }
+#pragma unroll
+    for (int w = 0; w < kCnnMergeWG; ++w) {
+      t1 += w < (int)gridDim.x ? u1[w] : 0.f;
+      t2 += w < (int)gridDim.x ? u2[w] : 0.f;
     }
   }
   return true;
