@@ -403,6 +403,49 @@ def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop, poo
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("pool,drop", [("average", False), ("max", True)])
+def test_cnn_embedding_original_block_above_512_rows_matches_oracle(pool, drop):
+    """train_scheme = original with more than 512 unique items per step: the block keeps the cnn_stats / cnn_merge launches,
+    each on several workgroups over slot ranges whose last arriver adds the per-workgroup rows in workgroup order (cnn.hip,
+    merge_ranges).  Parity with the float64 CnnTowerOracle, and the same bits from a second model run on the same
+    inputs -- whichever workgroup happens to arrive last."""
+    data = synthetic.make_citeulike_like(users=300, items=1500, train_links=6000, seed=8, content_len=20, vocab=150)
+    conf = _conf_cnn("skip-gram", "original", b=256, k=3, wdrop=0.3 if drop else 0.0, cdrop=0.2 if drop else 0.0)
+    conf.poolings = [pool]
+    runs = []
+    for rep in range(2):
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "cnn_embedding", seed=2)
+        head, tw = md["model"], md["model"].core.tower
+        orc = to = None
+        if rep == 0:
+            orc, to = _oracle_cnn(conf, md, data, dtype=np.float64)   # ~9,000 terms meet in the pad word's row: the float32 oracle is
+            to.conv_pooling = pool                                   # 1e-4 from the float64 one there, the kernels 4e-8
+        b, k = conf.batch_size_p, conf.num_negatives
+        rs = np.random.RandomState(7)
+        for step in range(2):
+            bt = data["train"][rs.choice(len(data["train"]), b, replace=False)]
+            u, c, y = so.assemble_original(bt, rs.randint(0, 1500, b * k), "skip-gram")
+            assert len(np.unique(c)) > 512
+            if drop and rep == 0:
+                orc.row_scale = tw.dropout_scale(step).cpu().numpy()
+                to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy()
+            got = head.train_on_batch([u, c], [y])
+            if rep:
+                continue
+            want = orc.step_original(u, c, y)
+            assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+            np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6)
+            for name in CNN_PARAMS:
+                if name == "bc":
+                    np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), atol=1e-5, err_msg=name)
+                    continue
+                np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=2e-5, atol=2e-6,
+                                           err_msg="%s step %d" % (name, step))
+        runs.append({n: getattr(tw, n).clone() for n in CNN_PARAMS})
+    for n in CNN_PARAMS:
+        assert torch.equal(runs[0][n], runs[1][n]), n
+
+
 def test_cnn_embedding_citeulike_tile_shape():
     """L = 200, word_dim = filters = 100: the shape whose conv forward runs the unmasked <7, 7> tile
     specialisation (two workgroups per item, 7 row tiles x 7 K groups each) and whose backward uses
