@@ -987,6 +987,9 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
             _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kFGP);
             pg[j] = gh;
             pg[128 + j] = gl;
+            // mse's dL/dS grows with the score (skip-gram's is a multiplicity times a sigmoid): past fp16's range the plane holds
+            // inf and the tables would turn NaN behind a finite loss -- inf - inf makes THIS step's loss NaN instead (0 otherwise)
+            if (LOSS != NNCF_LOSS_SKIP_GRAM) l += (float)gh - (float)gh;
           } else {
             sG[i * kFGP + j] = h * inv_b;
           }

@@ -193,3 +193,46 @@ def test_pair_strips_epoch_runner_equals_step_by_step(force_row_tiles):
     l2 = np.array([e2.step_neg_shared(ua[t * b:(t + 1) * b], ca[t * b:(t + 1) * b]).item() for t in range(steps)])
     assert np.array_equal(l1, l2.astype(np.float32))
     assert torch.equal(e1.U, e2.U) and torch.equal(e1.V, e2.V)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "16"))))
+def test_pair_strips_random_shapes_terminate_and_match(force_row_tiles, seed):
+    """Random small shapes through the strip form of the pairwise losses -- tiny catalogues (most strips empty), one-user
+    batches, both schemes and losses, 'mf' and 'content', 1 / 2 / 4 row tiles, row scales from 1e-3 to 30 (the large-batch
+    kernels split their operands into two fp16 planes: devutil.h split_h) -- two steps each against the float64 oracle.
+    NNCF_SOAK_SEEDS=<n> widens the sweep (tools/soak.sh)."""
+    rs = np.random.RandomState(7000 + seed)
+    b = int(rs.choice([32, 64, 96, 128, 160, 256, 512]))
+    d = int(rs.choice([4, 20, 64, 100, 128]))
+    nu = int(rs.choice([1, 2, 7, 40, 400, 3000]))
+    ni = int(rs.choice([2, 5, 33, 300, 2000]))
+    group = bool(rs.randint(2))
+    loss = str(rs.choice(["log-loss", "max-margin"]))
+    model = str(rs.choice(["mf", "content"]))
+    scale = float(rs.choice([1e-3, 0.1, 1.0, 1.0, 30.0]))
+    if model == "content":
+        scale = max(scale, 0.1)   # the backward of x / |x| multiplies fp32's rounding by 1 / |x|: rows of 1e-3 leave nothing to compare
+    force_row_tiles(int(rs.choice([1, 2, 4])))
+    conf, eng, orc = _mk(loss, b, d, nu, ni, model, "pairwide", seed=seed)
+    if scale != 1.0:
+        eng.U.mul_(scale)
+        eng.V.mul_(scale)
+        orc.U *= scale
+        orc.V *= scale
+    for step in range(2):
+        uid = rs.randint(0, nu, b)
+        cid = np.repeat(rs.randint(0, ni, b // 4), 4) if group else rs.randint(0, ni, b)
+        if len(np.unique(cid)) < 2:          # the pairwise losses compare a positive with the OTHER items' scores
+            continue
+        if group:
+            want = orc.step_group_neg_shared(uid, cid)
+            got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        else:
+            want = orc.step_neg_shared(uid, cid)
+            got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+        assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (step, got, want)
+        # absolute term: 1e-5 of the rows' scale, times 1 / |x| of the smallest normalised rows (|x| ~ 0.5 scale sqrt(d / 3) at init)
+        sc = max(1.0, scale) * max(1.0, 1.0 / (0.5 * scale * np.sqrt(d / 3.0)))
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=1e-5 * sc)
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=1e-5 * sc)

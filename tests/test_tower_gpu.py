@@ -1,5 +1,7 @@
 """GPU: model_choice = basic_embedding (mean-pool text tower above the step kernels) against the
 oracle: per-step loss, every parameter after the update, inference-mode scores."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1031,7 +1033,7 @@ def test_cnn_embedding_default_preset_filter_bank(text_data, scheme, loss, drop,
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "10"))))
 def test_text_tower_random_small_batches_terminate_and_match(text_data, seed):
     """basic_embedding through the one-launch step with very few unique items (1 ... 40 of a 64-row batch: most item
     strips empty, BatchNorm over a handful of rows) and with users repeated: every case finishes (the in-launch
