@@ -1,6 +1,8 @@
 """GPU: the HIP step kernels (through the C ABI) against the numpy oracle on identical inputs.
 Tolerances: loss 1e-5 relative (north_star), table rows 1e-5 relative / 2e-6 absolute after the
 update (fp32 summation order differs between MFMA/shuffle reductions and numpy)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -504,3 +506,50 @@ def test_sparse_adam_as_written_matches_oracle(scheme):
         np.testing.assert_allclose(eng.opt_state["mU"].cpu().numpy(), orc.slot_u.m, rtol=2e-4, atol=1e-7)
         np.testing.assert_allclose(eng.opt_state["vV"].cpu().numpy(), orc.slot_v.v, rtol=2e-4, atol=1e-9)
     assert np.abs(orc.U - sum_orc.U).max() > 1e-3      # the two semantics really differ on this data
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "16"))))
+def test_random_shapes_all_schemes_and_losses_match(seed):
+    """Random shapes through the three schemes' default kernel paths (no path forced) -- every loss, 'mf' and 'content', b = 1 .. 512
+    (odd sizes under `original`), k = 1 .. 10, d = 4 .. 128, catalogues from two rows (everything a duplicate) to thousands -- two steps each
+    against the float64 oracle.  NNCF_SOAK_SEEDS=<n> widens the sweep (tools/soak.sh)."""
+    rs = np.random.RandomState(9000 + seed)
+    scheme = str(rs.choice(["original", "neg_shared", "group_neg_shared"]))
+    loss = str(rs.choice(LOSSES))
+    model = str(rs.choice(["mf", "content"]))
+    d = int(rs.choice([4, 20, 50, 64, 100, 128]))
+    nu = int(rs.choice([1, 2, 7, 40, 400, 3000]))
+    ni = int(rs.choice([2, 5, 33, 300, 2000]))
+    if scheme == "original":
+        b, k = int(rs.choice([1, 3, 17, 64, 100, 256, 512])), int(rs.choice([1, 3, 5, 10]))
+    else:
+        b, k = int(rs.choice([32, 64, 96, 160, 256, 512])), 0   # the shared-negative schemes take multiples of 32 (anything else: ValueError)
+    gamma = {"max-margin": 0.1, "log-loss": 10.}.get(loss)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=1e-3, learn_rate=0.05, model_choice=model)
+    eng = Engine(nu, ni, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    for step in range(2):
+        pu, pi = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        if scheme == "original":
+            uid, cid, y = so.assemble_original(np.stack([pu, pi, np.ones(b, dtype=int)], 1), rs.randint(0, ni, b * k), loss)
+            want = orc.step_original(uid, cid, y)
+            got = eng.step_original(eng.ids(uid[:b]), eng.ids(cid)).item()
+        elif scheme == "neg_shared":
+            if len(np.unique(pi)) < 2:
+                continue
+            want = orc.step_neg_shared(pu, pi)
+            got = eng.step_neg_shared(eng.ids(pu), eng.ids(pi)).item()
+        else:
+            pi = np.repeat(pi[:b // 4], 4)
+            if len(np.unique(pi)) < 2:
+                continue
+            want = orc.step_group_neg_shared(pu, pi)
+            got = eng.step_group_neg_shared(eng.ids(pu), eng.ids(pi)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)), (step, scheme, loss, model, b, k, d, nu, ni, got, want)
+        # absolute term: the backward of x / |x| multiplies fp32's rounding by 1 / |x| (|x| ~ 0.5 sqrt(d / 3) at init)
+        amp = max(1.0, 1.0 / (0.5 * np.sqrt(d / 3.0)))
+        amp *= max(1.0, b * (1 + k) / (512.0 * min(nu, ni)))   # ... and grows with the terms that meet in one row (5,632 links onto 2 rows)
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6 * amp, err_msg=str((scheme, loss, model, b, k, d, nu, ni)))
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=5e-6 * amp, err_msg=str((scheme, loss, model, b, k, d, nu, ni)))
