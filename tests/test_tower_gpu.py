@@ -405,6 +405,54 @@ def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop, poo
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "12"))))
+def test_cnn_tower_random_small_batches_terminate_and_match(text_data, seed):
+    """cnn_embedding with random filter length / count, pooling, dropouts, scheme and loss over batches with very few unique items
+    (1 ... 40 of a 64-row batch) and repeated users: every case finishes and matches the float64 CnnTowerOracle."""
+    rs = np.random.RandomState(800 + seed)
+    scheme = str(rs.choice(["neg_shared", "group_neg_shared", "original"]))
+    loss = str(rs.choice(["skip-gram", "mse", "log-loss", "max-margin"]))
+    fl, F = int(rs.choice([1, 3, 5])), int(rs.choice([4, 20, 33]))
+    pool, drop = str(rs.choice(["average", "max"])), bool(rs.randint(2))
+    conf = _conf_cnn(loss, scheme, fl=fl, F=F, wdrop=0.3 if drop else 0.0, cdrop=0.2 if drop else 0.0)
+    conf.poolings = [pool]
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "cnn_embedding", seed=2)
+    orc, to = _oracle_cnn(conf, md, text_data, dtype=np.float64)
+    to.conv_pooling = pool
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    b, k = conf.batch_size_p, conf.num_negatives
+    n_items, n_users = int(rs.choice([2, 3, 5, 17, 40])), int(rs.choice([1, 3, 50, 300]))
+    pool_items = rs.choice(260, n_items, replace=False)
+    for step in range(2):
+        u = rs.randint(0, n_users, b)
+        c = pool_items[rs.randint(0, n_items, b)]
+        if drop:
+            orc.row_scale = tw.dropout_scale(step).cpu().numpy()
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy()
+        if scheme == "original":
+            u, c, y = so.assemble_original(np.stack([u, c, np.ones(b, dtype=int)], 1), pool_items[rs.randint(0, n_items, b * k)], loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "group_neg_shared":
+            c = np.repeat(c[::4], 4)
+            y = np.ones(b)
+            if len(np.unique(c)) < 2:
+                continue
+            want = orc.step_group_neg_shared(u, c)
+        else:
+            y = np.ones(b)
+            if len(np.unique(c)) < 2:
+                continue
+            want = orc.step_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        info = (scheme, loss, fl, F, pool, drop, n_items, n_users, step)
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (info, got, want)
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5, err_msg=str(info))
+        for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4, err_msg=str((name,) + info))
+
+
 @pytest.mark.parametrize("pool,drop", [("average", False), ("max", True)])
 def test_cnn_embedding_original_block_above_512_rows_matches_oracle(pool, drop):
     """train_scheme = original with more than 512 unique items per step: the block keeps the cnn_stats / cnn_merge launches,
