@@ -409,7 +409,8 @@ def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop, poo
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "12"))))
 def test_cnn_tower_random_small_batches_terminate_and_match(text_data, seed):
     """cnn_embedding with random filter length / count, pooling, dropouts, scheme and loss over batches with very few unique items
-    (1 ... 40 of a 64-row batch) and repeated users: every case finishes and matches the float64 CnnTowerOracle."""
+    (3 ... 40 of a 64-row batch) and repeated users: every case finishes and matches the float64 CnnTowerOracle -- to the fixed
+    tolerance plus four times the float32 oracle's own distance from the float64 one (what fp32 can hold in that case)."""
     rs = np.random.RandomState(800 + seed)
     scheme = str(rs.choice(["neg_shared", "group_neg_shared", "original"]))
     loss = str(rs.choice(["skip-gram", "mse", "log-loss", "max-margin"]))
@@ -419,38 +420,54 @@ def test_cnn_tower_random_small_batches_terminate_and_match(text_data, seed):
     conf.poolings = [pool]
     md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "cnn_embedding", seed=2)
     orc, to = _oracle_cnn(conf, md, text_data, dtype=np.float64)
-    to.conv_pooling = pool
+    o32, t32 = _oracle_cnn(conf, md, text_data, dtype=np.float32)   # its distance from the float64 one = what fp32 can hold in this case
+    to.conv_pooling = t32.conv_pooling = pool
     head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
     tw = head.core.tower
     b, k = conf.batch_size_p, conf.num_negatives
-    n_items, n_users = int(rs.choice([2, 3, 5, 17, 40])), int(rs.choice([1, 3, 50, 300]))
+    # three unique items and up: BatchNorm over TWO rows leaves +-1 and a gradient that is rounding noise times 1 / sigma (and a max
+    # pooling whose winner flips on it) -- 5 of 400 such cases end 3e-5 .. 4e-4 from the float64 oracle after the second step
+    n_items, n_users = int(rs.choice([3, 5, 17, 40])), int(rs.choice([1, 3, 50, 300]))
     pool_items = rs.choice(260, n_items, replace=False)
     for step in range(2):
         u = rs.randint(0, n_users, b)
         c = pool_items[rs.randint(0, n_items, b)]
         if drop:
-            orc.row_scale = tw.dropout_scale(step).cpu().numpy()
-            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy()
+            orc.row_scale = o32.row_scale = tw.dropout_scale(step).cpu().numpy()
+            to.conv_mask = t32.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy()
         if scheme == "original":
             u, c, y = so.assemble_original(np.stack([u, c, np.ones(b, dtype=int)], 1), pool_items[rs.randint(0, n_items, b * k)], loss)
-            want = orc.step_original(u, c, y)
+            want, w32 = orc.step_original(u, c, y), o32.step_original(u, c, y)
         elif scheme == "group_neg_shared":
             c = np.repeat(c[::4], 4)
             y = np.ones(b)
             if len(np.unique(c)) < 2:
                 continue
-            want = orc.step_group_neg_shared(u, c)
+            want, w32 = orc.step_group_neg_shared(u, c), o32.step_group_neg_shared(u, c)
         else:
             y = np.ones(b)
             if len(np.unique(c)) < 2:
                 continue
-            want = orc.step_neg_shared(u, c)
+            want, w32 = orc.step_neg_shared(u, c), o32.step_neg_shared(u, c)
         got = head.train_on_batch([u, c], [y])
         info = (scheme, loss, fl, F, pool, drop, n_items, n_users, step)
-        assert abs(got - want) <= 2e-5 * max(1, abs(want)), (info, got, want)
-        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5, err_msg=str(info))
+        assert np.isfinite(got), info
+        # a pre-activation within rounding of 0 (or two pooled maxima within rounding of each other) makes the backward's 0 / 1 mask a
+        # coin toss at fp32 -- seed 620: |pre| = 1.5e-6 in one of 1,440 places, that filter's gradient then differs by O(1e-2): stop there
+        pre = to.cache["y1"]
+        if np.abs(pre).min() < 2e-5:
+            break
+        if pool == "max":
+            act = np.sort(np.maximum(pre, 0) * (to.cache["mask"] if to.cache["mask"] is not None else 1.0), axis=1)
+            gap = act[:, -1] - act[:, -2]
+            if ((gap > 0) & (gap < 2e-5)).any():
+                break
+        assert abs(got - want) <= 2e-5 * max(1, abs(want)) + 4 * abs(w32 - want), (info, got, want)
+        far = lambda a32, a64: 4 * float(np.abs(np.asarray(a32, dtype=np.float64) - a64).max())   # noqa: E731
+        np.testing.assert_allclose(head.engine.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5 + far(o32.U, orc.U), err_msg=str(info))
         for name in ("W", "Wc", "g1", "b1", "Wd", "gamma", "beta"):
-            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3, atol=1e-4, err_msg=str((name,) + info))
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=1e-3,
+                                       atol=1e-4 + far(getattr(t32, name), getattr(to, name)), err_msg=str((name,) + info))
 
 
 @pytest.mark.parametrize("pool,drop", [("average", False), ("max", True)])
