@@ -553,3 +553,77 @@ def test_random_shapes_all_schemes_and_losses_match(seed):
         amp *= max(1.0, b * (1 + k) / (512.0 * min(nu, ni)))   # ... and grows with the terms that meet in one row (5,632 links onto 2 rows)
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=5e-6 * amp, err_msg=str((scheme, loss, model, b, k, d, nu, ni)))
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=5e-6 * amp, err_msg=str((scheme, loss, model, b, k, d, nu, ni)))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "16"))))
+def test_random_shapes_with_interaction_bias_and_adam_match(seed):
+    """The sweep above with the options that ride on the step kernels: interaction_bias = 'both' (interaction_dot.py:62-71), Keras
+    Adam and the lazy-sparse Adam (utils/optimizer.py:108-147) -- three steps each (the moments matter from the second on).  Tolerance:
+    the fixed one plus four times the float32 oracle's own distance from the float64 one (Adam divides by sqrt(v): where v ~ g^2 a
+    rounding-sized gradient difference is a finite step)."""
+    rs = np.random.RandomState(11000 + seed)
+    scheme = str(rs.choice(["original", "neg_shared", "group_neg_shared"]))
+    loss = str(rs.choice(LOSSES))
+    bias = "both" if rs.randint(2) else None
+    opt = str(rs.choice(["sgd", "adam", "sparse_adam"]))
+    if bias and opt != "sgd" and scheme != "original":
+        opt = "sgd"   # the shared-negative schemes take Adam or an interaction bias
+    d = int(rs.choice([4, 20, 50, 64, 100, 128]))
+    nu = int(rs.choice([1, 2, 7, 40, 400, 3000]))
+    ni = int(rs.choice([2, 5, 33, 300, 2000]))
+    if scheme == "original":
+        b, k = int(rs.choice([1, 3, 17, 64, 100, 256, 512])), int(rs.choice([1, 3, 5, 10]))
+    else:
+        b, k = int(rs.choice([32, 64, 96, 160, 256, 512])), 0
+    gamma = {"max-margin": 0.1, "log-loss": 10.}.get(loss)
+    kw = dict(interaction_bias=bias) if bias else {}
+    conf = so.OracleConf(batch_size_p=b, num_negatives=k, loss=loss, loss_gamma=gamma, u_reg=1e-3, learn_rate=0.05 if opt == "sgd" else 0.01,
+                         model_choice="mf", optimizer=opt, **kw)
+    eng = Engine(nu, ni, d, b, k, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5, **kw)
+    if opt != "sgd":
+        eng.set_optimizer(opt)
+    o64 = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    o32 = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    if bias:
+        eng.bias["ub"].copy_(torch.as_tensor(rs.randn(nu).astype(np.float32) * 0.2))
+        eng.bias["cb"].copy_(torch.as_tensor(rs.randn(ni).astype(np.float32) * 0.2))
+        for o in (o64, o32):
+            o.ub[:] = eng.bias["ub"].cpu().numpy()
+            o.cb[:] = eng.bias["cb"].cpu().numpy()
+    info = (scheme, loss, bias, opt, b, k, d, nu, ni)
+    for step in range(3):
+        pu, pi = rs.randint(0, nu, b), rs.randint(0, ni, b)
+        if scheme == "original":
+            uid, cid, y = so.assemble_original(np.stack([pu, pi, np.ones(b, dtype=int)], 1), rs.randint(0, ni, b * k), loss)
+            want, w32 = o64.step_original(uid, cid, y), o32.step_original(uid, cid, y)
+            got = eng.step_original(eng.ids(uid[:b]), eng.ids(cid)).item()
+        elif scheme == "neg_shared":
+            if len(np.unique(pi)) < 2:
+                continue
+            want, w32 = o64.step_neg_shared(pu, pi), o32.step_neg_shared(pu, pi)
+            got = eng.step_neg_shared(eng.ids(pu), eng.ids(pi)).item()
+        else:
+            pi = np.repeat(pi[:b // 4], 4)
+            if len(np.unique(pi)) < 2:
+                continue
+            want, w32 = o64.step_group_neg_shared(pu, pi), o32.step_group_neg_shared(pu, pi)
+            got = eng.step_group_neg_shared(eng.ids(pu), eng.ids(pi)).item()
+        assert abs(got - want) <= RTOL_LOSS * max(1.0, abs(want)) + 4 * abs(w32 - want), (step, info, got, want)
+        far = lambda a32, a64: 4 * float(np.abs(np.asarray(a32, dtype=np.float64) - a64).max())   # noqa: E731
+        base = 5e-6 * max(1.0, 1.0 / (0.5 * np.sqrt(d / 3.0))) * max(1.0, b * (1 + k) / (512.0 * min(nu, ni)))
+        for got_t, w64, w32_t in ((eng.U, o64.U, o32.U), (eng.V, o64.V, o32.V)):
+            g = got_t.cpu().numpy()
+            bad = np.abs(g - w64) > base + far(w32_t, w64) + 2e-5 * np.abs(w64)
+            if opt != "sgd":
+                # Adam's step is lr g / (sqrt(v) + 1e-8): an element whose gradient is itself rounding noise (|g| ~ 1e-8) moves by a
+                # fraction of lr that no two summation orders agree on -- 1 element of 2e5 in 3 of 1,500 sweep cases; a hinge at its
+                # kink (max-margin) does the same to one row: allow a row's worth, each within lr (+ the float32 oracle's own distance)
+                assert bad.sum() <= max(d, int(1e-5 * bad.size)) and np.abs(g - w64).max() <= conf.learn_rate + far(w32_t, w64), \
+                    ((step,) + info, int(bad.sum()), float(np.abs(g - w64).max()))
+            else:
+                assert not bad.any(), ((step,) + info, int(bad.sum()), float(np.abs(g - w64).max()))
+        if bias:
+            np.testing.assert_allclose(eng.bias["ub"].cpu().numpy(), o64.ub, rtol=2e-5, atol=base + far(o32.ub, o64.ub), err_msg=str((step,) + info))
+            np.testing.assert_allclose(eng.bias["cb"].cpu().numpy(), o64.cb, rtol=2e-5, atol=base + far(o32.cb, o64.cb), err_msg=str((step,) + info))
