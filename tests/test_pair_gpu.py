@@ -236,3 +236,42 @@ def test_pair_strips_random_shapes_terminate_and_match(force_row_tiles, seed):
         sc = max(1.0, scale) * max(1.0, 1.0 / (0.5 * scale * np.sqrt(d / 3.0)))
         np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=1e-5 * sc)
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=1e-5 * sc)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_LARGE", "4"))))
+def test_large_batch_random_shapes_match(seed):
+    """The large-batch regime on its default paths (b > 2,048: fused_wide / pair_wide, products on the f16 pipe): random b (ragged
+    strips and stages included), d, loss (all four), scheme, 'mf' / 'content', row scale, and catalogues from 5 rows (every row a
+    heavy duplicate: multiplicities in the hundreds) to 3 b -- one step against the float64 oracle.  NNCF_SOAK_LARGE widens it."""
+    rs = np.random.RandomState(15000 + seed)
+    b = int(rs.choice([2080, 2560, 4096, 4128, 5120, 8192]))
+    d = int(rs.choice([16, 32, 64, 100, 128]))
+    loss = str(rs.choice(["skip-gram", "mse", "log-loss", "max-margin"]))
+    group = bool(rs.randint(2))
+    model = str(rs.choice(["mf", "content"]))
+    nu = int(rs.choice([5, 300, 3 * b]))
+    ni = int(rs.choice([5, 300, 2 * b]))
+    scale = float(rs.choice([0.1, 1.0, 1.0, 4.0])) if loss != "mse" else 1.0
+    gamma = GAMMA.get(loss, 10.)
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=gamma, u_reg=1e-3, learn_rate=0.05, model_choice=model,
+                         neg_loss_weight=8. if loss == "mse" else 128.)
+    eng = Engine(nu, ni, d, b, 0, loss, conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                 conf.normalize_user, conf.normalize_item, seed=seed, init_scale=0.5)
+    eng.U.mul_(scale)
+    eng.V.mul_(scale)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    uid = rs.randint(0, nu, b)
+    cid = np.repeat(rs.randint(0, ni, b // 4), 4) if group else rs.randint(0, ni, b)
+    info = (b, d, loss, group, model, nu, ni, scale)
+    if group:
+        want = orc.step_group_neg_shared(uid, cid)
+        got = eng.step_group_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    else:
+        want = orc.step_neg_shared(uid, cid)
+        got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (info, got, want)
+    # absolute term: 1e-5 of the rows' scale; x / |x|'s backward multiplies fp32's rounding by 1 / |x|; b / min(nu, ni) terms meet in a row
+    amp = max(1.0, scale) * max(1.0, 1.0 / (0.5 * scale * np.sqrt(d / 3.0))) * max(1.0, b / (512.0 * min(nu, ni)))
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=1e-5 * amp, err_msg=str(info))
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=1e-5 * amp, err_msg=str(info))
