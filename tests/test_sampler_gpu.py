@@ -1,5 +1,6 @@
 """GPU: the HIP sampler against the reference's golden streams and the oracle (bit-exact)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -258,3 +259,35 @@ def test_device_sample_with_negs_equals_its_oracle_and_the_reference_semantics(n
     gs = GroupSampler(train, group_by="item", chop=2, neg_dist="uniform", neg_sign=0)
     x = np.array([3 * 2 * gs.p_n_div_p_d[g] for g in sorted(gs.p_n_div_p_d)])
     assert np.any(np.abs(x - np.round(x)) > 0.05)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SAMPLER", "12"))))
+def test_random_distributions_powers_and_batch_sizes_are_bit_exact(seed):
+    """Random vocabularies (2 ... 60,000 entries; counts that are uniform, Zipf-like, mostly zero, one giant entry), powers
+    0 / 0.5 / 0.75 / 1, start states and ragged batch sizes: boundaries, every draw and the state after, bit for bit against
+    the oracle (sampler.h's table + LCG).  NNCF_SOAK_SAMPLER widens the sweep (tools/soak.sh)."""
+    rs = np.random.RandomState(17000 + seed)
+    V = int(rs.choice([2, 3, 17, 100, 1000, 8001, 60000]))
+    kind = int(rs.randint(4))
+    if kind == 0:
+        dist = np.ones(V)
+    elif kind == 1:
+        dist = np.floor(1.0 + rs.pareto(1.1, size=V) * 2.0)
+    elif kind == 2:
+        dist = rs.randint(0, 3, size=V).astype(np.float64) * (rs.rand(V) < 0.2)
+        dist[rs.randint(V)] = 1.0      # at least one entry can be drawn
+    else:
+        dist = rs.randint(1, 5, size=V).astype(np.float64)
+        dist[rs.randint(V)] = 1e7
+    power = float(rs.choice([0.0, 0.5, 0.75, 1.0]))
+    state0 = int(rs.randint(1, 2 ** 31 - 1))
+    o = so.OracleSampler(dist, power, state0)
+    s = MultinomialSampler(dist, dist.size, power, state0)
+    assert np.array_equal(s.bounds(), o.bounds()), (V, kind, power)
+    for n in [int(x) for x in rs.choice([0, 1, 2, 63, 64, 65, 255, 257, 1000, 5121, 30011], size=5)]:
+        assert np.array_equal(s.sample_batch(n), o.sample_batch(n)), (V, kind, power, n)
+        if n % 2:
+            assert s.sample() == o.sample()
+    assert s.state == o.state
+    s.close()
+    o.close()
