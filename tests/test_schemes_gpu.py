@@ -1,5 +1,7 @@
 """GPU: the remaining train schemes (presample / group_sample / reverse through the row-wise
 kernels, sampled_neg_shared through the per-positive kernels) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -254,3 +256,32 @@ def test_group_sample_trainer_with_device_sample_with_negs(small_data):
         assert abs(got - cost / it) <= 1e-5 * max(1, abs(cost / it)), (epoch, got, cost / it)
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "12"))))
+def test_rowwise_random_batches_match_oracle(small_data, seed):
+    """The row-wise kernels (presample / group_sample / reverse feed them arbitrary (user, item, label) rows): random b, k, d, both
+    pointwise losses, label mixes from all-negative to all-positive, ids drawn from 1 ... 400 users and 1 ... 300 items (every
+    row a duplicate at one end) -- three steps against the float64 oracle."""
+    rs = np.random.RandomState(19000 + seed)
+    loss = str(rs.choice(["skip-gram", "mse"]))
+    b, k, d = int(rs.choice([1, 8, 32, 100, 512])), int(rs.choice([1, 3, 10])), int(rs.choice([4, 16, 50, 100, 128]))
+    conf = _conf(loss, b=b, k=k, d=d, lr=0.05)
+    helper = get_data(dict(small_data), conf, reverse_samping=True, rand_seed=3)
+    md = get_model(conf, helper, "mf", seed=4)
+    eng = md["model"].engine
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), _oconf(conf), dtype=np.float64)
+    n = b * (1 + k)
+    nu, ni = int(rs.choice([1, 2, 30, 400])), int(rs.choice([1, 2, 30, 300]))
+    ppos = float(rs.choice([0.0, 0.1, 0.5, 1.0]))
+    for step in range(3):
+        uid, cid = rs.randint(0, nu, n), rs.randint(0, ni, n)
+        y = np.where(rs.rand(n) < ppos, 1, -1 if loss == "skip-gram" else 0)
+        want = orc.step_original(uid, cid, y)
+        got = md["model"].train_on_batch([uid, cid], [y])
+        info = (loss, b, k, d, nu, ni, ppos, step)
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (info, got, want)
+        amp = max(1.0, n / (512.0 * min(nu, ni)))   # the terms that meet in one row
+        np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=4e-6 * amp, err_msg=str(info))
+        np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=4e-6 * amp, err_msg=str(info))
