@@ -1,4 +1,6 @@
 """GPU: the host mirror (get_model / Trainer / Evaluator) end to end against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -241,6 +243,53 @@ def test_topk_selection_against_numpy():
         assert int(val.item()) == 1
         np.testing.assert_allclose(met.cpu().numpy(), _np_metrics(sc, truth, topk), rtol=1e-6, atol=1e-7,
                                    err_msg="n=%d k=%d" % (n, topk))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "12"))))
+def test_topk_random_rows_ties_and_truth_lists(seed):
+    """nncf_eval_topk over SEVERAL users at once: random row counts and lengths (1 ... 70,000 candidates; leading dimension
+    above the row length), scores that are continuous, heavily tied (3 distinct values) or constant, k = 1 ... 1,024, truth
+    lists that are empty (dropped from the mean, objectives.py:316), short or longer than k -- per-user AP / recall /
+    precision against metrics_ranking.py:14-29 restated in numpy (ties to the lower slot)."""
+    import ctypes
+    from nncf_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(21000 + seed)
+    rows = int(rs.choice([1, 2, 5, 17]))
+    n = int(rs.choice([1, 3, 50, 64, 65, 600, 5000, 17000, 70000]))
+    ld = n + int(rs.choice([0, 0, 1, 37]))
+    topk = int(rs.choice([1, 5, 50, 50, 300, 1024]))
+    kind = int(rs.randint(3))
+    if kind == 0:
+        sc = rs.normal(size=(rows, ld)).astype(np.float32)
+    elif kind == 1:
+        sc = rs.randint(0, 3, size=(rows, ld)).astype(np.float32)
+    else:
+        sc = np.full((rows, ld), 0.25, dtype=np.float32)
+    ptr, idx = [0], []
+    for r in range(rows):
+        m = int(rs.choice([0, 1, 3, 40, 2000]))
+        m = min(m, n)
+        t = np.sort(rs.choice(n, size=m, replace=False)).astype(np.int32)
+        idx.append(t)
+        ptr.append(ptr[-1] + m)
+    flat = np.concatenate(idx) if ptr[-1] else np.zeros(1, dtype=np.int32)
+    scores = torch.as_tensor(sc).cuda().contiguous()
+    ptr_t = torch.as_tensor(np.array(ptr, dtype=np.int32)).cuda()
+    idx_t = torch.as_tensor(flat.astype(np.int32)).cuda()
+    met = torch.zeros(rows * 3, device="cuda")
+    val = torch.zeros(rows, dtype=torch.int32, device="cuda")
+    _lib.check(L.nncf_eval_topk(ctypes.c_void_p(scores.data_ptr()), rows, ld, n, ctypes.c_void_p(ptr_t.data_ptr()),
+                                ctypes.c_void_p(idx_t.data_ptr()), topk, ctypes.c_void_p(met.data_ptr()),
+                                ctypes.c_void_p(val.data_ptr()), _lib.stream_ptr()))
+    got, ok = met.cpu().numpy().reshape(rows, 3), val.cpu().numpy()
+    for r in range(rows):
+        info = (rows, n, ld, topk, kind, r, len(idx[r]))
+        if len(idx[r]) == 0:
+            assert ok[r] == 0, info
+            continue
+        assert ok[r] == 1, info
+        np.testing.assert_allclose(got[r], _np_metrics(sc[r, :n], idx[r], topk), rtol=1e-6, atol=1e-7, err_msg=str(info))
 
 
 def test_group_trainer_with_device_shuffle_learns():
