@@ -36,6 +36,8 @@
 //                   item order and take the SGD / Adam step on Wk (+ transposed copy), conv bias,
 //                   BN1 gamma / beta -- disjoint parameters, one launch less
 // Everything has a fixed summation order (no float atomics); conv dropout is a counter-based hash.
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "tower.h"
@@ -81,7 +83,7 @@ __device__ __forceinline__ float conv_keep(const TowerArgs& a, int64_t pos_index
 // developer timing (NNCF_CNN_DBG=64): thread 0 of every workgroup stamps the phases of the conv kernels
 __device__ __forceinline__ void cnn_stamp(const TowerArgs& a, int kernel, int idx) {
   if ((a.cnn.dbg & 64) && threadIdx.x == 0)
-    a.cnn.stamps[((int64_t)kernel * a.cap * a.cnn.np + blockIdx.x) * 16 + idx] = (long long)wall_clock64();
+    a.cnn.stamps[((int64_t)kernel * a.cnn.gcap * a.cnn.np + blockIdx.x) * 16 + idx] = (long long)wall_clock64();
 }
 
 // ---- the item's static word index, rebuilt in LDS by every workgroup ---------------------------
@@ -89,7 +91,7 @@ __device__ __forceinline__ void cnn_stamp(const TowerArgs& a, int kernel, int id
 // fixed stride of L per item: no pointer hop); item_spos = the item's positions sorted by (word,
 // position), so entry j owns sorted indices [start_j, start_j + cnt_j).  Kept entries (row dropout
 // scale != 0) get compact indices 0 .. nc-1 in entry order.
-struct ItemIdx {
+struct alignas(16) ItemIdx {
   uint8_t pos[256];    // sorted index -> position
   uint8_t start[256];  // entry -> first sorted index (exclusive scan of the counts; L past the last entry)
   uint8_t cnt[256];    // entry -> occurrences
@@ -100,7 +102,9 @@ struct ItemIdx {
   float cs[256];       // compact index -> row-dropout scale
   int wtot[4];
   int nc;
+  int pad_[3];
 };
+static_assert(sizeof(ItemIdx) == kCnnIdxInt4 * 16, "CnnArgs::idx holds one ItemIdx per slot, copied in 16-byte words");
 
 // Threads [0, 256) of the workgroup (blockDim >= 256, L <= 254); returns the number of kept entries.
 // fill: cnt_t[w][s] = 1 + entry ordinal of word w in this item (what tower_word_kernel lists).
@@ -197,7 +201,8 @@ __host__ __device__ inline int fwd_xpitch(int wd, bool exact) { return odd_pitch
 // NKT 16-column groups + NTAIL 4-column k-steps cover word_dim exactly (NTAIL: lane kq takes column 16 NKT + 4 tt + kq of both
 // operands as dwords -- 100 = 6 x 16 + 4 costs 25 k-steps instead of 28).  MASK: any smaller width (zero-padded LDS rows,
 // zero filter fragments past wd).
-template <int NKT, int NTAIL, bool MASK, int NTG>
+// FLX: the exact filter length (LDS pitches and tap offsets become compile-time constants) or 0 = run-time.
+template <int NKT, int NTAIL, bool MASK, int NTG, int FLX>
 __global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs a, int ngrp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ ItemIdx ix;
@@ -206,7 +211,8 @@ __global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs 
   const int s = blockIdx.x / ngrp, g = blockIdx.x % ngrp;
   if (s >= valid_rows(a)) return;
   const int item = a.ids[s];
-  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
+  const int F = a.cnn.F, fl = FLX ? FLX : a.cnn.fl, pad = fl >> 1, L = a.L;
+  const int wd = MASK ? a.wd : 16 * NKT + 4 * NTAIL;   // the exact variant: the width is the template's (row pitches become constants)
   const int KW = fl * wd;
   const int XP = fwd_xpitch(wd, !MASK), PP = fl * 16 * NTG + 4;   // PP / 4 odd too: the MFMA result's 16-byte stores do not collide
   float* sX = smem;                        // [kCnnCW][XP]      scaled rows of the distinct kept words
@@ -236,6 +242,10 @@ __global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs 
   if (wave < nunit) load_b(wave);   // the first strip's fragment travels while the index is built and the rows are gathered
   if (tid < PP / 4) reinterpret_cast<float4*>(sP + kCnnCW * PP)[tid] = zero4();
   const int nc = item_index(a, item, s, a.fill && g == 0 && a.cnn.c_off == 0, ix);
+  if (a.train && g == 0 && a.cnn.c_off == 0) {   // the backward takes this index instead of rebuilding it (same mask, same slots)
+    if (tid < kCnnIdxInt4) a.cnn.idx[(int64_t)s * kCnnIdxInt4 + tid] = reinterpret_cast<const int4*>(&ix)[tid];
+    if (tid == 0) a.cnn.nck[s] = nc;
+  }
   cnn_stamp(a, 0, 1);
   constexpr int CH = 4 * NTG;                 // 16-byte chunks of this group's filters per position
   constexpr int PSTEP = kFwdThreads / CH;     // a thread owns chunk fq of positions prow, prow + PSTEP, ...
@@ -251,7 +261,11 @@ __global__ void __launch_bounds__(kFwdThreads, 4) cnn_conv_fwd_kernel(TowerArgs 
     __syncthreads();
     cnn_stamp(a, 0, 2);
     for (int u = wave; u < nunit; u += kFwdThreads / 64) {
-      if (u != wave || c0) load_b(u);
+      if (u != wave || c0) {   // rare (a second pass of words / more strips than waves): its address is formed here, not kept
+        int uu = u;           // alive from the kernel's top as a hoisted 64-bit pointer (the forward's last spill)
+        asm volatile("" : "+s"(uu));
+        load_b(uu);
+      }
       const int pcol = ((u / ntl) * NTG + u % ntl) * 16 + 4 * kq;
       const float* abase = sX + (int64_t)x * XP + 4 * kq;
 #pragma unroll
@@ -446,6 +460,74 @@ __global__ void __launch_bounds__(1024) cnn_stats_kernel(TowerArgs a) {
   }
 }
 
+// ---- work units of the conv backward (round 5) ----------------------------------------------------------------------
+// The backward launch lasts as long as its word-richest item (its S' rows, (a) row tiles and (b) k-steps all grow with the
+// kept distinct words n_c; round 4's stamps: mean workgroup end 21 us, last 31 us of a 39 us launch).  One extra workgroup of
+// the pooling launch -- which runs between the forward that counted n_c and the backward -- cuts every item with more than
+// `split_words` kept words in two along its words ((a)'s rows are disjoint; (b)'s K split leaves a second dWk block that
+// cnn_update_block adds behind the slots' blocks) and sorts the units heaviest first: the launch holds ~1.3 x the resident
+// workgroups, so the lightest units are the ones that start late.  Everything here is integer work with a fixed result
+// (bitonic sort of (words, unit id) keys): the order of every float sum downstream is that of the slots, whoever runs first.
+// buf: >= 1024 + 3 * 512 + 16 ints of LDS; 512 threads; nv <= 512.
+__device__ __forceinline__ void cnn_units_build(const TowerArgs& a, int* buf) {
+  unsigned* key = reinterpret_cast<unsigned*>(buf);   // [1024]
+  int* sNc = buf + 1024;                               // [512] kept words of slot
+  int* sX = buf + 1536;                                // [512] slot of split rank
+  int* sSplit = buf + 2048;                            // [512] split rank of slot, -1: one unit
+  int* sW = buf + 2560;                                // [8] wave totals
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = valid_rows(a), T = a.cnn.split_words, capx = a.cnn.capx;
+  const int nc = tid < nv ? a.cnn.nck[tid] : 0;
+  const bool heavy = tid < nv && nc > T && nc >= 2;
+  const unsigned long long m = __ballot(heavy);
+  if (lane == 0) sW[wave] = __popcll(m);
+  key[tid] = 0u;
+  key[512 + tid] = 0u;
+  __syncthreads();
+  int rank = __popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) rank += sW[w];
+  const bool split = heavy && rank < capx;
+  int nx = 0;
+  for (int w = 0; w < 8; ++w) nx += sW[w];
+  nx = min(nx, capx);
+  sNc[tid] = nc;
+  sSplit[tid] = split ? rank : -1;
+  if (split) sX[rank] = tid;
+  // key = (words + 1) << 10 | (1023 - unit id): descending = heaviest first, ties by unit id; empty = 0 sorts last
+  if (tid < nv) key[tid] = ((unsigned)((split ? (nc + 1) >> 1 : nc) + 1) << 10) | (unsigned)(1023 - tid);
+  if (split) key[512 + rank] = ((unsigned)((nc >> 1) + 1) << 10) | (unsigned)(1023 - (512 + rank));
+  __syncthreads();
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int lo = 2 * j * (tid / j) + (tid % j), hi = lo + j;   // 512 disjoint pairs per stage
+      const unsigned x = key[lo], y = key[hi];
+      const bool desc = (lo & k) == 0;
+      if (desc ? x < y : x > y) {
+        key[lo] = y;
+        key[hi] = x;
+      }
+      __syncthreads();
+    }
+  }
+  const int nunits = nv + nx;
+  for (int i = tid; i < nunits; i += 512) {
+    const int id = 1023 - (int)(key[i] & 1023u);
+    int4 u;
+    if (id < 512) {
+      const int n = sNc[id];
+      u = make_int4(id, sSplit[id] >= 0 ? ((n + 1) >> 1) << 16 : n << 16, id, 0);
+    } else {
+      const int sl = sX[id - 512], n = sNc[sl];
+      u = make_int4(sl, ((n + 1) >> 1) | (n << 16), nv + (id - 512), 1);
+    }
+    a.cnn.units[i] = u;
+  }
+  if (tid == 0) {
+    a.cnn.split[0] = nunits;
+    a.cnn.split[1] = nx;
+  }
+}
+
 // a = relu(y*mul+add) * dropout, mean over the L positions -> h[s]; z[s] = h[s].Wd + bd
 // (train) or E[s] = relu(BN_running(z[s])) (inference).
 // Backward preparation: da[p][c] = dh[s][c]/L * m[p][c] with m = dropout scale * [y*mul+add > 0] known
@@ -469,6 +551,10 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
   const int tid = threadIdx.x, grp = tid >> 4, q = tid & 15;
   const int F = a.cnn.F, f4 = F >> 2, d4 = a.d >> 2, L = a.L;
   const int s = blockIdx.x;
+  if (s == a.m) {   // the extra workgroup of a training block that the backward will run over work units (host: grid = m + 1)
+    cnn_units_build(a, reinterpret_cast<int*>(&sR[0][0]));
+    return;
+  }
   if (s >= valid_rows(a)) return;
   const bool prep = a.train && a.fill;
   const int c4 = tid & 31, kp = (tid >> 5) & 7, kper = (F + 7) >> 3;   // dense part: the first 256 threads
@@ -793,7 +879,9 @@ constexpr int kCnnCWB = 96;
 constexpr int kHeavy = 16;         // a word with more positions than this is summed by a 32-lane team
 // kBwdThreads = 512 (filter lengths <= 3): 8 waves, <= 128 VGPRs, ~72 KB of LDS: two workgroups per CU; 256 for the longer
 // filters' register arrays (one strip pair per wave)
-template <int NTG, int FLMAX, int kBwdThreads>
+// FLX: the exact filter length (1 or 3: every LDS pitch and row offset is then a compile-time constant -- immediates instead of
+// address registers, which is what the 128-register budget of two workgroups per CU needs), 0 = run-time (the long filters).
+template <int NTG, int FLMAX, int kBwdThreads, int FLX>
 __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_conv_bwd_kernel(TowerArgs a, int ngrp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ ItemIdx ix;
@@ -804,11 +892,23 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
   constexpr int NW = kBwdThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x / ngrp, g = blockIdx.x % ngrp;
+  const int blk = blockIdx.x / ngrp, g = blockIdx.x % ngrp;
   const int nv = valid_rows(a);
-  if (s >= nv) return;
-  const int item = a.ids[s];
-  const int F = a.cnn.F, fl = a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
+  // this workgroup's unit: an item, or one half of the kept words of a word-rich item (cnn_units_build; heaviest units first)
+  int s = blk, c_lo = 0, c_hi = -1, oslot = blk;
+  bool half1 = false;
+  if (a.cnn.capx) {
+    const int4 u = a.cnn.units[blk];   // the buffer holds m + capx entries: always readable
+    if (blk >= a.cnn.split[0]) return;
+    s = u.x;
+    c_lo = u.y & 0xFFFF;
+    c_hi = u.y >> 16;
+    oslot = u.z;
+    half1 = u.w != 0;
+  } else if (s >= nv) {
+    return;
+  }
+  const int F = a.cnn.F, fl = FLX ? FLX : a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
   constexpr int CH = 4 * NTG, FW = 16 * NTG;
   const int DP = FW + 4;                  // dY tile pitch: rows 4 banks apart
   const int SP = fl * FW + 4;             // SP / 4 odd: conflict-free 16-byte fragment reads in (a)
@@ -820,7 +920,9 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
   const bool fok = f0 < F;
   const bool maxp = a.cnn.pool_max != 0;
   cnn_stamp(a, 1, 0);
-  // the first round of Y rows does not wait for the index
+  // the forward's index of this slot (one 16-byte word per thread) and the first round of Y rows travel together
+  int4 ixw = make_int4(0, 0, 0, 0);
+  if (tid < kCnnIdxInt4) ixw = a.cnn.idx[(int64_t)s * kCnnIdxInt4 + tid];
   constexpr int NY = 4;
   const int nit = rows * CH;
   float4 y[NY];
@@ -876,7 +978,9 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
       sTot[(wave * 2 + 1) * CH + lane] = p2;
     }
   }
-  const int nc = item_index(a, item, s, false, ix);
+  if (tid < kCnnIdxInt4) reinterpret_cast<int4*>(&ix)[tid] = ixw;
+  __syncthreads();
+  if (c_hi < 0) c_hi = ix.nc;
   if (a.cnn.fold) {
     cs1 = zero4();
     cs2 = zero4();
@@ -885,7 +989,7 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
       cs1 = add4(cs1, sTot[(w * 2 + 0) * CH + fq]);
       cs2 = add4(cs2, sTot[(w * 2 + 1) * CH + fq]);
     }
-    if (s == 0 && tid < CH && f0 < 128) {   // for the parameter step (cnn_update_block): dbeta1, dgamma1
+    if (s == 0 && !half1 && tid < CH && f0 < 128) {   // for the parameter step (cnn_update_block): dbeta1, dgamma1
       *reinterpret_cast<float4*>(a.cnn.st1 + 640 + f0) = cs1;
       *reinterpret_cast<float4*>(a.cnn.st1 + 768 + f0) = cs2;
     }
@@ -944,7 +1048,7 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
 #pragma unroll
     for (int w = 0; w < NW; ++w) t = add4(t, sGb[w * CH + tid]);
     const int f = FW * g + 4 * tid;
-    if (f < 128) *reinterpret_cast<float4*>(a.cnn.gbpart + (int64_t)s * 128 + f) = t;
+    if (f < 128 && !half1) *reinterpret_cast<float4*>(a.cnn.gbpart + (int64_t)s * 128 + f) = t;
   }
   const int nKw = (wd + 15) >> 4;
   const int ntl = min(NTG, (F - FW * g + 15) >> 4);           // filter tiles of this group that hold a real filter
@@ -954,12 +1058,16 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
   // this item's dWk block of the group's filters, element-group major: gWpart[element / 64][slot][64] -- the update workgroup of
   // an element group reads ONE contiguous run of (slots x 256 B).  Always written (zeros for an item whose words were all
   // dropped); a second pass of words (more than kCnnCWB kept: rare) adds to what the first one stored.
-  float* gw = a.cnn.gWpart + (int64_t)s * kCnnUpdElems;
+  float* gw = a.cnn.gWpart + (int64_t)oslot * kCnnUpdElems;
   auto put_tile = [&](const f32x4& c, int kt, int tap, int ftl, bool add) {
     const int k = kt * 16 + x, f = FW * g + 16 * ftl + 4 * kq;
     if (k < wd && f < F) {   // streaming stores: read once by cnn_update -- not worth L2 lines
-      const int64_t el = ((int64_t)tap * wd + k) * F + f;   // a multiple of 4: the four floats stay in one group of 64
-      float* dst = gw + (el / kCnnUpdElems) * (int64_t)a.cap * kCnnUpdElems + (el % kCnnUpdElems);
+      // 32-bit element offsets (the block array holds < 2^31 floats: the host checks): the compiler hoists these addresses out
+      // of the word loop, and as 64-bit pairs they were 24 live registers -- the backward's last spills (round 5 audit)
+      int kk = k;
+      asm volatile("" : "+v"(kk));      // the address is formed HERE, once per tile, not as six loop-invariant pointers kept alive
+      const int el = (tap * wd + kk) * F + f;   // a multiple of 4: the four floats stay in one group of 64
+      float* dst = gw + ((unsigned)(el / kCnnUpdElems) * (unsigned)(a.cnn.gcap * kCnnUpdElems) + (unsigned)(el % kCnnUpdElems));
       float4 v = make_float4(c[0], c[1], c[2], c[3]);
       if (add) v = add4(v, *reinterpret_cast<const float4*>(dst));
       __builtin_nontemporal_store(v.x, dst);
@@ -968,16 +1076,16 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
       __builtin_nontemporal_store(v.w, dst + 3);
     }
   };
-  if (nc == 0) {
+  if (c_hi <= c_lo) {
     for (int ks = 0; ks < KPW; ++ks)
       for (int tap = 0; tap < fl; ++tap)
         for (int ftl = 0; ftl < ntl; ++ftl)
           if (wave + NW * ks < nKw) put_tile(f32x4{0.f, 0.f, 0.f, 0.f}, wave + NW * ks, tap, ftl, false);
   }
   float* dxw = a.cnn.dXw + (int64_t)g * a.cnn.pstride;
-  for (int c0 = 0; c0 < nc; c0 += kCnnCWB) {
-    const int ncl = min(kCnnCWB, nc - c0), nmt = (ncl + 15) >> 4, nst = (ncl + 3) >> 2;
-    if (c0) __syncthreads();   // the previous pass's MFMAs have read sS
+  for (int c0 = c_lo; c0 < c_hi; c0 += kCnnCWB) {
+    const int ncl = min(kCnnCWB, c_hi - c0), nmt = (ncl + 15) >> 4, nst = (ncl + 3) >> 2;
+    if (c0 > c_lo) __syncthreads();   // the previous pass's MFMAs have read sS
     // heavy words of the pass (one wave lists them by ballot, in word order)
     if (wave == 0) {
       int nh = 0;
@@ -1064,7 +1172,7 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
     }
     __syncthreads();
     cnn_stamp(a, 1, 3);
-    float xb[KPW][kCnnCWB / 4];   // the words' rows of the strip: requested now, used after (a)
+    float xb[KPW][kCnnCWB / 4];   // the words' rows of the strip: requested now, used by (b) right behind the barrier
 #pragma unroll
     for (int ks = 0; ks < KPW; ++ks) {
       const int kt = wave + NW * ks, kcol = kt * 16 + x;
@@ -1078,6 +1186,34 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
     for (int ks = 0; ks < KPW; ++ks) {
       const int kt = wave + NW * ks;
       if (kt < nKw) {
+        // ---- (b) dWk tiles of the strip: K = the pass's words; S' one dword per lane from LDS, the rows from registers.  First:
+        // its operand xb (24 registers) is dead before (a) raises its three accumulator tiles (round 4 ran (a) first and spilled 18) ----
+        // dY's side is the MFMA's A operand: D[i = 4kq + r][j = x] = dWk[tap][16kt + x][16ftl + 4kq + r]
+#pragma unroll
+        for (int tap = 0; tap < FLMAX; ++tap) {
+          if (tap < fl) {
+#pragma unroll
+            for (int ftl = 0; ftl < NTG; ++ftl) {
+              if (ftl < ntl) {
+                const float* pa = sS + (int64_t)kq * SP + (tap * NTG + ftl) * 16 + x;
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st0 = 0; st0 < kCnnCWB / 4; st0 += 4) {   // four k-steps' operands in flight
+                  if (st0 < nst) {   // rows past the pass's words are zero in S'
+                    float av[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = pa[(int64_t)4 * (st0 + e) * SP];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], xb[ks][st0 + e], c, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+                }
+                put_tile(c, kt, tap, ftl, c0 > c_lo);
+              }
+            }
+          }
+        }
+        cnn_stamp(a, 1, 4);
         // ---- (a) partial dL/dW rows of the pass's words, columns [16kt, 16kt + 16) -----------------------------------
         // the filter fragment is the A operand: D[i = 4kq + r][j = x] = dL/dW[word 16mt + x][16kt + 4kq + r]
         const int k0 = kt * 16 + 4 * kq;
@@ -1143,33 +1279,6 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
             }
           }
         }
-        cnn_stamp(a, 1, 4);
-        // ---- (b) dWk tiles of the strip: K = the pass's words; S' one dword per lane from LDS, the rows from registers ----
-        // dY's side is the MFMA's A operand: D[i = 4kq + r][j = x] = dWk[tap][16kt + x][16ftl + 4kq + r]
-#pragma unroll
-        for (int tap = 0; tap < FLMAX; ++tap) {
-          if (tap < fl) {
-#pragma unroll
-            for (int ftl = 0; ftl < NTG; ++ftl) {
-              if (ftl < ntl) {
-                const float* pa = sS + (int64_t)kq * SP + (tap * NTG + ftl) * 16 + x;
-                f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st0 = 0; st0 < kCnnCWB / 4; st0 += 4) {   // four k-steps' operands in flight
-                  if (st0 < nst) {   // rows past the pass's words are zero in S'
-                    float av[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) av[e] = pa[(int64_t)4 * (st0 + e) * SP];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], xb[ks][st0 + e], c, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                  }
-                }
-                put_tile(c, kt, tap, ftl, c0 > 0);
-              }
-            }
-          }
-        }
       }
     }
   }
@@ -1196,9 +1305,20 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
   const int64_t cap = t->cfg.max_rows, L = t->cfg.content_len, wd = t->cfg.word_dim, F = t->cfg.conv_filters;
   const int64_t np = cnn_groups((int)F);
   float* dXw = c.take<float>(np * cap * L * wd);   // shared by the banks (the backward accumulates into it)
+  // the forward's per-slot index and the backward's work units: one copy, every bank reads it
+  const int64_t capx_cap = cnn_capx_cap((int)cap), gcap = cap + capx_cap;
+  int4* idx = c.take<int4>(cap * kCnnIdxInt4);
+  int4* units = c.take<int4>(gcap);
+  int* nck = c.take<int>(cap);
+  int* split = c.take<int>(4);
   for (int g = 0; g < t->nb; ++g) {
     CnnArgs& a = t->bank_at(g);
     const int64_t fl = a.fl;
+    a.idx = idx;
+    a.units = units;
+    a.nck = nck;
+    a.split = split;
+    a.gcap = (int)gcap;
     a.dXw = dXw;
     a.np = (int)np;
     a.pstride = cap * L * wd;
@@ -1210,9 +1330,9 @@ size_t cnn_carve(nncf_tower* t, Carver& c) {
     a.mpart = c.take<float>(2 * kCnnMergeWG * 256);
     a.mcnt = c.take<unsigned>(4);
     a.amax = c.take<uint8_t>(cap * 128);
-    a.gWpart = c.take<float>(cap * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
+    a.gWpart = c.take<float>(gcap * (((int64_t)fl * wd * F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems);
     a.gbpart = c.take<float>(cap * 128);
-    a.stamps = c.take<long long>(2 * cap * np * 16);
+    a.stamps = c.take<long long>(2 * gcap * np * 16);
   }
   return c.off;
 }
@@ -1252,13 +1372,31 @@ static TowerArgs bank_args(const nncf_tower* t, const TowerArgs& a, int g) {
   b.cnn.dx_acc = g > 0;
   b.cnn.last = g == t->nb - 1;
   b.cnn.fold = a.m <= kCnnFoldRows && !getenv_flag("NNCF_CNN_NOFOLD");
+  b.cnn.capx = a.cnn.capx;
+  b.cnn.split_words = a.cnn.split_words;
   return b;
 }
 
 static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st);
 static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st);
 
+// Work units of the backward (cnn_units_build): blocks of <= kCnnFoldRows rows in training, OPT-IN through NNCF_CNN_SPLIT = the
+// number of kept words above which an item is cut in two (read per call).  Default 0 = one workgroup per (slot, filter group)
+// in slot order, no unit table and no builder workgroup.  Measured at config [4] (125 items x 4 groups = 500 workgroups, all
+// resident at once; rocprofv3, same box): 0 -> cnn_conv_bwd 35.5 us, cnn_pool_dense 14.3; 64 -> 34.0 / 16.2; 48 -> 37.1 / 16.2;
+// 32 -> 42.7 / 16.3.  A unit pays the launch's fixed part again (index + BatchNorm sums + dY tile: ~8 of a mean workgroup's
+// 19 us) and its table costs every workgroup a dependent trip, so cutting buys less than the builder's sort adds to the
+// pooling launch; it stays for blocks whose word counts are more skewed than CiteULike's.  Both the forward (the pooling
+// launch builds the units) and the backward call this with the same block.
+static void cnn_set_units(const nncf_tower* t, TowerArgs& a) {
+  const char* e = getenv("NNCF_CNN_SPLIT");
+  const int split_words = e && e[0] ? atoi(e) : 0;
+  a.cnn.split_words = split_words;
+  a.cnn.capx = (a.train && a.m <= kCnnFoldRows && split_words > 0) ? std::min(std::max(a.m / 2, 1), cnn_capx_cap(t->cfg.max_rows)) : 0;
+}
+
 int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  cnn_set_units(t, a);
   for (int g = 0; g < t->nb; ++g) {
     TowerArgs b = bank_args(t, a, g);
     if (int rc = cnn_forward_bank(t, b, st)) return rc;
@@ -1268,22 +1406,27 @@ int cnn_forward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
 
 static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int fl = a.cnn.fl, ngrp = cnn_groups(a.cnn.F);
-  const bool exact = a.wd == 100;
+  const bool exact = a.wd == 100 && (fl == 3 || fl == 1);
   const size_t lds = ((size_t)kCnnCW * fwd_xpitch(a.wd, exact) + (size_t)(kCnnCW + 1) * (fl * 16 * kCnnNTG + 4)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv forward tiles of %zu bytes exceed the LDS", lds);
   {
     ProfScope _ps("cnn_conv_fwd_kernel", st);
     const dim3 grid((unsigned)(a.m * ngrp));
-    if (a.wd == 100) {  // 6 K groups + one 4-column k-step: the CiteULike shape
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<6, 1, false, kCnnNTG>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<6, 1, false, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
+#define NNCF_FWD_LAUNCH(NKT_, NTAIL_, MASK_, FLX_)                                                                                       \
+  do {                                                                                                                                  \
+    if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<NKT_, NTAIL_, MASK_, kCnnNTG, FLX_>), lds)) return rc;     \
+    hipLaunchKernelGGL((cnn_conv_fwd_kernel<NKT_, NTAIL_, MASK_, kCnnNTG, FLX_>), grid, dim3(kFwdThreads), lds, st, a, ngrp);          \
+  } while (0)
+    if (a.wd == 100 && fl == 3) {  // 6 K groups + one 4-column k-step: the CiteULike shape, the `best` preset's length
+      NNCF_FWD_LAUNCH(6, 1, false, 3);
+    } else if (a.wd == 100 && fl == 1) {
+      NNCF_FWD_LAUNCH(6, 1, false, 1);
     } else if (a.wd <= 64) {
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<4, 0, true, kCnnNTG>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<4, 0, true, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
+      NNCF_FWD_LAUNCH(4, 0, true, 0);
     } else {
-      if (int rc = set_lds(reinterpret_cast<const void*>(&cnn_conv_fwd_kernel<8, 0, true, kCnnNTG>), lds)) return rc;
-      hipLaunchKernelGGL((cnn_conv_fwd_kernel<8, 0, true, kCnnNTG>), grid, dim3(kFwdThreads), lds, st, a, ngrp);
+      NNCF_FWD_LAUNCH(8, 0, true, 0);
     }
+#undef NNCF_FWD_LAUNCH
   }
   if (a.train && !a.cnn.fold) {
     ProfScope _ps("cnn_stats_kernel", st);
@@ -1291,8 +1434,9 @@ static int cnn_forward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_pool_dense_kernel", st);
-    if (a.cnn.pool_max) hipLaunchKernelGGL(cnn_pool_dense_kernel<true>, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
-    else hipLaunchKernelGGL(cnn_pool_dense_kernel<false>, dim3((unsigned)a.m), dim3(kPoolThreads), 0, st, a);
+    const unsigned extra = (a.train && a.cnn.capx > 0 && a.cnn.c_off == 0) ? 1u : 0u;   // + the unit builder of the backward
+    if (a.cnn.pool_max) hipLaunchKernelGGL(cnn_pool_dense_kernel<true>, dim3((unsigned)a.m + extra), dim3(kPoolThreads), 0, st, a);
+    else hipLaunchKernelGGL(cnn_pool_dense_kernel<false>, dim3((unsigned)a.m + extra), dim3(kPoolThreads), 0, st, a);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -1306,6 +1450,7 @@ __global__ void __launch_bounds__(512) cnn_update_kernel(TowerArgs a) {
 // after tower_bwd_kernel produced dL/dh in a.dh: everything up to the per-(item, word) gradient rows.  Banks 1 .. take
 // their parameter step here (bank 0's rides in the word kernel's launch, tower.hip).
 int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
+  cnn_set_units(t, a);   // on the caller's arguments too: the word kernel's conv-weight blocks count the second dWk blocks
   for (int g = 0; g < t->nb; ++g) {
     TowerArgs b = bank_args(t, a, g);
     if (g > 0) {
@@ -1327,8 +1472,11 @@ static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int fl = a.cnn.fl, ngrp = cnn_groups(a.cnn.F), FW = 16 * kCnnNTG;
   const size_t lds = ((size_t)(a.L + fl - 1) * (FW + 4) + (size_t)kCnnCWB * (fl * FW + 4)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tiles of %zu bytes exceed the LDS", lds);
-  const void* bwd_fn = fl <= 3 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 3, 512>)
-                               : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 7, 256>);
+  NNCF_REQUIRE((int64_t)a.cnn.gcap * (((int64_t)fl * a.wd * a.cnn.F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems < (1ll << 31),
+               "the per-slot dWk blocks exceed 2^31 floats (32-bit offsets in cnn_conv_bwd_kernel)");
+  const void* bwd_fn = fl == 3   ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 3, 512, 3>)
+                       : fl == 1 ? reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 1, 512, 1>)
+                                 : reinterpret_cast<const void*>(&cnn_conv_bwd_kernel<kCnnNTG, 7, 256, 0>);
   if (int rc = set_lds(bwd_fn, lds)) return rc;
   if (!a.cnn.fold) {
     ProfScope _ps("cnn_merge_kernel", st);
@@ -1336,9 +1484,10 @@ static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   }
   {
     ProfScope _ps("cnn_conv_bwd_kernel", st);
-    const dim3 grid((unsigned)(a.m * ngrp));
-    if (fl <= 3) hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 3, 512>), grid, dim3(512), lds, st, a, ngrp);
-    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 7, 256>), grid, dim3(256), lds, st, a, ngrp);
+    const dim3 grid((unsigned)((a.m + a.cnn.capx) * ngrp));
+    if (fl == 3) hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 3, 512, 3>), grid, dim3(512), lds, st, a, ngrp);
+    else if (fl == 1) hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 1, 512, 1>), grid, dim3(512), lds, st, a, ngrp);
+    else hipLaunchKernelGGL((cnn_conv_bwd_kernel<kCnnNTG, 7, 256, 0>), grid, dim3(256), lds, st, a, ngrp);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -77,18 +77,36 @@ int comm_all_to_all(nncf_comm* c, const void* d_send, const int64_t* send_cnt, v
   char* rp = static_cast<char*>(d_recv);
   int64_t so = 0, ro = 0;
   NNCF_RCCL_CHECK(g_rccl.GroupStart());
-  for (int r = 0; r < R; ++r) {
+  // Between GroupStart and GroupEnd nothing may return: an open group is thread-local state of RCCL, and every later
+  // collective of this thread (torch's too) would queue behind it without ever launching.  The first failure is kept,
+  // the group is always closed, then the failure is reported.
+  ncclResult_t bad = ncclSuccess;
+  hipError_t hbad = hipSuccess;
+  const char* what = "";
+  for (int r = 0; r < R && bad == ncclSuccess && hbad == hipSuccess; ++r) {
     const int64_t sb = send_cnt[r] * (int64_t)elem_bytes, rb = recv_cnt[r] * (int64_t)elem_bytes;
     if (r == c->rank && !c->self_via_rccl) {   // the own share never leaves the device
-      if (sb > 0 && sp + so != rp + ro) NNCF_HIP_CHECK(hipMemcpyAsync(rp + ro, sp + so, (size_t)sb, hipMemcpyDeviceToDevice, st));
+      if (sb > 0 && sp + so != rp + ro) {
+        hbad = hipMemcpyAsync(rp + ro, sp + so, (size_t)sb, hipMemcpyDeviceToDevice, st);
+        what = "hipMemcpyAsync (own share)";
+      }
     } else {
-      if (sb > 0) NNCF_RCCL_CHECK(g_rccl.Send(sp + so, (size_t)sb, ncclChar, r, static_cast<ncclComm_t>(c->nccl), st));
-      if (rb > 0) NNCF_RCCL_CHECK(g_rccl.Recv(rp + ro, (size_t)rb, ncclChar, r, static_cast<ncclComm_t>(c->nccl), st));
+      if (sb > 0) {
+        bad = g_rccl.Send(sp + so, (size_t)sb, ncclChar, r, static_cast<ncclComm_t>(c->nccl), st);
+        what = "ncclSend";
+      }
+      if (rb > 0 && bad == ncclSuccess) {
+        bad = g_rccl.Recv(rp + ro, (size_t)rb, ncclChar, r, static_cast<ncclComm_t>(c->nccl), st);
+        what = "ncclRecv";
+      }
     }
     so += sb;
     ro += rb;
   }
-  NNCF_RCCL_CHECK(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (hbad != hipSuccess) return fail(NNCF_ERR_HIP, "%s failed inside an RCCL group: %s", what, hipGetErrorString(hbad));
+  if (bad != ncclSuccess) return fail(NNCF_ERR_HIP, "RCCL: %s failed: %s", what, g_rccl.GetErrorString(bad));
+  if (end != ncclSuccess) return fail(NNCF_ERR_HIP, "RCCL: ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
   return NNCF_OK;
 }
 
@@ -144,7 +162,10 @@ int nncf_comm_create_callback(nncf_xfer_fn fn, void* user, int32_t n_ranks, int3
 
 int nncf_comm_destroy(nncf_comm* c) {
   if (!c) return NNCF_OK;
-  if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
+  if (c->nccl && g_rccl.CommDestroy) {
+    DeviceGuard guard(c->device);   // ncclCommDestroy frees device memory of the communicator's own device
+    (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->nccl));
+  }
   delete c;
   return NNCF_OK;
 }

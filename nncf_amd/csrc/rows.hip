@@ -477,6 +477,10 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   const bool strong = d_user_shard != nullptr;
   NNCF_REQUIRE(b % kTile == 0, "batch_size_p must be a multiple of %d", kTile);
   NNCF_REQUIRE(m->cfg.item_count >= b, "the model's item table is the landing buffer: it must hold batch_size_p rows");
+  // every landing buffer (rows, moments) is written PACKED by the gathers and the exchanges (elem_bytes = 4 dim) and read by the
+  // model's kernels with the model's row stride: the two must agree for every session, not only under Adam
+  NNCF_REQUIRE(m->cfg.row_stride == m->cfg.dim, "the sharded trainers land packed rows in the model's tables: row_stride (%d) must equal dim (%d)",
+               (int)m->cfg.row_stride, (int)m->cfg.dim);
   NNCF_REQUIRE(!(m->opt == 1 && m->dup_as_written), "the sharded trainers sum an id's gradient rows before the step: the as-written "
                "sparse Adam (last occurrence wins) has no meaning across ranks");
   // Pairwise losses (objectives.py:90-98: every score against its column's positive) in the strong form: dL/dS of a

@@ -8,6 +8,7 @@
 // [guide[g], guide[g+1]] for the first id with bound[id] > r  (== table[r]).
 // Both arrays stay L2-resident; a draw costs one 8-byte guide read plus a few bound reads.
 #include <cmath>
+#include <cstdlib>
 #include <ctime>
 #include <new>
 #include <vector>
@@ -93,42 +94,129 @@ static void build_guide(const std::vector<int32_t>& bound, int shift, std::vecto
 // ---------------------------------------------------------------------------------------
 // Device
 // ---------------------------------------------------------------------------------------
+constexpr size_t kSamplerLds = 150 * 1024;          // LDS the table-resident variant may take (160 KB per CU)
+constexpr int64_t kSamplerQuadMinDraws = 1 << 17;   // from here on four draws per thread and 16-byte stores
+constexpr int64_t kSamplerLdsMinDraws = 1 << 19;     // below this the LDS fill (~120 KB per workgroup) costs more than it saves
+
 struct JumpTable {
   Affine p[48];  // p[j] = f^(2^j); 2^48 draws is far beyond any batch
 };
 
-__device__ __forceinline__ int32_t lookup(const int32_t* __restrict__ bound, const int32_t* __restrict__ guide,
-                                          int shift, uint32_t r) {
-  const uint32_t g = r >> shift;
-  int32_t lo = guide[g], hi = guide[g + 1];
-  // first id in [lo, hi] with bound[id] > r
-  while (lo < hi) {
-    const int32_t mid = (lo + hi) >> 1;
-    if ((uint32_t)bound[mid] > r) hi = mid; else lo = mid + 1;
-  }
-  return lo;
+// r = x mod 1e8 for x < 2^48 (x = state >> 16), exactly, without the software 64-bit division the `%` operator
+// compiles to (~200 VALU instructions; the round-4 kernel spent most of its issue slots there).  Granlund-Montgomery:
+// with N = 48 bits of dividend and l = ceil(log2 1e8) = 27, m = ceil(2^(N+l) / 1e8) satisfies
+// 2^75 <= m * 1e8 < 2^75 + 2^27, so floor(x / 1e8) = (x * m) >> 75 for every x < 2^48; the remainder then needs only
+// the low 32 bits (r < 1e8 < 2^32).  tests/test_oracle_sampler.py checks this form against `%` on the 48-bit corner
+// cases and on 10^7 random states; the golden streams and their SHA-256 pin the kernel.
+constexpr uint64_t kModMagic = 377789318629572ULL;   // ceil(2^75 / 1e8)
+static_assert((unsigned __int128)kModMagic * 100000000ULL >= ((unsigned __int128)1 << 75), "magic too small");
+static_assert((unsigned __int128)kModMagic * 100000000ULL < ((unsigned __int128)1 << 75) + ((unsigned __int128)1 << 27), "magic too large");
+__host__ __device__ __forceinline__ uint32_t mod_table(uint64_t x48) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const uint64_t q = __umul64hi(x48, kModMagic) >> 11;
+#else
+  const uint64_t q = (uint64_t)(((unsigned __int128)x48 * kModMagic) >> 75);
+#endif
+  return (uint32_t)x48 - (uint32_t)q * (uint32_t)kTableSize;
 }
 
-// Draw j (0-based within the logical batch) uses state f^(j+1)(state0):
-//   nodesampler.cpp:23-26,73-76.  Thread t produces draws first+t, first+t+T, ...
-__global__ void __launch_bounds__(256) sample_kernel(const int32_t* __restrict__ bound,
-                                                     const int32_t* __restrict__ guide, int shift,
-                                                     uint64_t state0, int64_t first, int64_t count,
-                                                     int32_t* __restrict__ out, JumpTable jt, int nbits,
-                                                     Affine stride) {
-  const int64_t T = (int64_t)gridDim.x * blockDim.x;
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= count) return;
-  uint64_t steps = (uint64_t)(first + j + 1);
-  uint64_t s = state0;
-  for (int b = 0; b < nbits; ++b) {
-    const uint64_t t = jt.p[b].a * s + jt.p[b].c;
-    s = ((steps >> b) & 1) ? t : s;
+// Draw j (0-based within the logical batch) uses state f^(j+1)(state0): nodesampler.cpp:23-26,73-76.
+// DPT = 4: a thread owns FOUR consecutive draws per iteration -- one 16-byte store (quads are aligned to 16 bytes of `out`
+// wherever it starts) -- and strides by f^(4T); its four binary searches (first id in [lo, hi] with bound[id] > r) run in
+// lock-step, branch-free, four reads in flight per round instead of four divergent loops one after the other.  DPT = 1: the
+// short batches of a training step (one draw per thread: the shortest chain).  LDS = true: bound[] and a coarser guide live in
+// the workgroup's LDS (the north-star's sketch; V <= ~25K ids: 68 KB + 49 KB at the CiteULike item count) -- every lookup of
+// a long stream (an epoch's negatives) is a few LDS reads instead of dependent L2 trips; short batches keep the global
+// tables (filling 117 KB of LDS would cost more than the draws).
+template <bool LDS, int DPT, bool LOCK>
+__global__ void __launch_bounds__(LDS ? 1024 : 256) sample_kernel(const int32_t* __restrict__ bound, const int32_t* __restrict__ guide,
+                                                                  int shift, int n_ids, int n_guide, uint64_t state0, int64_t first,
+                                                                  int64_t count, int32_t* __restrict__ out, JumpTable jt, int nbits,
+                                                                  Affine stride) {
+  extern __shared__ __attribute__((aligned(16))) int32_t s_tab[];
+  const int32_t* bnd = bound;
+  const int32_t* gd = guide;
+  if (LDS) {
+    int32_t* sb = s_tab;                        // [n_ids rounded up to 4]
+    int32_t* sg = s_tab + ((n_ids + 3) & ~3);   // [n_guide]
+    for (int i = threadIdx.x * 4; i < n_ids; i += blockDim.x * 4)   // both arrays are padded to 16 bytes on the device
+      *reinterpret_cast<int4*>(sb + i) = *reinterpret_cast<const int4*>(bound + i);
+    for (int i = threadIdx.x * 4; i < n_guide; i += blockDim.x * 4)
+      *reinterpret_cast<int4*>(sg + i) = *reinterpret_cast<const int4*>(guide + i);
+    __syncthreads();
+    bnd = sb;
+    gd = sg;
   }
-  for (; j < count; j += T) {
-    const uint32_t r = (uint32_t)((s >> 16) % (uint64_t)kTableSize);
-    out[j] = lookup(bound, guide, shift, r);
-    s = stride.a * s + stride.c;
+  const int mis = DPT == 4 ? (int)((reinterpret_cast<uintptr_t>(out) >> 2) & 3) : 0;
+  const int64_t TD = (int64_t)gridDim.x * blockDim.x * DPT;
+  int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * DPT - mis;   // quad q covers out indices [4q - mis, 4q - mis + 4)
+  if (j >= count) return;
+  int e0 = j < 0 ? (int)-j : 0;   // the stream's first quad may start before index 0 (thread 0 only)
+  auto jump = [&](uint64_t steps) {
+    uint64_t x = state0;
+    for (int b = 0; b < nbits; ++b) {
+      const uint64_t t = jt.p[b].a * x + jt.p[b].c;
+      x = ((steps >> b) & 1) ? t : x;
+    }
+    return x;
+  };
+  uint64_t s = jump((uint64_t)(first + j + e0 + 1));
+  for (; j < count; j += TD) {
+    uint64_t st[DPT];   // st[k]: the state of out index j + e0 + k
+    st[0] = s;
+#pragma unroll
+    for (int e = 1; e < DPT; ++e) st[e] = kLcgA * st[e - 1] + kLcgC;
+    uint32_t r[DPT];
+    int32_t lo[DPT], hi[DPT];
+#pragma unroll
+    for (int e = 0; e < DPT; ++e) {   // the guide reads travel together
+      r[e] = mod_table(st[e] >> 16);
+      const uint32_t g = r[e] >> shift;
+      lo[e] = gd[g];
+      hi[e] = gd[g + 1];
+    }
+    if (LOCK) {   // global tables: the DPT searches advance together, DPT dependent L2 trips in flight per round
+      bool open = false;
+#pragma unroll
+      for (int e = 0; e < DPT; ++e) open |= lo[e] < hi[e];
+      while (open) {
+        int32_t mid[DPT], bv[DPT];
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+          mid[e] = (lo[e] + hi[e]) >> 1;   // a finished search has lo == hi: reads bound[lo], changes nothing
+          bv[e] = bnd[mid[e]];
+        }
+        open = false;
+#pragma unroll
+        for (int e = 0; e < DPT; ++e) {
+          const bool act = lo[e] < hi[e], up = (uint32_t)bv[e] > r[e];
+          hi[e] = (act && up) ? mid[e] : hi[e];
+          lo[e] = (act && !up) ? mid[e] + 1 : lo[e];
+          open |= lo[e] < hi[e];
+        }
+      }
+    } else {      // LDS tables: one search after the other -- lock-step issues a read per draw and round for every lane of the
+#pragma unroll    // wave, finished or not, and the LDS with its bank conflicts is the bound there (measured: 157 vs 138 us at 6.7e7 draws)
+      for (int e = 0; e < DPT; ++e) {
+        while (lo[e] < hi[e]) {
+          const int32_t mid = (lo[e] + hi[e]) >> 1;
+          if ((uint32_t)bnd[mid] > r[e]) hi[e] = mid; else lo[e] = mid + 1;
+        }
+      }
+    }
+    if (DPT == 1) {
+      out[j] = lo[0];
+      s = stride.a * s + stride.c;
+    } else if (e0 == 0 && j + DPT <= count) {
+      *reinterpret_cast<int4*>(out + j) = make_int4(lo[0], lo[1 % DPT], lo[2 % DPT], lo[3 % DPT]);
+      s = stride.a * s + stride.c;
+    } else {
+#pragma unroll
+      for (int k = 0; k < DPT; ++k)
+        if (k < DPT - e0 && j + e0 + k < count) out[j + e0 + k] = lo[k];
+      s = e0 ? jump((uint64_t)(first + j + TD + 1)) : stride.a * s + stride.c;
+      e0 = 0;
+    }
   }
 }
 
@@ -145,6 +233,9 @@ struct nncf_sampler {
   std::vector<int32_t> bound;  // host copy (nncf_sampler_bounds)
   int32_t* d_bound = nullptr;
   int32_t* d_guide = nullptr;
+  int n_guide = 0;
+  int32_t* d_guide_lds = nullptr;   // the coarser guide of the LDS-resident variant (NULL: the tables do not fit the LDS)
+  int shift_lds = 0, n_guide_lds = 0;
   int32_t* d_scratch = nullptr;  // staging for nncf_sampler_sample_batch
   int64_t scratch_cap = 0;
   JumpTable jt;
@@ -191,18 +282,39 @@ int nncf_sampler_create(const double* dist, int64_t n, double power, uint64_t se
   auto cleanup = [&](int code) {
     if (s->d_bound) (void)hipFree(s->d_bound);
     if (s->d_guide) (void)hipFree(s->d_guide);
+    if (s->d_guide_lds) (void)hipFree(s->d_guide_lds);
     delete s;
     return code;
   };
   if (guard.status != hipSuccess) return cleanup(fail(NNCF_ERR_HIP, "hipSetDevice(%d) failed", device));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->sm_count = prop.multiProcessorCount;
-  if (hipMalloc(&s->d_bound, sizeof(int32_t) * (size_t)n) != hipSuccess ||
-      hipMalloc(&s->d_guide, sizeof(int32_t) * guide.size()) != hipSuccess)
+  // device arrays padded to 16 bytes (the LDS variant copies them in 16-byte pieces)
+  const size_t nb4 = ((size_t)n + 3) & ~(size_t)3, ng4 = (guide.size() + 3) & ~(size_t)3;
+  s->n_guide = (int)guide.size();
+  if (hipMalloc(&s->d_bound, sizeof(int32_t) * nb4) != hipSuccess || hipMalloc(&s->d_guide, sizeof(int32_t) * ng4) != hipSuccess)
     return cleanup(fail(NNCF_ERR_NOMEM, "device allocation of sampler tables failed"));
-  if (hipMemcpy(s->d_bound, s->bound.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+  if (hipMemset(s->d_bound, 0, sizeof(int32_t) * nb4) != hipSuccess || hipMemset(s->d_guide, 0, sizeof(int32_t) * ng4) != hipSuccess ||
+      hipMemcpy(s->d_bound, s->bound.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(s->d_guide, guide.data(), sizeof(int32_t) * guide.size(), hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(fail(NNCF_ERR_HIP, "upload of sampler tables failed"));
+  // LDS-resident variant: bound[] + the finest guide that still fits kSamplerLds bytes next to it (at least 2^9 buckets)
+  {
+    int sh = s->shift;
+    auto guide_entries = [](int shf) { return (size_t)(((kTableSize - 1) >> shf) + 1) + 1; };
+    while (sh < 20 && (nb4 + ((guide_entries(sh) + 3) & ~(size_t)3)) * sizeof(int32_t) > kSamplerLds) ++sh;
+    if ((nb4 + ((guide_entries(sh) + 3) & ~(size_t)3)) * sizeof(int32_t) <= kSamplerLds && guide_entries(sh) >= 512) {
+      std::vector<int32_t> gl;
+      build_guide(s->bound, sh, gl);
+      const size_t gl4 = (gl.size() + 3) & ~(size_t)3;
+      if (hipMalloc(&s->d_guide_lds, sizeof(int32_t) * gl4) != hipSuccess) return cleanup(fail(NNCF_ERR_NOMEM, "device allocation of sampler tables failed"));
+      if (hipMemset(s->d_guide_lds, 0, sizeof(int32_t) * gl4) != hipSuccess ||
+          hipMemcpy(s->d_guide_lds, gl.data(), sizeof(int32_t) * gl.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(NNCF_ERR_HIP, "upload of sampler tables failed"));
+      s->shift_lds = sh;
+      s->n_guide_lds = (int)gl.size();
+    }
+  }
   *out = s;
   return NNCF_OK;
 }
@@ -211,6 +323,7 @@ int nncf_sampler_destroy(nncf_sampler* s) {
   if (!s) return NNCF_OK;
   if (s->d_bound) hipFree(s->d_bound);
   if (s->d_guide) hipFree(s->d_guide);
+  if (s->d_guide_lds) hipFree(s->d_guide_lds);
   if (s->d_scratch) hipFree(s->d_scratch);
   delete s;
   return NNCF_OK;
@@ -240,18 +353,44 @@ int nncf_sampler_sample_slice_dev(nncf_sampler* s, int64_t offset, int64_t count
   if (count == 0) return NNCF_OK;
   NNCF_REQUIRE(d_out != nullptr, "d_out is NULL");
   NNCF_REQUIRE((uint64_t)(offset + count) < (1ULL << 47), "batch too large");
-  const int threads = 256;
-  int64_t blocks = (count + threads - 1) / threads;
-  const int64_t cap = (int64_t)s->sm_count * 8;  // grid-stride beyond 8 blocks per CU
-  if (blocks > cap) blocks = cap;
-  const int64_t T = blocks * threads;
+  NNCF_REQUIRE((reinterpret_cast<uintptr_t>(d_out) & 3) == 0, "d_out must be 4-byte aligned");
+  // jump-ahead bits: a step's short batch (one draw per thread) jumps at most offset + count; the quad kernels' misaligned first
+  // quad re-jumps one grid stride further
+  const int64_t reach = offset + count + (count >= kSamplerQuadMinDraws ? (1 << 23) : 0);
   int nbits = 1;
-  while (nbits < 48 && ((uint64_t)(offset + count) >> nbits)) ++nbits;
-  const Affine stride = lcg_power((uint64_t)T);
-  {
+  while (nbits < 48 && ((uint64_t)reach >> nbits)) ++nbits;
+  static const bool no_lds = []() { const char* e = getenv("NNCF_SAMPLER_LDS"); return e && e[0] == '0'; }();
+  const bool use_lds = s->d_guide_lds != nullptr && count >= kSamplerLdsMinDraws && !no_lds;
+  if (use_lds) {
+    // one 1024-thread workgroup per CU, the tables in its LDS, every thread strides over the stream four draws at a time
+    const int threads = 1024;
+    int64_t blocks = (count + 3 + threads * 4 - 1) / (threads * 4);   // + 3: a misaligned start shifts the quads
+    if (blocks > s->sm_count) blocks = s->sm_count;
+    const Affine stride = lcg_power((uint64_t)(blocks * threads * 4));
+    const size_t lds = ((((size_t)s->n + 3) & ~(size_t)3) + (((size_t)s->n_guide_lds + 3) & ~(size_t)3)) * sizeof(int32_t);
+    static KernelDeviceState kst;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sample_kernel<true, 4, false>), kSamplerLds, kst)) return rc;
     ProfScope _ps("sample_kernel", as_stream(stream));
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound,
-                     s->d_guide, s->shift, s->state, offset, count, d_out, s->jt, nbits, stride);
+    hipLaunchKernelGGL((sample_kernel<true, 4, false>), dim3((unsigned)blocks), dim3(threads), lds, as_stream(stream), s->d_bound, s->d_guide_lds,
+                       s->shift_lds, (int)s->n, s->n_guide_lds, s->state, offset, count, d_out, s->jt, nbits, stride);
+  } else {
+    const int threads = 256;
+    const int dpt = count >= kSamplerQuadMinDraws ? 4 : 1;   // a step's batch: one draw per thread, the shortest chain
+    int64_t blocks = (count + (dpt - 1) + threads * dpt - 1) / (threads * dpt);
+    const int64_t cap = (int64_t)s->sm_count * 8;  // grid-stride beyond 8 blocks per CU
+    if (blocks > cap) blocks = cap;
+    const Affine stride = lcg_power((uint64_t)(blocks * threads * dpt));
+    ProfScope _ps("sample_kernel", as_stream(stream));
+    static const bool no_lock = []() { const char* e = getenv("NNCF_SAMPLER_LOCKSTEP"); return e && e[0] == '0'; }();   // developer A/B
+    if (dpt == 4 && !no_lock)
+      hipLaunchKernelGGL((sample_kernel<false, 4, true>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
+                         s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
+    else if (dpt == 4)
+      hipLaunchKernelGGL((sample_kernel<false, 4, false>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
+                         s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
+    else
+      hipLaunchKernelGGL((sample_kernel<false, 1, false>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
+                         s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

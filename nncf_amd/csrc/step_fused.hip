@@ -49,6 +49,10 @@ constexpr int kFDP = 128 + 4;      // LDS row pitch (floats): 16-byte rows; 4 ba
 constexpr int kFGP = kFNB + 4;     // pitch of the gradient tile
 constexpr int kFOP = 132;          // pitch of the output rows (16-byte aligned)
 constexpr int kFKeys = 128;        // positive-column keys of a workgroup's own rows held in LDS
+// z rows of a 16-lane group in flight in the statistics pass: 32 groups x 14 = 448 rows in ONE round of loads (a neg_shared batch
+// of 512 Zipf links holds ~420 unique items; group_neg_shared 125).  16 (512 rows) put the kernel at 264 live registers: 8-9
+// spilled to scratch (round 4's ISA audit), each reload a dependent trip in a chain-bound launch.
+constexpr int kStatRows = 14;
 
 __host__ __device__ constexpr size_t fused_lds_bytes() {
   return sizeof(float) * (kFM * kFDP + kFNB * kFDP + kFM * kFGP + 16 + 16 + 8 + 5 * 128) +
@@ -233,12 +237,12 @@ __device__ __forceinline__ void fused_body(const StepArgs& a, const int32_t* __r
       }
       const Row x0 = row_load(a.bn_z, 0, a.stride, d4, q);
       Row s1 = row_zero(), s2 = row_zero();
-      for (int r0 = g; r0 < nv; r0 += 32 * 16) {
-        Row z[16];
+      for (int r0 = g; r0 < nv; r0 += 32 * kStatRows) {
+        Row z[kStatRows];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
+        for (int e = 0; e < kStatRows; ++e) z[e] = (r0 + 32 * e < nv) ? row_load(a.bn_z, r0 + 32 * e, a.stride, d4, q) : x0;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {  // shifted sums (shift = row 0): no cancellation
+        for (int e = 0; e < kStatRows; ++e) {  // shifted sums (shift = row 0): no cancellation
           const float4 da = make_float4(z[e].a.x - x0.a.x, z[e].a.y - x0.a.y, z[e].a.z - x0.a.z, z[e].a.w - x0.a.w);
           const float4 db = make_float4(z[e].b.x - x0.b.x, z[e].b.y - x0.b.y, z[e].b.z - x0.b.z, z[e].b.w - x0.b.w);
           s1.a = add4(s1.a, da);

@@ -53,7 +53,17 @@ struct CnnArgs {
   int fold;                  // blocks of <= kCnnFoldRows rows: cnn_pool_dense merges the forward's statistics partials itself and
                              // cnn_conv_bwd the BatchNorm backward's sums (no cnn_stats / cnn_merge launch); workgroup 0 publishes st1
   long long gexp_off;        // this bank's [Wk | bc, g1, b1 (128 each)] block in the flat gradient, from the start of the conv section
+  // Round 5: the backward takes the forward's index and runs over WORK UNITS (cnn.hip).
+  int4* idx;                 // [cap][kCnnIdxInt4] the ItemIdx a forward workgroup built for slot s (this step's dropout mask), verbatim
+  int* nck;                  // [cap] kept distinct words of slot s
+  int4* units;               // [cap + capx_cap] {slot, first word | end word << 16, dWk block, second half?}, heaviest first (cnn_units_build)
+  int* split;                // [0] units, [1] items split in two
+  int capx;                  // this call: at most this many items are split (0: one unit per slot, in slot order, `units` unused)
+  int split_words;           // an item with more kept words than this is split along its words over two workgroups
+  int gcap;                  // dWk blocks per element group in gWpart (cap + capx_cap)
 };
+constexpr int kCnnIdxInt4 = 226;   // sizeof(ItemIdx) / 16 (cnn.hip static_asserts it)
+__host__ __device__ inline int cnn_capx_cap(int cap) { return (cap < 512 ? cap : 512) / 2; }
 constexpr int kCnnFoldRows = 512;
 constexpr int kCnnMergeWG = 32;   // workgroups of cnn_stats / cnn_merge on such blocks: one compute unit reads 2,700 slots' partials at
                                   // ~25 GB/s (122 us); 32 read them in parallel and the last to arrive adds the 32 rows
@@ -234,7 +244,9 @@ constexpr int kCnnUpdGroups = 512 / kCnnUpdElems;     // part-groups (one wave e
 __host__ __device__ inline int cnn_update_blocks(int nel) { return (nel + kCnnUpdElems - 1) / kCnnUpdElems + 1; }
 __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, float* sG) {
   const int F = a.cnn.F, fl = a.cnn.fl, nel = fl * a.wd * F;
-  const int nparts = valid_rows(a);  // one dWk block per slot [0, n_valid), contiguous
+  // one dWk block per slot [0, n_valid) + one per item the backward split in two (cnn_units_build), contiguous, summed in that order
+  const int nv_ = valid_rows(a);
+  const int nparts = nv_ + (a.cnn.capx ? a.cnn.split[1] : 0);
   const int nb = (nel + kCnnUpdElems - 1) / kCnnUpdElems;
   if (blk < nb) {
     const int c = threadIdx.x & (kCnnUpdElems - 1), g = threadIdx.x / kCnnUpdElems;
@@ -246,7 +258,7 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           u[e] = (p0 + kCnnUpdGroups * e < nparts)
-                     ? a.cnn.gWpart[((int64_t)blk * a.cap + (p0 + kCnnUpdGroups * e)) * kCnnUpdElems + c] : 0.f;
+                     ? a.cnn.gWpart[((int64_t)blk * a.cnn.gcap + (p0 + kCnnUpdGroups * e)) * kCnnUpdElems + c] : 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc += u[e];
       }
@@ -271,10 +283,10 @@ __device__ __forceinline__ void cnn_update_block(const TowerArgs& a, int blk, fl
   // the last block: conv bias and BN1 scale / shift (<= 128 columns): four part-groups of 128 lanes
   const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
   float acc = 0.f;
-  for (int p0 = g; p0 < nparts; p0 += 4 * 16) {   // 16 loads in flight: a load per iteration made this ONE workgroup the
-    float u[16];                                    // launch's long pole (62 dependent trips to memory, ~19 us)
+  for (int p0 = g; p0 < nv_; p0 += 4 * 16) {   // 16 loads in flight: a load per iteration made this ONE workgroup the
+    float u[16];                                 // launch's long pole (62 dependent trips to memory, ~19 us)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) u[e] = (p0 + 4 * e < nparts) ? a.cnn.gbpart[(int64_t)(p0 + 4 * e) * 128 + c] : 0.f;
+    for (int e = 0; e < 16; ++e) u[e] = (p0 + 4 * e < nv_) ? a.cnn.gbpart[(int64_t)(p0 + 4 * e) * 128 + c] : 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc += u[e];
   }

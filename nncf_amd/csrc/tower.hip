@@ -1531,7 +1531,7 @@ int nncf_tower_destroy(nncf_tower* t) {
 int nncf_tower_debug_stamps(nncf_tower* t, long long* out_host, int64_t n) {
   NNCF_REQUIRE(t != nullptr && out_host != nullptr, "tower / output is NULL");
   NNCF_REQUIRE(t->cnn.F > 0 && (t->cnn.dbg & 64), "not a CNN tower created with NNCF_CNN_DBG=64");
-  NNCF_REQUIRE(n >= 0 && n <= (int64_t)2 * t->cfg.max_rows * t->cnn.np * 16, "more stamps requested than the tower holds");
+  NNCF_REQUIRE(n >= 0 && n <= (int64_t)2 * t->cnn.gcap * t->cnn.np * 16, "more stamps requested than the tower holds");
   NNCF_HIP_CHECK(hipMemcpy(out_host, t->cnn.stamps, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost));
   return NNCF_OK;
 }

@@ -35,6 +35,7 @@ all-reduce.  The exchange logic is backend-agnostic: `HipBackend` runs the kerne
 backend and run the same code over gloo on CPU; with a gloo process group and CUDA tensors the payloads are staged
 through host memory (two ranks sharing one GPU in the tests).
 """
+import contextlib
 import ctypes
 import os
 
@@ -332,9 +333,15 @@ class Communicator(object):
             _lib.check(L.nncf_comm_unique_id(buf))
         box = [bytes(buf.raw)]
         if world > 1:
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            # broadcast_object_list over nccl stages through the CURRENT device: make it this rank's own
+            ctx = torch.cuda.device(torch.device(device)) if torch.device(device).type == "cuda" and torch.device(device).index is not None \
+                else contextlib.nullcontext()
+            with ctx:
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         h = ctypes.c_void_p()
-        idx = torch.device(device).index or 0
+        idx = torch.device(device).index
+        if idx is None:                      # 'cuda' without an index means the CURRENT device, not device 0
+            idx = torch.cuda.current_device()
         _lib.check(L.nncf_comm_create(ctypes.c_char_p(box[0]), world, rank, idx, ctypes.byref(h)))
         return cls(h, "rccl")
 
@@ -402,10 +409,20 @@ class Communicator(object):
             pass
 
 
+def _default_transport(native_ok, backend, world):
+    """native (RCCL issued by the library) only where it has run on hardware: one nccl rank.  Two or more ranks take torch's
+    collectives unless NNCF_SHARD_TRANSPORT=native opts in (the peer-to-peer variable-split exchange between
+    distinct GPUs has never executed)."""
+    return "native" if (native_ok and backend == "nccl" and world == 1) else "torch"
+
+
 class _Exchanger(object):
     """all-to-alls of one rank's trainer.  Transports (NNCF_SHARD_TRANSPORT overrides the choice):
       native    the library issues every exchange itself over RCCL, one native call per 64-step chunk (nncf_shard_run_chunk over
-                a Communicator.rccl): the default whenever the process group's backend is nccl and the backend is the HIP one
+                a Communicator.rccl).  Default for ONE nccl rank (the hardware-tested case: NNCF_SHARD_NOALIAS=1); with two or
+                more ranks it is OPT-IN (NNCF_SHARD_TRANSPORT=native) until a multi-GPU box has run the two-rank parity tests
+                over it -- no such box has been available to the build, and an untested peer-to-peer path must
+                not be the one a first multi-GPU run takes silently
       callback  the same native call sequence over Communicator.callback (gloo + host staging): two ranks on one GPU
       torch     this module issues torch.distributed collectives between the library's calls: the process group's own
                 transport for device tensors (nccl), host staging for a gloo group; the numpy backends of the CPU tests
@@ -423,9 +440,11 @@ class _Exchanger(object):
         want = os.environ.get("NNCF_SHARD_TRANSPORT", "")
         if want not in ("", "native", "callback", "torch"):
             raise ValueError("NNCF_SHARD_TRANSPORT must be native, callback or torch")
-        self.transport = want or ("native" if (native_ok and backend == "nccl") else "torch")
+        self.transport = want or _default_transport(native_ok, backend, self.world)
         if self.transport != "torch" and not native_ok:
             raise ValueError("NNCF_SHARD_TRANSPORT=%s needs the HIP backend" % self.transport)
+        if self.transport == "native" and backend != "nccl":
+            raise ValueError("NNCF_SHARD_TRANSPORT=native needs an nccl process group (got %r)" % (backend,))
         self.comm = None
 
     @property
@@ -664,7 +683,13 @@ class DataParallelTower(object):
         backend = dist.get_backend(group) if dist.is_initialized() else None
         hip = hasattr(replica, "tower")            # HipTowerReplica (the numpy replicas of the CPU tests have no device)
         want = os.environ.get("NNCF_SHARD_TRANSPORT", "")
-        self.transport = want or ("native" if (hip and backend == "nccl") else "torch")
+        if want not in ("", "native", "callback", "torch"):
+            raise ValueError("NNCF_SHARD_TRANSPORT must be native, callback or torch")
+        self.transport = want or _default_transport(hip, backend, self.world)
+        if self.transport != "torch" and not hip:
+            raise ValueError("NNCF_SHARD_TRANSPORT=%s needs the HIP backend" % self.transport)
+        if self.transport == "native" and backend != "nccl":
+            raise ValueError("NNCF_SHARD_TRANSPORT=native needs an nccl process group (got %r)" % (backend,))
         # one rank has nothing to reduce -- unless NNCF_SHARD_NOALIAS=1 asks that ONE rank to drive the real collective
         self.reduce = self.world > 1 or (dist.is_initialized() and os.environ.get("NNCF_SHARD_NOALIAS", "0") not in ("", "0"))
         self.comm = None

@@ -1,0 +1,45 @@
+"""CPU: register / scratch audit of the shipped code objects (tools/isa_resources.py).
+
+VERDICT r4: several hot kernels spilled VGPRs to scratch without the design saying so; in a chain-bound kernel every
+scratch reload is one more dependent trip.  This test reads the gfx950 code objects out of nncf_amd/libnncf_hip.so (no
+recompilation, no GPU) and fails when a kernel of a DEFAULT path spills a vector register.  Kernels that are reachable
+only through a developer switch are listed in OPT_IN with the switch that selects them."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_resources  # noqa: E402
+
+# kernel-name patterns that no default path launches, and why
+OPT_IN = [
+    (r"rocprim::", "rocPRIM's radix sort (device shuffle): library code, its private segment is the sort's own"),
+]
+
+
+@pytest.fixture(scope="module")
+def rows():
+    return isa_resources.audit()
+
+
+def test_every_kernel_of_the_library_is_listed(rows):
+    names = " ".join(r["name"] for r in rows)
+    for k in ("sample_kernel", "fused_strip_kernel", "fused_wide_kernel", "pair_wide_kernel", "shared_tile_kernel", "cnn_conv_fwd_kernel",
+              "cnn_conv_bwd_kernel", "tower_pool_kernel", "tower_word_kernel", "tower_bwd_kernel", "eval_topk_kernel", "plan"):
+        assert k in names, k
+    assert len(rows) > 150
+
+
+def test_no_default_path_kernel_spills_vector_registers(rows):
+    bad = []
+    for r in rows:
+        if any(re.search(p, r["name"]) for p, _ in OPT_IN):
+            continue
+        if r.get("vgpr_spill_count", 0) or r.get("scratch_loads", 0) or r.get("scratch_stores", 0):
+            bad.append("%s: %d VGPRs spilled, %d scratch loads / %d stores, %d B private" % (
+                r["name"], r.get("vgpr_spill_count", 0), r.get("scratch_loads", 0), r.get("scratch_stores", 0),
+                r.get("private_segment_fixed_size", 0)))
+    assert not bad, "kernels that spill:\n" + "\n".join(bad)

@@ -116,3 +116,33 @@ def test_sampler_argument_errors():
         ns.build_bounds(np.zeros(5))  # nothing to sample (reference: undefined behaviour)
     with pytest.raises(ValueError):
         ns.build_bounds(np.array([1., -2.]))
+
+
+def test_multiply_high_modulo_is_the_percent_operator():
+    """csrc/sampler.hip mod_table: r = x mod 1e8 for x < 2^48 as x - ((x * ceil(2^75 / 1e8)) >> 75) * 1e8 in the low 32
+    bits -- what replaces the software 64-bit `%` of nodesampler.cpp:25.  Exactness on the corner cases (every multiple of
+    1e8 and its neighbours at both ends of the 48-bit range) and on random states; the kernel itself is pinned by the golden
+    streams and the SHA-256 of 10^7 draws (tests/test_sampler_gpu.py)."""
+    D, M = 10 ** 8, -(-2 ** 75 // 10 ** 8)
+    assert M == 377789318629572 and 2 ** 75 <= M * D < 2 ** 75 + 2 ** 27
+
+    def mod_table(x):
+        q = (x * M) >> 75
+        return ((x & 0xFFFFFFFF) - ((q & 0xFFFFFFFF) * D & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+    top = 2 ** 48 - 1
+    corners = [0, 1, D - 1, D, D + 1, top, top - 1]
+    for k in list(range(1, 2000)) + list(range(top // D - 2000, top // D + 1)):
+        corners += [k * D - 1, k * D, k * D + 1]
+    for x in corners:
+        if 0 <= x <= top:
+            assert mod_table(x) == x % D, x
+    rs = np.random.RandomState(0)
+    state = 12345
+    for _ in range(200000):   # states of the reference's own LCG (nodesampler.cpp:24)
+        state = (state * 25214903917 + 11) & (2 ** 64 - 1)
+        x = state >> 16
+        assert mod_table(x) == x % D
+    xs = (rs.randint(0, 2 ** 24, size=300000).astype(object) << 24) | rs.randint(0, 2 ** 24, size=300000).astype(object)
+    for x in xs:
+        assert mod_table(int(x)) == int(x) % D

@@ -96,6 +96,32 @@ def test_large_vocab_guide_path():
     o.close()
 
 
+def test_lds_resident_tables_and_misaligned_outputs_give_the_same_stream():
+    """Round 5: long streams run with bound[] + a coarser guide in LDS (sample_kernel<true>), four draws per thread and
+    16-byte stores; an output that does not start on 16 bytes shifts the quads.  Every variant is the oracle's stream."""
+    import torch
+    rs = np.random.RandomState(3)
+    dist = (rs.zipf(1.3, 17000) % 5000 + 1).astype(np.float64)
+    n = (1 << 20) + 37
+    o = so.OracleSampler(dist, 1.0, 999)
+    want = o.sample_batch(n)
+    o.close()
+    s = MultinomialSampler(dist, dist.size, 1.0, 999)
+    buf = torch.full((n + 8,), -7, dtype=torch.int32, device="cuda")
+    for off in (0, 1, 2, 3):
+        buf.fill_(-7)
+        s.sample_slice_device(0, n, out=buf[off:off + n])
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[off:off + n], want), off
+        assert (got[:off] == -7).all() and (got[off + n:] == -7).all(), off   # nothing written outside the slice
+    # a slice in the middle of the stream, LDS variant (>= 2^19 draws) and global-table variant (short)
+    for lo, cnt in ((12345, 1 << 19), (5, (1 << 17) + 1), (777, 5000), (3, 1), (1 << 19, 3)):
+        for off in (0, 3):
+            got = s.sample_slice_device(lo, cnt, out=buf[off:off + cnt]).cpu().numpy()
+            assert np.array_equal(got, want[lo:lo + cnt]), (lo, cnt, off)
+    s.close()
+
+
 def test_seed_zero_is_time_seeded():
     dist = np.ones(10)
     s = MultinomialSampler(dist, 10, 1.0, 0)

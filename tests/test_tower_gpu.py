@@ -357,10 +357,13 @@ CNN_PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta", "rm", "r
                                                  ("original", "skip-gram", 3, False),
                                                  ("group_neg_shared", "max-margin", 3, True)])
 @pytest.mark.parametrize("pool", ["average", "max"])
-def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop, pool):
+@pytest.mark.parametrize("split", [0, 12])
+def test_cnn_embedding_steps_match_oracle(text_data, scheme, loss, fl, drop, pool, split, monkeypatch):
     """cnn_embedding (conv + BN + relu + dropout + average | max pooling over the whole length, cnn_model.py:100-109, in
     front of Dense/BN/ReLU) against CnnTowerOracle: loss, every parameter and the running statistics after each step; the
-    kernels' row-dropout and conv-dropout hash masks are materialised and fed to the oracle."""
+    kernels' row-dropout and conv-dropout hash masks are materialised and fed to the oracle.  split: NNCF_CNN_SPLIT -- the conv
+    backward over work units (items with more kept words cut in two, heaviest first: csrc/cnn.hip cnn_units_build)."""
+    monkeypatch.setenv("NNCF_CNN_SPLIT", str(split))
     conf = _conf_cnn(loss, scheme, fl=fl, wdrop=0.3 if drop else 0.0, cdrop=0.2 if drop else 0.0)
     conf.poolings = [pool]
     helper = get_data(dict(text_data), conf, rand_seed=5)

@@ -31,13 +31,14 @@ for _ in range(5):
 torch.cuda.synchronize()
 ngrp = (((tw.F + 15) // 16) + 1) // 2
 print('F', tw.F, 'fl', tw.filter_lens, 'groups', ngrp, 'cap', tw.cap)
-n = 2 * tw.cap * ngrp * 16
+ucap = tw.cap + min(tw.cap, 512) // 2   # slots + split halves (cnn_units_build)
+n = 2 * ucap * ngrp * 16
 out = np.zeros(n, dtype=np.int64)
 _lib.check(tw._L.nncf_tower_debug_stamps(tw.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), out.size))
-st = out.reshape(2, tw.cap * ngrp, 16)
-nwg = 125 * ngrp
+st = out.reshape(2, ucap * ngrp, 16)
+nwg = ucap * ngrp
 names = [["start", "index", "rows->LDS", "P gemm", "assembly", "Y stores", "stats"],
-         ["start", "index", "dY tile", "rows + S", "(a) dW rows", "(b) dWk", "stores"]]
+         ["start", "index", "dY tile", "rows + S", "(b) dWk", "(a) dW rows", "stores"]]
 for k, kn in enumerate(("cnn_conv_fwd", "cnn_conv_bwd")):
     raw = st[k, :nwg, :7]
     raw = raw[raw[:, 0] != 0]
