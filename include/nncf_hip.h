@@ -522,6 +522,17 @@ int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, i
                    const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
                    int32_t* d_valid, void* stream);
 
+/* The same evaluation without the score matrix (round 5): test_eval_mat + evaluate_mat (utils/objectives.py:296-370) and
+ * eval_multiple (utils/metrics_ranking.py:6-35) in ONE kernel.  Users d_uid[n_users] (rows of the model's user table) are
+ * scored against the candidate items d_cand[n_cand] (rows of its item table; slot j of the truth CSR = d_cand[j]) with the
+ * arithmetic of nncf_predict_scores -- normalisation, InteractionDot bias, fp32 matrix products in the same order -- and every
+ * user keeps its k best in on-chip lists: d_metrics / d_valid come out bit-identical to nncf_predict_scores followed by
+ * nncf_eval_topk (ties to the lower slot included), nothing of size users x candidates is ever stored, any n_cand.
+ * Limits: topk <= 128 (beyond: the two calls above). */
+int nncf_eval_whole(nncf_model* m, const int32_t* d_uid, int64_t n_users, const int32_t* d_cand, int32_t n_cand,
+                    const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
+                    int32_t* d_valid, void* stream);
+
 /* Row movers and routing of the sharded path (no reference counterpart).
  * nncf_shard_route: for a batch's item ids d_cid[n], with item rows owned by rank id / item_shard:
  *   d_req[n_ranks][cap] = the unique ids to request from each owner (ascending, -1 padded) and

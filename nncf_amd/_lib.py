@@ -176,6 +176,7 @@ def _declare(lib):
         "nncf_group_sample": [vp, i64, i32, vp, vp, u64, i32, vp, vp, vp],
         "nncf_group_sample_with_negs": [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, u64, i32, i32, vp, vp, vp, vp, vp],
         "nncf_eval_topk": [vp, i64, i64, i32, vp, vp, i32, vp, vp, vp],
+        "nncf_eval_whole": [vp, vp, i64, vp, i32, vp, vp, i32, vp, vp, vp],
         "nncf_plan_ids": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     })
     for name, args in sig.items():

@@ -708,10 +708,12 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
 // stage), L2 traffic per step drops by MT, and the element-wise dL/dS of tile m is independent of the MFMAs of
 // tile m + 1 (VALU under the matrix pipe).  No BatchNorm fusion and no split: the text towers cap the batch at
 // 1024 and 2 b / (16 MT) >= 256 workgroups already.
-template <int MT>
+// GROUP: + the user strips' positive-count tile [16 MT][kMP] of 16-bit counts (below)
+constexpr int kMP = 132;   // pitch in 16-bit cells: rows 4 apart are 8 banks apart -- the element-wise reads do not collide
+template <int MT, bool GROUP>
 __host__ __device__ constexpr size_t wide_lds_bytes() {
   return sizeof(float) * (16 * MT * kFDP + kFNB * kFDP + 16 * MT * kFGP + 16 * MT + 16 * MT + 8) +
-         sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4);
+         sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4) + (GROUP ? sizeof(uint16_t) * 16 * MT * kMP : 0);
 }
 
 template <int NG, int MT>
@@ -751,6 +753,13 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   int* sKeyStart = sKeys + kFKeys * MT;     // [OWN]
   int* sKeyCnt = sKeyStart + OWN;           // [OWN]
   int* sTop = sKeyCnt + OWN;                // [4]
+  // group_neg_shared, user strips: a user's positions hold SEVERAL positive columns (one per position: the rank of its item).
+  // Round 4 kept the key lists' (start, count) of a lane's 4 MT rows in registers and searched a list per ELEMENT in a loop of
+  // data-dependent length: 32 more registers than the budget (48-160 spilled at MT = 4) and no software pipelining.  Now the
+  // stage's positives are scattered once into a tile of 16-bit counts m[own row][column of the stage] (LDS integer atomics:
+  // order-free), and the element-wise block reads m like any other operand.
+  constexpr bool CM = GROUP && USIDE;
+  uint16_t* sM = reinterpret_cast<uint16_t*>(sTop + 4);   // [OWN][kMP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tid >> 4, q = tid & 15;
@@ -766,7 +775,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   auto opp_id = [&](int j) -> int { return USIDE ? (GROUP ? pv.uniq[j] : cid[j]) : uid[j]; };
   auto opp_key = [&](int j) -> int { return USIDE ? (GROUP ? j : pu.inverse[j]) : pv.inverse[j]; };
   const int nst = (n_opp + kFNB - 1) / kFNB;
-  int idA[4], keyA[4], idB[4], keyB[4];
+  int idA[4], keyA[4];   // ids / keys of the NEXT stage: requested under one stage's back-GEMM, used under the next one's
   auto load_ids = [&](int st, int* ids, int* keys) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -777,7 +786,6 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
   };
   load_ids(0, idA, keyA);
-  load_ids(1, idB, keyB);
   __syncthreads();
 
   Row rcur[4], rnext[4];
@@ -789,12 +797,8 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   };
   load_rows(idA, rcur);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    kcur[e] = keyA[e];
-    idA[e] = idB[e];
-    keyA[e] = keyB[e];
-  }
-  load_ids(2, idB, keyB);
+  for (int e = 0; e < 4; ++e) kcur[e] = keyA[e];
+  load_ids(1, idA, keyA);
 
   // ---- own rows: 16 MT unique ids of this side; only LDS keeps them across the stages (the finalize re-reads
   // the raw row: nobody else writes it) ------------------------------------------------------------------------
@@ -861,19 +865,36 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
       }
     }
   }
+  auto m_zero = [&]() {
+    if (CM)
+      for (int i = tid; i < OWN * kMP / 2; i += 512) reinterpret_cast<uint32_t*>(sM)[i] = 0u;
+  };
+  auto m_scatter = [&](int st) {   // every position of this strip's users whose item is a column of stage st
+    if (!CM) return;
+#pragma unroll
+    for (int rr = 0; rr < RPG; ++rr) {
+      const int o = g + 32 * rr;
+      if (o < OWN) {
+        const int ks = sKeyStart[o], kc = sKeyCnt[o], n = kc < 0 ? -kc : kc;
+        for (int t = q; t < n; t += 16) {
+          const int key = kc >= 0 ? sKeys[ks + t] : pv.inverse[pu.order[ks + t]];   // (a list that did not fit the LDS: from the plan)
+          if ((key >> 7) == st) atomicAdd(reinterpret_cast<unsigned*>(sM) + ((o * kMP + (key & 127)) >> 1), 1u << (16 * (key & 1)));
+        }
+      }
+    }
+  };
+  m_zero();
   __syncthreads();
   const int x = lane & 15, kq = lane >> 4;
   float cnt_r[MT][4];
-  int ks_r[MT][4], kc_r[MT][4];
+  int ks_r[MT][4];   // the single positive column of a row (every case but the user strips of group_neg_shared)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * mt + 4 * kq + r;
       cnt_r[mt][r] = sCnt[i];
-      ks_r[mt][r] = sKeyStart[i];
-      kc_r[mt][r] = sKeyCnt[i];
-      if (!(GROUP && USIDE)) ks_r[mt][r] = (kc_r[mt][r] > 0) ? sKeys[ks_r[mt][r]] : -2;
+      ks_r[mt][r] = (!CM && sKeyCnt[i] > 0) ? sKeys[sKeyStart[i]] : -2;
     }
 
   FSTAMP(3);
@@ -900,17 +921,10 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
       else lds_store_row_f(sOpp + (g + 32 * e) * kFDP, q, r);
       if (q == 0) sOppKey[g + 32 * e] = kcur[e];
     }
+    m_scatter(st);   // (the tile was zeroed a barrier ago)
     __syncthreads();
     if (last_stage && tid == 0) readers_arrive(f);
     if (st < 4) FSTAMP(5 + 4 * st);
-    load_rows(idA, rnext);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      kcur[e] = keyA[e];
-      idA[e] = idB[e];
-      keyA[e] = keyB[e];
-    }
-    load_ids(st + 3, idB, keyB);
 
     // S tiles and dL/dS, software-pipelined: the MFMAs of tile m + 1 are issued before the element-wise work of
     // tile m (VALU / transcendental under the matrix pipe; one basic block for the pointwise non-group case).
@@ -958,17 +972,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           const int i = 16 * mt + 4 * kq + r;
           const float sc = acc[r];
           const float c = cnt_r[mt][r];
-          float m = 0.f;
-          if (!(GROUP && USIDE)) {
-            m = (ks_r[mt][r] == okey) ? 1.f : 0.f;
-          } else {
-            const int ks = ks_r[mt][r], kc = kc_r[mt][r];
-            if (kc >= 0) {
-              for (int t = 0; t < kc; ++t) m += (sKeys[ks + t] == okey) ? 1.f : 0.f;
-            } else {
-              for (int t = 0; t < -kc; ++t) m += (pv.inverse[pu.order[ks + t]] == okey) ? 1.f : 0.f;
-            }
-          }
+          const float m = CM ? (float)sM[i * kMP + j] : (ks_r[mt][r] == okey) ? 1.f : 0.f;
           float l, h;
           if (LOSS == NNCF_LOSS_SKIP_GRAM) {
             // label -1 off the positive: softplus(s); label +1: softplus(-s); one exponential for both, no branch
@@ -999,8 +1003,8 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           }
           lsum += l;
         }
-        if (mt + 1 < MT && !(GROUP && USIDE)) {
-#pragma unroll
+        if (mt + 1 < MT && LOSS == NNCF_LOSS_SKIP_GRAM) {   // (mse has a third of the element-wise work: forcing this interleave on it
+#pragma unroll                                           // only lengthens live ranges -- 10-21 registers spilled at MT = 4)
           for (int t = 0; t < 32; ++t) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU of the previous tile's dL/dS
@@ -1011,8 +1015,16 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
     if (st < 4) FSTAMP(6 + 4 * st);
     __syncthreads();
+    m_zero();        // for the next stage's scatter (behind the barrier that closes this stage)
     if (last_stage && tid == 0) seen = readers_seen(f);
     if (st < 4) FSTAMP(7 + 4 * st);
+    // the next stage's rows (their ids arrived a stage ago) and the ids of the stage after it are requested HERE, under the
+    // back-GEMM -- not at the top of the stage: 32 registers of rows in flight across the S + dL/dS block (two operand
+    // fragment sets, MT key lists) were what pushed the MT = 4 instantiations past 256 registers (round 5 audit: 14-160 spilled)
+    load_rows(idA, rnext);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kcur[e] = keyA[e];   // (this stage's keys went to LDS at its top)
+    load_ids(st + 2, idA, keyA);
     if (back_wave && H16) {
       // dOwn[own][col] += G[own][j] . Opp[j][col] over the stage's 128 opposite rows in four k-steps of 32: the lane (col x, kq) gathers
       // column 16 wave + x of rows 32 t + 8 kq + e (hi and lo planes: 16 two-byte reads); accD0: hi.hi, accD1: the cross terms
@@ -1229,13 +1241,14 @@ int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT, H16>;
   static KernelDeviceState kds;
   int capacity = 0;
-  if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), wide_lds_bytes<MT>(), kds, &capacity)) return rc;
+  constexpr size_t lds = wide_lds_bytes<MT, GROUP>();
+  if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), lds, kds, &capacity)) return rc;
   FusedArgs fa = f;
   // in place (with the hand-shake) only when the whole grid is resident at once on a device this model has to itself
   if (!(update && (2 * gu > capacity || f.shared_device || force_deferred()))) fa.stage = nullptr;
   {
     ProfScope _ps("fused_wide_kernel", stream);
-    hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), wide_lds_bytes<MT>(), stream, a, uid, cid, fa, pu, pv, update, gu);
+    hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), lds, stream, a, uid, cid, fa, pu, pv, update, gu);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return fa.stage ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;

@@ -647,7 +647,7 @@ constexpr int kRowsInFlight = 8;
 // postings order (ascending item id) per wave, the waves' stripes in wave order: fixed order, no atomics.  Hot words are skipped
 // (their partial rows come from tower_bwd_kernel), dropped words too (no cell was ever written for them in the dense mode either).
 template <bool CNN, bool MAXP = false, int NB = 1, bool PM = false>
-__global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
+__global__ void __launch_bounds__(512, (CNN || MAXP) ? 6 : 8) tower_word_kernel(TowerArgs a, int ks, int nfused, float lr_over_L) {
   __shared__ int sList[8 * kListCap];
   __shared__ float2 sAccW[8 * kWordsPerWG * 64];  // [wave][word][lane]
   __shared__ int sHit[kWordsPerWG];
@@ -720,8 +720,11 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
     my_nu = u.w;
     my_w = (u.x >= 0 && u.w > 0) ? u.x : a.n_words;
   }
-  float2 wold = make_float2(0.f, 0.f);
-  if (my_w < a.n_words && lane < d2) wold = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
+  // the word's row: requested here and used at the very end -- except in postings mode, whose walk has no register left to
+  // keep it in (it was spilled to scratch and reloaded: round 5 audit); there it is requested behind the walk, in front of
+  // the barrier that closes it
+  float2 wold_early = make_float2(0.f, 0.f);
+  if (!PM && my_w < a.n_words && lane < d2) wold_early = reinterpret_cast<const float2*>(a.W + (int64_t)my_w * a.wd)[lane];
   if (tid < kWordsPerWG) sHit[tid] = 0;
   float2* accw = sAccW + wave * kWordsPerWG * 64;
 #pragma unroll
@@ -750,6 +753,10 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
           pend[j] = u.z;
         }
       }
+      // workgroup-uniform (the unit table and the dropout hash of a word are): scalar registers -- as sixteen VECTOR registers
+      // they were what the 64-register budget of four workgroups per CU lacked (4 spilled to scratch: round 5 audit)
+      pbeg[j] = __builtin_amdgcn_readfirstlane(pbeg[j]);
+      pend[j] = __builtin_amdgcn_readfirstlane(pend[j]);
       rounds = max(rounds, (pend[j] - pbeg[j] + 511) >> 9);
     }
   }
@@ -917,26 +924,22 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
       cnt = 0;
     };
     for (int r = 0; r < rounds; ++r) {
-      int it[kWordsPerWG];
-      unsigned cb[kWordsPerWG];
+      unsigned pk[kWordsPerWG];   // item | count << 24 (all ones: no entry) -- the packed word is what stays in registers
       int2 sv[kWordsPerWG];
 #pragma unroll
       for (int j = 0; j < kWordsPerWG; ++j) {
         const int e = pbeg[j] + 512 * r + 64 * wave + lane;
-        const bool ok = e < pend[j];
-        const unsigned pk = ok ? a.post_item[e] : 0xFFFFFFFFu;   // item | count << 24
-        it[j] = ok ? (int)(pk & 0xFFFFFFu) : -1;
-        cb[j] = ok ? pk >> 24 : 0u;
+        pk[j] = e < pend[j] ? a.post_item[e] : 0xFFFFFFFFu;
       }
 #pragma unroll
-      for (int j = 0; j < kWordsPerWG; ++j) sv[j] = it[j] >= 0 ? a.slot_of[it[j]] : make_int2(0, 0);
+      for (int j = 0; j < kWordsPerWG; ++j) sv[j] = pk[j] != 0xFFFFFFFFu ? a.slot_of[pk[j] & 0xFFFFFFu] : make_int2(0, 0);
 #pragma unroll
       for (int j = 0; j < kWordsPerWG; ++j) {
-        const bool hit = it[j] >= 0 && sv[j].x == a.pm_stamp && sv[j].y < n;
+        const bool hit = pk[j] != 0xFFFFFFFFu && sv[j].x == a.pm_stamp && sv[j].y < n;
         const unsigned long long mask = __ballot(hit);
         const int pc = __popcll(mask);
         if (cnt + pc > kListCap) drain();
-        if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (sv[j].y << 8) | (int)cb[j];
+        if (hit) list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (j << 24) | (sv[j].y << 8) | (int)(pk[j] >> 24);
         if (mask && lane == 0) sHit[j] = 1;
         cnt += pc;
       }
@@ -951,7 +954,20 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
     for (int j = 0; j < kWordsPerWG; ++j)
       if (bits & (1u << j)) a.cnt_t[(int64_t)(bid + j * G) * a.cap + slot] = 0;
   }
+  // postings mode: the row travels straight into LDS (global_load_lds: no destination register to keep alive or to spill) --
+  // into this wave's list, which the walk above has finished with: [x of the 64 lanes][y of the 64 lanes]
+  if (PM && my_w < a.n_words && lane < d2) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* src = a.W + (int64_t)my_w * a.wd + 2 * lane;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)list, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + 1), (lptr_t)(list + 64), 4, 0, 0);
+  }
   __syncthreads();
+  // the tail's own copy of the lane index, formed here: the one from the kernel's top (zero-extended for 64-bit addresses)
+  // was what the postings instantiation spilled to scratch across the walk and reloaded nine times down here (round 5 audit)
+  int lane_e = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_e));
   // hot word: its cells were consumed by tower_bwd_kernel's role-A workgroups, which left one partial row each
   int hot_h = -1, hot_cells = 0;
   if (!CNN && !MAXP && a.n_hot > 0 && my_w < a.n_words) {
@@ -959,21 +975,21 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
       if (a.hot[h] == my_w) hot_h = h;
     if (hot_h >= 0) {
       const int np = (n + 15) >> 4;
-      for (int p = lane; p < np; p += 64) hot_cells += a.hot_cnt[(int64_t)p * kHotWords + hot_h];
+      for (int p = lane_e; p < np; p += 64) hot_cells += a.hot_cnt[(int64_t)p * kHotWords + hot_h];
       hot_cells = wave_sum_i(hot_cells);
     }
   }
   int my_hit = sHit[wave];
   if (PM)
     for (int jj = 1; jj < my_nu && wave + jj < kWordsPerWG; ++jj) my_hit |= sHit[wave + jj];
-  if (a.gexp && my_w < a.n_words && lane < d2 && !my_hit && hot_cells == 0)
-    reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(0.f, 0.f);
-  if (my_w < a.n_words && (my_hit || hot_cells > 0) && lane < d2) {
+  if (a.gexp && my_w < a.n_words && lane_e < d2 && !my_hit && hot_cells == 0)
+    reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane_e] = make_float2(0.f, 0.f);
+  if (my_w < a.n_words && (my_hit || hot_cells > 0) && lane_e < d2) {
     float2 sum = make_float2(0.f, 0.f);
     if (!PM) {
 #pragma unroll
       for (int v = 0; v < 8; ++v) {
-        const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane];
+        const float2 t = sAccW[(v * kWordsPerWG + wave) * 64 + lane_e];
         sum.x += t.x;
         sum.y += t.y;
       }
@@ -981,14 +997,14 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
       for (int jj = 0; jj < my_nu && wave + jj < kWordsPerWG; ++jj)
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
-          const float2 t = sAccW[(v * kWordsPerWG + wave + jj) * 64 + lane];
+          const float2 t = sAccW[(v * kWordsPerWG + wave + jj) * 64 + lane_e];
           sum.x += t.x;
           sum.y += t.y;
         }
     }
     if (hot_cells > 0 && !(a.skip_words & 8)) {   // partials in workgroup order; written on other compute units: every load is a trip to memory, 16 in flight
       const int np = (n + 15) >> 4;
-      const float2* hp = reinterpret_cast<const float2*>(a.hot_part + (int64_t)hot_h * 128) + lane;
+      const float2* hp = reinterpret_cast<const float2*>(a.hot_part + (int64_t)hot_h * 128) + lane_e;
       for (int p0 = 0; p0 < np; p0 += 16) {
         float2 u[16];
 #pragma unroll
@@ -1001,15 +1017,20 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
       }
     }
 
+    float2 wold = wold_early;
+    if (PM) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of the row (issued before the barrier above)
+      wold = make_float2(__builtin_bit_cast(float, list[lane_e]), __builtin_bit_cast(float, list[64 + lane_e]));
+    }
     // gradient = scale[w] / L * sum (mean-pool); the CNN rows already carry scale and 1/L
     const float gs = cnn ? 1.f : (MAXP ? word_scale(a, my_w) : word_scale(a, my_w) / (float)a.L);
     if (a.gexp) {
-      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane] = make_float2(gs * sum.x, gs * sum.y);
+      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane_e] = make_float2(gs * sum.x, gs * sum.y);
       return;
     }
     if (a.opt) {
-      float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
-      float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
+      float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane_e;
+      float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane_e;
       float2 mm = *mp, vv = *vp;
       wold.x = adam1(gs * sum.x, &mm.x, &vv.x, wold.x, a);
       wold.y = adam1(gs * sum.y, &mm.y, &vv.y, wold.y, a);
@@ -1020,18 +1041,23 @@ __global__ void __launch_bounds__(512, CNN ? 6 : 8) tower_word_kernel(TowerArgs 
       wold.x = fmaf(-sc, sum.x, wold.x);
       wold.y = fmaf(-sc, sum.y, wold.y);
     }
-    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
-  } else if (a.opt == 2 && !a.gexp && my_w < a.n_words && lane < d2) {
+    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane_e] = wold;
+  } else if (a.opt == 2 && !a.gexp && my_w < a.n_words && lane_e < d2) {
     // dense Adam (Keras): a word without a gradient this step still takes the zero-gradient step
     // -- done here, where the word is visited anyway, instead of in a separate pass over the table
-    float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane;
-    float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane;
+    float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane_e;
+    float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane_e;
     float2 mm = *mp, vv = *vp;
+    float2 wold = wold_early;
+    if (PM) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wold = make_float2(__builtin_bit_cast(float, list[lane_e]), __builtin_bit_cast(float, list[64 + lane_e]));
+    }
     wold.x = adam1(0.f, &mm.x, &vv.x, wold.x, a);
     wold.y = adam1(0.f, &mm.y, &vv.y, wold.y, a);
     *mp = mm;
     *vp = vv;
-    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane] = wold;
+    reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane_e] = wold;
   }
 }
 

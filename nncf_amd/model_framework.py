@@ -94,6 +94,10 @@ class NegSharedModel(_Head):
     def predict_on_batch_device(self, uid_dev, cid_dev, out=None):
         return self.engine.predict_scores(uid_dev, cid_dev, out=out)
 
+    def predict_engine(self):
+        """the engine whose tables predict_on_batch scores with (the fused evaluator, nncf_eval_whole, reads them directly)"""
+        return self.engine
+
 
 class GroupNegSharedModel(_Head):
     """model_dict['model_group_neg_shared'] (model_framework.py:131-136,158-161); needs exactly
@@ -371,6 +375,9 @@ class TowerHead(_Head):
 
     def predict_on_batch_device(self, uid_dev, cid_dev, out=None):
         return self.core.eval_engine().predict_scores(uid_dev, cid_dev, out=out)
+
+    def predict_engine(self):
+        return self.core.eval_engine()   # shared user table + the tower's inference rows of ALL items (refreshed when it changed)
 
 
 class TowerSampledNegSharedHead(_Head):

@@ -10,6 +10,7 @@ test_seen/test with sampled negatives, :231-294) needs pandas/sklearn-style per-
 not part of the measured path; it raises NotImplementedError.
 """
 import ctypes
+import os
 from datetime import datetime
 
 import numpy as np
@@ -81,14 +82,29 @@ class Evaluator(object):
             }
         return self._dev
 
-    def _whole(self, model_predict, which, topk, user_chunk=2048):
-        """test_eval_mat + evaluate_mat (objectives.py:296-370) for one candidate set."""
-        engine = model_predict.engine
+    FUSED_MAX_TOPK = 128   # nncf_eval_whole (csrc/eval.hip kEvalMaxK)
+
+    def _whole(self, model_predict, which, topk, user_chunk=2048, fused=None):
+        """test_eval_mat + evaluate_mat (objectives.py:296-370) for one candidate set.  Default: ONE kernel scores and ranks
+        (nncf_eval_whole: no (users x candidates) matrix); fused=False (or NNCF_EVAL_FUSED=0, or eval_topk > 128) takes the
+        two-kernel path over a score chunk -- both leave the same bits."""
+        predict_engine = getattr(model_predict, "predict_engine", None)
+        engine = predict_engine() if predict_engine is not None else model_predict.engine
         st = self._device_state(engine)
         items, ptr, idx = st[which]
         n_cand = int(items.numel())
         L = _lib.lib()
         metrics, valid = st["metrics"], st["valid"]
+        if fused is None:
+            fused = os.environ.get("NNCF_EVAL_FUSED", "1") != "0"
+        if fused and topk <= self.FUSED_MAX_TOPK and hasattr(engine, "_h"):
+            with torch.cuda.device(engine.device):
+                stream = _lib.stream_ptr(torch.cuda.current_stream(engine.device))
+                _lib.check(L.nncf_eval_whole(
+                    engine._h, ctypes.c_void_p(st["users"].data_ptr()), self.user_count, ctypes.c_void_p(items.data_ptr()), n_cand,
+                    ctypes.c_void_p(ptr.data_ptr()), ctypes.c_void_p(idx.data_ptr()), int(topk),
+                    ctypes.c_void_p(metrics.data_ptr()), ctypes.c_void_p(valid.data_ptr()), stream))
+            return self._mean(metrics, valid, topk)
         scores = torch.empty((min(user_chunk, self.user_count), n_cand), dtype=torch.float32, device=engine.device)
         with torch.cuda.device(engine.device):
             stream = _lib.stream_ptr(torch.cuda.current_stream(engine.device))
@@ -99,6 +115,10 @@ class Evaluator(object):
                     ctypes.c_void_p(scores.data_ptr()), u1 - u0, n_cand, n_cand,
                     ctypes.c_void_p(ptr[u0:].data_ptr()), ctypes.c_void_p(idx.data_ptr()), int(topk),
                     ctypes.c_void_p(metrics[3 * u0:].data_ptr()), ctypes.c_void_p(valid[u0:].data_ptr()), stream))
+        return self._mean(metrics, valid, topk)
+
+    @staticmethod
+    def _mean(metrics, valid, topk):
         v = valid.bool()
         m = metrics.view(-1, 3)[v].double()
         n = int(v.sum().item())

@@ -1,0 +1,166 @@
+"""GPU: the one-kernel evaluator (nncf_eval_whole, csrc/eval.hip eval_fused_kernel) -- whole@k without the score matrix.
+
+Reference: utils/objectives.py:296-370 (test_eval_mat + evaluate_mat), utils/metrics_ranking.py:6-35 (eval_multiple).
+Two bars: (1) bit-identical to the two-kernel path (nncf_predict_scores + nncf_eval_topk), ties to the lower slot included,
+on adversarial small shapes; (2) at BASELINE's full shape (16K users x 17K items, d = 100) equal to the float64 oracle's
+map / recall / precision@50 to the north-star's 1e-5 -- the first full-shape test of the metric's second half."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import torch  # noqa: E402
+
+from oracle import step_oracle as so  # noqa: E402
+from nncf_amd import _lib, synthetic  # noqa: E402
+from nncf_amd.conf import get_conf  # noqa: E402
+from nncf_amd.data_utils import get_data  # noqa: E402
+from nncf_amd.model_framework import get_model  # noqa: E402
+from nncf_amd.objectives import Evaluator  # noqa: E402
+
+
+def _conf(d, b=64, bias=None, norm=True, topk=50, model="mf"):
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.1, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d,
+          "item_dim": d, "chop_size": 4, "interaction_bias": bias, "u_reg": 0., "eval_topk": topk, "optimizer": "sgd"}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    if not norm:
+        conf.emb_normalization = False
+    return conf
+
+
+def _both_paths(ev, head, which, topk):
+    st = None
+    out = []
+    for fused in (True, False):
+        res = ev._whole(head, which, topk, fused=fused)
+        st = ev._dev
+        out.append((res, st["metrics"].clone(), st["valid"].clone()))
+        st["metrics"].zero_()
+        st["valid"].fill_(-7)
+    return out
+
+
+@pytest.mark.parametrize("d,users,items,bias,norm,topk", [
+    (24, 600, 500, None, True, 50),          # users not a multiple of 64, 500 candidates: 7 full stages + a ragged one
+    (100, 130, 3000, None, True, 50),        # the d = 100 instantiation (25 k-steps), lists cut several times
+    (128, 64, 700, "both", True, 128),       # d = 128, interaction bias, the largest k the kernel takes
+    (20, 257, 40, "item", False, 50),        # fewer candidates than k: every candidate is ranked
+    (64, 1000, 2000, "user", True, 1),       # k = 1
+])
+def test_fused_evaluator_is_bit_identical_to_the_two_kernel_path(d, users, items, bias, norm, topk):
+    data = synthetic.make_citeulike_like(users=users, items=items, train_links=max(6 * users, 2000), seed=3)
+    conf = _conf(d, bias=bias, norm=norm, topk=topk)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "mf", seed=4)
+    head = md["model_neg_shared"]
+    eng = head.engine
+    if bias:   # non-zero bias vectors (they start at zero)
+        rs = np.random.RandomState(1)
+        for t in (eng.bias["ub"], eng.bias["cb"]):
+            if t is not None:
+                t.copy_(torch.as_tensor(rs.normal(scale=0.3, size=tuple(t.shape)).astype(np.float32)))
+    ev = Evaluator(helper, helper.data_spec, conf)
+    for which in ("train", "test"):
+        (rf, mf_, vf), (rt, mt, vt) = _both_paths(ev, head, which, topk)
+        assert torch.equal(vf, vt), which
+        keep = vt == 1
+        assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), which
+        assert rf == rt and rf["users"] > 0
+
+
+def test_fused_evaluator_breaks_ties_like_the_two_kernel_path():
+    """Constant and few-valued score rows: all-zero user rows (every candidate ties at 0), duplicated item rows (pairs of
+    tied candidates everywhere) -- the total order of the rank keys (score bits | inverted slot) decides, in both paths."""
+    data = synthetic.make_citeulike_like(users=200, items=900, train_links=5000, seed=8)
+    conf = _conf(32, norm=False)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "mf", seed=4)
+    head = md["model_neg_shared"]
+    eng = head.engine
+    U = eng.U.cpu().numpy().copy()
+    V = eng.V.cpu().numpy().copy()
+    U[:50] = 0.                      # every score of these users is exactly 0
+    V[1::2] = V[0::2][:V[1::2].shape[0]]   # items 2i and 2i + 1 share a row
+    V[:, :] = np.round(V * 4) / 4    # few distinct values: many exact ties between unrelated items too
+    eng.set_tables(U, V)
+    ev = Evaluator(helper, helper.data_spec, conf)
+    for which in ("train", "test"):
+        (rf, mf_, vf), (rt, mt, vt) = _both_paths(ev, head, which, 50)
+        assert torch.equal(vf, vt)
+        keep = vt == 1
+        assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), which
+
+
+def test_nncf_eval_whole_refuses_what_it_does_not_take():
+    data = synthetic.make_citeulike_like(users=100, items=90, train_links=1000, seed=8)
+    conf = _conf(24)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "mf", seed=4)
+    eng = md["model_neg_shared"].engine
+    L = _lib.lib()
+    z = torch.zeros(400, dtype=torch.int32, device="cuda")
+    f = torch.zeros(400, dtype=torch.float32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert L.nncf_eval_whole(eng._h, p(z), 10, p(z), 5, p(z), p(z), 129, p(f), p(z), None) != 0      # k beyond the kernel's lists
+    assert L.nncf_eval_whole(eng._h, p(z), 10, p(z), 0, p(z), p(z), 50, p(f), p(z), None) != 0       # no candidates
+    assert L.nncf_eval_whole(eng._h, None, 10, p(z), 5, p(z), p(z), 50, p(f), p(z), None) != 0
+    assert L.nncf_eval_whole(eng._h, p(z), 0, p(z), 5, p(z), p(z), 50, p(f), p(z), None) == 0        # no users: nothing to do
+
+
+@pytest.mark.timeout(1200)
+def test_evaluator_at_the_baseline_shape_equals_the_oracle_and_the_two_kernel_path():
+    """BASELINE shape: 16,000 users x 17,000 items, d = 100, Recall / MAP / Precision@50 over the train candidates (~13.6K) and
+    the test candidates (~3.4K).  (1) fused == two-kernel path, per user, bitwise; (2) both == metrics_ranking.py's
+    eval_multiple (oracle/step_oracle.py) on float64 scores of the same tables, mean over users, <= 1e-5."""
+    data = synthetic.make_citeulike_like()
+    conf = _conf(100, b=512)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "mf", seed=4)
+    head = md["model_neg_shared"]
+    eng = head.engine
+    # a few hundred training steps give the tables structure (popular items score high: hits among the top 50)
+    tr = helper.data["train"]
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        bt = tr[rs.choice(len(tr), 512, replace=False)]
+        head.train_on_batch([bt[:, 0], bt[:, 1]], [bt[:, 2]])
+    ev = Evaluator(helper, helper.data_spec, conf)
+    ocf = so.OracleConf(batch_size_p=512, num_negatives=0, loss="skip-gram", loss_gamma=10, neg_loss_weight=16, u_reg=0.,
+                        learn_rate=0.1, emb_normalization=conf.emb_normalization, model_choice="mf")
+    o64 = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), ocf, dtype=np.float64)
+    nu, ni = helper.data_spec.user_count, helper.data_spec.item_count
+    _, uh, _, _ = o64._user_side(np.arange(nu))
+    _, vh, _ = o64._item_side(np.arange(ni))
+    for which, links in (("train", tr), ("test", helper.data["test"][helper.data["test"][:, 2] == 1])):
+        (rf, mf_, vf), (rt, mt, vt) = _both_paths(ev, head, which, 50)
+        assert torch.equal(vf, vt)
+        keep = vt == 1
+        assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), which
+        # the oracle, user chunk by user chunk (evaluate_whole's dense truth matrix would be 0.9 GB at this shape)
+        cand = np.unique((tr if which == "train" else helper.data["test"])[:, 1])
+        slot = -np.ones(ni, dtype=np.int64)
+        slot[cand] = np.arange(len(cand))
+        lk = links[slot[links[:, 1]] >= 0]
+        order = np.argsort(lk[:, 0], kind="stable")
+        lk = lk[order]
+        starts = np.searchsorted(lk[:, 0], np.arange(nu + 1))
+        vc = vh[cand]
+        acc = np.zeros(3)
+        n_ok = 0
+        for u0 in range(0, nu, 1024):
+            pred = uh[u0:u0 + 1024] @ vc.T
+            for u in range(u0, min(nu, u0 + 1024)):
+                if starts[u + 1] == starts[u]:
+                    continue
+                truth = np.zeros(len(cand))
+                truth[slot[lk[starts[u]:starts[u + 1], 1]]] = 1
+                acc += np.asarray(so.eval_multiple(truth, pred[u - u0], 50))
+                n_ok += 1
+        want = acc / n_ok
+        assert rf["users"] == n_ok
+        for i, name in enumerate(("map", "recall", "precision")):
+            assert abs(rf["%s@50" % name] - want[i]) <= 1e-5, (which, name, rf, want)
+        assert rf["recall@50"] > 0.01   # the comparison is not about empty hit lists
