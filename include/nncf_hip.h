@@ -528,7 +528,7 @@ int nncf_eval_topk(const float* d_scores, int64_t n_users, int64_t row_stride, i
  * arithmetic of nncf_predict_scores -- normalisation, InteractionDot bias, fp32 matrix products in the same order -- and every
  * user keeps its k best in on-chip lists: d_metrics / d_valid come out bit-identical to nncf_predict_scores followed by
  * nncf_eval_topk (ties to the lower slot included), nothing of size users x candidates is ever stored, any n_cand.
- * Limits: topk <= 128 (beyond: the two calls above). */
+ * Limits: topk <= 100 (beyond: the two calls above). */
 int nncf_eval_whole(nncf_model* m, const int32_t* d_uid, int64_t n_users, const int32_t* d_cand, int32_t n_cand,
                     const int32_t* d_truth_ptr, const int32_t* d_truth_idx, int32_t topk, float* d_metrics,
                     int32_t* d_valid, void* stream);

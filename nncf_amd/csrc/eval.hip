@@ -19,6 +19,8 @@
 //
 // Tie policy: the reference breaks score ties with np.random noise (metrics_ranking.py:8,13);
 // here ties go to the lower candidate slot, so results are reproducible.
+#include <cstdlib>
+
 #include "common.h"
 #include "devutil.h"
 #include "model.h"
@@ -166,78 +168,143 @@ __global__ void __launch_bounds__(NT) eval_topk_kernel(const float* __restrict__
 
 // ---- round 5: scores and ranking in ONE kernel -- the (users x candidates) matrix is never written ---------------------
 // predict_tile_kernel wrote 64.8 MB of scores per 2,048-user chunk (1.04 GB per whole@50 pass at the CiteULike shape, 8 GB
-// per chunk at config [3]'s 10^6 items) and eval_topk_kernel read them back twice: 2.56 ms per pass, 0.14 of the fp32-MFMA
+// per chunk at config [3]'s 10^6 items) and eval_topk_kernel read them back twice: 2.5 ms per pass, 0.14 of the fp32-MFMA
 // peak.  Here a workgroup owns 64 users for the whole sweep: their (normalised) rows live in registers as the MFMA's A
-// fragments, the candidates stream through LDS in stages of 64, and every user keeps a list of the keys that beat its
-// threshold:
-//   * scores: the SAME arithmetic as predict_tile_kernel -- v_mfma_f32_16x16x4_f32 over k = 4 kk + (lane >> 4), kk
-//     ascending, then + user bias + item bias -- so every score, every 64-bit rank key (score bits | inverted slot: a total
+// fragments, the candidates stream through a double-buffered LDS stage of 64 rows, and every user keeps a list of the keys
+// that beat its threshold:
+//   * scores: the SAME arithmetic as predict_tile_kernel -- v_mfma_f32_16x16x4_f32 over k = 4 kk + (lane >> 4), the even and
+//     the odd kk each in ascending order in their own accumulator, the two added, then + user bias + item bias -- so every score, every 64-bit rank key (score bits | inverted slot: a total
 //     order) and therefore the top k are bit-identical to nncf_predict_scores + nncf_eval_topk, ties included;
-//   * per user a list of kEvalList keys in LDS and a threshold key tau (0 at first): a score whose key beats tau is appended
-//     (one LDS integer atomic for the position).  Between stages a wave looks after 8 users: a list that could overflow in
-//     the next stage (more than kEvalList - 64 keys) is cut down to its k largest and tau becomes the k-th of them -- found
-//     bit by bit from the top with wave ballots (64 rounds of counts, no sort, no shuffles).  With 78 keys of slack a list
-//     is cut after the candidates seen have grown 4.8-fold: ~4 cuts per user for 13,600 candidates;
+//   * per user a list of LIST keys in LDS and a threshold key tau (0 at first): a score that reaches the float image of tau
+//     takes the exact 64-bit test, the few that pass are appended (one LDS integer atomic for the position);
+//   * when ANY list of the workgroup could overflow in the next stage, EVERY wave cuts ALL of its 8 users' lists down to
+//     their k largest (tau := the k-th, found bit by bit from the top with wave ballots: no sort, no shuffles; two users'
+//     searches interleaved) in one extra barrier interval.  Cutting on demand, user by user, put one ~5 k-cycle search on
+//     the critical path of nearly every stage (everybody waits at the stage barrier for the one wave that cuts: 0.65 ms of
+//     a 1.6 ms pass); cut together, the users' thresholds move together and a sweep of 13,600 candidates has ~6 cut stages;
+//   * the two waves of a SIMD run half a stage apart (products | ranking against ranking | products), stage s + 1 is stored
+//     while stage s is multiplied: one barrier per stage;
 //   * at the end the list is cut to k once more, the k keys are ranked by counting, hits by binary search in the user's
 //     truth CSR, map / recall / precision per metrics_ranking.py:14-29 in rank order -- the arithmetic of eval_topk_kernel.
 // Work: 2 n_users n_cand d flop on the fp32 matrix pipe (exact fp32: the ranking must not depend on the pipe), 25 LDS reads
 // per 50 MFMAs and wave; bound: fp32 MFMA.  Memory: O(users) -- config [3]'s 10^6 candidates need no 8 GB chunk.
 constexpr int kEvalUsers = 64;     // users per workgroup (four 16-row MFMA tiles)
 constexpr int kEvalStage = 64;     // candidates per stage (four 16-column tiles)
-constexpr int kEvalList = 192;     // keys a user's list holds
-constexpr int kEvalMaxK = 128;     // top-k this kernel takes (beyond: the two-kernel path)
+constexpr int kEvalMaxK = 100;     // top-k this kernel takes (beyond: the two-kernel path)
+template <int NK>
+__host__ __device__ constexpr int eval_list_cap() { return NK <= 25 ? 192 : 176; }   // keys per user list (160 KB of LDS in all)
 
 template <int NK>
 __host__ __device__ constexpr size_t eval_fused_lds() {
-  return sizeof(float) * (size_t)kEvalStage * (4 * NK + 2) + sizeof(unsigned long long) * (kEvalUsers * kEvalList + kEvalUsers) +
-         sizeof(int) * kEvalUsers + sizeof(float) * (kEvalUsers + kEvalStage);
+  return sizeof(float) * (size_t)2 * kEvalStage * (4 * NK + 2) + sizeof(unsigned long long) * (kEvalUsers * eval_list_cap<NK>() + kEvalUsers) +
+         sizeof(int) * (kEvalUsers + 4) + sizeof(float) * (kEvalUsers + 2 * kEvalStage);
 }
 
-// the k-th largest of the wave's keys (NR per lane, all distinct or 0 = empty; at least k of them non-zero): bit by bit
-template <int NR>
-__device__ __forceinline__ unsigned long long wave_kth_largest(const unsigned long long (&key)[NR], int k) {
-  unsigned long long t = 0ull;
-  for (int bit = 63; bit >= 0; --bit) {
-    const unsigned long long c = t | (1ull << bit);
-    int n = 0;
+// the k-th largest of each of TWO key sets held by the wave (3 keys per lane and set; distinct or 0 = empty; at least k non-zero),
+// both searches advanced together: a round is a compare -> ballot -> count -> select chain through the scalar unit, two
+// independent chains hide each other's latency.  First the score halves (32 rounds); the slot halves only if several keys
+// share the k-th score.
+__device__ __forceinline__ void wave_kth_largest2(const unsigned long long (&ka)[3], const unsigned long long (&kb)[3], int k,
+                                                  unsigned long long& ta, unsigned long long& tb) {
+  uint32_t ha = 0u, hb = 0u;
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t ca = ha | (1u << bit), cb = hb | (1u << bit);
+    int na = 0, nb = 0;
 #pragma unroll
-    for (int e = 0; e < NR; ++e) n += __popcll(__ballot(key[e] >= c));
-    if (n >= k) t = c;
+    for (int e = 0; e < 3; ++e) {
+      na += __popcll(__ballot((uint32_t)(ka[e] >> 32) >= ca));
+      nb += __popcll(__ballot((uint32_t)(kb[e] >> 32) >= cb));
+    }
+    if (na >= k) ha = ca;
+    if (nb >= k) hb = cb;
   }
-  return t;
+  // keys above the k-th score: n_gt; the k-th is the (k - n_gt)-th largest slot half among the keys AT that score
+  auto finish = [&](const unsigned long long (&key)[3], uint32_t h) -> unsigned long long {
+    int ngt = 0, neq = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      ngt += __popcll(__ballot((uint32_t)(key[e] >> 32) > h));
+      neq += __popcll(__ballot((uint32_t)(key[e] >> 32) == h));
+    }
+    uint32_t lo = 0u;
+    if (neq == 1) {   // the usual case: one key holds the k-th score
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const unsigned long long m = __ballot((uint32_t)(key[e] >> 32) == h);
+        if (m) lo = (uint32_t)__shfl((int)(uint32_t)key[e], __builtin_ctzll(m));
+      }
+    } else {
+      const int kk2 = k - ngt;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t c = lo | (1u << bit);
+        int n = 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) n += __popcll(__ballot((uint32_t)(key[e] >> 32) == h && (uint32_t)key[e] >= c));
+        if (n >= kk2) lo = c;
+      }
+    }
+    return ((unsigned long long)h << 32) | lo;
+  };
+  ta = finish(ka, ha);
+  tb = finish(kb, hb);
 }
 
-// one wave cuts list u down to its k largest keys (any order) and returns the k-th; c = keys in the list
-__device__ __forceinline__ unsigned long long eval_cut_list(unsigned long long* list, int c, int k, int lane) {
-  unsigned long long key[3];
-#pragma unroll
-  for (int e = 0; e < 3; ++e) key[e] = (lane + 64 * e < c) ? list[lane + 64 * e] : 0ull;
-  const unsigned long long t = wave_kth_largest<3>(key, k);
-  __builtin_amdgcn_wave_barrier();   // every read of the list above precedes the stores below (one wave, LDS in order)
-  int base = 0;
+// one wave cuts TWO lists (ca / cb keys; a count <= k leaves that list alone) down to their k largest keys (any order);
+// returns the k-th of each (0: left alone)
+template <int LIST>
+__device__ __forceinline__ void eval_cut_lists2(unsigned long long* la, int ca, unsigned long long* lb, int cb, int k, int lane,
+                                                unsigned long long& ta, unsigned long long& tb) {
+  unsigned long long ka[3], kb[3];
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    const bool keep = key[e] >= t;   // t > 0: empty entries never pass
-    const unsigned long long m = __ballot(keep);
-    if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = key[e];
-    base += __popcll(m);
+    ka[e] = (lane + 64 * e < ca) ? la[lane + 64 * e] : 0ull;
+    kb[e] = (lane + 64 * e < cb) ? lb[lane + 64 * e] : 0ull;
   }
-  return t;
+  const bool doa = ca > k, dob = cb > k;
+  if (!doa && !dob) {
+    ta = tb = 0ull;
+    return;
+  }
+  // a list that is left alone takes part in the search with k of its own keys... simpler: give it a dummy that never matters
+  if (!doa) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) ka[e] = kb[e];
+  }
+  if (!dob) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) kb[e] = ka[e];
+  }
+  wave_kth_largest2(ka, kb, k, ta, tb);
+  __builtin_amdgcn_wave_barrier();   // every read of the lists above precedes the stores below (one wave, LDS in order)
+  auto compact = [&](unsigned long long* list, const unsigned long long (&key)[3], unsigned long long t) {
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const bool keep = key[e] >= t;   // t > 0: empty entries never pass
+      const unsigned long long m = __ballot(keep);
+      if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = key[e];
+      base += __popcll(m);
+    }
+  };
+  if (doa) compact(la, ka, ta); else ta = 0ull;
+  if (dob) compact(lb, kb, tb); else tb = 0ull;
 }
 
 template <int NK>
 __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32_t* __restrict__ uid, int64_t n_users,
                                                          const int32_t* __restrict__ cand, int n_cand,
                                                          const int32_t* __restrict__ truth_ptr, const int32_t* __restrict__ truth_idx,
-                                                         int topk, float* __restrict__ metrics, int32_t* __restrict__ valid) {
+                                                         int topk, float* __restrict__ metrics, int32_t* __restrict__ valid, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float eval_smem[];
   constexpr int DP = 4 * NK + 2;   // row pitch: the fragments' dword reads (16 rows x 2 k of a half wave) hit 32 different banks
-  float* sRow = eval_smem;                                                                    // [64][DP] user rows, then the stages
-  unsigned long long* sKeys = reinterpret_cast<unsigned long long*>(sRow + kEvalStage * DP);  // [64][kEvalList]
-  unsigned long long* sTau = sKeys + kEvalUsers * kEvalList;                                  // [64]
-  int* sCnt = reinterpret_cast<int*>(sTau + kEvalUsers);                                      // [64]
-  float* sUb = reinterpret_cast<float*>(sCnt + kEvalUsers);                                   // [64] user bias
-  float* sCb = sUb + kEvalUsers;                                                              // [64] item bias of the stage
+  constexpr int LIST = eval_list_cap<NK>();
+  float* sRow = eval_smem;                                                                        // [2][64][DP] the stages (first: the users)
+  unsigned long long* sKeys = reinterpret_cast<unsigned long long*>(sRow + 2 * kEvalStage * DP);  // [64][LIST]
+  unsigned long long* sTau = sKeys + kEvalUsers * LIST;                                           // [64]
+  int* sCnt = reinterpret_cast<int*>(sTau + kEvalUsers);                                          // [64]
+  int* sFlag = sCnt + kEvalUsers;                                                                 // [4]: [st & 1] somebody's list is nearly full
+  float* sUb = reinterpret_cast<float*>(sFlag + 4);                                               // [64] user bias
+  float* sCb = sUb + kEvalUsers;                                                                  // [2][64] item bias of the stage (by stage parity)
   const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = tid >> 4, q = tid & 15;           // 32 groups of 16 lanes: rows g and g + 32 of a stage
@@ -245,6 +312,15 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   const int d4 = a.d >> 2;
   const int64_t u0 = (int64_t)blockIdx.x * kEvalUsers;
   const int kk = min(topk, n_cand);
+  auto store_row = [&](float* dst, const Row& hat) {   // columns [d, 4 NK) are zeros: they add nothing to a score
+    float2* p = reinterpret_cast<float2*>(dst);
+    p[2 * q] = make_float2(hat.a.x, hat.a.y);
+    p[2 * q + 1] = make_float2(hat.a.z, hat.a.w);
+    if (q + 16 < NK) {
+      p[32 + 2 * q] = make_float2(hat.b.x, hat.b.y);
+      p[32 + 2 * q + 1] = make_float2(hat.b.z, hat.b.w);
+    }
+  };
   // ---- the workgroup's users -> LDS -> A fragments in registers ---------------------------------------------------------
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -259,20 +335,15 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       real = truth_ptr[u + 1] > truth_ptr[u];   // objectives.py:316: users without a true item are dropped
     }
     if (a.norm_u) hat = row_scale(hat, inv_norm(row16_sum(row_dot_partial(hat, hat))));
-    float2* p = reinterpret_cast<float2*>(sRow + r * DP);   // columns [d, 4 NK) are zeros: they add nothing to a score
-    p[2 * q] = make_float2(hat.a.x, hat.a.y);
-    p[2 * q + 1] = make_float2(hat.a.z, hat.a.w);
-    if (q + 16 < NK) {
-      p[32 + 2 * q] = make_float2(hat.b.x, hat.b.y);
-      p[32 + 2 * q + 1] = make_float2(hat.b.z, hat.b.w);
-    }
+    store_row(sRow + r * DP, hat);
     if (q == 0) {
       sCnt[r] = 0;
-      sTau[r] = real ? 0ull : ~0ull;   // nothing beats the threshold of a user that is not ranked
+      sTau[r] = (real && !(dbg & 1)) ? 0ull : ~0ull;   // nothing beats the threshold of a user that is not ranked (dbg 1: developer timing, no list traffic)
       sUb[r] = u < n_users ? user_bias(a, id) : 0.f;
       if (u < n_users && !real) valid[u] = 0;
     }
   }
+  if (tid < 4) sFlag[tid] = 0;
   __syncthreads();
   float afr[2][NK];
 #pragma unroll
@@ -280,13 +351,19 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 #pragma unroll
     for (int k = 0; k < NK; ++k) afr[t][k] = sRow[(32 * rp + 16 * t + x) * DP + 4 * k + kq];
   float ub_r[2][4];
+  float tau_f[2][4];   // float image of the thresholds (the exact 64-bit test runs only where a score reaches it); refreshed after cuts
+  unsigned long long tau_k[2][4];   // the threshold keys themselves
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ub_r[t][r] = sUb[32 * rp + 16 * t + 4 * kq + r];
-  // ---- candidate stages: ids two stages ahead, rows one stage ahead in registers --------------------------------------
+    for (int r = 0; r < 4; ++r) {
+      ub_r[t][r] = sUb[32 * rp + 16 * t + 4 * kq + r];
+      tau_k[t][r] = sTau[32 * rp + 16 * t + 4 * kq + r];
+      tau_f[t][r] = (tau_k[t][r] == 0ull) ? -__builtin_inff() : __builtin_inff();
+    }
+  // ---- candidate stages: ids two stages ahead, rows one stage ahead in registers, LDS stage double-buffered ----------
   const int nst = (n_cand + kEvalStage - 1) / kEvalStage;
-  int idn[2];
+  int idn[2], idc[2];   // ids of the rows requested next / of the rows in rown
   Row rown[2];
   auto load_ids = [&](int st) {
 #pragma unroll
@@ -295,96 +372,174 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       idn[e] = (st < nst && j < n_cand) ? cand[j] : -1;
     }
   };
-  auto load_rows = [&]() {
+  auto load_rows = [&]() {   // the rows of the ids in idn; they become the current ids
 #pragma unroll
-    for (int e = 0; e < 2; ++e) rown[e] = idn[e] >= 0 ? row_load(a.V, idn[e], a.stride, d4, q) : row_zero();
+    for (int e = 0; e < 2; ++e) {
+      rown[e] = idn[e] >= 0 ? row_load(a.V, idn[e], a.stride, d4, q) : row_zero();
+      idc[e] = idn[e];
+    }
   };
-  load_ids(0);
-  load_rows();
-  int idc[2] = {idn[0], idn[1]};
-  load_ids(1);
-  __syncthreads();   // the A fragments are out of sRow
-  for (int st = 0; st < nst; ++st) {
-    // stage st's rows (in registers since the last stage) -> LDS
+  auto store_stage = [&](int st) {   // the rows in rown (their ids in idc) -> buffer st & 1
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int r = g + 32 * e;
       Row hat = rown[e];
       if (a.norm_v) hat = row_scale(hat, inv_norm(row16_sum(row_dot_partial(hat, hat))));
-      float2* p = reinterpret_cast<float2*>(sRow + r * DP);
-      p[2 * q] = make_float2(hat.a.x, hat.a.y);
-      p[2 * q + 1] = make_float2(hat.a.z, hat.a.w);
-      if (q + 16 < NK) {
-        p[32 + 2 * q] = make_float2(hat.b.x, hat.b.y);
-        p[32 + 2 * q + 1] = make_float2(hat.b.z, hat.b.w);
-      }
-      if (q == 0) sCb[r] = idc[e] >= 0 ? item_bias(a, idc[e]) : 0.f;
+      store_row(sRow + ((st & 1) * kEvalStage + r) * DP, hat);
+      if (q == 0) sCb[(st & 1) * kEvalStage + r] = idc[e] >= 0 ? item_bias(a, idc[e]) : 0.f;
     }
-    // lists that could overflow in this stage are cut to their k largest (wave w: users 8 w .. 8 w + 7)
-    for (int e = 0; e < 8; ++e) {
-      const int u = 8 * wave + e;
-      const int c = sCnt[u];
-      if (c + kEvalStage > kEvalList) {   // wave-uniform
-        const unsigned long long t = eval_cut_list(sKeys + u * kEvalList, c, kk, lane);
-        if (lane == 0) {
-          sTau[u] = t;
-          sCnt[u] = kk;
-        }
+  };
+  load_ids(0);
+  load_rows();
+  load_ids(1);
+  __syncthreads();   // the A fragments are out of sRow
+  store_stage(0);
+  load_rows();
+  load_ids(2);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float cb_prev = 0.f;
+  auto products = [&](int st) {
+    acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (dbg & 2) return;   // (developer timing without the products)
+    // the whole B fragment is requested before the first MFMA (a read per k-step, waited for in place, made the loop
+    // LDS-latency-bound: 55 cycles per MFMA instead of 32 -- in-kernel stamps)
+    const float* pb = sRow + ((st & 1) * kEvalStage + 16 * ct + x) * DP + kq;
+    float bfr[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) bfr[k] = pb[4 * k];
+    // per element TWO accumulation chains, k-steps 0, 2, 4, ... and 1, 3, 5, ..., added at the end (predict_tile_kernel does the
+    // same): a dependent v_mfma_f32_16x16x4_f32 issues ~84 cycles after its predecessor here, so two row tiles x one chain ran
+    // the pipe at 42-55 cycles per MFMA instead of 32 (in-kernel stamps); four chains keep it busy
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, o0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NK; k += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][k], bfr[k], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][k], bfr[k], e1, 0, 0, 0);
+      if (k + 1 < NK) {
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][k + 1], bfr[k + 1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][k + 1], bfr[k + 1], o1, 0, 0, 0);
       }
     }
-    __syncthreads();
-    // the next stage's rows and the ids of the one after travel under this stage's MFMAs
-    idc[0] = idn[0];
-    idc[1] = idn[1];
-    load_rows();
-    load_ids(st + 2);
-    unsigned long long tau_r[2][4];
+    acc0 = e0 + o0;
+    acc1 = e1 + o1;
+  };
+  // ranking of the tile in acc0 / acc1: column j (item bias cb).  A score at or above the float image of its user's threshold
+  // takes the exact test (64-bit key against the threshold key); the few that pass are appended -- all positions requested
+  // first (independent LDS atomics), then the keys stored.
+  auto ranking = [&](int st_of, float cb, int parity) {
+    const int j = st_of * kEvalStage + 16 * ct + x;
+    if (j >= n_cand) return;
+    float sc[2][4];
+    bool any = false;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tau_r[t][r] = sTau[32 * rp + 16 * t + 4 * kq + r];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float* pb = sRow + (16 * ct + x) * DP + kq;
+      for (int r = 0; r < 4; ++r) {
+        sc[t][r] = (t ? acc1[r] : acc0[r]) + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
+        any |= sc[t][r] >= tau_f[t][r];
+      }
+    if (!any) return;
+    // exact test against the threshold KEYS (registers), then all the list positions at once: eight independent LDS atomics in
+    // flight, one wait, eight stores (a threshold read from LDS and a wait per slot made this path ~2.5 k cycles per stage)
+    unsigned long long key[2][4];
+    bool want[2][4];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-      const float bv = pb[4 * k];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][k], bv, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][k], bv, acc1, 0, 0, 0);
-    }
-    const int j = st * kEvalStage + 16 * ct + x;
-    const float cb = sCb[16 * ct + x];
-    if (j < n_cand) {
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int r = 0; r < 4; ++r) {
+        key[t][r] = rank_key(sc[t][r], j);
+        want[t][r] = key[t][r] > tau_k[t][r];
+      }
+    int pos[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = (t ? acc1[r] : acc0[r]) + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
-          const unsigned long long key = rank_key(sc, j);
-          if (key > tau_r[t][r]) {
-            const int i = 32 * rp + 16 * t + 4 * kq + r;
-            const int pos = atomicAdd(&sCnt[i], 1);   // < kEvalList: at most 64 appends per user and stage
-            sKeys[i * kEvalList + pos] = key;
-          }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pos[t][r] = want[t][r] ? atomicAdd(&sCnt[32 * rp + 16 * t + 4 * kq + r], 1) : -1;   // < LIST: <= 64 appends per user and stage
+    bool full = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (pos[t][r] >= 0) {
+          sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
+          full |= pos[t][r] >= LIST - kEvalStage;
+        }
+    // the append that leaves a list with less than a stage's worth of room raises the workgroup's flag: everybody cuts behind
+    // this stage's barrier (a count read by another wave could miss appends still in flight; the appender cannot)
+    if (full) sFlag[parity] = 1;
+  };
+  auto refresh_tau = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned long long tk = sTau[32 * rp + 16 * t + 4 * kq + r];
+        tau_k[t][r] = tk;
+        // the score bits of the threshold key, back as a float (orderable() inverted); all-ones: an unranked user
+        const uint32_t ob = (uint32_t)(tk >> 32);
+        const uint32_t fb = (ob & 0x80000000u) ? (ob & 0x7FFFFFFFu) : ~ob;
+        tau_f[t][r] = tk == 0ull ? -__builtin_inff() : (tk == ~0ull ? __builtin_inff() : __uint_as_float(fb));
+      }
+  };
+  // wave w cuts the lists of users 8 w .. 8 w + 7 that hold more than k keys, two at a time
+  auto cut_mine = [&]() {
+    for (int e = 0; e < 8; e += 2) {
+      const int ua = 8 * wave + e, ub2 = ua + 1;
+      unsigned long long ta, tb;
+      eval_cut_lists2<LIST>(sKeys + ua * LIST, sCnt[ua], sKeys + ub2 * LIST, sCnt[ub2], kk, lane, ta, tb);
+      if (lane == 0) {
+        if (ta) {
+          sTau[ua] = ta;
+          sCnt[ua] = kk;
+        }
+        if (tb) {
+          sTau[ub2] = tb;
+          sCnt[ub2] = kk;
         }
       }
     }
+  };
+  __syncthreads();   // stage 0 is in LDS
+  for (int st = 0; st < nst; ++st) {
+    // (a) the rows of stage st + 1 (in registers since the last iteration) -> the other buffer; the rows of stage st + 2 and the
+    //     ids of st + 3 are requested; (b) products + ranking, the two row-tile pairs half a stage apart; (c) barrier;
+    //     (d) if a list is nearly full: everybody cuts, one more barrier
+    if (st + 1 < nst) store_stage(st + 1);
+    load_rows();          // stage st + 2 (its ids arrived a stage ago)
+    load_ids(st + 3);
+    const float cb = sCb[(st & 1) * kEvalStage + 16 * ct + x];
+    if (rp == 0 || (dbg & 4)) {
+      products(st);
+      ranking(st, cb, st & 1);
+    } else {
+      if (st > 0) ranking(st - 1, cb_prev, st & 1);
+      products(st);
+      cb_prev = cb;
+    }
     __syncthreads();
+    if (sFlag[st & 1]) {        // uniform: written before the barrier, cleared behind the next one
+      cut_mine();
+      __syncthreads();
+      if (tid == 0) sFlag[st & 1] = 0;
+      refresh_tau();
+    }
   }
+  // waves 4-7 still owe the last stage's ranking (up to 64 more appends per user: room was made above)
+  if (rp == 1 && nst > 0 && !(dbg & 4)) ranking(nst - 1, cb_prev, 2);   // (flag slot 2: nobody looks)
+  __syncthreads();
   // ---- per user: the k largest keys in rank order, hits, metrics (wave w: users 8 w .. 8 w + 7) ------------------------
+  cut_mine();
+  __builtin_amdgcn_wave_barrier();
   for (int e = 0; e < 8; ++e) {
     const int ul = 8 * wave + e;
     const int64_t u = u0 + ul;
     if (u >= n_users) break;
     const int t0 = truth_ptr[u], t1 = truth_ptr[u + 1];
     if (t1 == t0) continue;
-    unsigned long long* list = sKeys + ul * kEvalList;
-    int c = sCnt[ul];
-    if (c > kk) {
-      eval_cut_list(list, c, kk, lane);
-      c = kk;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // rank of every kept key = the number of keys above it (all distinct); two keys per lane (k <= 128)
+    unsigned long long* list = sKeys + ul * LIST;
+    const int c = min(sCnt[ul], kk);
+    // rank of every kept key = the number of keys above it (all distinct); two keys per lane (k <= 100)
     unsigned long long mine[2];
     int rank[2] = {0, 0};
 #pragma unroll
@@ -408,13 +563,9 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
         }
         hit = lo < t1 && truth_idx[lo] == slot;
       }
-      // lanes hold arbitrary ranks: set bit `rank` of the mask through per-half ballots
 #pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        const bool in_w = hit && (rank[h] >> 6) == w;
-        // a wave-wide OR of one-hot 64-bit values: two 32-bit reductions by ballot-free shuffles would cost more than this loop of
-        // at most 64 set bits, so the bits are gathered with an LDS-free butterfly
-        unsigned long long v = in_w ? (1ull << (rank[h] & 63)) : 0ull;
+      for (int w = 0; w < 2; ++w) {   // a wave-wide OR of one-hot 64-bit values (lanes hold arbitrary ranks)
+        unsigned long long v = (hit && (rank[h] >> 6) == w) ? (1ull << (rank[h] & 63)) : 0ull;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
         hm[w] |= v;
@@ -445,17 +596,19 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 int launch_eval_fused(const StepArgs& a, const int32_t* uid, int64_t n_users, const int32_t* cand, int n_cand, const int32_t* truth_ptr,
                       const int32_t* truth_idx, int topk, float* metrics, int32_t* valid, hipStream_t stream) {
   const unsigned grid = (unsigned)((n_users + kEvalUsers - 1) / kEvalUsers);
+  const char* de = getenv("NNCF_EVAL_DBG");   // developer timing switches (1: no list traffic, 2: no products): wrong results
+  const int dbg = de ? atoi(de) : 0;
   ProfScope _ps("eval_fused_kernel", stream);
   if (a.d == 100) {
     static KernelDeviceState kst;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<25>), eval_fused_lds<25>(), kst)) return rc;
     hipLaunchKernelGGL(eval_fused_kernel<25>, dim3(grid), dim3(512), eval_fused_lds<25>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid);
+                       truth_idx, topk, metrics, valid, dbg);
   } else {
     static KernelDeviceState kst;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<32>), eval_fused_lds<32>(), kst)) return rc;
     hipLaunchKernelGGL(eval_fused_kernel<32>, dim3(grid), dim3(512), eval_fused_lds<32>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid);
+                       truth_idx, topk, metrics, valid, dbg);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;

@@ -122,13 +122,13 @@ __host__ __device__ __forceinline__ uint32_t mod_table(uint64_t x48) {
 
 // Draw j (0-based within the logical batch) uses state f^(j+1)(state0): nodesampler.cpp:23-26,73-76.
 // DPT = 4: a thread owns FOUR consecutive draws per iteration -- one 16-byte store (quads are aligned to 16 bytes of `out`
-// wherever it starts) -- and strides by f^(4T); its four binary searches (first id in [lo, hi] with bound[id] > r) run in
-// lock-step, branch-free, four reads in flight per round instead of four divergent loops one after the other.  DPT = 1: the
+// wherever it starts) -- and strides by f^(4T); its four guide reads travel together, then one binary search after the other
+// (first id in [lo, hi] with bound[id] > r).  DPT = 1: the
 // short batches of a training step (one draw per thread: the shortest chain).  LDS = true: bound[] and a coarser guide live in
 // the workgroup's LDS (the north-star's sketch; V <= ~25K ids: 68 KB + 49 KB at the CiteULike item count) -- every lookup of
 // a long stream (an epoch's negatives) is a few LDS reads instead of dependent L2 trips; short batches keep the global
 // tables (filling 117 KB of LDS would cost more than the draws).
-template <bool LDS, int DPT, bool LOCK>
+template <bool LDS, int DPT>
 __global__ void __launch_bounds__(LDS ? 1024 : 256) sample_kernel(const int32_t* __restrict__ bound, const int32_t* __restrict__ guide,
                                                                   int shift, int n_ids, int n_guide, uint64_t state0, int64_t first,
                                                                   int64_t count, int32_t* __restrict__ out, JumpTable jt, int nbits,
@@ -175,33 +175,14 @@ __global__ void __launch_bounds__(LDS ? 1024 : 256) sample_kernel(const int32_t*
       lo[e] = gd[g];
       hi[e] = gd[g + 1];
     }
-    if (LOCK) {   // global tables: the DPT searches advance together, DPT dependent L2 trips in flight per round
-      bool open = false;
+    // one search after the other: advancing the DPT searches in lock-step (DPT reads in flight per round) was measured and lost on
+    // both table homes -- it issues a read per draw and round for every lane of the wave, finished or not (6.7e7 draws: LDS tables
+    // 157 vs 138 us, global tables 449 vs 318 us)
 #pragma unroll
-      for (int e = 0; e < DPT; ++e) open |= lo[e] < hi[e];
-      while (open) {
-        int32_t mid[DPT], bv[DPT];
-#pragma unroll
-        for (int e = 0; e < DPT; ++e) {
-          mid[e] = (lo[e] + hi[e]) >> 1;   // a finished search has lo == hi: reads bound[lo], changes nothing
-          bv[e] = bnd[mid[e]];
-        }
-        open = false;
-#pragma unroll
-        for (int e = 0; e < DPT; ++e) {
-          const bool act = lo[e] < hi[e], up = (uint32_t)bv[e] > r[e];
-          hi[e] = (act && up) ? mid[e] : hi[e];
-          lo[e] = (act && !up) ? mid[e] + 1 : lo[e];
-          open |= lo[e] < hi[e];
-        }
-      }
-    } else {      // LDS tables: one search after the other -- lock-step issues a read per draw and round for every lane of the
-#pragma unroll    // wave, finished or not, and the LDS with its bank conflicts is the bound there (measured: 157 vs 138 us at 6.7e7 draws)
-      for (int e = 0; e < DPT; ++e) {
-        while (lo[e] < hi[e]) {
-          const int32_t mid = (lo[e] + hi[e]) >> 1;
-          if ((uint32_t)bnd[mid] > r[e]) hi[e] = mid; else lo[e] = mid + 1;
-        }
+    for (int e = 0; e < DPT; ++e) {
+      while (lo[e] < hi[e]) {
+        const int32_t mid = (lo[e] + hi[e]) >> 1;
+        if ((uint32_t)bnd[mid] > r[e]) hi[e] = mid; else lo[e] = mid + 1;
       }
     }
     if (DPT == 1) {
@@ -369,9 +350,9 @@ int nncf_sampler_sample_slice_dev(nncf_sampler* s, int64_t offset, int64_t count
     const Affine stride = lcg_power((uint64_t)(blocks * threads * 4));
     const size_t lds = ((((size_t)s->n + 3) & ~(size_t)3) + (((size_t)s->n_guide_lds + 3) & ~(size_t)3)) * sizeof(int32_t);
     static KernelDeviceState kst;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sample_kernel<true, 4, false>), kSamplerLds, kst)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&sample_kernel<true, 4>), kSamplerLds, kst)) return rc;
     ProfScope _ps("sample_kernel", as_stream(stream));
-    hipLaunchKernelGGL((sample_kernel<true, 4, false>), dim3((unsigned)blocks), dim3(threads), lds, as_stream(stream), s->d_bound, s->d_guide_lds,
+    hipLaunchKernelGGL((sample_kernel<true, 4>), dim3((unsigned)blocks), dim3(threads), lds, as_stream(stream), s->d_bound, s->d_guide_lds,
                        s->shift_lds, (int)s->n, s->n_guide_lds, s->state, offset, count, d_out, s->jt, nbits, stride);
   } else {
     const int threads = 256;
@@ -381,15 +362,11 @@ int nncf_sampler_sample_slice_dev(nncf_sampler* s, int64_t offset, int64_t count
     if (blocks > cap) blocks = cap;
     const Affine stride = lcg_power((uint64_t)(blocks * threads * dpt));
     ProfScope _ps("sample_kernel", as_stream(stream));
-    static const bool no_lock = []() { const char* e = getenv("NNCF_SAMPLER_LOCKSTEP"); return e && e[0] == '0'; }();   // developer A/B
-    if (dpt == 4 && !no_lock)
-      hipLaunchKernelGGL((sample_kernel<false, 4, true>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
-                         s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
-    else if (dpt == 4)
-      hipLaunchKernelGGL((sample_kernel<false, 4, false>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
+    if (dpt == 4)
+      hipLaunchKernelGGL((sample_kernel<false, 4>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
                          s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
     else
-      hipLaunchKernelGGL((sample_kernel<false, 1, false>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
+      hipLaunchKernelGGL((sample_kernel<false, 1>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), s->d_bound, s->d_guide,
                          s->shift, (int)s->n, s->n_guide, s->state, offset, count, d_out, s->jt, nbits, stride);
   }
   NNCF_HIP_CHECK(hipGetLastError());

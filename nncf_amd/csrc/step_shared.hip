@@ -515,10 +515,17 @@ __global__ void __launch_bounds__(256) predict_tile_kernel(StepArgs a, const int
   }
   __syncthreads();
   const int wr = wave >> 1, wc = wave & 1;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // Two accumulation chains per element -- k-steps 0, 2, 4, ... and 1, 3, 5, ... -- added at the end: the definition of a
+  // predicted score, shared bit for bit with the one-kernel evaluator (csrc/eval.hip eval_fused_kernel, which needs the
+  // second chain to keep the matrix pipe busy).
+  f32x4 acc_e = {0.f, 0.f, 0.f, 0.f}, acc_o = {0.f, 0.f, 0.f, 0.f};
   const float* pa = sU + (wr * 16 + (lane & 15)) * DP + (lane >> 4);
   const float* pb = sV + (wc * 16 + (lane & 15)) * DP + (lane >> 4);
-  for (int kk = 0; kk < d4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], pb[4 * kk], acc, 0, 0, 0);
+  for (int kk = 0; kk < d4; kk += 2) {
+    acc_e = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], pb[4 * kk], acc_e, 0, 0, 0);
+    if (kk + 1 < d4) acc_o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk + 4], pb[4 * kk + 4], acc_o, 0, 0, 0);
+  }
+  const f32x4 acc = acc_e + acc_o;
   const int64_t gj = bj * kTile + wc * 16 + (lane & 15);
   const float bv = (gj < qn) ? item_bias(a, cid[gj]) : 0.f;
 #pragma unroll

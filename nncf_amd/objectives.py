@@ -82,11 +82,11 @@ class Evaluator(object):
             }
         return self._dev
 
-    FUSED_MAX_TOPK = 128   # nncf_eval_whole (csrc/eval.hip kEvalMaxK)
+    FUSED_MAX_TOPK = 100   # nncf_eval_whole (csrc/eval.hip kEvalMaxK)
 
     def _whole(self, model_predict, which, topk, user_chunk=2048, fused=None):
         """test_eval_mat + evaluate_mat (objectives.py:296-370) for one candidate set.  Default: ONE kernel scores and ranks
-        (nncf_eval_whole: no (users x candidates) matrix); fused=False (or NNCF_EVAL_FUSED=0, or eval_topk > 128) takes the
+        (nncf_eval_whole: no (users x candidates) matrix); fused=False (or NNCF_EVAL_FUSED=0, or eval_topk > 100) takes the
         two-kernel path over a score chunk -- both leave the same bits."""
         predict_engine = getattr(model_predict, "predict_engine", None)
         engine = predict_engine() if predict_engine is not None else model_predict.engine

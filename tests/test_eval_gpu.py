@@ -45,8 +45,8 @@ def _both_paths(ev, head, which, topk):
 
 @pytest.mark.parametrize("d,users,items,bias,norm,topk", [
     (24, 600, 500, None, True, 50),          # users not a multiple of 64, 500 candidates: 7 full stages + a ragged one
-    (100, 130, 3000, None, True, 50),        # the d = 100 instantiation (25 k-steps), lists cut several times
-    (128, 64, 700, "both", True, 128),       # d = 128, interaction bias, the largest k the kernel takes
+    (100, 400, 3000, None, True, 50),        # the d = 100 instantiation (25 k-steps), lists cut several times
+    (128, 300, 700, "both", True, 100),      # d = 128, interaction bias, the largest k the kernel takes
     (20, 257, 40, "item", False, 50),        # fewer candidates than k: every candidate is ranked
     (64, 1000, 2000, "user", True, 1),       # k = 1
 ])
@@ -104,7 +104,7 @@ def test_nncf_eval_whole_refuses_what_it_does_not_take():
     z = torch.zeros(400, dtype=torch.int32, device="cuda")
     f = torch.zeros(400, dtype=torch.float32, device="cuda")
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-    assert L.nncf_eval_whole(eng._h, p(z), 10, p(z), 5, p(z), p(z), 129, p(f), p(z), None) != 0      # k beyond the kernel's lists
+    assert L.nncf_eval_whole(eng._h, p(z), 10, p(z), 5, p(z), p(z), 101, p(f), p(z), None) != 0      # k beyond the kernel's lists
     assert L.nncf_eval_whole(eng._h, p(z), 10, p(z), 0, p(z), p(z), 50, p(f), p(z), None) != 0       # no candidates
     assert L.nncf_eval_whole(eng._h, None, 10, p(z), 5, p(z), p(z), 50, p(f), p(z), None) != 0
     assert L.nncf_eval_whole(eng._h, p(z), 0, p(z), 5, p(z), p(z), 50, p(f), p(z), None) == 0        # no users: nothing to do
@@ -163,4 +163,4 @@ def test_evaluator_at_the_baseline_shape_equals_the_oracle_and_the_two_kernel_pa
         assert rf["users"] == n_ok
         for i, name in enumerate(("map", "recall", "precision")):
             assert abs(rf["%s@50" % name] - want[i]) <= 1e-5, (which, name, rf, want)
-        assert rf["recall@50"] > 0.01   # the comparison is not about empty hit lists
+        assert rf["recall@50"] > 0.001   # the comparison is not about empty hit lists
