@@ -109,6 +109,7 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
       p.t_part = m->sws.c_part;      // [b / 32][b] floats carved; b / (16 MT) strips are used
       p.stage = m->fstage;
       p.loss_part = m->fpart;
+      p.dom = m->fdom;
       return launch_pair_wide(a, group, uid, cid, p, pu, pv, loss_out, update, st);
     }
     if (!m->tile_ok)
@@ -134,6 +135,7 @@ int shared_step(nncf_model* m, const StepArgs& a, int group, const int32_t* uid,
   f.slab = m->fslab;
   f.cnt = m->fcnt;
   f.done = m->fdone;
+  f.dom = m->fdom;
   f.err = m->ferr;
   f.spin_ticks = m->spin_ticks;
   f.shared_device = m->shared_device;
@@ -194,6 +196,7 @@ void carve(nncf_model* m, Carver& c) {
     m->fslab = c.take<float>(sp > 1 ? 2 * mb * sp * 16 * 128 : 4);
     m->fcnt = c.take<int>(2 * mb);
     m->fdone = c.take<int>(2);
+    m->fdom = c.take<int>(8);
     m->ferr = c.take<int>(2);
     m->fstage = c.take<float>(2 * (size_t)b * 128);
     m->panchor = c.take<float>(b);

@@ -278,6 +278,7 @@ struct nncf_model {
   int* fcnt = nullptr;        // [2 strips per side] arrival tickets (zero between launches)
   float* fstage = nullptr;    // [2][b][128] staged gradient rows of a deferred step (FusedArgs::stage)
   int* fdone = nullptr;       // [2] workgroups that finished reading, by launch parity (FusedArgs::done)
+  int* fdom = nullptr;        // [2][4] value range of the batch's rows, by launch parity (FusedArgs::dom)
   int* ferr = nullptr;        // [1] raised by a hand-shake wait that timed out (FusedArgs::err); sticky
   int shared_device = 0;      // nncf_model_set_shared_device: never wait inside a launch (stage + commit)
   long long spin_ticks = 25000000;   // bound of the in-launch wait, 100 MHz ticks (NNCF_FUSED_SPIN_MS)

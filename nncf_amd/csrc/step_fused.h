@@ -45,6 +45,12 @@ struct FusedArgs {
   // fused_commit_kernel, a second launch, steps the tables
   float* stage = nullptr;
   long long* dbg = nullptr;   // developer timing: [workgroup][32] s_memtime stamps (NNCF_DEBUG_TIMING=1)
+  // Large-batch kernels, f16-plane products (round 5): dom[parity][4] = {max |x| of the batch's user rows, of its item rows
+  // (float bits), largest multiplicity of a user, of an item}, written by wide_domain_kernel in front of the step.  The
+  // f16-plane instantiation runs only if every staged value and every dL/dS entry fits fp16's range by a margin; otherwise
+  // it returns at once and the fp32-pipe instantiation, launched right behind it with the same arguments, takes the step.
+  // NULL: no guard (NNCF_WIDE_F16SPLIT=0 / =force).
+  int* dom = nullptr;
 };
 
 // pointwise loss, no InteractionDot bias, b a multiple of 16

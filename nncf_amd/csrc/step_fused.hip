@@ -33,6 +33,8 @@
 //
 // The loss of a step is the sum of per-workgroup partials; it is finalised by the NEXT launch of this
 // kernel (or by fused_loss_flush_kernel at the end of an entry point): nothing waits for it.
+#include <algorithm>
+
 #include "common.h"
 #include "devutil.h"
 #include "model.h"
@@ -700,6 +702,85 @@ __global__ void __launch_bounds__(512) fused_strip_kernel(StepArgs a, const int3
   }
 }
 
+// ---- the f16-plane pipe's domain (round 5) -----------------------------------------------------------------------------
+// Round 4 moved the wide kernels' products to fp16 hi / lo planes: exact to 6e-8 INSIDE fp16's range, inf -> NaN outside it
+// (|x| >= 65,504; an mse gradient 2 w (s - y) of a diverging run) where the reference's fp32 keeps going.  Now the step
+// decides for itself: wide_domain_kernel takes the range of exactly the rows this batch touches (one pass over 2 b rows,
+// ~3 us at b = 8,192) and the largest multiplicities from the plans; fused_wide_kernel<H16> runs only if wide_in_domain()
+// holds, its fp32-pipe twin, launched behind it with the same arguments, only if it does not.  One of the two returns at
+// once (~2 us): no NaN where fp32 has none, and nothing for the host to read.
+constexpr float kDomRow = 32768.f;     // staged values: hi = fp16(x) and lo = fp16((x - hi) 2048) both finite
+constexpr float kDomGrad = 60000.f;    // dL/dS entries (times the step's power-of-two scale)
+__device__ __forceinline__ float wide_gscale(float wneg) { return exp2f(-ceilf(log2f(fmaxf(wneg, 1.f / 64.f)))); }
+
+template <int LOSS, bool GROUP>
+__device__ __forceinline__ bool wide_in_domain(const StepArgs& a, const FusedArgs& f, const PlanView& pv) {
+  if (!f.dom) return true;
+  const int* dm = f.dom + 4 * f.parity;
+  const float umax = __int_as_float(dm[0]), vmax = __int_as_float(dm[1]);
+  const float cmax = (float)max(dm[2], dm[3]);
+  if (!(umax < kDomRow && vmax < kDomRow)) return false;   // (NaN rows fail the test too: the fp32 pipe reports them as it always did)
+  const int n_items = GROUP ? pv.counts[0] : a.b;
+  const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
+  const float gs = wide_gscale(wneg);
+  // rows entering the products: normalised (|x| <= 1) or raw; a score is at most d |u|max |v|max
+  const float ur = a.norm_u ? 1.f : umax, vr = a.norm_v ? 1.f : vmax;
+  float hmax;
+  if (LOSS == NNCF_LOSS_SKIP_GRAM) hmax = cmax * fmaxf(wneg, 1.f);                                   // multiplicity x weight x sigmoid
+  else hmax = 2.f * cmax * fmaxf(wneg, 1.f) * ((float)a.d * ur * vr + 1.f);                          // mse: 2 w (s - y)
+  return hmax * gs < kDomGrad;
+}
+
+// grid: ceil(2 b / 64) workgroups of 1,024 threads; a 16-lane group per batch position and side
+template <bool GROUP>
+__global__ void __launch_bounds__(1024) wide_domain_kernel(StepArgs a, const int32_t* __restrict__ uid, const int32_t* __restrict__ cid,
+                                                          FusedArgs f, PlanView pu, PlanView pv) {
+  __shared__ int sMax[16][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = tid >> 4, q = tid & 15;
+  const int d4 = a.d >> 2, b = a.b;
+  const int j = blockIdx.x * 64 + g;
+  float mx = 0.f;
+  int cm = 0;
+  bool item = false;
+  if (j < 2 * b) {
+    item = j >= b;
+    const int p = item ? j - b : j;
+    const Row r = row_load(item ? a.V : a.U, item ? cid[p] : uid[p], a.stride, d4, q);
+    const float4 aa = r.a, bb = r.b;
+    mx = fmaxf(fmaxf(fmaxf(fabsf(aa.x), fabsf(aa.y)), fmaxf(fabsf(aa.z), fabsf(aa.w))),
+               fmaxf(fmaxf(fabsf(bb.x), fabsf(bb.y)), fmaxf(fabsf(bb.z), fabsf(bb.w))));
+    if (!(mx == mx) || !(aa.x == aa.x && aa.y == aa.y && aa.z == aa.z && aa.w == aa.w && bb.x == bb.x && bb.y == bb.y && bb.z == bb.z && bb.w == bb.w))
+      mx = __builtin_inff();   // a NaN anywhere: outside every domain (fmaxf drops NaNs)
+    // multiplicities: segment p of this side's plan, if there is one (group: a unique item is one column)
+    const PlanView& po = item ? pv : pu;
+    if (q == 0 && p < po.counts[0] && !(GROUP && item)) cm = reinterpret_cast<const int4*>(po.desc)[p].w;
+  }
+  // the workgroup's maxima per side: 16 groups -> 4 waves -> LDS -> one atomic each (positive floats order like their bits)
+  int mu = item ? 0 : __float_as_int(mx), mv = item ? __float_as_int(mx) : 0, cu = item ? 0 : cm, cv = item ? cm : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mu = max(mu, __shfl_xor(mu, o));
+    mv = max(mv, __shfl_xor(mv, o));
+    cu = max(cu, __shfl_xor(cu, o));
+    cv = max(cv, __shfl_xor(cv, o));
+  }
+  if (lane == 0) {
+    sMax[wave][0] = mu;
+    sMax[wave][1] = mv;
+    sMax[wave][2] = cu;
+    sMax[wave][3] = cv;
+  }
+  __syncthreads();
+  if (tid < 4) {
+    int v = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v = max(v, sMax[w][tid]);
+    // most workgroups do not raise the running maximum: look before the atomic (2 b / 64 workgroups on four addresses)
+    int* cell = f.dom + 4 * f.parity + tid;
+    if (v > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, v);
+  }
+}
+
 // ---- large batches (b >= 4096): MT row tiles of 16 own rows per workgroup --------------------------------------
 // At b = 512 the step is latency-bound and 16-row strips split over several workgroups fill the chip; at b >= 4096
 // it is fp32-MFMA-bound and a 16-row strip pays the staging of every 128-row stage (global -> LDS, normalisation,
@@ -900,7 +981,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   FSTAMP(3);
   const float inv_b = 1.f / (float)b;
   const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
-  const float gscale = exp2f(-ceilf(log2f(fmaxf(wneg, 1.f / 64.f))));   // H16: 64 at lambda / N = 1 / 64 and below, 1 / 128 at lambda = 128, N = 2
+  const float gscale = wide_gscale(wneg);   // H16: 64 at lambda / N = 1 / 64 and below, 1 / 128 at lambda = 128, N = 2
   f32x4 accD0[MT], accD1[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -1143,7 +1224,10 @@ __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32
                                                          PlanView pv, int update, int gu) {
   extern __shared__ __attribute__((aligned(16))) float fused_smem[];
   const int id = blockIdx.x;
+  // f16 planes only inside their domain; outside it the fp32-pipe twin behind this launch takes the step (wide_in_domain)
+  if (f.dom && wide_in_domain<LOSS, GROUP>(a, f, pv) != H16) return;
   if (id == 2 * gu) {
+    if (f.dom && threadIdx.x < 4) f.dom[4 * (f.parity ^ 1) + threadIdx.x] = 0;   // the next step's range cells
     if (threadIdx.x < 64 && f.prev_out) {
       float l = 0.f;
       for (int i = threadIdx.x; i < f.prev_n; i += 64) l += f.prev_part[i];
@@ -1228,40 +1312,72 @@ int launch_commit(const StepArgs& a, const FusedArgs& f, const PlanView& pu, con
   return NNCF_OK;
 }
 
-// NNCF_WIDE_F16SPLIT=0: the products of the wide kernel on the fp32 matrix pipe (as before round 4)
-static bool wide_f16_split() {   // (read per launch: tests switch it inside one process)
+// NNCF_WIDE_F16SPLIT (read per launch: tests switch it inside one process): unset / 1 = the wide kernel's products on the f16
+// pipe as fp16 planes WHERE THAT IS EXACT, decided per step on the device (wide_in_domain), the fp32 pipe otherwise;
+// 0 = always the fp32 matrix pipe (as before round 4); force = f16 planes without the guard (measurement)
+static int wide_f16_mode() {
   const char* e = getenv("NNCF_WIDE_F16SPLIT");
-  return !(e && atoi(e) == 0);
+  if (!e || !e[0]) return 1;
+  if (e[0] == 'f') return 2;
+  return atoi(e) == 0 ? 0 : 1;
 }
 
+// staged: -1 = decide here (in place, with the hand-shake, only when the whole grid is resident at once on a device this model
+// has to itself); 0 / 1 = the caller decided (the guarded pair below must agree).  commit: run the commit launch of a staged step.
 template <int LOSS, bool GROUP, bool NU, bool NV, int MT, bool H16>
 int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
-             const PlanView& pv, int update, hipStream_t stream) {
+             const PlanView& pv, int update, hipStream_t stream, int staged = -1, bool commit = true, int* capacity_out = nullptr,
+             bool launch = true) {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
   auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT, H16>;
   static KernelDeviceState kds;
   int capacity = 0;
   constexpr size_t lds = wide_lds_bytes<MT, GROUP>();
   if (int rc = prepare_kernel(reinterpret_cast<const void*>(kern), lds, kds, &capacity)) return rc;
+  if (capacity_out) *capacity_out = capacity;
+  if (!launch) return NNCF_OK;
   FusedArgs fa = f;
-  // in place (with the hand-shake) only when the whole grid is resident at once on a device this model has to itself
-  if (!(update && (2 * gu > capacity || f.shared_device || force_deferred()))) fa.stage = nullptr;
+  const bool st = staged >= 0 ? staged != 0 : (update && (2 * gu > capacity || f.shared_device || force_deferred()));
+  if (!st) fa.stage = nullptr;
   {
     ProfScope _ps("fused_wide_kernel", stream);
     hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), lds, stream, a, uid, cid, fa, pu, pv, update, gu);
   }
   NNCF_HIP_CHECK(hipGetLastError());
-  return fa.stage ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;
+  return (fa.stage && commit) ? launch_commit<GROUP>(a, fa, pu, pv, stream) : NNCF_OK;
+}
+
+// the f16-plane step with its guard: range of the batch's rows -> f16-plane kernel -> fp32-pipe twin (one of the two returns at once)
+template <int LOSS, bool GROUP, bool NU, bool NV, int MT>
+int launch_w_guarded(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
+                     const PlanView& pv, int update, hipStream_t stream) {
+  {
+    ProfScope _ps("wide_domain_kernel", stream);
+    hipLaunchKernelGGL(wide_domain_kernel<GROUP>, dim3((2 * a.b + 63) / 64), dim3(1024), 0, stream, a, uid, cid, f, pu, pv);
+  }
+  // ONE stage + commit decision for the twins (whichever runs must be resident at once to step in place): the smaller capacity
+  const int gu = (a.b + 16 * MT - 1) / (16 * MT);
+  int cap_h = 0, cap_f = 0;
+  if (int rc = launch_w<LOSS, GROUP, NU, NV, MT, true>(a, uid, cid, f, pu, pv, update, stream, -1, false, &cap_h, /*launch=*/false)) return rc;
+  if (int rc = launch_w<LOSS, GROUP, NU, NV, MT, false>(a, uid, cid, f, pu, pv, update, stream, -1, false, &cap_f, /*launch=*/false)) return rc;
+  const int staged = (update && (2 * gu > std::min(cap_h, cap_f) || f.shared_device || force_deferred())) ? 1 : 0;
+  if (int rc = launch_w<LOSS, GROUP, NU, NV, MT, true>(a, uid, cid, f, pu, pv, update, stream, staged, /*commit=*/false)) return rc;
+  return launch_w<LOSS, GROUP, NU, NV, MT, false>(a, uid, cid, f, pu, pv, update, stream, staged, /*commit=*/true);
 }
 
 template <int LOSS, bool GROUP, bool NU, bool NV>
 int launch_f(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream) {
   const int mt = fused_row_tiles(a);
-  if (mt == 4 && wide_f16_split()) return launch_w<LOSS, GROUP, NU, NV, 4, true>(a, uid, cid, f, pu, pv, update, stream);
-  if (mt == 2 && wide_f16_split()) return launch_w<LOSS, GROUP, NU, NV, 2, true>(a, uid, cid, f, pu, pv, update, stream);
-  if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4, false>(a, uid, cid, f, pu, pv, update, stream);
-  if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2, false>(a, uid, cid, f, pu, pv, update, stream);
+  const int mode = wide_f16_mode();   // 1: f16 planes where they are exact, else the fp32 pipe (default); 0: fp32 pipe; 2: f16 planes, unguarded
+  FusedArgs fu = f;
+  fu.dom = nullptr;
+  if (mt == 4 && mode == 1) return launch_w_guarded<LOSS, GROUP, NU, NV, 4>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 2 && mode == 1) return launch_w_guarded<LOSS, GROUP, NU, NV, 2>(a, uid, cid, f, pu, pv, update, stream);
+  if (mt == 4 && mode == 2) return launch_w<LOSS, GROUP, NU, NV, 4, true>(a, uid, cid, fu, pu, pv, update, stream);
+  if (mt == 2 && mode == 2) return launch_w<LOSS, GROUP, NU, NV, 2, true>(a, uid, cid, fu, pu, pv, update, stream);
+  if (mt == 4) return launch_w<LOSS, GROUP, NU, NV, 4, false>(a, uid, cid, fu, pu, pv, update, stream);
+  if (mt == 2) return launch_w<LOSS, GROUP, NU, NV, 2, false>(a, uid, cid, fu, pu, pv, update, stream);
   const int gu = (a.b + kFM - 1) / kFM;                       // user strips: this launch's rows
   const int gv = ((a.bc ? a.bc : a.b) + kFM - 1) / kFM;       // item strips: all columns
   const int nblk = ((gu + gv + 7) / 8) * 8 * f.split;

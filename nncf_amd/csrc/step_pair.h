@@ -12,6 +12,10 @@ struct PairArgs {
   float* t_part = nullptr;     // [strips][b]   per strip of the position-streaming side: sum of dL/dS over its own rows
   float* stage = nullptr;      // [2][b][128]   dL/d(normalised row) of every unique row, by rank (users, then items)
   float* loss_part = nullptr;  // [strips] (neg_shared) / [2 strips] (group): loss + regulariser partials
+  // f16-plane products only where they are exact (round 5; step_fused.hip wide_in_domain): dom[4] = {max |x| of the batch's user rows,
+  // of its item rows (float bits), the largest multiplicity of a row, unused}, taken by pair_anchor_kernel, cleared by the commit
+  // kernel; pair_wide_kernel<H16> runs inside the domain, its fp32-pipe twin behind it outside.  NULL: no guard.
+  int* dom = nullptr;
 };
 
 // log-loss / max-margin, id tables, no InteractionDot bias, no exported gradients, b a multiple of 16

@@ -83,22 +83,73 @@ __device__ __forceinline__ void pair_lh(float x, float gamma, float& l, float& h
   }
 }
 
+// + the value range of the batch's rows and the largest multiplicity for the f16-plane guard (PairArgs::dom)
+template <bool GROUP>
 __global__ void __launch_bounds__(256) pair_anchor_kernel(StepArgs a, const int32_t* __restrict__ uid,
                                                           const int32_t* __restrict__ cid, float* __restrict__ anchor,
-                                                          float* __restrict__ uhat, float* __restrict__ vhat) {
-  const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
+                                                          float* __restrict__ uhat, float* __restrict__ vhat, int* __restrict__ dom,
+                                                          PlanView pu, PlanView pv) {
+  __shared__ int sMax[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = tid >> 4, q = tid & 15;
   const int p = blockIdx.x * 16 + g;
-  if (p >= a.b) return;
   const int d4 = a.d >> 2;
-  Row ru = row_load(a.U, uid[p], a.stride, d4, q);
-  Row rv = row_load(a.V, cid[p], a.stride, d4, q);
-  if (a.norm_u) ru = row_scale(ru, inv_norm(row16_sum(row_dot_partial(ru, ru))));
-  if (a.norm_v) rv = row_scale(rv, inv_norm(row16_sum(row_dot_partial(rv, rv))));
-  const float s = row_dot(ru, rv);
-  if (q == 0) anchor[p] = s;
-  // the commit kernel steps both tables in place: the rows its corrections need are kept as they were
-  row_store(uhat, p, a.d, d4, q, ru);
-  row_store(vhat, p, a.d, d4, q, rv);
+  int mu = 0, mv = 0, cm = 0;
+  if (p < a.b) {
+    Row ru = row_load(a.U, uid[p], a.stride, d4, q);
+    Row rv = row_load(a.V, cid[p], a.stride, d4, q);
+    if (dom) {
+      auto amax = [](const Row& r) {
+        float m = fmaxf(fmaxf(fmaxf(fabsf(r.a.x), fabsf(r.a.y)), fmaxf(fabsf(r.a.z), fabsf(r.a.w))),
+                        fmaxf(fmaxf(fabsf(r.b.x), fabsf(r.b.y)), fmaxf(fabsf(r.b.z), fabsf(r.b.w))));
+        const float sum = (r.a.x + r.a.y) + (r.a.z + r.a.w) + (r.b.x + r.b.y) + (r.b.z + r.b.w);
+        return sum == sum ? m : __builtin_inff();   // a NaN anywhere: outside every domain
+      };
+      mu = __float_as_int(amax(ru));
+      mv = __float_as_int(amax(rv));
+      if (q == 0) {   // multiplicities of the side that streams by position's OWN rows: unique users (neg_shared); group: columns are unique
+        cm = 1;
+        if (!GROUP && p < pu.counts[0]) cm = reinterpret_cast<const int4*>(pu.desc)[p].w;
+      }
+    }
+    if (a.norm_u) ru = row_scale(ru, inv_norm(row16_sum(row_dot_partial(ru, ru))));
+    if (a.norm_v) rv = row_scale(rv, inv_norm(row16_sum(row_dot_partial(rv, rv))));
+    const float s = row_dot(ru, rv);
+    if (q == 0) anchor[p] = s;
+    // the commit kernel steps both tables in place: the rows its corrections need are kept as they were
+    row_store(uhat, p, a.d, d4, q, ru);
+    row_store(vhat, p, a.d, d4, q, rv);
+  }
+  if (!dom) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mu = max(mu, __shfl_xor(mu, o));
+    mv = max(mv, __shfl_xor(mv, o));
+    cm = max(cm, __shfl_xor(cm, o));
+  }
+  if (lane == 0) {
+    sMax[wave][0] = mu;
+    sMax[wave][1] = mv;
+    sMax[wave][2] = cm;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const int v = max(max(sMax[0][tid], sMax[1][tid]), max(sMax[2][tid], sMax[3][tid]));
+    if (v > __hip_atomic_load(dom + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dom + tid, v);
+  }
+}
+
+// f16 planes where they are exact: staged rows (normalised: |x| <= 1, else raw) and the dL/dS plane -- (c - m) gamma sigmoid for
+// log-loss, (c - m) for max-margin -- inside fp16's range by a margin (multiplicity x loss_gamma beyond 65,504 turned
+// the tables NaN behind a finite loss)
+template <int LOSS>
+__device__ __forceinline__ bool pair_in_domain(const StepArgs& a, const PairArgs& p) {
+  if (!p.dom) return true;
+  const float umax = a.norm_u ? 1.f : __int_as_float(p.dom[0]), vmax = a.norm_v ? 1.f : __int_as_float(p.dom[1]);
+  if (!(__int_as_float(p.dom[0]) < 3.0e38f && __int_as_float(p.dom[1]) < 3.0e38f)) return false;   // inf / NaN rows: the fp32 pipe reports them
+  const float cmax = (float)max(p.dom[2], 1);
+  const float hmax = cmax * (LOSS == NNCF_LOSS_LOG_LOSS ? fmaxf(a.gamma, 1.f) : 1.f);
+  return umax < 32768.f && vmax < 32768.f && hmax < 60000.f;
 }
 
 // POS (this side streams by position and owns the loss and the T sums): USIDE for neg_shared, the item side for group.
@@ -135,8 +186,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   // by-position side: the streamed row's index itself (a batch position for neg_shared, a unique-item rank for group)
   auto opp_key = [&](int j) -> int { return POS ? (USIDE ? pu.inverse[j] : pv.inverse[j]) : j; };
   const int nst = (n_opp + kPNB - 1) / kPNB;
-  int idA[4], keyA[4], idB[4], keyB[4];
-  float dA[4], dB[4];
+  int idA[4], keyA[4];   // ids / keys / anchors of the NEXT stage: requested under one stage's back-GEMM, used under the next one's
+  float dA[4];           // (one set, and the rows requested there too: the two sets + rows in flight across S + dL/dS spilled 8-17 registers)
   auto load_ids = [&](int st, int* ids, int* keys, float* dd) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -148,7 +199,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     }
   };
   load_ids(0, idA, keyA, dA);
-  load_ids(1, idB, keyB, dB);
   __syncthreads();
 
   Row rcur[4], rnext[4];
@@ -164,11 +214,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   for (int e = 0; e < 4; ++e) {
     kcur[e] = keyA[e];
     dcur[e] = dA[e];
-    idA[e] = idB[e];
-    keyA[e] = keyB[e];
-    dA[e] = dB[e];
   }
-  load_ids(2, idB, keyB, dB);
+  load_ids(1, idA, keyA, dA);
 
   // ---- own rows: 16 MT unique ids (POS) or 16 MT batch positions of this side ----------------------------------
   // {table row, multiplicity, key (POS: the rank; else what a streamed row's key is compared with), stage slot, anchor}
@@ -266,16 +313,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       }
     }
     __syncthreads();
-    load_rows(idA, rnext);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      kcur[e] = keyA[e];
-      dcur[e] = dA[e];
-      idA[e] = idB[e];
-      keyA[e] = keyB[e];
-      dA[e] = dB[e];
-    }
-    load_ids(st + 3, idB, keyB, dB);
 
     // S tiles and dL/dS: the MFMAs of tile m + 1 are issued before the element-wise work of tile m
     {
@@ -358,6 +395,14 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       }
     }
     __syncthreads();
+    // the next stage's rows (their ids arrived a stage ago) and the ids of the stage after it: requested here, under the back-GEMM
+    load_rows(idA, rnext);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kcur[e] = keyA[e];   // (this stage's keys / anchors went to LDS at its top)
+      dcur[e] = dA[e];
+    }
+    load_ids(st + 2, idA, keyA, dA);
     if (back_wave && update && H16) {
       const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + 16 * wave + x;
 #pragma unroll
@@ -443,6 +488,7 @@ __global__ void __launch_bounds__(512) pair_wide_kernel(StepArgs a, const int32_
                                                         PlanView pv, int update, int gu) {
   extern __shared__ __attribute__((aligned(16))) float pair_smem[];
   const int id = blockIdx.x;
+  if (p.dom && pair_in_domain<LOSS>(a, p) != H16) return;   // f16 planes inside their domain, the fp32-pipe twin outside
   const int nseg_u = pu.counts[0], nseg_v = pv.counts[0];
   const int strip = id >> 1;
   // rows a side's strips share out: unique rows where it streams by position, the b batch positions where it does not
@@ -478,6 +524,7 @@ __global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p
   const int q = tid & 15;
   const int b = a.b, d4 = a.d >> 2;
   if (blockIdx.x == gridDim.x - 1) {
+    if (p.dom && tid < 4) p.dom[tid] = 0;   // the next step's range cells (pair_anchor_kernel)
     if (tid >= 64) return;
     float l = 0.f;
     for (int t0 = lane; t0 < n_loss; t0 += 64 * 8) {
@@ -536,20 +583,29 @@ __global__ void __launch_bounds__(256) pair_commit_kernel(StepArgs a, PairArgs p
 
 namespace {
 
-template <int LOSS, bool GROUP, int MT, bool H16>
-int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
-              const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
+// mode 1: range of the batch's rows (with the anchors) -> f16-plane strips -> fp32-pipe twin (one of the two returns at once) ->
+// commit; 0 / 2: the fp32 pipe / the f16 planes alone, no guard
+template <int LOSS, bool GROUP, int MT>
+int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p0, const PlanView& pu,
+              const PlanView& pv, float* loss_out, int update, hipStream_t stream, int mode) {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
-  auto kern = pair_wide_kernel<LOSS, GROUP, MT, H16>;
-  static KernelDeviceState kds;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pair_lds_bytes<MT>(), kds)) return rc;
+  PairArgs p = p0;
+  if (mode != 1) p.dom = nullptr;
+  static KernelDeviceState kds_h, kds_f;
+  if (mode != 0)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(pair_wide_kernel<LOSS, GROUP, MT, true>), pair_lds_bytes<MT>(), kds_h)) return rc;
+  if (mode != 2)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(pair_wide_kernel<LOSS, GROUP, MT, false>), pair_lds_bytes<MT>(), kds_f)) return rc;
   {
     ProfScope _ps("pair_anchor_kernel", stream);
-    hipLaunchKernelGGL(pair_anchor_kernel, dim3((a.b + 15) / 16), dim3(256), 0, stream, a, uid, cid, p.anchor, p.uhat, p.vhat);
+    hipLaunchKernelGGL(pair_anchor_kernel<GROUP>, dim3((a.b + 15) / 16), dim3(256), 0, stream, a, uid, cid, p.anchor, p.uhat, p.vhat, p.dom, pu, pv);
   }
   {
     ProfScope _ps("pair_wide_kernel", stream);
-    hipLaunchKernelGGL(kern, dim3(2 * gu), dim3(512), pair_lds_bytes<MT>(), stream, a, uid, cid, p, pu, pv, update, gu);
+    if (mode != 0)
+      hipLaunchKernelGGL((pair_wide_kernel<LOSS, GROUP, MT, true>), dim3(2 * gu), dim3(512), pair_lds_bytes<MT>(), stream, a, uid, cid, p, pu, pv, update, gu);
+    if (mode != 2)
+      hipLaunchKernelGGL((pair_wide_kernel<LOSS, GROUP, MT, false>), dim3(2 * gu), dim3(512), pair_lds_bytes<MT>(), stream, a, uid, cid, p, pu, pv, update, gu);
   }
   const int max_chunks = (a.b + kChunkSlots - 1) / kChunkSlots;
   {
@@ -564,13 +620,11 @@ int launch_pw(const StepArgs& a, const int32_t* uid, const int32_t* cid, const P
 template <int LOSS, bool GROUP>
 int launch_pm(const StepArgs& a, const int32_t* uid, const int32_t* cid, const PairArgs& p, const PlanView& pu,
               const PlanView& pv, float* loss_out, int update, hipStream_t stream) {
-  const char* e = getenv("NNCF_WIDE_F16SPLIT");   // 0: the products on the fp32 matrix pipe (as before round 4; step_fused.hip)
-  const bool h16 = !(e && atoi(e) == 0);
-  if (pair_row_tiles(a) == 4)
-    return h16 ? launch_pw<LOSS, GROUP, 4, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
-               : launch_pw<LOSS, GROUP, 4, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
-  return h16 ? launch_pw<LOSS, GROUP, 2, true>(a, uid, cid, p, pu, pv, loss_out, update, stream)
-             : launch_pw<LOSS, GROUP, 2, false>(a, uid, cid, p, pu, pv, loss_out, update, stream);
+  // NNCF_WIDE_F16SPLIT as in step_fused.hip: unset / 1 = f16 planes where exact (device-side guard), 0 = fp32 pipe, force = planes, unguarded
+  const char* e = getenv("NNCF_WIDE_F16SPLIT");
+  const int mode = (!e || !e[0]) ? 1 : (e[0] == 'f' ? 2 : (atoi(e) == 0 ? 0 : 1));
+  if (pair_row_tiles(a) == 4) return launch_pw<LOSS, GROUP, 4>(a, uid, cid, p, pu, pv, loss_out, update, stream, mode);
+  return launch_pw<LOSS, GROUP, 2>(a, uid, cid, p, pu, pv, loss_out, update, stream, mode);
 }
 
 }  // namespace

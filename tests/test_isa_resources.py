@@ -17,8 +17,6 @@ import isa_resources  # noqa: E402
 # kernel-name patterns that no default path launches, and why
 OPT_IN = [
     (r"rocprim::", "rocPRIM's radix sort (device shuffle): library code, its private segment is the sort's own"),
-    (r"pair_wide_kernel<\d+, (true|false), \d+, false>", "NNCF_WIDE_F16SPLIT=0: the large-batch pairwise strips on the fp32 matrix pipe "
-                                                         "(the default since round 4 is the f16-plane pipe, H16 = true)"),
 ]
 
 

@@ -275,3 +275,40 @@ def test_large_batch_random_shapes_match(seed):
     amp = max(1.0, scale) * max(1.0, 1.0 / (0.5 * scale * np.sqrt(d / 3.0))) * max(1.0, b / (512.0 * min(nu, ni)))
     np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-5, atol=1e-5 * amp, err_msg=str(info))
     np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-5, atol=1e-5 * amp, err_msg=str(info))
+
+
+@pytest.mark.parametrize("case", ["gamma_times_multiplicity", "large_rows"])
+def test_pair_strips_leave_the_fp16_planes_outside_their_domain(force_row_tiles, monkeypatch, case):
+    """the f16-plane strips store dL/dS = (c - m) gamma sigmoid unscaled -- multiplicity x loss_gamma beyond 65,504
+    (a one-user batch with a large gamma) turned the tables NaN behind a finite loss; and un-normalised rows beyond fp16's range
+    never fitted the planes.  Round 5: pair_anchor_kernel takes the range of the batch's rows and the largest multiplicity, and
+    the step runs on the fp32-pipe twin when the planes would not be exact -- it equals the float64 oracle either way."""
+    monkeypatch.delenv("NNCF_WIDE_F16SPLIT", raising=False)
+    force_row_tiles(2)
+    b, d, nu, ni = 256, 20, 40, 300
+    rs = np.random.RandomState(9)
+    if case == "gamma_times_multiplicity":
+        GAMMA["log-loss"] = 300.          # 256 positions of ONE user x gamma = 76,800
+        try:
+            conf, eng, orc = _mk("log-loss", b, d, nu, ni, "mf", "pairwide", seed=2, lr=0.01)
+        finally:
+            GAMMA["log-loss"] = 10.
+        uid = np.zeros(b, dtype=np.int64)
+        cid = rs.randint(0, ni, b)
+    else:   # un-normalised rows (emb_normalization off), one of them of magnitude 10^6
+        conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="max-margin", loss_gamma=GAMMA["max-margin"], u_reg=1e-3,
+                             learn_rate=0.01, model_choice="mf", emb_normalization=False)
+        assert not conf.normalize_user and not conf.normalize_item
+        eng = _engine("pairwide", nu, ni, d, b, 0, "max-margin", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate,
+                      False, False, seed=2, init_scale=0.5)
+        uid, cid = _batch(rs, b, nu, ni, False)
+        eng.U[uid[0], :] = 1e6
+        orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float64)
+    want = orc.step_neg_shared(uid, cid)
+    got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    assert np.isfinite(got) and abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+    tu, tv = np.unique(uid), np.unique(cid)
+    U, V = eng.U.cpu().numpy(), eng.V.cpu().numpy()
+    assert np.isfinite(U).all() and np.isfinite(V).all()
+    np.testing.assert_allclose(U[tu], orc.U[tu], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(V[tv], orc.V[tv], rtol=2e-5, atol=5e-6)
