@@ -439,6 +439,15 @@ int nncf_tower_step(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t*
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all,
                      const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss,
                      int32_t* d_n_u, void* stream);
+/* Data-parallel form of nncf_tower_epoch (no reference counterpart: /root/reference/main.py:34-35 is single-device;
+ * SURVEY.md 8(e)): the tower has a gradient export buffer (nncf_tower_set_grad_export); per step the library runs the planned
+ * step, all-reduces the flat gradient over `comm` (nncf_comm_*: RCCL or the callback transport; NULL = one rank) on `stream`
+ * and takes the optimiser step with scale * gradient (nncf_tower_apply_grads) -- one native call per epoch instead of three
+ * ctypes calls per step. */
+struct nncf_comm;   /* the transport object of the multi-GPU trainers, declared with its entry points below */
+int nncf_tower_epoch_dp(nncf_tower* t, nncf_model* m, int32_t scheme, struct nncf_comm* comm, const int32_t* d_uid_all,
+                        const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss, float scale,
+                        void* stream);
 /* The epoch runner in two halves, for callers that put something between the steps (the
  * data-parallel path: all-reduce + nncf_tower_apply_grads after every step): plan up to 64
  * consecutive steps in one launch (d_uid[n_steps*b], d_cid[n_steps*b], d_neg[n_steps*b*k] for

@@ -165,6 +165,7 @@ def _declare(lib):
         "nncf_tower_backward": [vp, vp, vp],
         "nncf_tower_step": [vp, vp, i32, vp, vp, vp, i32, vp, vp],
         "nncf_tower_epoch": [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp],
+        "nncf_tower_epoch_dp": [vp, vp, i32, vp, vp, vp, vp, i64, vp, f32, vp],
         "nncf_tower_step_rowwise": [vp, vp, vp, vp, vp, vp, i32, vp, vp],
         "nncf_tower_plan_steps": [vp, vp, i32, vp, vp, vp, i64, vp],
         "nncf_tower_step_at": [vp, vp, i32, i64, vp, vp, vp],

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "tower.h"
+#include "comm.h"
 #include "step_fused.h"
 
 namespace nncf {
@@ -1884,6 +1885,46 @@ int nncf_tower_step_at(nncf_tower* t, nncf_model* m, int32_t scheme, int64_t ind
   t->fwd_cached = false;
   if (rc) return rc;
   return flush_pending_loss(m, as_stream(stream));
+}
+
+// Data-parallel epoch runner (round 5; SURVEY.md 8(e), no reference counterpart: /root/reference/main.py:34-35 selects one
+// device): nncf_tower_epoch with the tower's gradients exported (nncf_tower_set_grad_export), ONE all-reduce of the flat
+// gradient per step issued by the library on the step's stream (nncf_comm_all_reduce_f32: ncclAllReduce, or the callback
+// transport) and nncf_tower_apply_grads behind it -- the loop DataParallelTower.run_epoch ran from Python (three ctypes
+// calls and a tensor slice per step).  comm == NULL: one rank, nothing to reduce.
+int nncf_tower_epoch_dp(nncf_tower* t, nncf_model* m, int32_t scheme, nncf_comm* comm, const int32_t* d_uid_all,
+                        const int32_t* d_cid_all, const int32_t* d_neg_all, int64_t n_steps, float* d_loss, float scale, void* stream) {
+  NNCF_REQUIRE(scheme != 3, "row-wise batches go through nncf_tower_epoch_rowwise");
+  if (int rc = check_pair(t, m, scheme)) return rc;
+  NNCF_REQUIRE(t->gexp != nullptr, "the data-parallel runner needs the gradient export buffer (nncf_tower_set_grad_export)");
+  if (n_steps == 0) return NNCF_OK;
+  NNCF_REQUIRE(d_uid_all && d_cid_all && d_loss && n_steps > 0, "bad argument");
+  NNCF_REQUIRE(scheme != 0 || d_neg_all, "train_scheme=original needs the presampled negatives");
+  const int64_t b = m->cfg.batch_size_p, k = m->cfg.num_negatives, cap = t->cfg.max_rows;
+  const int n = (int)(scheme == 0 ? b * (1 + k) : b);
+  const int64_t nfl = nncf_tower_grad_floats(t);
+  hipStream_t st = as_stream(stream);
+  for (int64_t t0 = 0; t0 < n_steps; t0 += kPlanChunk) {
+    const int64_t cnt = (n_steps - t0 < kPlanChunk) ? n_steps - t0 : kPlanChunk;
+    int rc;
+    if (scheme == 0)
+      rc = launch_plan_steps(d_uid_all + t0 * b, b, (int)b, m->plan_u, d_cid_all + t0 * b, b, (int)b, d_neg_all + t0 * b * k, b * k,
+                             (int)(b * k), m->plan_v, t->uniq_g, cap, t->n_u, cnt, st, nullptr);
+    else
+      rc = launch_plan_steps(d_uid_all + t0 * b, b, (int)b, m->plan_u, d_cid_all + t0 * b, b, (int)b, nullptr, 0, 0, m->plan_v,
+                             t->uniq_g, cap, t->n_u, cnt, st, nullptr);
+    if (rc) return rc;
+    for (int64_t i = 0; i < cnt; ++i) {
+      const int64_t s = t0 + i;
+      rc = tower_step_body(t, m, scheme, d_uid_all + s * b, m->plan_u.at(i), m->plan_v.at(i), t->uniq_g + i * cap, t->n_u + i, n,
+                           d_loss + s, 1, nullptr, st);
+      if (rc) return rc;
+      if (comm && (rc = nncf_comm_all_reduce_f32(comm, t->gexp, nfl, stream))) return rc;
+      if ((rc = nncf_tower_apply_grads(t, t->gexp, scale, 0, stream))) return rc;
+    }
+  }
+  t->fwd_cached = false;
+  return flush_pending_loss(m, st);
 }
 
 int nncf_tower_epoch(nncf_tower* t, nncf_model* m, int32_t scheme, const int32_t* d_uid_all, const int32_t* d_cid_all,

@@ -659,6 +659,19 @@ class HipTowerReplica(object):
             self._lib.check(self._lib.lib().nncf_tower_apply_grads(self.tower.handle, ctypes.c_void_p(self.grad.data_ptr()),
                                                                    float(scale), 0, e._stream()))
 
+    def run_epoch_native(self, uid_all, cid_all, n_steps, losses, comm=None, scale=1.0):
+        """nncf_tower_epoch_dp: n_steps planned steps, each followed by the all-reduce of the exported gradient (issued by the
+        library over `comm`, a Communicator; None: one rank) and the optimiser step -- ONE native call for the whole loop."""
+        e, L = self.engine, self._lib.lib()
+        if losses is None:
+            losses = torch.empty(int(n_steps), dtype=torch.float32, device=e.device)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(e.device):
+            self._lib.check(L.nncf_tower_epoch_dp(self.tower.handle, e._h, self._SCHEME[self.scheme], comm.handle if comm is not None else None,
+                                                  p(uid_all), p(cid_all), None, int(n_steps), p(losses), float(scale), e._stream()))
+        self.tower.version += int(n_steps)
+        return losses
+
 
 class DataParallelTower(object):
     """Synchronous data-parallel SGD for model_choice = basic_embedding (no reference counterpart).
@@ -718,6 +731,15 @@ class DataParallelTower(object):
         single-GPU epoch runner does; per step: planned step -> all-reduce -> apply."""
         be = self.be
         chunk = getattr(be, "PLAN_CHUNK", 0)
+        # HIP replicas that can plan ahead run the whole loop natively (round 5): the library issues the all-reduce itself over
+        # a native communicator -- or reduces nothing on one aliased rank.  The torch transport keeps the loop below.
+        native = chunk and hasattr(be, "run_epoch_native") and (not self.reduce or self.comm is not None) \
+            and os.environ.get("NNCF_DP_NATIVE", "1") != "0"
+        if native and n_steps > 0:
+            if self.reduce:
+                self.wire_bytes += int(n_steps) * be.grad.numel() * be.grad.element_size()
+            return be.run_epoch_native(uid_all[:n_steps * b], cid_all[:n_steps * b], n_steps, losses,
+                                       comm=self.comm if self.reduce else None)
         for t0 in range(0, n_steps, max(chunk, 1)):
             cnt = min(max(chunk, 1), n_steps - t0)
             if chunk:

@@ -245,6 +245,40 @@ def test_data_parallel_run_epoch_equals_plain_epoch():
     np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_data_parallel_native_runner_equals_the_python_loop_bitwise(monkeypatch):
+    """nncf_tower_epoch_dp (round 5: planned step -> all-reduce -> apply for every step in ONE native call) against
+    DataParallelTower's Python loop of the same three library calls per step (NNCF_DP_NATIVE=0): losses, user table and every
+    tower parameter bit for bit, over 70 steps (two plan chunks) of neg_shared and group_neg_shared."""
+    from nncf_amd import synthetic
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    from nncf_amd.sharded import DataParallelTower, HipTowerReplica
+    data = synthetic.make_citeulike_like(users=300, items=260, train_links=5000, seed=3, content_len=24, vocab=120)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.05, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
+          "user_dim": 24, "item_dim": 24, "word_dim": 24, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.3}
+    conf = get_conf("synthetic", "best", dict({"optimizer": "sgd"}, **pd), model_choice="basic_embedding")
+    rs = np.random.RandomState(2)
+    steps, b = 70, 64
+    bt = data["train"][rs.choice(len(data["train"]), steps * b, replace=True)]
+    for scheme in ("neg_shared", "group_neg_shared"):
+        cid_np = np.repeat(bt[::4, 1], 4)[:steps * b] if scheme == "group_neg_shared" else bt[:, 1]
+        out = []
+        for native in ("1", "0"):
+            monkeypatch.setenv("NNCF_DP_NATIVE", native)
+            md = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)
+            dp = DataParallelTower(HipTowerReplica(md, scheme))
+            e = dp.be.engine
+            losses = torch.zeros(steps, device="cuda")
+            dp.run_epoch(e.ids(bt[:, 0]), e.ids(cid_np), steps, b, losses)
+            torch.cuda.synchronize()
+            tw = dp.be.tower
+            out.append([losses.clone(), e.U.clone()] + [getattr(tw, n).clone() for n in ("W", "Wd", "bd", "gamma", "beta")])
+        for x, y in zip(*out):
+            assert torch.equal(x, y), scheme
+
+
 def test_sharded_large_batch_world1():
     """The large-batch regime of config 4 through the sharded path at world 1: b = 4,096 links per step -- the
     4,096-entry request plan, the wide one-launch step exporting the item gradients, gather / scatter of 4,096 landing
