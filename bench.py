@@ -377,7 +377,9 @@ STEP_KERNELS = ("tower_pool_kernel", "tower_stats_kernel", "tower_bn_kernel", "t
                 "shared_tile_kernel", "shared_apply_kernel", "original_score_kernel", "original_apply_kernel",
                 "rowwise_score_kernel", "rowwise_apply_kernel", "pair_anchor_kernel", "pair_wide_kernel", "pair_commit_kernel",
                 "bias_update_kernel", "adam_idle_kernel", "cnn_conv_fwd_kernel", "cnn_stats_kernel", "cnn_pool_dense_kernel",
-                "cnn_merge_kernel", "cnn_conv_bwd_kernel", "cnn_update_kernel")
+                "cnn_merge_kernel", "cnn_conv_bwd_kernel", "cnn_update_kernel",
+                # round 5: the f16-plane guard of the large-batch step (range of the batch's rows; the fp32-pipe twin that returns at once)
+                "wide_domain_kernel", "fused_wide_twin_kernel")
 
 
 def calibrate_brackets(roofs, step_ms, prof_n):

@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         key[t][r] = rank_key(sc[t][r], j);
-        want[t][r] = key[t][r] > tau_k[t][r];
+        want[t][r] = sc[t][r] >= tau_f[t][r] && key[t][r] > tau_k[t][r];
       }
     int pos[2][4];
 #pragma unroll
@@ -502,18 +502,22 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   };
   __syncthreads();   // stage 0 is in LDS
   for (int st = 0; st < nst; ++st) {
-    // (a) the rows of stage st + 1 (in registers since the last iteration) -> the other buffer; the rows of stage st + 2 and the
-    //     ids of st + 3 are requested; (b) products + ranking, the two row-tile pairs half a stage apart; (c) barrier;
-    //     (d) if a list is nearly full: everybody cuts, one more barrier
-    if (st + 1 < nst) store_stage(st + 1);
-    load_rows();          // stage st + 2 (its ids arrived a stage ago)
-    load_ids(st + 3);
+    // Waves 0-3: products(st) | ranking(st), the rows of stage st + 1 -> the other buffer, the rows of st + 2 requested.
+    // Waves 4-7: ranking(st - 1), the same staging | products(st).  A SIMD's two waves (w, w + 4) thus hold the matrix pipe
+    // in turns: one multiplies while the other does its element-wise / LDS / memory work.  Then the barrier; if a list is nearly
+    // full, everybody cuts and there is one more.
     const float cb = sCb[(st & 1) * kEvalStage + 16 * ct + x];
     if (rp == 0 || (dbg & 4)) {
       products(st);
       ranking(st, cb, st & 1);
+      if (st + 1 < nst) store_stage(st + 1);
+      load_rows();          // stage st + 2 (its ids arrived a stage ago)
+      load_ids(st + 3);
     } else {
       if (st > 0) ranking(st - 1, cb_prev, st & 1);
+      if (st + 1 < nst) store_stage(st + 1);
+      load_rows();
+      load_ids(st + 3);
       products(st);
       cb_prev = cb;
     }

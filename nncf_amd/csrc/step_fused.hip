@@ -1327,7 +1327,7 @@ static int wide_f16_mode() {
 template <int LOSS, bool GROUP, bool NU, bool NV, int MT, bool H16>
 int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const FusedArgs& f, const PlanView& pu,
              const PlanView& pv, int update, hipStream_t stream, int staged = -1, bool commit = true, int* capacity_out = nullptr,
-             bool launch = true) {
+             bool launch = true, const char* prof_name = "fused_wide_kernel") {
   const int gu = (a.b + 16 * MT - 1) / (16 * MT);
   auto kern = fused_wide_kernel<LOSS, GROUP, NU, NV, MT, H16>;
   static KernelDeviceState kds;
@@ -1340,7 +1340,7 @@ int launch_w(const StepArgs& a, const int32_t* uid, const int32_t* cid, const Fu
   const bool st = staged >= 0 ? staged != 0 : (update && (2 * gu > capacity || f.shared_device || force_deferred()));
   if (!st) fa.stage = nullptr;
   {
-    ProfScope _ps("fused_wide_kernel", stream);
+    ProfScope _ps(prof_name, stream);
     hipLaunchKernelGGL(kern, dim3(2 * gu + 1, 1), dim3(512), lds, stream, a, uid, cid, fa, pu, pv, update, gu);
   }
   NNCF_HIP_CHECK(hipGetLastError());
@@ -1362,7 +1362,10 @@ int launch_w_guarded(const StepArgs& a, const int32_t* uid, const int32_t* cid, 
   if (int rc = launch_w<LOSS, GROUP, NU, NV, MT, false>(a, uid, cid, f, pu, pv, update, stream, -1, false, &cap_f, /*launch=*/false)) return rc;
   const int staged = (update && (2 * gu > std::min(cap_h, cap_f) || f.shared_device || force_deferred())) ? 1 : 0;
   if (int rc = launch_w<LOSS, GROUP, NU, NV, MT, true>(a, uid, cid, f, pu, pv, update, stream, staged, /*commit=*/false)) return rc;
-  return launch_w<LOSS, GROUP, NU, NV, MT, false>(a, uid, cid, f, pu, pv, update, stream, staged, /*commit=*/true);
+  // (measurement hook: the twin that normally returns at once is bracketed under its own name, so that "fused_wide_kernel" stays the
+  // launch that does the work; a step outside the planes' domain shows up the other way round)
+  return launch_w<LOSS, GROUP, NU, NV, MT, false>(a, uid, cid, f, pu, pv, update, stream, staged, /*commit=*/true, nullptr, true,
+                                                   "fused_wide_twin_kernel");
 }
 
 template <int LOSS, bool GROUP, bool NU, bool NV>

@@ -141,8 +141,14 @@ def test_trainer_epochs_match_oracle_loop(small_data, scheme, loss):
     assert got[0] == -1 and costs[0] == -1          # epoch 0 trains nothing (train_original.py:34,43)
     for g, w in zip(got[1:], costs[1:]):
         assert abs(g - w) <= 1e-5 * max(1, abs(w)), (got, costs)
-    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=2e-4, atol=2e-5)
+    # trained tables: bounds from the number of summed terms (tests/tolerances.py), not flat constants.  Both sides are fp32 here
+    # (the oracle loop runs in float32 like the reference), each with its own summation order: twice the fp32-vs-float64 bound.
+    from tests.tolerances import sum_bound
+    steps_run = conf.max_epoch * (len(small_data["train"]) // b)
+    for name, got_t, want_t, init_t in (("U", eng.U.cpu().numpy(), orc.U, U0), ("V", eng.V.cpu().numpy(), orc.V, V0)):
+        bound = 2.0 * sum_bound(want_t, init_t, terms=b * (1 + k), updates=steps_run)
+        err = np.abs(got_t.astype(np.float64) - want_t.astype(np.float64))
+        assert (err <= bound).all(), "%s: worst |err| / bound = %.3f" % (name, float((err / bound).max()))
     # Recall@50 of the trained model: GPU evaluator on GPU tables vs oracle evaluator on oracle tables.
     # Rank flips from 1e-6-level table differences move recall by O(1/users); tolerance says so.
     ocf = _oracle_conf(conf)
@@ -151,7 +157,8 @@ def test_trainer_epochs_match_oracle_loop(small_data, scheme, loss):
     _, vh, _ = o64._item_side(np.arange(helper.data_spec.item_count))
     want = so.evaluate_whole(uh, vh, small_data["test"][:, :2], small_data["test"][:, 1], 50)
     test_res = trainer.history[-1][4]
-    assert abs(test_res["recall@50"] - want["recall"]) < 5e-3
+    # a rank flip at the top-50 boundary moves ONE user's recall by at most 1 and the mean by at most 1 / users: three flips
+    assert abs(test_res["recall@50"] - want["recall"]) <= 3.0 / want["users"]
     # ... and on IDENTICAL tables (the oracle's trained tables uploaded into the engine) the product evaluator's
     # Recall / MAP / Precision@50 equal the oracle's to the north-star's 1e-5 (tie-free scores: an exact comparison)
     eng.set_tables(orc.U, orc.V)

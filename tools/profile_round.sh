@@ -2,7 +2,7 @@
 # Collects the round's evidence on the GPU box: bench JSON lines + rocprofv3 summaries.
 # usage (from the repo root, on the GPU box): bash tools/profile_round.sh r04
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
@@ -84,5 +84,18 @@ NNCF_FORCE_SHARDED=1 python3 bench.py --model mf --scaling strong --loss log-los
 python3 bench.py --model cnn_embedding --scheme original --cpu-seconds 0 --steps 200 --warmup 20 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_original.json
 python3 bench.py --model cnn_embedding --scheme neg_shared --cpu-seconds 0 --steps 390 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_neg_shared.json
 NNCF_CNN_DBG=64 python3 tools/cnn_timing.py > $OUT/${TAG}_cnn_phase_stamps.txt 2>/dev/null
-python3 tools/sampler_bench.py > $OUT/${TAG}_sampler_bench.json 2>/dev/null
+python3 tools/sampler_bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_sampler_bench.json
+# round 5: the one-kernel evaluator (whole@50 pass, fused vs predict + topk), its kernel trace, the register audit of the shipped
+# library, the group_neg_shared pointwise large-batch line (the positive-count tile) and the f16-plane guard's A/B
+python3 tools/eval_bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_eval_bench.json
+python3 tools/eval_bench.py 128 2>/dev/null | tail -1 > $OUT/${TAG}_eval_bench_d128.json
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_ev -o p -- python3 $R/tools/eval_bench.py > /dev/null 2>&1); python3 tools/prof_summary.py $OUT/prof_ev/p_results.db $OUT/${TAG}_eval_kernel_trace.txt; rm -rf $OUT/prof_ev
+python3 tools/isa_resources.py --out $OUT/${TAG}_isa_resources.txt > /dev/null
+for l in skip-gram mse; do
+python3 bench.py --large --batch 8192 --scheme group_neg_shared --loss $l --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_group_neg_shared_${l}_b8192.json
+done
+run_prof large_mf_group_b8192_kernel_trace "--stats" --large --batch 8192 --scheme group_neg_shared --loss skip-gram --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
+NNCF_WIDE_F16SPLIT=force python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192_unguarded.json
+NNCF_DP_NATIVE=0 NNCF_FORCE_SHARDED=1 python3 bench.py --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_data_parallel_world1_pythonloop.json
+for sp in 0 48 64; do NNCF_CNN_SPLIT=$sp bash tools/quick_prof.sh ${TAG}_cnn_split$sp --model cnn_embedding --scheme group_neg_shared --steps 390 --warmup 39 > /dev/null 2>&1; mv $OUT/quick_${TAG}_cnn_split$sp.txt $OUT/${TAG}_cnn_split${sp}_kernel_trace.txt; done
 ls -la $OUT/${TAG}_*
