@@ -182,8 +182,7 @@ __global__ void __launch_bounds__(NT) eval_topk_kernel(const float* __restrict__
 //     searches interleaved) in one extra barrier interval.  Cutting on demand, user by user, put one ~5 k-cycle search on
 //     the critical path of nearly every stage (everybody waits at the stage barrier for the one wave that cuts: 0.65 ms of
 //     a 1.6 ms pass); cut together, the users' thresholds move together and a sweep of 13,600 candidates has ~6 cut stages;
-//   * the two waves of a SIMD run half a stage apart (products | ranking against ranking | products), stage s + 1 is stored
-//     while stage s is multiplied: one barrier per stage;
+//   * stage s + 1 is stored (and s + 2 requested) behind stage s's products and ranking: one barrier per stage;
 //   * at the end the list is cut to k once more, the k keys are ranked by counting, hits by binary search in the user's
 //     truth CSR, map / recall / precision per metrics_ranking.py:14-29 in rank order -- the arithmetic of eval_topk_kernel.
 // Work: 2 n_users n_cand d flop on the fp32 matrix pipe (exact fp32: the ranking must not depend on the pipe), 25 LDS reads
@@ -397,7 +396,6 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   load_rows();
   load_ids(2);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  float cb_prev = 0.f;
   auto products = [&](int st) {
     acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -502,25 +500,15 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   };
   __syncthreads();   // stage 0 is in LDS
   for (int st = 0; st < nst; ++st) {
-    // Waves 0-3: products(st) | ranking(st), the rows of stage st + 1 -> the other buffer, the rows of st + 2 requested.
-    // Waves 4-7: ranking(st - 1), the same staging | products(st).  A SIMD's two waves (w, w + 4) thus hold the matrix pipe
-    // in turns: one multiplies while the other does its element-wise / LDS / memory work.  Then the barrier; if a list is nearly
-    // full, everybody cuts and there is one more.
+    // products(st), ranking(st), then the rows of stage st + 1 -> the other buffer and the rows of st + 2 requested; the barrier;
+    // if a list is nearly full, everybody cuts and there is one more.  (Running the two waves of a SIMD half a stage apart --
+    // one multiplies while the other ranks and stages -- was measured both ways round and never won: 1.10 / 1.19 ms against 1.09.)
     const float cb = sCb[(st & 1) * kEvalStage + 16 * ct + x];
-    if (rp == 0 || (dbg & 4)) {
-      products(st);
-      ranking(st, cb, st & 1);
-      if (st + 1 < nst) store_stage(st + 1);
-      load_rows();          // stage st + 2 (its ids arrived a stage ago)
-      load_ids(st + 3);
-    } else {
-      if (st > 0) ranking(st - 1, cb_prev, st & 1);
-      if (st + 1 < nst) store_stage(st + 1);
-      load_rows();
-      load_ids(st + 3);
-      products(st);
-      cb_prev = cb;
-    }
+    products(st);
+    ranking(st, cb, st & 1);
+    if (st + 1 < nst) store_stage(st + 1);
+    load_rows();          // stage st + 2 (its ids arrived a stage ago)
+    load_ids(st + 3);
     __syncthreads();
     if (sFlag[st & 1]) {        // uniform: written before the barrier, cleared behind the next one
       cut_mine();
@@ -529,9 +517,6 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       refresh_tau();
     }
   }
-  // waves 4-7 still owe the last stage's ranking (up to 64 more appends per user: room was made above)
-  if (rp == 1 && nst > 0 && !(dbg & 4)) ranking(nst - 1, cb_prev, 2);   // (flag slot 2: nobody looks)
-  __syncthreads();
   // ---- per user: the k largest keys in rank order, hits, metrics (wave w: users 8 w .. 8 w + 7) ------------------------
   cut_mine();
   __builtin_amdgcn_wave_barrier();
