@@ -518,14 +518,25 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     }
   }
   // ---- per user: the k largest keys in rank order, hits, metrics (wave w: users 8 w .. 8 w + 7) ------------------------
+  // the truth lists of this wave's 8 users are requested before the last cut: bounds first, then the first 64 slots of each
+  // (eight loads in flight; a binary search per key in global memory was 4-5 dependent trips per user, one user after the other)
+  int tp0[8], tp1[8], tv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t u = u0 + 8 * wave + e;
+    tp0[e] = u < n_users ? truth_ptr[u] : 0;
+    tp1[e] = u < n_users ? truth_ptr[u + 1] : 0;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) tv[e] = (tp0[e] + lane < tp1[e]) ? truth_idx[tp0[e] + lane] : -1;
   cut_mine();
   __builtin_amdgcn_wave_barrier();
+#pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ul = 8 * wave + e;
     const int64_t u = u0 + ul;
-    if (u >= n_users) break;
-    const int t0 = truth_ptr[u], t1 = truth_ptr[u + 1];
-    if (t1 == t0) continue;
+    const int t0 = tp0[e], t1 = tp1[e];
+    if (u >= n_users || t1 == t0) continue;   // (wave-uniform)
     unsigned long long* list = sKeys + ul * LIST;
     const int c = min(sCnt[ul], kk);
     // rank of every kept key = the number of keys above it (all distinct); two keys per lane (k <= 100)
@@ -538,20 +549,26 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       rank[0] += o > mine[0] ? 1 : 0;
       rank[1] += o > mine[1] ? 1 : 0;
     }
+    // is a key's slot one of the user's true slots?  The truth list walks past every lane (64 slots per round, broadcast from
+    // the lane that holds each)
+    const int slot0 = (lane < c) ? (int)(0xFFFFFFFFu - (uint32_t)mine[0]) : -2;
+    const int slot1 = (lane + 64 < c) ? (int)(0xFFFFFFFFu - (uint32_t)mine[1]) : -2;
+    bool hit0 = false, hit1 = false;
+    int tvv = tv[e];
+    for (int tb = t0; tb < t1; tb += 64) {
+      if (tb != t0) tvv = (tb + lane < t1) ? truth_idx[tb + lane] : -1;   // a user with more than 64 true items: further rounds
+      const int nt = min(64, t1 - tb);
+      for (int i = 0; i < nt; ++i) {
+        const int ts = __builtin_amdgcn_readlane(tvv, i);
+        hit0 |= ts == slot0;
+        hit1 |= ts == slot1;
+      }
+    }
     // hit of rank r -> two 64-bit masks in rank order
     unsigned long long hm[2] = {0ull, 0ull};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      bool hit = false;
-      if (lane + 64 * h < c) {
-        const int slot = (int)(0xFFFFFFFFu - (uint32_t)mine[h]);
-        int lo = t0, hi = t1;   // binary search in the user's sorted truth slots
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (truth_idx[mid] < slot) lo = mid + 1; else hi = mid;
-        }
-        hit = lo < t1 && truth_idx[lo] == slot;
-      }
+      const bool hit = h ? hit1 : hit0;
 #pragma unroll
       for (int w = 0; w < 2; ++w) {   // a wave-wide OR of one-hot 64-bit values (lanes hold arbitrary ranks)
         unsigned long long v = (hit && (rank[h] >> 6) == w) ? (1ull << (rank[h] & 63)) : 0ull;

@@ -164,3 +164,58 @@ def test_evaluator_at_the_baseline_shape_equals_the_oracle_and_the_two_kernel_pa
         for i, name in enumerate(("map", "recall", "precision")):
             assert abs(rf["%s@50" % name] - want[i]) <= 1e-5, (which, name, rf, want)
         assert rf["recall@50"] > 0.001   # the comparison is not about empty hit lists
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("NNCF_SOAK_SEEDS", "10"))))
+def test_fused_evaluator_random_shapes_against_the_two_kernel_path(seed):
+    """Seeded random sweep (tools/soak.sh raises the seed count): users 1 .. 700, candidates 3 .. 6,000, d = 4 .. 128, k = 1 .. 100,
+    normalisation on / off, interaction bias, continuous or heavily quantised tables (exact score ties everywhere), users with
+    no true item -- nncf_eval_whole against nncf_predict_scores + nncf_eval_topk, per user, bit for bit."""
+    from nncf_amd.engine import Engine
+    rs = np.random.RandomState(31000 + seed)
+    users = int(rs.choice([1, 5, 63, 64, 65, 200, 700]))
+    items = int(rs.choice([3, 40, 64, 65, 500, 2000, 6000]))
+    d = int(rs.choice([4, 20, 24, 64, 100, 128]))
+    topk = int(rs.choice([1, 5, 50, 50, 100]))
+    norm = bool(rs.randint(2))
+    bias = [None, "user", "item", "both"][int(rs.randint(4))]
+    eng = Engine(users, items, d, 32, 0, "skip-gram", 10.0, 16.0, 0., 0.1, norm, norm, seed=seed, init_scale=0.5, interaction_bias=bias)
+    U, V = eng.U.cpu().numpy().copy(), eng.V.cpu().numpy().copy()
+    if rs.randint(3) == 0:      # few distinct values: exact ties between unrelated pairs
+        U, V = np.round(U * 2) / 2, np.round(V * 2) / 2
+        U[: users // 3] = 0.
+    eng.set_tables(U, V)
+    if bias:
+        for t in (eng.bias["ub"], eng.bias["cb"]):
+            if t is not None:
+                t.copy_(torch.as_tensor(rs.normal(scale=0.3, size=tuple(t.shape)).astype(np.float32)))
+    n_cand = int(rs.randint(max(1, items // 2), items + 1))
+    cand = np.sort(rs.choice(items, n_cand, replace=False)).astype(np.int32)
+    ptr = [0]
+    idx = []
+    for u in range(users):
+        nt = 0 if rs.randint(5) == 0 else int(rs.randint(1, min(n_cand, 80) + 1))
+        idx.extend(np.sort(rs.choice(n_cand, nt, replace=False)).tolist())
+        ptr.append(len(idx))
+    dev = eng.device
+    uid = torch.arange(users, dtype=torch.int32, device=dev)
+    cand_t = torch.as_tensor(cand).to(dev)
+    ptr_t = torch.as_tensor(np.asarray(ptr, dtype=np.int32)).to(dev)
+    idx_t = torch.as_tensor(np.asarray(idx if idx else [0], dtype=np.int32)).to(dev)
+    L = _lib.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    outs = []
+    for fused in (True, False):
+        met = torch.full((users * 3,), -5.0, device=dev)
+        val = torch.full((users,), -7, dtype=torch.int32, device=dev)
+        if fused:
+            _lib.check(L.nncf_eval_whole(eng._h, p(uid), users, p(cand_t), n_cand, p(ptr_t), p(idx_t), topk, p(met), p(val), _lib.stream_ptr()))
+        else:
+            sc = eng.predict_scores(uid, cand_t)
+            _lib.check(L.nncf_eval_topk(p(sc), users, n_cand, n_cand, p(ptr_t), p(idx_t), topk, p(met), p(val), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((met, val))
+    (mf_, vf), (mt, vt) = outs
+    assert torch.equal(vf, vt), (users, items, d, topk)
+    keep = vt == 1
+    assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), (users, items, d, topk, norm, bias)

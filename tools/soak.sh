@@ -5,5 +5,5 @@
 # usage: bash tools/soak.sh [seeds]      -> gpurun_out/soak.log
 N=${1:-300}
 mkdir -p gpurun_out
-NNCF_SOAK_SEEDS=$N NNCF_SOAK_LARGE=$((N / 5)) NNCF_SOAK_SAMPLER=$((N / 4)) python -m pytest tests/test_fused_gpu.py tests/test_pair_gpu.py tests/test_tower_gpu.py tests/test_step_gpu.py tests/test_sharded_gpu.py tests/test_sampler_gpu.py tests/test_schemes_gpu.py tests/test_trainer_gpu.py -m gpu -q -k "random" -p no:cacheprovider 2>&1 | tail -40 > gpurun_out/soak.log
+NNCF_SOAK_SEEDS=$N NNCF_SOAK_LARGE=$((N / 5)) NNCF_SOAK_SAMPLER=$((N / 4)) python -m pytest tests/test_fused_gpu.py tests/test_pair_gpu.py tests/test_tower_gpu.py tests/test_step_gpu.py tests/test_sharded_gpu.py tests/test_sampler_gpu.py tests/test_schemes_gpu.py tests/test_trainer_gpu.py tests/test_eval_gpu.py -m gpu -q -k "random" -p no:cacheprovider 2>&1 | tail -40 > gpurun_out/soak.log
 tail -40 gpurun_out/soak.log
