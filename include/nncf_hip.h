@@ -383,6 +383,22 @@ int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_wor
  * step the id rows of the batch's unique items with the model's optimiser (d_m / d_v: zero-initialised moment arrays
  * shaped like the table for the Adam modes, d_stamp [item_count] int32 zeros for dense Adam; NULL for sparse SGD). */
 int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, float* d_m, float* d_v, int32_t* d_stamp);
+/* item_dense_transform variants (mean_pool.py:82-97, cnn_model.py:114-126): Activation(dense_hidden_actv) -- 0 relu (the
+ * presets), 1 tanh, 2 sigmoid, 3 hard_sigmoid, 4 softplus, 5 softsign, 6 linear (Keras-1 names) -- and
+ * Dropout(dense_hidden_dropout) behind Dense + BatchNormalization.  Anything but (relu, 0) makes the tower's steps materialise
+ * the item block act(BN(z)) * mask, run the step kernels on it as on an id table and start the backward from
+ * dL/dE * mask * act'(y) (as conf.use_content_id does; not the one-launch fast path).  The dropout mask is a counter-based
+ * hash of (nncf_tower_set_dropout's seed, train-forward index, row, column); nncf_tower_dense_mask writes the mask
+ * (including its 1/keep scale) of forward `step_index` for m rows, [m][item_dim] floats, for tests. */
+int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout);
+int nncf_tower_dense_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d_out, void* stream);
+/* conf.c_reg (mean_pool.py:56-59, cnn_model.py:45-48: activity_l2(conf.c_reg) on the word Embedding; L1L2Act,
+ * utils/utilities.py:122-135): c_reg * sum over (position, column) of the mean over the block's rows of E^2 joins the loss
+ * of every model step of this tower, E = the Embedding's OUTPUT after its row dropout [K-mem]; the word rows of the block
+ * take its gradient 2 c_reg / n * (occurrences in the block) * scale[w]^2 * W[w] with the step's own.  0 switches it off
+ * (every preset of the reference).  Costs three small launches per step (count the block's words, per-word squares, one
+ * ordered sum into the loss); all tower kinds, all schemes, the data-parallel gradient export included. */
+int nncf_tower_set_c_reg(nncf_tower* t, float c_reg);
 /* Embedding(dropout=rate) of Keras 1 (mean_pool.py:56-59; 0.5 in the 'best' preset,
  * basic_embedding_conf.py:112): per train-mode forward a fresh mask drops whole word rows
  * (survivors scaled by 1/(1-rate)).  The mask is a counter-based hash of (seed, forward index,

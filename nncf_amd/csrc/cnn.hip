@@ -803,10 +803,10 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
       const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
       const float4 mu = reinterpret_cast<const float4*>(a.rm)[tid], var = reinterpret_cast<const float4*>(a.rv)[tid];
       float4 o;
-      o.x = fmaxf(g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x, 0.f);
-      o.y = fmaxf(g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y, 0.f);
-      o.z = fmaxf(g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z, 0.f);
-      o.w = fmaxf(g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w, 0.f);
+      o.x = tail_act(a.tail_act, g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x);
+      o.y = tail_act(a.tail_act, g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y);
+      o.z = tail_act(a.tail_act, g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z);
+      o.w = tail_act(a.tail_act, g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w);
       reinterpret_cast<float4*>(a.E + (int64_t)s * a.d)[tid] = o;
     }
   }

@@ -142,6 +142,18 @@ struct TowerArgs {
   const uint32_t* hot_bits;  // [ceil(n_words / 32)] membership of the hot list (the cells the pool kernel still writes)
   int pm_nwg;                // workgroups of the schedule
   int pm, pm_stamp;          // this forward / backward runs in postings mode; its stamp
+  // activity_l2(conf.c_reg) on the word Embedding's OUTPUT (mean_pool.py:56-59, cnn_model.py:45-48; utilities.py:122-135):
+  // loss += c_reg / n * sum_w T[w] |scale[w] W[w]|^2, T[w] = occurrences of w in the block's n rows (every position counts).
+  // item_dense_transform variants (mean_pool.py:82-97): Activation(dense_hidden_actv) other than relu, Dropout(dense_hidden_dropout).
+  // Such a tower's steps materialise the item block (as conf.use_content_id does) and its backward starts from
+  // dA * mask * act'(y) (tower_tail_grad_kernel) with the relu gates of the BatchNorm-backward kernels open (tail_pre).
+  int tail_act;              // kAct*: 0 = relu (the presets)
+  int tail_pre;              // the backward's dA already carries mask * act'(y)
+  float tail_keep;           // Dropout retain probability of this forward (1 = off)
+  unsigned long long tail_seed;
+  float c_reg;               // 0: off (every preset of the reference)
+  int32_t* wcount;           // [n_words] T[w]: filled by tower_wcount_kernel, consumed and cleared by the word kernel's tail
+  float* creg_q;             // [n_words] T[w] |scale[w] W[w]|^2 (tower_creg_kernel), summed in word order into the loss
   CnnArgs cnn;
 };
 constexpr int kHotWords = 16;
@@ -173,6 +185,39 @@ __device__ __forceinline__ float word_scale(const TowerArgs& a, int w) {
   const unsigned long long x = splitmix64(a.drop_seed + (unsigned long long)w * 0x9E3779B97F4A7C15ull);
   const float u = (float)(x >> 40) * (1.f / 16777216.f);
   return u < a.keep ? 1.f / a.keep : 0.f;
+}
+
+// Keras-1 activations of the Dense tail (keras/activations.py by name; hard_sigmoid = clip(0.2 y + 0.5, 0, 1) [K-mem])
+enum { kActRelu = 0, kActTanh, kActSigmoid, kActHardSigmoid, kActSoftplus, kActSoftsign, kActLinear, kActCount };
+__device__ __forceinline__ float tail_act(int k, float y) {
+  switch (k) {
+    case kActRelu: return fmaxf(y, 0.f);
+    case kActTanh: return tanhf(y);
+    case kActSigmoid: return 1.f / (1.f + expf(-y));
+    case kActHardSigmoid: return fminf(fmaxf(fmaf(0.2f, y, 0.5f), 0.f), 1.f);
+    case kActSoftplus: return fmaxf(y, 0.f) + log1pf(expf(-fabsf(y)));
+    case kActSoftsign: return y / (1.f + fabsf(y));
+    default: return y;
+  }
+}
+__device__ __forceinline__ float tail_act_grad(int k, float y) {
+  switch (k) {
+    case kActRelu: return y > 0.f ? 1.f : 0.f;
+    case kActTanh: { const float t = tanhf(y); return 1.f - t * t; }
+    case kActSigmoid: { const float s = 1.f / (1.f + expf(-y)); return s * (1.f - s); }
+    case kActHardSigmoid: return (y > -2.5f && y < 2.5f) ? 0.2f : 0.f;
+    case kActSoftplus: return 1.f / (1.f + expf(-y));
+    case kActSoftsign: { const float t = 1.f + fabsf(y); return 1.f / (t * t); }
+    default: return 1.f;
+  }
+}
+// Dropout(dense_hidden_dropout) mask of element (row, c) of the block, including its 1/keep scale: counter-based hash,
+// evaluated where needed (forward, backward, nncf_tower_dense_mask for the tests).  [K-mem] TF's RNG stream cannot match.
+__device__ __forceinline__ float tail_mask(float keep, unsigned long long seed, int row, int c) {
+  if (keep >= 1.f) return 1.f;
+  const unsigned long long x = splitmix64(seed + ((unsigned long long)row * 128ull + (unsigned long long)c) * 0x9E3779B97F4A7C15ull);
+  const float u = (float)(x >> 40) * (1.f / 16777216.f);
+  return u < keep ? 1.f / keep : 0.f;
 }
 
 // workspace layout (floats)
@@ -356,6 +401,16 @@ struct nncf_tower {
   float v_reg = 0.f;             // activity_l2(v_reg) on the Emb_Cid output
   nncf::AdamTable acid;          // its Adam state (borrowed; stamp for dense Adam)
   float* cid_reg = nullptr;      // own allocation [max_rows] |Emb_Cid row|^2 of the block's rows
+  // item_dense_transform variants (nncf_tower_set_dense_tail; TowerArgs::tail_act)
+  int tail_act = 0;
+  float tail_drop = 0.f;
+  uint64_t tail_step = 0;        // train-mode forwards since nncf_tower_set_dense_tail / set_dropout (mask index)
+  float* dA_tail = nullptr;      // own allocation [max_rows][item_dim]: dA * mask * act'(y)
+  bool tail_general() const { return tail_act != 0 || tail_drop > 0.f; }
+  // conf.c_reg (nncf_tower_set_c_reg; TowerArgs::c_reg)
+  float c_reg = 0.f;
+  int32_t* wcount = nullptr;     // own allocation [word_count], all-zero between steps
+  float* creg_q = nullptr;       // own allocation [word_count]
   // hot words (nncf_tower_set_hot_words; TowerArgs::hot)
   int32_t* hot = nullptr;        // own allocation [kHotWords]
   int n_hot = 0;

@@ -206,10 +206,10 @@ __global__ void __launch_bounds__(256, BIG ? 6 : 1) tower_pool_kernel(TowerArgs 
       const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
       const float4 mu = reinterpret_cast<const float4*>(a.rm)[tid], var = reinterpret_cast<const float4*>(a.rv)[tid];
       float4 o;
-      o.x = fmaxf(g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x, 0.f);
-      o.y = fmaxf(g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y, 0.f);
-      o.z = fmaxf(g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z, 0.f);
-      o.w = fmaxf(g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w, 0.f);
+      o.x = tail_act(a.tail_act, g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x);
+      o.y = tail_act(a.tail_act, g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y);
+      o.z = tail_act(a.tail_act, g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z);
+      o.w = tail_act(a.tail_act, g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w);
       reinterpret_cast<float4*>(a.E + (int64_t)s * a.d)[tid] = o;
     }
   }
@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(128) tower_stats_merge_kernel(TowerArgs a, int
   stats_finalize(a, threadIdx.x, t1, t2, valid_rows(a));
 }
 
-// E = relu(z * mul + add) for standalone forwards (the training step applies it on load).
+// E = act(z * mul + add) [* dropout mask] for standalone forwards and materialised blocks (the training step of the
+// default tail -- relu, no dropout -- applies it on load).
 __global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
   __shared__ float sMul[128], sAdd[128];
   const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2, nv = valid_rows(a);
@@ -358,10 +359,35 @@ __global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = col_of(q, e);
-      relem(o, e) = fmaxf(fmaf(relem(z, e), sMul[c], sAdd[c]), 0.f);
+      relem(o, e) = tail_act(a.tail_act, fmaf(relem(z, e), sMul[c], sAdd[c])) * tail_mask(a.tail_keep, a.tail_seed, row, c);
     }
   }
   row_store(a.E, row, a.d, d4, q, o);
+}
+
+// out = dA * mask * act'(y), y = z * mul + add: the Dense tail's Activation / Dropout backward, in front of the
+// BatchNorm-backward kernels (which then run with TowerArgs::tail_pre: their relu gates open)
+__global__ void __launch_bounds__(256) tower_tail_grad_kernel(TowerArgs a, float* __restrict__ out) {
+  __shared__ float sMul[128], sAdd[128];
+  const int grp = threadIdx.x >> 4, q = threadIdx.x & 15, d4 = a.d >> 2, nv = valid_rows(a);
+  const int row = blockIdx.x * 16 + grp;
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    sMul[c] = a.ws[ws_muinv() + 384 + c];
+    sAdd[c] = a.ws[ws_muinv() + 512 + c];
+  }
+  __syncthreads();
+  if (row >= a.m) return;
+  Row o = row_zero();
+  if (row < nv) {
+    Row z = row_load(a.z, row, a.d, d4, q), g = row_load(a.dA, row, a.d, d4, q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col_of(q, e);
+      relem(o, e) = relem(g, e) * tail_mask(a.tail_keep, a.tail_seed, row, c) * tail_act_grad(a.tail_act, fmaf(relem(z, e), sMul[c], sAdd[c]));
+    }
+  }
+  row_store(out, row, a.d, d4, q, o);
 }
 
 // ---- backward --------------------------------------------------------------------------------
@@ -386,7 +412,7 @@ __global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
     for (int e = 0; e < 8; ++e) {
       const int c = col_of(q, e);
       const float x = relem(z, e);
-      const float dy = (fmaf(x, sMul[c], sAdd[c]) > 0.f) ? relem(g, e) : 0.f;
+      const float dy = (a.tail_pre || fmaf(x, sMul[c], sAdd[c]) > 0.f) ? relem(g, e) : 0.f;
       relem(s1, e) += dy;
       relem(s2, e) += dy * (x - sMu[c]) * sInv[c];
     }
@@ -516,7 +542,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
       for (int e = 0; e < 8; ++e) {
         const int c = col_of(q, e);
         const float xh = (relem(zz, e) - sMu[c]) * sInv[c];
-        const float dy = (fmaf(relem(zz, e), sMul[c], sAdd[c]) > 0.f) ? relem(gg, e) : 0.f;
+        const float dy = (a.tail_pre || fmaf(relem(zz, e), sMul[c], sAdd[c]) > 0.f) ? relem(gg, e) : 0.f;
         relem(dz, e) = sG[c] * sInv[c] * rn * (n * dy - sA[c] - xh * sBq[c]);
       }
     }
@@ -596,7 +622,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
     for (int u = 0; u < 16; ++u) {
       const int r = rbeg + 4 * (st0 + 4 * u) + kq;
       const float xh = (zv[u] - mu) * inv;
-      const float dy = (fmaf(zv[u], mul, add) > 0.f) ? gv[u] : 0.f;
+      const float dy = (a.tail_pre || fmaf(zv[u], mul, add) > 0.f) ? gv[u] : 0.f;
       const float dzv = (r < rend) ? coef * (n * dy - sa - xh * sbq) : 0.f;
       colsum += dzv;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[u], dzv, acc, 0, 0, 0);
@@ -983,6 +1009,14 @@ __global__ void __launch_bounds__(512, (CNN || MAXP) ? 6 : 8) tower_word_kernel(
   int my_hit = sHit[wave];
   if (PM)
     for (int jj = 1; jj < my_nu && wave + jj < kWordsPerWG; ++jj) my_hit |= sHit[wave + jj];
+  // conf.c_reg: the word's occurrences in the block (tower_wcount_kernel), taken and reset by one exchange
+  float cg = 0.f;   // 2 c_reg / n * T[w] * scale[w]^2: the regulariser's gradient is cg * W[w]
+  if (a.c_reg != 0.f && my_w < a.n_words) {
+    int T = lane_e == 0 ? atomicExch(a.wcount + my_w, 0) : 0;
+    T = __shfl(T, 0);
+    const float sc = a.train ? word_scale(a, my_w) : 1.f;
+    cg = 2.f * a.c_reg / (float)max(n, 1) * (float)T * sc * sc;
+  }
   if (a.gexp && my_w < a.n_words && lane_e < d2 && !my_hit && hot_cells == 0)
     reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane_e] = make_float2(0.f, 0.f);
   if (my_w < a.n_words && (my_hit || hot_cells > 0) && lane_e < d2) {
@@ -1026,21 +1060,31 @@ __global__ void __launch_bounds__(512, (CNN || MAXP) ? 6 : 8) tower_word_kernel(
     // gradient = scale[w] / L * sum (mean-pool); the CNN rows already carry scale and 1/L
     const float gs = cnn ? 1.f : (MAXP ? word_scale(a, my_w) : word_scale(a, my_w) / (float)a.L);
     if (a.gexp) {
-      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane_e] = make_float2(gs * sum.x, gs * sum.y);
+      float2 g = make_float2(gs * sum.x, gs * sum.y);
+      if (cg != 0.f) g = make_float2(fmaf(cg, wold.x, g.x), fmaf(cg, wold.y, g.y));
+      reinterpret_cast<float2*>(a.gexp + (int64_t)my_w * a.wd)[lane_e] = g;
       return;
     }
     if (a.opt) {
       float2* mp = reinterpret_cast<float2*>(a.aw.m + (int64_t)my_w * a.wd) + lane_e;
       float2* vp = reinterpret_cast<float2*>(a.aw.v + (int64_t)my_w * a.wd) + lane_e;
       float2 mm = *mp, vv = *vp;
-      wold.x = adam1(gs * sum.x, &mm.x, &vv.x, wold.x, a);
-      wold.y = adam1(gs * sum.y, &mm.y, &vv.y, wold.y, a);
+      float2 g = make_float2(gs * sum.x, gs * sum.y);
+      if (cg != 0.f) g = make_float2(fmaf(cg, wold.x, g.x), fmaf(cg, wold.y, g.y));
+      wold.x = adam1(g.x, &mm.x, &vv.x, wold.x, a);
+      wold.y = adam1(g.y, &mm.y, &vv.y, wold.y, a);
       *mp = mm;
       *vp = vv;
     } else {
       const float sc = cnn ? a.lr : (MAXP ? a.lr : lr_over_L) * word_scale(a, my_w);
+      const float dec = a.lr * cg;   // the regulariser's share of the step: -lr * cg * W[w] (0 unless conf.c_reg)
+      const float2 w0 = wold;
       wold.x = fmaf(-sc, sum.x, wold.x);
       wold.y = fmaf(-sc, sum.y, wold.y);
+      if (dec != 0.f) {
+        wold.x = fmaf(-dec, w0.x, wold.x);
+        wold.y = fmaf(-dec, w0.y, wold.y);
+      }
     }
     reinterpret_cast<float2*>(a.W + (int64_t)my_w * a.wd)[lane_e] = wold;
   } else if (a.opt == 2 && !a.gexp && my_w < a.n_words && lane_e < d2) {
@@ -1180,6 +1224,51 @@ void carve_tower(nncf_tower* t, Carver& c) {
   t->n_u = c.take<int32_t>(kPlanChunk);
 }
 
+// conf.c_reg (TowerArgs::c_reg).  tower_wcount_kernel: one workgroup per block row, T[w] += 1 per position (integer atomics:
+// the order does not matter).  tower_creg_kernel: one wave per word, q[w] = T[w] |scale[w] W[w]|^2 (0 for a word outside the
+// block); `clear` (a loss-only step: no word kernel follows) also resets T[w].  tower_creg_loss_kernel: one workgroup adds
+// c_reg / n * sum_w q[w] to *loss -- thread i sums words i, i + 1024, ... in order, the 1,024 sums by a fixed tree.
+__global__ void __launch_bounds__(256) tower_wcount_kernel(TowerArgs a) {
+  const int s = blockIdx.x;
+  if (s >= valid_rows(a)) return;
+  const int32_t* row = a.content + (int64_t)a.ids[s] * a.L;
+  for (int l = threadIdx.x; l < a.L; l += 256) atomicAdd(a.wcount + row[l], 1);
+}
+
+__global__ void __launch_bounds__(256) tower_creg_kernel(TowerArgs a, int clear) {
+  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= a.n_words) return;
+  const int T = a.wcount[w];
+  float q = 0.f;
+  if (T > 0) {
+    const float sc = a.train ? word_scale(a, w) : 1.f;
+    float sq = 0.f;
+    if (sc != 0.f && 2 * lane < a.wd) {
+      const float2 v = reinterpret_cast<const float2*>(a.W + (int64_t)w * a.wd)[lane];
+      sq = fmaf(v.x, v.x, v.y * v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    q = (float)T * sc * sc * sq;
+    if (clear && lane == 0) a.wcount[w] = 0;
+  }
+  if (lane == 0) a.creg_q[w] = q;
+}
+
+__global__ void __launch_bounds__(1024) tower_creg_loss_kernel(TowerArgs a, float* __restrict__ loss) {
+  __shared__ float sPart[1024];
+  float t = 0.f;
+  for (int w = threadIdx.x; w < a.n_words; w += 1024) t += a.creg_q[w];
+  sPart[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sPart[threadIdx.x] += sPart[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss += a.c_reg * sPart[0] / (float)max(valid_rows(a), 1);
+}
+
+
 TowerArgs base_args(const nncf_tower* t) {
   TowerArgs a{};
   const nncf_tower_params& p = t->prm;
@@ -1211,6 +1300,13 @@ TowerArgs base_args(const nncf_tower* t) {
   a.hot_bits = a.n_hot > 0 ? t->hot_bits : nullptr;
   a.pm = 0;
   a.pm_stamp = 0;
+  a.tail_act = t->tail_act;
+  a.tail_pre = 0;
+  a.tail_keep = 1.f;
+  a.tail_seed = 0;
+  a.c_reg = t->c_reg;
+  a.wcount = t->wcount;
+  a.creg_q = t->creg_q;
   return a;
 }
 
@@ -1228,6 +1324,10 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
   if (train && t->drop_rate > 0.f) {
     a.keep = 1.f - t->drop_rate;
     a.drop_seed = step_seed(t, t->drop_step++);
+  }
+  if (train && t->tail_drop > 0.f) {
+    a.tail_keep = 1.f - t->tail_drop;
+    a.tail_seed = splitmix64(step_seed(t, t->tail_step++) ^ 0x7A11D80F0A11ull);
   }
   if (a.cnn.F > 0) {
     if (train && t->conv_drop > 0.f) {
@@ -1271,8 +1371,11 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 // nfused > 0: the BN backward's column sums arrive as nfused partials from the step's apply kernel
 // step_t: the optimiser step this backward belongs to (1-based)
 int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0,
-                   bool sums_done = false) {
+                   bool sums_done = false, bool words_counted = false) {
   TowerArgs a = t->last;
+  if (a.c_reg != 0.f && !words_counted) {   // conf.c_reg outside a model step: the word kernel's tail needs T[w]
+    hipLaunchKernelGGL(tower_wcount_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  }
   a.dA = dA;
   a.gexp = t->gexp;
   a.opt = t->gexp ? 0 : t->opt;
@@ -1288,6 +1391,12 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     a.vD = t->vD;
   }
   const int m = a.m;
+  if (t->tail_general()) {   // Activation / Dropout backward of a non-default Dense tail, out of place
+    NNCF_REQUIRE(t->dA_tail != nullptr && !nfused && !sums_done, "the Dense tail variants run on the materialised block only");
+    hipLaunchKernelGGL(tower_tail_grad_kernel, dim3((m + 15) / 16), dim3(256), 0, st, a, t->dA_tail);
+    a.dA = t->dA_tail;
+    a.tail_pre = 1;
+  }
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
   const int ntile = ((a.hd + 15) / 16) * ((a.d + 15) / 16);
@@ -1335,6 +1444,21 @@ int check_pair(const nncf_tower* t, const nncf_model* m, int scheme) {
   return NNCF_OK;
 }
 
+// conf.c_reg inside a model step, behind the step's own launch: count the block's words, add the regulariser to *loss (the
+// deferred loss of a one-launch step is summed first: the term is ADDED to it).  update = 0: no word kernel follows, the
+// counts are reset here.
+int tower_c_reg(nncf_tower* t, nncf_model* m, float* loss, int update, hipStream_t st) {
+  if (t->c_reg == 0.f) return NNCF_OK;
+  if (int rc = flush_pending_loss(m, st)) return rc;
+  const TowerArgs a = t->last;
+  ProfScope _ps("tower_creg_kernel", st);
+  hipLaunchKernelGGL(tower_wcount_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(tower_creg_kernel, dim3((unsigned)((a.n_words + 3) / 4)), dim3(256), 0, st, a, update ? 0 : 1);
+  hipLaunchKernelGGL(tower_creg_loss_kernel, dim3(1), dim3(1024), 0, st, a, loss);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
 // one planned step: plans pu / pv (localized), the block's global ids and count on device
 int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid, const PlanView& pu,
                     const PlanView& pv, const int32_t* uniq_g, const int32_t* n_u, int n, float* loss, int update,
@@ -1348,17 +1472,21 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   sa.bn_stats = t->ws + ws_muinv();
   sa.item_gid = uniq_g;  // InteractionDot item bias is indexed by catalogue id, the block by tf.unique rank
   // shared schemes with a pointwise loss: ONE launch does statistics + scores + loss + both updates
-  if (t->cid_tab) {
+  if (t->cid_tab || t->tail_general()) {
     // conf.use_content_id: the item row is relu(BN(z)) + Emb_Cid[id] -- the block is MATERIALISED into the model's item
     // table (statistics launch, BatchNorm + ReLU, + the id rows), the step kernels run on it as on an id table and
     // export dL/dE, which is both the id rows' gradient and the tower backward's input (its BatchNorm sums by their
     // own launch).  Not the fused fast path: the option is off in every shipped configuration.
-    NNCF_REQUIRE(!t->gexp, "use_content_id is not built for the data-parallel gradient export");
+    // A Dense tail other than relu without dropout (item_dense_transform, mean_pool.py:82-97) takes the same road without
+    // the id rows: act(BN(z)) [* mask] is materialised, the step exports dL/dE, the backward starts at tower_tail_grad_kernel.
+    NNCF_REQUIRE(!t->gexp || !t->cid_tab, "use_content_id is not built for the data-parallel gradient export");
     int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, m->V, st, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(cid_add_kernel, dim3((n + 15) / 16), dim3(256), 0, st, m->V, t->cfg.item_dim, t->cid_tab, uniq_g, n_u, n,
-                       t->cid_reg);
-    NNCF_HIP_CHECK(hipGetLastError());
+    if (t->cid_tab) {
+      hipLaunchKernelGGL(cid_add_kernel, dim3((n + 15) / 16), dim3(256), 0, st, m->V, t->cfg.item_dim, t->cid_tab, uniq_g, n_u, n,
+                         t->cid_reg);
+      NNCF_HIP_CHECK(hipGetLastError());
+    }
     StepArgs pa = make_args(m);       // plain table mode: no BatchNorm on load, no fused sums
     pa.item_gid = uniq_g;
     if (scheme == 0)
@@ -1369,19 +1497,22 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
       rc = shared_step(m, pa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, nullptr);
     if (rc) return rc;
     if ((rc = flush_pending_loss(m, st))) return rc;
+    if ((rc = tower_c_reg(t, m, loss, update, st))) return rc;
     StepArgs ca = pa;                 // the id table's own row width / optimiser state
     ca.stride = t->cfg.item_dim;
     ca.lr = t->cfg.learn_rate;
     if (update) {
-      hipLaunchKernelGGL(cid_update_kernel, dim3((n + 15) / 16), dim3(256), 0, st, ca, t->acid, t->cid_tab, uniq_g, n_u, n, m->export_gV,
-                         t->v_reg, t->cid_reg, loss);
-      NNCF_HIP_CHECK(hipGetLastError());
-      if (pa.opt == 2)
-        if (int rc2 = launch_adam_idle(ca, t->cid_tab, t->acid, t->cfg.item_count, st)) return rc2;
-      if ((rc = tower_backward(t, m->export_gV, st, 0, m->opt ? m->adam_t + 1 : 0, false))) return rc;
+      if (t->cid_tab) {
+        hipLaunchKernelGGL(cid_update_kernel, dim3((n + 15) / 16), dim3(256), 0, st, ca, t->acid, t->cid_tab, uniq_g, n_u, n, m->export_gV,
+                           t->v_reg, t->cid_reg, loss);
+        NNCF_HIP_CHECK(hipGetLastError());
+        if (pa.opt == 2)
+          if (int rc2 = launch_adam_idle(ca, t->cid_tab, t->acid, t->cfg.item_count, st)) return rc2;
+      }
+      if ((rc = tower_backward(t, m->export_gV, st, 0, m->opt ? m->adam_t + 1 : 0, false, t->c_reg != 0.f))) return rc;
       return finish_update(m, pa, st);
     }
-    if (t->v_reg != 0.f) {   // loss only: the regulariser still belongs to the loss
+    if (t->cid_tab && t->v_reg != 0.f) {   // loss only: the regulariser still belongs to the loss
       hipLaunchKernelGGL(cid_update_kernel, dim3(1), dim3(256), 0, st, ca, t->acid, t->cid_tab, uniq_g, n_u, 0, m->export_gV, t->v_reg,
                          t->cid_reg, loss);
       NNCF_HIP_CHECK(hipGetLastError());
@@ -1432,13 +1563,15 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
     rc = launch_rowwise(sa, uid, cid_local, y, m->rws, pu, pv, n, loss, update, st);
   else
     rc = shared_step(m, sa, scheme == 2, uid, cid_local, pu, pv, loss, update, st, (one_launch || tile_stats) ? &fa : nullptr);
-  if (rc || !update) return rc;
+  if (rc) return rc;
+  if ((rc = tower_c_reg(t, m, loss, update, st))) return rc;
+  if (!update) return NNCF_OK;
   if (big) {
     TowerArgs ma = t->last;
     ProfScope _ps("tower_merge_kernel", st);
     hipLaunchKernelGGL(tower_merge_kernel, dim3(1), dim3(1024), 0, st, ma, t->bpart, cv);
   }
-  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big);
+  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big, t->c_reg != 0.f);
   if (rc) return rc;
   return finish_update(m, sa, st);
 }
@@ -1548,6 +1681,9 @@ int nncf_tower_destroy(nncf_tower* t) {
   if (t && t->hot_cnt) (void)hipFree(t->hot_cnt);
   if (t && t->hot_bits) (void)hipFree(t->hot_bits);
   if (t && t->cid_reg) (void)hipFree(t->cid_reg);
+  if (t && t->dA_tail) (void)hipFree(t->dA_tail);
+  if (t && t->wcount) (void)hipFree(t->wcount);
+  if (t && t->creg_q) (void)hipFree(t->creg_q);
   if (!t) return NNCF_OK;
   if (t->arena) hipFree(t->arena);
   if (t->stamps) hipFree(t->stamps);
@@ -1667,6 +1803,7 @@ int nncf_tower_set_dropout(nncf_tower* t, float rate, uint64_t seed) {
   t->drop_seed = seed;
   t->drop_step = 0;
   t->conv_step = 0;
+  t->tail_step = 0;
   return NNCF_OK;
 }
 
@@ -1784,6 +1921,52 @@ int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, flo
   t->cid_tab = d_id_table;
   t->v_reg = v_reg;
   t->acid = AdamTable{d_m, d_v, d_stamp};
+  return NNCF_OK;
+}
+
+int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(activation >= 0 && activation < kActCount, "activation %d: 0 relu, 1 tanh, 2 sigmoid, 3 hard_sigmoid, 4 softplus, "
+               "5 softsign, 6 linear", activation);
+  NNCF_REQUIRE(dropout >= 0.f && dropout < 1.f, "dropout rate %g out of [0, 1)", (double)dropout);
+  if ((activation != 0 || dropout > 0.f) && !t->dA_tail) {
+    DeviceGuard guard(t->device);
+    if (hipMalloc(&t->dA_tail, sizeof(float) * (size_t)t->cfg.max_rows * t->cfg.item_dim) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "Dense tail gradient buffer allocation failed");
+  }
+  t->tail_act = activation;
+  t->tail_drop = dropout;
+  t->tail_step = 0;
+  return NNCF_OK;
+}
+
+__global__ void tower_tail_mask_kernel(float keep, unsigned long long seed, int64_t n, int d, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = tail_mask(keep, seed, (int)(i / d), (int)(i % d));
+}
+
+int nncf_tower_dense_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d_out, void* stream) {
+  NNCF_REQUIRE(t && d_out && m > 0, "bad argument");
+  const float keep = t->tail_drop > 0.f ? 1.f - t->tail_drop : 1.f;
+  const unsigned long long seed = splitmix64(step_seed(t, step_index) ^ 0x7A11D80F0A11ull);
+  const int64_t n = m * t->cfg.item_dim;
+  hipLaunchKernelGGL(tower_tail_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), keep, seed, n,
+                     t->cfg.item_dim, d_out);
+  NNCF_HIP_CHECK(hipGetLastError());
+  return NNCF_OK;
+}
+
+int nncf_tower_set_c_reg(nncf_tower* t, float c_reg) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(c_reg >= 0.f, "c_reg must be >= 0");
+  if (c_reg != 0.f && !t->wcount) {
+    DeviceGuard guard(t->device);
+    const size_t nw = (size_t)t->cfg.word_count;
+    if (hipMalloc(&t->wcount, sizeof(int32_t) * nw) != hipSuccess || hipMalloc(&t->creg_q, sizeof(float) * nw) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "c_reg buffers allocation failed");
+    NNCF_HIP_CHECK(hipMemset(t->wcount, 0, sizeof(int32_t) * nw));
+  }
+  t->c_reg = c_reg;
   return NNCF_OK;
 }
 

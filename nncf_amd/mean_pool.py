@@ -261,6 +261,32 @@ class MeanPoolTower(object):
             _lib.check(self._L.nncf_tower_set_pooling(self.handle, int(pooling == "max")))
         self.version += 1
 
+    DENSE_ACTIVATIONS = ("relu", "tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear")
+
+    def set_dense_tail(self, activation="relu", dropout=0.0):
+        """item_dense_transform['dense_hidden_actv'] / ['dense_hidden_dropout'] (mean_pool.py:82-97, cnn_model.py:114-126)."""
+        if activation not in self.DENSE_ACTIVATIONS:
+            raise NotImplementedError("dense_hidden_actv = %r: built are %s" % (activation, ", ".join(self.DENSE_ACTIVATIONS)))
+        if self.d_l != self.d and activation in ("sigmoid", "hard_sigmoid", "softplus"):
+            raise NotImplementedError("dense_hidden_actv = %r needs item_dim %% 4 == 0 (act(0) != 0 would fill the pad columns)" % activation)
+        self.dense_act, self.dense_dropout = activation, float(dropout)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_dense_tail(self.handle, self.DENSE_ACTIVATIONS.index(activation), self.dense_dropout))
+        self.version += 1
+
+    def dense_mask(self, step_index, m):
+        """Dropout(dense_hidden_dropout) mask of the step_index-th train-mode forward, first m rows (checkers)."""
+        out = torch.empty(m, self.d, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_dense_mask(self.handle, int(step_index), m, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out[:, :self.d_l] if hasattr(self, "d_l") else out
+
+    def set_c_reg(self, c_reg):
+        """conf.c_reg (mean_pool.py:56-59, cnn_model.py:45-48): activity_l2(c_reg) on the word Embedding's output."""
+        self.c_reg = float(c_reg)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_c_reg(self.handle, self.c_reg))
+
     def set_content_id(self, v_reg=0.0, seed=0, optimizer="sgd"):
         """conf.use_content_id (mean_pool.py:102-108): the tower's output + Emb_Cid[item id]; Embedding(item_count,
         item_dim) init uniform(+-0.05) [K-mem], activity_l2(v_reg) on its output."""

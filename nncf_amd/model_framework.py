@@ -459,17 +459,14 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     if getattr(conf, "pretrain", None):
         raise NotImplementedError("the text towers are built for pretrain=None (what the demo scripts run: the pretrained "
                                   "sentence vectors are not in the repo)")
-    if float(getattr(conf, "c_reg", 0) or 0) != 0.0:
-        # mean_pool.py:56-59 / cnn_model.py:45-48: activity_l2(conf.c_reg) on the word Embedding's OUTPUT.  Every preset of the
-        # reference sets it to 0 (basic_embedding_conf.py:38,106; cnn_embedding_conf.py:38,114); whether Keras 1.2.2 applies
-        # an Embedding's activity regulariser before or after its row dropout cannot be pinned here.  Refused, not ignored.
-        raise NotImplementedError("c_reg = %r: the activity regulariser on the word-embedding output is not built (every preset "
-                                  "of the reference runs c_reg = 0); set c_reg = 0" % conf.c_reg)
     pooling = getattr(conf, "pooling", "average")
     assert conv is not None or pooling in ("average", "max"), "[ERROR] unknown pooling: %s" % pooling   # mean_pool.py:76
     idt = conf.item_dense_transform
-    assert idt["dense_hidden_dim"] == conf.item_dim and idt["dense_hidden_actv"] == "relu" and \
-        idt["dense_hidden_dropout"] == 0., "item_dense_transform other than Dense(item_dim)+relu is not built"
+    # mean_pool.py:78-101 / cnn_model.py:112-130: Dense(dense_hidden_dim) -> BatchNorm -> Activation -> Dropout.  The tower's
+    # output is the item row: dense_hidden_dim must be item_dim; a tower WITHOUT the transform (or with conf.no_BN) is not built.
+    if not idt or idt["dense_hidden_dim"] != conf.item_dim or getattr(conf, "no_BN", False):
+        raise NotImplementedError("item_dense_transform must be Dense(item_dim) + BatchNormalization (got %r, no_BN = %r)"
+                                  % (idt, getattr(conf, "no_BN", False)))
     kw = engine_kwargs(conf, data_spec, "basic_embedding")
     cap = conf.batch_size_p * (1 + conf.num_negatives)          # most unique items a batch can hold
     kw["item_count"] = cap
@@ -483,6 +480,10 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
         tower.set_pooling("max")                                        # cnn_model.py:107-109
     if getattr(conf, "use_content_id", False):                          # mean_pool.py:102-108
         tower.set_content_id(getattr(conf, "v_reg", 0.0), seed=seed)
+    if idt["dense_hidden_actv"] != "relu" or float(idt["dense_hidden_dropout"]) != 0.:   # mean_pool.py:96-97
+        tower.set_dense_tail(idt["dense_hidden_actv"], float(idt["dense_hidden_dropout"]))
+    if float(getattr(conf, "c_reg", 0) or 0) != 0.0:                    # mean_pool.py:56-59, cnn_model.py:45-48
+        tower.set_c_reg(conf.c_reg)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)
     opt = getattr(conf, "optimizer", "sgd")
     if opt != "sgd":

@@ -360,9 +360,23 @@ class TowerOracle(object):
         self.pooling = "average"   # conf.pooling (mean_pool.py:68-76): 'average' | 'max'
         self.Cid = None            # conf.use_content_id (mean_pool.py:102-108): Emb_Cid table (item_count, d), or None
         self.v_reg = self.dt.type(0)   # activity_l2(v_reg) on the Emb_Cid output
+        self.c_reg = self.dt.type(0)   # activity_l2(c_reg) on the word Embedding's output (mean_pool.py:56-59, cnn_model.py:45-48)
+        self.dense_act = "relu"        # item_dense_transform['dense_hidden_actv'] (mean_pool.py:83,96): any of ACTIVATIONS
+        self.dense_mask = None         # Dropout(dense_hidden_dropout) (mean_pool.py:84,97): (n, d) mask INCLUDING its 1/keep scale
         self.extra_loss = 0.0
 
     PARAMS = ("W", "Wd", "bd", "gamma", "beta")
+
+    # Keras-1 activations by name (keras/activations.py; hard_sigmoid = clip(0.2 x + 0.5, 0, 1) [K-mem]): value, derivative
+    ACTIVATIONS = {
+        "relu": (lambda y: np.maximum(y, 0), lambda y: (y > 0).astype(y.dtype)),
+        "tanh": (np.tanh, lambda y: 1 - np.tanh(y) ** 2),
+        "sigmoid": (lambda y: 1 / (1 + np.exp(-y)), lambda y: (1 / (1 + np.exp(-y))) * (1 - 1 / (1 + np.exp(-y)))),
+        "hard_sigmoid": (lambda y: np.clip(0.2 * y + 0.5, 0, 1), lambda y: 0.2 * ((y > -2.5) & (y < 2.5)).astype(y.dtype)),
+        "softplus": (lambda y: np.logaddexp(y, 0), lambda y: 1 / (1 + np.exp(-y))),
+        "softsign": (lambda y: y / (1 + np.abs(y)), lambda y: 1 / (1 + np.abs(y)) ** 2),
+        "linear": (lambda y: y, lambda y: np.ones_like(y)),
+    }
 
     def _front_forward(self, toks, row_scale, train):
         """tokens (n, L) -> pooled block h (n, hd): here the mean of the word rows."""
@@ -439,14 +453,35 @@ class TowerOracle(object):
         y = self.gamma * xhat + self.beta
         if train:
             self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
-        return self._plus_content_id(np.maximum(y, 0).astype(self.dt), cid_u, train)
+        act = self.ACTIVATIONS[self.dense_act][0](y)
+        if train and self.dense_mask is not None:
+            act = act * self.dense_mask[:len(act)]
+        out = self._plus_content_id(act.astype(self.dt), cid_u, train)
+        if train and self.c_reg != 0:
+            # L1L2Act (utilities.py:122-135) on the Embedding output (n, L, wd), AFTER its row dropout [K-mem: Keras-1 Embedding
+            # scales the table rows, the regulariser sees the gathered result]: c_reg * sum_{l, c} mean_n(E^2)
+            E = self.W[toks] if row_scale is None else self.W[toks] * row_scale[toks][..., None]
+            self.extra_loss += float(self.c_reg * np.sum(np.mean(E * E, axis=0)))
+        return out
+
+    def _c_reg_grad(self, dW):
+        """d(c_reg * sum mean_n(E^2)) / dW: 2 c_reg / n * scale[w]^2 * W[w] per occurrence of w in the block."""
+        if self.c_reg == 0:
+            return
+        c = self.cache
+        toks, rs = c["toks"], c["row_scale"]
+        n = self.dt.type(toks.shape[0])
+        E = self.W[toks] if rs is None else self.W[toks] * (rs[toks] ** 2)[..., None]
+        np.add.at(dW, toks, (2 * self.c_reg / n * E).astype(self.dt))
 
     def backward_update(self, dA, conf=None, t=None):
         """conf / t: OracleConf with optimizer != 'sgd' and the 1-based optimiser step."""
         c = self.cache
         self._content_id_update(dA, conf, t)
         n = self.dt.type(dA.shape[0])
-        dy = dA * (c["y"] > 0)
+        dy = dA * self.ACTIVATIONS[self.dense_act][1](c["y"])
+        if self.dense_mask is not None:
+            dy = dy * self.dense_mask[:len(dy)]
         dgamma = (dy * c["xhat"]).sum(axis=0)
         dbeta = dy.sum(axis=0)
         dxhat = dy * self.gamma
@@ -457,6 +492,7 @@ class TowerOracle(object):
         self.grads = dict(Wd=dWd, bd=dbd, gamma=dgamma, beta=dbeta)
         self.grads.update(self._front_backward(dh.astype(self.dt)))
         dW = self.grads["W"]
+        self._c_reg_grad(dW)
         self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
         self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
         if getattr(self, "export_only", False):   # data-parallel: gradients leave, nothing is applied

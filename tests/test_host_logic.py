@@ -208,19 +208,6 @@ def test_cnn_front_spec_from_the_reference_presets():
     assert _conv_spec(mx)["pooling"] == "max"
 
 
-def test_c_reg_is_refused_not_ignored():
-    """mean_pool.py:56-59 / cnn_model.py:45-48: activity_l2(conf.c_reg) on the word-embedding output is not built; a non-zero
-    value must stop get_model (it was carried in conf.py and consumed nowhere).  Checked before any device work."""
-    from nncf_amd.data_utils import get_data
-    from nncf_amd.model_framework import get_model
-    data = synthetic.make_citeulike_like(users=50, items=40, train_links=400, seed=3, content_len=12, vocab=30)
-    for mc in ("basic_embedding", "cnn_embedding"):
-        conf = get_conf("synthetic", "best", {"reset_after_getconf": True, "c_reg": 1e-4}, model_choice=mc)
-        helper = get_data(dict(data), conf, rand_seed=5)
-        with pytest.raises(NotImplementedError, match="c_reg"):
-            get_model(conf, helper, mc)
-
-
 def test_postings_schedule_invariants():
     """nncf_amd.mean_pool.postings_schedule (the static schedule behind nncf_tower_set_postings): every word exactly once as
     a first unit, a word's units contiguous in ONE workgroup and covering its postings in order, hot words with an empty

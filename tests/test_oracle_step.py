@@ -285,10 +285,12 @@ def test_tower_oracle_vs_autograd_full_chain():
         np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
 
 
-@pytest.mark.parametrize("pooling,content_id", [("max", False), ("average", True), ("max", True)])
-def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id):
+@pytest.mark.parametrize("pooling,content_id,c_reg", [("max", False, 0.), ("average", True, 0.), ("max", True, 0.),
+                                                      ("average", False, 0.03), ("max", True, 0.03)])
+def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id, c_reg):
     """conf.pooling = 'max' (mean_pool.py:70-72: MaxPooling1D over the whole length) and conf.use_content_id
-    (mean_pool.py:102-108: tower output + Emb_Cid[cid], activity_l2(v_reg) on the Embedding output): loss and every
+    (mean_pool.py:102-108: tower output + Emb_Cid[cid], activity_l2(v_reg) on the Embedding output) and conf.c_reg
+    (mean_pool.py:56-59: activity_l2(c_reg) on the word Embedding's output, after its row dropout): loss and every
     gradient of the oracle against torch autograd of the formulas; word-row dropout on (dropped rows are zeros that
     still take part in the maximum)."""
     rs = np.random.RandomState(1)
@@ -305,6 +307,7 @@ def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id
     tw.pooling = pooling
     if content_id:
         tw.Cid, tw.v_reg = Cid.copy(), 0.05
+    tw.c_reg = c_reg
     o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
     o.row_scale = scale
     uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
@@ -324,6 +327,7 @@ def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id
         ce = tp[5][torch.tensor(cu, dtype=torch.long)]
         E = E + ce
         extra = 0.05 * (ce * ce).mean(0).sum()
+    extra = extra + c_reg * (rows * rows).mean(0).sum()       # L1L2Act: sum over (L, wd) of the mean over the block's rows
     l_t = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf) + extra
     l_t.backward()
     assert abs(l_o - l_t.item()) < 1e-10
@@ -332,6 +336,43 @@ def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id
     np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
     if content_id:    # the SGD step the oracle took on the id rows = lr * autograd's gradient
         np.testing.assert_allclose(Cid - tw.Cid, 0.1 * tp[5].grad.numpy(), atol=1e-10)
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear", "relu"])
+def test_tower_oracle_dense_tail_variants_vs_autograd(act):
+    """item_dense_transform['dense_hidden_actv'] other than relu and Dropout(dense_hidden_dropout) (mean_pool.py:82-97): loss
+    and every gradient of the oracle against torch autograd of Dense -> BatchNorm -> Activation -> Dropout (a given mask)."""
+    rs = np.random.RandomState(2)
+    I, L, Wc, wd, d, nu, b = 30, 7, 20, 8, 8, 10, 8
+    C = rs.randint(0, Wc, (I, L))
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = rs.uniform(-.1, .1, d), rs.uniform(.5, 1.5, d), rs.uniform(-.1, .1, d)
+    U = rs.uniform(-.5, .5, (nu, d))
+    mask = (rs.rand(b, d) < 0.8) / 0.8
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="log-loss", u_reg=1e-3, learn_rate=0.1, model_choice="basic_embedding")
+    tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.1, dtype=np.float64)
+    tw.dense_act, tw.dense_mask = act, mask
+    o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+    cid[3] = cid[0]
+    l_o = o.step_neg_shared(uid, cid)
+    tU = torch.tensor(U, requires_grad=True)
+    tp = [torch.tensor(x, requires_grad=True) for x in (W, Wd, bd, ga, be)]
+    cu, cx = so.tf_unique(cid)
+    h = tp[0][torch.tensor(C[cu])].sum(1) / L
+    z = h @ tp[1] + tp[2]
+    mu = z.mean(0)
+    y = tp[3] * (z - mu) / torch.sqrt(((z - mu) ** 2).mean(0) + 1e-3) + tp[4]
+    f = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "hard_sigmoid": lambda v: torch.clamp(0.2 * v + 0.5, 0, 1),
+         "softplus": torch.nn.functional.softplus, "softsign": torch.nn.functional.softsign, "linear": lambda v: v,
+         "relu": torch.relu}[act]
+    E = f(y) * torch.tensor(mask[:len(cu)])
+    l_t = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf)
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    for name, t in zip(("W", "Wd", "bd", "gamma", "beta"), tp):
+        np.testing.assert_allclose(tw.grads[name], t.grad.numpy(), atol=1e-10, err_msg=name)
+    np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
 
 
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])

@@ -1198,6 +1198,167 @@ def test_pooling_max_and_use_content_id_match_oracle(text_data, pooling, content
     np.testing.assert_allclose(emb, E, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("model,scheme,loss,opt,big", [
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", False),       # one-launch step: the term joins the deferred loss
+    ("basic_embedding", "original", "skip-gram", "sgd", False),
+    ("basic_embedding", "group_neg_shared", "log-loss", "adam", False),
+    ("basic_embedding", "original", "skip-gram", "sparse_adam", True),   # 2,048-row block: postings walk + hot words
+    ("cnn_embedding", "neg_shared", "skip-gram", "sgd", False),
+    ("cnn_embedding", "original", "log-loss", "sgd", False),
+])
+def test_c_reg_matches_oracle(text_data, model, scheme, loss, opt, big):
+    """conf.c_reg (mean_pool.py:56-59, cnn_model.py:45-48: activity_l2(c_reg) on the word Embedding's output; L1L2Act,
+    utilities.py:122-135): three steps with word-row dropout against the float64 oracle -- loss (with the regulariser), user
+    table, every tower parameter -- a loss-only step in between (the term belongs to the loss, the counts must be left clean),
+    and the same steps with c_reg = 0 must differ (the term is not ignored)."""
+    c_reg = 0.05
+    data = text_data
+    if big:
+        data = synthetic.make_citeulike_like(users=400, items=3000, train_links=9000, seed=4, content_len=24, vocab=300)
+    n_items = len(data["C"])
+
+    def make(creg):
+        if model == "cnn_embedding":
+            conf = _conf_cnn(loss, scheme, wdrop=0.3, cdrop=0.2)
+        else:
+            conf = _conf(loss, scheme, lr=0.02 if opt != "sgd" else 0.2, **(dict(b=512, k=3, d=32) if big else {}))
+            conf.word_emb_dropout_rate = 0.3
+        conf.optimizer = opt
+        conf.c_reg = creg
+        md = get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2)
+        return conf, md
+
+    conf, md = make(c_reg)
+    _, md0 = make(0.0)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, data, dtype=np.float64)
+    orc.conf.optimizer = opt
+    to.c_reg = c_reg
+    key = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]
+    head, head0 = md[key], md0[key]
+    tw = head.core.tower
+    if big:
+        assert getattr(tw, "post_units", None) is not None
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = data["train"]
+    rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
+    names = CNN_PARAMS if model == "cnn_embedding" else ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if model == "cnn_embedding":
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, n_items, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        reg = to.extra_loss
+        assert reg > 0
+        got = head.train_on_batch([u, c], [y])
+        got0 = head0.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+        if step == 0:   # same parameters, same masks: the two losses differ by the regulariser
+            assert abs((got - got0) - reg) <= 1e-5 * max(1, abs(want)), (got, got0, reg)
+        np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in names:
+            if name == "bc" or (opt != "sgd" and name in ("bd", "rm")):
+                continue   # gradients that are rounding noise behind a BatchNorm
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+    assert np.abs(tw.W.cpu().numpy() - md0[key].core.tower.W.cpu().numpy()).max() > 1e-4   # the term moved the word rows
+    # loss-only steps (the monitor heads): the regulariser belongs to the loss, and the second one finds the counts clean
+    e = head.core.engine
+    W0 = tw.W.clone()
+    for step in (3, 4):
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if model == "cnn_embedding":
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+        if scheme == "original":
+            want = orc.step_original(u, c, y, update=False)
+            got = float(head.core.step("original", e.ids(u[:b]), e.ids(c), update=False).item())
+        else:
+            want = (orc.step_neg_shared if scheme == "neg_shared" else orc.step_group_neg_shared)(u, c, update=False)
+            got = float(head.core.step(scheme, e.ids(u), e.ids(c), update=False).item())
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+    assert torch.equal(tw.W, W0)
+
+
+@pytest.mark.parametrize("model,scheme,loss,opt,act,drop", [
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", "tanh", 0.0),
+    ("basic_embedding", "neg_shared", "log-loss", "sgd", "relu", 0.3),
+    ("basic_embedding", "original", "skip-gram", "sgd", "sigmoid", 0.2),
+    ("basic_embedding", "group_neg_shared", "log-loss", "adam", "softplus", 0.0),
+    ("basic_embedding", "neg_shared", "mse", "sgd", "hard_sigmoid", 0.0),
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", "softsign", 0.2),
+    ("basic_embedding", "original", "log-loss", "sgd", "linear", 0.0),
+    ("cnn_embedding", "neg_shared", "skip-gram", "sgd", "tanh", 0.2),
+    ("cnn_embedding", "original", "skip-gram", "sgd", "linear", 0.0),
+])
+def test_dense_tail_variants_match_oracle(text_data, model, scheme, loss, opt, act, drop):
+    """item_dense_transform['dense_hidden_actv'] other than relu and Dropout(dense_hidden_dropout) (mean_pool.py:82-97,
+    cnn_model.py:114-126): three steps with word-row dropout against the float64 oracle (the kernels' masks materialised and
+    fed to it) -- loss, user table, every tower parameter -- then inference-mode scores (no dropout, running statistics)."""
+    if model == "cnn_embedding":
+        conf = _conf_cnn(loss, scheme, wdrop=0.3, cdrop=0.2)
+    else:
+        conf = _conf(loss, scheme, lr=0.02 if opt != "sgd" else 0.2)
+        conf.word_emb_dropout_rate = 0.3
+    conf.optimizer = opt
+    conf.item_dense_transform = {"dense_hidden_dim": conf.item_dim, "dense_hidden_dropout": drop, "dense_hidden_actv": act}
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), model, seed=2)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, text_data, dtype=np.float64)
+    orc.conf.optimizer = opt
+    to.dense_act = act
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
+    names = CNN_PARAMS if model == "cnn_embedding" else ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if model == "cnn_embedding":
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+        if drop:
+            to.dense_mask = tw.dense_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+            assert 0.5 < (to.dense_mask > 0).mean() < 0.95 and set(np.unique(to.dense_mask)) <= {0.0, float(np.float32(1) / np.float32(1 - drop))}
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in names:
+            if name == "bc" or (opt != "sgd" and name in ("bd", "rm")):
+                continue   # gradients that are rounding noise behind a BatchNorm
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+    if opt != "sgd":
+        return
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam", "sparse_adam"])
 @pytest.mark.parametrize("hot_words", ["1", "0"])
 def test_postings_mode_equals_the_count_matrix_scan(monkeypatch, opt, hot_words):
