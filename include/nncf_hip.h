@@ -689,7 +689,10 @@ int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_c
  *   d_counts[4] = {n_segments, n, n_chunks, 0},
  *   d_desc[4n] = per segment {id, first position, start in d_order, count} (16-byte aligned),
  *   d_slot_seg[n] = segment of every sorted slot,
- *   d_chunk_start[n/16 + 2] = slot ranges of whole segments handed to one apply workgroup. */
+ *   d_chunk_start[n/16 + 2] = slot ranges of whole segments handed to one apply workgroup.
+ * n <= 32768 (the per-step capacity of a model: batch_size_p * (1 + num_negatives)).  Up to 8192 entries everything is sorted
+ * and scanned in LDS; above, the per-entry arrays are global; above 16384 the sort keys too, sorted through one 16384-key LDS
+ * tile (this stand-alone entry allocates that scratch for the call and waits for the stream). */
 int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, int32_t* d_seg_start, int32_t* d_uniq,
                   int32_t* d_inverse, int32_t* d_counts, int32_t* d_desc, int32_t* d_slot_seg,
                   int32_t* d_chunk_start, void* stream);

@@ -20,6 +20,7 @@ struct PlanView {
   int32_t* slot_seg = nullptr;   // segment index of every sorted slot
   int32_t* chunk_start = nullptr;  // sorted-slot ranges of whole segments, ~kChunkSlots slots each
   int32_t* aux = nullptr;        // lists above 8192 entries only: per-position scratch that no longer fits LDS
+  unsigned long long* keys = nullptr;   // lists above 16384 entries only: the (id, position) sort keys (LDS holds one 16384-entry tile)
   int64_t list_stride = 0;
 
   __host__ __device__ int64_t chunk_stride() const { return list_stride / 16 + 2; }
@@ -35,6 +36,7 @@ struct PlanView {
     v.slot_seg += L * list_stride;
     v.chunk_start += L * chunk_stride();
     if (v.aux) v.aux += L * list_stride;
+    if (v.keys) v.keys += L * list_stride;
     return v;
   }
 };

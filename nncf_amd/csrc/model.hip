@@ -214,6 +214,7 @@ void carve(nncf_model* m, Carver& c) {
     v.slot_seg = c.take<int32_t>(kPlanChunk * cap);
     v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
     v.aux = cap > 8192 ? c.take<int32_t>(kPlanChunk * cap) : nullptr;
+    v.keys = cap > 16384 ? c.take<unsigned long long>(kPlanChunk * cap) : nullptr;
   };
   plan(m->plan_u, m->cap_u);
   plan(m->plan_v, m->cap_v);
@@ -258,8 +259,8 @@ int nncf_model_create(const nncf_model_cfg* cfg, float* d_user_table, float* d_i
   NNCF_REQUIRE(cfg->row_stride >= cfg->dim && cfg->row_stride % 4 == 0, "row_stride = %d must be >= dim and a multiple of 4",
                cfg->row_stride);
   NNCF_REQUIRE(cfg->loss >= 0 && cfg->loss <= 3, "[ERROR!] loss %d not specified.", cfg->loss);
-  NNCF_REQUIRE((int64_t)cfg->batch_size_p * (1 + cfg->num_negatives) <= 16384,
-               "batch_size_p * (1 + num_negatives) = %lld exceeds the per-step plan capacity 16384",
+  NNCF_REQUIRE((int64_t)cfg->batch_size_p * (1 + cfg->num_negatives) <= 32768,
+               "batch_size_p * (1 + num_negatives) = %lld exceeds the per-step plan capacity 32768",
                (long long)cfg->batch_size_p * (1 + cfg->num_negatives));
   NNCF_REQUIRE(cfg->user_count > 0 && cfg->item_count > 0, "empty table");
   NNCF_REQUIRE(((uintptr_t)d_user_table & 15) == 0 && ((uintptr_t)d_item_table & 15) == 0, "tables must be 16-byte aligned");

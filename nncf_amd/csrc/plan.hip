@@ -44,11 +44,19 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
   // up to 8192 entries everything lives in LDS (16 B per entry); above, only the sort keys do (8 B per entry,
   // 128 KiB at 16384) and the two per-entry int arrays are global: `seg` IS the slot_seg output, `aux` is
   // PlanView::aux.  A workgroup reads back its own global writes after a barrier (same CU, same L1).
+  // Above 16384 entries (CAP = 32768: config [3]'s bandwidth-bound batches) the keys live in global memory too
+  // (PlanView::keys) and are sorted through ONE 16384-entry LDS tile: both halves sorted in LDS (the second descending),
+  // the one cross-half compare-exchange step against global memory, both halves merged in LDS.  Everything behind the sort
+  // reads the keys where they are; the dead tile then holds the small scan areas.
   constexpr bool BIG = CAP > 8192;
-  unsigned long long* key = reinterpret_cast<unsigned long long*>(smem);   // CAP
-  int* seg = BIG ? out.slot_seg + L * out.list_stride : reinterpret_cast<int*>(key + CAP);   // CAP: segment of sorted slot
-  int* aux = BIG ? out.aux + L * out.list_stride : seg + CAP;                                  // CAP: first-occurrence flags / ranks
-  int* scratch = BIG ? reinterpret_cast<int*>(key + CAP) : aux + CAP;                          // NT
+  constexpr bool HUGE = CAP > 16384;
+  constexpr int TILE = HUGE ? 16384 : CAP;
+  unsigned long long* lkey = reinterpret_cast<unsigned long long*>(smem);   // TILE
+  unsigned long long* key = HUGE ? out.keys + L * out.list_stride : lkey;    // CAP
+  int* seg = BIG ? out.slot_seg + L * out.list_stride : reinterpret_cast<int*>(lkey + CAP);   // CAP: segment of sorted slot
+  int* aux = BIG ? out.aux + L * out.list_stride : seg + CAP;                                   // CAP: first-occurrence flags / ranks
+  int* scratch = HUGE ? reinterpret_cast<int*>(smem) : (BIG ? reinterpret_cast<int*>(lkey + CAP) : aux + CAP);   // max(NT, CAP / 16)
+  int* scan2 = scratch + (CAP / kChunkSlots > NT ? CAP / kChunkSlots : NT);   // a second small scan area (see the carve)
   const int tid = threadIdx.x;
   const int n = na + nb;
   ids_a += L * stride_a;
@@ -62,31 +70,91 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
   int32_t* chunk_start = out.chunk_start + L * out.chunk_stride();
   int4* desc = reinterpret_cast<int4*>(out.desc + L * out.list_stride * 4);
 
-  int m = 2;  // sort size: next power of two >= n
-  while (m < n) m <<= 1;
-  for (int i = tid; i < m; i += NT) {
-    unsigned long long k = ~0ull;
-    if (i < n) {
-      const uint32_t id = (uint32_t)(i < na ? ids_a[i] : ids_b[i - na]);
-      k = ((unsigned long long)id << 32) | (uint32_t)i;
+  auto make_key = [&](int i) -> unsigned long long {
+    if (i >= n) return ~0ull;
+    const uint32_t id = (uint32_t)(i < na ? ids_a[i] : ids_b[i - na]);
+    return ((unsigned long long)id << 32) | (uint32_t)i;
+  };
+  if constexpr (!HUGE) {
+    int m = 2;  // sort size: next power of two >= n
+    while (m < n) m <<= 1;
+    for (int i = tid; i < m; i += NT) {
+      key[i] = make_key(i);
+      if (!BIG || i < n) aux[i] = 0;   // the global array holds list_stride >= n entries, not m
     }
-    key[i] = k;
-    aux[i] = 0;
-  }
-  __syncthreads();
-  // bitonic sort, ascending by (id, position)
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (m >> 1); t += NT) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const bool asc = (i & k) == 0;
-        const unsigned long long a = key[i], b = key[l];
-        if ((a > b) == asc) {
-          key[i] = b;
-          key[l] = a;
+    __syncthreads();
+    // bitonic sort, ascending by (id, position)
+    for (int k = 2; k <= m; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (m >> 1); t += NT) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const bool asc = (i & k) == 0;
+          const unsigned long long a = key[i], b = key[l];
+          if ((a > b) == asc) {
+            key[i] = b;
+            key[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    // the same network over 2 * TILE entries (n > TILE here), the stages with j < TILE inside the LDS tile
+    for (int h = 0; h < 2; ++h) {   // stages k = 2 .. TILE: each half alone; direction from the GLOBAL index (k = TILE: half 1 descends)
+      for (int i = tid; i < TILE; i += NT) {
+        lkey[i] = make_key(h * TILE + i);
+        if (h * TILE + i < n) aux[h * TILE + i] = 0;
+      }
+      __syncthreads();
+      for (int k = 2; k <= TILE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (TILE >> 1); t += NT) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const bool asc = ((h * TILE + i) & k) == 0;
+            const unsigned long long a = lkey[i], b = lkey[l];
+            if ((a > b) == asc) {
+              lkey[i] = b;
+              lkey[l] = a;
+            }
+          }
+          __syncthreads();
         }
       }
+      if (h == 0) {   // (the global arrays hold list_stride >= n entries: the pads behind entry n stay implicit)
+        for (int i = tid; i < min(TILE, n); i += NT) key[i] = lkey[i];
+        __syncthreads();
+      }
+    }
+    // stage k = 2 TILE, j = TILE: entry i of half 0 (global) against entry i of half 1 (the tile), ascending
+    for (int i = tid; i < TILE; i += NT) {
+      const unsigned long long a = i < n ? key[i] : ~0ull, b = lkey[i];
+      if (a > b) {   // (never for i >= n: then half 1 is all pads)
+        key[i] = b;
+        lkey[i] = a;
+      }
+    }
+    __syncthreads();
+    for (int h = 1; h >= 0; --h) {   // j = TILE / 2 .. 1 of that stage: each half alone again, ascending
+      if (h == 0) {
+        for (int i = tid; i < TILE; i += NT) lkey[i] = i < n ? key[i] : ~0ull;
+        __syncthreads();
+      }
+      for (int j = TILE >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (TILE >> 1); t += NT) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const unsigned long long a = lkey[i], b = lkey[l];
+          if (a > b) {
+            lkey[i] = b;
+            lkey[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < TILE; i += NT)
+        if (h * TILE + i < n) key[h * TILE + i] = lkey[i];
       __syncthreads();
     }
   }
@@ -162,7 +230,7 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
   // Chunks for the apply kernels: sorted-slot ranges that hold whole segments, cut at the
   // first segment head at or after every multiple of kChunkSlots.
   __syncthreads();
-  const int nm = (n + kChunkSlots - 1) / kChunkSlots;  // <= CAP / 16 <= NT
+  const int nm = (n + kChunkSlots - 1) / kChunkSlots;  // <= CAP / 16
   for (int m = tid; m < nm; m += NT) {
     const int i = m * kChunkSlots;
     int bslot = 0;
@@ -173,15 +241,25 @@ __device__ __forceinline__ void plan_body(const int32_t* __restrict__ ids_a, int
   // distinct boundaries, in order (a boundary repeats when a segment spans several multiples of kChunkSlots): flag + scan
   // (was one thread walking all nm entries: 352 dependent LDS reads for `original`'s 5,632 ids)
   {
-    int bs = n, keep = 0;
-    if (tid < nm) {
-      bs = scratch[tid];
-      const int prev = tid > 0 ? scratch[tid - 1] : -1;
-      keep = (bs != prev && bs < n) ? 1 : 0;
+    constexpr int CPT = (CAP / kChunkSlots + NT - 1) / NT;   // consecutive boundaries per thread: 1, or 2 at CAP = 32768
+    int bs[CPT], keep[CPT], mine = 0;
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const int idx = tid * CPT + e;
+      bs[e] = n;
+      keep[e] = 0;
+      if (idx < nm) {
+        bs[e] = scratch[idx];
+        const int prev = idx > 0 ? scratch[idx - 1] : -1;
+        keep[e] = (bs[e] != prev && bs[e] < n) ? 1 : 0;
+      }
+      mine += keep[e];
     }
     int c_total;
-    const int c = block_exclusive_scan<NT>(keep, scratch + NT, &c_total);   // scratch[NT ..]: a second small area (see the carve)
-    if (keep) chunk_start[c] = bs;
+    int c = block_exclusive_scan<NT>(mine, scan2, &c_total);
+#pragma unroll
+    for (int e = 0; e < CPT; ++e)
+      if (keep[e]) chunk_start[c++] = bs[e];
     for (int e = c_total + tid; e <= nm; e += NT) chunk_start[e] = n;       // unused chunks are empty ranges [n, n)
     if (tid == 0) {
       counts[2] = c_total;
@@ -292,7 +370,11 @@ int launch_plan_steps(const int32_t* uid, int64_t stride_u, int nu, const PlanVi
   if (n <= 16384 && pu.aux && pv.aux)
     return launch_plan_steps_t<16384, 1024>(16384 * 8 + 1024 * 4 + 256, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b, stride_b, nb,
                                             pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
-  return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (16384 with a scratch array, 8192 without)", n);
+  if (n <= 32768 && pu.aux && pv.aux && pu.keys && pv.keys)   // (a list of <= 16384 entries of such a step sorts as a padded 32768 one)
+    return launch_plan_steps_t<32768, 1024>(16384 * 8 + 1024 * 4 + 256, uid, stride_u, nu, pu, ids_a, stride_a, na, ids_b, stride_b, nb,
+                                            pv, uniq_global, uniq_stride, n_u_out, n_u_copy, n_lists, stream);
+  return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (32768 with scratch + key arrays, 16384 with a "
+              "scratch array, 8192 without)", n);
 }
 
 int launch_plan_pair(const int32_t* ids0, int n0, const PlanView& out0, const int32_t* ids1, int n1,
@@ -344,8 +426,19 @@ int launch_plan(const int32_t* ids_a, int64_t stride_a, int na, const int32_t* i
       hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
                        ids_b, stride_b, nb, out);
     }
+  } else if (n <= 32768 && out.aux && out.keys) {
+    constexpr int CAP = 32768, NT = 1024;
+    const size_t lds = 16384 * 8 + NT * 4 + 256;  // one 16384-key tile
+    static KernelDeviceState kds;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&plan_kernel<CAP, NT>), lds, kds)) return rc;
+    {
+      ProfScope _ps("plan_kernel", stream);
+      hipLaunchKernelGGL((plan_kernel<CAP, NT>), dim3((unsigned)n_lists), dim3(NT), lds, stream, ids_a, stride_a, na,
+                       ids_b, stride_b, nb, out);
+    }
   } else {
-    return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (16384 with a scratch array, 8192 without)", n);
+    return fail(NNCF_ERR_INVALID, "id list of %d entries exceeds the plan capacity (32768 with scratch + key arrays, 16384 with a "
+                "scratch array, 8192 without)", n);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -361,7 +454,7 @@ extern "C" int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, 
   NNCF_REQUIRE(d_ids && d_order && d_seg_start && d_uniq && d_inverse && d_counts && d_desc && d_slot_seg && d_chunk_start,
                "NULL argument");
   NNCF_REQUIRE(((uintptr_t)d_desc & 15) == 0, "d_desc must be 16-byte aligned");
-  NNCF_REQUIRE(n > 0 && n <= 8192, "n = %d out of range (1..8192)", n);
+  NNCF_REQUIRE(n > 0 && n <= 32768, "n = %d out of range (1..32768)", n);
   PlanView v;
   v.order = d_order;
   v.seg_start = d_seg_start;
@@ -372,5 +465,15 @@ extern "C" int nncf_plan_ids(const int32_t* d_ids, int32_t n, int32_t* d_order, 
   v.slot_seg = d_slot_seg;
   v.chunk_start = d_chunk_start;
   v.list_stride = n;
-  return launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, as_stream(stream));
+  if (n <= 8192) return launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, as_stream(stream));
+  // larger lists need per-entry scratch outside LDS (a model owns such arrays; this stand-alone entry borrows them for
+  // the call and waits for the stream before giving them back)
+  void* tmp = nullptr;
+  if (hipMalloc(&tmp, (size_t)n * 12) != hipSuccess) return fail(NNCF_ERR_NOMEM, "plan scratch allocation failed");
+  v.keys = n > 16384 ? reinterpret_cast<unsigned long long*>(tmp) : nullptr;
+  v.aux = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(tmp) + (size_t)n * 8);
+  int rc = launch_plan(d_ids, 0, n, nullptr, 0, 0, v, 1, as_stream(stream));
+  if (hipStreamSynchronize(as_stream(stream)) != hipSuccess && !rc) rc = fail(NNCF_ERR_HIP, "plan launch failed");
+  (void)hipFree(tmp);
+  return rc;
 }

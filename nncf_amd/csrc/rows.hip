@@ -459,6 +459,7 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     v.slot_seg = c.take<int32_t>(kPlanChunk * n);
     v.chunk_start = c.take<int32_t>(kPlanChunk * v.chunk_stride());
     v.aux = n > 8192 ? c.take<int32_t>(kPlanChunk * n) : nullptr;
+    v.keys = n > 16384 ? c.take<unsigned long long>(kPlanChunk * n) : nullptr;
   }
 }
 

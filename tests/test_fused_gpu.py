@@ -401,6 +401,28 @@ def test_fused_batch_16384():
         np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.timeout(900)
+def test_fused_batch_32768():
+    """b = 32768 (inside config [3]'s "b >~ 16K per GPU" regime): the 32768-entry plan (sort keys in global
+    memory, one 16384-key LDS tile), 2 x 512 wide workgroups, staged rows + commit launch.  One step against the float32
+    oracle (4 GB per b x b temporary); many duplicate users / items (tables of b / 4 rows)."""
+    b, d = 32768, 16
+    nu, ni = b // 4, b // 4
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="mse", u_reg=0., learn_rate=4.0, model_choice="mf",
+                         neg_loss_weight=8.)
+    eng = Engine(nu, ni, d, b, 0, "mse", conf.loss_gamma, conf.neg_loss_weight, conf.u_reg, conf.learn_rate, False, False,
+                 seed=11, init_scale=0.5)
+    orc = so.StepOracle(eng.U.cpu().numpy(), eng.V.cpu().numpy(), conf, dtype=np.float32)
+    rs = np.random.RandomState(5)
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, ni, b)
+    want = orc.step_neg_shared(uid, cid)
+    got = eng.step_neg_shared(eng.ids(uid), eng.ids(cid)).item()
+    # the loss is a mean of 2^30 float32 terms on BOTH sides (the oracle's own float32 sum is good to ~1e-5 here)
+    assert abs(got - want) <= 5e-5 * max(1.0, abs(want)), (got, want)
+    np.testing.assert_allclose(eng.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(eng.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NNCF_SOAK_SEEDS", "24"))))
 def test_fused_random_shapes_terminate_and_match(force_row_tiles, seed):

@@ -34,7 +34,9 @@ def _check_tables(eng, orc):
 
 def test_plan_ids_matches_tf_unique():
     rs = np.random.RandomState(0)
-    for n, hi in [(1, 5), (2, 1), (37, 10), (512, 60), (512, 100000), (1024, 300), (1500, 200), (5632, 900), (8192, 17000)]:
+    for n, hi in [(1, 5), (2, 1), (37, 10), (512, 60), (512, 100000), (1024, 300), (1500, 200), (5632, 900), (8192, 17000),
+                  # above 8192 the per-entry arrays leave LDS; above 16384 the sort keys too (one 16384-key tile, csrc/plan.hip)
+                  (12000, 3000), (16384, 50), (16385, 40000), (20000, 7), (30001, 2000), (32768, 1), (32768, 100000), (32768, 3)]:
         ids = rs.randint(0, hi, n)
         order, seg_start, uniq, inverse, nseg = plan_ids(torch.as_tensor(ids, device="cuda"))
         u_ref, x_ref = so.tf_unique(ids)

@@ -63,6 +63,9 @@ python3 bench.py --large --batch 8192 --loss $l --scheme $sc --steps 100 --warmu
 done; done
 python3 bench.py --large --batch 4096 --loss log-loss --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b4096.json
 python3 bench.py --large --batch 16384 --loss log-loss --steps 50 --warmup 5 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b16384.json
+# the 32768-entry plan (sort keys in global memory): config [3]'s "b >~ 16K per GPU" regime
+python3 bench.py --large --batch 32768 --steps 20 --warmup 3 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b32768.json
+python3 bench.py --large --batch 32768 --loss log-loss --steps 20 --warmup 3 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_log-loss_b32768.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_style_steps20.json
 python3 bench.py --model cnn_embedding --scheme group_neg_shared --dim 50 --filter-lens 1,3,5 --conv-dropout 0.3 --dropout 0 --cpu-seconds 6 --steps 780 2>/dev/null | tail -1 > $OUT/${TAG}_bench_cnn_embedding_default_preset_group_neg_shared.json
 NNCF_TILE_STATS=launch python3 bench.py --scheme group_neg_shared --cpu-seconds 0 --steps 1170 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_group_neg_shared_statslaunch.json
