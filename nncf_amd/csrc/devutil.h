@@ -162,6 +162,19 @@ __device__ __forceinline__ void lds_store_row_h(float* dst, int q, Row v) {
   *reinterpret_cast<f16x4*>(p + 192 + 4 * q) = l[1];
 }
 
+// ds_read_b64_tr_b16 (gfx950): the 16 lanes of a group each name 8 aligned bytes (4 fp16) of a [4 rows][16 columns] block --
+// lane t: row t / 4, columns 4 (t % 4) .. + 3, any row stride -- and lane t receives COLUMN t of the block (rows 0 .. 3).
+// Two of them are a lane's 8 consecutive k-values of a 16x16x32 MFMA B operand read from a row-major [k][n] image: what 8
+// two-byte reads and their packing did in the large-batch kernels' back-GEMM (round 5 stamps: the longest phase of a stage).
+typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ f16x8 lds_read_tr8(const _Float16* p_rows0to3, const _Float16* p_rows4to7) {
+  typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(const_cast<_Float16*>(p_rows0to3)));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(const_cast<_Float16*>(p_rows4to7)));
+  const f16x4 ha = __builtin_bit_cast(f16x4, a), hb = __builtin_bit_cast(f16x4, b);
+  return __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // both signs from the same exponential: softplus(z), sigmoid(z), softplus(-z), sigmoid(-z)
 __device__ __forceinline__ void softplus_sigmoid_both(float z, float& sp, float& sg, float& spn, float& sgn) {
   const float e = __expf(-fabsf(z));

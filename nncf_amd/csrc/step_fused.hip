@@ -794,7 +794,7 @@ constexpr int kMP = 132;   // pitch in 16-bit cells: rows 4 apart are 8 banks ap
 template <int MT, bool GROUP>
 __host__ __device__ constexpr size_t wide_lds_bytes() {
   return sizeof(float) * (16 * MT * kFDP + kFNB * kFDP + 16 * MT * kFGP + 16 * MT + 16 * MT + 8) +
-         sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4) + (GROUP ? sizeof(uint16_t) * 16 * MT * kMP : 0);
+         sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4) + (GROUP ? sizeof(uint16_t) * 16 * MT * kMP + sizeof(int) * 8 * MT : 0);
 }
 
 template <int NG, int MT>
@@ -841,6 +841,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   // order-free), and the element-wise block reads m like any other operand.
   constexpr bool CM = GROUP && USIDE;
   uint16_t* sM = reinterpret_cast<uint16_t*>(sTop + 4);   // [OWN][kMP]
+  int* sMf = reinterpret_cast<int*>(sM + OWN * kMP);       // [MT][8]: does tile (row tile, 16-column group) of this stage hold a positive?
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = tid >> 4, q = tid & 15;
@@ -947,8 +948,10 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     }
   }
   auto m_zero = [&]() {
-    if (CM)
+    if (CM) {
       for (int i = tid; i < OWN * kMP / 2; i += 512) reinterpret_cast<uint32_t*>(sM)[i] = 0u;
+      if (tid < 8 * MT) sMf[tid] = 0;
+    }
   };
   auto m_scatter = [&](int st) {   // every position of this strip's users whose item is a column of stage st
     if (!CM) return;
@@ -959,7 +962,10 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
         const int ks = sKeyStart[o], kc = sKeyCnt[o], n = kc < 0 ? -kc : kc;
         for (int t = q; t < n; t += 16) {
           const int key = kc >= 0 ? sKeys[ks + t] : pv.inverse[pu.order[ks + t]];   // (a list that did not fit the LDS: from the plan)
-          if ((key >> 7) == st) atomicAdd(reinterpret_cast<unsigned*>(sM) + ((o * kMP + (key & 127)) >> 1), 1u << (16 * (key & 1)));
+          if ((key >> 7) == st) {
+            atomicAdd(reinterpret_cast<unsigned*>(sM) + ((o * kMP + (key & 127)) >> 1), 1u << (16 * (key & 1)));
+            sMf[(o >> 4) * 8 + ((key & 127) >> 4)] = 1;
+          }
         }
       }
     }
@@ -967,16 +973,18 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   m_zero();
   __syncthreads();
   const int x = lane & 15, kq = lane >> 4;
-  float cnt_r[MT][4];
-  int ks_r[MT][4];   // the single positive column of a row (every case but the user strips of group_neg_shared)
+  // The score tiles are computed TRANSPOSED (opposite rows as the MFMA's A operand): a lane holds, per row tile, ONE own row
+  // (16 mt + x) against FOUR consecutive columns of the stage (16 wave + 4 kq + r) -- its dL/dS entries are 8 contiguous bytes
+  // of each fp16 plane of that own row (two ds_write_b64 per tile where the untransposed tile wrote eight 2-byte cells), and
+  // the per-row operands (multiplicity, positive column) are MT registers each instead of 4 MT.
+  float cnt_o[MT];
+  int ks_o[MT];   // the single positive column of the row (every case but the user strips of group_neg_shared)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * mt + 4 * kq + r;
-      cnt_r[mt][r] = sCnt[i];
-      ks_r[mt][r] = (!CM && sKeyCnt[i] > 0) ? sKeys[sKeyStart[i]] : -2;
-    }
+  for (int mt = 0; mt < MT; ++mt) {
+    const int i = 16 * mt + x;
+    cnt_o[mt] = sCnt[i];
+    ks_o[mt] = (!CM && sKeyCnt[i] > 0) ? sKeys[sKeyStart[i]] : -2;
+  }
 
   FSTAMP(3);
   const float inv_b = 1.f / (float)b;
@@ -1028,61 +1036,93 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
           for (int t = 0; t < 4; ++t) {   // acc0: hi.hi; acc1: the cross terms (times 2048)
             const f16x8 ah = __builtin_bit_cast(f16x8, fa[t]), al = __builtin_bit_cast(f16x8, fa[4 + t]);
             const f16x8 bh = __builtin_bit_cast(f16x8, fb[t]), bl = __builtin_bit_cast(f16x8, fb[4 + t]);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc1, 0, 0, 0);   // (A = the opposite rows: D[opposite][own])
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc1, 0, 0, 0);
           }
           return acc0 + acc1 * (1.f / kHLoScale);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          NNCF_MFMA4(fa[t], fb[t], acc0, acc1);
+          NNCF_MFMA4(fb[t], fa[t], acc0, acc1);
         }
         return acc0 + acc1;
       };
-      const int j = 16 * wave + x;
-      const int okey = sOppKey[j];
-      const bool cvalid = st * kFNB + j < n_opp;
+      const int jq = 16 * wave + 4 * kq;   // this lane's columns of the stage: jq + r
+      const int4 ok4 = *reinterpret_cast<const int4*>(sOppKey + jq);
+      const int okey[4] = {ok4.x, ok4.y, ok4.z, ok4.w};
+      const int nleft = n_opp - st * kFNB - jq;   // column jq + r is real iff r < nleft
       f32x4 acc = s_one(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 nxt = acc;
         if (mt + 1 < MT) nxt = s_one(mt + 1);
+        const int i = 16 * mt + x;
+        const float c = cnt_o[mt];
+        // skip-gram: a 16 x 16 tile without a positive and without columns past the list (all but ~3 % of them at b = 8,192)
+        // is weight x softplus / weight x sigmoid of the score and nothing else -- no positive's term, no validity select,
+        // one sign of the pair.  Wave-uniform branch.  (A padded own row has count 0: its terms are 0 x finite.)
+        bool plain = false;
+        if (LOSS == NNCF_LOSS_SKIP_GRAM) {
+          bool anyp;
+          if (CM) anyp = sMf[mt * 8 + wave] != 0;
+          else anyp = __ballot((ks_o[mt] == okey[0]) | (ks_o[mt] == okey[1]) | (ks_o[mt] == okey[2]) | (ks_o[mt] == okey[3])) != 0ull;
+          plain = !anyp && st * kFNB + 16 * wave + 15 < n_opp;
+        }
+        float hv[4];
+        if (plain) {
+          const float cw = c * wneg, cg = cw * (H16 ? gscale : inv_b);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * mt + 4 * kq + r;
-          const float sc = acc[r];
-          const float c = cnt_r[mt][r];
-          const float m = CM ? (float)sM[i * kMP + j] : (ks_r[mt][r] == okey) ? 1.f : 0.f;
-          float l, h;
-          if (LOSS == NNCF_LOSS_SKIP_GRAM) {
-            // label -1 off the positive: softplus(s); label +1: softplus(-s); one exponential for both, no branch
-            // (objectives.py:99-112)
-            float sp, sg, spn, sgn;
-            softplus_sigmoid_both(sc, sp, sg, spn, sgn);
-            l = (c - m) * wneg * sp + m * spn;
-            h = (c - m) * wneg * sg - m * sgn;
-          } else {
-            l = (c - m) * wneg * sc * sc + m * (sc - 1.f) * (sc - 1.f);
-            h = 2.f * ((c - m) * wneg * sc + m * (sc - 1.f));
+          for (int r = 0; r < 4; ++r) {
+            float sp, sg;
+            softplus_sigmoid(acc[r], sp, sg);
+            lsum = fmaf(cw, sp, lsum);
+            hv[r] = cg * sg;
           }
-          if (!cvalid || c == 0.f) {
-            l = 0.f;
-            h = 0.f;
+        } else {
+          uint2 mw = make_uint2(0u, 0u);
+          if (CM) mw = *reinterpret_cast<const uint2*>(sM + i * kMP + jq);   // four 16-bit counts
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sc = acc[r];
+            const float m = CM ? (float)(((r < 2 ? mw.x : mw.y) >> (16 * (r & 1))) & 0xFFFFu) : (ks_o[mt] == okey[r]) ? 1.f : 0.f;
+            float l, h;
+            if (LOSS == NNCF_LOSS_SKIP_GRAM) {
+              // label -1 off the positive: softplus(s); label +1: softplus(-s); one exponential for both, no branch
+              // (objectives.py:99-112)
+              float sp, sg, spn, sgn;
+              softplus_sigmoid_both(sc, sp, sg, spn, sgn);
+              l = (c - m) * wneg * sp + m * spn;
+              h = (c - m) * wneg * sg - m * sgn;
+            } else {
+              l = (c - m) * wneg * sc * sc + m * (sc - 1.f) * (sc - 1.f);
+              h = 2.f * ((c - m) * wneg * sc + m * (sc - 1.f));
+            }
+            if (r >= nleft || c == 0.f) {
+              l = 0.f;
+              h = 0.f;
+            }
+            hv[r] = h * (H16 ? gscale : inv_b);
+            lsum += l;
           }
-          if (H16) {   // the tile of dL/dS as two fp16 planes [hi j = 0..127][lo j = 0..127] per own row, times gscale
-            _Float16 gh, gl;
-            split_h(h * gscale, gh, gl);
-            _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kFGP);
-            pg[j] = gh;
-            pg[128 + j] = gl;
+        }
+        if (H16) {   // the tile of dL/dS as two fp16 planes [hi j = 0..127][lo j = 0..127] per own row, times gscale
+          f16x4 gh, gl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            _Float16 a_, b_;
+            split_h(hv[r], a_, b_);
+            gh[r] = a_;
+            gl[r] = b_;
             // mse's dL/dS grows with the score (skip-gram's is a multiplicity times a sigmoid): past fp16's range the plane holds
             // inf and the tables would turn NaN behind a finite loss -- inf - inf makes THIS step's loss NaN instead (0 otherwise)
-            if (LOSS != NNCF_LOSS_SKIP_GRAM) l += (float)gh - (float)gh;
-          } else {
-            sG[i * kFGP + j] = h * inv_b;
+            if (LOSS != NNCF_LOSS_SKIP_GRAM) lsum += (float)a_ - (float)a_;
           }
-          lsum += l;
+          _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kFGP);
+          *reinterpret_cast<f16x4*>(pg + jq) = gh;
+          *reinterpret_cast<f16x4*>(pg + 128 + jq) = gl;
+        } else {
+          *reinterpret_cast<float4*>(sG + i * kFGP + jq) = make_float4(hv[0], hv[1], hv[2], hv[3]);
         }
         if (mt + 1 < MT && LOSS == NNCF_LOSS_SKIP_GRAM) {   // (mse has a third of the element-wise work: forcing this interleave on it
 #pragma unroll                                           // only lengthens live ranges -- 10-21 registers spilled at MT = 4)
@@ -1109,16 +1149,14 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
     if (back_wave && H16) {
       // dOwn[own][col] += G[own][j] . Opp[j][col] over the stage's 128 opposite rows in four k-steps of 32: the lane (col x, kq) gathers
       // column 16 wave + x of rows 32 t + 8 kq + e (hi and lo planes: 16 two-byte reads); accD0: hi.hi, accD1: the cross terms
-      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + 16 * wave + x;
+      // (transpose reads: lane x of group kq names row 8 kq + x / 4 [+ 4], columns 16 wave + 4 (x % 4) .. + 3 and receives column
+      // 16 wave + x of rows 8 kq .. + 3 [+ 4] -- devutil.h lds_read_tr8)
+      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + (size_t)(8 * kq + (x >> 2)) * (2 * kFDP) + 16 * wave + 4 * (x & 3);
 #pragma unroll
       for (int t = 0; t < kFNB / 32; ++t) {
-        f16x8 vh, vl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const _Float16* pr = pcol + (size_t)(32 * t + 8 * kq + e) * (2 * kFDP);
-          vh[e] = pr[0];
-          vl[e] = pr[128];
-        }
+        const _Float16* pr = pcol + (size_t)(32 * t) * (2 * kFDP);
+        const f16x8 vh = lds_read_tr8(pr, pr + 4 * (2 * kFDP));
+        const f16x8 vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kFDP));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kFGP + 4 * kq);

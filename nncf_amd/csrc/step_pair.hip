@@ -404,16 +404,14 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     }
     load_ids(st + 2, idA, keyA, dA);
     if (back_wave && update && H16) {
-      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + 16 * wave + x;
+      // the stage's rows as the MFMA's [k][n] operand by transpose reads (devutil.h lds_read_tr8): lane x of group kq names row
+      // 8 kq + x / 4 [+ 4], columns 16 wave + 4 (x % 4) .. + 3 and receives column 16 wave + x of rows 8 kq .. + 3 [+ 4]
+      const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + (size_t)(8 * kq + (x >> 2)) * (2 * kPDP) + 16 * wave + 4 * (x & 3);
 #pragma unroll
       for (int t = 0; t < kPNB / 32; ++t) {
-        f16x8 vh, vl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const _Float16* pr = pcol + (size_t)(32 * t + 8 * kq + e) * (2 * kPDP);
-          vh[e] = pr[0];
-          vl[e] = pr[128];
-        }
+        const _Float16* pr = pcol + (size_t)(32 * t) * (2 * kPDP);
+        const f16x8 vh = lds_read_tr8(pr, pr + 4 * (2 * kPDP));
+        const f16x8 vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kPDP));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kPGP + 4 * kq);
