@@ -175,6 +175,20 @@ __device__ __forceinline__ f16x8 lds_read_tr8(const _Float16* p_rows0to3, const 
   return __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// The same in base 2, for a score that arrives as y = z log2(e) (the large-batch skip-gram kernel stages its own rows times
+// log2 e): sigmoid(z) and softplus(z) / ln 2 -- v_exp_f32 and v_log_f32 ARE base-2, the two constant multiplies disappear and
+// the caller multiplies its loss sum by ln 2 once.
+__device__ __forceinline__ void softplus2_sigmoid_both(float y, float& sp2, float& sg, float& spn2, float& sgn) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(y));
+  const float u = 1.f + e;
+  const float r = __builtin_amdgcn_rcpf(u);
+  const float lg = __builtin_amdgcn_logf(u);
+  sp2 = fmaxf(y, 0.f) + lg;
+  spn2 = fmaxf(-y, 0.f) + lg;
+  sg = y >= 0.f ? r : e * r;
+  sgn = y >= 0.f ? e * r : r;
+}
+
 // both signs from the same exponential: softplus(z), sigmoid(z), softplus(-z), sigmoid(-z)
 __device__ __forceinline__ void softplus_sigmoid_both(float z, float& sp, float& sg, float& spn, float& sgn) {
   const float e = __expf(-fabsf(z));

@@ -920,6 +920,9 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
         const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
         ss = row16_sum(row_dot_partial(raw, raw));
         hat = (USIDE ? NU : NV) ? row_scale(raw, inv_norm(ss)) : raw;
+        // skip-gram: the own rows are staged times log2(e) -- the score tile IS y = s log2 e, what v_exp_f32 / v_log_f32 take
+        // (only the S tiles read these rows: the finalize re-reads the raw row)
+        if (LOSS == NNCF_LOSS_SKIP_GRAM) hat = row_scale(hat, 1.44269504088896341f);
         kcnt = cnt;
         if (q == 0) {
           kstart = atomicAdd(&sTop[0], cnt);
@@ -1071,14 +1074,21 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
         }
         float hv[4];
         if (plain) {
+          // the lane's four elements share the own row, so its weight: softplus summed as log2 of the PRODUCT of the four
+          // (1 + e) in [1, 2] (one v_log_f32 per tile) + the sum of max(y, 0); base 2 throughout (ln 2 at the end)
           const float cw = c * wneg, cg = cw * (H16 ? gscale : inv_b);
+          float prod = 1.f, zs = 0.f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float sp, sg;
-            softplus_sigmoid(acc[r], sp, sg);
-            lsum = fmaf(cw, sp, lsum);
-            hv[r] = cg * sg;
+            const float y = acc[r];
+            const float e = __builtin_amdgcn_exp2f(-fabsf(y));
+            const float u = 1.f + e;
+            const float rc = __builtin_amdgcn_rcpf(u);
+            hv[r] = cg * (y >= 0.f ? rc : e * rc);
+            prod *= u;
+            zs += fmaxf(y, 0.f);
           }
+          lsum = fmaf(cw, __builtin_amdgcn_logf(prod) + zs, lsum);
         } else {
           uint2 mw = make_uint2(0u, 0u);
           if (CM) mw = *reinterpret_cast<const uint2*>(sM + i * kMP + jq);   // four 16-bit counts
@@ -1091,7 +1101,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
               // label -1 off the positive: softplus(s); label +1: softplus(-s); one exponential for both, no branch
               // (objectives.py:99-112)
               float sp, sg, spn, sgn;
-              softplus_sigmoid_both(sc, sp, sg, spn, sgn);
+              softplus2_sigmoid_both(sc, sp, sg, spn, sgn);   // (sc = s log2 e; l in units of ln 2)
               l = (c - m) * wneg * sp + m * spn;
               h = (c - m) * wneg * sg - m * sgn;
             } else {
@@ -1204,7 +1214,8 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   if (USIDE && tid == 0) {
     float reg = 0.f;
     for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
-    const float l = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+    float l = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
+    if (LOSS == NNCF_LOSS_SKIP_GRAM) l *= 0.693147180559945309f;   // the element-wise block summed softplus / ln 2
     f.loss_part[blk] = l * inv_b + a.u_reg * reg * inv_b;
   }
   if (!update) return;
