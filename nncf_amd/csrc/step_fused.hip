@@ -1167,14 +1167,21 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
         const _Float16* pr = pcol + (size_t)(32 * t) * (2 * kFDP);
         const f16x8 vh = lds_read_tr8(pr, pr + 4 * (2 * kFDP));
         const f16x8 vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kFDP));
+        // product by product over the MT row tiles: an accumulator's next use is MT MFMAs away (tile by tile, accD1's two
+        // products sat one MFMA apart: the second waited for the first's result)
+        f16x8 gh[MT], gl[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kFGP + 4 * kq);
-          const f16x8 gh = __builtin_bit_cast(f16x8, pg4[4 * t]), gl = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
-          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vl, accD1[mt], 0, 0, 0);
-          accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vh, accD0[mt], 0, 0, 0);
-          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, vh, accD1[mt], 0, 0, 0);
+          gh[mt] = __builtin_bit_cast(f16x8, pg4[4 * t]);
+          gl[mt] = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vl, accD1[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vh, accD0[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mt], vh, accD1[mt], 0, 0, 0);
       }
     } else if (back_wave) {
       const float* pbv = sOpp + (4 * kq) * kFDP + 16 * wave + x;
