@@ -60,11 +60,13 @@ __device__ __forceinline__ void lds_store_row_p(float* dst, int q, Row v) {
   C1 = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (B).w, C1, 0, 0, 0)
 
 // d loss / dS of one off-positive element (x = anchor - score), without the 1 / (b N) of K.mean
+// (log-loss in the strip kernel below: x arrives as (anchor - score) gamma log2(e) -- the scaling sits in the staged rows and
+// anchors -- and l leaves in units of ln 2)
 template <int LOSS>
 __device__ __forceinline__ float pair_h(float x, float gamma) {
   if (LOSS == NNCF_LOSS_LOG_LOSS) {   // -log sigmoid(gamma x): objectives.py:97,200
-    float sp, sg;
-    softplus_sigmoid(-gamma * x, sp, sg);
+    float sp, sg, spn, sgn;
+    softplus2_sigmoid_both(-x, sp, sg, spn, sgn);
     return gamma * sg;
   }
   return (gamma - x > 0.f) ? 1.f : 0.f;   // max(0, gamma - x): objectives.py:92-93,195-197
@@ -72,8 +74,8 @@ __device__ __forceinline__ float pair_h(float x, float gamma) {
 template <int LOSS>
 __device__ __forceinline__ void pair_lh(float x, float gamma, float& l, float& h) {
   if (LOSS == NNCF_LOSS_LOG_LOSS) {
-    float sp, sg;
-    softplus_sigmoid(-gamma * x, sp, sg);
+    float sp, sg, spn, sgn;
+    softplus2_sigmoid_both(-x, sp, sg, spn, sgn);
     l = sp;
     h = gamma * sg;
   } else {
@@ -149,7 +151,9 @@ __device__ __forceinline__ bool pair_in_domain(const StepArgs& a, const PairArgs
   if (!(__int_as_float(p.dom[0]) < 3.0e38f && __int_as_float(p.dom[1]) < 3.0e38f)) return false;   // inf / NaN rows: the fp32 pipe reports them
   const float cmax = (float)max(p.dom[2], 1);
   const float hmax = cmax * (LOSS == NNCF_LOSS_LOG_LOSS ? fmaxf(a.gamma, 1.f) : 1.f);
-  return umax < 32768.f && vmax < 32768.f && hmax < 60000.f;
+  // log-loss stages its own rows times gamma log2(e) (pair_body): the planes hold THAT
+  const float k2 = LOSS == NNCF_LOSS_LOG_LOSS ? fmaxf(fabsf(a.gamma) * 1.44269504f, 1.f) : 1.f;
+  return umax * k2 < 32768.f && vmax * k2 < 32768.f && hmax < 60000.f;
 }
 
 // POS (this side streams by position and owns the loss and the T sums): USIDE for neg_shared, the item side for group.
@@ -258,6 +262,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
         const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
         ss = row16_sum(row_dot_partial(raw, raw));
         hat = norm_own ? row_scale(raw, inv_norm(ss)) : raw;
+        // log-loss: own rows (and every anchor) times gamma log2(e): score - anchor IS the base-2 argument y of
+        // -log sigmoid(gamma (anchor - score)) = ln 2 * log2(1 + 2^y) -- what v_exp_f32 / v_log_f32 take (only the S tiles read these rows)
+        if (LOSS == NNCF_LOSS_LOG_LOSS) hat = row_scale(hat, a.gamma * 1.44269504088896341f);
       }
       if (H16) lds_store_row_h(sOwn + o * kPDP, q, hat);   // two fp16 planes per row (devutil.h): the products run on the fp16 pipe
       else lds_store_row_p(sOwn + o * kPDP, q, hat);
@@ -283,14 +290,15 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
   // per own row, read from LDS where it is used (broadcast reads; 32 registers less than holding them: no scratch at
   // MT = 4): POS: multiplicity and rank; else the own position's anchor (NaN: no position in this slot) and its key
   if (!POS) {
-    if (tid < OWN) sCnt[tid] = sCnt[tid] > 0.f ? sAnch[tid] : __builtin_nanf("");
+    if (tid < OWN) sCnt[tid] = sCnt[tid] > 0.f ? sAnch[tid] * (LOSS == NNCF_LOSS_LOG_LOSS ? a.gamma * 1.44269504088896341f : 1.f) : __builtin_nanf("");
     __syncthreads();
   }
   const float inv_m = 1.f / ((float)b * (float)n_items);   // K.mean over the b x N matrix
   const float gamma = a.gamma;
   // the positive element's own loss term: -log sigmoid(0) (log-loss); max(0, gamma - 0) for group's max-margin, none
   // for neg_shared's (objectives.py:93 exempts the diagonal, :195-197 does not)
-  const float l_pos = LOSS == NNCF_LOSS_LOG_LOSS ? 0.6931471805599453f : (GROUP ? fmaxf(gamma, 0.f) : 0.f);
+  // (log-loss sums in units of ln 2 -- base-2 logarithms -- and multiplies once at the end: its positive's term is 1)
+  const float l_pos = LOSS == NNCF_LOSS_LOG_LOSS ? 1.f : (GROUP ? fmaxf(gamma, 0.f) : 0.f);
   f32x4 accD0[MT], accD1[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -309,7 +317,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       else lds_store_row_p(sOpp + (g + 32 * e) * kPDP, q, r);
       if (q == 0) {
         sOppKey[g + 32 * e] = kcur[e];
-        if (POS) sOppD[g + 32 * e] = dcur[e];
+        if (POS) sOppD[g + 32 * e] = dcur[e] * (LOSS == NNCF_LOSS_LOG_LOSS ? gamma * 1.44269504088896341f : 1.f);
       }
     }
     __syncthreads();
@@ -331,67 +339,122 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
           for (int t = 0; t < 4; ++t) {
             const f16x8 ah = __builtin_bit_cast(f16x8, fa[t]), al = __builtin_bit_cast(f16x8, fa[4 + t]);
             const f16x8 bh = __builtin_bit_cast(f16x8, fb[t]), bl = __builtin_bit_cast(f16x8, fb[4 + t]);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc1, 0, 0, 0);   // (A = the streamed rows: D[streamed][own])
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc1, 0, 0, 0);
           }
           return acc0 + acc1 * (1.f / kHLoScale);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          NNCF_PMFMA4(fa[t], fb[t], acc0, acc1);
+          NNCF_PMFMA4(fb[t], fa[t], acc0, acc1);
         }
         return acc0 + acc1;
       };
-      const int j = 16 * wave + x;
-      const int okey = sOppKey[j];
-      const float od = POS ? sOppD[j] : 0.f;
-      const bool cvalid = st * kPNB + j < n_opp;
-      float tsum = 0.f;
+      // The score tiles are computed TRANSPOSED (as step_fused.hip wide_body): a lane holds ONE own row per row tile (16 mt + x)
+      // against FOUR consecutive streamed columns (16 wave + 4 kq + r) -- the own row's multiplicity / anchor and key are two LDS
+      // reads per tile (not per element), the dL/dS entries 8 contiguous bytes of each plane.
+      const int jq = 16 * wave + 4 * kq;
+      const int4 ok4 = *reinterpret_cast<const int4*>(sOppKey + jq);
+      const int okey[4] = {ok4.x, ok4.y, ok4.z, ok4.w};
+      const float4 od4 = POS ? *reinterpret_cast<const float4*>(sOppD + jq) : zero4();
+      const float od[4] = {od4.x, od4.y, od4.z, od4.w};
+      const int nleft = n_opp - st * kPNB - jq;   // column jq + r is real iff r < nleft
+      float tsum[4] = {0.f, 0.f, 0.f, 0.f};
       f32x4 acc = s_one(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 nxt = acc;
         if (mt + 1 < MT) nxt = s_one(mt + 1);
+        const int i = 16 * mt + x;
+        const float ci = sCnt[i];   // POS: the own row's multiplicity; else the own position's anchor (NaN: no position in this slot)
+        const int ki = sKey[i];
+        float hv[4];
+        // a tile without a positive / exempt element, without columns past the list and (by-position side) without empty
+        // slots -- all but a few per cent -- is weight x f(score - anchor) and nothing else.  Wave-uniform branch.
+        const bool special = (ki == okey[0]) | (ki == okey[1]) | (ki == okey[2]) | (ki == okey[3]) | (!POS && ci != ci);
+        const bool plain = __ballot(special) == 0ull && st * kPNB + 16 * wave + 15 < n_opp;
+        if (plain) {
+          if (LOSS == NNCF_LOSS_LOG_LOSS) {
+            // y = (score - anchor) gamma log2 e (the scaling is in the staged rows and anchors): sigmoid = 1 / (1 + 2^-y) by the
+            // stable form, softplus / ln 2 = max(y, 0) + log2(1 + 2^-|y|); the lane's four elements share their weight, so the
+            // logarithm is taken of the PRODUCT of the four (1 + e) in [1, 2]: one v_log_f32 per tile
+            const float cg = POS ? ci * gamma : gamma;
+            float prod = 1.f, zs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * mt + 4 * kq + r;
-          const float sc = acc[r];
-          float h = 0.f;
-          if (POS) {
-            const float c = sCnt[i];
-            const float m = (sKey[i] == okey) ? 1.f : 0.f;
-            float l;
-            pair_lh<LOSS>(od - sc, gamma, l, h);
-            l = (c - m) * l + m * l_pos;
-            h = (c - m) * h;
-            if (!cvalid || c == 0.f) {
-              l = 0.f;
-              h = 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const float y = acc[r] - (POS ? od[r] : ci);
+              const float e = __builtin_amdgcn_exp2f(-fabsf(y));
+              const float u = 1.f + e;
+              const float rc = __builtin_amdgcn_rcpf(u);
+              const float h = cg * (y >= 0.f ? rc : e * rc);
+              if (POS) {
+                prod *= u;
+                zs += fmaxf(y, 0.f);
+                tsum[r] += h;
+              }
+              hv[r] = H16 ? h : h * inv_m;
             }
-            lsum += l;
-            tsum += h;
+            if (POS) lsum = fmaf(ci, __builtin_amdgcn_logf(prod) + zs, lsum);
           } else {
-            const float an = sCnt[i];
-            h = pair_h<LOSS>(an - sc, gamma);
-            if (!cvalid || an != an || sKey[i] == okey) h = 0.f;   // an != an: no own position in this slot
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float act = gamma - ((POS ? od[r] : ci) - acc[r]);   // max(0, gamma - x): objectives.py:92-93,195-197
+              const float h = act > 0.f ? (POS ? ci : 1.f) : 0.f;
+              if (POS) {
+                lsum = fmaf(ci, fmaxf(act, 0.f), lsum);
+                tsum[r] += h;
+              }
+              hv[r] = H16 ? h : h * inv_m;
+            }
           }
-          if (H16) {   // dL/dS unscaled (a multiplicity times a sigmoid / 0 or 1) as two fp16 planes; 1 / (b N) at the output
-            _Float16 gh, gl;
-            split_h(h, gh, gl);
-            _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kPGP);
-            pg[j] = gh;
-            pg[128 + j] = gl;
-          } else {
-            sG[i * kPGP + j] = h * inv_m;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sc = acc[r];
+            float h = 0.f;
+            if (POS) {
+              const float m = (ki == okey[r]) ? 1.f : 0.f;
+              float l;
+              pair_lh<LOSS>(od[r] - sc, gamma, l, h);
+              l = (ci - m) * l + m * l_pos;
+              h = (ci - m) * h;
+              if (r >= nleft || ci == 0.f) {
+                l = 0.f;
+                h = 0.f;
+              }
+              lsum += l;
+              tsum[r] += h;
+            } else {
+              h = pair_h<LOSS>(ci - sc, gamma);
+              if (r >= nleft || ci != ci || ki == okey[r]) h = 0.f;
+            }
+            hv[r] = H16 ? h : h * inv_m;   // H16: dL/dS unscaled (a multiplicity times a sigmoid / 0 or 1); 1 / (b N) at the output
           }
+        }
+        if (H16) {
+          f16x4 gh, gl;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            _Float16 a_, b_;
+            split_h(hv[r], a_, b_);
+            gh[r] = a_;
+            gl[r] = b_;
+          }
+          _Float16* pg = reinterpret_cast<_Float16*>(sG + i * kPGP);
+          *reinterpret_cast<f16x4*>(pg + jq) = gh;
+          *reinterpret_cast<f16x4*>(pg + 128 + jq) = gl;
+        } else {
+          *reinterpret_cast<float4*>(sG + i * kPGP + jq) = make_float4(hv[0], hv[1], hv[2], hv[3]);
         }
         acc = nxt;
       }
-      if (POS) {   // this strip's part of the column (row) sum of h at the streamed position: the four row quarters
-        tsum += __shfl_xor(tsum, 16);
-        tsum += __shfl_xor(tsum, 32);
-        if (kq == 0 && cvalid) p.t_part[(int64_t)blk * b + st * kPNB + j] = tsum * inv_m;
+      if (POS) {   // this strip's part of the column (row) sum of h at the streamed positions: over the 16 own rows of a lane group
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = row16_sum(tsum[r]);   // four DPP adds
+          if (x == 0 && r < nleft) p.t_part[(int64_t)blk * b + st * kPNB + jq + r] = t * inv_m;
+        }
       }
     }
     __syncthreads();
@@ -457,7 +520,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
     float reg = 0.f;
     for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
     float l = 0.f;
-    if (POS) l = (((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]))) * inv_m;
+    if (POS) l = (((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]))) * inv_m *
+                 (LOSS == NNCF_LOSS_LOG_LOSS ? 0.693147180559945309f : 1.f);
     // utilities.py:122-135 over the b rows: by the user strips
     p.loss_part[(USIDE ? 0 : gu) + blk] = l + (USIDE ? a.u_reg * reg * inv_b : 0.f);
   }
