@@ -1062,18 +1062,28 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
         if (mt + 1 < MT) nxt = s_one(mt + 1);
         const int i = 16 * mt + x;
         const float c = cnt_o[mt];
-        // skip-gram: a 16 x 16 tile without a positive and without columns past the list (all but ~3 % of them at b = 8,192)
-        // is weight x softplus / weight x sigmoid of the score and nothing else -- no positive's term, no validity select,
-        // one sign of the pair.  Wave-uniform branch.  (A padded own row has count 0: its terms are 0 x finite.)
+        // a 16 x 16 tile without a positive and without columns past the list (all but ~3 % of them at b = 8,192) is
+        // weight x softplus / weight x sigmoid of the score (skip-gram; mse: weight x s^2 / 2 weight x s) and nothing else -- no
+        // positive's term, no validity select, one sign of the pair.  Wave-uniform branch.  (A padded own row has count 0: its
+        // terms are 0 x finite.)
         bool plain = false;
-        if (LOSS == NNCF_LOSS_SKIP_GRAM) {
+        {
           bool anyp;
           if (CM) anyp = sMf[mt * 8 + wave] != 0;
           else anyp = __ballot((ks_o[mt] == okey[0]) | (ks_o[mt] == okey[1]) | (ks_o[mt] == okey[2]) | (ks_o[mt] == okey[3])) != 0ull;
           plain = !anyp && st * kFNB + 16 * wave + 15 < n_opp;
         }
         float hv[4];
-        if (plain) {
+        if (plain && LOSS != NNCF_LOSS_SKIP_GRAM) {   // mse off the positives: w s^2, dL/dS = 2 w s
+          const float cw = c * wneg, cg = 2.f * cw * (H16 ? gscale : inv_b);
+          float q2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            q2 = fmaf(acc[r], acc[r], q2);
+            hv[r] = cg * acc[r];
+          }
+          lsum = fmaf(cw, q2, lsum);
+        } else if (plain) {
           // the lane's four elements share the own row, so its weight: softplus summed as log2 of the PRODUCT of the four
           // (1 + e) in [1, 2] (one v_log_f32 per tile) + the sum of max(y, 0); base 2 throughout (ln 2 at the end)
           const float cw = c * wneg, cg = cw * (H16 ? gscale : inv_b);
