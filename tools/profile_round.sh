@@ -97,6 +97,8 @@ python3 tools/isa_resources.py --out $OUT/${TAG}_isa_resources.txt > /dev/null
 for l in skip-gram mse; do
 python3 bench.py --large --batch 8192 --scheme group_neg_shared --loss $l --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_group_neg_shared_${l}_b8192.json
 done
+python3 bench.py --large --batch 8192 --loss mse --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_mse_b8192.json
+python3 tools/fused_timing.py skip-gram 8192 128 2>/dev/null | tail -19 > $OUT/${TAG}_wide_phase_stamps.txt
 run_prof large_mf_group_b8192_kernel_trace "--stats" --large --batch 8192 --scheme group_neg_shared --loss skip-gram --steps 40 --warmup 8 --cpu-seconds 0 --profile-launches 10
 NNCF_WIDE_F16SPLIT=force python3 bench.py --large --batch 8192 --steps 100 --warmup 10 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_large_mf_neg_shared_b8192_unguarded.json
 NNCF_DP_NATIVE=0 NNCF_FORCE_SHARDED=1 python3 bench.py --steps 1170 --cpu-seconds 0 $B 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_data_parallel_world1_pythonloop.json
