@@ -1031,9 +1031,9 @@ def main():
                 r["peak"] = PEAK_F16_MFMA_TFLOPS
                 if r.get("achieved") is not None:
                     r["frac"] = r["achieved"] / PEAK_F16_MFMA_TFLOPS
-                for k in ("frac_uncorrected_bracket", "frac_empty_bracket_subtracted", "frac_profiles"):
-                    if r.get(k) is not None:
-                        r[k] = r[k] * PEAK_F32_MFMA_TFLOPS / PEAK_F16_MFMA_TFLOPS
+                for fkey in ("frac_uncorrected_bracket", "frac_empty_bracket_subtracted", "frac_profiles"):
+                    if r.get(fkey) is not None:
+                        r[fkey] = r[fkey] * PEAK_F32_MFMA_TFLOPS / PEAK_F16_MFMA_TFLOPS
                 issued = 4.0 * r["algorithmic_per_launch"]          # 8/6 (S recomputed) x 3 piece products
                 r["issued_f16_tflops"] = issued / (r["kernel_ms"] * 1e-3) / 1e12
                 r["frac_issued_of_f16_mfma_peak"] = r["issued_f16_tflops"] / PEAK_F16_MFMA_TFLOPS
