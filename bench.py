@@ -353,6 +353,27 @@ def emit(line):
     print(json.dumps(line), flush=True)
 
 
+def price_on_f16_pipe(r, split_on):
+    """Large-batch kernels (WIDE_KERNELS): the products run on the f16 matrix pipe (three f16 MFMAs per fp32-equivalent product):
+    `peak` is THAT pipe's dense peak and `frac` the algorithmic (fp32-equivalent) flop against it.  Rounds 2-4 priced the same
+    algorithmic flop against the fp32-MFMA peak: kept as frac_of_fp32_mfma_peak (round-comparable; above 0.75 = 6/8 of it the fp32
+    pipe could not have done it at all, and since round 5 it reaches 1); what the pipe is actually asked for is named too."""
+    r["pipe"] = ("f16 MFMA: 3 v_mfma_f32_16x16x32_f16 per fp32-equivalent 16x16x32 product (hi.hi + (hi.lo + lo.hi) / 2048), fp32 "
+                 "accumulate" if split_on else "f32 MFMA (NNCF_WIDE_F16SPLIT=0)")
+    if not split_on:
+        return
+    r["frac_of_fp32_mfma_peak"] = r.get("frac")
+    r["peak"] = PEAK_F16_MFMA_TFLOPS
+    if r.get("achieved") is not None:
+        r["frac"] = r["achieved"] / PEAK_F16_MFMA_TFLOPS
+    for fkey in ("frac_uncorrected_bracket", "frac_empty_bracket_subtracted", "frac_profiles"):
+        if r.get(fkey) is not None:
+            r[fkey] = r[fkey] * PEAK_F32_MFMA_TFLOPS / PEAK_F16_MFMA_TFLOPS
+    issued = 4.0 * r["algorithmic_per_launch"]          # 8/6 (S recomputed) x 3 piece products
+    r["issued_f16_tflops"] = issued / (r["kernel_ms"] * 1e-3) / 1e12
+    r["frac_issued_of_f16_mfma_peak"] = r["issued_f16_tflops"] / PEAK_F16_MFMA_TFLOPS
+
+
 def roof_entry(name, bound, work, what, raw_ms, ov_ms, launches, rp_ms=None):
     """roofline object of one kernel from THIS run's HIP-event bracket: `kernel_ms` = mean bracket of its launches on
     the launch stream minus the mean EMPTY bracket (two event records back to back, measured in the same pass: the
@@ -671,6 +692,8 @@ def main_sharded(args, conf, rank, world, local_rank):
     work = 6.0 * rows * b * d
     roof = roof_entry(name, "mfma", work, "6*rows*b*d flop (S, G.V, G^T.U) of this rank's %d x %d block of the score matrix; the kernel "
                       "issues 8*rows*b*d (S recomputed by the item pass)" % (rows, b), raw_ms, ov_ms, launches) if launches else None
+    if roof and name in WIDE_KERNELS and roof.get("kernel_ms"):
+        price_on_f16_pipe(roof, os.environ.get("NNCF_WIDE_F16SPLIT", "1") != "0")
     cpu = None
     if rank == 0 and args.cpu_seconds > 0 and not args.large:
         rs2 = np.random.RandomState(5)     # timing only: tables of the global shape, rank 0's batches
@@ -1020,23 +1043,7 @@ def main():
     split_on = os.environ.get("NNCF_WIDE_F16SPLIT", "1") != "0"
     for r in roofs:
         if r.get("kernel") in WIDE_KERNELS and r.get("kernel_ms"):
-            # The products run on the f16 matrix pipe (three f16 MFMAs per fp32-equivalent product): `peak` is THAT pipe's dense
-            # peak and `frac` the algorithmic (fp32-equivalent) flop against it.  Rounds 2-4 priced the same algorithmic flop
-            # against the fp32-MFMA peak: kept as frac_of_fp32_mfma_peak (round-comparable; above 0.75 = 6/8 of it the fp32 pipe
-            # could not have done it at all, and since round 5 it passes 1); what the pipe is actually asked for is named too.
-            r["pipe"] = ("f16 MFMA: 3 v_mfma_f32_16x16x32_f16 per fp32-equivalent 16x16x32 product (hi.hi + (hi.lo + lo.hi) / 2048), fp32 "
-                         "accumulate" if split_on else "f32 MFMA (NNCF_WIDE_F16SPLIT=0)")
-            if split_on:
-                r["frac_of_fp32_mfma_peak"] = r.get("frac")
-                r["peak"] = PEAK_F16_MFMA_TFLOPS
-                if r.get("achieved") is not None:
-                    r["frac"] = r["achieved"] / PEAK_F16_MFMA_TFLOPS
-                for fkey in ("frac_uncorrected_bracket", "frac_empty_bracket_subtracted", "frac_profiles"):
-                    if r.get(fkey) is not None:
-                        r[fkey] = r[fkey] * PEAK_F32_MFMA_TFLOPS / PEAK_F16_MFMA_TFLOPS
-                issued = 4.0 * r["algorithmic_per_launch"]          # 8/6 (S recomputed) x 3 piece products
-                r["issued_f16_tflops"] = issued / (r["kernel_ms"] * 1e-3) / 1e12
-                r["frac_issued_of_f16_mfma_peak"] = r["issued_f16_tflops"] / PEAK_F16_MFMA_TFLOPS
+            price_on_f16_pipe(r, split_on)
     roof = roofs[0]
     roof["traffic"] = measured_traffic(args, conf, d, roof["kernel"])
 
