@@ -213,6 +213,44 @@ def test_data_parallel_replica_world1_equals_plain_step(model, optimizer):
     np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("model", ["basic_embedding", "cnn_embedding"])
+def test_data_parallel_replica_with_c_reg_and_a_dense_tail_variant(model):
+    """The gradient-export road of round 5's fidelity items: conf.c_reg (the word kernel's tail adds the regulariser's share to
+    the exported row, the loss carries the term) and item_dense_transform = tanh + dropout 0.2 (the materialised item block;
+    the backward starts from dL/dE * mask * act') through HipTowerReplica + DataParallelTower == the plain in-place step."""
+    from nncf_amd import synthetic
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    from nncf_amd.sharded import DataParallelTower, HipTowerReplica
+    data = synthetic.make_citeulike_like(users=300, items=260, train_links=5000, seed=3, content_len=24, vocab=120)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "neg_loss_weight": 16,
+          "loss_gamma": 10, "learn_rate": 0.1, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": 64,
+          "user_dim": 24, "item_dim": 24, "word_dim": 24, "chop_size": 4, "u_reg": 1e-4, "word_emb_dropout_rate": 0.3,
+          "num_filters": [20], "filter_lengths": [3], "conv_dropout_rate": 0.2, "optimizer": "sgd", "c_reg": 0.05}
+    conf = get_conf("synthetic", "best", pd, model_choice=model)
+    conf.item_dense_transform = {"dense_hidden_dim": conf.item_dim, "dense_hidden_dropout": 0.2, "dense_hidden_actv": "tanh"}
+    mds = [get_model(conf, get_data(dict(data), conf, rand_seed=5), model, seed=2) for _ in range(2)]
+    dp = DataParallelTower(HipTowerReplica(mds[0], "neg_shared"))
+    plain = mds[1]["model_neg_shared"]
+    e = plain.engine
+    rs = np.random.RandomState(1)
+    for step in range(4):
+        bt = data["train"][rs.choice(len(data["train"]), 64, replace=False)]
+        u, c = e.ids(bt[:, 0]), e.ids(bt[:, 1])
+        got = float(dp.step(u, c).item())
+        want = float(plain.core.step("neg_shared", u, c).item())
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+    t0, t1 = dp.be.tower, plain.core.tower
+    names = ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
+    if model == "cnn_embedding":
+        names += ("Wc", "bc", "g1", "b1", "rm1", "rv1")
+    for name in names:
+        np.testing.assert_allclose(getattr(t0, name).cpu().numpy(), getattr(t1, name).cpu().numpy(), rtol=1e-5, atol=1e-6,
+                                   err_msg=name)
+    np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
 def test_data_parallel_run_epoch_equals_plain_epoch():
     """DataParallelTower.run_epoch (plans of 64 steps per launch, planned step -> apply) over 70 steps ==
     the single-GPU epoch runner, bitwise on the user table and to rounding on the tower (the gradient
