@@ -1108,15 +1108,35 @@ __global__ void __launch_bounds__(512, (CNN || MAXP) ? 6 : 8) tower_word_kernel(
 
 // Data-parallel training: parameters -= step(scale * g) from an exported (and all-reduced)
 // gradient buffer.  Lazy-sparse Adam skips exactly-zero gradient elements of the word table.
+// The word table (all but 0.3 % of the buffer) four floats per thread: threads [0, n_words wd / 4); the dense parameters behind
+// it one per thread.
+__device__ __forceinline__ void tower_apply_words(const TowerArgs& a, const float* __restrict__ g, float scale, size_t i4) {
+  const float4 g4 = reinterpret_cast<const float4*>(g)[i4];
+  const float gv[4] = {scale * g4.x, scale * g4.y, scale * g4.z, scale * g4.w};
+  // untouched elements (most of the table in any step): SGD's w - lr * 0 is w, lazy-sparse Adam skips them -- nothing to load or store
+  if (a.opt != 2 && gv[0] == 0.f && gv[1] == 0.f && gv[2] == 0.f && gv[3] == 0.f) return;
+  float4* wp = reinterpret_cast<float4*>(a.W) + i4;
+  float4 w4 = *wp;
+  float w[4] = {w4.x, w4.y, w4.z, w4.w};
+  if (!a.opt) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] -= a.lr * gv[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (a.opt == 2 || gv[e] != 0.f) w[e] = adam1(gv[e], a.aw.m + 4 * i4 + e, a.aw.v + 4 * i4 + e, w[e], a);
+  }
+  *wp = make_float4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ void __launch_bounds__(256) tower_apply_kernel(TowerArgs a, const float* __restrict__ g, float scale, CnnBanks bs) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t nW = (size_t)a.n_words * a.wd, nel = (size_t)a.hd * a.d;
-  if (i < nW) {
-    const float gv = scale * g[i];
-    if (!a.opt) a.W[i] -= a.lr * gv;
-    else if (a.opt == 2 || gv != 0.f) a.W[i] = adam1(gv, a.aw.m + i, a.aw.v + i, a.W[i], a);
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nW / 4) {
+    tower_apply_words(a, g, scale, t);
     return;
   }
+  const size_t i = nW + (t - nW / 4);
   const size_t j = i - nW;
   if (j < nel + 384) {
     float* p;
@@ -1790,7 +1810,8 @@ int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int6
   for (int g = 0; g < t->nb; ++g) bs.b[g] = t->bank_at(g);
   {
     ProfScope _ps("tower_apply_kernel", as_stream(stream));
-    hipLaunchKernelGGL(tower_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, d_grad, scale, bs);
+    const int64_t nW = (int64_t)a.n_words * a.wd;   // word_dim % 4 == 0: whole float4s
+    hipLaunchKernelGGL(tower_apply_kernel, dim3((unsigned)((nW / 4 + (n - nW) + 255) / 256)), dim3(256), 0, as_stream(stream), a, d_grad, scale, bs);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
