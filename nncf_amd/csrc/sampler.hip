@@ -111,13 +111,24 @@ struct JumpTable {
 constexpr uint64_t kModMagic = 377789318629572ULL;   // ceil(2^75 / 1e8)
 static_assert((unsigned __int128)kModMagic * 100000000ULL >= ((unsigned __int128)1 << 75), "magic too small");
 static_assert((unsigned __int128)kModMagic * 100000000ULL < ((unsigned __int128)1 << 75) + ((unsigned __int128)1 << 27), "magic too large");
+constexpr uint32_t kModMagic32 = 2882303761u;        // floor(2^58 / 1e8)
+static_assert((unsigned __int128)kModMagic32 * 100000000ULL <= ((unsigned __int128)1 << 58) &&
+              ((unsigned __int128)kModMagic32 + 1) * 100000000ULL > ((unsigned __int128)1 << 58), "kModMagic32 != floor(2^58 / 1e8)");
 __host__ __device__ __forceinline__ uint32_t mod_table(uint64_t x48) {
 #ifdef __HIP_DEVICE_COMPILE__
-  const uint64_t q = __umul64hi(x48, kModMagic) >> 11;
+  // Device: TWO 32-bit multiplies.  With y = x >> 16 (< 2^32) and C = floor(2^58 / 1e8) (< 2^32), t = floor(y C / 2^42) satisfies
+  // x / 1e8 - 0.0017 < y C / 2^42 <= x / 1e8 (the dropped 16 bits cost < 2^16 / 1e8, the rounded constant < 2^32 / 2^42), so t is
+  // floor(x / 1e8) or one less: the remainder formed in 32-bit wrap-around arithmetic lies in [0, 2e8) and one conditional
+  // subtraction finishes it.  (The 64 x 64 -> high product of the multiply-high form is five quarter-rate multiplies; round 5's PMC
+  // pass has the kernel VALU-bound with a third of its cycles in 64-bit integer multiplies: profiles/r05_sampler_pmc.txt.)
+  const uint32_t q = __umulhi((uint32_t)(x48 >> 16), kModMagic32) >> 10;
+  uint32_t r = (uint32_t)x48 - q * (uint32_t)kTableSize;
+  if (r >= (uint32_t)kTableSize) r -= (uint32_t)kTableSize;
+  return r;
 #else
   const uint64_t q = (uint64_t)(((unsigned __int128)x48 * kModMagic) >> 75);
-#endif
   return (uint32_t)x48 - (uint32_t)q * (uint32_t)kTableSize;
+#endif
 }
 
 // Draw j (0-based within the logical batch) uses state f^(j+1)(state0): nodesampler.cpp:23-26,73-76.

@@ -146,3 +146,39 @@ def test_multiply_high_modulo_is_the_percent_operator():
     xs = (rs.randint(0, 2 ** 24, size=300000).astype(object) << 24) | rs.randint(0, 2 ** 24, size=300000).astype(object)
     for x in xs:
         assert mod_table(int(x)) == int(x) % D
+
+
+def test_two_multiply_modulo_is_the_percent_operator():
+    """csrc/sampler.hip mod_table, DEVICE form (round 5: the kernel is bound by quarter-rate integer multiplies): with y = x >> 16
+    and C = floor(2^58 / 1e8) < 2^32, q = mulhi32(y, C) >> 10 is floor(x / 1e8) or one less, so r = (x - q 1e8) mod 2^32 lies
+    in [0, 2e8) and one conditional subtraction finishes it.  Corner cases (every multiple of 1e8 +- 1 in a stride through the
+    48-bit range, the values around every 2^16 boundary next to a multiple), the reference LCG's own states, 10^7 random
+    states (vectorised in uint64: y C < 2^64); the kernel itself is pinned by the golden streams and the SHA-256 of 10^7 draws."""
+    D = 10 ** 8
+    C = 2 ** 58 // D
+    assert C == 2882303761 and C < 2 ** 32
+
+    def mod_dev(x):
+        q = (((x >> 16) * C) >> 32) >> 10
+        assert q in (x // D, x // D - 1), x
+        r = ((x & 0xFFFFFFFF) - (q * D & 0xFFFFFFFF)) & 0xFFFFFFFF
+        return r - D if r >= D else r
+
+    top = 2 ** 48 - 1
+    corners = [0, 1, D - 1, D, D + 1, top, top - 1, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1]
+    for k in list(range(1, 3000)) + list(range(1, top // D, 997)) + list(range(top // D - 3000, top // D + 1)):
+        v = k * D
+        corners += [v - 1, v, v + 1, v | 0xFFFF, v & ~0xFFFF, (v & ~0xFFFF) - 1]
+    for x in corners:
+        if 0 <= x <= top:
+            assert mod_dev(x) == x % D, x
+    state = 12345
+    for _ in range(200000):   # states of the reference's own LCG (nodesampler.cpp:24)
+        state = (state * 25214903917 + 11) & (2 ** 64 - 1)
+        assert mod_dev(state >> 16) == (state >> 16) % D
+    rs = np.random.RandomState(1)
+    x = (rs.randint(0, 2 ** 24, size=10 ** 7).astype(np.uint64) << np.uint64(24)) | rs.randint(0, 2 ** 24, size=10 ** 7).astype(np.uint64)
+    q = (((x >> np.uint64(16)) * np.uint64(C)) >> np.uint64(42))
+    r = ((x & np.uint64(0xFFFFFFFF)) - ((q * np.uint64(D)) & np.uint64(0xFFFFFFFF))) & np.uint64(0xFFFFFFFF)
+    r = np.where(r >= np.uint64(D), r - np.uint64(D), r)
+    assert np.array_equal(r, x % np.uint64(D))
