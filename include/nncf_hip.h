@@ -426,7 +426,7 @@ int nncf_tower_conv_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d
  * conv_b, bn1_gamma, bn1_beta (128 each)]; every live element written, zeros for words outside the
  * batch; the pads of the 128-float vectors are left alone (hand in a zeroed buffer).  After the all-reduce,
  * nncf_tower_apply_grads takes the optimiser step with scale * d_grad (step_t: 1-based Adam step,
- * 0 = the tower's own counter). */
+ * 0 = the tower's own counter).  d_grad: 16-byte aligned (NNCF_ERR_INVALID otherwise). */
 int64_t nncf_tower_grad_floats(const nncf_tower* t);
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad);
 int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream);

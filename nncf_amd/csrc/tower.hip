@@ -1787,12 +1787,14 @@ int64_t nncf_tower_grad_floats(const nncf_tower* t) {
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(((uintptr_t)d_grad & 15) == 0, "d_grad must be 16-byte aligned");
   t->gexp = d_grad;
   return NNCF_OK;
 }
 
 int nncf_tower_apply_grads(nncf_tower* t, const float* d_grad, float scale, int64_t step_t, void* stream) {
   NNCF_REQUIRE(t && d_grad, "NULL argument");
+  NNCF_REQUIRE(((uintptr_t)d_grad & 15) == 0, "d_grad must be 16-byte aligned (the word table's share is read four floats at a time)");
   TowerArgs a = base_args(t);
   a.opt = t->opt;
   if (t->opt) {

@@ -251,6 +251,31 @@ def test_data_parallel_replica_with_c_reg_and_a_dense_tail_variant(model):
     np.testing.assert_allclose(dp.be.engine.U.cpu().numpy(), e.U.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_gradient_buffer_alignment_is_checked():
+    """nncf_tower_set_grad_export / nncf_tower_apply_grads read and write the flat gradient four floats at a time: a pointer off
+    16 bytes is refused (NNCF_ERR_INVALID -> ValueError), not dereferenced."""
+    import ctypes
+    from nncf_amd import _lib, synthetic
+    from nncf_amd.conf import get_conf
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    data = synthetic.make_citeulike_like(users=100, items=80, train_links=1000, seed=3, content_len=12, vocab=40)
+    pd = {"reset_after_getconf": True, "max_epoch": 1, "loss": "skip-gram", "num_negatives": 0, "batch_size_p": 32, "user_dim": 8,
+          "item_dim": 8, "word_dim": 8, "optimizer": "sgd"}
+    conf = get_conf("synthetic", "best", pd, model_choice="basic_embedding")
+    tw = get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding", seed=2)["model"].core.tower
+    L = _lib.lib()
+    n = int(L.nncf_tower_grad_floats(tw.handle))
+    buf = torch.zeros(n + 8, device="cuda")
+    with torch.cuda.device(buf.device):
+        with pytest.raises(ValueError, match="16-byte"):
+            _lib.check(L.nncf_tower_set_grad_export(tw.handle, ctypes.c_void_p(buf.data_ptr() + 4)))
+        with pytest.raises(ValueError, match="16-byte"):
+            _lib.check(L.nncf_tower_apply_grads(tw.handle, ctypes.c_void_p(buf.data_ptr() + 8), 1.0, 0, None))
+        _lib.check(L.nncf_tower_apply_grads(tw.handle, ctypes.c_void_p(buf.data_ptr()), 1.0, 0, None))   # aligned: a zero gradient
+    torch.cuda.synchronize()
+
+
 def test_data_parallel_run_epoch_equals_plain_epoch():
     """DataParallelTower.run_epoch (plans of 64 steps per launch, planned step -> apply) over 70 steps ==
     the single-GPU epoch runner, bitwise on the user table and to rounding on the tower (the gradient
