@@ -240,3 +240,21 @@ def test_postings_schedule_invariants():
                 lens = blk[j:j + k, 2] - blk[j:j + k, 1]
                 assert lens.max() <= 512 or k == 8
                 j += k
+
+
+def test_bench_prices_the_large_batch_kernels_on_the_f16_pipe():
+    """bench.py price_on_f16_pipe: the large-batch kernels' products run on the f16 matrix pipe -- `peak` is that pipe's dense peak,
+    `frac` = achieved / peak stays a fraction (the fp32-equivalent flop against the fp32-MFMA peak reaches 1 since round 5 and is
+    kept beside it), and the issued f16 flop (4 x algorithmic) is named."""
+    import bench
+    r = {"kernel": "fused_wide_kernel", "bound": "mfma", "achieved": 154.0, "peak": bench.PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": 154.0 / bench.PEAK_F32_MFMA_TFLOPS, "frac_uncorrected_bracket": 0.97, "algorithmic_per_launch": 51.54e9, "kernel_ms": 0.3354}
+    bench.price_on_f16_pipe(r, True)
+    assert r["peak"] == bench.PEAK_F16_MFMA_TFLOPS and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert abs(r["frac_of_fp32_mfma_peak"] - 154.0 / bench.PEAK_F32_MFMA_TFLOPS) < 1e-12
+    assert abs(r["issued_f16_tflops"] - 4 * 51.54e9 / 0.3354e-3 / 1e12) < 1e-6
+    assert 0 < r["frac_issued_of_f16_mfma_peak"] < 1 and r["pipe"].startswith("f16 MFMA")
+    r2 = {"kernel": "fused_wide_kernel", "achieved": 77.0, "peak": bench.PEAK_F32_MFMA_TFLOPS, "frac": 0.49, "algorithmic_per_launch": 51.54e9,
+          "kernel_ms": 0.666}
+    bench.price_on_f16_pipe(r2, False)      # NNCF_WIDE_F16SPLIT=0: the fp32 pipe, priced as before
+    assert r2["peak"] == bench.PEAK_F32_MFMA_TFLOPS and r2["frac"] == 0.49 and r2["pipe"].startswith("f32 MFMA")
