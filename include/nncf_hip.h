@@ -391,6 +391,11 @@ int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, flo
  * hash of (nncf_tower_set_dropout's seed, train-forward index, row, column); nncf_tower_dense_mask writes the mask
  * (including its 1/keep scale) of forward `step_index` for m rows, [m][item_dim] floats, for tests. */
 int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout);
+/* A tower WITHOUT item_dense_transform (mean_pool.py:78-101, cnn_model.py:112-130: the else branch): the pooled block -- the
+ * mean / max of the word rows, or the pooled conv features -- is the item row itself (its width must be item_dim); no Dense,
+ * BatchNorm or Activation, no parameters behind the pooling.  Steps run on the materialised block as for the tail variants
+ * (conf.use_content_id still adds its id rows); set before hot words / postings; no gradient export. */
+int nncf_tower_set_no_dense(nncf_tower* t, int32_t no_dense);
 int nncf_tower_dense_mask(nncf_tower* t, uint64_t step_index, int64_t m, float* d_out, void* stream);
 /* conf.c_reg (mean_pool.py:56-59, cnn_model.py:45-48: activity_l2(conf.c_reg) on the word Embedding; L1L2Act,
  * utils/utilities.py:122-135): c_reg * sum over (position, column) of the mean over the block's rows of E^2 joins the loss

@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
         out[32 + q] = b2.a;
         out[32 + q + 16] = b2.b;
       }
-      if (a.train) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, best);
+      if (a.train || a.no_dense) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, best);
       reinterpret_cast<float4*>(sH)[q] = best.a;
       reinterpret_cast<float4*>(sH)[q + 16] = best.b;
     }
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(kPoolThreads) cnn_pool_dense_kernel(TowerArgs 
       sum.b = add4(sum.b, reinterpret_cast<const float4*>(sR[0] + g * kTP)[q + 16]);
     }
     sum = row_scale(sum, 1.f / (float)L);
-    if (a.train) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, sum);   // this bank's columns of the pooled block
+    if (a.train || a.no_dense) row_store(a.h + a.cnn.c_off, s, a.hd, f4, q, sum);   // this bank's columns of the pooled block
     reinterpret_cast<float4*>(sH)[q] = sum.a;
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
   }

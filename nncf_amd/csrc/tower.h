@@ -147,6 +147,7 @@ struct TowerArgs {
   // item_dense_transform variants (mean_pool.py:82-97): Activation(dense_hidden_actv) other than relu, Dropout(dense_hidden_dropout).
   // Such a tower's steps materialise the item block (as conf.use_content_id does) and its backward starts from
   // dA * mask * act'(y) (tower_tail_grad_kernel) with the relu gates of the BatchNorm-backward kernels open (tail_pre).
+  int no_dense;              // no item_dense_transform (mean_pool.py:78-101 else branch): the pooled block IS the item block
   int tail_act;              // kAct*: 0 = relu (the presets)
   int tail_pre;              // the backward's dA already carries mask * act'(y)
   float tail_keep;           // Dropout retain probability of this forward (1 = off)
@@ -406,7 +407,9 @@ struct nncf_tower {
   float tail_drop = 0.f;
   uint64_t tail_step = 0;        // train-mode forwards since nncf_tower_set_dense_tail / set_dropout (mask index)
   float* dA_tail = nullptr;      // own allocation [max_rows][item_dim]: dA * mask * act'(y)
-  bool tail_general() const { return tail_act != 0 || tail_drop > 0.f; }
+  int no_dense = 0;              // nncf_tower_set_no_dense: no Dense / BatchNorm / Activation behind the pooling
+  bool tail_variant() const { return tail_act != 0 || tail_drop > 0.f; }
+  bool tail_general() const { return tail_variant() || no_dense; }   // the step runs on the materialised item block
   // conf.c_reg (nncf_tower_set_c_reg; TowerArgs::c_reg)
   float c_reg = 0.f;
   int32_t* wcount = nullptr;     // own allocation [word_count], all-zero between steps

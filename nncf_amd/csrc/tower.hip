@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256, BIG ? 6 : 1) tower_pool_kernel(TowerArgs 
         if (a.train && real) a.amax[(int64_t)s * a.wd + col] = bw;
       }
     }
-    if (a.train) row_store(a.h, s, a.wd, wd4, q, sum);
+    if (a.train || a.no_dense) row_store(a.h, s, a.wd, wd4, q, sum);
     reinterpret_cast<float4*>(sH)[q] = sum.a;  // chunks past wd are the zeros row_load produced
     reinterpret_cast<float4*>(sH)[q + 16] = sum.b;
   }
@@ -363,6 +363,13 @@ __global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
     }
   }
   row_store(a.E, row, a.d, d4, q, o);
+}
+
+// a tower without item_dense_transform: the pooled block h [m][hd] is the item block E [m][d] (hd == d); rows past n_valid: zeros
+__global__ void __launch_bounds__(256) tower_copy_h_kernel(TowerArgs a) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = a.d >> 2;
+  if (row >= a.m) return;
+  row_store(a.E, row, a.d, d4, q, row < valid_rows(a) ? row_load(a.h, row, a.hd, d4, q) : row_zero());
 }
 
 // out = dA * mask * act'(y), y = z * mul + add: the Dense tail's Activation / Dropout backward, in front of the
@@ -1320,6 +1327,7 @@ TowerArgs base_args(const nncf_tower* t) {
   a.hot_bits = a.n_hot > 0 ? t->hot_bits : nullptr;
   a.pm = 0;
   a.pm_stamp = 0;
+  a.no_dense = t->no_dense;
   a.tail_act = t->tail_act;
   a.tail_pre = 0;
   a.tail_keep = 1.f;
@@ -1366,6 +1374,15 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     else if (m > 1024) hipLaunchKernelGGL((tower_pool_kernel<false, true>), dim3((unsigned)m), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(tower_pool_kernel<false>, dim3((unsigned)m), dim3(256), 0, st, a);
   }
+  if (t->no_dense) {   // no Dense / BatchNorm / Activation: E = the pooled block (the kernels above left it in h; what they wrote to z / E is unused)
+    if (E) hipLaunchKernelGGL(tower_copy_h_kernel, dim3((m + 15) / 16), dim3(256), 0, st, a);
+    if (train) {
+      t->last = a;
+      t->fwd_cached = true;
+    }
+    NNCF_HIP_CHECK(hipGetLastError());
+    return NNCF_OK;
+  }
   if (train && stats_by_consumer) {  // the one-launch step derives the statistics itself (step_fused.hip)
     t->last = a;
     t->fwd_cached = true;
@@ -1411,7 +1428,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
     a.vD = t->vD;
   }
   const int m = a.m;
-  if (t->tail_general()) {   // Activation / Dropout backward of a non-default Dense tail, out of place
+  if (t->tail_variant()) {   // Activation / Dropout backward of a non-default Dense tail, out of place
     NNCF_REQUIRE(t->dA_tail != nullptr && !nfused && !sums_done, "the Dense tail variants run on the materialised block only");
     hipLaunchKernelGGL(tower_tail_grad_kernel, dim3((m + 15) / 16), dim3(256), 0, st, a, t->dA_tail);
     a.dA = t->dA_tail;
@@ -1420,13 +1437,19 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   const int ks = (m + kRowsPerK - 1) / kRowsPerK;
   const int nA = (m + 15) / 16;
   const int ntile = ((a.hd + 15) / 16) * ((a.d + 15) / 16);
-  if (!nfused && !sums_done) {
-    ProfScope _ps("tower_sums_kernel", st);
-    hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
-  }
-  {
-    ProfScope _ps("tower_bwd_kernel", st);
-    hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks, nfused);
+  if (t->no_dense) {
+    // no Dense tail: dL/d(pooled block) IS the step's dL/dE; nothing of Dense / BatchNorm to differentiate or to step
+    NNCF_REQUIRE(!nfused && !sums_done, "a tower without the Dense transform runs on the materialised block only");
+    a.dh = const_cast<float*>(a.dA);
+  } else {
+    if (!nfused && !sums_done) {
+      ProfScope _ps("tower_sums_kernel", st);
+      hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
+    }
+    {
+      ProfScope _ps("tower_bwd_kernel", st);
+      hipLaunchKernelGGL(tower_bwd_kernel, dim3(nA + ntile * ks), dim3(256), 0, st, a, nA, ks, nfused);
+    }
   }
   if (a.cnn.F > 0) {  // dL/dh -> conv backward -> per-(item, word) gradient rows
     a.cnn.keep = t->last.cnn.keep;
@@ -1438,7 +1461,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   if (const char* e = getenv("NNCF_WORD_DBG")) a.skip_words |= atoi(e);   // developer timing: 2 no row gathers, 4 no cell scan, 8 no hot partials
   {
     ProfScope _ps("tower_word_kernel", st);
-    const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = (a.hd * a.d + 511) / 512;
+    const int nwb = (a.n_words + kWordsPerWG - 1) / kWordsPerWG, nupd = t->no_dense ? 0 : (a.hd * a.d + 511) / 512;
     const int ncnn = a.cnn.F > 0 ? cnn_update_blocks(a.cnn.fl * a.wd * a.cnn.F) : 0;   // cnn_update_block workgroups
     if (a.cnn.F > 0) hipLaunchKernelGGL((tower_word_kernel<true>), dim3(nwb + nupd + ncnn), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
     else if (a.pool_max) hipLaunchKernelGGL((tower_word_kernel<false, true>), dim3(nwb + nupd), dim3(512), 0, st, a, ks, nfused, a.lr / (float)a.L);
@@ -1787,6 +1810,7 @@ int64_t nncf_tower_grad_floats(const nncf_tower* t) {
 
 int nncf_tower_set_grad_export(nncf_tower* t, float* d_grad) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(!d_grad || !t->no_dense, "the Dense-less tower has no gradient export");
   NNCF_REQUIRE(((uintptr_t)d_grad & 15) == 0, "d_grad must be 16-byte aligned");
   t->gexp = d_grad;
   return NNCF_OK;
@@ -1870,6 +1894,7 @@ int nncf_tower_forward(nncf_tower* t, const int32_t* d_item_ids, int64_t m, cons
 }
 
 int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n) {
+  NNCF_REQUIRE(!t || !t->no_dense || n == 0, "hot words need the Dense backward (the Dense-less tower has none)");
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE(n >= 0 && n <= kHotWords && (n == 0 || host_words), "0..%d hot words", kHotWords);
   NNCF_REQUIRE(t->pm_units == nullptr, "set the hot words before the postings (the schedule gives hot words empty ranges)");
@@ -1896,6 +1921,7 @@ int nncf_tower_set_hot_words(nncf_tower* t, const int32_t* host_words, int32_t n
 }
 
 int nncf_tower_set_postings(nncf_tower* t, const int32_t* d_units, int32_t n_workgroups, const uint32_t* d_postings, int64_t* d_slot_of) {
+  NNCF_REQUIRE(!t || !t->no_dense || !d_units, "postings are not built for the Dense-less tower");
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE((d_units && d_postings && d_slot_of && n_workgroups > 0) || (!d_units && !d_postings && !d_slot_of),
                "postings: the schedule, the postings and slot_of, or none of them");
@@ -1947,11 +1973,23 @@ int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, flo
   return NNCF_OK;
 }
 
+int nncf_tower_set_no_dense(nncf_tower* t, int32_t no_dense) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  if (no_dense) {
+    NNCF_REQUIRE(t->hd() == t->cfg.item_dim, "without the Dense transform the pooled width (%d) must be item_dim (%d)", t->hd(), t->cfg.item_dim);
+    NNCF_REQUIRE(t->n_hot == 0 && !t->pm_units, "set the Dense-less mode before hot words / postings (their partial rows come from the Dense backward)");
+    NNCF_REQUIRE(!t->gexp && !t->tail_variant(), "the Dense-less tower has no gradient export and no Dense tail variant");
+  }
+  t->no_dense = no_dense ? 1 : 0;
+  return NNCF_OK;
+}
+
 int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE(activation >= 0 && activation < kActCount, "activation %d: 0 relu, 1 tanh, 2 sigmoid, 3 hard_sigmoid, 4 softplus, "
                "5 softsign, 6 linear", activation);
   NNCF_REQUIRE(dropout >= 0.f && dropout < 1.f, "dropout rate %g out of [0, 1)", (double)dropout);
+  NNCF_REQUIRE(!t->no_dense || (activation == 0 && dropout == 0.f), "the Dense-less tower has no Dense tail to vary");
   if ((activation != 0 || dropout > 0.f) && !t->dA_tail) {
     DeviceGuard guard(t->device);
     if (hipMalloc(&t->dA_tail, sizeof(float) * (size_t)t->cfg.max_rows * t->cfg.item_dim) != hipSuccess)

@@ -75,11 +75,14 @@ class MeanPoolTower(object):
     object (nncf_tower_*) borrows their pointers and owns every scratch buffer."""
 
     def __init__(self, C, word_count, word_dim, item_dim, learn_rate, device, seed=0, dropout_rate=0.0,
-                 eps=1e-3, momentum=0.99, max_rows=512, conv=None):
+                 eps=1e-3, momentum=0.99, max_rows=512, conv=None, dense=True):
         """conv: None (MeanPool) or dict(filters=F, filter_len=fl, dropout=p): the CNN tower of
         cnn_embedding (modules/content/cnn_model.py) -- one Convolution1D('same') + BatchNorm + relu +
-        Dropout + average pooling in front of the same Dense/BN/ReLU tail."""
+        Dropout + average pooling in front of the same Dense/BN/ReLU tail.
+        dense=False: no item_dense_transform (mean_pool.py:78-101, the else branch): the pooled block is the item row (its
+        width -- word_dim, or the conv filters -- must be item_dim); the Dense / BatchNorm tensors exist but are never used."""
         self.device = device
+        self.dense = bool(dense)
         self._L = _lib.lib()
         C = np.ascontiguousarray(np.asarray(C))
         self.item_count, self.Lc = C.shape
@@ -172,7 +175,9 @@ class MeanPoolTower(object):
         idx = torch.device(dev).index or 0
         _lib.check(self._L.nncf_tower_create(ctypes.byref(cfg), ctypes.byref(prm), idx, ctypes.byref(h)))
         self.handle = h
-        if not self.conv and os.environ.get("NNCF_HOT_WORDS", "1") != "0":
+        if not self.dense:   # before hot words / postings: both lean on the Dense backward's workgroups
+            _lib.check(self._L.nncf_tower_set_no_dense(self.handle, 1))
+        if self.dense and not self.conv and os.environ.get("NNCF_HOT_WORDS", "1") != "0":
             # the words that sit in most items (the pad id in all of them): their gradient rows are summed by the Dense
             # backward's workgroups instead of one wave of the word kernel (nncf_tower_set_hot_words); speed only
             df = np.bincount(words, minlength=self.word_count)          # document frequency: one CSR entry per (item, word)
@@ -181,7 +186,7 @@ class MeanPoolTower(object):
             self.hot_words = top
             if top.size:
                 _lib.check(self._L.nncf_tower_set_hot_words(self.handle, top.ctypes.data_as(_lib.c_i32p), int(top.size)))
-        if not self.conv and self.cap > 1024 and self.item_count <= (1 << 24) and os.environ.get("NNCF_WORD_POSTINGS", "1") != "0":
+        if self.dense and not self.conv and self.cap > 1024 and self.item_count <= (1 << 24) and os.environ.get("NNCF_WORD_POSTINGS", "1") != "0":
             # blocks of thousands of rows (`original`, the row-wise schemes): the word kernel walks the static transposed CSR
             # (word -> items that hold it) instead of scanning a ~1 % full count matrix (nncf_tower_set_postings); speed only
             order = np.argsort(words, kind="stable")                       # entries by word, items ascending inside a word

@@ -464,23 +464,28 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     idt = conf.item_dense_transform
     # mean_pool.py:78-101 / cnn_model.py:112-130: Dense(dense_hidden_dim) -> BatchNorm -> Activation -> Dropout.  The tower's
     # output is the item row: dense_hidden_dim must be item_dim; a tower WITHOUT the transform (or with conf.no_BN) is not built.
-    if not idt or idt["dense_hidden_dim"] != conf.item_dim or getattr(conf, "no_BN", False):
-        raise NotImplementedError("item_dense_transform must be Dense(item_dim) + BatchNormalization (got %r, no_BN = %r)"
+    # No transform at all (item_dense_transform falsy): the pooled block is the item row -- its width must be item_dim.
+    if idt and (idt["dense_hidden_dim"] != conf.item_dim or getattr(conf, "no_BN", False)):
+        raise NotImplementedError("item_dense_transform must be Dense(item_dim) + BatchNormalization, or absent (got %r, no_BN = %r)"
                                   % (idt, getattr(conf, "no_BN", False)))
+    if not idt:
+        pooled = int(list(conf.num_filters)[0]) * len(conv["filter_lens"]) if conv is not None else conf.word_dim
+        if pooled != conf.item_dim:
+            raise ValueError("without item_dense_transform the pooled width (%d) must equal item_dim (%d)" % (pooled, conf.item_dim))
     kw = engine_kwargs(conf, data_spec, "basic_embedding")
     cap = conf.batch_size_p * (1 + conf.num_negatives)          # most unique items a batch can hold
     kw["item_count"] = cap
     engine = Engine(device=device, seed=seed, **kw)
     tower = MeanPoolTower(data_helper.data["C"], data_spec.word_count, conf.word_dim, conf.item_dim,
                           abs(conf.learn_rate), engine.device, seed=seed,
-                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap, conv=conv)
+                          dropout_rate=getattr(conf, "word_emb_dropout_rate", 0.), max_rows=cap, conv=conv, dense=bool(idt))
     if conv is None and pooling == "max":
         tower.set_pooling("max")                                        # mean_pool.py:70-72
     if conv is not None and conv.get("pooling") == "max":
         tower.set_pooling("max")                                        # cnn_model.py:107-109
     if getattr(conf, "use_content_id", False):                          # mean_pool.py:102-108
         tower.set_content_id(getattr(conf, "v_reg", 0.0), seed=seed)
-    if idt["dense_hidden_actv"] != "relu" or float(idt["dense_hidden_dropout"]) != 0.:   # mean_pool.py:96-97
+    if idt and (idt["dense_hidden_actv"] != "relu" or float(idt["dense_hidden_dropout"]) != 0.):   # mean_pool.py:96-97
         tower.set_dense_tail(idt["dense_hidden_actv"], float(idt["dense_hidden_dropout"]))
     if float(getattr(conf, "c_reg", 0) or 0) != 0.0:                    # mean_pool.py:56-59, cnn_model.py:45-48
         tower.set_c_reg(conf.c_reg)

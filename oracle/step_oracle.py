@@ -363,6 +363,7 @@ class TowerOracle(object):
         self.c_reg = self.dt.type(0)   # activity_l2(c_reg) on the word Embedding's output (mean_pool.py:56-59, cnn_model.py:45-48)
         self.dense_act = "relu"        # item_dense_transform['dense_hidden_actv'] (mean_pool.py:83,96): any of ACTIVATIONS
         self.dense_mask = None         # Dropout(dense_hidden_dropout) (mean_pool.py:84,97): (n, d) mask INCLUDING its 1/keep scale
+        self.no_dense = False          # item_dense_transform falsy (mean_pool.py:78-101, else branch): the pooled block is the item row
         self.extra_loss = 0.0
 
     PARAMS = ("W", "Wd", "bd", "gamma", "beta")
@@ -442,6 +443,14 @@ class TowerOracle(object):
         if train:
             self.cache = dict(toks=toks, row_scale=row_scale)
         h = self._front_forward(toks, row_scale, train)
+        if self.no_dense:          # no Dense / BatchNorm / Activation: h itself (+ Emb_Cid, + c_reg below)
+            if train:
+                self.cache.update(h=h)
+            out = self._plus_content_id(h.astype(self.dt), cid_u, train)
+            if train and self.c_reg != 0:
+                E = self.W[toks] if row_scale is None else self.W[toks] * row_scale[toks][..., None]
+                self.extra_loss += float(self.c_reg * np.sum(np.mean(E * E, axis=0)))
+            return out
         z = h @ self.Wd + self.bd
         if train:
             mu = z.mean(axis=0)
@@ -478,6 +487,29 @@ class TowerOracle(object):
         """conf / t: OracleConf with optimizer != 'sgd' and the 1-based optimiser step."""
         c = self.cache
         self._content_id_update(dA, conf, t)
+        if self.no_dense:          # dL/dh = dL/dE; only the front (word table, conv weights) has parameters
+            self.grads = {k: np.zeros_like(getattr(self, k)) for k in ("Wd", "bd", "gamma", "beta")}
+            self.grads.update(self._front_backward(np.asarray(dA, dtype=self.dt)))
+            self._c_reg_grad(self.grads["W"])
+            if getattr(self, "export_only", False):
+                return
+            live = [k for k in self.PARAMS if k not in ("Wd", "bd", "gamma", "beta")]   # W, and a single-bank conv front's weights
+            if conf is None or conf.optimizer == "sgd":
+                for k in live:
+                    getattr(self, k).__isub__(self.lr * self.grads[k].astype(self.dt))
+            else:
+                if not hasattr(self, "slots"):
+                    self.slots = {k: AdamSlot(getattr(self, k)) for k in live}
+                lr_t = adam_lr_t(self.lr, conf.beta1, conf.beta2, t)
+                rows = None
+                if conf.optimizer == "sparse_adam":
+                    toks = c["toks"].reshape(-1)
+                    if c["row_scale"] is not None:
+                        toks = toks[c["row_scale"][toks] != 0]
+                    rows = np.unique(toks)
+                for k in live:
+                    self.slots[k].step(getattr(self, k), self.grads[k].astype(self.dt), lr_t, conf, rows if k == "W" else None)
+            return
         n = self.dt.type(dA.shape[0])
         dy = dA * self.ACTIVATIONS[self.dense_act][1](c["y"])
         if self.dense_mask is not None:

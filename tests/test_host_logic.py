@@ -258,3 +258,19 @@ def test_bench_prices_the_large_batch_kernels_on_the_f16_pipe():
           "kernel_ms": 0.666}
     bench.price_on_f16_pipe(r2, False)      # NNCF_WIDE_F16SPLIT=0: the fp32 pipe, priced as before
     assert r2["peak"] == bench.PEAK_F32_MFMA_TFLOPS and r2["frac"] == 0.49 and r2["pipe"].startswith("f32 MFMA")
+
+
+def test_dense_less_tower_needs_the_pooled_width_to_be_item_dim():
+    """conf.item_dense_transform = None (mean_pool.py:78-101, the else branch): the pooled block is the item row, so word_dim (or
+    the conv filters) must equal item_dim -- checked in get_model before any device work; conf.no_BN stays refused."""
+    from nncf_amd.data_utils import get_data
+    from nncf_amd.model_framework import get_model
+    data = synthetic.make_citeulike_like(users=50, items=40, train_links=400, seed=3, content_len=12, vocab=30)
+    conf = get_conf("synthetic", "best", {"reset_after_getconf": True, "word_dim": 16, "item_dim": 24, "user_dim": 24}, model_choice="basic_embedding")
+    conf.item_dense_transform = None
+    with pytest.raises(ValueError, match="pooled width"):
+        get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding")
+    conf2 = get_conf("synthetic", "best", {"reset_after_getconf": True}, model_choice="basic_embedding")
+    conf2.no_BN = True
+    with pytest.raises(NotImplementedError, match="no_BN"):
+        get_model(conf2, get_data(dict(data), conf2, rand_seed=5), "basic_embedding")

@@ -375,6 +375,35 @@ def test_tower_oracle_dense_tail_variants_vs_autograd(act):
     np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
 
 
+def test_tower_oracle_without_the_dense_transform_vs_autograd():
+    """item_dense_transform falsy (mean_pool.py:78-101, the else branch): the pooled block is the item row -- loss and gradients of
+    the oracle's Dense-less path (with c_reg on) against torch autograd."""
+    rs = np.random.RandomState(2)
+    I, L, Wc, wd, d, nu, b = 30, 7, 20, 8, 8, 10, 8
+    C = rs.randint(0, Wc, (I, L))
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = rs.uniform(-.1, .1, d), rs.uniform(.5, 1.5, d), rs.uniform(-.1, .1, d)
+    U = rs.uniform(-.5, .5, (nu, d))
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="log-loss", u_reg=1e-3, learn_rate=0.1, model_choice="basic_embedding")
+    tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.1, dtype=np.float64)
+    tw.no_dense, tw.c_reg = True, 0.02
+    o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+    cid[3] = cid[0]
+    l_o = o.step_neg_shared(uid, cid)
+    tU, tW = torch.tensor(U, requires_grad=True), torch.tensor(W, requires_grad=True)
+    cu, cx = so.tf_unique(cid)
+    rows = tW[torch.tensor(C[cu])]
+    l_t = _torch_neg_shared(tU, rows.sum(1) / L, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf) + 0.02 * (rows * rows).mean(0).sum()
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    np.testing.assert_allclose(tw.grads["W"], tW.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
+    np.testing.assert_allclose(W - tw.W, 0.1 * tW.grad.numpy(), atol=1e-10)    # the SGD step it took
+    for k, v in (("Wd", Wd), ("bd", bd), ("gamma", ga), ("beta", be)):        # nothing behind the pooling moves
+        assert np.array_equal(getattr(tw, k), v), k
+
+
 @pytest.mark.parametrize("kind", ["adam", "sparse_adam"])
 def test_adam_slot_against_torch_adam(kind):
     """AdamSlot (Keras / TF formula lr_t m / (sqrt v + eps)) against torch.optim.Adam /

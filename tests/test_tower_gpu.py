@@ -1359,6 +1359,74 @@ def test_dense_tail_variants_match_oracle(text_data, model, scheme, loss, opt, a
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("model,scheme,loss,opt,content_id", [
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", False),
+    ("basic_embedding", "original", "log-loss", "sgd", False),
+    ("basic_embedding", "group_neg_shared", "log-loss", "adam", False),
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", True),
+    ("cnn_embedding", "neg_shared", "skip-gram", "sgd", False),
+    ("cnn_embedding", "original", "skip-gram", "sgd", False),
+])
+def test_tower_without_the_dense_transform_matches_oracle(text_data, model, scheme, loss, opt, content_id):
+    """conf.item_dense_transform = None (mean_pool.py:78-101 / cnn_model.py:112-130, the else branch): the pooled block -- mean of
+    the word rows, or the pooled conv features -- is the item row.  Three steps with word-row dropout against the float64
+    oracle (loss, user table, word table, conv weights), nothing behind the pooling moves, then inference-mode scores."""
+    if model == "cnn_embedding":
+        conf = _conf_cnn(loss, scheme, F=24, wdrop=0.3, cdrop=0.2)      # pooled width = num_filters = item_dim
+    else:
+        conf = _conf(loss, scheme, lr=0.02 if opt != "sgd" else 0.2)    # pooled width = word_dim = item_dim
+        conf.word_emb_dropout_rate = 0.3
+    conf.optimizer = opt
+    conf.item_dense_transform = None
+    conf.use_content_id = content_id
+    conf.v_reg = 0.05 if content_id else 0.0
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), model, seed=2)
+    orc, to = (_oracle_cnn if model == "cnn_embedding" else _oracle)(conf, md, text_data, dtype=np.float64)
+    orc.conf.optimizer = opt
+    to.no_dense = True
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    if content_id:
+        to.Cid, to.v_reg = tw.Cid.cpu().numpy().astype(np.float64), 0.05
+    dense0 = {k: getattr(tw, k).clone() for k in ("Wd", "bd", "gamma", "beta", "rm", "rv")}
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
+    names = ("W",) + (("Wc", "g1", "b1", "rm1", "rv1") if model == "cnn_embedding" else ()) + (("Cid",) if content_id else ())
+    for step in range(3):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if model == "cnn_embedding":
+            to.conv_mask = tw.conv_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in names:
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+    for kname, v in dense0.items():
+        assert torch.equal(getattr(tw, kname), v), kname
+    if opt != "sgd":
+        return
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
+
+
 @pytest.mark.parametrize("opt", ["sgd", "adam", "sparse_adam"])
 @pytest.mark.parametrize("hot_words", ["1", "0"])
 def test_postings_mode_equals_the_count_matrix_scan(monkeypatch, opt, hot_words):
