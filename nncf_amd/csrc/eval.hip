@@ -19,7 +19,9 @@
 //
 // Tie policy: the reference breaks score ties with np.random noise (metrics_ranking.py:8,13);
 // here ties go to the lower candidate slot, so results are reproducible.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "devutil.h"
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         sc[t][r] = (t ? acc1[r] : acc0[r]) + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
-        any |= sc[t][r] >= tau_f[t][r];
+        any |= !(sc[t][r] < tau_f[t][r]);   // NaN scores pass: the exact key test ranks them as eval_topk_kernel does (orderable())
       }
     if (!any) return;
     // exact test against the threshold KEYS (registers), then all the list positions at once: eight independent LDS atomics in
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         key[t][r] = rank_key(sc[t][r], j);
-        want[t][r] = sc[t][r] >= tau_f[t][r] && key[t][r] > tau_k[t][r];
+        want[t][r] = !(sc[t][r] < tau_f[t][r]) && key[t][r] > tau_k[t][r];
       }
     int pos[2][4];
 #pragma unroll
@@ -602,8 +604,21 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 int launch_eval_fused(const StepArgs& a, const int32_t* uid, int64_t n_users, const int32_t* cand, int n_cand, const int32_t* truth_ptr,
                       const int32_t* truth_idx, int topk, float* metrics, int32_t* valid, hipStream_t stream) {
   const unsigned grid = (unsigned)((n_users + kEvalUsers - 1) / kEvalUsers);
-  const char* de = getenv("NNCF_EVAL_DBG");   // developer timing switches (1: no list traffic, 2: no products): wrong results
-  const int dbg = de ? atoi(de) : 0;
+  // developer timing switches (1: no list traffic, 2: no products) leave WRONG metrics: read once, honoured only together with
+  // NNCF_EVAL_DBG_ACK=wrong-results (tools/eval_bench.py sets both), and announced on stderr -- a stray variable cannot
+  // silently corrupt an evaluation
+  static const int dbg = []() {
+    const char* de = getenv("NNCF_EVAL_DBG");
+    const int v = de ? atoi(de) : 0;
+    if (!v) return 0;
+    const char* ack = getenv("NNCF_EVAL_DBG_ACK");
+    if (!ack || strcmp(ack, "wrong-results") != 0) {
+      fprintf(stderr, "[nncf] NNCF_EVAL_DBG=%d ignored (developer timing switch; needs NNCF_EVAL_DBG_ACK=wrong-results)\n", v);
+      return 0;
+    }
+    fprintf(stderr, "[nncf] WARNING: NNCF_EVAL_DBG=%d -- nncf_eval_whole skips work, its metrics are WRONG (developer timing only)\n", v);
+    return v;
+  }();
   ProfScope _ps("eval_fused_kernel", stream);
   if (a.d == 100) {
     static KernelDeviceState kst;

@@ -172,7 +172,9 @@ class MeanPoolTower(object):
                                                          self.rv, self.C, self.item_ptr, self.item_word, self.item_cnt)] +
                                  [(t.data_ptr() if t is not None else None) for t in extra]))
         h = ctypes.c_void_p()
-        idx = torch.device(dev).index or 0
+        idx = torch.device(dev).index          # 'cuda' without an index means the CURRENT device (as Communicator.rccl resolves it)
+        if idx is None:
+            idx = torch.cuda.current_device()
         _lib.check(self._L.nncf_tower_create(ctypes.byref(cfg), ctypes.byref(prm), idx, ctypes.byref(h)))
         self.handle = h
         if not self.dense:   # before hot words / postings: both lean on the Dense backward's workgroups

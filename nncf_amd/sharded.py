@@ -736,10 +736,20 @@ class DataParallelTower(object):
         native = chunk and hasattr(be, "run_epoch_native") and (not self.reduce or self.comm is not None) \
             and os.environ.get("NNCF_DP_NATIVE", "1") != "0"
         if native and n_steps > 0:
+            # the native runner strides the id streams by the ENGINE's batch size: a different `b`, or streams shorter than
+            # n_steps batches, would be a device out-of-bounds read with nothing to report it
+            eb = int(be.engine.b)
+            if int(b) != eb:
+                raise ValueError("run_epoch: b = %d, but the replica's engine was built for batch_size_p = %d" % (b, eb))
+            if uid_all.numel() < n_steps * b or cid_all.numel() < n_steps * b:
+                raise ValueError("run_epoch: %d steps of %d links need %d ids, got %d / %d" % (n_steps, b, n_steps * b, uid_all.numel(),
+                                                                                             cid_all.numel()))
+            if losses is not None and losses.numel() < n_steps:
+                raise ValueError("run_epoch: losses holds %d entries for %d steps" % (losses.numel(), n_steps))
             if self.reduce:
                 self.wire_bytes += int(n_steps) * be.grad.numel() * be.grad.element_size()
-            return be.run_epoch_native(uid_all[:n_steps * b], cid_all[:n_steps * b], n_steps, losses,
-                                       comm=self.comm if self.reduce else None)
+            be.run_epoch_native(uid_all[:n_steps * b], cid_all[:n_steps * b], n_steps, losses, comm=self.comm if self.reduce else None)
+            return losses      # the caller's tensor (None when none was passed): the same contract as the loop below
         for t0 in range(0, n_steps, max(chunk, 1)):
             cnt = min(max(chunk, 1), n_steps - t0)
             if chunk:
@@ -754,3 +764,4 @@ class DataParallelTower(object):
                 if self.reduce:
                     self._all_reduce()
                 be.apply(1.0)
+        return losses

@@ -365,6 +365,21 @@ class TowerOracle(object):
         self.dense_mask = None         # Dropout(dense_hidden_dropout) (mean_pool.py:84,97): (n, d) mask INCLUDING its 1/keep scale
         self.no_dense = False          # item_dense_transform falsy (mean_pool.py:78-101, else branch): the pooled block is the item row
         self.extra_loss = 0.0
+        self.bag = None                # use_bag(): items x words count matrix (scipy CSR) -- the same sums, bag by bag
+
+    def use_bag(self):
+        """Average pooling as a bag of words: sum_l W[tok[l]] * s[tok[l]] == sum_w count[item, w] * s[w] * W[w].  The same
+        real-number sum as the token-wise form below taken word by word instead of position by position (~45 distinct
+        words instead of 200 positions per item); in float64 the two agree to ~1e-15 relative
+        (tests/test_oracle_step.py::test_bag_form_of_the_mean_pool_oracle).  For the epoch-long parity loops at the
+        BASELINE shape, where the token-wise form's (n, L, wd) temporaries cost 0.2 s per step."""
+        import scipy.sparse as sp
+        n_items, L = self.C.shape
+        rows = np.repeat(np.arange(n_items), L)
+        self.bag = sp.csr_matrix((np.ones(rows.size, dtype=self.dt), (rows, self.C.reshape(-1))),
+                                 shape=(n_items, self.W.shape[0]))
+        self.bag.sum_duplicates()
+        return self
 
     PARAMS = ("W", "Wd", "bd", "gamma", "beta")
 
@@ -381,6 +396,14 @@ class TowerOracle(object):
 
     def _front_forward(self, toks, row_scale, train):
         """tokens (n, L) -> pooled block h (n, hd): here the mean of the word rows."""
+        if self.bag is not None and self.pooling == "average":
+            import scipy.sparse as sp
+            A = self.bag[self._cur_ids]
+            if row_scale is not None:
+                A = A @ sp.diags(np.asarray(row_scale, dtype=self.dt))
+            if train:
+                self.cache["A"] = A
+            return np.asarray(A @ self.W, dtype=self.dt) / self.dt.type(toks.shape[1])
         E = self.W[toks]                                       # (n_u, L, wd)
         if row_scale is not None:
             E = E * row_scale[toks][..., None]
@@ -395,6 +418,8 @@ class TowerOracle(object):
         """dL/dh -> gradients of the front's parameters (dict), from self.cache."""
         c = self.cache
         L = self.dt.type(c["toks"].shape[1])
+        if "A" in c:                   # use_bag(): dW[w] = sum_items count * s[w] * dh[item] / L
+            return dict(W=np.asarray(c["A"].T @ (dh / L), dtype=self.dt))
         dW = np.zeros_like(self.W)
         if self.pooling == "max":      # the gradient of column c goes to the word at the argmax position [K-mem: first maximum]
             am = c["argmax"]
@@ -440,6 +465,7 @@ class TowerOracle(object):
 
     def forward(self, cid_u, train=True, row_scale=None):
         toks = self.C[np.asarray(cid_u)]                       # (n_u, L)
+        self._cur_ids = np.asarray(cid_u)
         if train:
             self.cache = dict(toks=toks, row_scale=row_scale)
         h = self._front_forward(toks, row_scale, train)

@@ -1,0 +1,87 @@
+"""GPU: WHOLE-EPOCH parity at the BASELINE shape (north_star: "loss and Recall@k within 1e-5 fp32").
+
+The product Trainer (nncf_amd.train_*: HIP kernels behind the C ABI, one native call per epoch) trains ONE epoch -- 390 steps of
+b = 512 over the CiteULike-a-shaped set (16K users x 17K items x 200K links, item text L = 200, 8,001 words, d = 100, word-row
+dropout 0.5) -- and is compared with the reference's trainer loop (models/train_neg_shared.py:34-78,
+models/train_group_neg_shared.py:42-68) written out over the float64 oracle (oracle/epoch_oracle.py) from the same initial
+parameters, the same shuffles (NumPy seed) and the product's own dropout masks:
+  * every one of the 390 per-step losses,
+  * every table / tower parameter / BatchNorm running statistic after the epoch, against the term-count bounds of tests/tolerances.py,
+  * Recall / MAP / Precision@50 over the train candidates and over the cold test items (utils/objectives.py:470-491): the
+    product's evaluator on the product's tables vs the oracle's evaluator on the oracle's tables.
+Sparse SGD (the north-star's optimiser) keeps all of it within 1e-5.  Keras Adam does not -- and cannot in fp32: the test pins
+that with a float32 run of the SAME oracle loop as the yardstick (see test_adam_epoch_...)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from nncf_amd import synthetic  # noqa: E402
+from tests import epoch_parity as ep  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def citeulike():
+    return synthetic.make_citeulike_like(content_len=200, vocab=8001)
+
+
+def _terms(res, data):
+    conf = res["conf"]
+    rows = conf.batch_size_p * (1 + conf.num_negatives)
+    L = data["C"].shape[1]
+    return {"U": rows, "V": rows, "W": rows * L, "Wd": rows, "bd": rows, "gamma": rows, "beta": rows}
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("scheme,loss", [("neg_shared", "skip-gram"),           # BASELINE configs[1]: the headline
+                                         ("group_neg_shared", "log-loss")])    # BASELINE configs[2]
+def test_sgd_epoch_at_the_baseline_shape_matches_the_oracle_loop(citeulike, scheme, loss):
+    res = ep.run_case(citeulike, model="basic_embedding", scheme=scheme, loss=loss, optimizer="sgd", epochs=1)
+    n = res["n_steps"]
+    assert n == 390 and res["got_losses"].size == 390
+    # (1) per-step loss, all 390 steps: north-star's 1e-5 (measured on MI355X: 1.2e-7 / 1.3e-7)
+    lr = ep.loss_report(res)
+    assert lr["first_step_over_1e-5"] is None, lr
+    assert abs(res["got_cost"][1] - res["want_cost"][1]) <= 1e-5 * max(1.0, abs(res["want_cost"][1]))
+    # (2) every parameter after 390 updates within its term-count bound (measured worst: 0.43 of the bound)
+    tr = ep.table_report(res, _terms(res, citeulike), updates=n)
+    for name, row in tr.items():
+        if name == "bd":
+            assert row["max_abs_err"] <= 1e-5, row       # rounding residue of a zero gradient (see table_report)
+        else:
+            assert row["worst_err_over_bound"] <= 1.0, (name, row)
+    # (3) Recall / MAP / Precision@50, train candidates and cold test items, each side on its OWN trained tables: 1e-5
+    mr = ep.metric_report(res)[1]
+    for key, row in mr.items():
+        if key.endswith("_users"):
+            assert row["product"] == row["oracle"], (key, row)
+        else:
+            assert abs(row["diff"]) <= 1e-5, (key, row)
+    assert mr["test_recall@50"]["oracle"] > 0.005        # not a comparison of empty hit lists
+
+
+@pytest.mark.timeout(1800)
+def test_adam_epoch_at_the_baseline_shape_against_the_oracle_loop_and_its_float32_control(citeulike):
+    """Keras Adam(0.01) (the reference's default optimiser, configs/basic_embedding_conf.py:59-60), dense: every entry of every
+    table moves by ~lr * m / sqrt(v) each step, i.e. by ~lr * sign(g) where |g| is small -- an entry whose gradient is within
+    fp32 rounding of zero flips direction between ANY two fp32 evaluation orders (and between fp32 and float64), and the Dense
+    bias in front of the BatchNorm (true gradient: zero) random-walks on its rounding residue.  A trajectory therefore leaves
+    the 1e-5 band after ~150 steps whatever computes it in fp32.  Pinned here:
+      * the first 64 steps (before the amplification) hold 1e-5 per step;
+      * the whole epoch stays within 2e-3 per step and the epoch's mean cost within 1e-4;
+      * Recall@50 / MAP@50 within 1.5e-3 of the oracle's;
+      * the yardstick: the SAME oracle loop run in float32 drifts from the float64 one at least a third as far as the product
+        does (per-step loss) -- the gap is the arithmetic's, not the kernels'."""
+    res = ep.run_case(citeulike, model="basic_embedding", scheme="neg_shared", loss="skip-gram", optimizer="adam", epochs=1,
+                      control_fp32=True)
+    g, w = res["got_losses"], res["want_losses"]
+    rel = np.abs(g - w) / np.maximum(1.0, np.abs(w))
+    assert rel[:64].max() <= 1e-5, (int(rel[:64].argmax()), float(rel[:64].max()))
+    assert rel.max() <= 2e-3, (int(rel.argmax()), float(rel.max()))
+    assert abs(res["got_cost"][1] - res["want_cost"][1]) <= 1e-4 * abs(res["want_cost"][1])
+    mr = ep.metric_report(res)[1]
+    for key in ("train_recall@50", "test_recall@50", "train_map@50", "test_map@50"):
+        assert abs(mr[key]["diff"]) <= 1.5e-3, (key, mr[key])
+    cr = ep.control_report(res)
+    assert cr["max_rel_step_loss_diff"] >= rel.max() / 3.0, (cr["max_rel_step_loss_diff"], float(rel.max()))
+    assert cr["first_step_over_1e-5"] is not None and cr["first_step_over_1e-5"] < 390

@@ -94,6 +94,33 @@ def test_fused_evaluator_breaks_ties_like_the_two_kernel_path():
         assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), which
 
 
+def test_fused_evaluator_ranks_nan_scores_like_the_two_kernel_path():
+    """A diverged model: NaN / inf scores.  eval_topk_kernel ranks a NaN by its bits (orderable(): a positive NaN
+    above +inf, a negative one below -inf); the fused kernel's float pre-filter must let NaNs through to the same 64-bit key
+    test -- `!(score < threshold)`, not `score >= threshold` -- or the two paths report different metrics."""
+    data = synthetic.make_citeulike_like(users=200, items=900, train_links=5000, seed=8)
+    conf = _conf(32, norm=False)
+    helper = get_data(dict(data), conf, rand_seed=5)
+    md = get_model(conf, helper, "mf", seed=4)
+    head = md["model_neg_shared"]
+    eng = head.engine
+    U = eng.U.cpu().numpy().copy()
+    V = eng.V.cpu().numpy().copy()
+    U[3:9] = np.nan                  # every score of these users is NaN
+    U[20, 0] = np.inf                # +-inf scores (and inf - inf = NaN further down the dot product)
+    U[21, 0] = -np.inf
+    V[5::97] = np.nan                # NaN columns for every user: scattered over the stages
+    V[11, 3] = -np.nan
+    V[400:420, 1] = np.inf
+    eng.set_tables(U, V)
+    ev = Evaluator(helper, helper.data_spec, conf)
+    for which in ("train", "test"):
+        (rf, mf_, vf), (rt, mt, vt) = _both_paths(ev, head, which, 50)
+        assert torch.equal(vf, vt)
+        keep = vt == 1
+        assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), which
+
+
 def test_nncf_eval_whole_refuses_what_it_does_not_take():
     data = synthetic.make_citeulike_like(users=100, items=90, train_links=1000, seed=8)
     conf = _conf(24)
