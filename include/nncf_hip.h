@@ -391,6 +391,12 @@ int nncf_tower_set_content_id(nncf_tower* t, float* d_id_table, float v_reg, flo
  * hash of (nncf_tower_set_dropout's seed, train-forward index, row, column); nncf_tower_dense_mask writes the mask
  * (including its 1/keep scale) of forward `step_index` for m rows, [m][item_dim] floats, for tests. */
 int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout);
+/* conf.no_BN (modules/content/mean_pool.py:88-93: `assert conf.no_BN == True` succeeds, so BatchNormalization1 is never
+ * applied): the tail is Dense -> Activation(dense_hidden_actv) -> Dropout(dense_hidden_dropout).  The Dense bias now has a
+ * gradient of its own (sum of dz), bn_gamma / bn_beta / the running statistics are never read or written.  Steps run on the
+ * materialised block like the other tail variants; mean-pool tower only (the CNN tower's convolution keeps its BatchNorm:
+ * cnn_model.py:93 would drop that one too), no gradient export. */
+int nncf_tower_set_no_bn(nncf_tower* t, int32_t no_bn);
 /* A tower WITHOUT item_dense_transform (mean_pool.py:78-101, cnn_model.py:112-130: the else branch): the pooled block -- the
  * mean / max of the word rows, or the pooled conv features -- is the item row itself (its width must be item_dim); no Dense,
  * BatchNorm or Activation, no parameters behind the pooling.  Steps run on the materialised block as for the tail variants

@@ -158,6 +158,7 @@ def _declare(lib):
         "nncf_tower_set_c_reg": [vp, f32],
         "nncf_tower_set_dense_tail": [vp, i32, f32],
         "nncf_tower_set_no_dense": [vp, i32],
+        "nncf_tower_set_no_bn": [vp, i32],
         "nncf_tower_dense_mask": [vp, u64, i64, vp, vp],
         "nncf_tower_sync_params": [vp, vp],
         "nncf_tower_conv_mask": [vp, u64, i64, vp, vp],

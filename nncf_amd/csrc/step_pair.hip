@@ -33,13 +33,23 @@
 #include "step.h"
 #include "step_pair.h"
 
+// scheduling fence of the large-batch kernels' operand pipelines (-DNNCF_WIDE_FENCES=0: the compiler's own schedule, for A/B runs)
+#ifndef NNCF_WIDE_FENCES
+#define NNCF_WIDE_FENCES 0       // as step_fused.hip: measured without effect, off
+#endif
+#if NNCF_WIDE_FENCES
+#define NNCF_WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define NNCF_WIDE_FENCE() ((void)0)
+#endif
+
 namespace nncf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kPNB = 128;          // opposite rows per stage
-constexpr int kPDP = 128 + 4;      // LDS row pitch (floats): conflict-free ds_read_b128 fragments
-constexpr int kPGP = kPNB + 4;     // pitch of the gradient tile
+constexpr int kPDP = 128 + 8;      // LDS row pitch (floats): pitch / 4 = 2 (mod 16) -- conflict-free ds_read_b128 fragments for the
+constexpr int kPGP = kPNB + 8;     // hardware's lane groups (step_fused.hip kFDP; rounds 2-5: 128 + 4, one 2-way conflict per group)
 constexpr int kPOP = 132;          // pitch of the output rows
 
 template <int MT>
@@ -328,11 +338,14 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       float4 fb[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) fb[t] = H16 ? pb4[(t & 3) * 4 + (t >> 2) * 16] : pb4[4 * t];   // H16: t < 4 hi plane, t >= 4 lo plane
-      auto s_one = [&](int mt) -> f32x4 {
+      // fragments requested a whole tile ahead of the MFMAs that consume them, behind scheduling fences (as step_fused.hip wide_body,
+      // round 6: left alone the compiler put every ds_read next to its MFMA behind an s_waitcnt lgkmcnt(0))
+      auto s_load = [&](int mt, float4* fa) {
         const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kPDP + 4 * kq);
-        float4 fa[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) fa[t] = H16 ? pa4[(t & 3) * 4 + (t >> 2) * 16] : pa4[4 * t];
+      };
+      auto s_mma = [&](const float4* fa) -> f32x4 {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (H16) {   // as step_fused.hip wide_body: acc0 hi.hi, acc1 the cross terms (times 2048)
 #pragma unroll
@@ -351,6 +364,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
         }
         return acc0 + acc1;
       };
+      float4 faA[8], faB[8];   // tile mt's fragments live in faA (mt even) / faB (mt odd)
+      s_load(0, faA);
+      if (MT > 1) s_load(1, faB);
+      if (H16) NNCF_WIDE_FENCE();
       // The score tiles are computed TRANSPOSED (as step_fused.hip wide_body): a lane holds ONE own row per row tile (16 mt + x)
       // against FOUR consecutive streamed columns (16 wave + 4 kq + r) -- the own row's multiplicity / anchor and key are two LDS
       // reads per tile (not per element), the dL/dS entries 8 contiguous bytes of each plane.
@@ -361,11 +378,13 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       const float od[4] = {od4.x, od4.y, od4.z, od4.w};
       const int nleft = n_opp - st * kPNB - jq;   // column jq + r is real iff r < nleft
       float tsum[4] = {0.f, 0.f, 0.f, 0.f};
-      f32x4 acc = s_one(0);
+      f32x4 acc = s_mma(faA);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 nxt = acc;
-        if (mt + 1 < MT) nxt = s_one(mt + 1);
+        if (mt + 2 < MT) s_load(mt + 2, (mt & 1) ? faB : faA);
+        if (H16) NNCF_WIDE_FENCE();
+        if (mt + 1 < MT) nxt = s_mma((mt & 1) ? faA : faB);
         const int i = 16 * mt + x;
         const float ci = sCnt[i];   // POS: the own row's multiplicity; else the own position's anchor (NaN: no position in this slot)
         const int ki = sKey[i];
@@ -470,20 +489,44 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const int32_t* __re
       // the stage's rows as the MFMA's [k][n] operand by transpose reads (devutil.h lds_read_tr8): lane x of group kq names row
       // 8 kq + x / 4 [+ 4], columns 16 wave + 4 (x % 4) .. + 3 and receives column 16 wave + x of rows 8 kq .. + 3 [+ 4]
       const _Float16* pcol = reinterpret_cast<const _Float16*>(sOpp) + (size_t)(8 * kq + (x >> 2)) * (2 * kPDP) + 16 * wave + 4 * (x & 3);
-#pragma unroll
-      for (int t = 0; t < kPNB / 32; ++t) {
+      // k-step t + 1's operands in flight under k-step t's 3 MT MFMAs: two operand sets, scheduling fences (round 6)
+      auto b_load = [&](int t, f16x8& vh, f16x8& vl, f16x8* gh, f16x8* gl) {
         const _Float16* pr = pcol + (size_t)(32 * t) * (2 * kPDP);
-        const f16x8 vh = lds_read_tr8(pr, pr + 4 * (2 * kPDP));
-        const f16x8 vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kPDP));
+        vh = lds_read_tr8(pr, pr + 4 * (2 * kPDP));
+        vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kPDP));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float4* pg4 = reinterpret_cast<const float4*>(sG + (16 * mt + x) * kPGP + 4 * kq);
-          const f16x8 gh = __builtin_bit_cast(f16x8, pg4[4 * t]), gl = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
-          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vl, accD1[mt], 0, 0, 0);
-          accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh, vh, accD0[mt], 0, 0, 0);
-          accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl, vh, accD1[mt], 0, 0, 0);
+          gh[mt] = __builtin_bit_cast(f16x8, pg4[4 * t]);
+          gl[mt] = __builtin_bit_cast(f16x8, pg4[16 + 4 * t]);
         }
-      }
+      };
+      // product by product over the row tiles (an accumulator's next use MT MFMAs away); per accumulator the same sequence of
+      // products as tile by tile: the same bits
+      auto b_mma = [&](const f16x8& vh, const f16x8& vl, const f16x8* gh, const f16x8* gl) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vl, accD1[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vh, accD0[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) accD1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mt], vh, accD1[mt], 0, 0, 0);
+      };
+      static_assert(kPNB / 32 == 4, "the back-GEMM pipeline below is written for four k-steps of 32");
+      f16x8 vhA, vlA, ghA[MT], glA[MT], vhB, vlB, ghB[MT], glB[MT];
+      b_load(0, vhA, vlA, ghA, glA);
+      b_load(1, vhB, vlB, ghB, glB);
+      NNCF_WIDE_FENCE();
+      b_mma(vhA, vlA, ghA, glA);
+      NNCF_WIDE_FENCE();
+      b_load(2, vhA, vlA, ghA, glA);
+      NNCF_WIDE_FENCE();
+      b_mma(vhB, vlB, ghB, glB);
+      NNCF_WIDE_FENCE();
+      b_load(3, vhB, vlB, ghB, glB);
+      NNCF_WIDE_FENCE();
+      b_mma(vhA, vlA, ghA, glA);
+      NNCF_WIDE_FENCE();
+      b_mma(vhB, vlB, ghB, glB);
     } else if (back_wave && update) {
       const float* pbv = sOpp + (4 * kq) * kPDP + 16 * wave + x;
 #pragma unroll

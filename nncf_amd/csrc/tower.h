@@ -13,7 +13,7 @@ namespace nncf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTP = 128;       // LDS pitch of pooled rows
-constexpr int kZP = 132;       // LDS pitch of dz rows (16-byte aligned, 4 banks apart)
+constexpr int kZP = 136;       // LDS pitch of dz rows: pitch / 4 = 2 (mod 16), conflict-free ds_read_b128 fragments (step_fused.hip kFDP)
 constexpr int kTowerWG = 64;   // at most this many workgroups emit statistics partials
 constexpr int kRowsPerK = 256;   // rows per K-part of the weight-gradient tiles
 
@@ -150,6 +150,8 @@ struct TowerArgs {
   int no_dense;              // no item_dense_transform (mean_pool.py:78-101 else branch): the pooled block IS the item block
   int tail_act;              // kAct*: 0 = relu (the presets)
   int tail_pre;              // the backward's dA already carries mask * act'(y)
+  int no_bn;                 // conf.no_BN (mean_pool.py:88-93): Dense -> Activation, no BatchNormalization in between -- the statistics
+                             // slots hold the identity (mu 0, inv 1, mul 1, add 0), the BatchNorm-backward sums are zero, gamma reads 1
   float tail_keep;           // Dropout retain probability of this forward (1 = off)
   unsigned long long tail_seed;
   float c_reg;               // 0: off (every preset of the reference)
@@ -408,7 +410,8 @@ struct nncf_tower {
   uint64_t tail_step = 0;        // train-mode forwards since nncf_tower_set_dense_tail / set_dropout (mask index)
   float* dA_tail = nullptr;      // own allocation [max_rows][item_dim]: dA * mask * act'(y)
   int no_dense = 0;              // nncf_tower_set_no_dense: no Dense / BatchNorm / Activation behind the pooling
-  bool tail_variant() const { return tail_act != 0 || tail_drop > 0.f; }
+  int no_bn = 0;                 // nncf_tower_set_no_bn: conf.no_BN (mean_pool.py:88-93)
+  bool tail_variant() const { return tail_act != 0 || tail_drop > 0.f || no_bn; }
   bool tail_general() const { return tail_variant() || no_dense; }   // the step runs on the materialised item block
   // conf.c_reg (nncf_tower_set_c_reg; TowerArgs::c_reg)
   float c_reg = 0.f;

@@ -206,10 +206,17 @@ __global__ void __launch_bounds__(256, BIG ? 6 : 1) tower_pool_kernel(TowerArgs 
       const float4 g = reinterpret_cast<const float4*>(a.gamma)[tid], bt = reinterpret_cast<const float4*>(a.beta)[tid];
       const float4 mu = reinterpret_cast<const float4*>(a.rm)[tid], var = reinterpret_cast<const float4*>(a.rv)[tid];
       float4 o;
-      o.x = tail_act(a.tail_act, g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x);
-      o.y = tail_act(a.tail_act, g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y);
-      o.z = tail_act(a.tail_act, g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z);
-      o.w = tail_act(a.tail_act, g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w);
+      if (a.no_bn) {   // conf.no_BN: Activation(Dense(h)) (mean_pool.py:88-96)
+        o.x = tail_act(a.tail_act, z.x);
+        o.y = tail_act(a.tail_act, z.y);
+        o.z = tail_act(a.tail_act, z.z);
+        o.w = tail_act(a.tail_act, z.w);
+      } else {
+        o.x = tail_act(a.tail_act, g.x * (z.x - mu.x) * rsqrtf(var.x + a.eps) + bt.x);
+        o.y = tail_act(a.tail_act, g.y * (z.y - mu.y) * rsqrtf(var.y + a.eps) + bt.y);
+        o.z = tail_act(a.tail_act, g.z * (z.z - mu.z) * rsqrtf(var.z + a.eps) + bt.z);
+        o.w = tail_act(a.tail_act, g.w * (z.w - mu.w) * rsqrtf(var.w + a.eps) + bt.w);
+      }
       reinterpret_cast<float4*>(a.E + (int64_t)s * a.d)[tid] = o;
     }
   }
@@ -282,6 +289,18 @@ __device__ __forceinline__ void column_sums(const TowerArgs& a, int nv, F&& elem
 
 // column totals of the shifted sums -> mu, inv, var, fused scale / shift, running statistics
 __device__ __forceinline__ void stats_finalize(const TowerArgs& a, int c, float t1, float t2, int nv) {
+  if (a.no_bn) {   // conf.no_BN: y = z -- the identity in the statistics slots; the running statistics do not exist
+    if (c < 128) {
+      float* mi = a.ws + ws_muinv();
+      const bool real = c < a.d;
+      mi[c] = 0.f;
+      mi[128 + c] = real ? 1.f : 0.f;
+      mi[256 + c] = 0.f;
+      mi[384 + c] = real ? 1.f : 0.f;
+      mi[512 + c] = 0.f;
+    }
+    return;
+  }
   if (c < a.d) {
     const float rn = 1.f / (float)max(nv, 1);
     const float m1 = t1 * rn;
@@ -435,6 +454,7 @@ __global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
     if (c < a.d) merge_partials(part, gridDim.x, c, t1, t2);
   }
   if (c < a.d) {
+    if (a.no_bn) t1 = t2 = 0.f;      // no BatchNorm: dz = dy (nothing to subtract), gamma / beta have no gradient
     a.ws[ws_bfin() + c] = t1;        // sum dy       (= dbeta)
     a.ws[ws_bfin() + 128 + c] = t2;  // sum dy*xhat  (= dgamma)
   }
@@ -504,7 +524,7 @@ __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int
     pinv = mi[128 + tid];
     pmul = mi[384 + tid];
     padd = mi[512 + tid];
-    pg = a.gamma[tid];
+    pg = a.no_bn ? 1.f : a.gamma[tid];   // (no_BN: dz = 1 * 1 / n * (n dy - 0 - xhat 0) = dy)
   }
   {
     // sum dy (= dbeta) by threads [0, 128), sum dy*xhat (= dgamma) by threads [128, 256): the partials of the step's apply
@@ -1330,6 +1350,7 @@ TowerArgs base_args(const nncf_tower* t) {
   a.no_dense = t->no_dense;
   a.tail_act = t->tail_act;
   a.tail_pre = 0;
+  a.no_bn = t->no_bn;
   a.tail_keep = 1.f;
   a.tail_seed = 0;
   a.c_reg = t->c_reg;
@@ -1981,6 +2002,20 @@ int nncf_tower_set_no_dense(nncf_tower* t, int32_t no_dense) {
     NNCF_REQUIRE(!t->gexp && !t->tail_variant(), "the Dense-less tower has no gradient export and no Dense tail variant");
   }
   t->no_dense = no_dense ? 1 : 0;
+  return NNCF_OK;
+}
+
+int nncf_tower_set_no_bn(nncf_tower* t, int32_t no_bn) {
+  NNCF_REQUIRE(t != nullptr, "tower is NULL");
+  NNCF_REQUIRE(!no_bn || !t->no_dense, "the Dense-less tower has no BatchNormalization to leave out");
+  NNCF_REQUIRE(!no_bn || t->cfg.conv_filters == 0, "conf.no_BN is built for the mean-pool tower (the CNN tower's conv BatchNorm stays)");
+  NNCF_REQUIRE(!no_bn || !t->gexp, "conf.no_BN is not built for the data-parallel gradient export");
+  if (no_bn && !t->dA_tail) {
+    DeviceGuard guard(t->device);
+    if (hipMalloc(&t->dA_tail, sizeof(float) * (size_t)t->cfg.max_rows * t->cfg.item_dim) != hipSuccess)
+      return fail(NNCF_ERR_NOMEM, "Dense tail gradient buffer allocation failed");
+  }
+  t->no_bn = no_bn ? 1 : 0;
   return NNCF_OK;
 }
 

@@ -281,6 +281,13 @@ class MeanPoolTower(object):
             _lib.check(self._L.nncf_tower_set_dense_tail(self.handle, self.DENSE_ACTIVATIONS.index(activation), self.dense_dropout))
         self.version += 1
 
+    def set_no_bn(self, no_bn=True):
+        """conf.no_BN (mean_pool.py:88-93): Dense -> Activation -> Dropout without the BatchNormalization."""
+        self.no_bn = bool(no_bn)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.nncf_tower_set_no_bn(self.handle, int(self.no_bn)))
+        self.version += 1
+
     def dense_mask(self, step_index, m):
         """Dropout(dense_hidden_dropout) mask of the step_index-th train-mode forward, first m rows (checkers)."""
         out = torch.empty(m, self.d, dtype=torch.float32, device=self.device)

@@ -465,9 +465,13 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
     # mean_pool.py:78-101 / cnn_model.py:112-130: Dense(dense_hidden_dim) -> BatchNorm -> Activation -> Dropout.  The tower's
     # output is the item row: dense_hidden_dim must be item_dim; a tower WITHOUT the transform (or with conf.no_BN) is not built.
     # No transform at all (item_dense_transform falsy): the pooled block is the item row -- its width must be item_dim.
-    if idt and (idt["dense_hidden_dim"] != conf.item_dim or getattr(conf, "no_BN", False)):
-        raise NotImplementedError("item_dense_transform must be Dense(item_dim) + BatchNormalization, or absent (got %r, no_BN = %r)"
-                                  % (idt, getattr(conf, "no_BN", False)))
+    # conf.no_BN (mean_pool.py:88-93 `assert conf.no_BN == True`: any other value, or no attribute, keeps the BatchNormalization)
+    no_bn = getattr(conf, "no_BN", None) == True   # noqa: E712  (the reference's own comparison)
+    if idt and idt["dense_hidden_dim"] != conf.item_dim:
+        raise NotImplementedError("item_dense_transform must be Dense(item_dim), or absent (got %r)" % (idt,))
+    if no_bn and conv is not None:
+        raise NotImplementedError("conf.no_BN is built for basic_embedding (cnn_model.py:93 would drop the convolution's "
+                                  "BatchNormalization too: not built)")
     if not idt:
         pooled = int(list(conf.num_filters)[0]) * len(conv["filter_lens"]) if conv is not None else conf.word_dim
         if pooled != conf.item_dim:
@@ -487,6 +491,8 @@ def _get_model_basic_embedding(conf, data_helper, device, seed, conv=None):
         tower.set_content_id(getattr(conf, "v_reg", 0.0), seed=seed)
     if idt and (idt["dense_hidden_actv"] != "relu" or float(idt["dense_hidden_dropout"]) != 0.):   # mean_pool.py:96-97
         tower.set_dense_tail(idt["dense_hidden_actv"], float(idt["dense_hidden_dropout"]))
+    if idt and no_bn:                                                   # mean_pool.py:88-93
+        tower.set_no_bn(True)
     if float(getattr(conf, "c_reg", 0) or 0) != 0.0:                    # mean_pool.py:56-59, cnn_model.py:45-48
         tower.set_c_reg(conf.c_reg)
     core = _TowerCore(engine, tower, data_spec.item_count, kw, device)

@@ -366,6 +366,7 @@ class TowerOracle(object):
         self.no_dense = False          # item_dense_transform falsy (mean_pool.py:78-101, else branch): the pooled block is the item row
         self.extra_loss = 0.0
         self.bag = None                # use_bag(): items x words count matrix (scipy CSR) -- the same sums, bag by bag
+        self.no_bn = False             # conf.no_BN (mean_pool.py:88-93): Dense -> Activation -> Dropout, no BatchNormalization
 
     def use_bag(self):
         """Average pooling as a bag of words: sum_l W[tok[l]] * s[tok[l]] == sum_w count[item, w] * s[w] * W[w].  The same
@@ -478,16 +479,21 @@ class TowerOracle(object):
                 self.extra_loss += float(self.c_reg * np.sum(np.mean(E * E, axis=0)))
             return out
         z = h @ self.Wd + self.bd
-        if train:
-            mu = z.mean(axis=0)
-            var = ((z - mu) ** 2).mean(axis=0)
+        if self.no_bn:     # mean_pool.py:88-93: `assert conf.no_BN == True` holds, BatchNormalization1 is never applied
+            y = z
+            if train:
+                self.cache.update(h=h, y=y)
         else:
-            mu, var = self.rm, self.rv
-        inv = 1.0 / np.sqrt(var + self.eps)
-        xhat = (z - mu) * inv
-        y = self.gamma * xhat + self.beta
-        if train:
-            self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
+            if train:
+                mu = z.mean(axis=0)
+                var = ((z - mu) ** 2).mean(axis=0)
+            else:
+                mu, var = self.rm, self.rv
+            inv = 1.0 / np.sqrt(var + self.eps)
+            xhat = (z - mu) * inv
+            y = self.gamma * xhat + self.beta
+            if train:
+                self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
         act = self.ACTIVATIONS[self.dense_act][0](y)
         if train and self.dense_mask is not None:
             act = act * self.dense_mask[:len(act)]
@@ -540,10 +546,13 @@ class TowerOracle(object):
         dy = dA * self.ACTIVATIONS[self.dense_act][1](c["y"])
         if self.dense_mask is not None:
             dy = dy * self.dense_mask[:len(dy)]
-        dgamma = (dy * c["xhat"]).sum(axis=0)
-        dbeta = dy.sum(axis=0)
-        dxhat = dy * self.gamma
-        dz = c["inv"] / n * (n * dxhat - dxhat.sum(axis=0) - c["xhat"] * (dxhat * c["xhat"]).sum(axis=0))
+        if self.no_bn:     # y = z: the Dense bias has a gradient of its own, gamma / beta none
+            dgamma, dbeta, dz = np.zeros_like(self.gamma), np.zeros_like(self.beta), dy
+        else:
+            dgamma = (dy * c["xhat"]).sum(axis=0)
+            dbeta = dy.sum(axis=0)
+            dxhat = dy * self.gamma
+            dz = c["inv"] / n * (n * dxhat - dxhat.sum(axis=0) - c["xhat"] * (dxhat * c["xhat"]).sum(axis=0))
         dWd = c["h"].T @ dz
         dbd = dz.sum(axis=0)
         dh = dz @ self.Wd.T
@@ -551,8 +560,9 @@ class TowerOracle(object):
         self.grads.update(self._front_backward(dh.astype(self.dt)))
         dW = self.grads["W"]
         self._c_reg_grad(dW)
-        self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
-        self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
+        if not self.no_bn:
+            self.rm = self.mom * self.rm + (1 - self.mom) * c["mu"]
+            self.rv = self.mom * self.rv + (1 - self.mom) * c["var"]
         if getattr(self, "export_only", False):   # data-parallel: gradients leave, nothing is applied
             return
         if conf is None or conf.optimizer == "sgd":

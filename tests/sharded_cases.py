@@ -39,14 +39,27 @@ def tables(seed=0):
     return (rs.uniform(-.5, .5, (NU, D)).astype(np.float32), rs.uniform(-.5, .5, (NI, D)).astype(np.float32))
 
 
-def weak_batches(world, seed=1):
-    """per rank: STEPS batches of B links whose users lie in the rank's range; odd steps repeat few items"""
+def weak_batches(world, seed=1, skew=False):
+    """per rank: STEPS batches of B links whose users lie in the rank's range; odd steps repeat few items.
+    skew: the variable-split cases a one-rank run cannot produce -- rank 0 asks ONLY its own item shard
+    (an EMPTY request to every other peer, every step of every chunk), the last rank asks ~nine ids of shard 0 for each of its
+    own (lopsided splits), and in steps 5 and 66 (one in each chunk) one single item B times (a one-row exchange)."""
     rs = np.random.RandomState(seed)
-    us = shard_size(NU, world)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
     out = []
     for r in range(world):
         lo, hi = r * us, min(NU, (r + 1) * us)
-        out.append([(rs.randint(lo, hi, B), rs.randint(0, 40 if t % 2 else NI, B)) for t in range(STEPS)])
+        steps = []
+        for t in range(STEPS):
+            cid = rs.randint(0, 40 if t % 2 else NI, B)
+            if skew and r == 0:
+                cid = rs.randint(0, 40 if t % 2 else isz, B)
+            elif skew and r == world - 1:
+                cid = np.where(rs.rand(B) < 0.9, rs.randint(0, isz, B), rs.randint(r * isz, NI, B))
+                if t in (5, 66):
+                    cid = np.full(B, 7)
+            steps.append((rs.randint(lo, hi, B), cid))
+        out.append(steps)
     return out
 
 
@@ -60,12 +73,12 @@ def global_batches(seed=7):
     return out
 
 
-def simulate_weak(loss, world):
+def simulate_weak(loss, world, skew=False):
     """every rank's batch sees the pre-step tables; user rows are disjoint across ranks; item gradients are summed over
     ranks (rank order) and applied once"""
     c = conf(loss)
     U, V = tables()
-    bt = weak_batches(world)
+    bt = weak_batches(world, skew=skew)
     lr = np.float32(c.learn_rate)
     losses = []
     for t in range(STEPS):

@@ -37,7 +37,7 @@ def main():
         losses = torch.zeros(sc.STEPS, dtype=torch.float32, device=be.device)
         if case == "weak":
             tr = ShardedNegShared(be, sc.NU, sc.NI, sc.B, sc.D)
-            bt = sc.weak_batches(world)[rank]
+            bt = sc.weak_batches(world, skew=os.environ.get("NNCF_TEST_SKEW") == "1")[rank]
             uid = be.ids(np.concatenate([u for u, _ in bt]) - rank * us)
             cid = be.ids(np.concatenate([c for _, c in bt]))
         else:

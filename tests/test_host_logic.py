@@ -262,7 +262,7 @@ def test_bench_prices_the_large_batch_kernels_on_the_f16_pipe():
 
 def test_dense_less_tower_needs_the_pooled_width_to_be_item_dim():
     """conf.item_dense_transform = None (mean_pool.py:78-101, the else branch): the pooled block is the item row, so word_dim (or
-    the conv filters) must equal item_dim -- checked in get_model before any device work; conf.no_BN stays refused."""
+    the conv filters) must equal item_dim -- checked in get_model before any device work."""
     from nncf_amd.data_utils import get_data
     from nncf_amd.model_framework import get_model
     data = synthetic.make_citeulike_like(users=50, items=40, train_links=400, seed=3, content_len=12, vocab=30)
@@ -270,7 +270,9 @@ def test_dense_less_tower_needs_the_pooled_width_to_be_item_dim():
     conf.item_dense_transform = None
     with pytest.raises(ValueError, match="pooled width"):
         get_model(conf, get_data(dict(data), conf, rand_seed=5), "basic_embedding")
-    conf2 = get_conf("synthetic", "best", {"reset_after_getconf": True}, model_choice="basic_embedding")
+    # conf.no_BN is built for the mean-pool tower since round 6 (tests/test_tower_gpu.py::test_no_bn_tower_matches_oracle);
+    # the CNN tower, whose convolution BatchNorm it would drop too (cnn_model.py:93), still refuses -- before any device work
+    conf2 = get_conf("synthetic", "best", {"reset_after_getconf": True}, model_choice="cnn_embedding")
     conf2.no_BN = True
-    with pytest.raises(NotImplementedError, match="no_BN"):
-        get_model(conf2, get_data(dict(data), conf2, rand_seed=5), "basic_embedding")
+    with pytest.raises(NotImplementedError):
+        get_model(conf2, get_data(dict(data), conf2, rand_seed=5), "cnn_embedding")

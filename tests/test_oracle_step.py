@@ -375,6 +375,87 @@ def test_tower_oracle_dense_tail_variants_vs_autograd(act):
     np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
 
 
+@pytest.mark.parametrize("act", ["relu", "tanh", "softsign"])
+def test_tower_oracle_no_bn_vs_autograd(act):
+    """conf.no_BN (mean_pool.py:88-93): Dense -> Activation -> Dropout(mask) without the BatchNormalization -- loss and every
+    gradient of the oracle against torch autograd; the Dense bias has a real gradient, gamma / beta / running statistics none."""
+    rs = np.random.RandomState(4)
+    I, L, Wc, wd, d, nu, b = 30, 7, 20, 8, 8, 10, 8
+    C = rs.randint(0, Wc, (I, L))
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = rs.uniform(-.1, .1, d), rs.uniform(.5, 1.5, d), rs.uniform(-.1, .1, d)
+    U = rs.uniform(-.5, .5, (nu, d))
+    mask = (rs.rand(b, d) < 0.8) / 0.8
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="log-loss", u_reg=1e-3, learn_rate=0.1, model_choice="basic_embedding")
+    tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.1, dtype=np.float64)
+    tw.dense_act, tw.dense_mask, tw.no_bn = act, mask, True
+    o = so.StepOracle(U, None, conf, dtype=np.float64, tower=tw)
+    uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+    cid[3] = cid[0]
+    l_o = o.step_neg_shared(uid, cid)
+    tU = torch.tensor(U, requires_grad=True)
+    tp = [torch.tensor(x, requires_grad=True) for x in (W, Wd, bd)]
+    cu, cx = so.tf_unique(cid)
+    z = (tp[0][torch.tensor(C[cu])].sum(1) / L) @ tp[1] + tp[2]
+    f = {"tanh": torch.tanh, "softsign": torch.nn.functional.softsign, "relu": torch.relu}[act]
+    E = f(z) * torch.tensor(mask[:len(cu)])
+    l_t = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf)
+    l_t.backward()
+    assert abs(l_o - l_t.item()) < 1e-10
+    for name, t in zip(("W", "Wd", "bd"), tp):
+        np.testing.assert_allclose(tw.grads[name], t.grad.numpy(), atol=1e-10, err_msg=name)
+    assert np.abs(tw.grads["bd"]).max() > 1e-4
+    np.testing.assert_allclose(o.last["dU"], tU.grad.numpy(), atol=1e-10)
+    for k, v in (("gamma", ga), ("beta", be), ("rm", np.zeros(d)), ("rv", np.ones(d))):   # no BatchNormalization: nothing of it moves
+        assert np.array_equal(getattr(tw, k), v), k
+    # inference phase: act(Dense(h)), no statistics
+    Ei = tw.forward(np.arange(5), train=False)
+    hi = tw.W[C[:5]].sum(1) / L
+    np.testing.assert_allclose(Ei, f(torch.tensor(hi @ tw.Wd + tw.bd)).numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_bag_form_of_the_mean_pool_oracle(opt):
+    """TowerOracle.use_bag(): sum over positions == sum over distinct words x counts.  The epoch-long parity loops at the BASELINE
+    shape (oracle/epoch_oracle.py) run the bag form; here it is pinned to the token-wise form (the one checked against autograd
+    above) over several steps with row dropout: loss and every parameter to ~1e-13."""
+    rs = np.random.RandomState(5)
+    I, L, Wc, wd, d, nu, b = 120, 30, 60, 12, 12, 50, 32
+    C = rs.randint(0, Wc, (I, L))
+    C[:, 20:] = 0     # a pad id that fills a third of every item
+    W, Wd = rs.uniform(-.5, .5, (Wc, wd)), rs.uniform(-.5, .5, (wd, d))
+    bd, ga, be = np.zeros(d), np.ones(d), np.zeros(d)
+    U = rs.uniform(-.5, .5, (nu, d))
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss="skip-gram", u_reg=1e-4, learn_rate=0.05, model_choice="basic_embedding",
+                         optimizer=opt)
+    pair = []
+    for bag in (False, True):
+        tw = so.TowerOracle(C, W, Wd, bd, ga, be, 0.05, dtype=np.float64)
+        if bag:
+            tw.use_bag()
+        pair.append((so.StepOracle(U, None, conf, dtype=np.float64, tower=tw), tw))
+    for step in range(5):
+        uid, cid = rs.randint(0, nu, b), rs.randint(0, I, b)
+        scale = (rs.rand(Wc) < 0.6) / 0.6 if step else None
+        ls = []
+        for o, tw in pair:
+            o.row_scale = scale
+            ls.append(o.step_neg_shared(uid, cid))
+        assert abs(ls[0] - ls[1]) <= 1e-12 * max(1, abs(ls[0]))
+    for name in ("W", "Wd", "bd", "gamma", "beta", "rm", "rv"):
+        if opt == "adam" and name in ("bd", "rm"):
+            # the Dense bias in front of a BatchNorm has no gradient: what Adam normalises (m / sqrt(v)) is the rounding residue
+            # of sum_n dz[n] -- ~1e-17 here, a different residue for every summation order -- so bd (and the running mean that
+            # carries it) drifts by ~1e-8 between two float64 evaluations of the SAME algebra; the training forward is blind to it
+            assert np.abs(getattr(pair[0][1], name) - getattr(pair[1][1], name)).max() < 1e-6
+            continue
+        np.testing.assert_allclose(getattr(pair[0][1], name), getattr(pair[1][1], name), rtol=1e-10, atol=1e-12, err_msg=name)
+    np.testing.assert_allclose(pair[0][0].U, pair[1][0].U, rtol=1e-10, atol=1e-13)
+    # (inference reads bd through z and the running mean that trails it by the momentum: Adam's residue drift shows at ~1e-8)
+    tol = dict(rtol=1e-10, atol=1e-13) if opt == "sgd" else dict(rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pair[0][1].forward(np.arange(40), train=False), pair[1][1].forward(np.arange(40), train=False), **tol)
+
+
 def test_tower_oracle_without_the_dense_transform_vs_autograd():
     """item_dense_transform falsy (mean_pool.py:78-101, the else branch): the pooled block is the item row -- loss and gradients of
     the oracle's Dense-less path (with c_reg on) against torch autograd."""

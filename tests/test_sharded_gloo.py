@@ -28,14 +28,28 @@ def _tables(seed=0):
     return (rs.uniform(-.5, .5, (NU, D)).astype(np.float32), rs.uniform(-.5, .5, (NI, D)).astype(np.float32))
 
 
-def _batches(world, seed=1):
-    """per rank: STEPS batches of B links whose users lie in the rank's range."""
+def _batches(world, seed=1, skew=False):
+    """per rank: STEPS batches of B links whose users lie in the rank's range.
+    skew: the variable-split cases a one-rank run cannot produce -- rank 0 asks ONLY its own item shard (every other peer gets
+    an EMPTY request from it, every step), the last rank asks nine items of shard 0 for every one of its own (unequal splits),
+    and in step 1 one single item B times (a one-row exchange); ranks in between ask everybody uniformly."""
     rs = np.random.RandomState(seed)
-    us = shard_size(NU, world)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
     out = []
     for r in range(world):
         lo, hi = r * us, min(NU, (r + 1) * us)
-        out.append([(rs.randint(lo, hi, B), rs.randint(0, NI, B)) for _ in range(STEPS)])
+        steps = []
+        for t in range(STEPS):
+            cid = rs.randint(0, NI, B)
+            if skew and r == 0:
+                cid = rs.randint(0, isz, B)
+            elif skew and r == world - 1:
+                own = rs.randint(r * isz, NI, B)
+                cid = np.where(rs.rand(B) < 0.9, rs.randint(0, isz, B), own)
+                if t == 1:
+                    cid = np.full(B, 3)
+            steps.append((rs.randint(lo, hi, B), cid))
+        out.append(steps)
     return out
 
 
@@ -327,12 +341,12 @@ class ReplicatedNumpyBackend(_CompactChunks):
             self._gather(index + 1)
 
 
-def simulate_global_steps(loss, world):
+def simulate_global_steps(loss, world, skew=False):
     """Single-process restatement: every rank's batch sees the pre-step tables; user rows are
     disjoint across ranks; item gradients are summed over ranks (rank order) and applied once."""
     conf = _conf(loss)
     U, V = _tables()
-    batches = _batches(world)
+    batches = _batches(world, skew=skew)
     lr = np.float32(conf.learn_rate)
     losses = []
     for t in range(STEPS):
@@ -371,7 +385,7 @@ def _worker(rank, world, port, loss, ret):
     dist.destroy_process_group()
 
 
-def _worker_chunked(rank, world, port, loss, ret):
+def _worker_chunked(rank, world, port, loss, ret, skew=False):
     """the same global steps through ShardedNegShared.run_epoch (plans + id all-to-all batched per chunk)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -382,7 +396,7 @@ def _worker_chunked(rank, world, port, loss, ret):
     be = ChunkedNumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, isz,
                              rank * isz)
     tr = ShardedNegShared(be, NU, NI, B, D)
-    bt = _batches(world)[rank]
+    bt = _batches(world, skew=skew)[rank]
     uid = torch.from_numpy(np.concatenate([(u - rank * us) for u, _ in bt]).astype(np.int32))
     cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
     losses = torch.zeros(STEPS)
@@ -425,6 +439,30 @@ def test_world2_chunked_epoch_matches_single_process_restatement(loss):
     mp.spawn(_worker_chunked, args=(world, _free_port(), loss, ret), nprocs=world, join=True)
     U, V, losses = simulate_global_steps(loss, world)
     us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_ = ret[r]
+        np.testing.assert_allclose(Ur, U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vr, V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+        for t in range(STEPS):
+            assert abs(lr_[t] - losses[t][r]) < 1e-5 * max(1, abs(losses[t][r]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_chunked_epoch_with_unequal_splits_and_an_empty_peer(loss, world):
+    """the variable-split exchange with UNEQUAL per-peer counts and EMPTY peers (rank 0 asks nobody but
+    itself; the last rank sends nine ids to shard 0 for each of its own, and one single row in step 1) -- the cases the
+    one-rank RCCL run on the GPU box (counts = everything to oneself) cannot produce.  Same single-process restatement."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_chunked, args=(world, _free_port(), loss, ret, True), nprocs=world, join=True)
+    U, V, losses = simulate_global_steps(loss, world, skew=True)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    # the premise: rank 0's requests never leave its shard, the last rank's splits are lopsided
+    bt = _batches(world, skew=True)
+    assert all((c < isz).all() for _, c in bt[0])
+    last = np.concatenate([c for _, c in bt[world - 1]])
+    assert (last < isz).mean() > 0.8 and len(np.unique(bt[world - 1][1][1])) == 1
     for r in range(world):
         Ur, Vr, lr_ = ret[r]
         np.testing.assert_allclose(Ur, U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)

@@ -35,7 +35,7 @@ def _free_port():
 def _run_ranks(case, world, tmp_path, loss="skip-gram", optimizer="sgd", **env_extra):
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    for k in ("NNCF_SHARD_TRANSPORT", "NNCF_SHARD_NOALIAS", "NNCF_COMM_SELF_VIA_RCCL", "NNCF_TEST_BACKEND", "NNCF_TEST_BIAS"):
+    for k in ("NNCF_SHARD_TRANSPORT", "NNCF_SHARD_NOALIAS", "NNCF_COMM_SELF_VIA_RCCL", "NNCF_TEST_BACKEND", "NNCF_TEST_BIAS", "NNCF_TEST_SKEW"):
         env.pop(k, None)
     env.update(env_extra)
     os.makedirs(str(tmp_path), exist_ok=True)
@@ -75,6 +75,24 @@ def test_weak_form_two_ranks_on_one_gpu(tmp_path, loss, transport):
     uniq = sum(len(np.unique(c)) for _, c in sc.weak_batches(world)[0])
     rows_bytes = 2 * uniq * 4 * ((sc.D + 3) // 4 * 4)       # rows out (as an owner ~ as a requester) + gradients
     assert got[0]["wire"] < 1.6 * rows_bytes + 4 * uniq + 2 * 2 * 64 * 4 * 2
+
+
+@pytest.mark.parametrize("transport", ["torch", "callback"])
+def test_weak_form_two_ranks_with_unequal_splits_and_an_empty_peer(tmp_path, transport):
+    """VERDICT r5 item 7b on the product's kernels: rank 0 requests nothing from rank 1 (an EMPTY split in every exchange of
+    every step), rank 1 sends ~nine ids to shard 0 for each of its own and, twice, a single row -- through the HIP plan /
+    gather / scatter-merge kernels and (transport = callback) nncf_shard_run_chunk's own variable-split exchange code, the code
+    that runs over RCCL on a multi-GPU node.  The one-rank RCCL run of the box can only ever send everything to itself."""
+    world = 2
+    got = _run_ranks("weak", world, tmp_path, "skip-gram", NNCF_SHARD_TRANSPORT=transport, NNCF_TEST_SKEW="1")
+    U, V, losses = sc.simulate_weak("skip-gram", world, skew=True)
+    us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+    assert all((c < isz).all() for _, c in sc.weak_batches(world, skew=True)[0])      # the premise: rank 0 never leaves its shard
+    U0, V0 = sc.tables()
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], losses[:, r], rtol=1e-5)
+        assert_within_sum_bound(got[r]["U"], U[r * us:(r + 1) * us], U0[r * us:(r + 1) * us], sc.B, 2 * sc.STEPS, "U shard %d" % r)
+        assert_within_sum_bound(got[r]["V"], V[r * isz:(r + 1) * isz], V0[r * isz:(r + 1) * isz], world * sc.B, 2 * sc.STEPS, "V shard %d" % r)
 
 
 @pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback"),

@@ -1359,6 +1359,77 @@ def test_dense_tail_variants_match_oracle(text_data, model, scheme, loss, opt, a
     np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
 
 
+@pytest.mark.parametrize("scheme,loss,opt,act,drop", [
+    ("neg_shared", "skip-gram", "sgd", "relu", 0.0),          # the preset's tail minus its BatchNorm
+    ("neg_shared", "log-loss", "sgd", "tanh", 0.25),
+    ("original", "skip-gram", "sgd", "relu", 0.0),            # a block of > 1,024 rows? no: b (1 + k) = 256 here; row-wise launch shapes
+    ("group_neg_shared", "log-loss", "sgd", "sigmoid", 0.0),
+    ("neg_shared", "skip-gram", "adam", "relu", 0.0),         # Keras Adam: the Dense bias now HAS a gradient
+    ("group_neg_shared", "max-margin", "sparse_adam", "softsign", 0.2),
+])
+def test_no_bn_tower_matches_oracle(text_data, scheme, loss, opt, act, drop):
+    """conf.no_BN = True (modules/content/mean_pool.py:88-93): Dense -> Activation -> Dropout with no BatchNormalization in
+    between.  Four steps with word-row dropout against the float64 oracle: loss, user table, W / Wd / bd (the Dense bias takes a
+    real gradient without the BatchNorm behind it); gamma, beta and the running statistics must not move; then the
+    inference-mode scores (act(Dense(h)): no statistics anywhere)."""
+    conf = _conf(loss, scheme, lr=0.02 if opt != "sgd" else 0.2)
+    conf.word_emb_dropout_rate = 0.3
+    conf.optimizer = opt
+    conf.no_BN = True
+    conf.item_dense_transform = {"dense_hidden_dim": conf.item_dim, "dense_hidden_dropout": drop, "dense_hidden_actv": act}
+    md = get_model(conf, get_data(dict(text_data), conf, rand_seed=5), "basic_embedding", seed=2)
+    orc, to = _oracle(conf, md, text_data, dtype=np.float64)
+    orc.conf.optimizer = opt
+    to.dense_act, to.no_bn = act, True
+    head = md[{"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}[scheme]]
+    tw = head.core.tower
+    assert tw.no_bn
+    frozen = {n: getattr(tw, n).clone() for n in ("gamma", "beta", "rm", "rv")}
+    b, k = conf.batch_size_p, conf.num_negatives
+    rs = np.random.RandomState(7)
+    train = text_data["train"]
+    rt, at = (5e-4, 5e-5) if opt != "sgd" else (2e-5, 5e-6)
+    bd0 = tw.bd.cpu().numpy().copy()
+    for step in range(4):
+        bt = train[rs.choice(len(train), b, replace=False)]
+        if scheme == "group_neg_shared":
+            bt[:, 1] = np.repeat(bt[::4, 1], 4)
+        orc.row_scale = tw.dropout_scale(step).cpu().numpy().astype(np.float64)
+        if drop:
+            to.dense_mask = tw.dense_mask(step, b * (1 + k)).cpu().numpy().astype(np.float64)
+        if scheme == "original":
+            u, c, y = so.assemble_original(bt, rs.randint(0, 260, b * k), loss)
+            want = orc.step_original(u, c, y)
+        elif scheme == "neg_shared":
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_neg_shared(u, c)
+        else:
+            u, c, y = bt[:, 0], bt[:, 1], bt[:, 2]
+            want = orc.step_group_neg_shared(u, c)
+        got = head.train_on_batch([u, c], [y])
+        assert abs(got - want) <= 1e-5 * max(1, abs(want)), (step, got, want)
+        np.testing.assert_allclose(head.core.engine.U.cpu().numpy(), orc.U, rtol=rt, atol=at)
+        for name in ("W", "Wd", "bd"):
+            np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
+                                       err_msg="%s step %d" % (name, step))
+    assert np.abs(tw.bd.cpu().numpy() - bd0).max() > 1e-4          # the bias really trains
+    for n, v in frozen.items():
+        assert torch.equal(getattr(tw, n), v), n                     # no BatchNormalization: nothing of it moves
+    users, items = np.arange(40), np.arange(0, 260, 3)
+    got = md["model_neg_shared"].predict_on_batch([users, items])
+    E = to.forward(items, train=False)
+    oc2 = so.StepOracle(orc.U, E, orc.conf, dtype=np.float64)
+    np.testing.assert_allclose(got, oc2.predict_neg_shared(users, np.arange(len(items))), rtol=3e-4, atol=3e-5)
+    # the reference's comparison is `conf.no_BN == True`: any other value keeps the BatchNormalization; the CNN tower refuses
+    conf2 = _conf(loss, scheme)
+    conf2.no_BN = False
+    assert not getattr(get_model(conf2, get_data(dict(text_data), conf2, rand_seed=5), "basic_embedding", seed=2)["model"].core.tower, "no_bn", False)
+    conf3 = _conf_cnn("skip-gram", "neg_shared")
+    conf3.no_BN = True
+    with pytest.raises(NotImplementedError):
+        get_model(conf3, get_data(dict(text_data), conf3, rand_seed=5), "cnn_embedding", seed=2)
+
+
 @pytest.mark.parametrize("model,scheme,loss,opt,content_id", [
     ("basic_embedding", "neg_shared", "skip-gram", "sgd", False),
     ("basic_embedding", "original", "log-loss", "sgd", False),
