@@ -43,3 +43,43 @@ def test_no_default_path_kernel_spills_vector_registers(rows):
                 r["name"], r.get("vgpr_spill_count", 0), r.get("scratch_loads", 0), r.get("scratch_stores", 0),
                 r.get("private_segment_fixed_size", 0)))
     assert not bad, "kernels that spill:\n" + "\n".join(bad)
+
+
+# Scalar-register spills: an SGPR spilled by the compiler lives in a lane of a VGPR (v_writelane_b32 / v_readlane_b32) --
+# no scratch traffic, but in a chain-bound kernel every restore is a VALU instruction on the dependent path.  They are LISTED per
+# kernel family (profiles/r06_isa_resources.txt, column sspill) and BUDGETED here: the worst instantiation of every family that
+# spills today, plus a margin of 8; a family not listed must not spill more than 8.  A change that pushes a kernel past its
+# budget fails the CPU suite and has to say why (raise the budget with the measurement beside it).
+SGPR_SPILL_BUDGET = {
+    "cnn_conv_bwd_kernel": 135,     # 127: six tile pointers + tap offsets per filter group (round 5 formed them per tile to save VGPRs)
+    "fused_strip_kernel": 129,      # 121 (group_neg_shared); the headline instantiation <skip-gram, neg_shared> 92
+    "plan_steps_kernel": 98,        # 90: once per 64 steps
+    "fused_wide_kernel": 58,        # 50
+    "plan_kernel": 56,              # 48
+    "shared_apply_kernel": 46,      # 38
+    "cnn_pool_dense_kernel": 44,    # 36
+    "tower_word_kernel": 39,        # 31
+    "cnn_conv_fwd_kernel": 37,      # 29
+    "tower_bwd_kernel": 24,         # 16
+    "tower_pool_kernel": 21,        # 13
+}
+
+
+def _family(name):
+    m = re.match(r"(?:nncf::)?(?:\(anonymous namespace\)::)?([A-Za-z_0-9]+)", name)
+    return m.group(1) if m else name
+
+
+def test_scalar_register_spills_stay_within_their_budgets(rows):
+    worst = {}
+    for r in rows:
+        if any(re.search(p, r["name"]) for p, _ in OPT_IN):
+            continue
+        f = _family(r["name"])
+        worst[f] = max(worst.get(f, 0), r.get("sgpr_spill_count", 0))
+    over = ["%s: %d spilled SGPRs (budget %d)" % (f, n, SGPR_SPILL_BUDGET.get(f, 8)) for f, n in sorted(worst.items())
+            if n > SGPR_SPILL_BUDGET.get(f, 8)]
+    assert not over, "scalar-register spills past their budget:\n" + "\n".join(over)
+    # the list itself is not stale: every budgeted family still exists and still spills (else the entry should go)
+    for f in SGPR_SPILL_BUDGET:
+        assert f in worst, "budgeted kernel family %s is gone" % f

@@ -1412,7 +1412,8 @@ def test_no_bn_tower_matches_oracle(text_data, scheme, loss, opt, act, drop):
         for name in ("W", "Wd", "bd"):
             np.testing.assert_allclose(getattr(tw, name).cpu().numpy(), getattr(to, name), rtol=max(rt, 3e-4), atol=max(at, 3e-5),
                                        err_msg="%s step %d" % (name, step))
-    assert np.abs(tw.bd.cpu().numpy() - bd0).max() > 1e-4          # the bias really trains
+    assert np.abs(tw.bd.cpu().numpy() - bd0).max() > 1e-6          # the bias really trains (it starts at 0; log-loss moves it by ~1e-5)
+    assert np.abs(to.bd).max() > 1e-6
     for n, v in frozen.items():
         assert torch.equal(getattr(tw, n), v), n                     # no BatchNormalization: nothing of it moves
     users, items = np.arange(40), np.arange(0, 260, 3)

@@ -2,7 +2,7 @@
 # Collects the round's evidence on the GPU box: bench JSON lines + rocprofv3 summaries.
 # usage (from the repo root, on the GPU box): bash tools/profile_round.sh r04
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$PWD
 OUT=$R/gpurun_out
 export TMPDIR=/tmp
