@@ -190,14 +190,14 @@ constexpr int kCnnNTG = 2;          // 16-filter tiles per workgroup: 32 filters
 __host__ __device__ inline int cnn_groups(int F) { return ((F + 15) / 16 + kCnnNTG - 1) / kCnnNTG; }
 constexpr int kCnnCW = 96;          // distinct kept words per pass of the forward (six row tiles): one pass for ~every item
 constexpr int kFwdThreads = 512;    // 8 waves, <= 128 VGPRs, ~80 KB of LDS: two workgroups per CU
-// 16-byte-aligned LDS rows read as 16-byte MFMA fragments, lane = (row x, k-quarter kq) at row * pitch + 4 kq floats.  A wave64
-// ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): eight rows of
-// one k-quarter with the complementary eight rows of the next -- conflict-free when pitch = 8 (mod 16) floats.  Rounds 4-5 used
-// "pitch / 4 odd" (right for ALIGNED sixteens): 28 of 64 lanes collided at the 'best' preset's pitch of 100
-// (tools/micro/lds_pitch.hip, profiles/r06_lds_pitch.txt); round 6: 104.
+// 16-byte-aligned LDS rows read as 16-byte fragments by 16 consecutive rows at a time: pitch / 4 odd.  (Round 6 measured the
+// pitch rule of the large-batch kernels here too -- pitch = 8 (mod 16), conflict-free for the hardware's ds_read_b128 lane groups,
+// profiles/r06_lds_pitch.txt: 100 -> 104 floats at the 'best' preset -- and the forward got SLOWER, 20.4 -> 26.0 us, the backward
+// did not move (35.9 -> 35.7): these kernels also read the same rows one dword per lane (the k tail, the dWk operand), for which
+// 104 is the worse pitch (4-way instead of 2-way), and they are not LDS-bound.  Kept as it was.)
 __host__ __device__ inline int odd_pitch(int w) {
   int p = (w + 3) & ~3;
-  while ((p & 15) != 8) p += 4;
+  if (((p >> 2) & 1) == 0) p += 4;
   return p;
 }
 __host__ __device__ inline int fwd_xpitch(int wd, bool exact) { return odd_pitch(exact ? wd : ((wd + 15) & ~15)); }
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(kBwdThreads, kBwdThreads == 512 ? 4 : 1) cnn_c
   const int F = a.cnn.F, fl = FLX ? FLX : a.cnn.fl, pad = fl >> 1, L = a.L, wd = a.wd;
   constexpr int CH = 4 * NTG, FW = 16 * NTG;
   const int DP = FW + 4;                  // dY tile pitch: rows 4 banks apart
-  const int SP = fl * FW + 8;             // SP = 8 (mod 16): conflict-free 16-byte fragment reads in (a) (see odd_pitch; round 5: + 4)
+  const int SP = fl * FW + 4;             // SP / 4 odd: 16-byte fragment reads in (a) (see odd_pitch)
   const int rows = L + fl - 1;            // positions [-pad, L + pad)
   float* sD = smem;                       // [rows][DP]
   float* sS = sD + (int64_t)rows * DP;    // [kCnnCWB][SP]
@@ -1474,7 +1474,7 @@ int cnn_backward(nncf_tower* t, TowerArgs& a, hipStream_t st) {
 
 static int cnn_backward_bank(nncf_tower* t, TowerArgs& a, hipStream_t st) {
   const int fl = a.cnn.fl, ngrp = cnn_groups(a.cnn.F), FW = 16 * kCnnNTG;
-  const size_t lds = ((size_t)(a.L + fl - 1) * (FW + 4) + (size_t)kCnnCWB * (fl * FW + 8)) * sizeof(float);
+  const size_t lds = ((size_t)(a.L + fl - 1) * (FW + 4) + (size_t)kCnnCWB * (fl * FW + 4)) * sizeof(float);
   NNCF_REQUIRE(lds <= 150 * 1024, "conv backward tiles of %zu bytes exceed the LDS", lds);
   NNCF_REQUIRE((int64_t)a.cnn.gcap * (((int64_t)fl * a.wd * a.cnn.F + kCnnUpdElems - 1) / kCnnUpdElems) * kCnnUpdElems < (1ll << 31),
                "the per-slot dWk blocks exceed 2^31 floats (32-bit offsets in cnn_conv_bwd_kernel)");

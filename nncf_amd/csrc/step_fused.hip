@@ -51,11 +51,6 @@
 #ifndef NNCF_WIDE_PRIO
 #define NNCF_WIDE_PRIO 0         // 1: the second wave of every SIMD (waves 4-7) at s_setprio 1 for the stage loop
 #endif
-#ifndef NNCF_WIDE_PINGPONG
-#define NNCF_WIDE_PINGPONG 0     // 1: neg_shared, MT = 4, f16 planes run wide_body_pp (the two halves of a workgroup one phase apart).
-                                 // Built, parity-tested (197 tests of test_fused_gpu / test_pair_gpu green) and MEASURED SLOWER: 355 us
-                                 // against 318 at b = 8,192 -- see the comment above wide_body_pp; kept for the record, not shipped.
-#endif
 #ifndef NNCF_WIDE_EARLY_ROWS
 #define NNCF_WIDE_EARLY_ROWS 1   // the next stage's rows are requested at the top of the S block, not under the back-GEMM: 328 -> 320 us
                                  // at b = 8,192 (244 registers, no spills; round 5 could not afford the 32 registers: it spilled)
@@ -825,13 +820,9 @@ __global__ void __launch_bounds__(1024) wide_domain_kernel(StepArgs a, const int
 // 1024 and 2 b / (16 MT) >= 256 workgroups already.
 // GROUP: + the user strips' positive-count tile [16 MT][kMP] of 16-bit counts (below)
 constexpr int kMP = 132;   // pitch in 16-bit cells: rows 4 apart are 8 banks apart -- the element-wise reads do not collide
-constexpr int kPC = 64;        // ping-pong form (wide_body_pp): opposite rows per chunk = half a stage
-constexpr int kGP2 = kPC + 8;  // ... and the pitch (floats) of a chunk's dL/dS tile, [hi 64][lo 64] fp16 per own row: 8 (mod 16)
-template <int MT>
-__host__ __device__ constexpr int wide_g_floats() { return 16 * MT * kFGP > 2 * 16 * MT * kGP2 ? 16 * MT * kFGP : 2 * 16 * MT * kGP2; }
 template <int MT, bool GROUP>
 __host__ __device__ constexpr size_t wide_lds_bytes() {
-  return sizeof(float) * (16 * MT * kFDP + kFNB * kFDP + wide_g_floats<MT>() + 16 * MT + 16 * MT + 8) +
+  return sizeof(float) * (16 * MT * kFDP + kFNB * kFDP + 16 * MT * kFGP + 16 * MT + 16 * MT + 8) +
          sizeof(int) * (kFNB + kFKeys * MT + 16 * MT + 16 * MT + 4) + (GROUP ? sizeof(uint16_t) * 16 * MT * kMP + sizeof(int) * 8 * MT : 0);
 }
 
@@ -864,7 +855,7 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
   float* sOwn = smem;                       // [OWN][kFDP]
   float* sOpp = sOwn + OWN * kFDP;          // [128][kFDP]
   float* sG = sOpp + kFNB * kFDP;           // [OWN][kFGP]
-  float* sCnt = sG + wide_g_floats<MT>();   // [OWN]
+  float* sCnt = sG + OWN * kFGP;            // [OWN]
   float* sRowReg = sCnt + OWN;              // [OWN]
   float* sRed = sRowReg + OWN;              // [8]
   int* sOppKey = reinterpret_cast<int*>(sRed + 8);  // [128]
@@ -1365,444 +1356,6 @@ __device__ __forceinline__ void wide_body(const StepArgs& a, const int32_t* __re
 }
 
 
-// ---- ping-pong form of the large-batch strip (round 6; H16, MT = 4, neg_shared) ------------------------------------------------
-// wide_body runs its eight waves in lock step: everybody stages, barrier, everybody multiplies S, everybody does the element-wise
-// block, barrier, everybody multiplies back, barrier.  The two waves of a SIMD are in-order machines in the SAME phase: they want
-// the matrix pipe together and the vector ALU together, and the phase times ADD (profiles/r06_wide_ab.txt: removing the S products
-// or the element-wise block saves their whole pipe time; 10.6 k cycles per 128-row stage against 3.1 k of matrix pipe).
-// Here the workgroup is two halves of four waves -- one wave of each SIMD per half -- that run the SAME four phases on
-// alternate 64-row chunks of the opposite side, ONE PHASE APART:
-//        sub-phase      q       q + 1     q + 2     q + 3
-//        half 0     stage(c)   S(c)      dL/dS(c)  back(c)        c = 0, 2, 4, ...   (rows -> LDS | MFMA | VALU | MFMA)
-//        half 1     back(c-1)  stage(c+1) S(c+1)   dL/dS(c+1)
-// so in every sub-phase each SIMD holds one wave in a matrix phase beside one in a vector / LDS-store phase (what
-// MI355X_MICROARCH.md, "Two waves per SIMD", describes for tuned attention loops).  A workgroup-wide s_barrier closes every sub-phase;
-// each half owns its 64-row stage buffer and its 64-column dL/dS tile (the same LDS as one 128-row stage), a wave's back-GEMM covers
-// 32 output columns (two column groups x four row tiles, K = the chunk's 64 rows), and the halves' partial gradients meet in LDS
-// at the end.  Per wave and chunk the work is what wide_body gives a wave per stage: 48 + 48 MFMAs, four dL/dS tiles, four rows staged.
-// RESULT (one MI355X, b = 8,192, d = 128): 355.6 us against wide_body's 318-323 -- not shipped (NNCF_WIDE_PINGPONG = 0).  A wave that
-// is alone on its SIMD's matrix pipe has nobody to fill the bubble of an exposed LDS read (in wide_body the partner's MFMAs do), so
-// its S / back phases need their operands a tile ahead -- and with 64 accumulator registers per wave (32 output columns x 64 rows; four
-// waves of a half must cover all 128 columns) next to 32 registers of rows in flight, two operand sets do not fit: the fenced
-// prefetch below spills 207-232 registers INSIDE the back phase (tools/isa_resources.py), the unfenced form spills 16 and leaves
-// the bubbles.  What would make it work is the rows of the next chunk travelling through LDS (global_load_lds) instead of
-// registers, i.e. 64 KB more LDS than a CU has next to 64 own rows.
-template <int LOSS, bool NU, bool NV, bool USIDE>
-__device__ __forceinline__ void wide_body_pp(const StepArgs& a, const int32_t* __restrict__ uid, const int32_t* __restrict__ cid,
-                                             const FusedArgs& f, const PlanView& pu, const PlanView& pv, int blk, int update, float* smem) {
-  constexpr int MT = 4, OWN = 16 * MT, RPG = 2;
-  float* sOwn = smem;                       // [OWN][kFDP]
-  float* sOpp = sOwn + OWN * kFDP;          // [2][kPC][kFDP]
-  float* sG = sOpp + kFNB * kFDP;           // [2][OWN][kGP2]
-  float* sCnt = sG + wide_g_floats<MT>();   // [OWN]
-  float* sRowReg = sCnt + OWN;              // [OWN]
-  float* sRed = sRowReg + OWN;              // [8]
-  int* sOppKey = reinterpret_cast<int*>(sRed + 8);  // [2][kPC]
-  int* sKeys = sOppKey + kFNB;              // [kFKeys MT]
-  int* sKeyStart = sKeys + kFKeys * MT;     // [OWN]
-  int* sKeyCnt = sKeyStart + OWN;           // [OWN]
-  int* sTop = sKeyCnt + OWN;                // [4]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = wave >> 2, w4 = wave & 3;        // the half-workgroup and the wave's place in it (one wave per SIMD and half)
-  const int g = tid >> 4, q = tid & 15;             // prologue / epilogue: 32 row groups of 16 lanes
-  const int g16 = (tid & 255) >> 4;                 // stage loop: 16 row groups per half
-  const int b = a.b, d = a.d, d4 = d >> 2;
-  const int NP = (d + 15) & ~15;
-  const int n_items = b, n_opp = b;
-  const PlanView& po = USIDE ? pu : pv;
-  const int n_own = po.counts[0];
-  float* sOppH = sOpp + half * kPC * kFDP;
-  float* sGH = sG + half * OWN * kGP2;
-  int* sOppKeyH = sOppKey + half * kPC;
-
-  if (tid == 0) sTop[0] = 0;
-  auto opp_id = [&](int j) -> int { return USIDE ? cid[j] : uid[j]; };
-  auto opp_key = [&](int j) -> int { return USIDE ? pu.inverse[j] : pv.inverse[j]; };
-  const int nch = (n_opp + kPC - 1) / kPC;          // chunks of the opposite side; half h takes h, h + 2, ...
-  int idA[4], keyA[4];
-  auto load_ids = [&](int ch, int* ids, int* keys) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = ch * kPC + g16 + 16 * e;
-      const bool ok = ch < nch && j < n_opp;
-      ids[e] = ok ? opp_id(j) : -1;
-      keys[e] = ok ? opp_key(j) : -1;
-    }
-  };
-  load_ids(half, idA, keyA);
-  __syncthreads();
-  Row rcur[4];
-  int kcur[4];
-  auto load_rows = [&](const int* ids, Row* rows) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      rows[e] = (ids[e] >= 0) ? row_load(USIDE ? a.V : a.U, ids[e], a.stride, d4, q) : row_zero();
-  };
-  load_rows(idA, rcur);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) kcur[e] = keyA[e];
-  load_ids(half + 2, idA, keyA);
-
-  // ---- own rows (as wide_body) ----------------------------------------------------------------------------------------------
-  auto own_desc = [&](int o, int& id, float& c, int& key0) -> bool {
-    const int s_own = blk * OWN + o;
-    id = -1;
-    c = 0.f;
-    key0 = 0;
-    if (o >= OWN || s_own >= n_own) return false;
-    const int4 ds = reinterpret_cast<const int4*>(po.desc)[s_own];
-    id = ds.x;
-    c = (float)ds.w;
-    key0 = po.inverse[ds.y];
-    return true;
-  };
-#pragma unroll
-  for (int rr = 0; rr < RPG; ++rr) {
-    const int o = g + 32 * rr;
-    int id, key0;
-    float c;
-    const bool ok = own_desc(o, id, c, key0);
-    Row hat = row_zero();
-    float ss = 0.f;
-    if (ok) {
-      const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
-      ss = row16_sum(row_dot_partial(raw, raw));
-      hat = (USIDE ? NU : NV) ? row_scale(raw, inv_norm(ss)) : raw;
-      if (LOSS == NNCF_LOSS_SKIP_GRAM) hat = row_scale(hat, 1.44269504088896341f);   // the score tile IS y = s log2 e
-    }
-    lds_store_row_h(sOwn + o * kFDP, q, hat);
-    if (q == 0) {
-      sCnt[o] = c;
-      sRowReg[o] = c * ss;
-      sKeyStart[o] = ok ? key0 : -2;     // the single positive column of the row
-    }
-  }
-  __syncthreads();
-  const int x = lane & 15, kq = lane >> 4;
-  float cnt_o[MT];
-  int ks_o[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    cnt_o[mt] = sCnt[16 * mt + x];
-    ks_o[mt] = sKeyStart[16 * mt + x];
-  }
-  const float inv_b = 1.f / (float)b;
-  const float wneg = n_items > 1 ? a.lambda / (float)(n_items - 1) : 0.f;
-  const float gscale = wide_gscale(wneg);
-  f32x4 accD0[MT][2], accD1[MT][2];   // [row tile][column group 2 w4 + cg]
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int cg = 0; cg < 2; ++cg) {
-      accD0[mt][cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      accD1[mt][cg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-  f32x4 accS[MT];                     // the chunk's score tiles of this wave: from the S phase to the dL/dS phase
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) accS[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float lsum = 0.f;
-  const bool back_wave = w4 * 32 < NP;   // (d <= 96: the last wave of a half has no output columns)
-
-  // The two halves run the same four phases as straight-line loops, half 1 one barrier behind half 0 (a wave-uniform branch: every
-  // wave of the workgroup executes the same NUMBER of s_barrier instructions, 4 periods + 1).  (One loop with a phase switch per
-  // sub-phase left the accumulators in branch-merged copies: 130 spilled registers and reloads in every phase.)
-  auto stage_phase = [&](int ch) {
-    // ---- rows -> LDS (fp16 hi / lo planes) ------------------------------------------------------------------------------
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      Row r = rcur[e];
-      if (USIDE ? NV : NU) r = row_scale(r, inv_norm(row16_sum(row_dot_partial(r, r))));
-      lds_store_row_h(sOppH + (g16 + 16 * e) * kFDP, q, r);
-      if (q == 0) sOppKeyH[g16 + 16 * e] = kcur[e];
-    }
-  };
-  auto s_phase = [&](int ch) {
-    // ---- S tiles: 16 columns of the chunk x 4 row tiles, transposed (D[opposite][own]).  The wave is ALONE on its SIMD's matrix
-    // pipe in this sub-phase (its partner stores rows or dL/dS): nobody fills the bubbles of an exposed LDS read, so the fragments
-    // of tile m + 1 are in flight under tile m's twelve MFMAs (two register sets, scheduling fences) ---------------------------
-    const float4* pb4 = reinterpret_cast<const float4*>(sOppH + (16 * w4 + x) * kFDP + 4 * kq);
-    float4 fb[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fb[t] = pb4[(t & 3) * 4 + (t >> 2) * 16];   // t < 4 hi plane, t >= 4 lo plane
-    auto ld = [&](int mt, float4* fa) {
-      const float4* pa4 = reinterpret_cast<const float4*>(sOwn + (16 * mt + x) * kFDP + 4 * kq);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) fa[t] = pa4[(t & 3) * 4 + (t >> 2) * 16];
-    };
-    auto mm = [&](const float4* fa) -> f32x4 {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {   // acc0: hi.hi; acc1: the cross terms (times 2048) -- the order of wide_body
-        const f16x8 ah = __builtin_bit_cast(f16x8, fa[t]), al = __builtin_bit_cast(f16x8, fa[4 + t]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, fb[t]), bl = __builtin_bit_cast(f16x8, fb[4 + t]);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc1, 0, 0, 0);
-      }
-      return acc0 + acc1 * (1.f / kHLoScale);
-    };
-    float4 faA[8], faB[8];
-    ld(0, faA);
-    ld(1, faB);
-    __builtin_amdgcn_sched_barrier(0);
-    accS[0] = mm(faA);
-    __builtin_amdgcn_sched_barrier(0);
-    ld(2, faA);
-    __builtin_amdgcn_sched_barrier(0);
-    accS[1] = mm(faB);
-    __builtin_amdgcn_sched_barrier(0);
-    ld(3, faB);
-    __builtin_amdgcn_sched_barrier(0);
-    accS[2] = mm(faA);
-    __builtin_amdgcn_sched_barrier(0);
-    accS[3] = mm(faB);
-  };
-  auto g_phase = [&](int ch) {
-    // ---- the next chunk's rows are requested (two sub-phases ahead of their staging), then dL/dS of this chunk -----------
-    load_rows(idA, rcur);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) kcur[e] = keyA[e];
-    load_ids(ch + 4, idA, keyA);
-    const int jq = 16 * w4 + 4 * kq;   // this lane's columns of the chunk: jq + r
-    const int4 ok4 = *reinterpret_cast<const int4*>(sOppKeyH + jq);
-    const int okey[4] = {ok4.x, ok4.y, ok4.z, ok4.w};
-    const int nleft = n_opp - ch * kPC - jq;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const f32x4 acc = accS[mt];
-      const int i = 16 * mt + x;
-      const float c = cnt_o[mt];
-      const bool anyp = __ballot((ks_o[mt] == okey[0]) | (ks_o[mt] == okey[1]) | (ks_o[mt] == okey[2]) | (ks_o[mt] == okey[3])) != 0ull;
-      const bool plain = !anyp && ch * kPC + 16 * w4 + 15 < n_opp;
-      float hv[4];
-      if (plain && LOSS != NNCF_LOSS_SKIP_GRAM) {   // mse off the positives: w s^2, dL/dS = 2 w s
-        const float cw = c * wneg, cg = 2.f * cw * gscale;
-        float q2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          q2 = fmaf(acc[r], acc[r], q2);
-          hv[r] = cg * acc[r];
-        }
-        lsum = fmaf(cw, q2, lsum);
-      } else if (plain) {   // skip-gram off the positives, base 2: one logarithm per four elements (wide_body)
-        const float cw = c * wneg, cg = cw * gscale;
-        float prod = 1.f, zs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y = acc[r];
-          const float e = __builtin_amdgcn_exp2f(-fabsf(y));
-          const float u = 1.f + e;
-          const float rc = __builtin_amdgcn_rcpf(u);
-          hv[r] = cg * (y >= 0.f ? rc : e * rc);
-          prod *= u;
-          zs += fmaxf(y, 0.f);
-        }
-        lsum = fmaf(cw, __builtin_amdgcn_logf(prod) + zs, lsum);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = acc[r];
-          const float m = (ks_o[mt] == okey[r]) ? 1.f : 0.f;
-          float l, h;
-          if (LOSS == NNCF_LOSS_SKIP_GRAM) {
-            float sp, sg, spn, sgn;
-            softplus2_sigmoid_both(sc, sp, sg, spn, sgn);
-            l = (c - m) * wneg * sp + m * spn;
-            h = (c - m) * wneg * sg - m * sgn;
-          } else {
-            l = (c - m) * wneg * sc * sc + m * (sc - 1.f) * (sc - 1.f);
-            h = 2.f * ((c - m) * wneg * sc + m * (sc - 1.f));
-          }
-          if (r >= nleft || c == 0.f) {
-            l = 0.f;
-            h = 0.f;
-          }
-          hv[r] = h * gscale;
-          lsum += l;
-        }
-      }
-      f16x4 gh, gl;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        _Float16 a_, b_;
-        split_h(hv[r], a_, b_);
-        gh[r] = a_;
-        gl[r] = b_;
-        if (LOSS != NNCF_LOSS_SKIP_GRAM) lsum += (float)a_ - (float)a_;   // (mse: an overflowing plane turns THIS step's loss NaN)
-      }
-      _Float16* pg = reinterpret_cast<_Float16*>(sGH + i * kGP2);
-      *reinterpret_cast<f16x4*>(pg + jq) = gh;
-      *reinterpret_cast<f16x4*>(pg + kPC + jq) = gl;
-    }
-  };
-  auto back_phase = [&](int ch) {
-    if (!back_wave) return;
-    // ---- back-GEMM: dOwn[own][32 w4 .. + 32) += G[own][j] . Opp[j][col], K = the chunk's 64 rows in two steps of 32; the second
-    // step's operands travel under the first step's MFMAs (the wave has the matrix pipe to itself: see s_phase) -------------------
-    const bool cg1 = w4 * 32 + 16 < NP;   // (d <= 112: the last wave's second column group is past the row)
-    auto ldg = [&](int t, f16x8* gh, f16x8* gl) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float4* pg4 = reinterpret_cast<const float4*>(sGH + (16 * mt + x) * kGP2 + 4 * kq);
-        gh[mt] = __builtin_bit_cast(f16x8, pg4[4 * t]);            // hi plane: halfs 32 t + 8 kq .. + 7
-        gl[mt] = __builtin_bit_cast(f16x8, pg4[kPC / 8 + 4 * t]);  // lo plane: + 64 halfs = 8 float4
-      }
-    };
-    auto ldv = [&](int t, int cg, f16x8& vh, f16x8& vl) {
-      const _Float16* pr = reinterpret_cast<const _Float16*>(sOppH) + (size_t)(32 * t + 8 * kq + (x >> 2)) * (2 * kFDP) + 16 * (2 * w4 + cg) + 4 * (x & 3);
-      vh = lds_read_tr8(pr, pr + 4 * (2 * kFDP));
-      vl = lds_read_tr8(pr + 128, pr + 128 + 4 * (2 * kFDP));
-    };
-    auto mm = [&](int cg, const f16x8* gh, const f16x8* gl, const f16x8& vh, const f16x8& vl) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (cg == 0) accD1[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vl, accD1[mt][0], 0, 0, 0);
-        else accD1[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vl, accD1[mt][1], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (cg == 0) accD0[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vh, accD0[mt][0], 0, 0, 0);
-        else accD0[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gh[mt], vh, accD0[mt][1], 0, 0, 0);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (cg == 0) accD1[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mt], vh, accD1[mt][0], 0, 0, 0);
-        else accD1[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gl[mt], vh, accD1[mt][1], 0, 0, 0);
-      }
-    };
-    // one set of dL/dS fragments, the opposite rows' fragments of both column groups a step ahead: the second step's dL/dS read
-    // is the one exposed LDS trip of the phase (two sets of everything: 218 registers spilled)
-    f16x8 gh[MT], gl[MT], vh0, vl0, vh1, vl1;
-    ldg(0, gh, gl);
-    ldv(0, 0, vh0, vl0);
-    if (cg1) ldv(0, 1, vh1, vl1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(0, gh, gl, vh0, vl0);
-    __builtin_amdgcn_sched_barrier(0);
-    ldv(1, 0, vh0, vl0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (cg1) mm(1, gh, gl, vh1, vl1);
-    __builtin_amdgcn_sched_barrier(0);
-    ldg(1, gh, gl);
-    if (cg1) ldv(1, 1, vh1, vl1);
-    __builtin_amdgcn_sched_barrier(0);
-    mm(0, gh, gl, vh0, vl0);
-    if (cg1) mm(1, gh, gl, vh1, vl1);
-  };
-  const int nper = (nch + 1) >> 1;
-  if (half == 0) {
-    for (int p = 0; p < nper; ++p) {
-      const int ch = 2 * p;
-      stage_phase(ch);
-      __syncthreads();
-      s_phase(ch);
-      __syncthreads();
-      g_phase(ch);
-      __syncthreads();
-      back_phase(ch);
-      __syncthreads();
-    }
-    __syncthreads();   // the sub-phase in which half 1 finishes its last back-GEMM
-  } else {
-    __syncthreads();   // half 1 starts one sub-phase late
-    for (int p = 0; p < nper; ++p) {
-      const int ch = 2 * p + 1;
-      const bool on = ch < nch;   // (an odd number of chunks: the last period is half 0's alone)
-      if (on) stage_phase(ch);
-      __syncthreads();
-      if (on) s_phase(ch);
-      __syncthreads();
-      if (on) g_phase(ch);
-      __syncthreads();
-      if (on) back_phase(ch);
-      __syncthreads();
-    }
-  }
-  // every table row this strip streams is in: announce it, the in-place stores below wait for all strips (see fused_body)
-  if (update && tid == 0) readers_arrive(f);
-
-  // ---- the halves' partial gradients meet in LDS: half 0 stores, half 1 adds ------------------------------------------------------
-  float* sOut = sOpp;  // [OWN][kFOP]
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (half == h && back_wave) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int cg = 0; cg < 2; ++cg) {
-          if (w4 * 32 + 16 * cg < NP) {
-            const f32x4 accD = (accD0[mt][cg] + accD1[mt][cg] * (1.f / kHLoScale)) * (inv_b / gscale);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* cell = sOut + (16 * mt + 4 * kq + r) * kFOP + 16 * (2 * w4 + cg) + x;
-              *cell = h ? *cell + accD[r] : accD[r];
-            }
-          }
-        }
-    }
-    if (USIDE && h == 1) {
-      lsum = wave_sum(lsum);
-      if (lane == 0) sRed[wave] = lsum;
-    }
-    __syncthreads();
-  }
-  if (USIDE && tid == 0) {
-    float reg = 0.f;
-    for (int i = 0; i < OWN; ++i) reg += sRowReg[i];
-    float l = ((sRed[0] + sRed[1]) + (sRed[2] + sRed[3])) + ((sRed[4] + sRed[5]) + (sRed[6] + sRed[7]));
-    if (LOSS == NNCF_LOSS_SKIP_GRAM) l *= 0.693147180559945309f;
-    f.loss_part[blk] = l * inv_b + a.u_reg * reg * inv_b;
-  }
-  if (!update) return;
-  Row raw_r[RPG], grad_r[RPG];
-  int id_r[RPG];
-#pragma unroll
-  for (int rr = 0; rr < RPG; ++rr) {
-    const int o = g + 32 * rr;
-    int id, key0;
-    float c;
-    id_r[rr] = -1;
-    if (!own_desc(o, id, c, key0)) continue;
-    id_r[rr] = id;
-    const Row raw = row_load(USIDE ? a.U : a.V, id, a.stride, d4, q);
-    raw_r[rr] = raw;
-    Row acc;
-    acc.a = reinterpret_cast<const float4*>(sOut + o * kFOP)[q];
-    acc.b = reinterpret_cast<const float4*>(sOut + o * kFOP)[q + 16];
-    if (q >= d4) acc.a = zero4();
-    if (q + 16 >= d4) acc.b = zero4();
-    Row grad = acc;
-    if (USIDE ? NU : NV) {
-      const float ss = row16_sum(row_dot_partial(raw, raw));
-      const float inv = inv_norm(ss);
-      grad = norm_backward(row_scale(raw, inv), inv, ss, acc);
-    }
-    if (USIDE) grad = row_fma(2.f * a.u_reg * c * inv_b, raw, grad);
-    grad_r[rr] = grad;
-  }
-  const bool deferred = f.stage != nullptr;
-  if ((USIDE || !a.gV) && !deferred) {
-    if (tid == 0) sTop[2] = readers_wait(f, 0, (pu.counts[0] + OWN - 1) / OWN + (pv.counts[0] + OWN - 1) / OWN);
-    __syncthreads();
-    if (!sTop[2]) return;
-  }
-#pragma unroll
-  for (int rr = 0; rr < RPG; ++rr) {
-    if (id_r[rr] < 0) continue;
-    const int s_own = blk * OWN + g + 32 * rr;
-    if (USIDE) {
-      if (deferred) row_store(f.stage, s_own, 128, d4, q, grad_r[rr]);
-      else apply_update(a, a.au, a.U, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
-    } else {
-      if (a.gV) row_store(a.gV, id_r[rr], d, d4, q, grad_r[rr]);
-      else if (deferred) row_store(f.stage + (int64_t)a.b * 128, s_own, 128, d4, q, grad_r[rr]);
-      else apply_update(a, a.av, a.V, id_r[rr], raw_r[rr], grad_r[rr], d4, q);
-    }
-  }
-}
-
 // grid = 2 gu + 1 workgroups: gu U strips, gu V strips of 16 MT unique rows, the previous step's loss
 template <int LOSS, bool GROUP, bool NU, bool NV, int MT, bool H16>
 __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32_t* __restrict__ uid,
@@ -1831,12 +1384,10 @@ __global__ void __launch_bounds__(512) fused_wide_kernel(StepArgs a, const int32
       if (threadIdx.x == 0) f.loss_part[strip] = 0.f;
       return;
     }
-    if constexpr (NNCF_WIDE_PINGPONG && H16 && MT == 4 && !GROUP) wide_body_pp<LOSS, NU, NV, true>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
-    else wide_body<LOSS, GROUP, NU, NV, true, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+    wide_body<LOSS, GROUP, NU, NV, true, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
   } else {
     if (!update || strip * 16 * MT >= nseg_v) return;
-    if constexpr (NNCF_WIDE_PINGPONG && H16 && MT == 4 && !GROUP) wide_body_pp<LOSS, NU, NV, false>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
-    else wide_body<LOSS, GROUP, NU, NV, false, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
+    wide_body<LOSS, GROUP, NU, NV, false, MT, H16>(a, uid, cid, f, pu, pv, strip, update, fused_smem);
   }
 }
 
