@@ -671,10 +671,17 @@ int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float*
  * with bias vectors (nncf_model_set_bias, indexed by landing slot: user_count / n_items >= batch_size_p) makes the session run
  * REPLICATED for every loss -- all 2 b rows AND their bias values to every rank, the whole one-device step (tile + apply +
  * bias update) on the landing buffers, the owners write rows and bias values back.  d_*_bias_shard: this rank's [user_shard] /
- * [item_shard] floats, one per bias vector the model has (NULL for the other).  The weak form refuses a model with a bias
- * (nncf_shard_create).  nncf_shard_bias_buffers: both ends of the bias exchange of `exchange` for a host-driven transport
- * (NULL / NULL without a bias; with one rank both ends are the model's vector). */
+ * [item_shard] floats, one per bias vector the model has (NULL for the other).  nncf_shard_bias_buffers: both ends of the
+ * bias exchange of `exchange` for a host-driven transport (NULL / NULL without a bias; with one rank both ends are the model's
+ * vector).
+ * WEAK form (round 6): the user bias vector is the model's own (local users, stepped in place: pass NULL); the item bias values
+ * travel with the item rows (d_item_bias_shard: this rank's [item_shard] floats), land in the model's item-bias vector (indexed
+ * by landing slot, >= batch_size_p values), the step exports d(loss)/d(cbias) per landing slot instead of stepping it, the
+ * values travel back next to the gradient rows and the owner adds the ranks' values of an id in rank order and takes the
+ * sparse-SGD step (Adam with a bias is refused on this form too).  nncf_shard_bias_grad_buffers: both ends of that extra exchange
+ * for a host-driven transport (NULL / NULL unless the weak session has an item-bias shard). */
 int nncf_shard_set_bias(nncf_shard* h, float* d_user_bias_shard, float* d_item_bias_shard);
+int nncf_shard_bias_grad_buffers(nncf_shard* h, int32_t exchange, float** gb_out, float** gb_in);
 /* Adam on the replicated form (pairwise losses; no bias): the moment rows of the requested ids travel with the table rows --
  * owners gather them from the shards' moment arrays (nncf_shard_set_optimizer), they land in the model's own moment arrays
  * (indexed by landing slot), the one-device step updates them, the owners write them back; Keras' dense Adam: the owned rows

@@ -136,6 +136,7 @@ def _declare(lib):
         "nncf_shard_set_comm": [vp, vp],
         "nncf_shard_set_bias": [vp, vp, vp],
         "nncf_shard_bias_buffers": [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)],
+        "nncf_shard_bias_grad_buffers": [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(vp)],
         "nncf_shard_moment_buffers": [vp, i32] + [ctypes.POINTER(vp)] * 4,
         "nncf_shard_run_chunk": [vp, vp, vp, i64, vp, f32, vp],
         "nncf_comm_unique_id": [vp],

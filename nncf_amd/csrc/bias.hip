@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) bias_update_kernel(StepArgs a, PlanView p
       for (int s = ds.z; s < ds.z + ds.w; ++s) g -= col_total(src.gr_part, src.b, nbj, pl.order[s]);
   }
   if (side == 0) bias_step(a, a.abu, a.ub, ds.x, g);
+  else if (a.gcb) a.gcb[ds.x] = g;   // exported per landing slot (weak sharded form): the owner sums the ranks' values and steps
   else bias_step(a, a.abc, a.cb, a.item_gid ? a.item_gid[ds.x] : ds.x, g);
 }
 

@@ -220,6 +220,9 @@ struct Exch {
   float* bshard = nullptr;       // this rank's [shard_rows] bias values
   float* bout = nullptr;         // owner side: the values of the rows of the current step, in request order
   float* bland = nullptr;        // requester side: the model's bias vector (indexed by landing slot, like the landing rows)
+  // weak form with an item bias: d(loss)/d(cbias) of the step per landing slot (requester) / per requested row (owner), travelling
+  // back next to the gradient rows -- same lists, same counts, element size 4
+  float *gb_out = nullptr, *gb_in = nullptr;
 };
 
 struct nncf_shard {
@@ -374,6 +377,36 @@ __global__ void __launch_bounds__(256) merge_step_kernel(StepArgs a, AdamTable a
   apply_update(a, ad, table, id - id_offset, raw, acc, d4, q);   // sparse SGD, or Adam on the summed gradient (step.h)
 }
 
+// weak form, item bias: the ranks' d(loss)/d(cbias) values of an id, summed in rank order by the lowest rank that asked for it (as
+// merge_step_kernel sums the gradient rows; one thread per requested row), then the sparse-SGD step of the owner's value
+__global__ void __launch_bounds__(256) merge_bias_kernel(float* __restrict__ bias, int id_offset, float lr, const float* __restrict__ gb,
+                                                         const int32_t* __restrict__ req_in, const int32_t* __restrict__ recv_off,
+                                                         const int32_t* __restrict__ step_off, int ranks, int s) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int r, k;
+  if (!owner_row(step_off, ranks, s, t, r, k)) return;
+  const int32_t* so = step_off + s * (ranks + 1);
+  const int id = req_in[recv_off[r * kPlanChunk + s] + k];
+  auto find = [&](int rr) -> int {
+    const int32_t* blk = req_in + recv_off[rr * kPlanChunk + s];
+    const int len = so[rr + 1] - so[rr];
+    int lo = 0, hi = len;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (blk[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return (lo < len && blk[lo] == id) ? lo : -1;
+  };
+  for (int rr = 0; rr < r; ++rr)
+    if (find(rr) >= 0) return;
+  float acc = gb[t];
+  for (int rr = r + 1; rr < ranks; ++rr) {
+    const int p = find(rr);
+    if (p >= 0) acc += gb[(int64_t)so[rr] + p];
+  }
+  bias[id - id_offset] -= lr * acc;
+}
+
 // Replicated strong form: after the local (whole) step stepped the landing rows in place, every rank writes the rows of the
 // ids IT owns back into its shard.  The ids this rank asked of itself at step s are the block (owner = me, step s) of its own
 // request list, ascending; their landing slots follow the blocks of the lower-ranked owners.  One 16-lane group per id.
@@ -444,6 +477,8 @@ static void carve_shard(nncf_shard* h, Carver& c) {
     e.g_in = alias ? e.g_out : c.take<float>((size_t)R * n * h->d);
     e.rows_out = alias ? nullptr : c.take<float>((size_t)R * n * h->d);   // one rank: gathered straight into the landing buffer
     e.bout = alias ? nullptr : c.take<float>((size_t)R * n);
+    e.gb_out = c.take<float>((size_t)n);
+    e.gb_in = alias ? e.gb_out : c.take<float>((size_t)R * n);
     if (!alias && h->replicated) {   // (the optimiser may be chosen after the session exists)
       e.mo_out = c.take<float>((size_t)R * n * h->d);
       e.vo_out = c.take<float>((size_t)R * n * h->d);
@@ -493,7 +528,11 @@ int nncf_shard_create(nncf_model* m, float* d_item_shard, int32_t item_stride, i
   // The InteractionDot bias (interaction_dot.py:96-107) takes the same road for every loss: the one-launch rectangular step has
   // no bias form, the one-device tile + apply + bias-update kernels do -- the bias values travel with the rows (nncf_shard_set_bias).
   const bool replicated = strong && (m->cfg.loss == NNCF_LOSS_LOG_LOSS || m->cfg.loss == NNCF_LOSS_MAX_MARGIN || m->ub || m->cb);
-  NNCF_REQUIRE(strong || (!m->ub && !m->cb), "interaction_bias on the sharded trainers: the same-global-batch (strong) form only");
+  // Weak form with an InteractionDot bias (round 6): the user bias vector is local like the user rows (the model's own, stepped in
+  // place); the item bias values travel with the item rows, the step exports d(loss)/d(cbias) per landing slot (StepArgs::gcb) and
+  // the owners add the ranks' values in rank order and take the sparse-SGD step (nncf_shard_set_bias; merge_bias_kernel).
+  NNCF_REQUIRE(strong || !m->cb || m->bias_items >= b, "weak form: the model's item-bias vector is indexed by landing slot and must hold batch_size_p values");
+  NNCF_REQUIRE(strong || !(m->opt && (m->ub || m->cb)), "weak form with an interaction bias steps with sparse SGD (the bias moments do not travel)");
   if (strong && !replicated) {
     NNCF_REQUIRE(user_shard > 0 && user_offset >= 0 && user_stride >= m->cfg.dim && user_stride % 4 == 0, "bad user shard shape");
     NNCF_REQUIRE(b % (16 * n_ranks) == 0, "same-global-batch form: batch_size_p = %d must be a multiple of 16 * n_ranks", b);
@@ -547,7 +586,13 @@ int nncf_shard_set_optimizer(nncf_shard* h, int32_t exchange, float* d_m, float*
 
 int nncf_shard_set_bias(nncf_shard* h, float* d_user_bias_shard, float* d_item_bias_shard) {
   NNCF_REQUIRE(h != nullptr, "shard is NULL");
-  NNCF_REQUIRE(h->replicated, "the bias travels with the rows of the replicated strong form only");
+  NNCF_REQUIRE(h->replicated || !h->strong, "the bias travels with the rows of the replicated strong form and of the weak form");
+  if (!h->strong) {   // weak form: the user bias is the model's own vector (local users); only the item bias has a shard elsewhere
+    NNCF_REQUIRE(!d_user_bias_shard || d_user_bias_shard == h->m->ub, "weak form: the user bias is local -- pass NULL (or the model's own vector)");
+    NNCF_REQUIRE((d_item_bias_shard != nullptr) == (h->m->cb != nullptr), "one item-bias shard iff the model has an item bias");
+    h->x[0].bshard = d_item_bias_shard;
+    return NNCF_OK;
+  }
   NNCF_REQUIRE((d_user_bias_shard != nullptr) == (h->m->ub != nullptr) && (d_item_bias_shard != nullptr) == (h->m->cb != nullptr),
                "one bias shard per bias vector of the model (nncf_model_set_bias), no more");
   h->x[1].bshard = d_user_bias_shard;
@@ -561,6 +606,16 @@ int nncf_shard_bias_buffers(nncf_shard* h, int32_t exchange, float** bias_out, f
   const Exch& e = h->x[exchange];
   if (bias_out) *bias_out = e.bshard ? (e.bout ? e.bout : e.bland) : nullptr;
   if (bias_in) *bias_in = e.bshard ? e.bland : nullptr;
+  return NNCF_OK;
+}
+
+int nncf_shard_bias_grad_buffers(nncf_shard* h, int32_t exchange, float** gb_out, float** gb_in) {
+  NNCF_REQUIRE(h != nullptr, "shard is NULL");
+  NNCF_REQUIRE(exchange >= 0 && exchange < h->nx, "exchange %d out of range", exchange);
+  const Exch& e = h->x[exchange];
+  const bool on = !h->strong && e.bshard;   // weak form with an item bias
+  if (gb_out) *gb_out = on ? e.gb_out : nullptr;
+  if (gb_in) *gb_in = on ? e.gb_in : nullptr;
   return NNCF_OK;
 }
 
@@ -736,6 +791,10 @@ int nncf_shard_step(nncf_shard* h, int64_t index, const int32_t* d_uid, float* d
     uid = h->x[1].slot + index * h->x[1].n;
   }
   NNCF_REQUIRE(uid != nullptr, "NULL argument");
+  if (!h->strong && m->cb) {   // weak form, item bias: values landed with the rows; the gradient leaves per landing slot
+    NNCF_REQUIRE(h->x[0].bshard, "the model has an item bias: nncf_shard_set_bias first");
+    a.gcb = h->x[0].gb_out;
+  }
   if (m->opt) {
     NNCF_REQUIRE(h->x[0].ad.m && (!h->strong || h->x[1].ad.m), "the model steps with Adam: the shards need their moment arrays (nncf_shard_set_optimizer)");
     NNCF_REQUIRE(m->opt != 2 || (h->x[0].ad.stamp && (!h->strong || h->x[1].ad.stamp)), "dense Adam: the shards need their stamp arrays");
@@ -762,6 +821,9 @@ int nncf_shard_apply(nncf_shard* h, int64_t index, int64_t n_steps, float lr, vo
       ProfScope _ps("scatter_merge_kernel", st);
       hipLaunchKernelGGL(merge_step_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, a, e.ad, e.shard, e.i0, e.g_in,
                          e.req_in, e.recv_off, e.step_off, h->ranks, (int)index);
+      if (!h->strong && e.bshard)   // weak form: the item bias values of the same ids
+        hipLaunchKernelGGL(merge_bias_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, e.bshard, e.i0, lr, e.gb_in, e.req_in,
+                           e.recv_off, e.step_off, h->ranks, (int)index);
       NNCF_HIP_CHECK(hipGetLastError());
     }
     if (a.opt == 2)   // Keras (dense) Adam: every other row of the shard takes the zero-gradient step
@@ -850,6 +912,8 @@ int nncf_shard_run_chunk(nncf_shard* h, const int32_t* d_uid, const int32_t* d_c
           rc_[r] = rcv[((size_t)r * nx + xi) * kPlanChunk + i];
         }
         if (int rc = comm_all_to_all(h->comm, e.g_out, sc.data(), e.g_in, rc_.data(), eb, st)) return rc;
+        if (!h->strong && e.bshard)   // weak form: d(loss)/d(cbias) of the same landing slots
+          if (int rc = comm_all_to_all(h->comm, e.gb_out, sc.data(), e.gb_in, rc_.data(), sizeof(float), st)) return rc;
       }
     }
     if (int rc = nncf_shard_apply(h, i, n_steps, lr, stream)) return rc;          // apply; rows of step i + 1 gathered

@@ -26,6 +26,8 @@ struct StepArgs {
   float* gV;  // if non-NULL the item rows are NOT updated: dL/dV rows are written to gV[row id][d]
               // (sharded mode: V is a buffer of fetched rows, gradients go back to their owners)
   float* gU = nullptr;   // the same for the user rows (same-global-batch multi-GPU step: both tables are landing buffers)
+  float* gcb = nullptr;  // if non-NULL the item bias is NOT stepped: d(loss)/d(cbias) per item-table row is written here (the weak
+                         // sharded form: the model's item rows AND bias values are landing slots, their owners take the step)
   // Rectangular neg_shared step (one-launch path only; no reference counterpart -- models/train_neg_shared.py:46-51 is one
   // b x b matrix on one device): bc != 0 -> this launch owns the b rows row0, row0 + row_step, ... of a bc x bc score
   // matrix.  uid[b] lists its positions' users, cid[bc] and the item plan all bc columns; the positive of local row i is

@@ -77,10 +77,8 @@ class HipBackend(object):
         self.mode, self.rank = mode, int(rank)
         kw = dict(engine_kwargs)
         self.bias = kw.get("interaction_bias")          # None | 'user' | 'item' | 'both' (interaction_dot.py:62-71)
-        if self.bias and mode != "strong":
-            raise NotImplementedError("interaction_bias on the sharded trainers: the same-global-batch form (ShardedGlobalBatch) only -- "
-                                      "the weak form's per-rank batches step the owners' rows from exported gradients, and the "
-                                      "one-launch step that exports them has no bias form")
+        if self.bias and mode != "strong" and kw.get("optimizer", "sgd") != "sgd":
+            raise NotImplementedError("interaction_bias on the weak sharded form steps with sparse SGD (the bias moments do not travel)")
         kw.pop("bias_item_count", None)
         self.b = kw["batch_size_p"]
         self.dim = (int(kw["dim"]) + 3) // 4 * 4   # physical row width (Engine pads to a multiple of 4)
@@ -123,7 +121,10 @@ class HipBackend(object):
         # this rank's shards of the InteractionDot bias vectors (zero-initialised, interaction_dot.py:62-71); the engine's own
         # vectors are their landing buffers (indexed by landing slot)
         zb = lambda rows: torch.zeros(rows, dtype=torch.float32, device=self.device)  # noqa: E731
-        self.bu = zb(local_users) if self.bias in ("user", "both") else None
+        if mode == "strong":
+            self.bu = zb(local_users) if self.bias in ("user", "both") else None
+        else:   # weak form: the users are local -- the engine's own user-bias vector IS the shard (stepped in place)
+            self.bu = self.engine.bias["ub"] if self.bias in ("user", "both") else None
         self.bi = zb(local_items) if self.bias in ("item", "both") else None
         self.lr = float(kw["learn_rate"])
         n = self.world * self.cap     # per-step protocol: the owner side merges the ranks' sorted request blocks (nncf_scatter_merge)
@@ -196,7 +197,7 @@ class HipBackend(object):
             self._sh = h
             if self.bias:
                 pb = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()  # noqa: E731
-                self._lib.check(L.nncf_shard_set_bias(h, pb(self.bu), pb(self.bi)))
+                self._lib.check(L.nncf_shard_set_bias(h, pb(self.bu) if strong else ctypes.c_void_p(), pb(self.bi)))
             if self.optimizer != "sgd":   # Adam state of this rank's shards (items; users too in the strong form)
                 dense = self.optimizer == "adam"
                 self._adam = []
@@ -239,8 +240,12 @@ class HipBackend(object):
                                          v_in=view(mb[3], n * self.dim, torch.float32, (n, self.dim)))
                 bo, bi_ = ctypes.c_void_p(), ctypes.c_void_p()
                 self._lib.check(L.nncf_shard_bias_buffers(h, xi, ctypes.byref(bo), ctypes.byref(bi_)))
-                if bo.value:   # the bias values of the same rows (replicated strong form with an interaction bias)
+                if bo.value:   # the bias values of the same rows (replicated strong form / weak form with an interaction bias)
                     bufs["x"][-1].update(bias_out=view(bo, own, torch.float32, (own,)), bias_in=view(bi_, n, torch.float32, (n,)))
+                go, gi = ctypes.c_void_p(), ctypes.c_void_p()
+                self._lib.check(L.nncf_shard_bias_grad_buffers(h, xi, ctypes.byref(go), ctypes.byref(gi)))
+                if go.value:   # weak form with an item bias: d(loss)/d(cbias) per landing slot travels back with the gradient rows
+                    bufs["x"][-1].update(gb_out=view(go, n, torch.float32, (n,)), gb_in=view(gi, own, torch.float32, (own,)))
             self._bufs = bufs
         return self._sh
 
@@ -528,8 +533,12 @@ class _Exchanger(object):
                     xb = bufs["x"][xi]
                     if exchange:
                         self._a2a(xb["g_in"], xb["g_out"], recv[:, xi, i], send[:, xi, i])
+                        if "gb_in" in xb:                                # ... and the item-bias gradients of the same slots
+                            self._a2a(xb["gb_in"], xb["gb_out"], recv[:, xi, i], send[:, xi, i])
                     else:
                         self._a2a(xb["g_in"], xb["g_out"])
+                        if "gb_in" in xb:
+                            self._a2a(xb["gb_in"], xb["gb_out"])
                 be.apply_at(i, cnt)                                      # apply; rows of step i + 1 gathered
         return losses
 

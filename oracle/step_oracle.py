@@ -906,6 +906,7 @@ class StepOracle(object):
                 continue
             d = np.zeros_like(tab)
             np.add.at(d, ids, gb.astype(self.dt))
+            self.last_gb = dict(getattr(self, "last_gb", {}), **{name[5:]: d})   # {'ub': ..., 'cb': ...}: summed per id (the sharded checkers)
             touched = np.unique(ids)
             if opt == "sgd":
                 tab[touched] -= lr * d[touched]

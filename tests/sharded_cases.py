@@ -73,27 +73,46 @@ def global_batches(seed=7):
     return out
 
 
-def simulate_weak(loss, world, skew=False):
+def simulate_weak(loss, world, skew=False, bias=None):
     """every rank's batch sees the pre-step tables; user rows are disjoint across ranks; item gradients are summed over
-    ranks (rank order) and applied once"""
-    c = conf(loss)
+    ranks (rank order) and applied once.  bias: the InteractionDot bias vectors likewise (user values with their user, the item
+    values' gradients summed over ranks); returns (U, V, losses[, ub, cb])."""
+    c = conf(loss, bias=bias)
     U, V = tables()
+    ub = np.zeros(NU, dtype=np.float32) if bias in ("user", "both") else None
+    cb = np.zeros(NI, dtype=np.float32) if bias in ("item", "both") else None
     bt = weak_batches(world, skew=skew)
     lr = np.float32(c.learn_rate)
     losses = []
     for t in range(STEPS):
         dV = np.zeros_like(V)
+        dcb = np.zeros(NI, dtype=np.float32)
         newU = U.copy()
+        new_ub = None if ub is None else ub.copy()
         row = []
         for r in range(world):
             uid, cid = bt[r][t]
             o = so.StepOracle(U, V, c, dtype=np.float32)
+            if ub is not None:
+                o.ub = ub.copy()
+            if cb is not None:
+                o.cb = cb.copy()
             row.append(o.step_neg_shared(uid, cid))
             touched = np.unique(uid)
             newU[touched] = o.U[touched]
+            if ub is not None:
+                new_ub[touched] = o.ub[touched]
+            if cb is not None:
+                dcb += o.last_gb["cb"]
             dV += o.last["dV"]
         U, V = newU, V - lr * dV
+        if ub is not None:
+            ub = new_ub
+        if cb is not None:
+            cb = cb - lr * dcb
         losses.append(row)
+    if bias:
+        return U, V, np.asarray(losses), ub, cb
     return U, V, np.asarray(losses)
 
 

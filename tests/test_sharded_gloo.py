@@ -194,11 +194,27 @@ class _CompactChunks(object):
 
 
 class ChunkedNumpyBackend(_CompactChunks, NumpyBackend):
-    """weak form: items exchanged, user rows local"""
+    """weak form: items exchanged, user rows local.  With an InteractionDot bias (conf.interaction_bias; round 6): the user bias
+    vector is local like the user rows, the item bias values travel with the item rows and their gradients back with the
+    gradient rows (HipBackend: nncf_shard_set_bias / nncf_shard_bias_grad_buffers on the weak form)."""
     nx = 1
 
     def _tables(self):
         return [(self.V, self.isz, self.i0, self.cap)]
+
+    def set_bias(self, ub_local, cb_shard):
+        self.ub, self.cb = ub_local, cb_shard      # float32 arrays or None
+
+    def _bias_shards(self):
+        return [getattr(self, "cb", None)]
+
+    def chunk_buffers(self):
+        first = not hasattr(self, "_bufs")
+        bufs = _CompactChunks.chunk_buffers(self)
+        if first and getattr(self, "cb", None) is not None:
+            xb = bufs["x"][0]
+            xb.update(gb_out=torch.zeros(xb["n"]), gb_in=torch.zeros(self.world * xb["n"]))
+        return bufs
 
     def plan_chunk(self, uid_chunk, cid_chunk, n_steps):
         self._plan_lists([cid_chunk], n_steps)
@@ -207,13 +223,35 @@ class ChunkedNumpyBackend(_CompactChunks, NumpyBackend):
         xb = self._bufs["x"][0]
         if self.world == 1:
             xb["rows_in"].copy_(xb["rows_out"][:self.cap])
+        if self.world == 1 and "bias_in" in xb:
+            xb["bias_in"].copy_(xb["bias_out"][:self.cap])
         o = so.StepOracle(self.U, xb["rows_in"].numpy(), self.conf, dtype=np.float32)
+        if getattr(self, "ub", None) is not None:
+            o.ub = self.ub                                  # local users: stepped in place
+        if "bias_in" in xb:
+            o.cb = xb["bias_in"].numpy().copy()             # landed values, indexed by landing slot
         loss = o.step_neg_shared(uid_step.numpy(), self._slots[0][index])
         self.U[...] = o.U
         xb["g_out"].copy_(torch.from_numpy(o.last["dV"].astype(np.float32)))
+        if "gb_out" in xb:                                  # d(loss)/d(cbias) per landing slot leaves; the owners step
+            xb["gb_out"].copy_(torch.from_numpy(o.last_gb["cb"].astype(np.float32)[:self.cap]))
         if self.world == 1:
             xb["g_in"][:self.cap] = xb["g_out"]
+            if "gb_out" in xb:
+                xb["gb_in"][:self.cap] = xb["gb_out"]
         loss_out.copy_(torch.tensor([loss]).reshape(loss_out.shape))
+
+    def apply_at(self, index, n_steps):
+        if getattr(self, "cb", None) is not None:           # the item bias of the requested ids: requester order, then one SGD step
+            gb = self._bufs["x"][0]["gb_in"].numpy()
+            acc, k = {}, 0
+            for blk in self._blocks(0, index):
+                for it in blk:
+                    acc[it] = acc.get(it, np.float32(0)) + gb[k]
+                    k += 1
+            for it, g in acc.items():
+                self.cb[it - self.i0] -= self.lr * g
+        _CompactChunks.apply_at(self, index, n_steps)
 
 
 class StrongNumpyBackend(_CompactChunks):
@@ -341,28 +379,48 @@ class ReplicatedNumpyBackend(_CompactChunks):
             self._gather(index + 1)
 
 
-def simulate_global_steps(loss, world, skew=False):
+def simulate_global_steps(loss, world, skew=False, bias=None):
     """Single-process restatement: every rank's batch sees the pre-step tables; user rows are
-    disjoint across ranks; item gradients are summed over ranks (rank order) and applied once."""
-    conf = _conf(loss)
+    disjoint across ranks; item gradients are summed over ranks (rank order) and applied once.
+    bias: the InteractionDot bias vectors go the same way (user values with their user, item values summed over ranks);
+    returns (U, V, losses[, ub, cb])."""
+    conf = _conf(loss, bias=bias)
     U, V = _tables()
+    ub = np.zeros(NU, dtype=np.float32) if bias in ("user", "both") else None
+    cb = np.zeros(NI, dtype=np.float32) if bias in ("item", "both") else None
     batches = _batches(world, skew=skew)
     lr = np.float32(conf.learn_rate)
     losses = []
     for t in range(STEPS):
         dV = np.zeros_like(V)
+        dcb = np.zeros(NI, dtype=np.float32)
         newU = U.copy()
+        new_ub = None if ub is None else ub.copy()
         step_losses = []
         for r in range(world):
             uid, cid = batches[r][t]
             o = so.StepOracle(U, V, conf, dtype=np.float32)
+            if ub is not None:
+                o.ub = ub.copy()
+            if cb is not None:
+                o.cb = cb.copy()
             step_losses.append(o.step_neg_shared(uid, cid))
             touched = np.unique(uid)
             newU[touched] = o.U[touched]
+            if ub is not None:
+                new_ub[touched] = o.ub[touched]
+            if cb is not None:
+                dcb += o.last_gb["cb"]
             dV += o.last["dV"]
         U = newU
         V = V - lr * dV
+        if ub is not None:
+            ub = new_ub
+        if cb is not None:
+            cb = cb - lr * dcb
         losses.append(step_losses)
+    if bias:
+        return U, V, losses, ub, cb
     return U, V, losses
 
 
@@ -385,23 +443,26 @@ def _worker(rank, world, port, loss, ret):
     dist.destroy_process_group()
 
 
-def _worker_chunked(rank, world, port, loss, ret, skew=False):
+def _worker_chunked(rank, world, port, loss, ret, skew=False, bias=None):
     """the same global steps through ShardedNegShared.run_epoch (plans + id all-to-all batched per chunk)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    conf = _conf(loss)
+    conf = _conf(loss, bias=bias)
     U, V = _tables()
     us, isz = shard_size(NU, world), shard_size(NI, world)
     be = ChunkedNumpyBackend(conf, U[rank * us:(rank + 1) * us].copy(), V[rank * isz:(rank + 1) * isz].copy(), world, isz,
                              rank * isz)
+    if bias:
+        be.set_bias(np.zeros(min(us, NU - rank * us), dtype=np.float32) if bias in ("user", "both") else None,
+                    np.zeros(min(isz, NI - rank * isz), dtype=np.float32) if bias in ("item", "both") else None)
     tr = ShardedNegShared(be, NU, NI, B, D)
     bt = _batches(world, skew=skew)[rank]
     uid = torch.from_numpy(np.concatenate([(u - rank * us) for u, _ in bt]).astype(np.int32))
     cid = torch.from_numpy(np.concatenate([c for _, c in bt]).astype(np.int32))
     losses = torch.zeros(STEPS)
     tr.run_epoch(uid, cid, STEPS, losses)
-    ret[rank] = (be.U.copy(), be.V.copy(), [float(x) for x in losses])
+    ret[rank] = (be.U.copy(), be.V.copy(), [float(x) for x in losses]) + ((getattr(be, "ub", None), getattr(be, "cb", None)) if bias else ())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -469,6 +530,35 @@ def test_chunked_epoch_with_unequal_splits_and_an_empty_peer(loss, world):
         np.testing.assert_allclose(Vr, V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
         for t in range(STEPS):
             assert abs(lr_[t] - losses[t][r]) < 1e-5 * max(1, abs(losses[t][r]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("loss,bias", [("skip-gram", "both"), ("mse", "item"), ("log-loss", "user")])
+def test_weak_form_with_an_interaction_bias(loss, bias, world):
+    """InteractionDot bias (interaction_dot.py:62-71,96-107) on the WEAK sharded form (round 6): the user bias
+    is local like the user rows, the item bias values travel with the item rows and their gradients come back with the gradient
+    rows; the owners add the ranks' values in rank order and take the SGD step.  Skewed batches (an empty peer, lopsided splits)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_chunked, args=(world, _free_port(), loss, ret, True, bias), nprocs=world, join=True)
+    U, V, losses, ub, cb = simulate_global_steps(loss, world, skew=True, bias=bias)
+    us, isz = shard_size(NU, world), shard_size(NI, world)
+    for r in range(world):
+        Ur, Vr, lr_, ubr, cbr = ret[r]
+        np.testing.assert_allclose(Ur, U[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vr, V[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+        for t in range(STEPS):
+            assert abs(lr_[t] - losses[t][r]) < 1e-5 * max(1, abs(losses[t][r]))
+        if ub is not None:
+            np.testing.assert_allclose(ubr, ub[r * us:(r + 1) * us], rtol=1e-5, atol=1e-6)
+            assert np.abs(ub).max() > 1e-4
+        else:
+            assert ubr is None
+        if cb is not None:
+            np.testing.assert_allclose(cbr, cb[r * isz:(r + 1) * isz], rtol=1e-5, atol=1e-6)
+            assert np.abs(cb).max() > 1e-4
+        else:
+            assert cbr is None
 
 
 def test_world1_equals_plain_step():

@@ -439,10 +439,48 @@ def test_strong_form_with_an_interaction_bias_equals_the_oracle(loss, bias):
         np.testing.assert_allclose(be.bi.cpu().numpy(), orc.cb, rtol=1e-4, atol=2e-5)
 
 
-def test_the_weak_form_refuses_an_interaction_bias():
+@pytest.mark.parametrize("bias", ["user", "item", "both"])
+@pytest.mark.parametrize("loss", ["skip-gram", "log-loss"])
+def test_weak_form_with_an_interaction_bias_equals_the_oracle(loss, bias):
+    """InteractionDot bias (interaction_dot.py:62-71,96-107) on the WEAK sharded form (ShardedNegShared), world 1:
+    the user bias is the engine's own vector, the item bias values are gathered with the rows into the landing vector, the
+    tile + apply + bias-update kernels export d(loss)/d(cbias) per landing slot (StepArgs::gcb) and merge_bias_kernel steps the
+    owner's shard -- 70 steps == the oracle's one-device step with the same bias."""
+    b, d, nu, ni, steps = 64, 20, 300, 500, 70
+    kw = dict(user_count=nu, item_count=ni, dim=d, batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias=bias)
+    be = HipBackend(kw, nu, ni, 0, world=1, item_shard=ni, item_offset=0, seed=0)
+    assert (be.bu is not None) == (bias != "item") and (be.bi is not None) == (bias != "user")
+    conf = so.OracleConf(batch_size_p=b, num_negatives=0, loss=loss, loss_gamma=10., neg_loss_weight=16., u_reg=1e-3,
+                         learn_rate=0.1, model_choice="mf", emb_normalization=False, interaction_bias=bias)
+    orc = so.StepOracle(be.U.cpu().numpy(), be.V.cpu().numpy(), conf, dtype=np.float64)
+    rs = np.random.RandomState(3)
+    uid = rs.randint(0, nu, steps * b)
+    uid[:6] = uid[0]
+    cid = np.where(np.arange(steps * b) // b % 2 == 1, rs.randint(0, 40, steps * b), rs.randint(0, ni, steps * b))
+    tr = ShardedNegShared(be, nu, ni, b, d)
+    losses = torch.zeros(steps, dtype=torch.float32, device=be.device)
+    tr.run_epoch(be.ids(uid), be.ids(cid), steps, losses)
+    be.engine.check()
+    l = losses.cpu().numpy()
+    for t in range(steps):
+        want = orc.step_neg_shared(uid[t * b:(t + 1) * b], cid[t * b:(t + 1) * b])
+        assert abs(l[t] - want) <= 1e-5 * max(1, abs(want)), (t, l[t], want)
+    np.testing.assert_allclose(be.U.cpu().numpy(), orc.U, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(be.V.cpu().numpy(), orc.V, rtol=1e-4, atol=2e-5)
+    if be.bu is not None:
+        assert np.abs(orc.ub).max() > 1e-3
+        np.testing.assert_allclose(be.bu.cpu().numpy(), orc.ub, rtol=1e-4, atol=2e-5)
+    if be.bi is not None:
+        assert np.abs(orc.cb).max() > 1e-3 or loss == "log-loss"   # (neg_shared pairwise: the item bias cancels, its gradient is 0)
+        np.testing.assert_allclose(be.bi.cpu().numpy(), orc.cb, rtol=1e-4, atol=2e-5)
+
+
+def test_the_weak_form_with_a_bias_refuses_adam():
     kw = dict(user_count=300, item_count=500, dim=20, batch_size_p=64, num_negatives=0, loss="skip-gram", loss_gamma=10.,
-              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias="both")
-    with pytest.raises(NotImplementedError, match="same-global-batch"):
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias="both",
+              optimizer="adam")
+    with pytest.raises(NotImplementedError, match="sparse SGD"):
         HipBackend(kw, 300, 500, 0, world=1, item_shard=500, item_offset=0, seed=0)
 
 

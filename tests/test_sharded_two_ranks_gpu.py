@@ -95,6 +95,34 @@ def test_weak_form_two_ranks_with_unequal_splits_and_an_empty_peer(tmp_path, tra
         assert_within_sum_bound(got[r]["V"], V[r * isz:(r + 1) * isz], V0[r * isz:(r + 1) * isz], world * sc.B, 2 * sc.STEPS, "V shard %d" % r)
 
 
+@pytest.mark.parametrize("loss,bias,transport", [("skip-gram", "both", "torch"), ("skip-gram", "both", "callback"), ("mse", "item", "callback"),
+                                                 ("log-loss", "user", "torch")])
+def test_weak_form_two_ranks_with_an_interaction_bias(tmp_path, loss, bias, transport):
+    """InteractionDot bias (interaction_dot.py:62-71,96-107) on the WEAK sharded form over two HIP ranks (round 6): the user bias is
+    the engine's own vector (local users), the item bias values travel with the rows (gather_bias_kernel), the tile + apply pair
+    exports d(loss)/d(cbias) per landing slot (StepArgs::gcb), the values come back next to the gradient rows and
+    merge_bias_kernel adds the ranks' values in rank order and steps the owner's shard -- with the skewed batches (an empty peer).
+    transport = callback: all of it from nncf_shard_run_chunk."""
+    world = 2
+    got = _run_ranks("weak", world, tmp_path, loss, NNCF_SHARD_TRANSPORT=transport, NNCF_TEST_BIAS=bias, NNCF_TEST_SKEW="1")
+    U, V, losses, ub, cb = sc.simulate_weak(loss, world, skew=True, bias=bias)
+    us, isz = sc.shard_size(sc.NU, world), sc.shard_size(sc.NI, world)
+    U0, V0 = sc.tables()
+    for r in range(world):
+        np.testing.assert_allclose(got[r]["losses"], losses[:, r], rtol=1e-5)
+        assert_within_sum_bound(got[r]["U"], U[r * us:(r + 1) * us], U0[r * us:(r + 1) * us], sc.B, 2 * sc.STEPS, "U shard %d" % r)
+        assert_within_sum_bound(got[r]["V"], V[r * isz:(r + 1) * isz], V0[r * isz:(r + 1) * isz], world * sc.B, 2 * sc.STEPS, "V shard %d" % r)
+        for name, want, lo, hi, terms in (("bu", ub, r * us, (r + 1) * us, sc.B), ("bi", cb, r * isz, (r + 1) * isz, world * sc.B)):
+            assert (name in got[r]) == (want is not None), name
+            if want is not None:
+                w = want[lo:hi]
+                assert_within_sum_bound(got[r][name], w, np.zeros_like(w), terms, 2 * sc.STEPS, "%s shard %d" % (name, r))
+    if ub is not None:
+        assert np.abs(ub).max() > 1e-3
+    if cb is not None:
+        assert np.abs(cb).max() > 1e-3
+
+
 @pytest.mark.parametrize("loss,transport", [("skip-gram", "torch"), ("mse", "torch"), ("skip-gram", "callback"),
                                             ("log-loss", "torch"), ("max-margin", "torch"), ("log-loss", "callback")])
 def test_strong_form_two_ranks_equal_the_single_device_step(tmp_path, loss, transport):
