@@ -191,7 +191,17 @@ __device__ __forceinline__ float word_scale(const TowerArgs& a, int w) {
 }
 
 // Keras-1 activations of the Dense tail (keras/activations.py by name; hard_sigmoid = clip(0.2 y + 0.5, 0, 1) [K-mem])
-enum { kActRelu = 0, kActTanh, kActSigmoid, kActHardSigmoid, kActSoftplus, kActSoftsign, kActLinear, kActCount };
+// kActSoftmax (keras/activations.py softmax on a 2-D tensor: over the item_dim columns of a row) is not element-wise: tail_act /
+// tail_act_grad pass it through as linear and the row kernels (tower_bn_kernel, tower_tail_grad_kernel, tower_softmax_rows_kernel)
+// do the row's maximum / sum / dot themselves
+enum { kActRelu = 0, kActTanh, kActSigmoid, kActHardSigmoid, kActSoftplus, kActSoftsign, kActLinear, kActSoftmax, kActCount };
+__device__ __forceinline__ float row16_max(float v) {   // over the 16 lanes of a row group
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  return v;
+}
 __device__ __forceinline__ float tail_act(int k, float y) {
   switch (k) {
     case kActRelu: return fmaxf(y, 0.f);

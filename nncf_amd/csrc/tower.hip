@@ -374,7 +374,28 @@ __global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
   __syncthreads();
   if (row >= a.m) return;
   Row o = row_zero();  // rows past n_valid: zeros (never referenced by the step, kept finite)
-  if (row < nv) {
+  if (a.tail_act == kActSoftmax) {   // softmax over the row's d columns (the 16 lanes of the group hold them), then the dropout mask
+    float y[8], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col_of(q, e);
+      y[e] = (row < nv && c < a.d) ? fmaf(relem(z, e), sMul[c], sAdd[c]) : -INFINITY;
+      mx = fmaxf(mx, y[e]);
+    }
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      y[e] = (y[e] == -INFINITY) ? 0.f : expf(y[e] - mx);
+      sum += y[e];
+    }
+    sum = row16_sum(sum);
+    if (row < nv) {
+      const float rs = 1.f / sum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) relem(o, e) = y[e] * rs * tail_mask(a.tail_keep, a.tail_seed, row, col_of(q, e));
+    }
+  } else if (row < nv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = col_of(q, e);
@@ -382,6 +403,31 @@ __global__ void __launch_bounds__(256) tower_bn_kernel(TowerArgs a) {
     }
   }
   row_store(a.E, row, a.d, d4, q, o);
+}
+
+// rows of E hold the pre-activation y (inference forwards of a softmax tail: tail_act passes softmax through as linear): E = softmax(E)
+__global__ void __launch_bounds__(256) tower_softmax_rows_kernel(float* __restrict__ E, int m, int d) {
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4), q = threadIdx.x & 15, d4 = d >> 2;
+  if (row >= m) return;   // (whole 16-lane groups leave together: the row reductions below stay inside a group)
+  Row y = row_load(E, row, d, d4, q);
+  float v[8], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = col_of(q, e) < d ? relem(y, e) : -INFINITY;
+    mx = fmaxf(mx, v[e]);
+  }
+  mx = row16_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = (v[e] == -INFINITY) ? 0.f : expf(v[e] - mx);
+    sum += v[e];
+  }
+  sum = row16_sum(sum);
+  Row o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) relem(o, e) = v[e] / sum;
+  row_store(E, row, d, d4, q, o);
 }
 
 // a tower without item_dense_transform: the pooled block h [m][hd] is the item block E [m][d] (hd == d); rows past n_valid: zeros
@@ -405,7 +451,35 @@ __global__ void __launch_bounds__(256) tower_tail_grad_kernel(TowerArgs a, float
   __syncthreads();
   if (row >= a.m) return;
   Row o = row_zero();
-  if (row < nv) {
+  if (a.tail_act == kActSoftmax) {   // dy_c = s_c (g_c - sum_j g_j s_j), g = dA * mask, s = softmax(y) recomputed from z
+    Row z = row < nv ? row_load(a.z, row, a.d, d4, q) : row_zero(), g = row < nv ? row_load(a.dA, row, a.d, d4, q) : row_zero();
+    float y[8], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col_of(q, e);
+      y[e] = (row < nv && c < a.d) ? fmaf(relem(z, e), sMul[c], sAdd[c]) : -INFINITY;
+      mx = fmaxf(mx, y[e]);
+    }
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      y[e] = (y[e] == -INFINITY) ? 0.f : expf(y[e] - mx);
+      sum += y[e];
+    }
+    sum = row16_sum(sum);
+    const float rs = row < nv ? 1.f / sum : 0.f;
+    float gm[8], dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      y[e] *= rs;
+      gm[e] = relem(g, e) * tail_mask(a.tail_keep, a.tail_seed, row, col_of(q, e));
+      dot = fmaf(gm[e], y[e], dot);
+    }
+    dot = row16_sum(dot);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) relem(o, e) = y[e] * (gm[e] - dot);
+  } else if (row < nv) {
     Row z = row_load(a.z, row, a.d, d4, q), g = row_load(a.dA, row, a.d, d4, q);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1404,6 +1478,8 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
     NNCF_HIP_CHECK(hipGetLastError());
     return NNCF_OK;
   }
+  if (!train && E && t->tail_act == kActSoftmax)   // inference rows hold the pre-activation (tail_act passes softmax through): finish them
+    hipLaunchKernelGGL(tower_softmax_rows_kernel, dim3((m + 15) / 16), dim3(256), 0, st, E, m, t->cfg.item_dim);
   if (train && stats_by_consumer) {  // the one-launch step derives the statistics itself (step_fused.hip)
     t->last = a;
     t->fwd_cached = true;
@@ -2022,7 +2098,7 @@ int nncf_tower_set_no_bn(nncf_tower* t, int32_t no_bn) {
 int nncf_tower_set_dense_tail(nncf_tower* t, int32_t activation, float dropout) {
   NNCF_REQUIRE(t != nullptr, "tower is NULL");
   NNCF_REQUIRE(activation >= 0 && activation < kActCount, "activation %d: 0 relu, 1 tanh, 2 sigmoid, 3 hard_sigmoid, 4 softplus, "
-               "5 softsign, 6 linear", activation);
+               "5 softsign, 6 linear, 7 softmax", activation);
   NNCF_REQUIRE(dropout >= 0.f && dropout < 1.f, "dropout rate %g out of [0, 1)", (double)dropout);
   NNCF_REQUIRE(!t->no_dense || (activation == 0 && dropout == 0.f), "the Dense-less tower has no Dense tail to vary");
   if ((activation != 0 || dropout > 0.f) && !t->dA_tail) {

@@ -268,13 +268,13 @@ class MeanPoolTower(object):
             _lib.check(self._L.nncf_tower_set_pooling(self.handle, int(pooling == "max")))
         self.version += 1
 
-    DENSE_ACTIVATIONS = ("relu", "tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear")
+    DENSE_ACTIVATIONS = ("relu", "tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear", "softmax")
 
     def set_dense_tail(self, activation="relu", dropout=0.0):
         """item_dense_transform['dense_hidden_actv'] / ['dense_hidden_dropout'] (mean_pool.py:82-97, cnn_model.py:114-126)."""
         if activation not in self.DENSE_ACTIVATIONS:
             raise NotImplementedError("dense_hidden_actv = %r: built are %s" % (activation, ", ".join(self.DENSE_ACTIVATIONS)))
-        if self.d_l != self.d and activation in ("sigmoid", "hard_sigmoid", "softplus"):
+        if self.d_l != self.d and activation in ("sigmoid", "hard_sigmoid", "softplus", "softmax"):
             raise NotImplementedError("dense_hidden_actv = %r needs item_dim %% 4 == 0 (act(0) != 0 would fill the pad columns)" % activation)
         self.dense_act, self.dense_dropout = activation, float(dropout)
         with torch.cuda.device(self.device):

@@ -494,7 +494,13 @@ class TowerOracle(object):
             y = self.gamma * xhat + self.beta
             if train:
                 self.cache.update(h=h, xhat=xhat, inv=inv, y=y, mu=mu, var=var)
-        act = self.ACTIVATIONS[self.dense_act][0](y)
+        if self.dense_act == "softmax":    # keras/activations.py softmax on a 2-D tensor: over the row's item_dim columns
+            e = np.exp(y - y.max(axis=1, keepdims=True))
+            act = e / e.sum(axis=1, keepdims=True)
+            if train:
+                self.cache["softmax"] = act
+        else:
+            act = self.ACTIVATIONS[self.dense_act][0](y)
         if train and self.dense_mask is not None:
             act = act * self.dense_mask[:len(act)]
         out = self._plus_content_id(act.astype(self.dt), cid_u, train)
@@ -543,9 +549,14 @@ class TowerOracle(object):
                     self.slots[k].step(getattr(self, k), self.grads[k].astype(self.dt), lr_t, conf, rows if k == "W" else None)
             return
         n = self.dt.type(dA.shape[0])
-        dy = dA * self.ACTIVATIONS[self.dense_act][1](c["y"])
-        if self.dense_mask is not None:
-            dy = dy * self.dense_mask[:len(dy)]
+        if self.dense_act == "softmax":    # dy_c = s_c (g_c - sum_j g_j s_j), g = dA * mask
+            g = dA if self.dense_mask is None else dA * self.dense_mask[:len(dA)]
+            sm = c["softmax"]
+            dy = sm * (g - (g * sm).sum(axis=1, keepdims=True))
+        else:
+            dy = dA * self.ACTIVATIONS[self.dense_act][1](c["y"])
+            if self.dense_mask is not None:
+                dy = dy * self.dense_mask[:len(dy)]
         if self.no_bn:     # y = z: the Dense bias has a gradient of its own, gamma / beta none
             dgamma, dbeta, dz = np.zeros_like(self.gamma), np.zeros_like(self.beta), dy
         else:

@@ -338,7 +338,7 @@ def test_tower_oracle_pooling_max_and_content_id_vs_autograd(pooling, content_id
         np.testing.assert_allclose(Cid - tw.Cid, 0.1 * tp[5].grad.numpy(), atol=1e-10)
 
 
-@pytest.mark.parametrize("act", ["tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear", "relu"])
+@pytest.mark.parametrize("act", ["tanh", "sigmoid", "hard_sigmoid", "softplus", "softsign", "linear", "relu", "softmax"])
 def test_tower_oracle_dense_tail_variants_vs_autograd(act):
     """item_dense_transform['dense_hidden_actv'] other than relu and Dropout(dense_hidden_dropout) (mean_pool.py:82-97): loss
     and every gradient of the oracle against torch autograd of Dense -> BatchNorm -> Activation -> Dropout (a given mask)."""
@@ -365,7 +365,7 @@ def test_tower_oracle_dense_tail_variants_vs_autograd(act):
     y = tp[3] * (z - mu) / torch.sqrt(((z - mu) ** 2).mean(0) + 1e-3) + tp[4]
     f = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "hard_sigmoid": lambda v: torch.clamp(0.2 * v + 0.5, 0, 1),
          "softplus": torch.nn.functional.softplus, "softsign": torch.nn.functional.softsign, "linear": lambda v: v,
-         "relu": torch.relu}[act]
+         "relu": torch.relu, "softmax": lambda v: torch.softmax(v, dim=1)}[act]
     E = f(y) * torch.tensor(mask[:len(cu)])
     l_t = _torch_neg_shared(tU, E, torch.tensor(uid), torch.tensor(cx, dtype=torch.long), conf)
     l_t.backward()

@@ -1298,6 +1298,9 @@ def test_c_reg_matches_oracle(text_data, model, scheme, loss, opt, big):
     ("basic_embedding", "neg_shared", "mse", "sgd", "hard_sigmoid", 0.0),
     ("basic_embedding", "neg_shared", "skip-gram", "sgd", "softsign", 0.2),
     ("basic_embedding", "original", "log-loss", "sgd", "linear", 0.0),
+    ("basic_embedding", "neg_shared", "skip-gram", "sgd", "softmax", 0.0),
+    ("basic_embedding", "group_neg_shared", "log-loss", "sgd", "softmax", 0.2),
+    ("cnn_embedding", "neg_shared", "skip-gram", "sgd", "softmax", 0.0),
     ("cnn_embedding", "neg_shared", "skip-gram", "sgd", "tanh", 0.2),
     ("cnn_embedding", "original", "skip-gram", "sgd", "linear", 0.0),
 ])
