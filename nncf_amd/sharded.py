@@ -148,6 +148,9 @@ class HipBackend(object):
         if self.optimizer != "sgd":
             raise NotImplementedError("the per-step protocol (static splits) steps the owners' rows with sparse SGD only; "
                                       "run_epoch (the chunked protocol) carries the Adam state of the shards")
+        if self.bias:   # the landing bias vector would be stepped in place and never reach its owner: refuse, do not mis-train
+            raise NotImplementedError("the per-step protocol (ShardedNegShared.step) has no interaction_bias form; "
+                                      "run_epoch (the chunked protocol) moves the item bias values and their gradients")
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         self._lib.check(self._lib.lib().nncf_shard_route(p(cid), cid.numel(), self.item_shard, self.world, self.cap,
                                                          p(self.req), p(self.slot), p(self._ws_route), self._stream()))

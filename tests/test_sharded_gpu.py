@@ -476,6 +476,18 @@ def test_weak_form_with_an_interaction_bias_equals_the_oracle(loss, bias):
         np.testing.assert_allclose(be.bi.cpu().numpy(), orc.cb, rtol=1e-4, atol=2e-5)
 
 
+def test_the_per_step_protocol_refuses_an_interaction_bias():
+    """ShardedNegShared.step() (static splits, nncf_step_neg_shared_export) would step the LANDING bias vector in place and the
+    owners would never see it: refused loudly; run_epoch (the chunked protocol) is the bias-carrying road."""
+    kw = dict(user_count=300, item_count=500, dim=20, batch_size_p=64, num_negatives=0, loss="skip-gram", loss_gamma=10.,
+              neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias="item")
+    be = HipBackend(kw, 300, 500, 0, world=1, item_shard=500, item_offset=0, seed=0)
+    tr = ShardedNegShared(be, 300, 500, 64, 20)
+    rs = np.random.RandomState(0)
+    with pytest.raises(NotImplementedError, match="chunked protocol"):
+        tr.step(be.ids(rs.randint(0, 300, 64)), be.ids(rs.randint(0, 500, 64)))
+
+
 def test_the_weak_form_with_a_bias_refuses_adam():
     kw = dict(user_count=300, item_count=500, dim=20, batch_size_p=64, num_negatives=0, loss="skip-gram", loss_gamma=10.,
               neg_loss_weight=16., u_reg=1e-3, learn_rate=0.1, normalize_user=False, normalize_item=False, interaction_bias="both",
