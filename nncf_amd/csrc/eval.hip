@@ -28,6 +28,18 @@
 #include "model.h"
 #include "step.h"
 
+#ifndef NNCF_EVAL_SLOTSKIP
+#define NNCF_EVAL_SLOTSKIP 0
+#endif
+// developer build (tools/build_variant.sh evalstamps "-DNNCF_EVAL_STAMPS=1"; tools/eval_stamps.py): every wave of workgroup 0 adds up
+// the shader cycles it spends in each phase of a stage into the model's stamp buffer (NNCF_DEBUG_TIMING=1)
+#ifndef NNCF_EVAL_STAMPS
+#define NNCF_EVAL_STAMPS 0
+#endif
+#ifndef NNCF_EVAL_PRELOAD
+#define NNCF_EVAL_PRELOAD 1
+#endif
+
 namespace nncf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -291,11 +303,109 @@ __device__ __forceinline__ void eval_cut_lists2(unsigned long long* la, int ca, 
   if (dob) compact(lb, kb, tb); else tb = 0ull;
 }
 
+// One wave cuts the lists of its EIGHT users at once (round 6; the pairwise search above cost ~25 k cycles per cut event: a fifth of a
+// whole@50 pass -- in-kernel stamps): user e of the wave owns the 8-lane group e, 24 keys per lane in registers.  The threshold is a
+// SCORE (the high half of a key), found bit by bit from the first bit in which the list's scores differ; the search stops as soon
+// as between k and `keep` keys reach the candidate -- any threshold that leaves at least k keys is a valid one, the k-th itself is
+// needed only at the very end (eval_cut_lists2) -- so a cut is ~6-8 rounds of 24 compares instead of 4 x 32 rounds of ballots.
+// A list whose k-th score is shared by so many keys that more than `keep` remain (equal scores: an untrained model) is left to the
+// exact routine: returned as a mask of user groups.
+template <int LIST>
+__device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, int* cnts, unsigned long long* taus, int k, int keep, int lane) {
+  static_assert(LIST <= 192, "24 keys per lane x 8 lanes");
+  const int ug = lane >> 3, sub = lane & 7;
+  unsigned long long* list = lists + ug * LIST;
+  const int cnt = cnts[ug];
+  const bool need = cnt > keep;   // (uniform within the group)
+  if (!__ballot(need)) return 0u;
+  uint32_t hi[24], lo[24];
+  uint32_t mx = 0u, mn = 0xFFFFFFFFu;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const bool real = sub + 8 * i < cnt;
+    const unsigned long long key = real ? list[sub + 8 * i] : 0ull;
+    hi[i] = (uint32_t)(key >> 32);
+    lo[i] = (uint32_t)key;
+    mx = max(mx, hi[i]);
+    mn = real ? min(mn, hi[i]) : mn;
+  }
+  auto group_max = [&](uint32_t v) -> uint32_t {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+    return max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  };
+  auto group_sum = [&](int v) -> int {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  };
+  mx = group_max(mx);
+  mn = ~group_max(~mn);
+  // the scores of the list agree above bit `top`: h starts as that common prefix (every key reaches it)
+  const uint32_t diff = mx ^ mn;
+  const int top = diff ? 31 - __builtin_clz(diff) : -1;
+  uint32_t h = (top >= 31) ? 0u : (mx & ~((2u << max(top, 0)) - 1u));
+  if (top < 0) h = mx;
+  bool done = !need || top < 0;   // (all scores equal: nothing to search; the count below decides)
+  int start = -1;   // the highest bit any of the wave's lists has to decide (scalar: a lane of each group)
+  {
+    const int mine_top = need ? top : -1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) start = max(start, __builtin_amdgcn_readlane(mine_top, 8 * e));
+  }
+  for (int bit = start; bit >= 0; --bit) {
+    if (!__ballot(!done)) break;
+    const uint32_t c = h | (1u << bit);
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) n += hi[i] >= c ? 1 : 0;
+    n = group_sum(n);
+    if (!done && n >= k) {
+      h = c;
+      done = n <= keep;
+    }
+  }
+  // keys that stay: score >= h (every key of that score: ties included)
+  int mine = 0;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) mine += (sub + 8 * i < cnt && hi[i] >= h) ? 1 : 0;
+  const int kept = group_sum(mine);
+  const bool ok = need && kept <= keep;     // else: too many keys share the k-th score (or the list is left alone)
+  // lane-major compaction: exclusive prefix of `mine` over the group's lanes
+  int inc = mine, t;
+  t = __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1
+  if (sub >= 1) inc += t;
+  t = __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
+  if (sub >= 2) inc += t;
+  t = __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
+  if (sub >= 4) inc += t;
+  int pos = inc - mine;
+  __builtin_amdgcn_wave_barrier();   // every read of the lists above precedes the stores below (one wave, LDS in order)
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      if (sub + 8 * i < cnt && hi[i] >= h) {
+        list[pos] = ((unsigned long long)hi[i] << 32) | lo[i];
+        ++pos;
+      }
+    }
+    if (sub == 0) {
+      taus[ug] = (unsigned long long)h << 32;   // every key of score h or above passes (key > tau: the slot half of a real key is never 0)
+      cnts[ug] = kept;
+    }
+  }
+  unsigned fb = 0u;
+  const unsigned long long bad = __ballot(need && !ok);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) fb |= ((bad >> (8 * e)) & 1ull) ? (1u << e) : 0u;
+  return fb;
+}
+
 template <int NK>
 __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32_t* __restrict__ uid, int64_t n_users,
                                                          const int32_t* __restrict__ cand, int n_cand,
                                                          const int32_t* __restrict__ truth_ptr, const int32_t* __restrict__ truth_idx,
-                                                         int topk, float* __restrict__ metrics, int32_t* __restrict__ valid, int dbg) {
+                                                         int topk, float* __restrict__ metrics, int32_t* __restrict__ valid, int dbg, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float eval_smem[];
   constexpr int DP = 4 * NK + 2;   // row pitch: the fragments' dword reads (16 rows x 2 k of a half wave) hit 32 different banks
   constexpr int LIST = eval_list_cap<NK>();
@@ -313,6 +423,19 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   const int d4 = a.d >> 2;
   const int64_t u0 = (int64_t)blockIdx.x * kEvalUsers;
   const int kk = min(topk, n_cand);
+#if NNCF_EVAL_STAMPS
+  unsigned ph[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned tprev = 0u;
+  auto cyc = [&]() -> unsigned { return (unsigned)__builtin_readcyclecounter(); };   // s_memtime (gfx9 has no SHADER_CYCLES register); waits for lgkmcnt
+#define ESTAMP(k)                                   \
+  {                                                 \
+    const unsigned now_ = cyc();                    \
+    ph[k] += now_ - tprev;                          \
+    tprev = now_;                                   \
+  }
+#else
+#define ESTAMP(k)
+#endif
   auto store_row = [&](float* dst, const Row& hat) {   // columns [d, 4 NK) are zeros: they add nothing to a score
     float2* p = reinterpret_cast<float2*>(dst);
     p[2 * q] = make_float2(hat.a.x, hat.a.y);
@@ -363,31 +486,39 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       tau_f[t][r] = (tau_k[t][r] == 0ull) ? -__builtin_inff() : __builtin_inff();
     }
   // ---- candidate stages: ids two stages ahead, rows one stage ahead in registers, LDS stage double-buffered ----------
+  // Every request of the loop is UNCONDITIONAL (a candidate index past the end reads the last candidate: its column is never ranked;
+  // a lane without a second chunk of the row repeats its first: zeroed at the store).  Predicated loads sit in branches, the
+  // compiler then cannot count what is in flight and waited for everything (s_waitcnt vmcnt(0)) at the top of every stage --
+  // the rows requested a few hundred cycles earlier, in front of the barrier (ISA, round 6).
   const int nst = (n_cand + kEvalStage - 1) / kEvalStage;
-  int idn[2], idc[2];   // ids of the rows requested next / of the rows in rown
+  int idn[2];      // ids of the rows requested next
   Row rown[2];
+  const int qa = min(q, d4 - 1), qb = (q + 16 < d4) ? q + 16 : qa;
   auto load_ids = [&](int st) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int j = st * kEvalStage + g + 32 * e;
-      idn[e] = (st < nst && j < n_cand) ? cand[j] : -1;
-    }
+    for (int e = 0; e < 2; ++e) idn[e] = cand[min(st * kEvalStage + g + 32 * e, n_cand - 1)];
   };
-  auto load_rows = [&]() {   // the rows of the ids in idn; they become the current ids
+  auto load_rows = [&]() {   // the rows of the ids in idn
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      rown[e] = idn[e] >= 0 ? row_load(a.V, idn[e], a.stride, d4, q) : row_zero();
-      idc[e] = idn[e];
+      const float4* p = reinterpret_cast<const float4*>(a.V + (int64_t)idn[e] * a.stride);
+      rown[e].a = p[qa];
+      rown[e].b = p[qb];
     }
   };
-  auto store_stage = [&](int st) {   // the rows in rown (their ids in idc) -> buffer st & 1
+  auto store_stage = [&](int st) {   // the rows in rown -> buffer st & 1
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int r = g + 32 * e;
       Row hat = rown[e];
+      if (d4 < 16 && q >= d4) hat.a = zero4();          // (uniform tests first: d = 100 / 128 fill their 4 NK columns, nothing to zero)
+      if (d4 < NK && q + 16 >= d4) hat.b = zero4();
       if (a.norm_v) hat = row_scale(hat, inv_norm(row16_sum(row_dot_partial(hat, hat))));
       store_row(sRow + ((st & 1) * kEvalStage + r) * DP, hat);
-      if (q == 0) sCb[(st & 1) * kEvalStage + r] = idc[e] >= 0 ? item_bias(a, idc[e]) : 0.f;
+      if (q == 0) {   // item bias (interaction_bias configurations only: a dependent trip here, not on the path of the others)
+        const int jj = st * kEvalStage + r;
+        sCb[(st & 1) * kEvalStage + r] = (a.cb && jj < n_cand) ? item_bias(a, cand[jj]) : 0.f;
+      }
     }
   };
   load_ids(0);
@@ -408,6 +539,16 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     float bfr[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) bfr[k] = pb[4 * k];
+#if NNCF_EVAL_PRELOAD
+    // ... and KEPT so: left alone the compiler reads two k-steps, waits, issues their four MFMAs, thirteen times over (ISA, round 6) --
+    // an LDS round trip in front of every 4 MFMAs.  The empty statements below make every element a live value at this point.
+#pragma unroll
+    for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(bfr[k]));
+#endif
+#if NNCF_EVAL_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ESTAMP(0);
+#endif
     // per element TWO accumulation chains, k-steps 0, 2, 4, ... and 1, 3, 5, ..., added at the end (predict_tile_kernel does the
     // same): a dependent v_mfma_f32_16x16x4_f32 issues ~84 cycles after its predecessor here, so two row tiles x one chain ran
     // the pipe at 42-55 cycles per MFMA instead of 32 (in-kernel stamps); four chains keep it busy
@@ -423,6 +564,10 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     }
     acc0 = e0 + o0;
     acc1 = e1 + o1;
+#if NNCF_EVAL_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1));
+    ESTAMP(1);
+#endif
   };
   // ranking of the tile in acc0 / acc1: column j (item bias cb).  A score at or above the float image of its user's threshold
   // takes the exact test (64-bit key against the threshold key); the few that pass are appended -- all positions requested
@@ -431,15 +576,51 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     const int j = st_of * kEvalStage + 16 * ct + x;
     if (j >= n_cand) return;
     float sc[2][4];
-    bool any = false;
+    unsigned long long any = 0ull;   // lanes with a score at its threshold: the eight compare masks OR-ed on the scalar unit (as per-lane
+                                     // booleans the compiler packed them into a byte with ~22 vector instructions per stage: ISA, round 6)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         sc[t][r] = (t ? acc1[r] : acc0[r]) + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
-        any |= !(sc[t][r] < tau_f[t][r]);   // NaN scores pass: the exact key test ranks them as eval_topk_kernel does (orderable())
+        any |= __ballot(!(sc[t][r] < tau_f[t][r]));   // NaN scores pass: the exact key test ranks them as eval_topk_kernel does (orderable())
       }
-    if (!any) return;
+    if (!any) return;   // (wave-uniform; a lane without a passing score goes through the tests below with every slot refused)
+#if NNCF_EVAL_SLOTSKIP
+    // Nearly every stage SOME score of the wave's 512 reaches its threshold (400 / stage-number expected: >= 2 up to the last of
+    // 213 stages), so this path runs all the time -- but only 2-6 of its (row, column) slots are concerned.  Each of the lane's
+    // eight slots is taken up only if a lane of the wave passes THERE (wave-uniform branch on the compare mask): the exact test
+    // against the threshold KEY (registers) and the list position (an LDS atomic) for the slots concerned, all positions requested
+    // first, then the stores.  Round 6: the straight-line form spent ~250 VALU instructions per wave and stage on keys nobody appended.
+    bool pass[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pass[t][r] = !(sc[t][r] < tau_f[t][r]);
+    unsigned long long key[2][4];
+    int pos[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pos[t][r] = -1;
+        if (__ballot(pass[t][r])) {
+          key[t][r] = rank_key(sc[t][r], j);
+          if (pass[t][r] && key[t][r] > tau_k[t][r]) pos[t][r] = atomicAdd(&sCnt[32 * rp + 16 * t + 4 * kq + r], 1);   // < LIST: <= 64 appends per user and stage
+        }
+      }
+    bool full = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (__ballot(pass[t][r])) {
+          if (pos[t][r] >= 0) {
+            sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
+            full |= pos[t][r] >= LIST - kEvalStage;
+          }
+        }
+#else
     // exact test against the threshold KEYS (registers), then all the list positions at once: eight independent LDS atomics in
     // flight, one wait, eight stores (a threshold read from LDS and a wait per slot made this path ~2.5 k cycles per stage)
     unsigned long long key[2][4];
@@ -465,6 +646,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
           sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
           full |= pos[t][r] >= LIST - kEvalStage;
         }
+#endif
     // the append that leaves a list with less than a stage's worth of room raises the workgroup's flag: everybody cuts behind
     // this stage's barrier (a count read by another wave could miss appends still in flight; the appender cannot)
     if (full) sFlag[parity] = 1;
@@ -500,25 +682,59 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
       }
     }
   };
+  // in-loop cut: all eight users of the wave at once, to between k and k + 14 keys -- at most LIST - 64: the next stage's appends
+  // (<= 64 per user) must fit -- and the exact routine for lists of equal scores
+  auto cut_fast = [&]() {
+    const unsigned fb = eval_cut_group8<LIST>(sKeys + 8 * wave * LIST, sCnt + 8 * wave, sTau + 8 * wave, kk, min(kk + 14, LIST - kEvalStage), lane);
+    if (fb) {   // (wave-uniform)
+      __builtin_amdgcn_wave_barrier();
+      for (int e = 0; e < 8; ++e) {
+        if (!((fb >> e) & 1u)) continue;
+        const int ua = 8 * wave + e;
+        unsigned long long ta, tb;
+        eval_cut_lists2<LIST>(sKeys + ua * LIST, sCnt[ua], sKeys + ua * LIST, 0, kk, lane, ta, tb);
+        if (lane == 0 && ta) {
+          sTau[ua] = ta;
+          sCnt[ua] = kk;
+        }
+      }
+    }
+  };
   __syncthreads();   // stage 0 is in LDS
   for (int st = 0; st < nst; ++st) {
     // products(st), ranking(st), then the rows of stage st + 1 -> the other buffer and the rows of st + 2 requested; the barrier;
     // if a list is nearly full, everybody cuts and there is one more.  (Running the two waves of a SIMD half a stage apart --
     // one multiplies while the other ranks and stages -- was measured both ways round and never won: 1.10 / 1.19 ms against 1.09.)
     const float cb = sCb[(st & 1) * kEvalStage + 16 * ct + x];
+#if NNCF_EVAL_STAMPS
+    if (st == 0) tprev = cyc();
+#endif
     products(st);
     ranking(st, cb, st & 1);
+#if NNCF_EVAL_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ESTAMP(2);
+#endif
     if (st + 1 < nst) store_stage(st + 1);
     load_rows();          // stage st + 2 (its ids arrived a stage ago)
     load_ids(st + 3);
+    ESTAMP(3);
     __syncthreads();
+    ESTAMP(4);
     if (sFlag[st & 1]) {        // uniform: written before the barrier, cleared behind the next one
-      cut_mine();
+      cut_fast();
       __syncthreads();
       if (tid == 0) sFlag[st & 1] = 0;
       refresh_tau();
+      ESTAMP(5);
     }
   }
+#if NNCF_EVAL_STAMPS
+  if (stamps && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) stamps[wave * 8 + k] = (long long)ph[k];
+  }
+#endif
   // ---- per user: the k largest keys in rank order, hits, metrics (wave w: users 8 w .. 8 w + 7) ------------------------
   // the truth lists of this wave's 8 users are requested before the last cut: bounds first, then the first 64 slots of each
   // (eight loads in flight; a binary search per key in global memory was 4-5 dependent trips per user, one user after the other)
@@ -602,7 +818,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
 }
 
 int launch_eval_fused(const StepArgs& a, const int32_t* uid, int64_t n_users, const int32_t* cand, int n_cand, const int32_t* truth_ptr,
-                      const int32_t* truth_idx, int topk, float* metrics, int32_t* valid, hipStream_t stream) {
+                      const int32_t* truth_idx, int topk, float* metrics, int32_t* valid, hipStream_t stream, long long* stamps) {
   const unsigned grid = (unsigned)((n_users + kEvalUsers - 1) / kEvalUsers);
   // developer timing switches (1: no list traffic, 2: no products) leave WRONG metrics: read once, honoured only together with
   // NNCF_EVAL_DBG_ACK=wrong-results (tools/eval_bench.py sets both), and announced on stderr -- a stray variable cannot
@@ -624,12 +840,12 @@ int launch_eval_fused(const StepArgs& a, const int32_t* uid, int64_t n_users, co
     static KernelDeviceState kst;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<25>), eval_fused_lds<25>(), kst)) return rc;
     hipLaunchKernelGGL(eval_fused_kernel<25>, dim3(grid), dim3(512), eval_fused_lds<25>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid, dbg);
+                       truth_idx, topk, metrics, valid, dbg, stamps);
   } else {
     static KernelDeviceState kst;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<32>), eval_fused_lds<32>(), kst)) return rc;
     hipLaunchKernelGGL(eval_fused_kernel<32>, dim3(grid), dim3(512), eval_fused_lds<32>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid, dbg);
+                       truth_idx, topk, metrics, valid, dbg, stamps);
   }
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
@@ -669,5 +885,5 @@ extern "C" int nncf_eval_whole(nncf_model* m, const int32_t* d_uid, int64_t n_us
   DeviceGuard guard(m->device);
   NNCF_HIP_CHECK(guard.status);
   return launch_eval_fused(make_args(m), d_uid, n_users, d_cand, n_cand, d_truth_ptr, d_truth_idx, topk, d_metrics, d_valid,
-                           as_stream(stream));
+                           as_stream(stream), m->sws.dbg);
 }
