@@ -28,16 +28,10 @@
 #include "model.h"
 #include "step.h"
 
-#ifndef NNCF_EVAL_SLOTSKIP
-#define NNCF_EVAL_SLOTSKIP 0
-#endif
 // developer build (tools/build_variant.sh evalstamps "-DNNCF_EVAL_STAMPS=1"; tools/eval_stamps.py): every wave of workgroup 0 adds up
 // the shader cycles it spends in each phase of a stage into the model's stamp buffer (NNCF_DEBUG_TIMING=1)
 #ifndef NNCF_EVAL_STAMPS
 #define NNCF_EVAL_STAMPS 0
-#endif
-#ifndef NNCF_EVAL_PRELOAD
-#define NNCF_EVAL_PRELOAD 1
 #endif
 
 namespace nncf {
@@ -539,12 +533,10 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     float bfr[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) bfr[k] = pb[4 * k];
-#if NNCF_EVAL_PRELOAD
     // ... and KEPT so: left alone the compiler reads two k-steps, waits, issues their four MFMAs, thirteen times over (ISA, round 6) --
     // an LDS round trip in front of every 4 MFMAs.  The empty statements below make every element a live value at this point.
 #pragma unroll
     for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(bfr[k]));
-#endif
 #if NNCF_EVAL_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     ESTAMP(0);
@@ -586,43 +578,13 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
         any |= __ballot(!(sc[t][r] < tau_f[t][r]));   // NaN scores pass: the exact key test ranks them as eval_topk_kernel does (orderable())
       }
     if (!any) return;   // (wave-uniform; a lane without a passing score goes through the tests below with every slot refused)
-#if NNCF_EVAL_SLOTSKIP
-    // Nearly every stage SOME score of the wave's 512 reaches its threshold (400 / stage-number expected: >= 2 up to the last of
-    // 213 stages), so this path runs all the time -- but only 2-6 of its (row, column) slots are concerned.  Each of the lane's
-    // eight slots is taken up only if a lane of the wave passes THERE (wave-uniform branch on the compare mask): the exact test
-    // against the threshold KEY (registers) and the list position (an LDS atomic) for the slots concerned, all positions requested
-    // first, then the stores.  Round 6: the straight-line form spent ~250 VALU instructions per wave and stage on keys nobody appended.
-    bool pass[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pass[t][r] = !(sc[t][r] < tau_f[t][r]);
-    unsigned long long key[2][4];
-    int pos[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pos[t][r] = -1;
-        if (__ballot(pass[t][r])) {
-          key[t][r] = rank_key(sc[t][r], j);
-          if (pass[t][r] && key[t][r] > tau_k[t][r]) pos[t][r] = atomicAdd(&sCnt[32 * rp + 16 * t + 4 * kq + r], 1);   // < LIST: <= 64 appends per user and stage
-        }
-      }
-    bool full = false;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (__ballot(pass[t][r])) {
-          if (pos[t][r] >= 0) {
-            sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
-            full |= pos[t][r] >= LIST - kEvalStage;
-          }
-        }
-#else
     // exact test against the threshold KEYS (registers), then all the list positions at once: eight independent LDS atomics in
     // flight, one wait, eight stores (a threshold read from LDS and a wait per slot made this path ~2.5 k cycles per stage)
+    // (Round 6, measured and not kept: taking up a slot only where a lane of the wave passes -- wave-uniform branches -- 1.116 against
+    // 1.081 ms; deciding the appends by a float compare and building keys only where they are stored -- 64 instead of 110 vector
+    // instructions -- 0.950 against 0.929 ms; ranking the tile of stage st - 1 behind the B-fragment request of stage st -- the LDS
+    // round trip covered, but the two waves of a SIMD then multiply one after the other, 42 instead of 32 cycles per MFMA -- 0.938
+    // against 0.929 ms: profiles/experiments/r06_eval_delayed_ranking.patch.)
     unsigned long long key[2][4];
     bool want[2][4];
 #pragma unroll
@@ -646,7 +608,6 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
           sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
           full |= pos[t][r] >= LIST - kEvalStage;
         }
-#endif
     // the append that leaves a list with less than a stage's worth of room raises the workgroup's flag: everybody cuts behind
     // this stage's barrier (a count read by another wave could miss appends still in flight; the appender cannot)
     if (full) sFlag[parity] = 1;

@@ -128,11 +128,12 @@ __device__ __forceinline__ void bn_tail_acc(BnTail& t, const StepArgs&, Row vraw
 }
 // every thread of the 256-thread workgroup calls this: the 16 groups in group order -> bn_part[chunk]; nchunks: chunk workgroups
 // of the launch (group merge, StepArgs::bn_gpart)
+template <bool GROUPS = false>   // GROUPS: the kernels of the large blocks (`original`, row-wise); the shared schemes' apply kernel carries none of it
 __device__ __forceinline__ void bn_tail_flush(const BnTail& t, const StepArgs& a, float* sR, int chunk, int nchunks = 0) {
   if (!t.sums) return;
   const int gl = threadIdx.x >> 4, q = threadIdx.x & 15;
   float* out = a.bn_part + (int64_t)chunk * 2 * 128;
-  const bool grouped = a.bn_gpart != nullptr;
+  const bool grouped = GROUPS && a.bn_gpart != nullptr;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();

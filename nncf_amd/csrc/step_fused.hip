@@ -131,7 +131,11 @@ __device__ __forceinline__ bool readers_wait(const FusedArgs& f, int seen, int t
   }
 }
 
-// NG groups of 16 columns of one S tile: 2 NG ds_read_b128, 4 NG MFMAs
+// NG groups of 16 columns of one S tile: 2 NG ds_read_b128, 4 NG MFMAs.  The compiler issues them as read one group -> wait -> its four
+// MFMAs, NG times (tools/isa_mfma_waits.py).  Forcing all 2 NG reads ahead of the first MFMA (as csrc/eval.hip does for its 25-dword
+// fragment) was measured in round 6 and LOSES here: 18.3 against 17.76 us per launch (mf: 14.65 against 14.02) -- the eight waves
+// then pull their 14 KB fragments through the LDS port together (112 KB = ~0.9 k cycles with no MFMA in flight) and multiply
+// afterwards, where the interleaved form has one wave's reads travel under another wave's MFMAs.
 template <int NG>
 __device__ __forceinline__ void s_tile(const float4* pa4, const float4* pb4, f32x4& acc0, f32x4& acc1) {
   float4 fa[NG], fb[NG];

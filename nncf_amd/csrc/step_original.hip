@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
           bn_tail_acc(bt, a, vraw, grad, loaded);
         });
-    bn_tail_flush(bt, a, sR, chunk, (int)gridDim.x - 1 - cu);
+    bn_tail_flush<true>(bt, a, sR, chunk, (int)gridDim.x - 1 - cu);
   }
 }
 
