@@ -505,8 +505,10 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     for (int e = 0; e < 2; ++e) {
       const int r = g + 32 * e;
       Row hat = rown[e];
-      if (d4 < 16 && q >= d4) hat.a = zero4();          // (uniform tests first: d = 100 / 128 fill their 4 NK columns, nothing to zero)
-      if (d4 < NK && q + 16 >= d4) hat.b = zero4();
+      // what the lane holds past the row's end is a repeat of an earlier chunk: zero where it would be STORED (d < 4 NK) or SUMMED
+      // (the row norm); uniform tests first -- an un-normalised d = 100 / 128 model has nothing to zero
+      if ((a.norm_v || d4 < 16) && q >= d4) hat.a = zero4();
+      if ((a.norm_v || d4 < NK) && q + 16 >= d4) hat.b = zero4();
       if (a.norm_v) hat = row_scale(hat, inv_norm(row16_sum(row_dot_partial(hat, hat))));
       store_row(sRow + ((st & 1) * kEvalStage + r) * DP, hat);
       if (q == 0) {   // item bias (interaction_bias configurations only: a dependent trip here, not on the path of the others)
@@ -625,28 +627,10 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
         tau_f[t][r] = tk == 0ull ? -__builtin_inff() : (tk == ~0ull ? __builtin_inff() : __uint_as_float(fb));
       }
   };
-  // wave w cuts the lists of users 8 w .. 8 w + 7 that hold more than k keys, two at a time
-  auto cut_mine = [&]() {
-    for (int e = 0; e < 8; e += 2) {
-      const int ua = 8 * wave + e, ub2 = ua + 1;
-      unsigned long long ta, tb;
-      eval_cut_lists2<LIST>(sKeys + ua * LIST, sCnt[ua], sKeys + ub2 * LIST, sCnt[ub2], kk, lane, ta, tb);
-      if (lane == 0) {
-        if (ta) {
-          sTau[ua] = ta;
-          sCnt[ua] = kk;
-        }
-        if (tb) {
-          sTau[ub2] = tb;
-          sCnt[ub2] = kk;
-        }
-      }
-    }
-  };
   // in-loop cut: all eight users of the wave at once, to between k and k + 14 keys -- at most LIST - 64: the next stage's appends
   // (<= 64 per user) must fit -- and the exact routine for lists of equal scores
-  auto cut_fast = [&]() {
-    const unsigned fb = eval_cut_group8<LIST>(sKeys + 8 * wave * LIST, sCnt + 8 * wave, sTau + 8 * wave, kk, min(kk + 14, LIST - kEvalStage), lane);
+  auto cut_fast = [&](int keep) {
+    const unsigned fb = eval_cut_group8<LIST>(sKeys + 8 * wave * LIST, sCnt + 8 * wave, sTau + 8 * wave, kk, keep, lane);
     if (fb) {   // (wave-uniform)
       __builtin_amdgcn_wave_barrier();
       for (int e = 0; e < 8; ++e) {
@@ -683,7 +667,7 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     __syncthreads();
     ESTAMP(4);
     if (sFlag[st & 1]) {        // uniform: written before the barrier, cleared behind the next one
-      cut_fast();
+      cut_fast(min(kk + 14, LIST - kEvalStage));
       __syncthreads();
       if (tid == 0) sFlag[st & 1] = 0;
       refresh_tau();
@@ -708,7 +692,8 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) tv[e] = (tp0[e] + lane < tp1[e]) ? truth_idx[tp0[e] + lane] : -1;
-  cut_mine();
+  cut_fast(kk);   // the final cut is EXACT: keep = k -- the search runs until exactly k keys reach the candidate (a shared k-th score: the
+                  // pairwise routine, by key); ~6 k instead of ~30 k cycles at the end of every launch
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

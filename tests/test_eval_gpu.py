@@ -26,9 +26,8 @@ def _conf(d, b=64, bias=None, norm=True, topk=50, model="mf"):
           "loss_gamma": 10, "learn_rate": 0.1, "neg_dist": "unigram", "neg_sampling_power": 1, "batch_size_p": b, "user_dim": d,
           "item_dim": d, "chop_size": 4, "interaction_bias": bias, "u_reg": 0., "eval_topk": topk, "optimizer": "sgd"}
     conf = get_conf("synthetic", "best", pd, model_choice=model)
-    if not norm:
-        conf.emb_normalization = False
-    return conf
+    conf.emb_normalization = bool(norm)   # (explicit both ways: the preset's value left the `norm=True` cases un-normalised -- round 6 found
+    return conf                           #  a row-norm bug of the one-kernel evaluator only through the epoch-level test)
 
 
 def _both_paths(ev, head, which, topk):
@@ -193,20 +192,28 @@ def test_evaluator_at_the_baseline_shape_equals_the_oracle_and_the_two_kernel_pa
         assert rf["recall@50"] > 0.001   # the comparison is not about empty hit lists
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("NNCF_SOAK_SEEDS", "10"))))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("NNCF_SOAK_SEEDS", "10")))) +
+                         ["norm-d100", "norm-d20", "norm-d128", "norm-d64", "norm-d4"])
 def test_fused_evaluator_random_shapes_against_the_two_kernel_path(seed):
     """Seeded random sweep (tools/soak.sh raises the seed count): users 1 .. 700, candidates 3 .. 6,000, d = 4 .. 128, k = 1 .. 100,
     normalisation on / off, interaction bias, continuous or heavily quantised tables (exact score ties everywhere), users with
-    no true item -- nncf_eval_whole against nncf_predict_scores + nncf_eval_topk, per user, bit for bit."""
+    no true item -- nncf_eval_whole against nncf_predict_scores + nncf_eval_topk, per user, bit for bit.
+    The named cases pin ITEM-row normalisation at every row width class (d = 100 fills the 25 k-steps exactly, d = 20 / 4 leave
+    lanes without a first / second chunk of the row, 64 / 128): the `mf` heads of the tests above never normalise the item side
+    (model_framework.py:109-111), the ten random seeds happen not to draw d = 100 with it, and round 6's unconditional row loads
+    summed a repeated chunk into the norm there -- found by the epoch-level test only."""
     from nncf_amd.engine import Engine
-    rs = np.random.RandomState(31000 + seed)
+    named = isinstance(seed, str)
+    rs = np.random.RandomState(31000 + (sum(map(ord, seed)) if named else seed))
     users = int(rs.choice([1, 5, 63, 64, 65, 200, 700]))
     items = int(rs.choice([3, 40, 64, 65, 500, 2000, 6000]))
     d = int(rs.choice([4, 20, 24, 64, 100, 128]))
     topk = int(rs.choice([1, 5, 50, 50, 100]))
     norm = bool(rs.randint(2))
     bias = [None, "user", "item", "both"][int(rs.randint(4))]
-    eng = Engine(users, items, d, 32, 0, "skip-gram", 10.0, 16.0, 0., 0.1, norm, norm, seed=seed, init_scale=0.5, interaction_bias=bias)
+    if named:
+        users, items, d, topk, norm = 200, 2000, int(seed.split("-d")[1]), 50, True
+    eng = Engine(users, items, d, 32, 0, "skip-gram", 10.0, 16.0, 0., 0.1, norm, norm, seed=(sum(map(ord, seed)) if named else seed), init_scale=0.5, interaction_bias=bias)
     U, V = eng.U.cpu().numpy().copy(), eng.V.cpu().numpy().copy()
     if rs.randint(3) == 0:      # few distinct values: exact ties between unrelated pairs
         U, V = np.round(U * 2) / 2, np.round(V * 2) / 2
