@@ -41,12 +41,6 @@ struct StepArgs {
   // if non-NULL the apply kernel of the shared schemes also emits, per item chunk, the column sums
   // of dy = dL/dE * [E > 0] and dy * xhat (the BatchNorm backward's reductions): [chunk][2][128]
   float* bn_part = nullptr;
-  // blocks of hundreds of item chunks (`original`, row-wise batches): the chunk rows are summed in groups of bn_gsize consecutive
-  // chunks by the group's last workgroup to arrive (bn_gcnt[group]: device-scope arrival counter, re-armed), in chunk order, into
-  // bn_gpart[group][2][128] -- <= 32 group rows, which the Dense backward's prologue adds in one round of loads (no merge launch)
-  float* bn_gpart = nullptr;
-  unsigned* bn_gcnt = nullptr;
-  int bn_gsize = 0;
   // text tower, blocks of more than 1,024 rows (`original`): the statistics launch leaves bn_nparts partial rows
   // (shifted sums, shift = block row 0); every workgroup of the score kernel merges them itself and workgroup 0 publishes
   // mu / inv / var / mul / add (bn_stats) + the running statistics -- no one-workgroup merge launch in between
@@ -126,14 +120,11 @@ __device__ __forceinline__ void bn_tail_acc(BnTail& t, const StepArgs&, Row vraw
   bn_tail_acc4(vraw.a, grad.a, loaded.a, t.mu.a, t.inv.a, t.s1.a, t.s2.a);
   bn_tail_acc4(vraw.b, grad.b, loaded.b, t.mu.b, t.inv.b, t.s1.b, t.s2.b);
 }
-// every thread of the 256-thread workgroup calls this: the 16 groups in group order -> bn_part[chunk]; nchunks: chunk workgroups
-// of the launch (group merge, StepArgs::bn_gpart)
-template <bool GROUPS = false>   // GROUPS: the kernels of the large blocks (`original`, row-wise); the shared schemes' apply kernel carries none of it
-__device__ __forceinline__ void bn_tail_flush(const BnTail& t, const StepArgs& a, float* sR, int chunk, int nchunks = 0) {
+// every thread of the 256-thread workgroup calls this: the 16 groups in group order -> bn_part[chunk]
+__device__ __forceinline__ void bn_tail_flush(const BnTail& t, const StepArgs& a, float* sR, int chunk) {
   if (!t.sums) return;
   const int gl = threadIdx.x >> 4, q = threadIdx.x & 15;
   float* out = a.bn_part + (int64_t)chunk * 2 * 128;
-  const bool grouped = GROUPS && a.bn_gpart != nullptr;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -143,40 +134,9 @@ __device__ __forceinline__ void bn_tail_flush(const BnTail& t, const StepArgs& a
     if (threadIdx.x < 128) {
       float v = 0.f;
       for (int g = 0; g < 16; ++g) v += sR[g * 128 + threadIdx.x];
-      // group merge: the chunk row is the payload of a cross-workgroup hand-over -- a write-through (sc1) store, no release
-      // fence (a fence writes the whole L2 back, and these workgroups have just written their table rows: measured 12.8 -> 46 us)
-      if (grouped) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(out + half * 128 + threadIdx.x), "v"(v) : "memory");
-      else out[half * 128 + threadIdx.x] = v;
+      out[half * 128 + threadIdx.x] = v;
     }
   }
-  if (!grouped) return;
-  // the storing waves drain their stores, ONE lane takes the ticket; the group's last workgroup to arrive adds the group's chunk rows
-  // in chunk order: the result does not depend on who that is (cdna_hip_programming.md, Guideline 16, R1; step_fused.hip's split strips)
-  __shared__ int s_last;
-  const int grp = chunk / a.bn_gsize, lo = grp * a.bn_gsize, hi = min(lo + a.bn_gsize, nchunks);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(a.bn_gcnt + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == (unsigned)(hi - lo - 1);
-    if (last) {
-      __hip_atomic_store(a.bn_gcnt + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const float* in = a.bn_part + threadIdx.x;   // thread -> element [half][column] of a chunk row
-  float v = 0.f;
-  for (int c0 = lo; c0 < hi; c0 += 16) {
-    float u[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) u[e] = in[(int64_t)min(c0 + e, hi - 1) * 256];   // (unconditional requests at a clamped chunk)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v += (c0 + e < hi) ? u[e] : 0.f;
-  }
-  a.bn_gpart[(int64_t)grp * 256 + threadIdx.x] = v;
 }
 
 __device__ __forceinline__ float user_bias(const StepArgs& a, int64_t u) { return a.ub ? a.ub[u] : 0.f; }

@@ -58,14 +58,14 @@ __global__ void __launch_bounds__(256) original_score_kernel(StepArgs a, const i
         const int c = threadIdx.x;
         float mul = 0.f, add = 0.f;
         if (c < a.d) {
-          float t1 = 0.f, t2 = 0.f, u1[16], u2[16];   // <= 16 partials (tower.hip fwd_stat_grid), all requested at once, added in order
+          float t1 = 0.f, t2 = 0.f, u1[8], u2[8];   // <= 8 partials, all requested at once, added in order
 #pragma unroll
-          for (int pp = 0; pp < 16; ++pp) {
+          for (int pp = 0; pp < 8; ++pp) {
             u1[pp] = pp < a.bn_nparts ? a.bn_parts[pp * 256 + c] : 0.f;
             u2[pp] = pp < a.bn_nparts ? a.bn_parts[pp * 256 + 128 + c] : 0.f;
           }
 #pragma unroll
-          for (int pp = 0; pp < 16; ++pp) {
+          for (int pp = 0; pp < 8; ++pp) {
             t1 += u1[pp];
             t2 += u2[pp];
           }
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) original_apply_kernel(StepArgs a, Origina
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q);
           bn_tail_acc(bt, a, vraw, grad, loaded);
         });
-    bn_tail_flush<true>(bt, a, sR, chunk, (int)gridDim.x - 1 - cu);
+    bn_tail_flush(bt, a, sR, chunk);
   }
 }
 

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) rowwise_apply_kernel(StepArgs a, RowwiseW
           else apply_update(a, a.av, a.V, c, vraw, grad, d4, q, aw ? (float)cnt : 1.f);
           bn_tail_acc(bt, a, vraw, grad, loaded);
         });
-    bn_tail_flush<true>(bt, a, sR, chunk, chunks);
+    bn_tail_flush(bt, a, sR, chunk);
   }
 }
 

@@ -384,7 +384,6 @@ struct nncf_tower {
   int32_t* ent_word = nullptr;  // fixed-stride copy of the item CSR (mean-pool tower)
   uint8_t* ent_cnt = nullptr;
   float* bpart = nullptr;
-  unsigned* gcnt = nullptr;     // arrival counters of the apply kernels' group merge (StepArgs::bn_gcnt), zero between launches
   int32_t *uniq_g = nullptr, *n_u = nullptr;  // kPlanChunk blocks of max_rows ids / kPlanChunk counts
   bool fwd_cached = false;
   nncf::TowerArgs last{};

@@ -534,6 +534,41 @@ __global__ void __launch_bounds__(1024) tower_sums_kernel(TowerArgs a) {
   }
 }
 
+// Totals of per-chunk partials [n][2][128] emitted by an apply kernel (blocks of more than 64 item
+// chunks: train_scheme = original) -> sum dy / sum dy*xhat, in chunk order.  One workgroup:
+// 8 chunk groups x 128 columns, 8 loads in flight each, groups combined in order.
+__global__ void __launch_bounds__(1024) tower_merge_kernel(TowerArgs a, const float* __restrict__ part, int n) {
+  __shared__ float sRed[8 * 2 * 128];
+  const int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+  float a1 = 0.f, a2 = 0.f;
+  for (int s0 = g; s0 < n; s0 += 8 * 48) {   // 48 pairs of loads in flight: `original`'s 352 partials (44 per thread) in ONE round
+    float u1[48], u2[48];
+#pragma unroll
+    for (int e = 0; e < 48; ++e) {
+      const int s = s0 + 8 * e;
+      u1[e] = s < n ? part[(int64_t)s * 256 + c] : 0.f;
+      u2[e] = s < n ? part[(int64_t)s * 256 + 128 + c] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 48; ++e) {
+      a1 += u1[e];
+      a2 += u2[e];
+    }
+  }
+  sRed[(g * 2 + 0) * 128 + c] = a1;
+  sRed[(g * 2 + 1) * 128 + c] = a2;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int gg = 0; gg < 8; ++gg) {
+      t1 += sRed[(gg * 2 + 0) * 128 + c];
+      t2 += sRed[(gg * 2 + 1) * 128 + c];
+    }
+    a.ws[ws_bfin() + c] = t1;
+    a.ws[ws_bfin() + 128 + c] = t2;
+  }
+}
+
 // dz = gamma inv / n (n dy - sum dy - xhat sum dy xhat) and the two products that need it.
 // Blocks [0, nA): role A, 16 rows each; blocks [nA, ...): role B, tile (it, jt) x K-part.
 __global__ void __launch_bounds__(256) tower_bwd_kernel(TowerArgs a, int nA, int ks, int nfused) {
@@ -1306,7 +1341,6 @@ void carve_tower(nncf_tower* t, Carver& c) {
   t->ent_word = c.take<int32_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
   t->ent_cnt = c.take<uint8_t>((int64_t)t->cfg.item_count * t->cfg.content_len);
   t->bpart = c.take<float>((cap / kChunkSlots + 2) * 256);  // per-chunk BN partials of the original apply kernel
-  t->gcnt = c.take<unsigned>(64);
   t->uniq_g = c.take<int32_t>(kPlanChunk * cap);
   t->n_u = c.take<int32_t>(kPlanChunk);
 }
@@ -1404,9 +1438,6 @@ inline unsigned long long step_seed(const nncf_tower* t, uint64_t step) {
 }
 
 inline int stat_grid(int m) { return (m + 1023) / 1024; }  // workgroups of the column-sum kernels (<= 8)
-// forward statistics of blocks of more than 1,024 rows (`original`: ~2,700): 512 rows per workgroup = the eight rows a 16-lane
-// group keeps in flight, ONE round of loads per workgroup (three workgroups of 900 rows took two); <= 16 partial rows
-inline int fwd_stat_grid(int m) { return m > 1024 ? (m + 511) / 512 : 1; }
 
 // forward of a block: rows of ids -> E.  train: batch statistics, h / z kept, optional fill.
 int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_valid, int train, int fill,
@@ -1455,9 +1486,9 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
   } else if (train) {
     {
       ProfScope _ps("tower_stats_kernel", st);
-      hipLaunchKernelGGL(tower_stats_kernel, dim3(fwd_stat_grid(m)), dim3(1024), 0, st, a);
+      hipLaunchKernelGGL(tower_stats_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
       // several partial rows: merged by one workgroup, or (merge_by_consumer: `original`) by the score kernel's own
-      if (fwd_stat_grid(m) > 1 && !merge_by_consumer) hipLaunchKernelGGL(tower_stats_merge_kernel, dim3(1), dim3(128), 0, st, a, fwd_stat_grid(m));
+      if (stat_grid(m) > 1 && !merge_by_consumer) hipLaunchKernelGGL(tower_stats_merge_kernel, dim3(1), dim3(128), 0, st, a, stat_grid(m));
     }
     if (E) {
       ProfScope _ps("tower_bn_kernel", st);
@@ -1474,7 +1505,7 @@ int tower_forward(nncf_tower* t, const int32_t* ids, int m, const int32_t* n_val
 // nfused > 0: the BN backward's column sums arrive as nfused partials from the step's apply kernel
 // step_t: the optimiser step this backward belongs to (1-based)
 int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 0, int64_t step_t = 0,
-                   bool words_counted = false) {
+                   bool sums_done = false, bool words_counted = false) {
   TowerArgs a = t->last;
   if (a.c_reg != 0.f && !words_counted) {   // conf.c_reg outside a model step: the word kernel's tail needs T[w]
     hipLaunchKernelGGL(tower_wcount_kernel, dim3((unsigned)a.m), dim3(256), 0, st, a);
@@ -1495,7 +1526,7 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   }
   const int m = a.m;
   if (t->tail_variant()) {   // Activation / Dropout backward of a non-default Dense tail, out of place
-    NNCF_REQUIRE(t->dA_tail != nullptr && !nfused, "the Dense tail variants run on the materialised block only");
+    NNCF_REQUIRE(t->dA_tail != nullptr && !nfused && !sums_done, "the Dense tail variants run on the materialised block only");
     hipLaunchKernelGGL(tower_tail_grad_kernel, dim3((m + 15) / 16), dim3(256), 0, st, a, t->dA_tail);
     a.dA = t->dA_tail;
     a.tail_pre = 1;
@@ -1505,10 +1536,10 @@ int tower_backward(nncf_tower* t, const float* dA, hipStream_t st, int nfused = 
   const int ntile = ((a.hd + 15) / 16) * ((a.d + 15) / 16);
   if (t->no_dense) {
     // no Dense tail: dL/d(pooled block) IS the step's dL/dE; nothing of Dense / BatchNorm to differentiate or to step
-    NNCF_REQUIRE(!nfused, "a tower without the Dense transform runs on the materialised block only");
+    NNCF_REQUIRE(!nfused && !sums_done, "a tower without the Dense transform runs on the materialised block only");
     a.dh = const_cast<float*>(a.dA);
   } else {
-    if (!nfused) {
+    if (!nfused && !sums_done) {
       ProfScope _ps("tower_sums_kernel", st);
       hipLaunchKernelGGL(tower_sums_kernel, dim3(stat_grid(m)), dim3(1024), 0, st, a);
     }
@@ -1618,7 +1649,7 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
         if (pa.opt == 2)
           if (int rc2 = launch_adam_idle(ca, t->cid_tab, t->acid, t->cfg.item_count, st)) return rc2;
       }
-      if ((rc = tower_backward(t, m->export_gV, st, 0, m->opt ? m->adam_t + 1 : 0, t->c_reg != 0.f))) return rc;
+      if ((rc = tower_backward(t, m->export_gV, st, 0, m->opt ? m->adam_t + 1 : 0, false, t->c_reg != 0.f))) return rc;
       return finish_update(m, pa, st);
     }
     if (t->cid_tab && t->v_reg != 0.f) {   // loss only: the regulariser still belongs to the loss
@@ -1633,12 +1664,12 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   // (NNCF_TILE_STATS=launch keeps the tower_stats launch: measurement / tests)
   static const bool tile_stats_launch = getenv("NNCF_TILE_STATS") != nullptr;
   const bool tile_stats = (scheme == 1 || scheme == 2) && !one_launch && m->tile_ok && !tile_stats_launch;
-  const bool score_merges = scheme == 0 && fwd_stat_grid(n) > 1;   // `original`: the score kernel merges the statistics partials
+  const bool score_merges = scheme == 0 && stat_grid(n) > 1;   // `original`: the score kernel merges the statistics partials
   int rc = tower_forward(t, uniq_g, n, n_u, 1, update, scale, nullptr, st, one_launch || tile_stats, score_merges);
   if (rc) return rc;
   if (score_merges) {
     sa.bn_parts = t->ws + ws_stats();
-    sa.bn_nparts = fwd_stat_grid(n);
+    sa.bn_nparts = stat_grid(n);
     sa.bn_pub = t->ws + ws_muinv();
     sa.bn_gamma = t->prm.bn_gamma;
     sa.bn_beta = t->prm.bn_beta;
@@ -1663,17 +1694,9 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   const int chunks = one_launch ? fused_max_blocks(b) : (b + kChunkSlots - 1) / kChunkSlots;
   const int nfused = ((scheme == 1 || scheme == 2) && update && chunks <= kTowerWG) ? chunks : 0;
   if (nfused) sa.bn_part = t->ws + ws_bsum();
-  // thousands of rows: partials per item chunk, summed in <= 32 groups of consecutive chunks by each group's last workgroup to
-  // arrive; the Dense backward's prologue adds the group rows (round 6: a one-workgroup merge launch of 5.4 us sat in between)
-  const bool big = (scheme == 0 || scheme == 3) && update;
+  const bool big = (scheme == 0 || scheme == 3) && update;   // thousands of rows: partials per item chunk, merged by one workgroup
   const int cv = (n + kChunkSlots - 1) / kChunkSlots;
-  const int gsize = (cv + 31) / 32, ngroups = (cv + gsize - 1) / gsize;
-  if (big) {
-    sa.bn_part = t->bpart;
-    sa.bn_gpart = t->ws + ws_bsum();
-    sa.bn_gcnt = t->gcnt;
-    sa.bn_gsize = gsize;
-  }
+  if (big) sa.bn_part = t->bpart;
   if (scheme == 0)
     rc = launch_original(sa, uid, cid_local, cid_local + b, m->ows, pu, pv, loss, update, st);
   else if (scheme == 3)
@@ -1683,7 +1706,12 @@ int tower_step_body(nncf_tower* t, nncf_model* m, int scheme, const int32_t* uid
   if (rc) return rc;
   if ((rc = tower_c_reg(t, m, loss, update, st))) return rc;
   if (!update) return NNCF_OK;
-  rc = tower_backward(t, m->export_gV, st, big ? ngroups : nfused, m->opt ? m->adam_t + 1 : 0, t->c_reg != 0.f);
+  if (big) {
+    TowerArgs ma = t->last;
+    ProfScope _ps("tower_merge_kernel", st);
+    hipLaunchKernelGGL(tower_merge_kernel, dim3(1), dim3(1024), 0, st, ma, t->bpart, cv);
+  }
+  rc = tower_backward(t, m->export_gV, st, nfused, m->opt ? m->adam_t + 1 : 0, big, t->c_reg != 0.f);
   if (rc) return rc;
   return finish_update(m, sa, st);
 }
