@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(NT) eval_topk_kernel(const float* __restrict__
 constexpr int kEvalUsers = 64;     // users per workgroup (four 16-row MFMA tiles)
 constexpr int kEvalStage = 64;     // candidates per stage (four 16-column tiles)
 constexpr int kEvalMaxK = 100;     // top-k this kernel takes (beyond: the two-kernel path)
+constexpr int kEvalDefaultWaves = 16;   // waves per workgroup unless NNCF_EVAL_WAVES says otherwise
 template <int NK>
 __host__ __device__ constexpr int eval_list_cap() { return NK <= 25 ? 192 : 176; }   // keys per user list (160 KB of LDS in all)
 
@@ -304,20 +305,21 @@ __device__ __forceinline__ void eval_cut_lists2(unsigned long long* la, int ca, 
 // needed only at the very end (eval_cut_lists2) -- so a cut is ~6-8 rounds of 24 compares instead of 4 x 32 rounds of ballots.
 // A list whose k-th score is shared by so many keys that more than `keep` remain (equal scores: an untrained model) is left to the
 // exact routine: returned as a mask of user groups.
-template <int LIST>
+template <int LIST, int UPW>
 __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, int* cnts, unsigned long long* taus, int k, int keep, int lane) {
-  static_assert(LIST <= 192, "24 keys per lane x 8 lanes");
-  const int ug = lane >> 3, sub = lane & 7;
+  constexpr int LPU = 64 / UPW, KPL = 192 / LPU;   // lanes per user (8 or 16), keys per lane (24 or 12)
+  static_assert(LIST <= 192 && (UPW == 8 || UPW == 4), "192 keys per user: 24 x 8 lanes or 12 x 16 lanes");
+  const int ug = lane / LPU, sub = lane % LPU;
   unsigned long long* list = lists + ug * LIST;
   const int cnt = cnts[ug];
   const bool need = cnt > keep;   // (uniform within the group)
   if (!__ballot(need)) return 0u;
-  uint32_t hi[24], lo[24];
+  uint32_t hi[KPL], lo[KPL];
   uint32_t mx = 0u, mn = 0xFFFFFFFFu;
 #pragma unroll
-  for (int i = 0; i < 24; ++i) {
-    const bool real = sub + 8 * i < cnt;
-    const unsigned long long key = real ? list[sub + 8 * i] : 0ull;
+  for (int i = 0; i < KPL; ++i) {
+    const bool real = sub + LPU * i < cnt;
+    const unsigned long long key = real ? list[sub + LPU * i] : 0ull;
     hi[i] = (uint32_t)(key >> 32);
     lo[i] = (uint32_t)key;
     mx = max(mx, hi[i]);
@@ -326,12 +328,16 @@ __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, i
   auto group_max = [&](uint32_t v) -> uint32_t {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
-    return max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+    if (LPU == 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror: the other half row
+    return v;
   };
   auto group_sum = [&](int v) -> int {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-    return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    if (LPU == 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    return v;
   };
   mx = group_max(mx);
   mn = ~group_max(~mn);
@@ -345,14 +351,14 @@ __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, i
   {
     const int mine_top = need ? top : -1;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) start = max(start, __builtin_amdgcn_readlane(mine_top, 8 * e));
+    for (int e = 0; e < UPW; ++e) start = max(start, __builtin_amdgcn_readlane(mine_top, LPU * e));
   }
   for (int bit = start; bit >= 0; --bit) {
     if (!__ballot(!done)) break;
     const uint32_t c = h | (1u << bit);
     int n = 0;
 #pragma unroll
-    for (int i = 0; i < 24; ++i) n += hi[i] >= c ? 1 : 0;
+    for (int i = 0; i < KPL; ++i) n += hi[i] >= c ? 1 : 0;
     n = group_sum(n);
     if (!done && n >= k) {
       h = c;
@@ -362,7 +368,7 @@ __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, i
   // keys that stay: score >= h (every key of that score: ties included)
   int mine = 0;
 #pragma unroll
-  for (int i = 0; i < 24; ++i) mine += (sub + 8 * i < cnt && hi[i] >= h) ? 1 : 0;
+  for (int i = 0; i < KPL; ++i) mine += (sub + LPU * i < cnt && hi[i] >= h) ? 1 : 0;
   const int kept = group_sum(mine);
   const bool ok = need && kept <= keep;     // else: too many keys share the k-th score (or the list is left alone)
   // lane-major compaction: exclusive prefix of `mine` over the group's lanes
@@ -373,12 +379,16 @@ __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, i
   if (sub >= 2) inc += t;
   t = __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
   if (sub >= 4) inc += t;
+  if (LPU == 16) {
+    t = __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
+    if (sub >= 8) inc += t;
+  }
   int pos = inc - mine;
   __builtin_amdgcn_wave_barrier();   // every read of the lists above precedes the stores below (one wave, LDS in order)
   if (ok) {
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      if (sub + 8 * i < cnt && hi[i] >= h) {
+    for (int i = 0; i < KPL; ++i) {
+      if (sub + LPU * i < cnt && hi[i] >= h) {
         list[pos] = ((unsigned long long)hi[i] << 32) | lo[i];
         ++pos;
       }
@@ -391,12 +401,14 @@ __device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, i
   unsigned fb = 0u;
   const unsigned long long bad = __ballot(need && !ok);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) fb |= ((bad >> (8 * e)) & 1ull) ? (1u << e) : 0u;
+  for (int e = 0; e < UPW; ++e) fb |= ((bad >> (LPU * e)) & 1ull) ? (1u << e) : 0u;
   return fb;
 }
 
-template <int NK>
-__global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32_t* __restrict__ uid, int64_t n_users,
+// RT: 16-row user tiles per wave.  RT = 2: 8 waves (4 column tiles x 2 pairs of row tiles), two waves per SIMD, 256 registers each;
+// RT = 1: 16 waves, four per SIMD, 128 registers each -- a tile per wave, twice the waves to fill each other's waits.
+template <int NK, int RT>
+__global__ void __launch_bounds__(1024 / RT) eval_fused_kernel(StepArgs a, const int32_t* __restrict__ uid, int64_t n_users,
                                                          const int32_t* __restrict__ cand, int n_cand,
                                                          const int32_t* __restrict__ truth_ptr, const int32_t* __restrict__ truth_idx,
                                                          int topk, float* __restrict__ metrics, int32_t* __restrict__ valid, int dbg, long long* stamps) {
@@ -412,8 +424,9 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   float* sCb = sUb + kEvalUsers;                                                                  // [2][64] item bias of the stage (by stage parity)
   const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = tid >> 4, q = tid & 15;           // 32 groups of 16 lanes: rows g and g + 32 of a stage
-  const int ct = wave & 3, rp = wave >> 2;        // this wave's column tile of the stage; its two row tiles 2 rp, 2 rp + 1
+  constexpr int NW = 16 / RT, NGRP = 4 * NW, RPG = kEvalStage / NGRP, UPW = kEvalUsers / NW;   // waves, 16-lane groups, rows of a stage per group, users a wave cuts
+  const int g = tid >> 4, q = tid & 15;           // NGRP groups of 16 lanes: rows g (+ NGRP) of a stage
+  const int ct = wave & 3, rp = wave >> 2;        // this wave's column tile of the stage; its row tiles RT rp .. RT rp + RT - 1
   const int d4 = a.d >> 2;
   const int64_t u0 = (int64_t)blockIdx.x * kEvalUsers;
   const int kk = min(topk, n_cand);
@@ -441,8 +454,8 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   };
   // ---- the workgroup's users -> LDS -> A fragments in registers ---------------------------------------------------------
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int r = g + 32 * e;
+  for (int e = 0; e < RPG; ++e) {
+    const int r = g + NGRP * e;
     const int64_t u = u0 + r;
     Row hat = row_zero();
     int id = 0;
@@ -463,20 +476,20 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   }
   if (tid < 4) sFlag[tid] = 0;
   __syncthreads();
-  float afr[2][NK];
+  float afr[RT][NK];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int k = 0; k < NK; ++k) afr[t][k] = sRow[(32 * rp + 16 * t + x) * DP + 4 * k + kq];
-  float ub_r[2][4];
-  float tau_f[2][4];   // float image of the thresholds (the exact 64-bit test runs only where a score reaches it); refreshed after cuts
-  unsigned long long tau_k[2][4];   // the threshold keys themselves
+    for (int k = 0; k < NK; ++k) afr[t][k] = sRow[(16 * (RT * rp + t) + x) * DP + 4 * k + kq];
+  float ub_r[RT][4];
+  float tau_f[RT][4];   // float image of the thresholds (the exact 64-bit test runs only where a score reaches it); refreshed after cuts
+  unsigned long long tau_k[RT][4];   // the threshold keys themselves
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      ub_r[t][r] = sUb[32 * rp + 16 * t + 4 * kq + r];
-      tau_k[t][r] = sTau[32 * rp + 16 * t + 4 * kq + r];
+      ub_r[t][r] = sUb[16 * (RT * rp + t) + 4 * kq + r];
+      tau_k[t][r] = sTau[16 * (RT * rp + t) + 4 * kq + r];
       tau_f[t][r] = (tau_k[t][r] == 0ull) ? -__builtin_inff() : __builtin_inff();
     }
   // ---- candidate stages: ids two stages ahead, rows one stage ahead in registers, LDS stage double-buffered ----------
@@ -485,16 +498,16 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   // compiler then cannot count what is in flight and waited for everything (s_waitcnt vmcnt(0)) at the top of every stage --
   // the rows requested a few hundred cycles earlier, in front of the barrier (ISA, round 6).
   const int nst = (n_cand + kEvalStage - 1) / kEvalStage;
-  int idn[2];      // ids of the rows requested next
-  Row rown[2];
+  int idn[RPG];      // ids of the rows requested next
+  Row rown[RPG];
   const int qa = min(q, d4 - 1), qb = (q + 16 < d4) ? q + 16 : qa;
   auto load_ids = [&](int st) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) idn[e] = cand[min(st * kEvalStage + g + 32 * e, n_cand - 1)];
+    for (int e = 0; e < RPG; ++e) idn[e] = cand[min(st * kEvalStage + g + NGRP * e, n_cand - 1)];
   };
   auto load_rows = [&]() {   // the rows of the ids in idn
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < RPG; ++e) {
       const float4* p = reinterpret_cast<const float4*>(a.V + (int64_t)idn[e] * a.stride);
       rown[e].a = p[qa];
       rown[e].b = p[qb];
@@ -502,8 +515,8 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   };
   auto store_stage = [&](int st) {   // the rows in rown -> buffer st & 1
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int r = g + 32 * e;
+    for (int e = 0; e < RPG; ++e) {
+      const int r = g + NGRP * e;
       Row hat = rown[e];
       // what the lane holds past the row's end is a repeat of an earlier chunk: zero where it would be STORED (d < 4 NK) or SUMMED
       // (the row norm); uniform tests first -- an un-normalised d = 100 / 128 model has nothing to zero
@@ -524,59 +537,66 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   store_stage(0);
   load_rows();
   load_ids(2);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  auto products = [&](int st) {
-    acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (dbg & 2) return;   // (developer timing without the products)
-    // the whole B fragment is requested before the first MFMA (a read per k-step, waited for in place, made the loop
-    // LDS-latency-bound: 55 cycles per MFMA instead of 32 -- in-kernel stamps)
+  f32x4 acc[RT];
+  float bfr[NK];   // the wave's B fragment of the stage
+  auto b_request = [&](int st) {
     const float* pb = sRow + ((st & 1) * kEvalStage + 16 * ct + x) * DP + kq;
-    float bfr[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) bfr[k] = pb[4 * k];
+  };
+  auto products = [&](int st) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (dbg & 2) return;   // (developer timing without the products)
+    b_request(st);
+    // the whole B fragment is requested before the first MFMA (a read per k-step, waited for in place, made the loop
+    // LDS-latency-bound: 55 cycles per MFMA instead of 32 -- in-kernel stamps)
     // ... and KEPT so: left alone the compiler reads two k-steps, waits, issues their four MFMAs, thirteen times over (ISA, round 6) --
     // an LDS round trip in front of every 4 MFMAs.  The empty statements below make every element a live value at this point.
+    if (RT == 2) {   // (four waves per SIMD cover the round trips by themselves: measured equal with and without, and 14 registers dearer)
 #pragma unroll
-    for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(bfr[k]));
+      for (int k = 0; k < NK; ++k) asm volatile("" : "+v"(bfr[k]));
+    }
 #if NNCF_EVAL_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     ESTAMP(0);
 #endif
     // per element TWO accumulation chains, k-steps 0, 2, 4, ... and 1, 3, 5, ..., added at the end (predict_tile_kernel does the
     // same): a dependent v_mfma_f32_16x16x4_f32 issues ~84 cycles after its predecessor here, so two row tiles x one chain ran
-    // the pipe at 42-55 cycles per MFMA instead of 32 (in-kernel stamps); four chains keep it busy
-    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, o0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    // the pipe at 42-55 cycles per MFMA instead of 32 (in-kernel stamps); four chains keep it busy (RT = 1: two chains, four waves)
+    f32x4 ev[RT], od[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) ev[t] = od[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < NK; k += 2) {
-      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][k], bfr[k], e0, 0, 0, 0);
-      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][k], bfr[k], e1, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) ev[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][k], bfr[k], ev[t], 0, 0, 0);
       if (k + 1 < NK) {
-        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][k + 1], bfr[k + 1], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][k + 1], bfr[k + 1], o1, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) od[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[t][k + 1], bfr[k + 1], od[t], 0, 0, 0);
       }
     }
-    acc0 = e0 + o0;
-    acc1 = e1 + o1;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = ev[t] + od[t];
 #if NNCF_EVAL_STAMPS
-    asm volatile("s_nop 0" ::"v"(acc0), "v"(acc1));
+    asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[RT - 1]));
     ESTAMP(1);
 #endif
   };
   // ranking of the tile in acc0 / acc1: column j (item bias cb).  A score at or above the float image of its user's threshold
   // takes the exact test (64-bit key against the threshold key); the few that pass are appended -- all positions requested
   // first (independent LDS atomics), then the keys stored.
-  auto ranking = [&](int st_of, float cb, int parity) {
+  auto ranking = [&](int st_of, float cb, int parity, const f32x4 (&ac)[RT]) {
     const int j = st_of * kEvalStage + 16 * ct + x;
     if (j >= n_cand) return;
-    float sc[2][4];
+    float sc[RT][4];
     unsigned long long any = 0ull;   // lanes with a score at its threshold: the eight compare masks OR-ed on the scalar unit (as per-lane
                                      // booleans the compiler packed them into a byte with ~22 vector instructions per stage: ISA, round 6)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        sc[t][r] = (t ? acc1[r] : acc0[r]) + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
+        sc[t][r] = ac[t][r] + ub_r[t][r] + cb;   // predict_tile_kernel: acc + user bias + item bias
         any |= __ballot(!(sc[t][r] < tau_f[t][r]));   // NaN scores pass: the exact key test ranks them as eval_topk_kernel does (orderable())
       }
     if (!any) return;   // (wave-uniform; a lane without a passing score goes through the tests below with every slot refused)
@@ -587,27 +607,27 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
     // instructions -- 0.950 against 0.929 ms; ranking the tile of stage st - 1 behind the B-fragment request of stage st -- the LDS
     // round trip covered, but the two waves of a SIMD then multiply one after the other, 42 instead of 32 cycles per MFMA -- 0.938
     // against 0.929 ms: profiles/experiments/r06_eval_delayed_ranking.patch.)
-    unsigned long long key[2][4];
-    bool want[2][4];
+    unsigned long long key[RT][4];
+    bool want[RT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         key[t][r] = rank_key(sc[t][r], j);
         want[t][r] = !(sc[t][r] < tau_f[t][r]) && key[t][r] > tau_k[t][r];
       }
-    int pos[2][4];
+    int pos[RT][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pos[t][r] = want[t][r] ? atomicAdd(&sCnt[32 * rp + 16 * t + 4 * kq + r], 1) : -1;   // < LIST: <= 64 appends per user and stage
+      for (int r = 0; r < 4; ++r) pos[t][r] = want[t][r] ? atomicAdd(&sCnt[16 * (RT * rp + t) + 4 * kq + r], 1) : -1;   // < LIST: <= 64 appends per user and stage
     bool full = false;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (pos[t][r] >= 0) {
-          sKeys[(32 * rp + 16 * t + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
+          sKeys[(16 * (RT * rp + t) + 4 * kq + r) * LIST + pos[t][r]] = key[t][r];
           full |= pos[t][r] >= LIST - kEvalStage;
         }
     // the append that leaves a list with less than a stage's worth of room raises the workgroup's flag: everybody cuts behind
@@ -616,10 +636,10 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   };
   auto refresh_tau = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const unsigned long long tk = sTau[32 * rp + 16 * t + 4 * kq + r];
+        const unsigned long long tk = sTau[16 * (RT * rp + t) + 4 * kq + r];
         tau_k[t][r] = tk;
         // the score bits of the threshold key, back as a float (orderable() inverted); all-ones: an unranked user
         const uint32_t ob = (uint32_t)(tk >> 32);
@@ -630,12 +650,12 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   // in-loop cut: all eight users of the wave at once, to between k and k + 14 keys -- at most LIST - 64: the next stage's appends
   // (<= 64 per user) must fit -- and the exact routine for lists of equal scores
   auto cut_fast = [&](int keep) {
-    const unsigned fb = eval_cut_group8<LIST>(sKeys + 8 * wave * LIST, sCnt + 8 * wave, sTau + 8 * wave, kk, keep, lane);
+    const unsigned fb = eval_cut_group8<LIST, UPW>(sKeys + UPW * wave * LIST, sCnt + UPW * wave, sTau + UPW * wave, kk, keep, lane);
     if (fb) {   // (wave-uniform)
       __builtin_amdgcn_wave_barrier();
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < UPW; ++e) {
         if (!((fb >> e) & 1u)) continue;
-        const int ua = 8 * wave + e;
+        const int ua = UPW * wave + e;
         unsigned long long ta, tb;
         eval_cut_lists2<LIST>(sKeys + ua * LIST, sCnt[ua], sKeys + ua * LIST, 0, kk, lane, ta, tb);
         if (lane == 0 && ta) {
@@ -649,13 +669,14 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   for (int st = 0; st < nst; ++st) {
     // products(st), ranking(st), then the rows of stage st + 1 -> the other buffer and the rows of st + 2 requested; the barrier;
     // if a list is nearly full, everybody cuts and there is one more.  (Running the two waves of a SIMD half a stage apart --
-    // one multiplies while the other ranks and stages -- was measured both ways round and never won: 1.10 / 1.19 ms against 1.09.)
+    // one multiplies while the other ranks and stages -- was measured both ways round and never won: 1.10 / 1.19 ms against 1.09;
+    // ranking the tile of stage st - 1 behind the B request of stage st: 0.938 against 0.929 ms at 8 waves, 0.86 against 0.825 at 16.)
     const float cb = sCb[(st & 1) * kEvalStage + 16 * ct + x];
 #if NNCF_EVAL_STAMPS
     if (st == 0) tprev = cyc();
 #endif
     products(st);
-    ranking(st, cb, st & 1);
+    ranking(st, cb, st & 1, acc);
 #if NNCF_EVAL_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     ESTAMP(2);
@@ -683,21 +704,21 @@ __global__ void __launch_bounds__(512) eval_fused_kernel(StepArgs a, const int32
   // ---- per user: the k largest keys in rank order, hits, metrics (wave w: users 8 w .. 8 w + 7) ------------------------
   // the truth lists of this wave's 8 users are requested before the last cut: bounds first, then the first 64 slots of each
   // (eight loads in flight; a binary search per key in global memory was 4-5 dependent trips per user, one user after the other)
-  int tp0[8], tp1[8], tv[8];
+  int tp0[UPW], tp1[UPW], tv[UPW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int64_t u = u0 + 8 * wave + e;
+  for (int e = 0; e < UPW; ++e) {
+    const int64_t u = u0 + UPW * wave + e;
     tp0[e] = u < n_users ? truth_ptr[u] : 0;
     tp1[e] = u < n_users ? truth_ptr[u + 1] : 0;
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) tv[e] = (tp0[e] + lane < tp1[e]) ? truth_idx[tp0[e] + lane] : -1;
+  for (int e = 0; e < UPW; ++e) tv[e] = (tp0[e] + lane < tp1[e]) ? truth_idx[tp0[e] + lane] : -1;
   cut_fast(kk);   // the final cut is EXACT: keep = k -- the search runs until exactly k keys reach the candidate (a shared k-th score: the
                   // pairwise routine, by key); ~6 k instead of ~30 k cycles at the end of every launch
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int ul = 8 * wave + e;
+  for (int e = 0; e < UPW; ++e) {
+    const int ul = UPW * wave + e;
     const int64_t u = u0 + ul;
     const int t0 = tp0[e], t1 = tp1[e];
     if (u >= n_users || t1 == t0) continue;   // (wave-uniform)
@@ -782,17 +803,26 @@ int launch_eval_fused(const StepArgs& a, const int32_t* uid, int64_t n_users, co
     return v;
   }();
   ProfScope _ps("eval_fused_kernel", stream);
+  // NNCF_EVAL_WAVES=8|16: waves per workgroup (two / four per SIMD); read once
+  static const int waves = []() {
+    const char* e = getenv("NNCF_EVAL_WAVES");
+    return (e && atoi(e) == 16) ? 16 : (e && atoi(e) == 8) ? 8 : kEvalDefaultWaves;
+  }();
+#define NNCF_EVAL_LAUNCH(NK_, RT_)                                                                                                        \
+  do {                                                                                                                                   \
+    static KernelDeviceState kst;                                                                                                        \
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<NK_, RT_>), eval_fused_lds<NK_>(), kst)) return rc; \
+    hipLaunchKernelGGL((eval_fused_kernel<NK_, RT_>), dim3(grid), dim3(1024 / RT_), eval_fused_lds<NK_>(), stream, a, uid, n_users, cand, \
+                       n_cand, truth_ptr, truth_idx, topk, metrics, valid, dbg, stamps);                                                 \
+  } while (0)
   if (a.d == 100) {
-    static KernelDeviceState kst;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<25>), eval_fused_lds<25>(), kst)) return rc;
-    hipLaunchKernelGGL(eval_fused_kernel<25>, dim3(grid), dim3(512), eval_fused_lds<25>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid, dbg, stamps);
+    if (waves == 16) NNCF_EVAL_LAUNCH(25, 1);
+    else NNCF_EVAL_LAUNCH(25, 2);
   } else {
-    static KernelDeviceState kst;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&eval_fused_kernel<32>), eval_fused_lds<32>(), kst)) return rc;
-    hipLaunchKernelGGL(eval_fused_kernel<32>, dim3(grid), dim3(512), eval_fused_lds<32>(), stream, a, uid, n_users, cand, n_cand, truth_ptr,
-                       truth_idx, topk, metrics, valid, dbg, stamps);
+    if (waves == 16) NNCF_EVAL_LAUNCH(32, 1);
+    else NNCF_EVAL_LAUNCH(32, 2);
   }
+#undef NNCF_EVAL_LAUNCH
   NNCF_HIP_CHECK(hipGetLastError());
   return NNCF_OK;
 }

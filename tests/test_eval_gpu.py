@@ -253,3 +253,18 @@ def test_fused_evaluator_random_shapes_against_the_two_kernel_path(seed):
     assert torch.equal(vf, vt), (users, items, d, topk)
     keep = vt == 1
     assert torch.equal(mf_.view(-1, 3)[keep], mt.view(-1, 3)[keep]), (users, items, d, topk, norm, bias)
+
+
+def test_the_eight_wave_instantiation_matches_too():
+    """nncf_eval_whole runs 16 waves per workgroup (a 16-row user tile per wave, four waves per SIMD); NNCF_EVAL_WAVES=8 selects the
+    two-tiles-per-wave form of rounds 5 / 6a (read once per process: a child process runs the pinned cases with it)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NNCF_EVAL_WAVES") == "8":
+        pytest.skip("already the child")
+    env = dict(os.environ, NNCF_EVAL_WAVES="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_eval_gpu.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "(norm- or is_bit_identical_to or ties or nan) and not eight_wave"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

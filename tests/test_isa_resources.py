@@ -56,7 +56,7 @@ SGPR_SPILL_BUDGET = {
     "plan_steps_kernel": 98,        # 90: once per 64 steps
     "fused_wide_kernel": 58,        # 50
     "plan_kernel": 56,              # 48
-    "eval_fused_kernel": 53,        # 45: round 6's list cut (24 keys per lane and the compaction masks) on top of 106 SGPRs; the restores sit in the
+    "eval_fused_kernel": 56,        # 48 (the 8-wave form; the default 16-wave form 15): round 6's list cut (keys and compaction masks) on top of 106 SGPRs; the restores sit in the
                                     #     interaction_bias branch of the stage loop and in the cuts, not on the default path of a stage
     "shared_apply_kernel": 46,      # 38
     "cnn_pool_dense_kernel": 44,    # 36

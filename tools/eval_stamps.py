@@ -33,15 +33,16 @@ def main():
     for which, items in (("train", ev.train_items), ("test", ev.test_items)):
         ev._whole(head, which, 50, fused=True)
         torch.cuda.synchronize()
-        out = np.zeros(64, dtype=np.int64)
+        nw = int(os.environ.get("NNCF_EVAL_WAVES", "16"))
+        out = np.zeros(8 * nw, dtype=np.int64)
         _lib.check(eng._L.nncf_model_debug_stamps(eng._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), out.size))
-        out = out.reshape(8, 8)
+        out = out.reshape(nw, 8)
         nst = (len(items) + 63) // 64
         print("## %s candidates: %d stages; shader cycles per stage and wave (workgroup 0)" % (which, nst))
-        print("%-34s" % "phase" + "".join("  wave%d" % w for w in range(8)) + "    mean")
+        print("%-34s" % "phase" + "".join("%7s" % ("w%d" % w) for w in range(nw)) + "    mean")
         for k, nm in enumerate(names):
-            print("%-34s" % nm + "".join("%7.0f" % (out[w, k] / nst) for w in range(8)) + "%8.0f" % (out[:, k].mean() / nst))
-        print("%-34s" % "sum" + "".join("%7.0f" % (out[w, :6].sum() / nst) for w in range(8)) + "%8.0f" % (out[:, :6].sum(axis=1).mean() / nst))
+            print("%-34s" % nm + "".join("%7.0f" % (out[w, k] / nst) for w in range(nw)) + "%8.0f" % (out[:, k].mean() / nst))
+        print("%-34s" % "sum" + "".join("%7.0f" % (out[w, :6].sum() / nst) for w in range(nw)) + "%8.0f" % (out[:, :6].sum(axis=1).mean() / nst))
 
 
 if __name__ == "__main__":
