@@ -298,15 +298,15 @@ __device__ __forceinline__ void eval_cut_lists2(unsigned long long* la, int ca, 
   if (dob) compact(lb, kb, tb); else tb = 0ull;
 }
 
-// One wave cuts the lists of its EIGHT users at once (round 6; the pairwise search above cost ~25 k cycles per cut event: a fifth of a
-// whole@50 pass -- in-kernel stamps): user e of the wave owns the 8-lane group e, 24 keys per lane in registers.  The threshold is a
-// SCORE (the high half of a key), found bit by bit from the first bit in which the list's scores differ; the search stops as soon
-// as between k and `keep` keys reach the candidate -- any threshold that leaves at least k keys is a valid one, the k-th itself is
-// needed only at the very end (eval_cut_lists2) -- so a cut is ~6-8 rounds of 24 compares instead of 4 x 32 rounds of ballots.
-// A list whose k-th score is shared by so many keys that more than `keep` remain (equal scores: an untrained model) is left to the
-// exact routine: returned as a mask of user groups.
+// One wave cuts the lists of ALL its users at once (round 6; the pairwise search above cost ~25 k cycles per cut event: a fifth of a
+// whole@50 pass -- in-kernel stamps): UPW users per wave (4 at 16 waves per workgroup, 8 at 8), user e of the wave owns the group of
+// 64 / UPW lanes e, 12 or 24 keys per lane in registers.  The threshold is a SCORE (the high half of a key), found bit by bit from
+// the first bit in which the list's scores differ; the search stops as soon as between k and `keep` keys reach the candidate --
+// any threshold that leaves at least k keys is a valid one; keep = k (the end of a launch) makes it the exact cut -- so a cut is
+// ~6-8 rounds of 12 / 24 compares instead of 4 x 32 rounds of ballots.  A list whose k-th score is shared by so many keys that more
+// than `keep` remain (equal scores: an untrained model) is left to the exact routine: returned as a mask of user groups.
 template <int LIST, int UPW>
-__device__ __forceinline__ unsigned eval_cut_group8(unsigned long long* lists, int* cnts, unsigned long long* taus, int k, int keep, int lane) {
+__device__ __forceinline__ unsigned eval_cut_groups(unsigned long long* lists, int* cnts, unsigned long long* taus, int k, int keep, int lane) {
   constexpr int LPU = 64 / UPW, KPL = 192 / LPU;   // lanes per user (8 or 16), keys per lane (24 or 12)
   static_assert(LIST <= 192 && (UPW == 8 || UPW == 4), "192 keys per user: 24 x 8 lanes or 12 x 16 lanes");
   const int ug = lane / LPU, sub = lane % LPU;
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(1024 / RT) eval_fused_kernel(StepArgs a, const
   // in-loop cut: all eight users of the wave at once, to between k and k + 14 keys -- at most LIST - 64: the next stage's appends
   // (<= 64 per user) must fit -- and the exact routine for lists of equal scores
   auto cut_fast = [&](int keep) {
-    const unsigned fb = eval_cut_group8<LIST, UPW>(sKeys + UPW * wave * LIST, sCnt + UPW * wave, sTau + UPW * wave, kk, keep, lane);
+    const unsigned fb = eval_cut_groups<LIST, UPW>(sKeys + UPW * wave * LIST, sCnt + UPW * wave, sTau + UPW * wave, kk, keep, lane);
     if (fb) {   // (wave-uniform)
       __builtin_amdgcn_wave_barrier();
       for (int e = 0; e < UPW; ++e) {
