@@ -18,6 +18,7 @@ from tests.tolerances import sum_bound
 
 HEAD_OF = {"original": "model", "neg_shared": "model_neg_shared", "group_neg_shared": "model_group_neg_shared"}
 TOWER_PARAMS = ("W", "Wd", "bd", "gamma", "beta", "rm", "rv")
+CNN_PARAMS = ("W", "Wc", "bc", "g1", "b1", "Wd", "bd", "gamma", "beta", "rm", "rv", "rm1", "rv1")   # cnn_embedding (one conv layer: the 'best' preset)
 
 
 def param_dict(model, scheme, loss, optimizer, epochs, b=512, d=100, k=10, chop=5, dropout=0.5, learn_rate=None):
@@ -35,10 +36,11 @@ def _quiet():
 
 
 def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram", optimizer="sgd", epochs=1, eval_epochs=None,
-             np_seed=4224, sampler_seed=12345, model_seed=0, device=0, learn_rate=None, log=None, control_fp32=False):
+             np_seed=4224, sampler_seed=12345, model_seed=0, device=0, learn_rate=None, log=None, control_fp32=False, max_steps=None):
     """Train the product Trainer for `epochs` epochs (evaluating whole@50 after every epoch, as main.py does), then the oracle
     loop from the same initial state; returns a dict of per-step losses (both sides), per-epoch metrics (both sides at
-    `eval_epochs`), final tables / parameters (both sides + the initial ones)."""
+    `eval_epochs`), final tables / parameters (both sides + the initial ones).  max_steps: only the first max_steps * b training
+    links are used (the float64 conv oracle of cnn_embedding takes seconds per step)."""
     import torch
     from nncf_amd.conf import get_conf
     from nncf_amd.data_utils import degree_dist, get_data, group_shuffle_train
@@ -49,6 +51,9 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
     pd = param_dict(model, scheme, loss, optimizer, epochs, learn_rate=learn_rate)
     conf = get_conf("synthetic_citeulike", "best", pd, model_choice=model)
     conf.eval_topk = 50
+    if max_steps:
+        data = dict(data, train=data["train"][:max_steps * conf.batch_size_p].copy())
+    tower_params = CNN_PARAMS if model == "cnn_embedding" else TOWER_PARAMS
     d_prod = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in data.items()}
     train0 = data["train"].copy()
     b, k = conf.batch_size_p, conf.num_negatives
@@ -64,7 +69,7 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
     if tw is None:
         init["V"] = eng.V.cpu().numpy().copy()
     else:
-        for n in TOWER_PARAMS:
+        for n in tower_params:
             init[n] = getattr(tw, n).cpu().numpy().copy()
 
     # ---- product ------------------------------------------------------------------------------------------------------
@@ -93,7 +98,7 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
     if tw is None:
         final["V"] = eng.V.cpu().numpy().copy()
     else:
-        for n in TOWER_PARAMS:
+        for n in tower_params:
             final[n] = getattr(tw, n).cpu().numpy().copy()
 
     # ---- the reference loop on the oracle (float64; and, as a control, the same loop in float32) ---------------------------
@@ -110,9 +115,13 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
     def oracle_loop(dtype, evaluate):
         oc = so.OracleConf(batch_size_p=b, num_negatives=k, loss=conf.loss, loss_gamma=conf.loss_gamma,
                            neg_loss_weight=conf.neg_loss_weight, u_reg=conf.u_reg, learn_rate=conf.learn_rate,
-                           emb_normalization=conf.emb_normalization, model_choice=model, optimizer=optimizer)
+                           emb_normalization=conf.emb_normalization, model_choice="basic_embedding" if tw is not None else model,
+                           optimizer=optimizer)
         to = None
-        if tw is not None:
+        if model == "cnn_embedding":
+            to = so.CnnTowerOracle(data["C"], init["W"], init["Wc"], init["bc"], init["g1"], init["b1"], init["Wd"], init["bd"],
+                                   init["gamma"], init["beta"], conf.learn_rate, dtype=dtype)
+        elif tw is not None:
             to = so.TowerOracle(data["C"], init["W"], init["Wd"], init["bd"], init["gamma"], init["beta"], conf.learn_rate,
                                 dtype=dtype).use_bag()
         orc = so.StepOracle(init["U"], init.get("V"), oc, dtype=dtype, tower=to)
@@ -131,6 +140,8 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
             base = (epoch - 1) * n_steps
 
             def sc(t):
+                if model == "cnn_embedding":   # the conv Dropout's mask of this train-mode forward (ones without conv dropout)
+                    to.conv_mask = tw.conv_mask(base + t, b * (1 + k) if scheme == "original" else b).cpu().numpy().astype(dtype)
                 v = scale_of(base + t)
                 return v if v is None else v.astype(dtype)
             ls = eo.run_reference_epoch(orc, scheme, batches, step_scale=sc, sampler=smp, k=k, loss_name=conf.loss)
@@ -145,7 +156,7 @@ def run_case(data, model="basic_embedding", scheme="neg_shared", loss="skip-gram
         if to is None:
             params["V"] = orc.V
         else:
-            for n in TOWER_PARAMS:
+            for n in tower_params:
                 params[n] = getattr(to, n)
         return orc, to, np.concatenate(losses), metrics, cost, params
 
@@ -172,7 +183,12 @@ def table_report(res, terms_of, updates):
             out[name] = {"worst_err_over_bound": None, "max_abs_err": float(err.max()), "max_abs_value": float(np.abs(want).max()),
                          "note": "zero true gradient under BatchNorm: rounding residue only"}
             continue
-        if name in ("rm", "rv"):       # running statistics: an exponential average of per-step batch statistics, not a gradient sum
+        if name in ("bc",):
+            # the conv bias in front of BN1: no gradient in exact arithmetic either (the statistics remove it)
+            out[name] = {"worst_err_over_bound": None, "max_abs_err": float(err.max()), "max_abs_value": float(np.abs(want).max()),
+                         "note": "zero true gradient under BatchNorm: rounding residue only"}
+            continue
+        if name in ("rm", "rv", "rm1", "rv1"):       # running statistics: an exponential average of per-step batch statistics, not a gradient sum
             bound = sum_bound(want, init, terms=terms_of.get("Wd", 512), updates=updates)
         else:
             bound = sum_bound(want, init, terms=terms_of[name], updates=updates)

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="basic_embedding", choices=["basic_embedding", "mf"])
+    ap.add_argument("--model", default="basic_embedding", choices=["basic_embedding", "mf", "cnn_embedding"])
     ap.add_argument("--scheme", default="neg_shared", choices=["neg_shared", "group_neg_shared", "original"])
     ap.add_argument("--loss", default=None)
     ap.add_argument("--optimizer", default="adam", choices=["sgd", "adam", "sparse_adam"])
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--eval-epochs", default=None, help="comma list of epochs at which the ORACLE is evaluated (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_convergence_parity.json"))
     ap.add_argument("--tag", default=None)
+    ap.add_argument("--max-steps", type=int, default=None, help="train on the first max-steps * b links only (cnn_embedding: the float64 conv oracle takes seconds per step)")
     ap.add_argument("--control-fp32", action="store_true", help="also run the oracle loop in float32: the drift precision alone causes")
     args = ap.parse_args()
     import __graft_entry__
@@ -40,12 +41,13 @@ def main():
     ev = [int(v) for v in args.eval_epochs.split(",")] if args.eval_epochs else None
     t0 = time.time()
     res = ep.run_case(data, model=args.model, scheme=args.scheme, loss=loss, optimizer=args.optimizer, epochs=args.epochs,
-                      eval_epochs=ev, learn_rate=args.learn_rate, control_fp32=args.control_fp32, log=lambda *a: print("[parity]", *a, file=sys.stderr, flush=True))
+                      eval_epochs=ev, learn_rate=args.learn_rate, control_fp32=args.control_fp32, max_steps=args.max_steps, log=lambda *a: print("[parity]", *a, file=sys.stderr, flush=True))
     conf = res["conf"]
     b, k = conf.batch_size_p, conf.num_negatives
     rows = b * (1 + k)
     L = data["C"].shape[1]
-    terms = {"U": rows, "V": rows, "W": rows * L, "Wd": rows, "bd": rows, "gamma": rows, "beta": rows}
+    terms = {"U": rows, "V": rows, "W": rows * L, "Wd": rows, "bd": rows, "gamma": rows, "beta": rows,
+             "Wc": rows * L, "bc": rows * L, "g1": rows * L, "b1": rows * L, "rm1": rows * L, "rv1": rows * L}
     updates = args.epochs * res["n_steps"]
     n = res["n_steps"]
     g, w = res["got_losses"], res["want_losses"]
