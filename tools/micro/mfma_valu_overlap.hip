@@ -2,11 +2,21 @@
 // accumulator chains: the evaluator's products, csrc/eval.hip) with V independent v_fma_f32 behind each of them, the instruction
 // stream fixed by inline assembly; against the MFMAs alone and the VALU instructions alone.  1 and 2 waves per SIMD.
 // "adds": time(interleaved) ~ time(MFMA) + time(VALU); "hides": ~ max of the two.
-// build: hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_valu_overlap.hip -o tools/micro/mfma_valu_overlap
+// build: hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_valu_overlap.hip -o tools/micro/mfma_valu_overlap   (+ -DF16_MFMA: v_mfma_f32_16x16x32_f16)
+// Result (profiles/r06_mfma_valu_overlap.txt): the fp32 instruction and vector work ADD; the f16 instruction (4 passes) runs beside it.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef F16_MFMA
+#define MFMA_NAME "f16 16x16x32"
+#else
+#define MFMA_NAME "f32 16x16x4 "
+#endif
+#ifdef F16_MFMA   // hipcc -DF16_MFMA: the f16 matrix instruction of the large-batch kernels (A / B: 8 halves = 4 registers each)
+#define M(c) "v_mfma_f32_16x16x32_f16 %" #c ", %15, %16, %" #c "\n\t"
+#else
 #define M(c) "v_mfma_f32_16x16x4_f32 %" #c ", %12, %13, %" #c "\n\t"
+#endif
 #define F(r) "v_fma_f32 %" #r ", %" #r ", %14, %" #r "\n\t"
 #define G2a F(4) F(5)
 #define G2b F(6) F(7)
@@ -19,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G6c F(8) F(9) F(10) F(11) F(4) F(5)
 #define G6d F(6) F(7) F(8) F(9) F(10) F(11)
 #define G8 F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11)
-#define OPS : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(a), "v"(b), "v"(s)
+#define OPS : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(a), "v"(b), "v"(s), "v"(ha), "v"(hb)
 // MODE 0: MFMA only; 1: VALU only (4 V per body); 2: interleaved
 template <int V, int MODE>
 __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) {
@@ -27,6 +37,9 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
   f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
   float f0 = tid, f1 = 1.f, f2 = 2.f, f3 = 3.f, f4 = 4.f, f5 = 5.f, f6 = 6.f, f7 = 7.f;
   const float a = 1.f + lane, b = 0.5f, s = 0.999f;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 ha, hb;
+  for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(0.01f * (lane + i)); hb[i] = (_Float16)0.5f; }
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -64,7 +77,7 @@ double run(int threads) {
 template <int V>
 void report(int threads) {
   const double m = run<V, 0>(threads), v = run<V, 1>(threads), x = run<V, 2>(threads);
-  printf("%d waves/SIMD  4 MFMA + 4 x %d VALU per body:  MFMA alone %6.1f   VALU alone %6.1f   interleaved %6.1f cycles  (sum %6.1f, max %6.1f)\n",
+  printf(MFMA_NAME " %d waves/SIMD  4 MFMA + 4 x %d VALU per body:  MFMA alone %6.1f   VALU alone %6.1f   interleaved %6.1f cycles  (sum %6.1f, max %6.1f)\n",
          threads / 256, V, m, v, x, m + v, m > v ? m : v);
 }
 int main() {
