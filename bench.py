@@ -485,6 +485,17 @@ def _profile_entry(args, conf, d, kernel):
     return (ent.get("kernels") or {}).get(kernel)
 
 
+def evaluator_traffic(d):
+    """HBM bytes per whole@50 pass of the one-kernel evaluator from the committed PMC passes over tools/eval_bench.py
+    (profiles/traffic.json, same corrections and the same source-hash rule as measured_traffic), or None."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("evaluator/whole@50/16Kx17K/d%d" % d) or {}
+    except Exception:
+        return None
+    import __graft_entry__ as ge
+    return ent.get("bytes_per_pass") if ent.get("csrc_hash") == ge._source_hash() else None
+
+
 def measured_traffic(args, conf, d, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE with the
     gfx950 corrections of MI355X_MICROARCH.md), or None."""
@@ -1123,7 +1134,7 @@ def main():
                          "1.04 GB of scores written per pass)" % (ev.user_count, len(ev.train_items), len(ev.test_items), d),
                          "pass_ms": pass_ms, "launches_per_pass": e_n / 5.0, "bound": "mfma", "achieved": e_flop / (pass_ms * 1e-3) / 1e12,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": e_flop / (pass_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "algorithmic_flop_per_pass": e_flop}
+                         "traffic": evaluator_traffic(d), "algorithmic_flop_per_pass": e_flop}
         recall = {"train": float(tr_res["recall@50"]), "test_cold_items": float(te_res["recall@50"]),
                   "after_steps": int(W + K * len(win_times) + prof_n * len(names)),
                   "note": "whole@50 after the warm-up, timed and roofline passes of this run (a short run, not a converged model)"

@@ -13,6 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _traffic(d):
+    """HBM bytes per pass from profiles/traffic.json (tools/make_traffic.py) while the kernel sources are the profiled ones"""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("evaluator/whole@50/16Kx17K/d%d" % d) or {}
+        import __graft_entry__ as ge
+        return ent.get("bytes_per_pass") if ent.get("csrc_hash") == ge._source_hash() else None
+    except Exception:
+        return None
+
+
 def main():
     import torch
     from nncf_amd import synthetic
@@ -51,7 +61,7 @@ def main():
         out[name] = {"pass_ms_wall": wall * 1e3, "kernel_ms_per_pass": (raw_ms - ov_ms) * launches / reps, "launches_per_pass": launches / reps}
     k_ms = out["fused"]["kernel_ms_per_pass"]
     out["roofline"] = {"kernel": "eval_fused_kernel", "bound": "mfma", "achieved": flop / (k_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                       "frac": flop / (k_ms * 1e-3) / 1e12 / 157.3, "traffic": None,
+                       "frac": flop / (k_ms * 1e-3) / 1e12 / 157.3, "traffic": _traffic(d),
                        "work": "2 x %d users x %d candidates x %d = %.1f GFLOP per pass (fp32 MFMA, exact fp32)" % (ev.user_count, n_cand, d, flop / 1e9)}
     print(json.dumps(out))
 

@@ -65,9 +65,28 @@ def source_hash():
     return g._source_hash()
 
 
+def evaluator_entry(d, tag):
+    """whole@50 pass of tools/eval_bench.py (train + test candidate sets = two launches of eval_fused_kernel): the PMC means are
+    per dispatch over both launch kinds, a pass is two dispatches."""
+    f = pmc_mean(os.path.join(d, "%s_eval_pmc_fetch.txt" % tag), "eval_fused_kernel", "FETCH_SIZE")
+    w = pmc_mean(os.path.join(d, "%s_eval_pmc_write.txt" % tag), "eval_fused_kernel", "WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    per_launch = int(round((2 * f + w) * 1024))
+    return {"kernel": "eval_fused_kernel", "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "bytes_per_launch": per_launch,
+            "launches_per_pass": 2, "bytes_per_pass": 2 * per_launch,
+            "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE over tools/eval_bench.py, separate passes "
+                   "(profiles/%s_eval_pmc_*.txt); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch, mean over the train- and "
+                   "the test-candidate launches; a whole@50 pass is one of each" % tag,
+            "round": int(tag.lstrip("r") or 0), "csrc_hash": source_hash()}
+
+
 def main():
     d, tag, out = sys.argv[1], sys.argv[2], sys.argv[3]
     table = {}
+    ev = evaluator_entry(d, tag)
+    if ev:
+        table["evaluator/whole@50/16Kx17K/d100"] = ev
     for key, (stem, kernel) in CASES.items():
         f = pmc_mean(os.path.join(d, "%s_%s_pmc_fetch.txt" % (tag, stem)), kernel, "FETCH_SIZE")
         w = pmc_mean(os.path.join(d, "%s_%s_pmc_write.txt" % (tag, stem)), kernel, "WRITE_SIZE")

@@ -20,6 +20,11 @@ run_prof basic_embedding_neg_shared_pmc_write "--pmc WRITE_SIZE" --steps 390 --w
 run_prof mf_neg_shared_kernel_trace "--stats" --model mf --steps 1170 --warmup 390 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_fetch "--pmc FETCH_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
 run_prof mf_neg_shared_pmc_write "--pmc WRITE_SIZE" --model mf --steps 390 --warmup 39 --cpu-seconds 0 --profile-launches 10
+for c in FETCH_SIZE WRITE_SIZE; do
+  n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $c -d $OUT/prof_evp -o p -- python3 $R/tools/eval_bench.py > /dev/null 2>&1)
+  python3 $R/tools/prof_summary.py $OUT/prof_evp/p_results.db $OUT/${TAG}_eval_pmc_$n.txt; rm -rf $OUT/prof_evp
+done
 python3 tools/make_traffic.py $OUT $TAG $OUT/${TAG}_traffic.json > /dev/null
 cp $OUT/${TAG}_traffic.json profiles/traffic.json
 python3 bench.py 2>/dev/null | tail -1 > $OUT/${TAG}_bench_basic_embedding_neg_shared.json
