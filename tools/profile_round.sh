@@ -36,6 +36,11 @@ run_prof large_mf_b8192_logloss_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
 run_prof large_mf_b8192_pmc_mfma "--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" --large --batch 8192 --steps 20 --warmup 4 --cpu-seconds 0 --profile-launches 10
 (cd /tmp && NNCF_FORCE_SHARDED=1 rocprofv3 --kernel-trace --stats -d $OUT/prof_sh -o p -- python3 $R/bench.py --model mf --steps 780 --warmup 390 --cpu-seconds 0 $B > $OUT/prof_sh.log 2>&1)
 python3 $R/tools/prof_summary.py $OUT/prof_sh/p_results.db $OUT/${TAG}_mf_sharded_world1_kernel_trace.txt; rm -rf $OUT/prof_sh
+for c in FETCH_SIZE WRITE_SIZE; do   # the evaluator's traffic (traffic.json: evaluator/...)
+  n=$(echo $c | tr 'A-Z' 'a-z' | sed 's/_size//')
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $c -d $OUT/prof_evp -o p -- python3 $R/tools/eval_bench.py > /dev/null 2>&1)
+  python3 $R/tools/prof_summary.py $OUT/prof_evp/p_results.db $OUT/${TAG}_eval_pmc_$n.txt; rm -rf $OUT/prof_evp
+done
 python3 tools/make_traffic.py $OUT $TAG $OUT/${TAG}_traffic.json > /dev/null
 cp $OUT/${TAG}_traffic.json profiles/traffic.json
 # bench lines (the headline first: full default run incl. cpu_baseline and the trained-Recall side run)
