@@ -40,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t orderable(float f) {
   const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending uint order == ascending float order
+  return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);  // negative: ~u, else u | sign bit -- ascending uint order == ascending float order
 }
 __device__ __forceinline__ unsigned long long rank_key(float score, int slot) {
   return ((unsigned long long)orderable(score) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)slot);
@@ -498,25 +498,34 @@ __global__ void __launch_bounds__(1024 / RT) eval_fused_kernel(StepArgs a, const
   // compiler then cannot count what is in flight and waited for everything (s_waitcnt vmcnt(0)) at the top of every stage --
   // the rows requested a few hundred cycles earlier, in front of the barrier (ISA, round 6).
   const int nst = (n_cand + kEvalStage - 1) / kEvalStage;
-  int idn[RPG];      // ids of the rows requested next
-  Row rown[RPG];
+  // Staging (candidate rows -> the LDS stage) is the work of the first EIGHT waves whatever the wave count: 32 groups of 16 lanes,
+  // rows g and g + 32.  At 16 waves the four waves of a SIMD get the matrix pipe oldest first -- waves 0-7 are through their
+  // products ~2 k cycles before waves 12-15 and used to wait that long at the stage barrier, while the late waves still had their
+  // share of the staging in front of it (in-kernel stamps: profiles/r06_eval_stamps.txt).
+  constexpr int SGRP = 32, SRPG = kEvalStage / SGRP;
+  const bool stager = g < SGRP;   // (wave-uniform: waves 0-7)
+  int idn[SRPG];      // ids of the rows requested next
+  Row rown[SRPG];
   const int qa = min(q, d4 - 1), qb = (q + 16 < d4) ? q + 16 : qa;
   auto load_ids = [&](int st) {
+    if (!stager) return;
 #pragma unroll
-    for (int e = 0; e < RPG; ++e) idn[e] = cand[min(st * kEvalStage + g + NGRP * e, n_cand - 1)];
+    for (int e = 0; e < SRPG; ++e) idn[e] = cand[min(st * kEvalStage + (g & (SGRP - 1)) + SGRP * e, n_cand - 1)];
   };
   auto load_rows = [&]() {   // the rows of the ids in idn
+    if (!stager) return;
 #pragma unroll
-    for (int e = 0; e < RPG; ++e) {
+    for (int e = 0; e < SRPG; ++e) {
       const float4* p = reinterpret_cast<const float4*>(a.V + (int64_t)idn[e] * a.stride);
       rown[e].a = p[qa];
       rown[e].b = p[qb];
     }
   };
   auto store_stage = [&](int st) {   // the rows in rown -> buffer st & 1
+    if (!stager) return;
 #pragma unroll
-    for (int e = 0; e < RPG; ++e) {
-      const int r = g + NGRP * e;
+    for (int e = 0; e < SRPG; ++e) {
+      const int r = g + SGRP * e;
       Row hat = rown[e];
       // what the lane holds past the row's end is a repeat of an earlier chunk: zero where it would be STORED (d < 4 NK) or SUMMED
       // (the row norm); uniform tests first -- an un-normalised d = 100 / 128 model has nothing to zero
