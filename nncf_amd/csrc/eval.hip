@@ -185,16 +185,21 @@ __global__ void __launch_bounds__(NT) eval_topk_kernel(const float* __restrict__
 //     order) and therefore the top k are bit-identical to nncf_predict_scores + nncf_eval_topk, ties included;
 //   * per user a list of LIST keys in LDS and a threshold key tau (0 at first): a score that reaches the float image of tau
 //     takes the exact 64-bit test, the few that pass are appended (one LDS integer atomic for the position);
-//   * when ANY list of the workgroup could overflow in the next stage, EVERY wave cuts ALL of its 8 users' lists down to
-//     their k largest (tau := the k-th, found bit by bit from the top with wave ballots: no sort, no shuffles; two users'
-//     searches interleaved) in one extra barrier interval.  Cutting on demand, user by user, put one ~5 k-cycle search on
-//     the critical path of nearly every stage (everybody waits at the stage barrier for the one wave that cuts: 0.65 ms of
-//     a 1.6 ms pass); cut together, the users' thresholds move together and a sweep of 13,600 candidates has ~6 cut stages;
+//   * when ANY list of the workgroup could overflow in the next stage, EVERY wave cuts the lists of ALL its users down to
+//     between k and k + 14 keys in one extra barrier interval (eval_cut_groups, round 6: one lane group per user, the threshold a
+//     SCORE found bit by bit; round 5 searched the exact k-th key pairwise with wave ballots, ~30 k cycles per event).  Cutting on
+//     demand, user by user, put one ~5 k-cycle search on the critical path of nearly every stage (everybody waits at the stage
+//     barrier for the one wave that cuts: 0.65 ms of a 1.6 ms pass); cut together, the users' thresholds move together and a sweep
+//     of 13,600 candidates has ~7 cut stages;
 //   * stage s + 1 is stored (and s + 2 requested) behind stage s's products and ranking: one barrier per stage;
-//   * at the end the list is cut to k once more, the k keys are ranked by counting, hits by binary search in the user's
-//     truth CSR, map / recall / precision per metrics_ranking.py:14-29 in rank order -- the arithmetic of eval_topk_kernel.
-// Work: 2 n_users n_cand d flop on the fp32 matrix pipe (exact fp32: the ranking must not depend on the pipe), 25 LDS reads
-// per 50 MFMAs and wave; bound: fp32 MFMA.  Memory: O(users) -- config [3]'s 10^6 candidates need no 8 GB chunk.
+//   * at the end the lists are cut to exactly k (the same routine with keep = k), the k keys are ranked by counting, hits by
+//     binary search in the user's truth CSR, map / recall / precision per metrics_ranking.py:14-29 in rank order -- the arithmetic
+//     of eval_topk_kernel.
+// Round 6: sixteen waves per workgroup (a 16-row user tile per wave, four waves per SIMD; NNCF_EVAL_WAVES=8: two tiles per wave),
+// every request of the stage loop unconditional, the staging done by the first eight waves: 1.08 -> 0.80 ms per whole@50 pass.
+// Work: 2 n_users n_cand d flop on the fp32 matrix pipe (exact fp32: the ranking must not depend on the pipe); the fp32 MFMA and
+// vector instructions do not overlap on a SIMD (tools/micro/mfma_valu_overlap.hip), so a stage costs products + ranking + staging.
+// Memory: O(users) -- config [3]'s 10^6 candidates need no 8 GB chunk.
 constexpr int kEvalUsers = 64;     // users per workgroup (four 16-row MFMA tiles)
 constexpr int kEvalStage = 64;     // candidates per stage (four 16-column tiles)
 constexpr int kEvalMaxK = 100;     // top-k this kernel takes (beyond: the two-kernel path)
